@@ -1,0 +1,114 @@
+"""Seeded synthetic inputs: generators A-E plus structured stress inputs.
+
+Pure integer code + numpy; identical on every box, so archives can be pinned by sha256.
+"""
+import numpy as np
+
+
+def xs32_stream(seed, n):
+    """n successive xorshift32 states: x^=x<<13; x^=x>>17; x^=x<<5 (mod 2^32)."""
+    out = np.empty(n, dtype=np.uint32)
+    x = seed & 0xFFFFFFFF
+    # vectorising a recurrence is not possible; do it in chunks with python ints on a small unrolled loop
+    for i in range(n):
+        x ^= (x << 13) & 0xFFFFFFFF
+        x ^= x >> 17
+        x ^= (x << 5) & 0xFFFFFFFF
+        out[i] = x
+    return out
+
+
+def gen_A(n):
+    return bytes(n)
+
+
+_xs_cache = {}
+
+
+def _xs(seed, n):
+    key = seed
+    if key not in _xs_cache or len(_xs_cache[key]) < n:
+        _xs_cache[key] = xs32_stream(seed, max(n, 1 << 20))
+    return _xs_cache[key][:n]
+
+
+def gen_B(n):
+    return (_xs(0x5A524130, n) & 0xFF).astype(np.uint8).tobytes()
+
+
+def gen_C(n):
+    out = bytearray()
+    i = 0
+    st = [b"OK", b"WARN", b"FAIL"]
+    while len(out) < n:
+        out += b"line %d of the zra golden corpus; value=%d status=%s\n" % (i, (i * 2654435761) & 0xFFFF, st[(i * 7) % 3])
+        i += 1
+    return bytes(out[:n])
+
+
+def gen_D(n):
+    x = _xs(0x5A524131, n)
+    return ((x & (x >> 8) & (x >> 16)) & 0xFF).astype(np.uint8).tobytes()
+
+
+def gen_E(n=1 << 20):
+    e = gen_C(1 << 20)[:700001] + gen_B(1 << 20)[:100003] + gen_A(50000) + gen_D(1 << 20)[:198572]
+    return e[:n]
+
+
+def gen_struct(n, seed=12345):
+    """2-symbol runs, byte runs, short periodic patterns and back-copies: hits every repcode path."""
+    rng = np.random.RandomState(seed)
+    out = bytearray()
+    while len(out) < n:
+        k = rng.randint(0, 6)
+        if k == 0:
+            out += bytes(rng.randint(0, 256, size=rng.randint(1, 40), dtype=np.uint8))
+        elif k == 1:
+            out += bytes([rng.randint(0, 256)]) * rng.randint(1, 300)
+        elif k == 2:
+            p = bytes(rng.randint(0, 256, size=rng.randint(2, 9), dtype=np.uint8))
+            out += p * rng.randint(2, 40)
+        elif k == 3 and len(out) > 16:
+            d = rng.randint(1, min(len(out), 60000))
+            ln = rng.randint(3, 200)
+            s = len(out) - d
+            for j in range(ln):
+                out.append(out[s + j])
+        elif k == 4:
+            a, b = rng.randint(0, 256, size=2)
+            out += bytes(rng.choice([a, b], size=rng.randint(4, 120)).astype(np.uint8))
+        else:
+            out += b"key=%d;" % rng.randint(0, 50)
+    return bytes(out[:n])
+
+
+def gen_alpha4(n, seed=7):
+    rng = np.random.RandomState(seed)
+    return bytes(rng.randint(0, 4, size=n, dtype=np.uint8))
+
+
+def gen_loglike(n, seed=99):
+    rng = np.random.RandomState(seed)
+    out = bytearray()
+    i = 0
+    lv = [b"INFO", b"DEBUG", b"WARN", b"ERROR"]
+    while len(out) < n:
+        out += b"2026-10-01T12:%02d:%02d.%03d %s req=%08x user=%d path=/api/v1/items/%d latency_ms=%d\n" % (
+            (i // 60) % 60, i % 60, rng.randint(0, 1000), lv[rng.randint(0, 4)], rng.randint(0, 1 << 32), rng.randint(0, 500), rng.randint(0, 100000), rng.randint(1, 900))
+        i += 1
+    return bytes(out[:n])
+
+
+def gen_litrle(n=262144):
+    """two-block 'literal-RLE' input (SURVEY Appendix A closing note)."""
+    rng = np.random.RandomState(5)
+    chunks = [bytes(rng.randint(0, 256, size=32, dtype=np.uint8)) for _ in range(512)]
+    b1 = b"y" * (131072 - 512 * 32) + b"".join(chunks)
+    b2 = b"".join(b"z" + c for c in chunks)
+    return (b1 + b2 + b"z" * n)[:n]
+
+
+ALL = {
+    "A": gen_A, "B": gen_B, "C": gen_C, "D": gen_D, "E": gen_E,
+}
