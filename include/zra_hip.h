@@ -1,0 +1,67 @@
+/* zra_amd — additive device-side C ABI of the MI355X-native ZRA engine.
+ *
+ * NOT part of the reference. The 29 reference entry points (include/zra.h) keep their host-pointer
+ * semantics; one kernel launch per call cannot serve BASELINE config C3 (1M random-access queries), and
+ * callers that already hold data in HBM should not bounce it through the host. These calls take DEVICE
+ * pointers (hipMalloc / torch.cuda tensors: plain addresses, no torch types) and are what bench.py times.
+ *
+ * Reference interfaces they accelerate:
+ *   ZraHipCompressBuffer      <- zra::CompressBuffer    (zra.cpp:194-234, zra.h:138)
+ *   ZraHipDecompressBuffer    <- zra::DecompressBuffer  (zra.cpp:243-250, zra.h:146)
+ *   ZraHipDecompressRABatch   <- zra::DecompressRA      (zra.cpp:258-296, zra.h:156), batched
+ *   ZraHipCompressFrames / ZraHipStitch <- the per-frame loop zra.cpp:216-225 split for multi-GPU sharding
+ */
+#ifndef ZRA_HIP_H
+#define ZRA_HIP_H
+#include "zra.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ZraHipEngine ZraHipEngine;
+
+/** Number of visible HIP devices (0 when there is no GPU / no driver). Never throws. */
+ZRA_EXPORT int ZraHipDeviceCount(void);
+
+/** Creates an engine bound to `device` (its own stream + scratch pool). Fails with ZStdError/GENERIC(1) when no GPU is usable. */
+ZRA_EXPORT ZraStatus ZraHipCreateEngine(ZraHipEngine** engine, int device);
+ZRA_EXPORT void ZraHipDestroyEngine(ZraHipEngine* engine);
+/** Blocks until all work queued on the engine's stream is complete. */
+ZRA_EXPORT ZraStatus ZraHipSynchronize(ZraHipEngine* engine);
+/** The engine's hipStream_t, as an opaque pointer (for event timing on the stream kernels run on). */
+ZRA_EXPORT void* ZraHipGetStream(ZraHipEngine* engine);
+
+/** CompressBuffer with device-resident input/output. dOut must hold ZraGetCompressedOutputBufferSize(inSize, frameSize) bytes.
+ *  Output is byte-identical to the reference at the same level (zstd 1.4.9 semantics). Synchronous. */
+ZRA_EXPORT ZraStatus ZraHipCompressBuffer(ZraHipEngine* engine, const void* dIn, size_t inSize, void* dOut, size_t* outSize,
+                                          int8_t compressionLevel, uint32_t frameSize, bool checksum);
+
+/** DecompressBuffer with a device-resident archive; dOut must hold the archive's uncompressedSize bytes. Synchronous. */
+ZRA_EXPORT ZraStatus ZraHipDecompressBuffer(ZraHipEngine* engine, const void* dIn, size_t inSize, void* dOut, size_t outCapacity);
+
+/** Batched DecompressRA: query i returns bytes [hOffsets[i], hOffsets[i]+hSizes[i]) of the original data at dOut + hOutOffsets[i].
+ *  hOffsets/hSizes/hOutOffsets are HOST arrays of nQueries entries. Bounds rule per query is the reference's
+ *  (offset+size >= uncompressedSize -> OutOfBoundsAccess, zra.cpp:260). Synchronous. */
+ZRA_EXPORT ZraStatus ZraHipDecompressRABatch(ZraHipEngine* engine, const void* dIn, size_t inSize, void* dOut,
+                                             const uint64_t* hOffsets, const uint64_t* hSizes, const uint64_t* hOutOffsets, size_t nQueries);
+
+/* ---- sharded compression (one process per GPU; frames [firstFrame, firstFrame+nFrames) of a larger input) ---- */
+/** Compresses nFrames frames of frameSize bytes (last may be shorter: inSize bytes total) from dIn into a packed body at dBody
+ *  (capacity nFrames*ZSTD_compressBound(frameSize)); writes the nFrames local frame sizes (u64, device) to dSizes and the
+ *  local body size to *bodySize. No header is produced. */
+ZRA_EXPORT ZraStatus ZraHipCompressFrames(ZraHipEngine* engine, const void* dIn, size_t inSize, void* dBody, uint64_t* dSizes,
+                                          size_t* bodySize, int8_t compressionLevel, uint32_t frameSize, bool checksum);
+
+/** Builds the complete ZRA header (38 bytes + 5*tableSize) on the HOST from all frame sizes (rank-ordered concatenation),
+ *  including the CRC-32 (zra.cpp:128-133). hHeader must hold 38 + 5*(nFramesTotal+1) bytes. */
+ZRA_EXPORT ZraStatus ZraHipStitchHeader(const uint64_t* hFrameSizes, size_t nFramesTotal, uint64_t uncompressedSize,
+                                        uint32_t frameSize, void* hHeader, size_t* headerSize);
+
+/** Last per-call timing of the dominant kernel on the engine's stream, measured with HIP events (milliseconds; 0 if none). */
+ZRA_EXPORT double ZraHipLastKernelMs(ZraHipEngine* engine);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,209 @@
+"""zra_amd — Python binding of libzra_amd.so, the MI355X-native ZRA engine.
+
+This module is plumbing only: it loads the in-tree C-ABI shared library (HIP kernels + C++ host engine)
+with ctypes and mirrors the reference's interface names (include/zra.h of zraorg/ZRA: ZraCompressBuffer,
+ZraDecompressBuffer, ZraDecompressRA, ... + the additive device-pointer calls of include/zra_hip.h).
+There is NO CPU codec here: without the built extension or without a GPU the compute calls raise.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libzra_amd.so")
+
+STATUS_NAMES = ["Success", "ZStdError", "ZraVersionLow", "HeaderInvalid", "HeaderIncomplete", "OutOfBoundsAccess",
+                "OutputBufferTooSmall", "CompressedSizeTooLarge", "InputFrameSizeMismatch"]
+
+
+class ZraStatus(ctypes.Structure):
+    _fields_ = [("zra", ctypes.c_int), ("zstd", ctypes.c_int)]
+
+    def tup(self):
+        return (self.zra, self.zstd)
+
+
+class ZraError(RuntimeError):
+    def __init__(self, status, what=""):
+        self.zra, self.zstd = status
+        name = STATUS_NAMES[self.zra] if 0 <= self.zra < len(STATUS_NAMES) else str(self.zra)
+        super().__init__("%s (zra=%d, zstd=%d) %s" % (name, self.zra, self.zstd, what))
+
+
+READ_FN = ctypes.CFUNCTYPE(None, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_void_p)
+
+_lib = None
+
+
+def load():
+    """Loads libzra_amd.so. Raises (loudly) if the HIP extension has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("zra_amd: %s is missing — run `python -c 'import __graft_entry__ as g; g.build()'` (hipcc, gfx950)" % LIB_PATH)
+    L = ctypes.CDLL(LIB_PATH)
+    sz, vp, u32, u64p = ctypes.c_size_t, ctypes.c_void_p, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint64)
+    szp = ctypes.POINTER(ctypes.c_size_t)
+    S = ZraStatus
+    sig = {
+        "ZraGetVersion": (ctypes.c_uint16, []),
+        "ZraGetErrorString": (ctypes.c_char_p, [S]),
+        "ZraCreateHeader": (S, [ctypes.POINTER(vp), READ_FN]),
+        "ZraCreateHeader2": (S, [ctypes.POINTER(vp), vp, sz]),
+        "ZraDeleteHeader": (None, [vp]),
+        "ZraGetVersionWithHeader": (sz, [vp]),
+        "ZraGetHeaderSizeWithHeader": (sz, [vp]),
+        "ZraGetUncompressedSizeWithHeader": (sz, [vp]),
+        "ZraGetFrameSizeWithHeader": (sz, [vp]),
+        "ZraGetMetadataSize": (sz, [vp]),
+        "ZraGetMetadata": (None, [vp, vp]),
+        "ZraGetCompressedOutputBufferSize": (sz, [sz, sz]),
+        "ZraCompressBuffer": (S, [vp, sz, vp, szp, ctypes.c_int8, u32, ctypes.c_bool, vp, sz]),
+        "ZraDecompressBuffer": (S, [vp, sz, vp]),
+        "ZraDecompressRA": (S, [vp, sz, vp, sz, sz]),
+        "ZraCreateCompressor": (S, [ctypes.POINTER(vp), sz, ctypes.c_int8, u32, ctypes.c_bool, vp, sz]),
+        "ZraDeleteCompressor": (None, [vp]),
+        "ZraGetOutputBufferSizeWithCompressor": (sz, [vp, sz]),
+        "ZraCompressWithCompressor": (S, [vp, vp, sz, vp, szp]),
+        "ZraGetHeaderSizeWithCompressor": (sz, [vp]),
+        "ZraGetHeaderWithCompressor": (S, [vp, vp]),
+        "ZraCreateDecompressor": (S, [ctypes.POINTER(vp), READ_FN, sz]),
+        "ZraDeleteDecompressor": (None, [vp]),
+        "ZraGetHeaderWithDecompressor": (vp, [vp]),
+        "ZraDecompressWithDecompressor": (S, [vp, sz, sz, vp]),
+        "ZraCreateFullDecompressor": (S, [ctypes.POINTER(vp), READ_FN, sz]),
+        "ZraDeleteFullDecompressor": (None, [vp]),
+        "ZraGetHeaderWithFullDecompressor": (vp, [vp]),
+        "ZraDecompressWithFullDecompressor": (S, [vp, vp, sz, szp]),
+        # zra_hip.h
+        "ZraHipDeviceCount": (ctypes.c_int, []),
+        "ZraHipCreateEngine": (S, [ctypes.POINTER(vp), ctypes.c_int]),
+        "ZraHipDestroyEngine": (None, [vp]),
+        "ZraHipSynchronize": (S, [vp]),
+        "ZraHipGetStream": (vp, [vp]),
+        "ZraHipLastKernelMs": (ctypes.c_double, [vp]),
+        "ZraHipCompressBuffer": (S, [vp, vp, sz, vp, szp, ctypes.c_int8, u32, ctypes.c_bool]),
+        "ZraHipDecompressBuffer": (S, [vp, vp, sz, vp, sz]),
+        "ZraHipDecompressRABatch": (S, [vp, vp, sz, vp, u64p, u64p, u64p, sz]),
+        "ZraHipCompressFrames": (S, [vp, vp, sz, vp, vp, szp, ctypes.c_int8, u32, ctypes.c_bool]),
+        "ZraHipStitchHeader": (S, [u64p, sz, ctypes.c_uint64, u32, vp, szp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)          # AttributeError here == a symbol include/*.h declares is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+C_ABI_SYMBOLS = [
+    "ZraGetVersion", "ZraGetErrorString", "ZraCreateHeader", "ZraCreateHeader2", "ZraDeleteHeader", "ZraGetVersionWithHeader",
+    "ZraGetHeaderSizeWithHeader", "ZraGetUncompressedSizeWithHeader", "ZraGetFrameSizeWithHeader", "ZraGetMetadataSize", "ZraGetMetadata",
+    "ZraGetCompressedOutputBufferSize", "ZraCompressBuffer", "ZraDecompressBuffer", "ZraDecompressRA", "ZraCreateCompressor",
+    "ZraDeleteCompressor", "ZraGetOutputBufferSizeWithCompressor", "ZraCompressWithCompressor", "ZraGetHeaderSizeWithCompressor",
+    "ZraGetHeaderWithCompressor", "ZraCreateDecompressor", "ZraDeleteDecompressor", "ZraGetHeaderWithDecompressor",
+    "ZraDecompressWithDecompressor", "ZraCreateFullDecompressor", "ZraDeleteFullDecompressor", "ZraGetHeaderWithFullDecompressor",
+    "ZraDecompressWithFullDecompressor",
+]
+HIP_ABI_SYMBOLS = ["ZraHipDeviceCount", "ZraHipCreateEngine", "ZraHipDestroyEngine", "ZraHipSynchronize", "ZraHipGetStream", "ZraHipLastKernelMs",
+                   "ZraHipCompressBuffer", "ZraHipDecompressBuffer", "ZraHipDecompressRABatch", "ZraHipCompressFrames", "ZraHipStitchHeader"]
+
+
+def _chk(st, what=""):
+    if st.zra != 0:
+        raise ZraError(st.tup(), what)
+
+
+def _cbuf(b):
+    return (ctypes.c_char * max(len(b), 1)).from_buffer_copy(bytes(b) if len(b) else b"\0")
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# host-pointer calls — same names and argument meaning as the reference's zra:: free functions (zra.hpp:139-194)
+def GetOutputBufferSize(input_size, frame_size):
+    return load().ZraGetCompressedOutputBufferSize(input_size, frame_size)
+
+
+def CompressBuffer(data, compressionLevel=0, frameSize=16384, checksum=True, meta=b""):
+    L = load()
+    cap = L.ZraGetCompressedOutputBufferSize(len(data), frameSize)
+    out = ctypes.create_string_buffer(cap)
+    osz = ctypes.c_size_t(0)
+    mb = _cbuf(meta)
+    _chk(L.ZraCompressBuffer(_cbuf(data), len(data), out, ctypes.byref(osz), compressionLevel, frameSize, checksum, mb if len(meta) else None, len(meta)))
+    return out.raw[: osz.value]
+
+
+def DecompressBuffer(archive):
+    L = load()
+    n = int.from_bytes(bytes(archive[18:26]), "little") if len(archive) >= 26 else 0
+    out = ctypes.create_string_buffer(max(n, 1))
+    _chk(L.ZraDecompressBuffer(_cbuf(archive), len(archive), out))
+    return out.raw[:n]
+
+
+def DecompressRA(archive, offset, size):
+    L = load()
+    out = ctypes.create_string_buffer(max(size, 1))
+    _chk(L.ZraDecompressRA(_cbuf(archive), len(archive), out, offset, size))
+    return out.raw[:size]
+
+
+# ---------------------------------------------------------------------------------------------------------------
+class Engine:
+    """Device-pointer engine (include/zra_hip.h). Pointers are plain integers (e.g. torch tensor .data_ptr())."""
+
+    def __init__(self, device=0):
+        self.L = load()
+        h = ctypes.c_void_p()
+        _chk(self.L.ZraHipCreateEngine(ctypes.byref(h), device), "ZraHipCreateEngine")
+        self.h = h
+
+    def close(self):
+        if self.h:
+            self.L.ZraHipDestroyEngine(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def stream(self):
+        return self.L.ZraHipGetStream(self.h)
+
+    def last_kernel_ms(self):
+        return self.L.ZraHipLastKernelMs(self.h)
+
+    def compress(self, d_in, in_size, d_out, level=3, frame_size=65536, checksum=True):
+        osz = ctypes.c_size_t(0)
+        _chk(self.L.ZraHipCompressBuffer(self.h, d_in, in_size, d_out, ctypes.byref(osz), level, frame_size, checksum))
+        return osz.value
+
+    def decompress(self, d_in, in_size, d_out, out_cap):
+        _chk(self.L.ZraHipDecompressBuffer(self.h, d_in, in_size, d_out, out_cap))
+
+    def decompress_ra_batch(self, d_in, in_size, d_out, offsets, sizes, out_offsets):
+        import numpy as np
+        o = np.ascontiguousarray(offsets, dtype=np.uint64)
+        s = np.ascontiguousarray(sizes, dtype=np.uint64)
+        oo = np.ascontiguousarray(out_offsets, dtype=np.uint64)
+        p = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64))
+        _chk(self.L.ZraHipDecompressRABatch(self.h, d_in, in_size, d_out, p(o), p(s), p(oo), len(o)))
+
+    def compress_frames(self, d_in, in_size, d_body, d_sizes, level=3, frame_size=65536, checksum=True):
+        bsz = ctypes.c_size_t(0)
+        _chk(self.L.ZraHipCompressFrames(self.h, d_in, in_size, d_body, d_sizes, ctypes.byref(bsz), level, frame_size, checksum))
+        return bsz.value
+
+
+def stitch_header(frame_sizes, uncompressed_size, frame_size):
+    """Host-side seek-table stitch for sharded compression: all ranks' frame sizes -> full ZRA header."""
+    import numpy as np
+    L = load()
+    fs = np.ascontiguousarray(frame_sizes, dtype=np.uint64)
+    out = ctypes.create_string_buffer(38 + 5 * (len(fs) + 1))
+    hsz = ctypes.c_size_t(0)
+    _chk(L.ZraHipStitchHeader(fs.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), len(fs), uncompressed_size, frame_size, out, ctypes.byref(hsz)))
+    return out.raw[: hsz.value]

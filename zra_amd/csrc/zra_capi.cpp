@@ -1,0 +1,466 @@
+// zra_amd — the drop-in boundary: C++ API (include/zra.hpp) and the 29-symbol C ABI (include/zra.h)
+// implemented on the HIP engine. Host-pointer semantics, status codes, exceptions and the documented quirks
+// follow the reference (source/zra.cpp); the per-frame codec work is never done on the CPU here.
+#include "zra.hpp"
+#include "zra.h"
+#include "zra_hip.h"
+#include "zra_engine.h"
+#include "zra_format.h"
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+
+using zra_eng::Engine;
+namespace fmt = zra_fmt;
+
+namespace {
+std::mutex g_mu;          // the default engine is shared by the (re-entrant in the reference) free functions
+Engine* g_engine = nullptr;
+
+Engine& default_engine() {
+  if (!g_engine) {
+    int dev = 0;
+    if (const char* s = std::getenv("ZRA_DEVICE")) dev = std::atoi(s);
+    zra_eng::Status st = Engine::create(&g_engine, dev);
+    if (st.zra) throw zra::Exception(zra::StatusCode::ZStdError, st.zstd ? st.zstd : 1);   // no GPU: fail loudly, no CPU fallback
+  }
+  return *g_engine;
+}
+void check(zra_eng::Status s) { if (s.zra) throw zra::Exception(static_cast<zra::StatusCode>(s.zra), s.zstd); }
+
+const char* zstd_error_string(int code) {   // ZSTD_getErrorString of zstd 1.4.9 for the codes this library can emit
+  switch (code) {
+    case 0: return "No error detected";
+    case 1: return "Error (generic)";
+    case 10: return "Unknown frame descriptor";
+    case 12: return "Version not supported";
+    case 14: return "Unsupported frame parameter";
+    case 16: return "Frame requires too much memory for decoding";
+    case 20: return "Corrupted block detected";
+    case 22: return "Restored data doesn't match checksum";
+    case 30: return "Dictionary is corrupted";
+    case 40: return "Unsupported parameter";
+    case 42: return "Parameter is out of bound";
+    case 64: return "Allocation error : not enough memory";
+    case 70: return "Destination buffer is too small";
+    case 72: return "Src size is incorrect";
+    default: return "Unspecified error code";
+  }
+}
+
+// Walk the zstd frames of a body on the host (block headers only), the way one ZSTD_decompressDCtx call over the
+// whole body does (zra.cpp:249): skippable frames are skipped, the seek table is NOT consulted.
+// offs receives frame boundaries (n+1 entries for n data frames, contiguous runs only: a skippable frame in the
+// middle is reported through `gaps`). Returns 0 or the zstd error code of the walk.
+int walk_frames(const zra::u8* body, size_t n, std::vector<uint64_t>& starts, std::vector<uint64_t>& ends) {
+  size_t pos = 0; bool more = false;
+  while (n - pos >= 5) {
+    uint32_t magic = fmt::rd32(body + pos);
+    if ((magic & 0xFFFFFFF0u) == 0x184D2A50u) {
+      if (n - pos < 8) return 72;
+      size_t skip = (size_t)fmt::rd32(body + pos + 4) + 8;
+      if (skip > n - pos) return 72;
+      pos += skip; continue;
+    }
+    if (magic != 0xFD2FB528u) return more ? 72 : 10;
+    const size_t f0 = pos;
+    unsigned fhd = body[pos + 4], did = fhd & 3, ss = (fhd >> 5) & 1, fcs = fhd >> 6;
+    size_t hs = 5 + !ss + (did == 3 ? 4 : did) + (fcs == 0 ? ss : fcs == 1 ? 2 : fcs == 2 ? 4 : 8);
+    if (n - pos < hs) return 72;
+    pos += hs;
+    for (;;) {
+      if (n - pos < 3) return 72;
+      uint32_t bh = (uint32_t)body[pos] | ((uint32_t)body[pos + 1] << 8) | ((uint32_t)body[pos + 2] << 16);
+      pos += 3;
+      unsigned type = (bh >> 1) & 3; size_t bs = type == 1 ? 1 : (bh >> 3);
+      if (type == 3) return 20;
+      if (bs > n - pos) return 72;
+      pos += bs;
+      if (bh & 1) break;
+    }
+    if (fhd & 4) { if (n - pos < 4) return 22; pos += 4; }
+    starts.push_back(f0); ends.push_back(pos);
+    more = true;
+  }
+  return pos == n ? 0 : 72;
+}
+}  // namespace
+
+namespace zra {
+  // ------------------------------------------------------------------ errors (zra.cpp:46-86)
+  Exception::Exception(StatusCode code, i32 zstdCode) : code(code), zstdCode(zstdCode) {}
+
+  const char* Exception::GetExceptionString(StatusCode code) {
+    static const char* const text[] = {
+        "The operation was successful",
+        "An error was returned by ZStandard",
+        "This archive was compressed using a newer version of ZRA",
+        "The header in the supplied buffer was invalid",
+        "The header hasn't been fully written before being accessed",
+        "The specified offset and size are past the data contained within the buffer",
+        "The output buffer is too small to contain the output",
+        "The compressed output's size exceeds the maximum limit",
+        "The input size is not divisible by the frame size and nor is it the final frame",
+    };
+    auto i = static_cast<unsigned>(code);
+    return i < sizeof(text) / sizeof(text[0]) ? text[i] : "An unknown error has occurred";
+  }
+
+  const char* Exception::what() const noexcept {
+    if (code != StatusCode::ZStdError) return GetExceptionString(code);
+    static thread_local std::string reason;
+    reason = std::string(GetExceptionString(code)) + ": " + zstd_error_string(zstdCode);
+    return reason.c_str();
+  }
+
+  u16 GetVersion() { return fmt::kVersion; }
+
+  // ------------------------------------------------------------------ Header (zra.cpp:141-187)
+  Header::Header(const std::function<void(size_t, size_t, void*)>& rf) : readFunction(rf) {
+    u8 fixed[fmt::kFixedSize];
+    readFunction(0, sizeof(fixed), fixed);
+    zra_eng::HeaderInfo h{};
+    int e = zra_eng::parse_fixed_header(fixed, &h);
+    if (e == zra_eng::kHeaderInvalid) throw Exception(StatusCode::HeaderInvalid);
+    version = h.version; size = h.size; uncompressedSize = h.uncompressedSize; frameSize = h.frameSize;
+    metaOffset = h.metaOffset; metaSize = h.metaSize; seekTableOffset = h.seekTableOffset; seekTableSize = h.seekTableSize;
+    if (e) throw Exception(static_cast<StatusCode>(e));
+  }
+
+  // The reference captures the view by reference (dangling for temporaries, zra.cpp:165); we keep a copy of the
+  // (pointer, size) pair instead — same behaviour whenever the reference's is defined.
+  Header::Header(const BufferView& buffer)
+      : Header([buffer](size_t offset, size_t readSize, void* out) {
+          if ((offset + readSize) >= buffer.size) throw Exception(StatusCode::OutOfBoundsAccess);   // ">=" as in zra.cpp:166
+          std::memcpy(out, buffer.data + offset, readSize);
+        }) {
+    if (buffer.size < size) throw Exception(StatusCode::OutOfBoundsAccess);
+  }
+
+  Buffer Header::GetSeekTable() const { Buffer t(seekTableSize); readFunction(seekTableOffset, seekTableSize, t.data()); return t; }
+  void Header::GetMetadata(const BufferView& buffer) const { readFunction(metaOffset, metaSize, buffer.data); }
+  Buffer Header::GetMetadata() const { Buffer m(metaSize); GetMetadata(m); return m; }
+
+  // ------------------------------------------------------------------ in-memory calls (zra.cpp:189-302)
+  size_t GetOutputBufferSize(size_t inputSize, u32 frameSize, u32 metaSize) {
+    u32 tableSize = fmt::table_size(inputSize, frameSize);
+    return fmt::kFixedSize + metaSize + (size_t)tableSize * fmt::kEntrySize + fmt::compress_bound(frameSize) * (size_t)(tableSize - 1);
+  }
+
+  size_t CompressBuffer(const BufferView& input, const BufferView& output, i8 level, u32 frameSize, bool checksum, const BufferView& meta) {
+    u32 tableSize = fmt::table_size(input.size, frameSize);
+    size_t need = fmt::kFixedSize + (size_t)tableSize * fmt::kEntrySize + fmt::compress_bound(frameSize) * (size_t)(tableSize - 1);
+    if (output.size < need) throw Exception(StatusCode::OutputBufferTooSmall);   // meta not counted, zra.cpp:196
+    std::lock_guard<std::mutex> lk(g_mu);
+    size_t outSize = 0;
+    check(default_engine().compress_host(input.data, input.size, output.data, &outSize, level, frameSize, checksum));
+    if (meta.size) {
+      // reference quirk (zra.cpp:202-205,231): meta is counted in headerSize/metaSize but never stored, the table stays at
+      // +38, and the CRC then runs meta.size bytes into the body. Reproduced bit-for-bit.
+      fmt::write_fixed(output.data, input.size, tableSize, frameSize, (u32)meta.size);
+      fmt::wr32(output.data + 14, fmt::header_hash(output.data, output.data + fmt::kFixedSize));
+    }
+    return outSize;
+  }
+
+  Buffer CompressBuffer(const BufferView& buffer, i8 level, u32 frameSize, bool checksum, const BufferView& meta) {
+    Buffer output(GetOutputBufferSize(buffer.size, frameSize));   // meta not counted, zra.cpp:237
+    output.resize(CompressBuffer(buffer, output, level, frameSize, checksum, meta));
+    output.shrink_to_fit();
+    return output;
+  }
+
+  void DecompressBuffer(const BufferView& input, const BufferView& output) {
+    Header header(input);
+    if (output.size < header.uncompressedSize) throw Exception(StatusCode::OutputBufferTooSmall);
+    // one multi-frame zstd call over the whole body in the reference (zra.cpp:249): walk the frames on the host,
+    // decode them all in parallel on the device.
+    const u8* body = input.data + header.size; const size_t bodySize = input.size - header.size;
+    std::vector<uint64_t> starts, ends;
+    int walkErr = walk_frames(body, bodySize, starts, ends);
+    std::lock_guard<std::mutex> lk(g_mu);
+    zra_eng::Status s = default_engine().decode_host(body, bodySize, starts, ends, header.frameSize, header.uncompressedSize, output.data, 0, (size_t)header.uncompressedSize);
+    check(s);
+    if (walkErr) throw Exception(StatusCode::ZStdError, walkErr);
+  }
+
+  Buffer DecompressBuffer(const BufferView& buffer) {
+    Buffer output(fmt::rd64(buffer.data + 18));   // read before validation, as zra.cpp:253
+    DecompressBuffer(buffer, output);
+    return output;
+  }
+
+  namespace {
+    // frames [first, last) of the seek table -> decode -> copy [skip, skip+size) into out (the 3 phases of zra.cpp:279-295
+    // collapse to this on a device that decodes all touched frames at once)
+    void ra_decode(const u8* table, const u8* span, u64 spanBase, u64 firstIdx, u64 count, const Header& header, u8* out, size_t skip, size_t size) {
+      std::vector<uint64_t> starts(count), ends(count);
+      for (u64 i = 0; i < count; i++) {
+        starts[i] = fmt::entry_get(table + (firstIdx + i) * 5) - spanBase;
+        ends[i] = fmt::entry_get(table + (firstIdx + i + 1) * 5) - spanBase;
+      }
+      const u64 spanSize = count ? ends[count - 1] : 0;
+      // every touched frame but possibly the archive's last regenerates frameSize bytes
+      const u64 firstByte = firstIdx * (u64)header.frameSize;
+      const u64 total = std::min<u64>(count * (u64)header.frameSize, header.uncompressedSize > firstByte ? header.uncompressedSize - firstByte : 0);
+      std::lock_guard<std::mutex> lk(g_mu);
+      check(default_engine().decode_host(span, spanSize, starts, ends, header.frameSize, total, out, skip, size));
+    }
+  }
+
+  void DecompressRA(const BufferView& input, const BufferView& output, size_t offset, size_t size) {
+    Header header(input);
+    if (offset + size >= header.uncompressedSize) throw Exception(StatusCode::OutOfBoundsAccess);   // ">=", zra.cpp:260
+    if (output.size < size) throw Exception(StatusCode::OutputBufferTooSmall);
+    const u64 q = offset / header.frameSize, r = offset % header.frameSize;
+    const u64 n = (r + size) / header.frameSize, t = (r + size) % header.frameSize;
+    const u64 count = n + (t ? 1 : 0);
+    if (size == 0 || count == 0) return;
+    const u8* table = input.data + header.seekTableOffset;
+    const u64 base = fmt::entry_get(table + q * 5);
+    ra_decode(table, input.data + header.size + base, base, q, count, header, output.data, r, size);
+  }
+
+  Buffer DecompressRA(const BufferView& buffer, size_t offset, size_t size) {
+    Buffer output(size);
+    DecompressRA(buffer, output, offset, size);
+    return output;
+  }
+
+  // ------------------------------------------------------------------ Compressor (zra.cpp:304-365)
+  struct Compressor::Impl {
+    i8 level; bool checksum;
+    u32 frameSize, tableSize;
+    Buffer header;
+    size_t entryIndex{0}, metaSize{0};
+    u64 outputOffset{0};
+    u8* entry(size_t i) { return header.data() + fmt::kFixedSize + metaSize + i * fmt::kEntrySize; }
+  };
+
+  Compressor::Compressor(size_t size, i8 level, u32 frameSize, bool checksum, const BufferView& meta) : impl(std::make_shared<Impl>()) {
+    impl->level = level; impl->checksum = checksum; impl->frameSize = frameSize;
+    impl->tableSize = fmt::table_size(size, frameSize);
+    impl->metaSize = meta.size;
+    impl->header.resize(fmt::kFixedSize + meta.size + (size_t)impl->tableSize * fmt::kEntrySize);
+    fmt::write_fixed(impl->header.data(), size, impl->tableSize, frameSize, (u32)meta.size);
+    if (meta.data) std::memcpy(impl->header.data() + fmt::kFixedSize, meta.data, meta.size);
+  }
+
+  size_t Compressor::GetOutputBufferSize(size_t inputSize) const {
+    return fmt::compress_bound(impl->frameSize) * ((inputSize / impl->frameSize) + ((inputSize % impl->frameSize) ? 1 : 0));
+  }
+
+  size_t Compressor::Compress(const BufferView& input, const BufferView& output) {
+    Impl& m = *impl;
+    if (output.size < GetOutputBufferSize(input.size)) throw Exception(StatusCode::OutputBufferTooSmall);
+    // the reference measures the entry index from +38 even with metadata present (zra.cpp:324); kept
+    const size_t refIndex = m.entryIndex + m.metaSize / fmt::kEntrySize;
+    if (input.size % m.frameSize && (refIndex + (input.size / m.frameSize) + 2) < m.tableSize) throw Exception(StatusCode::InputFrameSizeMismatch);
+    size_t bodySize = 0;
+    std::vector<uint64_t> sizes;
+    if (input.size) {
+      std::lock_guard<std::mutex> lk(g_mu);
+      check(default_engine().compress_frames_host(input.data, input.size, output.data, sizes, &bodySize, m.level, m.frameSize, m.checksum));
+    }
+    for (uint64_t c : sizes) {
+      fmt::entry_put(m.entry(m.entryIndex++), m.outputOffset);
+      m.outputOffset += c;
+    }
+    if (input.size % m.frameSize) m.frameSize = (u32)(input.size % m.frameSize);   // member shrinks on the short last frame, zra.cpp:330
+    if (m.outputOffset >= fmt::kMaxCompressedSize) throw Exception(StatusCode::CompressedSizeTooLarge);
+    if (m.entryIndex == (size_t)m.tableSize - 1) {
+      fmt::entry_put(m.entry(m.entryIndex++), m.outputOffset);
+      fmt::wr32(m.header.data() + 14, fmt::header_hash(m.header.data(), m.header.data() + fmt::kFixedSize));
+    }
+    return bodySize;
+  }
+
+  void Compressor::Compress(const BufferView& input, Buffer& output) {
+    output.resize(GetOutputBufferSize(input.size));
+    output.resize(Compress(input, BufferView(output)));
+  }
+
+  const Buffer& Compressor::GetHeader() {
+    if (impl->entryIndex == impl->tableSize) return impl->header;
+    throw Exception(StatusCode::HeaderIncomplete);
+  }
+  size_t Compressor::GetHeaderSize() { return impl->header.size(); }
+
+  // ------------------------------------------------------------------ Decompressor (zra.cpp:367-424)
+  Decompressor::Decompressor(const std::function<void(size_t, size_t, void*)>& rf, size_t maxCacheSize)
+      : readFunction(rf), header(rf), seekTable(header.GetSeekTable()), maxCacheSize(maxCacheSize) {}
+
+  void Decompressor::Decompress(size_t offset, size_t size, const BufferView& output) {
+    if (offset + size > header.uncompressedSize) throw Exception(StatusCode::OutOfBoundsAccess);   // ">" here, zra.cpp:370
+    if (output.size < size) throw Exception(StatusCode::OutputBufferTooSmall);
+    const u64 q = offset / header.frameSize, r = offset % header.frameSize;
+    const u64 n = (r + size) / header.frameSize, t = (r + size) % header.frameSize;
+    const u64 count = n + (t ? 1 : 0);
+    const u8* table = seekTable.data();
+    const u64 base = fmt::entry_get(table + q * 5);
+    const u64 compressedSize = fmt::entry_get(table + (q + count) * 5) - base;
+    Buffer own;
+    Buffer& in = compressedSize > maxCacheSize ? own : cache;
+    in.resize(compressedSize);
+    readFunction(header.size + base, compressedSize, in.data());
+    if (size == 0 || count == 0) return;
+    ra_decode(table, in.data(), base, q, count, header, output.data, r, size);
+  }
+  void Decompressor::Decompress(size_t offset, size_t size, Buffer& output) { output.resize(size); Decompress(offset, size, BufferView(output)); }
+  Buffer Decompressor::Decompress(size_t offset, size_t size) { Buffer b; Decompress(offset, size, b); return b; }
+
+  // ------------------------------------------------------------------ FullDecompressor (zra.cpp:426-436)
+  FullDecompressor::FullDecompressor(const std::function<void(size_t, size_t, void*)>& rf)
+      : readFunction(rf), header(rf), seekTable(header.GetSeekTable()) {}
+
+  size_t FullDecompressor::Decompress(const BufferView& output) {
+    if (output.size < header.frameSize) throw Exception(StatusCode::OutputBufferTooSmall);
+    const size_t lastIndex = seekTable.size() / fmt::kEntrySize - 1;
+    const size_t stop = std::min(lastIndex, entryIndex + output.size / header.frameSize);
+    const u8* table = seekTable.data();
+    const u64 base = fmt::entry_get(table + entryIndex * 5);
+    cache.resize(fmt::entry_get(table + stop * 5) - base);
+    readFunction(header.size + base, cache.size(), cache.data());
+    const size_t first = entryIndex, count = stop - entryIndex;
+    entryIndex = stop;
+    if (!count) return 0;
+    const u64 firstByte = (u64)first * header.frameSize;
+    const size_t produced = (size_t)std::min<u64>((u64)count * header.frameSize, header.uncompressedSize - firstByte);
+    ra_decode(table, cache.data(), base, first, count, header, output.data, 0, produced);
+    return produced;
+  }
+}  // namespace zra
+
+// ====================================================================================== C ABI (zra.cpp:439-626)
+namespace {
+ZraStatus mk(ZraStatusCode z, int zstd = 0) { return ZraStatus{z, (int)(int8_t)zstd}; }
+ZraStatus mk(const zra::Exception& e) { return mk(static_cast<ZraStatusCode>(e.code), e.zstdCode); }
+ZraStatus mk(zra_eng::Status s) { return ZraStatus{static_cast<ZraStatusCode>(s.zra), s.zstd}; }
+template <typename F> ZraStatus guarded(F&& f) {
+  try { f(); return mk(Success); } catch (const zra::Exception& e) { return mk(e); }
+}
+}  // namespace
+
+extern "C" {
+uint16_t ZraGetVersion(void) { return zra::GetVersion(); }
+const char* ZraGetErrorString(ZraStatus status) {
+  static thread_local std::string s;
+  s = zra::Exception(static_cast<zra::StatusCode>(status.zra), status.zstd).what();
+  return s.c_str();
+}
+
+ZraStatus ZraCreateHeader(ZraHeader** header, ZraReadFunction* rf) {
+  return guarded([&] { *header = reinterpret_cast<ZraHeader*>(new zra::Header(std::function<void(size_t, size_t, void*)>(rf))); });
+}
+ZraStatus ZraCreateHeader2(ZraHeader** header, void* buffer, size_t size) {
+  return guarded([&] { *header = reinterpret_cast<ZraHeader*>(new zra::Header(zra::BufferView(buffer, size))); });
+}
+void ZraDeleteHeader(ZraHeader* h) { delete reinterpret_cast<zra::Header*>(h); }
+size_t ZraGetVersionWithHeader(ZraHeader* h) { return reinterpret_cast<zra::Header*>(h)->version; }
+size_t ZraGetHeaderSizeWithHeader(ZraHeader* h) { return reinterpret_cast<zra::Header*>(h)->size; }
+size_t ZraGetUncompressedSizeWithHeader(ZraHeader* h) { return reinterpret_cast<zra::Header*>(h)->uncompressedSize; }
+size_t ZraGetFrameSizeWithHeader(ZraHeader* h) { return reinterpret_cast<zra::Header*>(h)->frameSize; }
+size_t ZraGetMetadataSize(ZraHeader* h) { return reinterpret_cast<zra::Header*>(h)->metaSize; }
+void ZraGetMetadata(ZraHeader* h, void* buffer) {
+  auto* o = reinterpret_cast<zra::Header*>(h);
+  o->GetMetadata(zra::BufferView(buffer, o->metaSize));
+}
+
+size_t ZraGetCompressedOutputBufferSize(size_t inputSize, size_t frameSize) { return zra::GetOutputBufferSize(inputSize, (uint32_t)frameSize); }
+
+ZraStatus ZraCompressBuffer(void* in, size_t inSize, void* out, size_t* outSize, int8_t level, uint32_t frameSize, bool checksum, void* meta, size_t metaSize) {
+  return guarded([&] {
+    *outSize = zra::CompressBuffer(zra::BufferView(in, inSize), zra::BufferView(out, zra::GetOutputBufferSize(inSize, frameSize)), level, frameSize,
+                                   checksum, zra::BufferView(meta, metaSize));
+  });
+}
+ZraStatus ZraDecompressBuffer(void* in, size_t inSize, void* out) {
+  return guarded([&] {
+    // capacity is read from the raw header before validation, like the wrapper at zra.cpp:519
+    uint64_t cap = inSize >= 26 ? zra_fmt::rd64(static_cast<uint8_t*>(in) + 18) : 0;
+    zra::DecompressBuffer(zra::BufferView(in, inSize), zra::BufferView(out, cap));
+  });
+}
+ZraStatus ZraDecompressRA(void* in, size_t inSize, void* out, size_t offset, size_t size) {
+  return guarded([&] { zra::DecompressRA(zra::BufferView(in, inSize), zra::BufferView(out, size), offset, size); });
+}
+
+ZraStatus ZraCreateCompressor(ZraCompressor** c, size_t size, int8_t level, uint32_t frameSize, bool checksum, void* meta, size_t metaSize) {
+  return guarded([&] { *c = reinterpret_cast<ZraCompressor*>(new zra::Compressor(size, level, frameSize, checksum, zra::BufferView(meta, metaSize))); });
+}
+void ZraDeleteCompressor(ZraCompressor* c) { delete reinterpret_cast<zra::Compressor*>(c); }
+size_t ZraGetOutputBufferSizeWithCompressor(ZraCompressor* c, size_t inputSize) { return reinterpret_cast<zra::Compressor*>(c)->GetOutputBufferSize(inputSize); }
+ZraStatus ZraCompressWithCompressor(ZraCompressor* c, void* in, size_t inSize, void* out, size_t* outSize) {
+  return guarded([&] {
+    auto* o = reinterpret_cast<zra::Compressor*>(c);
+    *outSize = o->Compress(zra::BufferView(in, inSize), zra::BufferView(out, o->GetOutputBufferSize(inSize)));
+  });
+}
+size_t ZraGetHeaderSizeWithCompressor(ZraCompressor* c) { return reinterpret_cast<zra::Compressor*>(c)->GetHeaderSize(); }
+ZraStatus ZraGetHeaderWithCompressor(ZraCompressor* c, void* out) {
+  return guarded([&] { const zra::Buffer& h = reinterpret_cast<zra::Compressor*>(c)->GetHeader(); std::memcpy(out, h.data(), h.size()); });
+}
+
+ZraStatus ZraCreateDecompressor(ZraDecompressor** d, ZraReadFunction* rf, size_t maxCacheSize) {
+  return guarded([&] { *d = reinterpret_cast<ZraDecompressor*>(new zra::Decompressor(std::function<void(size_t, size_t, void*)>(rf), maxCacheSize)); });
+}
+void ZraDeleteDecompressor(ZraDecompressor* d) { delete reinterpret_cast<zra::Decompressor*>(d); }
+ZraHeader* ZraGetHeaderWithDecompressor(ZraDecompressor* d) { return reinterpret_cast<ZraHeader*>(&reinterpret_cast<zra::Decompressor*>(d)->header); }
+ZraStatus ZraDecompressWithDecompressor(ZraDecompressor* d, size_t offset, size_t size, void* out) {
+  return guarded([&] { reinterpret_cast<zra::Decompressor*>(d)->Decompress(offset, size, zra::BufferView(out, size)); });
+}
+
+ZraStatus ZraCreateFullDecompressor(ZraFullDecompressor** d, ZraReadFunction* rf, size_t /*maxCacheSize: ignored, zra.cpp:602-604*/) {
+  return guarded([&] { *d = reinterpret_cast<ZraFullDecompressor*>(new zra::FullDecompressor(std::function<void(size_t, size_t, void*)>(rf))); });
+}
+void ZraDeleteFullDecompressor(ZraFullDecompressor* d) { delete reinterpret_cast<zra::FullDecompressor*>(d); }
+ZraHeader* ZraGetHeaderWithFullDecompressor(ZraFullDecompressor* d) { return reinterpret_cast<ZraHeader*>(&reinterpret_cast<zra::FullDecompressor*>(d)->header); }
+ZraStatus ZraDecompressWithFullDecompressor(ZraFullDecompressor* d, void* out, size_t cap, size_t* outSize) {
+  return guarded([&] { *outSize = reinterpret_cast<zra::FullDecompressor*>(d)->Decompress(zra::BufferView(out, cap)); });
+}
+
+// ---------------------------------------------------------------------------- device-side additions (zra_hip.h)
+struct ZraHipEngine { Engine* e; };
+
+int ZraHipDeviceCount(void) { int n = 0; return hipGetDeviceCount(&n) == hipSuccess ? n : 0; }
+ZraStatus ZraHipCreateEngine(ZraHipEngine** engine, int device) {
+  Engine* e = nullptr;
+  zra_eng::Status s = Engine::create(&e, device);
+  if (s.zra) return mk(s);
+  *engine = new ZraHipEngine{e};
+  return mk(Success);
+}
+void ZraHipDestroyEngine(ZraHipEngine* engine) { if (engine) { delete engine->e; delete engine; } }
+ZraStatus ZraHipSynchronize(ZraHipEngine* engine) { return mk(engine->e->sync()); }
+void* ZraHipGetStream(ZraHipEngine* engine) { return (void*)engine->e->stream(); }
+double ZraHipLastKernelMs(ZraHipEngine* engine) { return engine->e->last_kernel_ms(); }
+
+ZraStatus ZraHipCompressBuffer(ZraHipEngine* engine, const void* dIn, size_t inSize, void* dOut, size_t* outSize, int8_t level, uint32_t frameSize, bool checksum) {
+  return mk(engine->e->compress_device((const uint8_t*)dIn, inSize, (uint8_t*)dOut, outSize, level, frameSize, checksum));
+}
+ZraStatus ZraHipDecompressBuffer(ZraHipEngine* engine, const void* dIn, size_t inSize, void* dOut, size_t outCapacity) {
+  return mk(engine->e->decompress_device((const uint8_t*)dIn, inSize, (uint8_t*)dOut, outCapacity));
+}
+ZraStatus ZraHipDecompressRABatch(ZraHipEngine* engine, const void* dIn, size_t inSize, void* dOut, const uint64_t* hOffsets, const uint64_t* hSizes,
+                                  const uint64_t* hOutOffsets, size_t nQueries) {
+  return mk(engine->e->decompress_ra_batch((const uint8_t*)dIn, inSize, (uint8_t*)dOut, hOffsets, hSizes, hOutOffsets, nQueries));
+}
+ZraStatus ZraHipCompressFrames(ZraHipEngine* engine, const void* dIn, size_t inSize, void* dBody, uint64_t* dSizes, size_t* bodySize, int8_t level,
+                               uint32_t frameSize, bool checksum) {
+  return mk(engine->e->compress_frames((const uint8_t*)dIn, inSize, (uint8_t*)dBody, dSizes, bodySize, level, frameSize, checksum));
+}
+ZraStatus ZraHipStitchHeader(const uint64_t* hFrameSizes, size_t nFramesTotal, uint64_t uncompressedSize, uint32_t frameSize, void* hHeader, size_t* headerSize) {
+  uint8_t* h = (uint8_t*)hHeader;
+  const uint32_t tableSize = (uint32_t)nFramesTotal + 1;
+  zra_fmt::write_fixed(h, uncompressedSize, tableSize, frameSize, 0);
+  uint64_t off = 0;
+  for (size_t i = 0; i < nFramesTotal; i++) { zra_fmt::entry_put(h + zra_fmt::kFixedSize + i * 5, off); off += hFrameSizes[i]; }
+  zra_fmt::entry_put(h + zra_fmt::kFixedSize + nFramesTotal * 5, off);
+  if (off + zra_fmt::kFixedSize + (size_t)tableSize * 5 >= zra_fmt::kMaxCompressedSize) return mk(CompressedSizeTooLarge);
+  zra_fmt::wr32(h + 14, zra_fmt::header_hash(h, h + zra_fmt::kFixedSize));
+  *headerSize = zra_fmt::kFixedSize + (size_t)tableSize * 5;
+  return mk(Success);
+}
+}  // extern "C"

@@ -1,0 +1,681 @@
+// zra_amd — frame DECODE kernels for gfx950 (MI355X).
+//
+// Replaces the reference's per-frame ZSTD_decompressDCtx work (zra.cpp:249,280,289,293,397,406,410,435):
+// one independent zstd frame per workgroup (256 threads = 4 waves), persistent grid with an atomic
+// frame queue. Format per RFC 8878 / SURVEY.md Appendix A.1-A.3.
+//
+// Wave specialisation inside a workgroup, per compressed block:
+//   wave 0          : FSE sequence decode (inherently serial bit chain) -> chunk ring in LDS
+//   waves 2,3       : position scan + literal copies of the previous chunk (fully parallel)
+//   wave 1          : match copies of the chunk before that (dependency order, 64 lanes per copy)
+// so the three stages of sequence execution overlap as a 3-deep pipeline over 512-sequence chunks.
+// Huffman literal streams (4 backward bitstreams) are decoded by 4 lanes concurrently with the first
+// sequence chunk. Decode tables live in LDS; the output window is the destination buffer in HBM/L2.
+#include "zra_dev.h"
+#include "zra_kernels.h"
+
+using namespace zra_dev;
+
+namespace {
+
+constexpr int DEC_THREADS = 256;
+constexpr int CHUNK = 512;          // sequences per pipeline chunk
+constexpr u32 BLOCK_MAX = 128u << 10;
+
+__constant__ u32 c_ll_base[36] = {0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,18,20,22,24,28,32,40,48,64,128,256,512,1024,2048,4096,8192,16384,32768,65536};
+__constant__ u8 c_ll_bits[36] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,1,1,1,1,2,2,3,3,4,6,7,8,9,10,11,12,13,14,15,16};
+__constant__ u32 c_ml_base[53] = {3,4,5,6,7,8,9,10,11,12,13,14,15,16,17,18,19,20,21,22,23,24,25,26,27,28,29,30,31,32,33,34,
+                                  35,37,39,41,43,47,51,59,67,83,99,131,259,515,1027,2051,4099,8195,16387,32771,65539};
+__constant__ u8 c_ml_bits[53] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,
+                                 1,1,1,1,2,2,3,3,4,4,5,7,8,9,10,11,12,13,14,15,16};
+__constant__ short c_ll_defnorm[36] = {4,3,2,2,2,2,2,2,2,2,2,2,2,1,1,1,2,2,2,2,2,2,2,2,2,3,2,1,1,1,1,1,-1,-1,-1,-1};
+__constant__ short c_ml_defnorm[53] = {1,4,3,2,2,2,2,2,2,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,
+                                       1,1,1,1,1,1,1,1,1,1,1,1,1,1,-1,-1,-1,-1,-1,-1,-1};
+__constant__ short c_of_defnorm[29] = {1,1,1,1,1,1,2,2,2,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,-1,-1,-1,-1,-1};
+
+// decode-table entry for LL / ML / OF (8 bytes): baseValue | nbAddBits<<32 | nbBits<<40 | nextBase<<48
+__device__ __forceinline__ u64 mk_seqsym(u32 baseValue, u32 addBits, u32 nbBits, u32 nextBase) {
+  return (u64)baseValue | ((u64)addBits << 32) | ((u64)nbBits << 40) | ((u64)nextBase << 48);
+}
+
+struct __attribute__((aligned(16))) DecShared {
+  u64 llT[512];
+  u64 mlT[512];
+  u64 ofT[256];
+  u16 huf[2048];            // sym | nbBits<<8
+  u32 seqLL[3][CHUNK];
+  u32 seqML[3][CHUNK];
+  u32 seqOF[3][CHUNK];
+  u32 seqOut[3][CHUNK];     // output position (block-relative) where the sequence's literals start
+  u32 seqLit[3][CHUNK];     // literal-buffer position of the sequence's literals
+  u32 chunkN[3];            // sequences in ring slot
+  short norm[256];          // scratch: normalised counts while building a table
+  u8 weights[256];
+  u8 spread[512];
+  u32 rankStart[16];
+  // per-frame / per-block control words (written by thread 0, read after a barrier)
+  u32 err;
+  u32 frame;                // frame index taken from the queue
+  u32 blkType, blkSize, blkLast, blkPos;
+  u32 litType, litRegen, litComp, litHdr, litStreams, litRle;
+  u32 hufValid, hufMaxBits, hufNSym;
+  u32 nbSeq, seqPos, seqModes;
+  u32 llLog, mlLog, ofLog, llValid, mlValid, ofValid;
+  u32 rep[3];
+  u32 streamOff[4], streamLen[4];
+  // sequence-decode carried state (wave 0 lane 0 only, kept here between chunks)
+  u32 sLL, sML, sOF;
+  i32 brPos;
+  u32 decoded;              // sequences decoded so far in this block
+  u32 outBase, litBase;     // running output / literal positions for the scan stage
+  u32 produced;             // bytes produced in this frame so far
+};
+
+// ---------------------------------------------------------------------------------------------
+// FSE table description (A.3) -> norm[] ; single thread. returns bytes consumed, 0 on corruption
+__device__ u32 read_ncount(short* norm, u32* maxSymIO, u32* tableLogOut, const u8* src, u32 n, u32 maxAL, const u8* lim) {
+  if (n < 1) return 0;
+  u32 bitpos = 0, nbits = n * 8;
+  auto peekf = [&](u32 k) -> u32 {
+    u32 byte = bitpos >> 3;
+    u64 v = byte < n ? ld64_safe(src + byte, src + n < lim ? src + n : lim) : 0;
+    return (u32)((v >> (bitpos & 7)) & ((1u << k) - 1));
+  };
+  u32 AL = peekf(4) + 5; bitpos += 4;
+  if (AL > maxAL) return 0;
+  i32 remaining = (1 << AL) + 1, thr = 1 << AL, nb = (i32)AL + 1;
+  u32 sym = 0, maxSym = *maxSymIO;
+  bool prev0 = false;
+  for (u32 s = 0; s <= maxSym; s++) norm[s] = 0;
+  while (remaining > 1 && sym <= maxSym) {
+    if (prev0) {
+      for (;;) {
+        u32 f = peekf(2); bitpos += 2;
+        sym += f;
+        if (f != 3) break;
+        if (bitpos > nbits) return 0;
+      }
+      if (sym > maxSym) return 0;
+    }
+    i32 max = (2 * thr - 1) - remaining, v;
+    u32 low = peekf(nb - 1);
+    if ((i32)low < max) { v = (i32)low; bitpos += nb - 1; }
+    else { v = (i32)peekf(nb); if (v >= thr) v -= max; bitpos += nb; }
+    v--;
+    remaining -= v < 0 ? -v : v;
+    norm[sym++] = (short)v;
+    prev0 = (v == 0);
+    if (remaining < 1) return 0;
+    while (remaining < thr) { nb--; thr >>= 1; }
+    if (bitpos > nbits) return 0;
+  }
+  if (remaining != 1 || bitpos > nbits) return 0;
+  *maxSymIO = sym - 1;
+  *tableLogOut = AL;
+  return (bitpos + 7) >> 3;
+}
+
+// Build an FSE decode table from norm[] (single wave; lanes cooperate on the final fill).
+// kind: 0 = LL, 1 = ML, 2 = OF
+__device__ void build_fse_dtable(u64* table, const short* norm, u32 maxSym, u32 tableLog, int kind, u8* spread, int lane) {
+  u32 size = 1u << tableLog, mask = size - 1;
+  if (lane == 0) {
+    u32 high = size - 1, step = (size >> 1) + (size >> 3) + 3, pos = 0;
+    for (u32 s = 0; s <= maxSym; s++) if (norm[s] == -1) spread[high--] = (u8)s;
+    for (u32 s = 0; s <= maxSym; s++) {
+      for (int i = 0; i < norm[s]; i++) {
+        spread[pos] = (u8)s;
+        pos = (pos + step) & mask;
+        while (pos > high) pos = (pos + step) & mask;
+      }
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  // cell u gets x = next[sym]++ in ascending u. One lane per symbol walks all cells (broadcast LDS reads).
+  if ((u32)lane <= maxSym && norm[lane] != 0) {
+    const u32 s = (u32)lane;
+    u32 x = norm[s] == -1 ? 1u : (u32)norm[s];
+    for (u32 u = 0; u < size; u++) {
+      if (spread[u] != s) continue;
+      u32 nbBits = tableLog - hb32(x);
+      u32 nextBase = (x << nbBits) - size;
+      u64 e;
+      if (kind == 0) e = mk_seqsym(c_ll_base[s], c_ll_bits[s], nbBits, nextBase);
+      else if (kind == 1) e = mk_seqsym(c_ml_base[s], c_ml_bits[s], nbBits, nextBase);
+      else e = mk_seqsym(1u << s, s, nbBits, nextBase);
+      table[u] = e;
+      x++;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// cooperative byte copy global->global by the calling group of `nthreads` threads (rank `t`)
+__device__ __forceinline__ void copy_bytes(u8* dst, const u8* src, u32 n, int t, int nthreads) {
+  // 16-byte body when both are 16B-aligned relative to each other is not guaranteed; use 8-byte unaligned moves
+  u32 n8 = n >> 3;
+  for (u32 i = t; i < n8; i += nthreads) st64(dst + 8 * i, ld64(src + 8 * i));
+  for (u32 i = (n8 << 3) + t; i < n; i += nthreads) dst[i] = src[i];
+}
+__device__ __forceinline__ void fill_bytes(u8* dst, u8 v, u32 n, int t, int nthreads) {
+  u64 vv = 0x0101010101010101ull * v;
+  u32 n8 = n >> 3;
+  for (u32 i = t; i < n8; i += nthreads) st64(dst + 8 * i, vv);
+  for (u32 i = (n8 << 3) + t; i < n; i += nthreads) dst[i] = v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// literals section header + Huffman tree description; thread 0 only. Sets S.lit* / S.huf* / S.err.
+__device__ void parse_literals_header(DecShared& S, const u8* src, u32 n, const u8* lim) {
+  if (n < 1) { S.err = ZE_CORRUPTION; return; }
+  u32 b0 = src[0], type = b0 & 3, sf = (b0 >> 2) & 3;
+  S.litType = type;
+  if (type < 2) {
+    u32 size, lh;
+    if (sf == 0 || sf == 2) { size = b0 >> 3; lh = 1; }
+    else if (sf == 1) { if (n < 2) { S.err = ZE_CORRUPTION; return; } size = ld16(src) >> 4; lh = 2; }
+    else { if (n < 3) { S.err = ZE_CORRUPTION; return; } size = ld24(src) >> 4; lh = 3; }
+    if (size > BLOCK_MAX) { S.err = ZE_CORRUPTION; return; }
+    u32 payload = type == 0 ? size : 1;
+    if (lh + payload > n) { S.err = ZE_CORRUPTION; return; }
+    S.litRegen = size; S.litHdr = lh; S.litComp = payload;
+    if (type == 1) S.litRle = src[lh];
+    return;
+  }
+  u32 need = sf < 2 ? 3 : sf == 2 ? 4 : 5;
+  if (n < need) { S.err = ZE_CORRUPTION; return; }
+  u32 regen, comp, lh, streams;
+  if (sf < 2) { u32 v = ld24(src); regen = (v >> 4) & 0x3FF; comp = v >> 14; lh = 3; streams = sf == 0 ? 1 : 4; }
+  else if (sf == 2) { u32 v = ld32(src); regen = (v >> 4) & 0x3FFF; comp = v >> 18; lh = 4; streams = 4; }
+  else { u64 v = (u64)ld32(src) | ((u64)src[4] << 32); regen = (u32)(v >> 4) & 0x3FFFF; comp = (u32)(v >> 22); lh = 5; streams = 4; }
+  if (regen > BLOCK_MAX || lh + comp > n) { S.err = ZE_CORRUPTION; return; }
+  S.litRegen = regen; S.litComp = comp; S.litHdr = lh; S.litStreams = streams;
+  const u8* p = src + lh; u32 rem = comp;
+  if (type == 2) {
+    // ---- tree description -> S.weights[0..nSym)
+    if (rem < 1) { S.err = ZE_CORRUPTION; return; }
+    u32 hbyte = p[0], nw = 0, used;
+    if (hbyte >= 128) {
+      nw = hbyte - 127; used = 1 + (nw + 1) / 2;
+      if (used > rem) { S.err = ZE_CORRUPTION; return; }
+      for (u32 i = 0; i < nw; i += 2) { u32 b = p[1 + i / 2]; S.weights[i] = (u8)(b >> 4); S.weights[i + 1] = (u8)(b & 15); }
+    } else {
+      used = 1 + hbyte;
+      if (used > rem || hbyte < 1) { S.err = ZE_CORRUPTION; return; }
+      u32 maxSym = 255, tl;
+      u32 h = read_ncount(S.norm, &maxSym, &tl, p + 1, hbyte, 6, lim);
+      if (!h) { S.err = ZE_CORRUPTION; return; }
+      // small serial FSE decode of the weights (<= 255 symbols); table (<= 64 cells) in the idle chunk ring
+      u64* const wt = (u64*)S.seqLL[0];
+      u16* const next = (u16*)S.seqML[0];
+      {
+        u32 size = 1u << tl, mask = size - 1, high = size - 1, step = (size >> 1) + (size >> 3) + 3, pos = 0;
+        for (u32 s = 0; s <= maxSym; s++) { next[s] = S.norm[s] == -1 ? 1 : (u16)S.norm[s]; if (S.norm[s] == -1) S.spread[high--] = (u8)s; }
+        for (u32 s = 0; s <= maxSym; s++)
+          for (int i = 0; i < S.norm[s]; i++) { S.spread[pos] = (u8)s; pos = (pos + step) & mask; while (pos > high) pos = (pos + step) & mask; }
+        if (pos != 0) { S.err = ZE_CORRUPTION; return; }
+        for (u32 u = 0; u < size; u++) {
+          u32 s = S.spread[u], x = next[s]++;
+          u32 nbBits = tl - hb32(x);
+          wt[u] = mk_seqsym(s, 0, nbBits, (x << nbBits) - size);
+        }
+      }
+      BitR br;
+      if (br.init(p + 1 + h, hbyte - h, lim)) { S.err = ZE_CORRUPTION; return; }
+      u32 s1 = br.read((int)tl), s2 = br.read((int)tl);
+      for (;;) {
+        if (nw >= 254) { S.err = ZE_CORRUPTION; return; }
+        u64 e1 = wt[s1];
+        S.weights[nw++] = (u8)e1;
+        s1 = (u32)(e1 >> 48) + br.read((int)((e1 >> 40) & 0xFF));
+        if (br.pos < 0) { S.weights[nw++] = (u8)wt[s2]; break; }
+        if (nw >= 254) { S.err = ZE_CORRUPTION; return; }
+        u64 e2 = wt[s2];
+        S.weights[nw++] = (u8)e2;
+        s2 = (u32)(e2 >> 48) + br.read((int)((e2 >> 40) & 0xFF));
+        if (br.pos < 0) { S.weights[nw++] = (u8)wt[s1]; break; }
+      }
+    }
+    u32 total = 0;
+    for (u32 i = 0; i < nw; i++) { u32 w = S.weights[i]; if (w > 11) { S.err = ZE_CORRUPTION; return; } total += (1u << w) >> 1; }
+    if (total == 0) { S.err = ZE_CORRUPTION; return; }
+    u32 maxBits = hb32(total) + 1;
+    if (maxBits > 11) { S.err = ZE_CORRUPTION; return; }
+    u32 rest = (1u << maxBits) - total;
+    if (rest == 0 || (rest & (rest - 1))) { S.err = ZE_CORRUPTION; return; }
+    S.weights[nw] = (u8)(hb32(rest) + 1);
+    S.hufNSym = nw + 1; S.hufMaxBits = maxBits;
+    // start cell of each weight class (cells ordered by weight ascending)
+    u32 cnt[13];
+    for (u32 w = 0; w <= 12; w++) cnt[w] = 0;
+    for (u32 i = 0; i <= nw; i++) cnt[S.weights[i]]++;
+    u32 acc = 0;
+    for (u32 w = 1; w <= maxBits; w++) { S.rankStart[w] = acc; acc += cnt[w] << (w - 1); }
+    if (acc != (1u << maxBits)) { S.err = ZE_CORRUPTION; return; }
+    S.hufValid = 2;   // 2 = new table to be filled by the workgroup
+    p += used; rem -= used;
+  } else {
+    if (!S.hufValid) { S.err = ZE_DICT_CORRUPTED; return; }
+  }
+  // stream layout
+  u32 base = (u32)(p - src);
+  if (streams == 1) { S.streamOff[0] = base; S.streamLen[0] = rem; }
+  else {
+    if (rem < 10) { S.err = ZE_CORRUPTION; return; }
+    u32 s1 = ld16(p), s2 = ld16(p + 2), s3 = ld16(p + 4);
+    if (6 + s1 + s2 + s3 > rem) { S.err = ZE_CORRUPTION; return; }
+    u32 seg = (regen + 3) / 4;
+    if (seg * 3 > regen) { S.err = ZE_CORRUPTION; return; }
+    S.streamOff[0] = base + 6; S.streamLen[0] = s1;
+    S.streamOff[1] = base + 6 + s1; S.streamLen[1] = s2;
+    S.streamOff[2] = base + 6 + s1 + s2; S.streamLen[2] = s3;
+    S.streamOff[3] = base + 6 + s1 + s2 + s3; S.streamLen[3] = rem - 6 - s1 - s2 - s3;
+  }
+}
+
+// sequences section header (nbSeq, modes, table descriptions -> S.norm per table is consumed immediately
+// by the workgroup, so this only parses nbSeq + modes; tables are parsed one at a time). thread 0.
+__device__ void parse_seq_header(DecShared& S, const u8* p, u32 rem) {
+  if (rem < 1) { S.err = ZE_SRCSIZE_WRONG; return; }
+  u32 nb = p[0], used;
+  if (nb == 0) { used = 1; if (rem != 1) { S.err = ZE_CORRUPTION; return; } }
+  else if (nb < 128) used = 1;
+  else if (nb < 255) { if (rem < 2) { S.err = ZE_SRCSIZE_WRONG; return; } nb = ((nb - 128) << 8) + p[1]; used = 2; }
+  else { if (rem < 3) { S.err = ZE_SRCSIZE_WRONG; return; } nb = (u32)p[1] + ((u32)p[2] << 8) + 0x7F00; used = 3; }
+  S.nbSeq = nb;
+  if (nb) {
+    if (rem < used + 1) { S.err = ZE_SRCSIZE_WRONG; return; }
+    S.seqModes = p[used]; used++;
+    if (S.seqModes & 3) { S.err = ZE_CORRUPTION; return; }
+  }
+  S.seqPos += used;
+}
+
+// one LL/ML/OF table: thread 0 parses (fills S.norm + logs), then wave 0 builds. returns via S fields.
+// kind 0 LL, 1 ML, 2 OF
+__device__ void seq_table_parse(DecShared& S, int kind, u32 mode, const u8* p, u32 rem, u32* tlOut, u32* msOut, u32* usedOut, const u8* lim) {
+  const u32 maxSymK = kind == 0 ? 35 : kind == 1 ? 52 : 31;
+  const u32 maxALK = kind == 2 ? 8 : 9;
+  *usedOut = 0;
+  if (mode == 0) {
+    u32 ms = kind == 0 ? 35 : kind == 1 ? 52 : 28;
+    for (u32 s = 0; s <= ms; s++) S.norm[s] = kind == 0 ? c_ll_defnorm[s] : kind == 1 ? c_ml_defnorm[s] : c_of_defnorm[s];
+    *tlOut = kind == 2 ? 5 : 6; *msOut = ms;
+  } else if (mode == 1) {
+    if (rem < 1 || p[0] > maxSymK) { S.err = ZE_CORRUPTION; return; }
+    *tlOut = 0; *msOut = p[0]; *usedOut = 1;
+  } else if (mode == 2) {
+    u32 ms = maxSymK, tl;
+    u32 h = read_ncount(S.norm, &ms, &tl, p, rem, maxALK, lim);
+    if (!h) { S.err = ZE_CORRUPTION; return; }
+    *tlOut = tl; *msOut = ms; *usedOut = h;
+  }
+}
+
+}  // namespace
+
+// =================================================================================================
+extern "C" __global__ void __launch_bounds__(DEC_THREADS)
+zra_decode_frames_kernel(ZraDecodeArgs a) {
+  __shared__ DecShared S;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  u8* const litScratch = a.litScratch + (size_t)blockIdx.x * ZRA_LIT_STRIDE;
+
+  for (;;) {
+    if (tid == 0) S.frame = atomicAdd(a.queue, 1u);
+    __syncthreads();
+    const u32 f = S.frame;
+    __syncthreads();
+    if (f >= a.nFrames) return;
+
+    const u64 so = a.frameOff[(size_t)f * a.offStride], se = a.frameOff[(size_t)f * a.offStride + 1];
+    const u8* const src = a.body + so;
+    const u32 srcSize = (u32)(se - so);
+    const u8* const lim = a.body + a.bodySize;
+    u8* const dst = a.out + a.outOff[f];
+    const u32 dstCap = a.outCap[f];
+
+    if (tid == 0) {
+      S.err = 0; S.produced = 0; S.hufValid = 0; S.llValid = S.mlValid = S.ofValid = 0;
+      S.rep[0] = 1; S.rep[1] = 4; S.rep[2] = 8; S.blkLast = 0;
+      // ---- frame header (A.1)
+      u32 hs = 0, checksum = 0;
+      if (se < so || se > a.bodySize || srcSize < 5) S.err = ZE_SRCSIZE_WRONG;
+      else if (ld32(src) != 0xFD2FB528u) S.err = ZE_PREFIX_UNKNOWN;
+      else {
+        u32 fhd = src[4], did = fhd & 3, ss = (fhd >> 5) & 1, fcs = fhd >> 6;
+        u32 didSize = did == 3 ? 4 : did;
+        u32 fcsSize = fcs == 0 ? ss : fcs == 1 ? 2 : fcs == 2 ? 4 : 8;
+        hs = 5 + !ss + didSize + fcsSize;
+        if (srcSize < hs) S.err = ZE_SRCSIZE_WRONG;
+        else if (fhd & 8) S.err = ZE_FRAMEPARAM_UNSUPPORTED;
+        else if (!ss) {
+          u32 b = src[5], wl = 10 + (b >> 3);
+          if (wl > 31) S.err = ZE_FRAMEPARAM_UNSUPPORTED;
+          else if (((1ull << wl) + ((1ull << wl) >> 3) * (b & 7)) > (1ull << 27) + 1) S.err = ZE_WINDOW_TOO_LARGE;
+        }
+        checksum = (fhd >> 2) & 1;
+      }
+      S.blkPos = hs;
+      a.frameMeta[2 * (size_t)f] = checksum;   // [2f] = has checksum, [2f+1] = stored checksum (set at frame end)
+    }
+    __syncthreads();
+
+    // ------------------------------------------------------------------ block loop
+    while (!S.err && !S.blkLast) {
+      if (tid == 0) {
+        u32 pos = S.blkPos;
+        if (srcSize - pos < 3) S.err = ZE_SRCSIZE_WRONG;
+        else {
+          u32 bh = ld24(src + pos);
+          S.blkLast = bh & 1; S.blkType = (bh >> 1) & 3; S.blkSize = bh >> 3;
+          pos += 3;
+          u32 payload = S.blkType == 1 ? 1 : S.blkSize;
+          if (S.blkType == 3) S.err = ZE_CORRUPTION;
+          else if (payload > srcSize - pos) S.err = ZE_SRCSIZE_WRONG;
+          else if (S.blkType == 2 && S.blkSize > BLOCK_MAX) S.err = ZE_CORRUPTION;
+          else if (S.blkType != 2 && S.blkSize > dstCap - S.produced) S.err = ZE_DSTSIZE_TOOSMALL;
+          S.blkPos = pos;
+        }
+      }
+      __syncthreads();
+      if (S.err) break;
+      const u32 btype = S.blkType, bsize = S.blkSize, bpos = S.blkPos;
+      u8* const out = dst + S.produced;          // this block's output start
+      const u32 outCap = dstCap - S.produced;
+
+      if (btype == 0) {
+        copy_bytes(out, src + bpos, bsize, tid, DEC_THREADS);
+        __syncthreads();
+        if (tid == 0) { S.produced += bsize; S.blkPos = bpos + bsize; }
+        __syncthreads();
+        continue;
+      }
+      if (btype == 1) {
+        fill_bytes(out, src[bpos], bsize, tid, DEC_THREADS);
+        __syncthreads();
+        if (tid == 0) { S.produced += bsize; S.blkPos = bpos + 1; }
+        __syncthreads();
+        continue;
+      }
+
+      // ------------------------------------------------------------ compressed block
+      const u8* const blk = src + bpos;
+      if (tid == 0) {
+        S.litStreams = 1; S.litRle = 0;
+        parse_literals_header(S, blk, bsize, lim);
+        if (!S.err) {
+          S.seqPos = S.litHdr + S.litComp;
+          parse_seq_header(S, blk + S.seqPos, bsize - S.seqPos);
+        }
+      }
+      __syncthreads();
+      if (S.err) break;
+
+      // ---- Huffman decode table fill (all threads): cells ordered by weight, then symbol
+      if (S.litType == 2 && S.hufValid == 2) {
+        const u32 nSym = S.hufNSym, maxBits = S.hufMaxBits;
+        // each thread owns one symbol: its start = rankStart[w] + (#earlier symbols of same weight) << (w-1)
+        for (u32 s = tid; s < nSym; s += DEC_THREADS) {
+          u32 w = S.weights[s];
+          if (w == 0) continue;
+          u32 before = 0;
+          for (u32 t = 0; t < s; t++) before += (S.weights[t] == w);
+          u32 len = 1u << (w - 1), start = S.rankStart[w] + before * len;
+          u16 e = (u16)(s | ((maxBits + 1 - w) << 8));
+          for (u32 c = 0; c < len; c++) S.huf[start + c] = e;
+        }
+      }
+      // ---- sequence decode tables: thread 0 parses each description, wave 0 builds it
+      const u32 nbSeq = S.nbSeq;
+      if (nbSeq) {
+        for (int kind = 0; kind < 3; kind++) {
+          // wire order is LL, OF, ML
+          const int k = kind == 0 ? 0 : kind == 1 ? 2 : 1;
+          const u32 mode = k == 0 ? (S.seqModes >> 6) : k == 2 ? ((S.seqModes >> 4) & 3) : ((S.seqModes >> 2) & 3);
+          __shared__ u32 tl, ms, used;
+          if (tid == 0) {
+            tl = ms = used = 0;
+            seq_table_parse(S, k, mode, blk + S.seqPos, bsize - S.seqPos, &tl, &ms, &used, lim);
+            S.seqPos += used;
+            if (mode == 3) { u32 v = k == 0 ? S.llValid : k == 1 ? S.mlValid : S.ofValid; if (!v) S.err = ZE_CORRUPTION; }
+          }
+          __syncthreads();
+          if (S.err) break;
+          u64* table = k == 0 ? S.llT : k == 1 ? S.mlT : S.ofT;
+          if (mode == 1) {
+            if (tid == 0) {
+              u32 s = ms;
+              table[0] = k == 0 ? mk_seqsym(c_ll_base[s], c_ll_bits[s], 0, 0) : k == 1 ? mk_seqsym(c_ml_base[s], c_ml_bits[s], 0, 0) : mk_seqsym(1u << s, s, 0, 0);
+            }
+          } else if (mode != 3 && wave == 0) {
+            build_fse_dtable(table, S.norm, ms, tl, k, S.spread, lane);
+          }
+          if (tid == 0 && mode != 3) {
+            if (k == 0) { S.llLog = tl; S.llValid = 1; } else if (k == 1) { S.mlLog = tl; S.mlValid = 1; } else { S.ofLog = tl; S.ofValid = 1; }
+          }
+          __syncthreads();
+        }
+        if (S.err) break;
+      }
+      __syncthreads();
+
+      // ---- literals: raw -> point into the source; RLE -> fill scratch; Huffman -> 4 lanes of wave 1
+      const u32 litType = S.litType, regen = S.litRegen;
+      const u8* lit = litScratch;
+      if (litType == 0) lit = blk + S.litHdr;
+      else if (litType == 1) fill_bytes(litScratch, (u8)S.litRle, regen, tid, DEC_THREADS);
+
+      if (tid == 0) {
+        S.decoded = 0; S.outBase = 0; S.litBase = 0; S.chunkN[0] = S.chunkN[1] = S.chunkN[2] = 0;
+        if (S.hufValid == 2) S.hufValid = 1;
+      }
+
+      // sequence bitstream init (wave 0 lane 0 keeps the reader in registers across chunks)
+      BitR br; br.base = blk; br.lim = lim; br.pos = 0; br.wlo = 0; br.w = 0;
+      u32 sLL = 0, sML = 0, sOF = 0;
+      u32 rep0 = S.rep[0], rep1 = S.rep[1], rep2 = S.rep[2];
+      if (tid == 0 && nbSeq) {
+        if (br.init(blk + S.seqPos, bsize - S.seqPos, lim)) S.err = ZE_CORRUPTION;
+        else {
+          sLL = br.read((int)S.llLog); sOF = br.read((int)S.ofLog); sML = br.read((int)S.mlLog);
+          if (br.pos < 0) S.err = ZE_CORRUPTION;
+        }
+      }
+      __syncthreads();
+      if (S.err) break;
+
+      // ---- pipeline over chunks. iteration t: wave0 decodes chunk t, waves 2-3 scan+copy literals of
+      //      chunk t-1, wave 1 copies matches of chunk t-2. (+ Huffman literal decode before chunk 0's literals)
+      const u32 nChunks = (nbSeq + CHUNK - 1) / CHUNK;
+      const bool hufLits = litType >= 2;
+      for (u32 t = 0; t < nChunks + 2 || (t == 0); t++) {
+        // -------- stage A: wave 0 lane 0 — FSE sequence decode of chunk t
+        if (wave == 0) {
+          if (lane == 0 && t < nChunks) {
+            const int slot = t % 3;
+            const u32 first = t * CHUNK, cnt = min((u32)CHUNK, nbSeq - first);
+            u32 bad = 0;
+            for (u32 i = 0; i < cnt; i++) {
+              const u64 eL = S.llT[sLL], eM = S.mlT[sML], eO = S.ofT[sOF];
+              const u32 ofBits = (u32)(eO >> 32) & 0xFF, mlBits = (u32)(eM >> 32) & 0xFF, llBits = (u32)(eL >> 32) & 0xFF;
+              if (ofBits > 31) { bad = 1; break; }
+              u32 offVal = (u32)eO + br.read((int)ofBits);
+              br.ensure((int)(mlBits + llBits));
+              u32 ml = (u32)eM + (mlBits ? br.peek((int)mlBits) : 0); br.skip((int)mlBits);
+              u32 ll = (u32)eL + (llBits ? br.peek((int)llBits) : 0); br.skip((int)llBits);
+              if (first + i + 1 < nbSeq) {
+                const int nL = (int)((eL >> 40) & 0xFF), nM = (int)((eM >> 40) & 0xFF), nO = (int)((eO >> 40) & 0xFF);
+                br.ensure(nL + nM + nO);
+                sLL = (u32)(eL >> 48) + (nL ? br.peek(nL) : 0); br.skip(nL);
+                sML = (u32)(eM >> 48) + (nM ? br.peek(nM) : 0); br.skip(nM);
+                sOF = (u32)(eO >> 48) + (nO ? br.peek(nO) : 0); br.skip(nO);
+              }
+              if (br.pos < 0) { bad = 1; break; }
+              // repcode resolution (A.3)
+              u32 off;
+              if (offVal > 3) { off = offVal - 3; rep2 = rep1; rep1 = rep0; rep0 = off; }
+              else {
+                u32 idx = offVal + (ll == 0);
+                if (idx == 1) off = rep0;
+                else {
+                  off = idx == 2 ? rep1 : idx == 3 ? rep2 : rep0 - 1;
+                  if (off == 0) { bad = 1; break; }
+                  if (idx != 2) rep2 = rep1;
+                  rep1 = rep0; rep0 = off;
+                }
+              }
+              S.seqLL[slot][i] = ll; S.seqML[slot][i] = ml; S.seqOF[slot][i] = off;
+            }
+            if (!bad && first + cnt == nbSeq && br.pos != 0) bad = 1;
+            if (bad) S.err = ZE_CORRUPTION;
+            S.chunkN[slot] = cnt;
+          }
+        }
+        // -------- Huffman literal streams: wave 1 lanes 0..3, during iteration 0 only
+        else if (wave == 1 && t == 0 && hufLits) {
+          const u32 nStreams = S.litStreams;
+          if ((u32)lane < nStreams) {
+            const u32 seg = nStreams == 1 ? regen : (regen + 3) / 4;
+            const u32 myLen = nStreams == 1 ? regen : (lane < 3 ? seg : regen - 3 * seg);
+            u8* o = litScratch + (size_t)lane * seg;
+            BitR hb;
+            bool bad = hb.init(blk + S.streamOff[lane], S.streamLen[lane], lim) != 0;
+            if (!bad) {
+              const int mb = (int)S.hufMaxBits;
+              u32 i = 0;
+              // 4 symbols per window reload (4*11 = 44 <= 56 guaranteed bits)
+              for (; i + 4 <= myLen; i += 4) {
+                hb.ensure(4 * mb);
+                u32 packed = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                  // peek may straddle below bit 0 only in the last symbols; ensure() handles zeros
+                  u32 e = S.huf[hb.peek(mb)];
+                  packed |= (e & 0xFF) << (8 * k);
+                  hb.skip((int)(e >> 8));
+                }
+                st32(o + i, packed);
+              }
+              for (; i < myLen; i++) {
+                hb.ensure(mb);
+                u32 e = S.huf[hb.peek(mb)];
+                o[i] = (u8)e;
+                hb.skip((int)(e >> 8));
+              }
+              if (hb.pos != 0) bad = true;
+            }
+            if (bad) S.err = ZE_CORRUPTION;
+          }
+        }
+        // -------- stage C: wave 1 — matches of chunk t-2 (dependency order; 64 lanes per copy)
+        if (wave == 1 && t >= 2 && t - 2 < nChunks) {
+          const int slot = (t - 2) % 3;
+          const u32 cnt = S.chunkN[slot];
+          for (u32 i = 0; i < cnt; i++) {
+            const u32 ml = S.seqML[slot][i], off = S.seqOF[slot][i];
+            const u32 d = S.seqOut[slot][i] + S.seqLL[slot][i];
+            if (d > outCap || off > S.produced + d || ml > outCap - d) { if (lane == 0) S.err = (d <= outCap && off > S.produced + d) ? ZE_CORRUPTION : ZE_DSTSIZE_TOOSMALL; break; }
+            u8* dp = out + d; const u8* sp = dp - off;
+            if (off >= ml) { for (u32 k = lane; k < ml; k += WAVE) dp[k] = sp[k]; }
+            else { for (u32 k = lane; k < ml; k += WAVE) dp[k] = sp[k % off]; }
+            // later sequences may read what this one wrote
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+          }
+        }
+        // -------- stage B: waves 2,3 — scan + literal copies of chunk t-1
+        if (wave >= 2 && t >= 1 && t - 1 < nChunks) {
+          const int slot = (t - 1) % 3;
+          const u32 cnt = S.chunkN[slot];
+          const int t2 = tid - 128;                      // 0..127
+          // exclusive scan of (ll+ml) and ll over the chunk: 4 sequences per thread, then wave scans
+          u32 llv[4], tot[4], sLLsum = 0, sTot = 0;
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            const u32 i = (u32)t2 * 4 + k;
+            llv[k] = i < cnt ? S.seqLL[slot][i] : 0;
+            tot[k] = i < cnt ? llv[k] + S.seqML[slot][i] : 0;
+            sLLsum += llv[k]; sTot += tot[k];
+          }
+          u32 incL = wave_incl_scan(sLLsum), incT = wave_incl_scan(sTot);
+          // a workgroup barrier here would involve waves 0/1 mid-stage, so wave 3 re-derives wave 2's total itself
+          u32 baseL = S.litBase, baseT = S.outBase;
+          if (wave == 3) {
+            // recompute the total of the first 256 sequences (wave 2's share)
+            u32 aL = 0, aT = 0;
+            for (u32 i = lane; i < min(cnt, 256u); i += WAVE) { aL += S.seqLL[slot][i]; aT += S.seqLL[slot][i] + S.seqML[slot][i]; }
+            baseL += wave_sum(aL); baseT += wave_sum(aT);
+          }
+          u32 exL = baseL + incL - sLLsum, exT = baseT + incT - sTot;
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            const u32 i = (u32)t2 * 4 + k;
+            if (i < cnt) {
+              S.seqOut[slot][i] = exT; S.seqLit[slot][i] = exL;
+              const u32 ll = llv[k];
+              if (ll) {
+                if (exL > regen || ll > regen - exL) S.err = ZE_CORRUPTION;
+                else if (exT > outCap || ll > outCap - exT) S.err = ZE_DSTSIZE_TOOSMALL;
+                else { const u8* lp = lit + exL; u8* op = out + exT; for (u32 b = 0; b < ll; b++) op[b] = lp[b]; }
+              }
+              exT += tot[k]; exL += llv[k];
+            }
+          }
+        }
+        __syncthreads();
+        // advance running bases after stage B of chunk t-1 (thread 0; totals recomputed cheaply by wave 0 is avoided:
+        // the last thread of the scan wrote nothing, so recompute here from the chunk in LDS)
+        if (t >= 1 && t - 1 < nChunks) {
+          const int slot = (t - 1) % 3;
+          const u32 cnt = S.chunkN[slot];
+          if (wave == 0) {
+            u32 aL = 0, aT = 0;
+            for (u32 i = lane; i < cnt; i += WAVE) { aL += S.seqLL[slot][i]; aT += S.seqLL[slot][i] + S.seqML[slot][i]; }
+            aL = wave_sum(aL); aT = wave_sum(aT);
+            if (lane == 0) { S.litBase += aL; S.outBase += aT; }
+          }
+        }
+        __syncthreads();
+        if (S.err) break;
+        if (nChunks == 0) break;
+      }
+      if (S.err) break;
+
+      // ---- block tail: remaining literals
+      {
+        const u32 lb = S.litBase, ob = S.outBase;
+        if (lb > regen) { if (tid == 0) S.err = ZE_CORRUPTION; }
+        else if (ob > outCap || regen - lb > outCap - ob) { if (tid == 0) S.err = ZE_DSTSIZE_TOOSMALL; }
+        else copy_bytes(out + ob, lit + lb, regen - lb, tid, DEC_THREADS);
+        __syncthreads();
+        if (tid == 0 && !S.err) {
+          S.produced += ob + (regen - lb);
+          S.blkPos = bpos + bsize;
+          S.rep[0] = rep0; S.rep[1] = rep1; S.rep[2] = rep2;
+        }
+      }
+      __syncthreads();
+    }
+
+    // ------------------------------------------------------------------ frame end
+    if (tid == 0) {
+      u32 err = S.err;
+      if (!err) {
+        u32 pos = S.blkPos;
+        if (a.frameMeta[2 * (size_t)f]) {
+          if (srcSize - pos < 4) err = ZE_CHECKSUM_WRONG;
+          else { a.frameMeta[2 * (size_t)f + 1] = ld32(src + pos); pos += 4; }
+        }
+        if (!err && pos != srcSize) err = ZE_SRCSIZE_WRONG;          // seek table and frame walk disagree
+        if (!err && S.produced != a.outExpect[f]) err = ZE_CORRUPTION; // frame does not regenerate frameSize bytes
+      }
+      a.status[f] = err;
+      a.produced[f] = S.produced;
+    }
+    __syncthreads();
+  }
+}

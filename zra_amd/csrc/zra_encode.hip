@@ -1,0 +1,278 @@
+// zra_amd — host side of the ENCODE path: zstd 1.4.9 parameter selection, scratch layout in HBM, the
+// block-round driver (A.4.2) over batches of frames, and the seek-table build (device scan + gather).
+// Replaces the loop body of the reference's CompressBuffer / Compressor::Compress (zra.cpp:216-225, 329-338).
+#include "zra_engine.h"
+#include "zra_dev.h"
+#include "zra_format.h"
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+extern "C" __global__ void zra_mf_kernel(ZraEncArgs a, uint32_t block);
+extern "C" __global__ void zra_entropy_kernel(ZraEncArgs a, uint32_t block);
+
+using namespace zra_dev;
+
+namespace {
+
+// ---- content checksum of every frame of a batch: 4 lanes per frame
+__global__ void zra_content_ck_kernel(const u8* in, u64 inSize, u32 frameSize, u32 firstFrame, u32 nFrames, u32* ck) {
+  const u32 gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const u32 f = gid >> 2; const int j = gid & 3;
+  const bool active = f < nFrames;
+  const u64 start = active ? (u64)(firstFrame + f) * frameSize : 0;
+  const u32 n = active ? (u32)min((u64)frameSize, inSize - start) : 0;
+  const u64 h = zra_xxh64_quad(in + start, n, j);
+  if (active && j == 0) ck[f] = (u32)h;
+}
+
+// ---- exclusive scan of the batch's frame sizes (single workgroup, 1024 threads, chunked) -> offsets + total
+__global__ void __launch_bounds__(1024) zra_scan_sizes_kernel(const u64* sizes, u32 n, u64* offsets, u64* total) {
+  __shared__ u64 wsum[16];
+  __shared__ u64 carry;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) carry = 0;
+  __syncthreads();
+  for (u32 base = 0; base < n; base += 1024) {
+    const u32 i = base + tid;
+    u64 v = i < n ? sizes[i] : 0, inc = v;
+    for (int d = 1; d < 64; d <<= 1) { u64 t = __shfl_up(inc, d, 64); if (lane >= d) inc += t; }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    u64 wbase = 0, tot = 0;
+    for (int w = 0; w < 16; w++) { if (w < wave) wbase += wsum[w]; tot += wsum[w]; }
+    if (i < n) offsets[i] = carry + wbase + inc - v;
+    __syncthreads();
+    if (tid == 0) carry += tot;
+    __syncthreads();
+  }
+  if (tid == 0) *total = carry;
+}
+
+// ---- gather: frame f of the batch moves from its slot to body + bodyBase + offsets[f] (one workgroup per frame);
+//      optionally writes the 5-byte seek-table entry and/or the u64 size
+__global__ void zra_gather_frames_kernel(const u8* slots, u64 slotStride, const u64* sizes, const u64* offsets, u8* body, u64 bodyBase,
+                                         u8* entries, u32 firstFrame, u64* sizesOut) {
+  const u32 f = blockIdx.x;
+  const u64 n = sizes[f], off = bodyBase + offsets[f];
+  const u8* s = slots + (size_t)f * slotStride; u8* d = body + off;
+  // slots are 16-byte aligned; destination is arbitrary: align on the source, let the stores be unaligned
+  const u64 n16 = n >> 4;
+  for (u64 i = threadIdx.x; i < n16; i += blockDim.x) {
+    const uint4 v = ((const uint4*)s)[i];
+    st64(d + 16 * i, (u64)v.x | ((u64)v.y << 32)); st64(d + 16 * i + 8, (u64)v.z | ((u64)v.w << 32));
+  }
+  for (u64 i = (n16 << 4) + threadIdx.x; i < n; i += blockDim.x) d[i] = s[i];
+  if (threadIdx.x == 0) {
+    if (entries) { u8* e = entries + (size_t)(firstFrame + f) * 5; st32(e, (u32)off); e[4] = (u8)(off >> 32); }
+    if (sizesOut) sizesOut[firstFrame + f] = n;
+  }
+}
+
+// ---- zstd 1.4.9 parameter rows (dumped there from the dependency): [wlog clog hlog slog mml tlen strat]
+const uint8_t kCP16[13][7] = {{14,14,15,2,4,0,2},{14,14,15,1,5,0,1},{14,14,15,1,4,0,1},{14,14,15,2,4,0,2},{14,14,14,4,4,2,3},{14,14,14,3,4,4,4},
+  {14,14,14,4,4,8,5},{14,14,14,6,4,8,5},{14,14,14,8,4,8,5},{14,15,14,5,4,8,6},{14,15,14,9,4,8,6},{14,15,14,3,4,12,7},{14,15,14,4,3,24,7}};
+const uint8_t kCP128[13][7] = {{17,15,16,2,5,0,2},{17,12,13,1,6,0,1},{17,13,15,1,5,0,1},{17,15,16,2,5,0,2},{17,17,17,2,4,0,2},{17,16,17,3,4,2,3},
+  {17,17,17,3,4,4,4},{17,17,17,3,4,8,5},{17,17,17,4,4,8,5},{17,17,17,5,4,8,5},{17,17,17,6,4,8,5},{17,17,17,5,4,8,6},{17,18,17,7,4,12,6}};
+const uint8_t kCP256[13][7] = {{18,16,16,1,4,0,2},{18,13,14,1,6,0,1},{18,14,14,1,5,0,2},{18,16,16,1,4,0,2},{18,16,17,2,5,2,3},{18,18,18,3,5,2,3},
+  {18,18,19,3,5,4,4},{18,18,19,4,4,4,4},{18,18,19,4,4,8,5},{18,18,19,5,4,8,5},{18,18,19,6,4,8,5},{18,18,19,5,4,12,6},{18,19,19,7,4,12,6}};
+
+inline uint32_t hbit(uint32_t x) { return 31u - (uint32_t)__builtin_clz(x); }
+
+// returns false when (level, size) needs a strategy this engine does not implement (btlazy2 and up, negative levels, > 256 KiB)
+bool get_params(int level, size_t S, ZraEncParams* p) {
+  if (level == 0) level = 3;
+  if (level < 1 || level > 12 || S > (256u << 10) || S == 0) return false;
+  const uint8_t* r = S <= (16u << 10) ? kCP16[level] : S <= (128u << 10) ? kCP128[level] : kCP256[level];
+  p->windowLog = r[0]; p->chainLog = r[1]; p->hashLog = r[2]; p->searchLog = r[3]; p->minMatch = r[4]; p->targetLength = r[5]; p->strategy = r[6];
+  const uint32_t srcLog = S < 64 ? 6 : hbit((uint32_t)S - 1) + 1;
+  if (p->windowLog > srcLog) p->windowLog = srcLog;
+  if (p->hashLog > p->windowLog + 1) p->hashLog = p->windowLog + 1;
+  const uint32_t cycleLog = p->chainLog - (p->strategy >= 6);
+  if (cycleLog > p->windowLog) p->chainLog -= cycleLog - p->windowLog;
+  if (p->windowLog < 10) p->windowLog = 10;
+  p->blockSize = std::min<uint32_t>(128u << 10, 1u << p->windowLog);
+  return p->strategy <= 5 && !(p->strategy == 1 && p->targetLength);
+}
+
+}  // namespace
+
+namespace zra_eng {
+
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return zerr(1); } while (0)
+
+Status Engine::compress_frames(const uint8_t* dIn, size_t inSize, uint8_t* dBody, uint64_t* dSizes, size_t* bodySize,
+                               int level, uint32_t frameSize, bool checksum) {
+  return compress_impl(dIn, inSize, dBody, 0, nullptr, dSizes, bodySize, level, frameSize, checksum);
+}
+
+// Shared driver. Frames are gathered to dBody + bodyBase0 + running offset; seek-table entries (5 B, offsets relative to
+// bodyBase0) are written to dEntries when non-null; u64 sizes to dSizes when non-null.
+Status Engine::compress_impl(const uint8_t* dIn, size_t inSize, uint8_t* dBody, uint64_t bodyBase0, uint8_t* dEntries, uint64_t* dSizes,
+                             size_t* bodySize, int level, uint32_t frameSize, bool checksum) {
+  HIPCHK(hipSetDevice(device_));
+  *bodySize = 0;
+  if (inSize == 0) return ok();
+  if (frameSize == 0) return zerr(42);
+  const uint64_t nFramesTotal = (inSize + frameSize - 1) / frameSize;
+  const size_t tailSize = inSize % frameSize;
+  ZraEncParams full{}, tail{};
+  if (nFramesTotal > 1 || !tailSize) { if (!get_params(level, frameSize, &full)) return zerr(40); } // parameter_unsupported: no CPU fallback
+  if (tailSize) { if (!get_params(level, tailSize, &tail)) return zerr(40); }
+  if (!(nFramesTotal > 1 || !tailSize)) full = tail;
+  if (!tailSize) tail = full;
+
+  const uint64_t tableWords = std::max((1ull << full.hashLog) + (1ull << full.chainLog), (1ull << tail.hashLog) + (1ull << tail.chainLog));
+  const uint32_t maxBlock = std::max(full.blockSize, tail.blockSize);
+  const uint64_t seqStride = maxBlock / 4 + 16;
+  const uint64_t litStride = ((uint64_t)maxBlock + 64 + 15) & ~15ull;
+  const uint32_t maxBlocksPerFrame = (std::min<uint64_t>(frameSize, inSize) + std::min(full.blockSize, tail.blockSize) - 1) / std::min(full.blockSize, tail.blockSize);
+  const uint64_t slotStride = (zra_fmt::compress_bound(frameSize) + 1024 + 4 * (uint64_t)maxBlocksPerFrame + 15) & ~15ull;
+  const uint64_t perFrame = tableWords * 4 + seqStride * 8 + litStride + slotStride + sizeof(ZraEncFrameState) + 64;
+  const uint64_t budget = 12ull << 30;
+  const uint32_t B = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>({nFramesTotal, budget / perFrame, 16384ull}));
+  if (!encTables_.reserve(B * tableWords * 4) || !encSeqs_.reserve(B * seqStride * 8) || !encLits_.reserve(B * litStride) ||
+      !encSlots_.reserve(B * slotStride) || !encMisc_.reserve(B * (sizeof(ZraEncFrameState) + sizeof(ZraEncBlockOut))) ||
+      !encCk_.reserve((size_t)B * 4) || !encSizes_.reserve((size_t)B * 16) || !encScan_.reserve(64))
+    return zerr(64);
+
+  ZraEncArgs a{};
+  a.in = dIn; a.inSize = inSize; a.frameSize = frameSize; a.checksum = checksum ? 1 : 0;
+  a.full = full; a.tail = tail;
+  a.tables = encTables_.as<uint32_t>(); a.tableStride = tableWords;
+  a.seqs = encSeqs_.as<uint64_t>(); a.seqStride = seqStride;
+  a.lits = encLits_.as<uint8_t>(); a.litStride = litStride;
+  a.slots = encSlots_.as<uint8_t>(); a.slotStride = slotStride;
+  a.state = encMisc_.as<ZraEncFrameState>();
+  a.blockOut = (ZraEncBlockOut*)(encMisc_.as<uint8_t>() + (size_t)B * sizeof(ZraEncFrameState));
+  a.contentCk = encCk_.as<uint32_t>();
+  a.sizes = encSizes_.as<uint64_t>();
+  uint64_t* dOffsets = encSizes_.as<uint64_t>() + B;
+  uint64_t* dTotal = encScan_.as<uint64_t>();
+
+  uint64_t bodyOff = 0;
+  double kernelMs = 0;
+  for (uint64_t f0 = 0; f0 < nFramesTotal; f0 += B) {
+    const uint32_t nb = (uint32_t)std::min<uint64_t>(B, nFramesTotal - f0);
+    a.firstFrame = (uint32_t)f0; a.nFrames = nb;
+    if (checksum)
+      hipLaunchKernelGGL(zra_content_ck_kernel, dim3((nb * 4 + 255) / 256), dim3(256), 0, stream_, dIn, (u64)inSize, frameSize, (u32)f0, nb, a.contentCk);
+    // frames of this batch: how many block rounds? (a short last frame may need fewer)
+    const uint64_t firstFrameSize = std::min<uint64_t>(frameSize, inSize - f0 * frameSize);
+    const ZraEncParams& P0 = firstFrameSize == frameSize ? full : tail;
+    const uint32_t rounds = (uint32_t)((firstFrameSize + P0.blockSize - 1) / P0.blockSize);
+    HIPCHK(hipEventRecord(ev0_, stream_));
+    for (uint32_t blk = 0; blk < rounds; blk++) {
+      hipLaunchKernelGGL(zra_mf_kernel, dim3(nb), dim3(64), 0, stream_, a, blk);
+      hipLaunchKernelGGL(zra_entropy_kernel, dim3(nb), dim3(256), 0, stream_, a, blk);
+    }
+    HIPCHK(hipEventRecord(ev1_, stream_));
+    hipLaunchKernelGGL(zra_scan_sizes_kernel, dim3(1), dim3(1024), 0, stream_, a.sizes, nb, dOffsets, dTotal);
+    hipLaunchKernelGGL(zra_gather_frames_kernel, dim3(nb), dim3(256), 0, stream_, a.slots, slotStride, a.sizes, dOffsets, dBody,
+                       bodyBase0 + bodyOff, dEntries ? dEntries : nullptr, (u32)f0, dSizes);
+    uint64_t total = 0;
+    HIPCHK(hipMemcpyAsync(&total, dTotal, 8, hipMemcpyDeviceToHost, stream_));
+    HIPCHK(hipStreamSynchronize(stream_));
+    HIPCHK(hipGetLastError());
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, ev0_, ev1_) == hipSuccess) kernelMs += ms;
+    // entries written by the gather kernel hold absolute (bodyBase0-including) offsets; fix-up is avoided by passing
+    // bodyBase0 only through `body` pointer arithmetic below
+    bodyOff += total;
+  }
+  lastKernelMs_ = kernelMs;
+  *bodySize = bodyOff;
+  return ok();
+}
+
+Status Engine::compress_device(const uint8_t* dIn, size_t inSize, uint8_t* dOut, size_t* outSize, int level, uint32_t frameSize, bool checksum) {
+  HIPCHK(hipSetDevice(device_));
+  if (frameSize == 0) return zerr(42);
+  const uint32_t tableSize = zra_fmt::table_size(inSize, frameSize);
+  const size_t headerSize = zra_fmt::kFixedSize + (size_t)tableSize * zra_fmt::kEntrySize;
+  size_t bodySize = 0;
+  // body is gathered straight behind the (not yet written) header; entries are offsets relative to the body start
+  Status s = compress_impl(dIn, inSize, dOut + headerSize, 0, dOut + zra_fmt::kFixedSize, nullptr, &bodySize, level, frameSize, checksum);
+  if (s.zra) return s;
+  if (headerSize + bodySize >= zra_fmt::kMaxCompressedSize) return {kCompressedTooLarge, 0};   // zra.cpp:227
+  // end sentinel + CRC-32 on the host (the table is 5 B/frame: 1.3 MiB at 16 GiB / 64 KiB)
+  std::vector<uint8_t> hdr(headerSize);
+  if (tableSize > 1)
+    HIPCHK(hipMemcpyAsync(hdr.data() + zra_fmt::kFixedSize, dOut + zra_fmt::kFixedSize, (size_t)(tableSize - 1) * 5, hipMemcpyDeviceToHost, stream_));
+  HIPCHK(hipStreamSynchronize(stream_));
+  zra_fmt::write_fixed(hdr.data(), inSize, tableSize, frameSize, 0);
+  zra_fmt::entry_put(hdr.data() + zra_fmt::kFixedSize + (size_t)(tableSize - 1) * 5, bodySize);
+  zra_fmt::wr32(hdr.data() + 14, zra_fmt::header_hash(hdr.data(), hdr.data() + zra_fmt::kFixedSize));
+  HIPCHK(hipMemcpyAsync(dOut, hdr.data(), zra_fmt::kFixedSize, hipMemcpyHostToDevice, stream_));
+  HIPCHK(hipMemcpyAsync(dOut + zra_fmt::kFixedSize + (size_t)(tableSize - 1) * 5, hdr.data() + zra_fmt::kFixedSize + (size_t)(tableSize - 1) * 5, 5,
+                        hipMemcpyHostToDevice, stream_));
+  HIPCHK(hipStreamSynchronize(stream_));
+  *outSize = headerSize + bodySize;
+  return ok();
+}
+
+// ------------------------------------------------------------------ host-pointer helpers used by the C/C++ API
+Status Engine::compress_host(const uint8_t* hIn, size_t n, uint8_t* hOut, size_t* outSize, int level, uint32_t frameSize, bool checksum) {
+  HIPCHK(hipSetDevice(device_));
+  if (frameSize == 0) return zerr(42);
+  const uint32_t tableSize = zra_fmt::table_size(n, frameSize);
+  const size_t cap = zra_fmt::kFixedSize + (size_t)tableSize * 5 + zra_fmt::compress_bound(frameSize) * (size_t)(tableSize - 1);
+  if (!hostIn_.reserve(n + 64) || !hostOut_.reserve(cap + 64)) return zerr(64);
+  if (n) HIPCHK(hipMemcpyAsync(hostIn_.p, hIn, n, hipMemcpyHostToDevice, stream_));
+  Status s = compress_device(hostIn_.as<uint8_t>(), n, hostOut_.as<uint8_t>(), outSize, level, frameSize, checksum);
+  if (s.zra) return s;
+  HIPCHK(hipMemcpyAsync(hOut, hostOut_.p, *outSize, hipMemcpyDeviceToHost, stream_));
+  HIPCHK(hipStreamSynchronize(stream_));
+  return ok();
+}
+
+Status Engine::compress_frames_host(const uint8_t* hIn, size_t n, uint8_t* hBody, std::vector<uint64_t>& sizes, size_t* bodySize,
+                                    int level, uint32_t frameSize, bool checksum) {
+  HIPCHK(hipSetDevice(device_));
+  const size_t nFrames = (n + frameSize - 1) / frameSize;
+  const size_t cap = zra_fmt::compress_bound(frameSize) * nFrames;
+  if (!hostIn_.reserve(n + 64) || !hostOut_.reserve(cap + nFrames * 8 + 64)) return zerr(64);
+  HIPCHK(hipMemcpyAsync(hostIn_.p, hIn, n, hipMemcpyHostToDevice, stream_));
+  uint64_t* dSizes = (uint64_t*)(hostOut_.as<uint8_t>() + ((cap + 15) & ~(size_t)15));
+  if (!hostOut_.reserve(((cap + 15) & ~(size_t)15) + nFrames * 8 + 64)) return zerr(64);
+  dSizes = (uint64_t*)(hostOut_.as<uint8_t>() + ((cap + 15) & ~(size_t)15));
+  Status s = compress_frames(hostIn_.as<uint8_t>(), n, hostOut_.as<uint8_t>(), dSizes, bodySize, level, frameSize, checksum);
+  if (s.zra) return s;
+  sizes.resize(nFrames);
+  HIPCHK(hipMemcpyAsync(hBody, hostOut_.p, *bodySize, hipMemcpyDeviceToHost, stream_));
+  HIPCHK(hipMemcpyAsync(sizes.data(), dSizes, nFrames * 8, hipMemcpyDeviceToHost, stream_));
+  HIPCHK(hipStreamSynchronize(stream_));
+  return ok();
+}
+
+Status Engine::decode_host(const uint8_t* hSpan, size_t spanSize, const std::vector<uint64_t>& starts, const std::vector<uint64_t>& ends,
+                           uint32_t frameSize, uint64_t total, uint8_t* hOut, size_t skip, size_t size) {
+  HIPCHK(hipSetDevice(device_));
+  const uint32_t nFrames = (uint32_t)starts.size();
+  if (nFrames == 0) return ok();
+  std::vector<uint64_t> se((size_t)nFrames * 2), oo(nFrames);
+  std::vector<uint32_t> ex(nFrames);
+  for (uint32_t i = 0; i < nFrames; i++) {
+    se[2 * (size_t)i] = starts[i]; se[2 * (size_t)i + 1] = ends[i];
+    const uint64_t o = (uint64_t)i * frameSize;
+    oo[i] = o;
+    ex[i] = o >= total ? 0 : (uint32_t)std::min<uint64_t>(frameSize, total - o);
+  }
+  if (!hostIn_.reserve(spanSize + 64) || !hostOut_.reserve((size_t)nFrames * frameSize + 64) || !frameOff_.reserve(se.size() * 8) ||
+      !outOff_.reserve((size_t)nFrames * 8) || !expect_.reserve((size_t)nFrames * 4))
+    return zerr(64);
+  HIPCHK(hipMemcpyAsync(hostIn_.p, hSpan, spanSize, hipMemcpyHostToDevice, stream_));
+  HIPCHK(hipMemcpyAsync(frameOff_.p, se.data(), se.size() * 8, hipMemcpyHostToDevice, stream_));
+  HIPCHK(hipMemcpyAsync(outOff_.p, oo.data(), (size_t)nFrames * 8, hipMemcpyHostToDevice, stream_));
+  HIPCHK(hipMemcpyAsync(expect_.p, ex.data(), (size_t)nFrames * 4, hipMemcpyHostToDevice, stream_));
+  HIPCHK(hipStreamSynchronize(stream_));
+  Status s = decode_jobs(hostIn_.as<uint8_t>(), spanSize, frameOff_.as<uint64_t>(), hostOut_.as<uint8_t>(), outOff_.as<uint64_t>(),
+                         expect_.as<uint32_t>(), nFrames, 2);
+  if (s.zra) return s;
+  if (skip + size > (uint64_t)nFrames * frameSize) return {kOutOfBounds, 0};
+  if (size) HIPCHK(hipMemcpyAsync(hOut, hostOut_.as<uint8_t>() + skip, size, hipMemcpyDeviceToHost, stream_));
+  HIPCHK(hipStreamSynchronize(stream_));
+  return ok();
+}
+
+}  // namespace zra_eng

@@ -1,0 +1,892 @@
+// zra_amd — ENCODE stage 2 for gfx950: entropy coding + block/frame assembly of zstd 1.4.9, bit-exact.
+//
+// One frame per workgroup (256 threads = 4 waves). Everything that is data-parallel runs on all lanes:
+//   * literal gathering + byte histogram (wave prefix-scans for positions, LDS atomics for counts)
+//   * Huffman literal streams: code lengths prefix-scanned across the workgroup, codes OR-ed into an LDS
+//     staging tile (ballot-free, conflict-tolerant LDS atomics), flushed with coalesced stores
+//   * sequence bitstream: the three FSE state chains (inherently serial) run on 3 lanes, then the
+//     state/extra bits of 1024 sequences at a time are prefix-scanned and packed the same way
+// The small serial pieces (Huffman tree, depth limiter, FSE normalisation, table descriptions) run on one
+// lane per table, three tables concurrently on three waves. Tables and staging live in LDS (~45 KiB).
+// Rules restated from SURVEY.md Appendix A.4.2, A.4.4-A.4.8 (validated there against libzstd 1.4.9).
+#include "zra_dev.h"
+#include "zra_kernels.h"
+
+using namespace zra_dev;
+
+namespace {
+
+constexpr int ENT_THREADS = 256;
+constexpr int SEQ_TILE = 1024;     // sequences per packing tile (4 per thread)
+constexpr int SYM_TILE = 4096;     // literal symbols per packing tile (16 per thread)
+constexpr int STAGE_WORDS = 4096;  // 16 KiB LDS bit-staging buffer
+
+__constant__ u8 c_LLcode[64] = {0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,16,17,17,18,18,19,19,20,20,20,20,21,21,21,21,22,22,22,22,22,22,22,22,
+                                23,23,23,23,23,23,23,23,24,24,24,24,24,24,24,24,24,24,24,24,24,24,24,24};
+__constant__ u8 c_MLcode[128] = {0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,17,18,19,20,21,22,23,24,25,26,27,28,29,30,31,32,32,33,33,34,34,35,35,
+                                 36,36,36,36,37,37,37,37,38,38,38,38,38,38,38,38,39,39,39,39,39,39,39,39,40,40,40,40,40,40,40,40,40,40,40,40,40,40,40,40,
+                                 41,41,41,41,41,41,41,41,41,41,41,41,41,41,41,41,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,
+                                 42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42};
+__constant__ u8 c_LLbits[36] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,1,1,1,1,2,2,3,3,4,6,7,8,9,10,11,12,13,14,15,16};
+__constant__ u8 c_MLbits[53] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,1,1,1,1,2,2,3,3,4,4,5,7,8,9,10,11,12,13,14,15,16};
+__constant__ short c_LLdef[36] = {4,3,2,2,2,2,2,2,2,2,2,2,2,1,1,1,2,2,2,2,2,2,2,2,2,3,2,1,1,1,1,1,-1,-1,-1,-1};
+__constant__ short c_MLdef[53] = {1,4,3,2,2,2,2,2,2,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,-1,-1,-1,-1,-1,-1,-1};
+__constant__ short c_OFdef[29] = {1,1,1,1,1,1,2,2,2,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,-1,-1,-1,-1,-1};
+// kInverseProbabilityLog256[i] = floor(-log2(i/256)*256), [0] = 0 (A.4.7 cost model)
+__constant__ u16 c_invProb[256] = {0,2048,1792,1642,1536,1453,1386,1329,1280,1236,1197,1162,1130,1100,1073,1047,1024,1001,980,960,941,923,906,889,874,859,844,830,817,804,791,779,768,756,745,734,724,714,704,694,685,676,667,658,650,642,633,626,618,610,603,595,588,581,574,567,561,554,548,542,535,529,523,517,512,506,500,495,489,484,478,473,468,463,458,453,448,443,438,434,429,424,420,415,411,407,402,398,394,390,386,382,377,373,370,366,362,358,354,350,347,343,339,336,332,329,325,322,318,315,311,308,305,302,298,295,292,289,286,282,279,276,273,270,267,264,261,258,256,253,250,247,244,241,239,236,233,230,228,225,222,220,217,215,212,209,207,204,202,199,197,194,192,190,187,185,182,180,178,175,173,171,168,166,164,162,159,157,155,153,151,149,146,144,142,140,138,136,134,132,130,128,126,123,121,119,117,115,114,112,110,108,106,104,102,100,98,96,94,93,91,89,87,85,83,82,80,78,76,74,73,71,69,67,66,64,62,61,59,57,55,54,52,50,49,47,46,44,42,41,39,37,36,34,33,31,30,28,26,25,23,22,20,19,17,16,14,13,11,10,8,7,5,4,2,1};
+
+__device__ __forceinline__ u32 ll_code(u32 v) { return v > 63 ? hb32(v) + 19 : c_LLcode[v]; }
+__device__ __forceinline__ u32 ml_code(u32 mlBase) { return mlBase > 127 ? hb32(mlBase) + 36 : c_MLcode[mlBase]; }
+__device__ __forceinline__ u32 hb32z(u32 x) { return x ? hb32(x) : 0; }
+
+struct __attribute__((aligned(16))) EncShared {
+  u32 stage[STAGE_WORDS];
+  u32 hist[4][256];
+  u32 cnt[3][64];
+  // Huffman construction (index 0 of node* is the sentinel "huffNode[-1]")
+  u32 nodeCount[514];
+  u16 nodeParent[514];
+  u8 nodeBits[514];
+  u8 nodeByte[256];
+  u8 hNb[256];
+  u16 hVal[256];
+  u8 weights[256];
+  u8 hufHdr[192];
+  // FSE
+  ZraFseCTable ct[3];        // 0 LL, 1 OF, 2 ML (next-block tables)
+  short norm[3][64];
+  u8 spread[3][512];
+  u8 ncount[3][192];
+  u32 ncountSize[3], mode[3], nextRepeat[3], tblErr[3];
+  u8 codes[3][SEQ_TILE];
+  u16 chain[3][SEQ_TILE];
+  u32 finalState[3];
+  u32 wsum[16];
+  u32 longCount;
+  // scalars shared through LDS
+  u32 sc[16];
+};
+
+// ---- workgroup exclusive scan of one u32 per thread; returns exclusive prefix, *total = sum over the workgroup
+__device__ __forceinline__ u32 block_excl_scan(EncShared& S, u32 v, u32* total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  u32 inc = wave_incl_scan(v);
+  __syncthreads();                       // protects wsum reuse between consecutive scans
+  if (lane == 63) S.wsum[wave] = inc;
+  __syncthreads();
+  u32 base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < 4; w++) { u32 s = S.wsum[w]; if (w < wave) base += s; tot += s; }
+  *total = tot;
+  return base + inc - v;
+}
+__device__ __forceinline__ u32 block_sum(EncShared& S, u32 v) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  v = wave_sum(v);
+  __syncthreads();
+  if (lane == 0) S.wsum[8 + wave] = v;
+  __syncthreads();
+  return S.wsum[8] + S.wsum[9] + S.wsum[10] + S.wsum[11];
+}
+__device__ __forceinline__ u32 block_max(EncShared& S, u32 v) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  v = wave_max(v);
+  __syncthreads();
+  if (lane == 0) S.wsum[12 + wave] = v;
+  __syncthreads();
+  return max(max(S.wsum[12], S.wsum[13]), max(S.wsum[14], S.wsum[15]));
+}
+
+// ---- per-lane bit writer into the LDS staging tile (forward LSB-first stream, A.4.5/A.4.7 convention)
+struct LaneBitW {
+  u32* stage; u32 word; u32 n; u64 acc;
+  __device__ __forceinline__ void init(u32* st, u32 startBit) { stage = st; word = startBit >> 5; n = startBit & 31; acc = 0; }
+  __device__ __forceinline__ void add(u32 v, u32 nb) {   // nb <= 32, v already masked to nb bits
+    acc |= (u64)v << n; n += nb;
+    if (n >= 32) { atomicOr(&stage[word], (u32)acc); acc >>= 32; n -= 32; word++; }
+  }
+  __device__ __forceinline__ void finish() { if (n) atomicOr(&stage[word], (u32)acc); }
+};
+
+// flush the first nbytes of the staging tile to dst (cooperative, coalesced dword stores)
+__device__ __forceinline__ void flush_stage(EncShared& S, u8* dst, u32 nbytes) {
+  const u32 nw = nbytes >> 2;
+  for (u32 i = threadIdx.x; i < nw; i += ENT_THREADS) st32(dst + 4 * i, S.stage[i]);
+  const u32 tail = nbytes & 3;
+  if (threadIdx.x < tail) dst[4 * nw + threadIdx.x] = (u8)(S.stage[nw] >> (8 * threadIdx.x));
+}
+
+// =============================================================================== FSE primitives (A.4.6), one lane
+__device__ u32 fse_optimal_tablelog(u32 maxLog, u32 n, u32 maxSym, u32 minus) {
+  u32 maxBitsSrc = hb32z(n - 1) - minus;         // unsigned wrap intended
+  u32 t = maxLog;
+  u32 a = hb32z(n) + 1, b = hb32z(maxSym) + 2;
+  u32 minBits = a < b ? a : b;
+  if (maxBitsSrc < t) t = maxBitsSrc;
+  if (minBits > t) t = minBits;
+  if (t < 5) t = 5;
+  if (t > 12) t = 12;
+  return t;
+}
+
+__device__ int fse_normalize_m2(short* norm, u32 t, const u32* cnt, u32 total, u32 maxSym, short low) {
+  const short NYA = -2;
+  u32 distributed = 0, toDist;
+  u32 lowThr = total >> t, lowOne = (u32)(((u64)total * 3) >> (t + 1));
+  for (u32 s = 0; s <= maxSym; s++) {
+    if (cnt[s] == 0) { norm[s] = 0; continue; }
+    if (cnt[s] <= lowThr) { norm[s] = low; distributed++; total -= cnt[s]; continue; }
+    if (cnt[s] <= lowOne) { norm[s] = 1; distributed++; total -= cnt[s]; continue; }
+    norm[s] = NYA;
+  }
+  toDist = (1u << t) - distributed;
+  if (toDist == 0) return 0;
+  if ((total / toDist) > lowOne) {
+    lowOne = (u32)(((u64)total * 3) / ((u64)toDist * 2));
+    for (u32 s = 0; s <= maxSym; s++)
+      if (norm[s] == NYA && cnt[s] <= lowOne) { norm[s] = 1; distributed++; total -= cnt[s]; }
+    toDist = (1u << t) - distributed;
+  }
+  if (distributed == maxSym + 1) {
+    u32 maxV = 0, maxC = 0;
+    for (u32 s = 0; s <= maxSym; s++) if (cnt[s] > maxC) { maxV = s; maxC = cnt[s]; }
+    norm[maxV] += (short)toDist;
+    return 0;
+  }
+  if (total == 0) {
+    for (u32 s = 0; toDist > 0; s = (s + 1) % (maxSym + 1)) if (norm[s] > 0) { toDist--; norm[s]++; }
+    return 0;
+  }
+  const u64 vLog = 62 - t, mid = (1ULL << (vLog - 1)) - 1;
+  const u64 rStep = ((((u64)1 << vLog) * toDist) + mid) / total;
+  u64 acc = mid;
+  for (u32 s = 0; s <= maxSym; s++) {
+    if (norm[s] == NYA) {
+      u64 end = acc + (u64)cnt[s] * rStep;
+      u32 w = (u32)(end >> vLog) - (u32)(acc >> vLog);
+      if (w < 1) return -1;
+      norm[s] = (short)w;
+      acc = end;
+    }
+  }
+  return 0;
+}
+
+// returns tableLog, 0 for the single-symbol case, <0 on error
+__device__ int fse_normalize(short* norm, u32 t, const u32* cnt, u32 total, u32 maxSym, bool useLowProb) {
+  const u32 rtb[8] = {0, 473195, 504333, 520860, 550000, 700000, 750000, 830000};
+  const short low = useLowProb ? -1 : 1;
+  const u64 scale = 62 - t, step = ((u64)1 << 62) / total, vStep = 1ULL << (scale - 20);
+  int still = 1 << t;
+  u32 largest = 0; short largestP = 0;
+  const u32 lowThr = total >> t;
+  for (u32 s = 0; s <= maxSym; s++) {
+    if (cnt[s] == total) return 0;
+    if (cnt[s] == 0) { norm[s] = 0; continue; }
+    if (cnt[s] <= lowThr) { norm[s] = low; still--; }
+    else {
+      short p = (short)(((u64)cnt[s] * step) >> scale);
+      if (p < 8) { u64 rest = vStep * rtb[p]; p += ((u64)cnt[s] * step) - ((u64)p << scale) > rest; }
+      if (p > largestP) { largestP = p; largest = s; }
+      norm[s] = p; still -= p;
+    }
+  }
+  if (-still >= (norm[largest] >> 1)) { if (fse_normalize_m2(norm, t, cnt, total, maxSym, low)) return -1; }
+  else norm[largest] += (short)still;
+  return (int)t;
+}
+
+// table description writer (forward LSB-first); returns bytes, 0 on error. out must hold 192 bytes.
+__device__ u32 fse_write_ncount(u8* out, const short* norm, u32 maxSym, u32 t) {
+  u64 acc = 0; int nacc = 0; u32 pos = 0;
+  const int tableSize = 1 << t;
+  int remaining = tableSize + 1, thr = tableSize, nb = (int)t + 1;
+  u32 sym = 0; const u32 alpha = maxSym + 1;
+  bool prev0 = false;
+  auto put = [&](u32 v, int n) { acc |= (u64)v << nacc; nacc += n; while (nacc >= 8) { out[pos++] = (u8)acc; acc >>= 8; nacc -= 8; } };
+  put(t - 5, 4);
+  while (sym < alpha && remaining > 1) {
+    if (prev0) {
+      u32 start = sym;
+      while (sym < alpha && !norm[sym]) sym++;
+      if (sym == alpha) break;
+      while (sym >= start + 24) { start += 24; put(0xFFFFu, 16); }
+      while (sym >= start + 3) { start += 3; put(3, 2); }
+      put(sym - start, 2);
+    }
+    int c = norm[sym++];
+    const int mx = (2 * thr - 1) - remaining;
+    remaining -= c < 0 ? -c : c;
+    c++;
+    if (c >= thr) c += mx;
+    put((u32)c, nb - (c < mx));
+    prev0 = (c == 1);
+    if (remaining < 1) return 0;
+    while (remaining < thr) { nb--; thr >>= 1; }
+    if (pos > 170) return 0;
+  }
+  if (remaining != 1) return 0;
+  if (nacc > 0) out[pos++] = (u8)acc;
+  return pos;
+}
+
+// serial (one lane) encoding-table build: spread, state table, per-symbol transforms
+__device__ int fse_build_ctable(ZraFseCTable* ct, const short* norm, u32 maxSym, u32 t, u8* cell) {
+  const u32 size = 1u << t, mask = size - 1, step = (size >> 1) + (size >> 3) + 3;
+  u32 high = size - 1, pos = 0;
+  u32 cumul[54];
+  ct->tableLog = t; ct->maxSym = maxSym; ct->rle = 0;
+  cumul[0] = 0;
+  for (u32 u = 1; u <= maxSym + 1; u++) cumul[u] = cumul[u - 1] + (norm[u - 1] == -1 ? 1u : (u32)norm[u - 1]);
+  for (u32 s = 0; s <= maxSym; s++) if (norm[s] == -1) cell[high--] = (u8)s;
+  for (u32 s = 0; s <= maxSym; s++)
+    for (int i = 0; i < norm[s]; i++) { cell[pos] = (u8)s; pos = (pos + step) & mask; while (pos > high) pos = (pos + step) & mask; }
+  if (pos != 0) return -1;
+  for (u32 u = 0; u < size; u++) ct->stateTable[cumul[cell[u]]++] = (u16)(size + u);
+  u32 total = 0;
+  for (u32 s = 0; s <= maxSym; s++) {
+    const int p = norm[s];
+    if (p == 0) { ct->deltaNbBits[s] = ((t + 1) << 16) - (1u << t); ct->deltaFindState[s] = 0; }
+    else if (p == 1 || p == -1) { ct->deltaNbBits[s] = (t << 16) - (1u << t); ct->deltaFindState[s] = (int)total - 1; total++; }
+    else {
+      const u32 maxBitsOut = t - hb32((u32)p - 1);
+      ct->deltaNbBits[s] = (maxBitsOut << 16) - ((u32)p << maxBitsOut);
+      ct->deltaFindState[s] = (int)total - p;
+      total += (u32)p;
+    }
+  }
+  return 0;
+}
+__device__ __forceinline__ u32 fse_init_state(const ZraFseCTable* ct, u32 sym) {
+  if (ct->rle) return 0;
+  const u32 d = ct->deltaNbBits[sym], nb = (d + (1u << 15)) >> 16, v = (nb << 16) - d;
+  return ct->stateTable[(v >> nb) + ct->deltaFindState[sym]];
+}
+__device__ __forceinline__ u32 fse_encode(const ZraFseCTable* ct, u32& state, u32 sym, u32& bits) {
+  if (ct->rle) { bits = 0; return 0; }
+  const u32 nb = (state + ct->deltaNbBits[sym]) >> 16;
+  bits = state & ((1u << nb) - 1);
+  state = ct->stateTable[(state >> nb) + ct->deltaFindState[sym]];
+  return nb;
+}
+
+// =============================================================================== Huffman (A.4.5)
+// depth limiter on the sorted node arrays (positions 0..lastNonNull, +1 offset in LDS arrays); one lane
+__device__ u32 huf_set_max_height(EncShared& S, u32 lastNonNull, u32 maxNbBits) {
+  u8* nb = S.nodeBits + 1; const u32* cnt = S.nodeCount + 1;
+  const u32 largestBits = nb[lastNonNull];
+  if (largestBits <= maxNbBits) return largestBits;
+  int totalCost = 0;
+  const u32 baseCost = 1u << (largestBits - maxNbBits);
+  int n = (int)lastNonNull;
+  while (nb[n] > maxNbBits) { totalCost += (int)(baseCost - (1u << (largestBits - nb[n]))); nb[n] = (u8)maxNbBits; n--; }
+  while (nb[n] == maxNbBits) n--;
+  totalCost >>= (largestBits - maxNbBits);
+  const u32 none = 0xF0F0F0F0u;
+  u32 rankLast[14];
+  for (int i = 0; i < 14; i++) rankLast[i] = none;
+  {
+    u32 cur = maxNbBits;
+    for (int pos = n; pos >= 0; pos--) { if (nb[pos] >= cur) continue; cur = nb[pos]; rankLast[maxNbBits - cur] = (u32)pos; }
+  }
+  while (totalCost > 0) {
+    u32 d = hb32((u32)totalCost) + 1;
+    for (; d > 1; d--) {
+      const u32 hp = rankLast[d], lp = rankLast[d - 1];
+      if (hp == none) continue;
+      if (lp == none) break;
+      if (cnt[hp] <= 2 * cnt[lp]) break;
+    }
+    while (d <= 12 && rankLast[d] == none) d++;
+    totalCost -= 1 << (d - 1);
+    if (rankLast[d - 1] == none) rankLast[d - 1] = rankLast[d];
+    nb[rankLast[d]]++;
+    if (rankLast[d] == 0) rankLast[d] = none;
+    else { rankLast[d]--; if (nb[rankLast[d]] != maxNbBits - d) rankLast[d] = none; }
+  }
+  while (totalCost < 0) {
+    if (rankLast[1] == none) {
+      while (nb[n] == maxNbBits) n--;
+      nb[n + 1]--;
+      rankLast[1] = (u32)(n + 1);
+      totalCost++;
+      continue;
+    }
+    nb[rankLast[1] + 1]--;
+    rankLast[1]++;
+    totalCost++;
+  }
+  return maxNbBits;
+}
+
+// FSE-compress the weight string (one lane). 0 = not compressible, 1 = single symbol. Uses S.ct[0]/S.spread[0]/S.norm[0] as scratch.
+__device__ u32 huf_compress_weights(EncShared& S, u8* dst, u32 cap, const u8* w, u32 n) {
+  u32 count[13]; short* norm = S.norm[0];
+  u32 maxSym = 0, maxCount = 0;
+  if (n <= 1) return 0;
+  for (int s = 0; s < 13; s++) count[s] = 0;
+  for (u32 i = 0; i < n; i++) count[w[i]]++;
+  for (u32 s = 0; s <= 12; s++) { if (count[s]) maxSym = s; if (count[s] > maxCount) maxCount = count[s]; }
+  if (maxCount == n) return 1;
+  if (maxCount == 1) return 0;
+  const u32 t = fse_optimal_tablelog(6, n, maxSym, 2);
+  if (fse_normalize(norm, t, count, n, maxSym, false) <= 0) return 0;
+  u8 tmp[192];
+  const u32 h = fse_write_ncount(tmp, norm, maxSym, t);
+  if (!h || h > cap) return 0;
+  for (u32 i = 0; i < h; i++) dst[i] = tmp[i];
+  ZraFseCTable* ct = &S.ct[0];
+  if (fse_build_ctable(ct, norm, maxSym, t, S.spread[0])) return 0;
+  if (n <= 2) return 0;
+  // two interleaved states, symbols consumed from the end (A.4.5 "weight serialisation")
+  u64 acc = 0; u32 nacc = 0, pos = h;
+  auto put = [&](u32 v, u32 nb) { acc |= (u64)(v & ((1u << nb) - 1)) << nacc; nacc += nb; while (nacc >= 8) { if (pos < cap) dst[pos] = (u8)acc; pos++; acc >>= 8; nacc -= 8; } };
+  const u8* ip = w + n;
+  u32 s1, s2, bits, nb;
+  if (n & 1) {
+    s1 = fse_init_state(ct, *--ip); s2 = fse_init_state(ct, *--ip);
+    nb = fse_encode(ct, s1, *--ip, bits); put(bits, nb);
+  } else { s2 = fse_init_state(ct, *--ip); s1 = fse_init_state(ct, *--ip); }
+  while (ip > w) {
+    nb = fse_encode(ct, s2, *--ip, bits); put(bits, nb);
+    if (ip > w) { nb = fse_encode(ct, s1, *--ip, bits); put(bits, nb); }
+  }
+  put(s2, t); put(s1, t);
+  put(1, 1);
+  if (nacc > 0) { if (pos < cap) dst[pos] = (u8)acc; pos++; }
+  if (pos > cap) return 0;
+  return pos;
+}
+
+// HUF_writeCTable into S.hufHdr (one lane); returns size, 0 on failure
+__device__ u32 huf_write_ctable(EncShared& S, u32 maxSym, u32 log) {
+  u8* w = S.weights; u8* dst = S.hufHdr;
+  for (u32 n = 0; n < maxSym; n++) w[n] = S.hNb[n] ? (u8)(log + 1 - S.hNb[n]) : 0;
+  const u32 h = huf_compress_weights(S, dst + 1, 190, w, maxSym);
+  if (h > 1 && h < maxSym / 2) { dst[0] = (u8)h; return h + 1; }
+  if (maxSym > 128) return 0;
+  dst[0] = (u8)(128 + (maxSym - 1));
+  w[maxSym] = 0;
+  for (u32 n = 0; n < maxSym; n += 2) dst[(n / 2) + 1] = (u8)((w[n] << 4) + w[n + 1]);
+  return ((maxSym + 1) / 2) + 1;
+}
+
+// Encode `len` literal symbols (reverse order, A.4.5) as one Huffman stream into dst; all 256 threads. Returns bytes.
+__device__ u32 huf_encode_stream(EncShared& S, const u8* lit, u32 len, const u8* nbTab, const u16* valTab, u8* dst) {
+  u32 carryBits = 0, carryVal = 0, bytesOut = 0;
+  for (u32 t0 = 0; t0 < len; t0 += SYM_TILE) {
+    const u32 cntT = min((u32)SYM_TILE, len - t0);
+    const bool lastTile = t0 + cntT == len;
+    const u32 zw = ((7 + cntT * 11 + 1) >> 5) + 2;
+    for (u32 i = threadIdx.x; i < zw; i += ENT_THREADS) S.stage[i] = (i == 0) ? carryVal : 0;
+    u8 sym[16]; u32 nb = 0;
+    const u32 r0 = t0 + 16 * threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      const u32 r = r0 + k;
+      sym[k] = r < t0 + cntT ? lit[len - 1 - r] : 0;
+      nb += r < t0 + cntT ? nbTab[sym[k]] : 0;
+    }
+    u32 tot;
+    const u32 ex = block_excl_scan(S, nb, &tot);      // contains the barriers that order the stage clear
+    LaneBitW bw; bw.init(S.stage, carryBits + ex);
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      const u32 r = r0 + k;
+      if (r < t0 + cntT) bw.add(valTab[sym[k]], nbTab[sym[k]]);
+    }
+    bw.finish();
+    u32 total = carryBits + tot;
+    if (lastTile) { if (threadIdx.x == 0) atomicOr(&S.stage[total >> 5], 1u << (total & 31)); total += 1; }
+    __syncthreads();
+    const u32 nbytes = lastTile ? (total + 7) >> 3 : total >> 3;
+    flush_stage(S, dst + bytesOut, nbytes);
+    carryBits = lastTile ? 0 : (total & 7);
+    carryVal = (S.stage[nbytes >> 2] >> (8 * (nbytes & 3))) & ((1u << carryBits) - 1);
+    bytesOut += nbytes;
+    __syncthreads();
+  }
+  return bytesOut;
+}
+
+// =============================================================================== sequence-table selection (A.4.7), one lane
+__device__ u32 cross_entropy_cost(const short* norm, u32 accLog, const u32* count, u32 max) {
+  const u32 shift = 8 - accLog; u64 cost = 0;
+  for (u32 s = 0; s <= max; s++) { const u32 na = norm[s] != -1 ? (u32)norm[s] : 1; cost += (u64)count[s] * c_invProb[na << shift]; }
+  return (u32)(cost >> 8);
+}
+__device__ u32 entropy_cost(const u32* count, u32 max, u32 total) {
+  u32 cost = 0;
+  for (u32 s = 0; s <= max; s++) {
+    u32 norm = (256 * count[s]) / total;
+    if (count[s] != 0 && norm == 0) norm = 1;
+    cost += count[s] * c_invProb[norm];
+  }
+  return cost >> 8;
+}
+constexpr u32 COST_ERR = 0xFFFFFFFFu;
+__device__ u32 fse_bit_cost(const ZraFseCTable* ct, const u32* count, u32 max) {
+  if (ct->rle || ct->maxSym < max) return COST_ERR;
+  const u32 tl = ct->tableLog; u64 cost = 0;
+  for (u32 s = 0; s <= max; s++) {
+    const u32 badCost = (tl + 1) << 8;
+    const u32 minNb = ct->deltaNbBits[s] >> 16, thr = (minNb + 1) << 16;
+    const u32 d = thr - (ct->deltaNbBits[s] + (1u << tl));
+    const u32 bitCost = (minNb + 1) * 256 - ((d << 8) >> tl);
+    if (!count[s]) continue;
+    if (bitCost >= badCost) return COST_ERR;
+    cost += (u64)count[s] * bitCost;
+  }
+  return (u32)(cost >> 8);
+}
+
+// mode: 0 predefined, 1 rle, 2 compressed, 3 repeat
+__device__ u32 select_encoding(u32* repeatMode, const u32* count, u32 max, u32 mostFrequent, u32 nbSeq, u32 FSELog, const ZraFseCTable* prevCT,
+                               const short* defNorm, u32 defLog, bool defaultAllowed, u32 strategy, short* normScratch) {
+  if (mostFrequent == nbSeq) { *repeatMode = 0; return (defaultAllowed && nbSeq <= 2) ? 0 : 1; }
+  if (strategy < 4) {
+    if (defaultAllowed) {
+      const u32 mult = 10 - strategy, dynMin = ((1u << defLog) * mult) >> 3;
+      if (*repeatMode == 2 && nbSeq < 1000) return 3;
+      if (nbSeq < dynMin || mostFrequent < (nbSeq >> (defLog - 1))) { *repeatMode = 0; return 0; }
+    }
+  } else {
+    const u64 INF = ~0ull;
+    u64 basic = defaultAllowed ? cross_entropy_cost(defNorm, defLog, count, max) : INF;
+    u64 repeat = INF;
+    if (*repeatMode != 0) { u32 c = fse_bit_cost(prevCT, count, max); repeat = c == COST_ERR ? INF : c; }
+    u64 nc = INF;
+    {
+      const u32 tl = fse_optimal_tablelog(FSELog, nbSeq, max, 2);
+      if (fse_normalize(normScratch, tl, count, nbSeq, max, nbSeq >= 2048) > 0) {
+        u8 tmp[192];
+        const u32 r = fse_write_ncount(tmp, normScratch, max, tl);
+        if (r) nc = r;
+      }
+    }
+    const u64 compressed = nc == INF ? INF : (nc << 3) + entropy_cost(count, max, nbSeq);
+    if (basic <= repeat && basic <= compressed) { *repeatMode = 0; return 0; }
+    if (repeat <= compressed) return 3;
+  }
+  *repeatMode = 1;
+  return 2;
+}
+
+}  // namespace
+
+// =================================================================================================
+extern "C" __global__ void __launch_bounds__(ENT_THREADS)
+zra_entropy_kernel(ZraEncArgs a, u32 block) {
+  __shared__ EncShared S;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const u32 f = blockIdx.x;
+  const u64 fstart = (u64)(a.firstFrame + f) * a.frameSize;
+  const u64 remaining = a.inSize - fstart;
+  const u32 fsize = (u32)(remaining < a.frameSize ? remaining : a.frameSize);
+  const ZraEncParams& P = (fsize == a.frameSize) ? a.full : a.tail;
+  const u32 bs = block * P.blockSize;
+  if (bs >= fsize) return;
+  const u32 be = min(fsize, bs + P.blockSize), L = be - bs;
+  const bool first = block == 0, last = be == fsize;
+  const u8* src = a.in + fstart;
+  ZraEncFrameState* st = &a.state[f];
+  const ZraEncBlockOut* bo = &a.blockOut[f];
+  u8* slot = a.slots + (size_t)f * a.slotStride;
+  const u32 strategy = P.strategy;
+
+  if (first && tid == 0) {
+    st32(slot, 0xFD2FB528u); slot[4] = a.checksum ? 4 : 0; slot[5] = (u8)((P.windowLog - 10) << 3);   // A.4.2 frame header
+    st->outPos = 6; st->hufRepeat = 0; st->llRepeat = st->ofRepeat = st->mlRepeat = 0;
+  }
+  __syncthreads();
+  const u32 outPos = first ? 6 : st->outPos;
+  u8* const op0 = slot + outPos;          // 3-byte block header goes here
+  u8* const blk = op0 + 3;                // block content
+  u32 cSize = 0;
+  bool newHuf = false; u32 newHufLog = 0, newHufMaxSym = 0;
+  const u32 nbSeq = bo->nbSeq;
+
+  if (!bo->skip) {
+    const u64* seqs = a.seqs + (size_t)f * a.seqStride;
+    u8* lits = a.lits + (size_t)f * a.litStride;
+
+    // ------------------------------------------------------------ phase 1: gather literals + histogram
+    for (int i = tid; i < 4 * 256; i += ENT_THREADS) (&S.hist[0][0])[i] = 0;
+    u32 litBase = 0, srcBase = bs;
+    __syncthreads();
+    for (u32 t0 = 0; t0 < nbSeq; t0 += SEQ_TILE) {
+      u32 llv[4], mlv[4], tl = 0, tt = 0;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const u32 i = t0 + 4 * tid + k;
+        const u64 q = i < nbSeq ? seqs[i] : 0;
+        llv[k] = (u32)q & 0xFFFFF; mlv[k] = (u32)(q >> 20) & 0xFFFFF;
+        tl += llv[k]; tt += llv[k] + mlv[k];
+      }
+      if (tid == 0) S.longCount = 0;
+      u32 totL, totT;
+      const u32 exL = block_excl_scan(S, tl, &totL);
+      const u32 exT = block_excl_scan(S, tt, &totT);
+      u32 lp = litBase + exL, sp = srcBase + exT;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const u32 ll = llv[k];
+        if (ll >= 32) {                              // long run: queue for the whole workgroup
+          const u32 e = atomicAdd(&S.longCount, 1u);
+          S.stage[3 * e] = lp; S.stage[3 * e + 1] = sp; S.stage[3 * e + 2] = ll;
+        } else {
+          for (u32 b = 0; b < ll; b++) { const u8 c = src[sp + b]; lits[lp + b] = c; atomicAdd(&S.hist[wave][c], 1u); }
+        }
+        lp += ll; sp += ll + mlv[k];
+      }
+      __syncthreads();
+      const u32 nLong = S.longCount;
+      for (u32 e = 0; e < nLong; e++) {
+        const u32 lp2 = S.stage[3 * e], sp2 = S.stage[3 * e + 1], ll2 = S.stage[3 * e + 2];
+        for (u32 b = tid; b < ll2; b += ENT_THREADS) { const u8 c = src[sp2 + b]; lits[lp2 + b] = c; atomicAdd(&S.hist[wave][c], 1u); }
+      }
+      litBase += totL; srcBase += totT;
+      __syncthreads();
+    }
+    const u32 lastLL = bo->lastLL;
+    for (u32 b = tid; b < lastLL; b += ENT_THREADS) { const u8 c = src[be - lastLL + b]; lits[litBase + b] = c; atomicAdd(&S.hist[wave][c], 1u); }
+    const u32 n = litBase + lastLL;           // literal count of the block
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+
+    // ------------------------------------------------------------ phase 2: literals section (A.4.5)
+    u32 litSec = 0;
+    {
+      // mode: 0 raw, 1 rle, 2 compressed (new table), 3 treeless (previous table)
+      u32 mode = 0, hSize = 0, streams = 1, encSize = 0;
+      u32 ssz[4] = {0, 0, 0, 0};
+      const u8* nbTab = S.hNb; const u16* valTab = S.hVal;
+      if (n > 63) {
+        const u32 cntS = S.hist[0][tid] + S.hist[1][tid] + S.hist[2][tid] + S.hist[3][tid];
+        __syncthreads();
+        S.hist[0][tid] = cntS;
+        const u32 largest = block_max(S, cntS);
+        const u32 maxSym = block_max(S, cntS ? (u32)tid : 0u);
+        u32 c = 0;                                  // compressed size candidate; 0 = not compressible
+        bool useOld = false;
+        if (largest == n) c = 1;
+        else if (largest > (n >> 7) + 4) {
+          u32 repeat = first ? 0u : st->hufRepeat;
+          if (repeat == 1) {
+            const int bad = __syncthreads_or((u32)tid <= maxSym && cntS != 0 && st->hufNbBits[tid] == 0);
+            if (bad) repeat = 0;
+          }
+          const bool preferRepeat = strategy < 4 && n <= 1024;
+          bool fail = false;
+          if (preferRepeat && repeat != 0) useOld = true;
+          else {
+            // ---- new tree: sort by (count desc, symbol asc), two-queue merge, depth limit, canonical codes
+            const u32 log = fse_optimal_tablelog(11, n, maxSym, 1);
+            if ((u32)tid <= maxSym) {
+              u32 rank = 0;
+              for (u32 t = 0; t <= maxSym; t++) { const u32 ct = S.hist[0][t]; rank += (ct > cntS) || (ct == cntS && t < (u32)tid); }
+              S.nodeCount[1 + rank] = cntS; S.nodeByte[rank] = (u8)tid;
+            }
+            __syncthreads();
+            if (tid == 0) {
+              u32* cntN = S.nodeCount + 1; u16* par = S.nodeParent + 1; u8* nbN = S.nodeBits + 1;
+              int nonNull = (int)maxSym;
+              while (cntN[nonNull] == 0) nonNull--;
+              const int START = 256;
+              int lowS = nonNull, nodeNb = START, nodeRoot = nodeNb + lowS - 1, lowN = nodeNb;
+              cntN[nodeNb] = cntN[lowS] + cntN[lowS - 1];
+              par[lowS] = par[lowS - 1] = (u16)nodeNb;
+              nodeNb++; lowS -= 2;
+              for (int k = nodeNb; k <= nodeRoot; k++) cntN[k] = 1u << 30;
+              S.nodeCount[0] = 1u << 31;
+              while (nodeNb <= nodeRoot) {
+                const int n1 = (cntN[lowS] < cntN[lowN]) ? lowS-- : lowN++;
+                const int n2 = (cntN[lowS] < cntN[lowN]) ? lowS-- : lowN++;
+                cntN[nodeNb] = cntN[n1] + cntN[n2];
+                par[n1] = par[n2] = (u16)nodeNb;
+                nodeNb++;
+              }
+              nbN[nodeRoot] = 0;
+              for (int k = nodeRoot - 1; k >= START; k--) nbN[k] = nbN[par[k]] + 1;
+              for (int k = 0; k <= nonNull; k++) nbN[k] = nbN[par[k]] + 1;
+              const u32 maxBits = huf_set_max_height(S, (u32)nonNull, log);
+              u16 nbPerRank[14], valPerRank[14];
+              for (int k = 0; k < 14; k++) nbPerRank[k] = valPerRank[k] = 0;
+              for (int k = 0; k <= nonNull; k++) nbPerRank[nbN[k]]++;
+              { u16 mn = 0; for (int k = (int)maxBits; k > 0; k--) { valPerRank[k] = mn; mn += nbPerRank[k]; mn >>= 1; } }
+              for (int k = 0; k < 256; k++) S.hNb[k] = 0;
+              for (u32 k = 0; k <= maxSym; k++) S.hNb[S.nodeByte[k]] = k <= (u32)nonNull ? nbN[k] : 0;
+              for (u32 k = 0; k <= maxSym; k++) S.hVal[k] = valPerRank[S.hNb[k]]++;
+              S.sc[0] = maxBits;
+              S.sc[1] = huf_write_ctable(S, maxSym, maxBits);
+            }
+            __syncthreads();
+            newHufLog = S.sc[0]; hSize = S.sc[1]; newHufMaxSym = maxSym;
+            if (!hSize) fail = true;
+            else if (repeat != 0) {
+              const u32 oldSize = block_sum(S, (u32)tid <= maxSym ? (u32)st->hufNbBits[tid] * cntS : 0u) >> 3;
+              const u32 newSize = block_sum(S, (u32)tid <= maxSym ? (u32)S.hNb[tid] * cntS : 0u) >> 3;
+              if (oldSize <= hSize + newSize || hSize + 12 >= n) useOld = true;
+            }
+            if (!fail && !useOld && hSize + 12 >= n) fail = true;   // "return 0": not compressible
+          }
+          if (!fail) {
+            if (useOld) {
+              // previous block's table -> LDS copies so both paths read the same arrays
+              S.hNb[tid] = st->hufNbBits[tid]; S.hVal[tid] = st->hufVal[tid];
+              hSize = 0;
+              __syncthreads();
+            }
+            streams = n < 256 ? 1 : 4;
+            // stream sizes from code lengths (prefix work is cheap: one pass over the literals)
+            const u32 seg = streams == 1 ? n : (n + 3) / 4;
+            u32 bits[4] = {0, 0, 0, 0};
+            for (u32 i = tid; i < n; i += ENT_THREADS) { const u32 j = streams == 1 ? 0 : min(i / seg, 3u); bits[j] += nbTab[lits[i]]; }
+            for (u32 j = 0; j < streams; j++) ssz[j] = (block_sum(S, bits[j]) + 1 + 7) >> 3;
+            encSize = streams == 1 ? ssz[0] : 6 + ssz[0] + ssz[1] + ssz[2] + ssz[3];
+            c = hSize + encSize;
+            if (c >= n - 1) c = 0;
+          }
+        }
+        const u32 minGain = (n >> (strategy >= 8 ? strategy - 1 : 6)) + 2;
+        if (c == 0 || c >= n - minGain) mode = 0;
+        else if (c == 1) mode = 1;
+        else mode = useOld ? 3 : 2;
+      }
+      // ---- emit
+      if (mode < 2) {
+        const u32 fl = 1 + (n > 31) + (n > 4095);
+        if (tid == 0) {
+          if (fl == 1) blk[0] = (u8)(mode + (n << 3));
+          else if (fl == 2) { const u32 v = mode + (1 << 2) + (n << 4); blk[0] = (u8)v; blk[1] = (u8)(v >> 8); }
+          else st32(blk, mode + (3 << 2) + (n << 4));       // 4th byte is overwritten by the payload below
+        }
+        __syncthreads();
+        if (mode == 1) { if (tid == 0) blk[fl] = lits[0]; litSec = fl + 1; }
+        else { for (u32 i = tid; i < n; i += ENT_THREADS) blk[fl + i] = lits[i]; litSec = fl + n; }
+      } else {
+        const u32 lh = 3 + (n >= 1024) + (n >= 16384);
+        const u32 c = hSize + encSize;
+        if (tid == 0) {
+          if (lh == 3) { const u32 v = mode + ((streams == 4) << 2) + (n << 4) + (c << 14); blk[0] = (u8)v; blk[1] = (u8)(v >> 8); blk[2] = (u8)(v >> 16); }
+          else if (lh == 4) st32(blk, mode + (2 << 2) + (n << 4) + (c << 18));
+          else { st32(blk, mode + (3 << 2) + (n << 4) + (c << 22)); blk[4] = (u8)(c >> 10); }
+        }
+        for (u32 i = tid; i < hSize; i += ENT_THREADS) blk[lh + i] = S.hufHdr[i];
+        u8* sp = blk + lh + hSize;
+        if (streams == 4) {
+          if (tid == 0) { sp[0] = (u8)ssz[0]; sp[1] = (u8)(ssz[0] >> 8); sp[2] = (u8)ssz[1]; sp[3] = (u8)(ssz[1] >> 8); sp[4] = (u8)ssz[2]; sp[5] = (u8)(ssz[2] >> 8); }
+          sp += 6;
+          const u32 seg = (n + 3) / 4;
+          for (u32 j = 0; j < 4; j++) {
+            const u32 len = j < 3 ? seg : n - 3 * seg;
+            huf_encode_stream(S, lits + j * seg, len, nbTab, valTab, sp);
+            sp += ssz[j];
+          }
+        } else huf_encode_stream(S, lits, n, nbTab, valTab, sp);
+        litSec = lh + c;
+        newHuf = mode == 2;
+      }
+    }
+    __syncthreads();
+
+    // ------------------------------------------------------------ phase 3: sequences section (A.4.7)
+    u8* op = blk + litSec;
+    if (tid == 0) {
+      if (nbSeq < 128) op[0] = (u8)nbSeq;
+      else if (nbSeq < 0x7F00) { op[0] = (u8)((nbSeq >> 8) + 0x80); op[1] = (u8)nbSeq; }
+      else { op[0] = 0xFF; op[1] = (u8)(nbSeq - 0x7F00); op[2] = (u8)((nbSeq - 0x7F00) >> 8); }
+    }
+    op += nbSeq < 128 ? 1 : nbSeq < 0x7F00 ? 2 : 3;
+    bool uncompressible = false;
+    if (nbSeq) {
+      u8* const seqHead = op++;
+      // ---- pass A: code histograms
+      for (int i = tid; i < 3 * 64; i += ENT_THREADS) (&S.cnt[0][0])[i] = 0;
+      __syncthreads();
+      for (u32 i = tid; i < nbSeq; i += ENT_THREADS) {
+        const u64 q = seqs[i];
+        const u32 ll = (u32)q & 0xFFFFF, ml = (u32)(q >> 20) & 0xFFFFF, ov = (u32)(q >> 40);
+        atomicAdd(&S.cnt[0][ll_code(ll)], 1u);
+        atomicAdd(&S.cnt[1][hb32(ov)], 1u);
+        atomicAdd(&S.cnt[2][ml_code(ml - 3)], 1u);
+      }
+      __syncthreads();
+      // ---- table selection + construction: wave k lane 0 handles stream k (0 LL, 1 OF, 2 ML)
+      if (wave < 3 && lane == 0) {
+        const int k = wave;
+        const u32 maxSymK = k == 0 ? 35 : k == 1 ? 31 : 52, FSELog = k == 1 ? 8 : 9, defLog = k == 1 ? 5 : 6, defMax = k == 0 ? 35 : k == 1 ? 28 : 52;
+        const short* defNorm = k == 0 ? c_LLdef : k == 1 ? c_OFdef : c_MLdef;
+        u32* count = S.cnt[k];
+        u32 mx = 0, most = 0;
+        for (u32 s = 0; s <= maxSymK; s++) { if (count[s]) mx = s; if (count[s] > most) most = count[s]; }
+        const u64 qLast = seqs[nbSeq - 1];
+        const u32 lastCode = k == 0 ? ll_code((u32)qLast & 0xFFFFF) : k == 1 ? hb32((u32)(qLast >> 40)) : ml_code(((u32)(qLast >> 20) & 0xFFFFF) - 3);
+        const ZraFseCTable* prevCT = k == 0 ? &st->ll : k == 1 ? &st->of : &st->ml;
+        u32 repeatMode = first ? 0 : (k == 0 ? st->llRepeat : k == 1 ? st->ofRepeat : st->mlRepeat);
+        const bool defaultAllowed = k != 1 || mx <= 28;
+        const u32 mode = select_encoding(&repeatMode, count, mx, most, nbSeq, FSELog, prevCT, defNorm, defLog, defaultAllowed, strategy, S.norm[k]);
+        S.mode[k] = mode; S.nextRepeat[k] = repeatMode; S.ncountSize[k] = 0; S.tblErr[k] = 0;
+        ZraFseCTable* ct = &S.ct[k];
+        if (mode == 1) { ct->rle = 1; ct->tableLog = 0; ct->maxSym = mx; S.ncount[k][0] = (u8)mx; S.ncountSize[k] = 1; }
+        else if (mode == 0) { for (u32 s = 0; s <= defMax; s++) S.norm[k][s] = defNorm[s]; if (fse_build_ctable(ct, S.norm[k], defMax, defLog, S.spread[k])) S.tblErr[k] = 1; }
+        else if (mode == 2) {
+          u32 n1 = nbSeq;
+          const u32 tl = fse_optimal_tablelog(FSELog, nbSeq, mx, 2);
+          if (count[lastCode] > 1) { count[lastCode]--; n1--; }
+          if (fse_normalize(S.norm[k], tl, count, n1, mx, n1 >= 2048) <= 0) S.tblErr[k] = 1;
+          else {
+            const u32 h = fse_write_ncount(S.ncount[k], S.norm[k], mx, tl);
+            if (!h || fse_build_ctable(ct, S.norm[k], mx, tl, S.spread[k])) S.tblErr[k] = 1;
+            S.ncountSize[k] = h;
+          }
+        }
+      }
+      __syncthreads();
+      // repeat mode: bring the previous table into LDS (cooperative copy), all three streams checked uniformly
+      for (int k = 0; k < 3; k++) {
+        if (S.mode[k] == 3) {
+          const u32* srcT = (const u32*)(k == 0 ? &st->ll : k == 1 ? &st->of : &st->ml);
+          u32* dstT = (u32*)&S.ct[k];
+          for (u32 i = tid; i < sizeof(ZraFseCTable) / 4; i += ENT_THREADS) dstT[i] = srcT[i];
+        }
+      }
+      __syncthreads();
+      const bool tblErr = S.tblErr[0] | S.tblErr[1] | S.tblErr[2];
+      u8* lastNCount = nullptr;
+      if (tid == 0) seqHead[0] = (u8)((S.mode[0] << 6) + (S.mode[1] << 4) + (S.mode[2] << 2));
+      for (int k = 0; k < 3; k++) {
+        const u32 sz = S.ncountSize[k];
+        if (S.mode[k] == 2) lastNCount = op;
+        for (u32 i = tid; i < sz; i += ENT_THREADS) op[i] = S.ncount[k][i];
+        op += sz;
+      }
+      // ---- pass B: FSE state chains (3 lanes) + parallel packing, 1024 sequences per tile, last sequence first
+      u32 state = 0;                       // wave 0 lanes 0..2 carry their stream's state across tiles
+      u32 carryBits = 0, carryVal = 0, bytesOut = 0;
+      const u32 tlog[3] = {S.ct[0].tableLog, S.ct[1].tableLog, S.ct[2].tableLog};
+      for (u32 t0 = 0; t0 < nbSeq && !tblErr; t0 += SEQ_TILE) {
+        const u32 cntT = min((u32)SEQ_TILE, nbSeq - t0);
+        const bool lastTile = t0 + cntT == nbSeq;
+        const u32 zw = ((7 + cntT * 90 + 28) >> 5) + 2;
+        for (u32 i = tid; i < zw; i += ENT_THREADS) S.stage[i] = (i == 0) ? carryVal : 0;
+        u32 llv[4], mlb[4], ofv[4], llc[4], mlc[4], ofc[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const u32 rl = 4 * tid + k;                 // reversed local index
+          if (rl < cntT) {
+            const u64 q = seqs[nbSeq - 1 - (t0 + rl)];
+            llv[k] = (u32)q & 0xFFFFF; mlb[k] = ((u32)(q >> 20) & 0xFFFFF) - 3; ofv[k] = (u32)(q >> 40);
+            llc[k] = ll_code(llv[k]); mlc[k] = ml_code(mlb[k]); ofc[k] = hb32(ofv[k]);
+            S.codes[0][rl] = (u8)llc[k]; S.codes[1][rl] = (u8)ofc[k]; S.codes[2][rl] = (u8)mlc[k];
+          } else { llv[k] = mlb[k] = ofv[k] = llc[k] = mlc[k] = ofc[k] = 0; }
+        }
+        __syncthreads();
+        if (wave == 0 && lane < 3) {
+          const ZraFseCTable* ct = &S.ct[lane];
+          for (u32 rl = 0; rl < cntT; rl++) {
+            const u32 code = S.codes[lane][rl];
+            if (t0 + rl == 0) { state = fse_init_state(ct, code); S.chain[lane][rl] = 0; }
+            else { u32 bits; const u32 nb = fse_encode(ct, state, code, bits); S.chain[lane][rl] = (u16)((nb << 12) | bits); }
+          }
+          if (lastTile) S.finalState[lane] = state;
+        }
+        __syncthreads();
+        u32 nbits = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const u32 rl = 4 * tid + k;
+          if (rl < cntT) nbits += (S.chain[0][rl] >> 12) + (S.chain[1][rl] >> 12) + (S.chain[2][rl] >> 12) + c_LLbits[llc[k]] + c_MLbits[mlc[k]] + ofc[k];
+        }
+        u32 tot;
+        const u32 ex = block_excl_scan(S, nbits, &tot);
+        LaneBitW bw; bw.init(S.stage, carryBits + ex);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const u32 rl = 4 * tid + k;
+          if (rl < cntT) {
+            const u32 cO = S.chain[1][rl], cM = S.chain[2][rl], cL = S.chain[0][rl];
+            bw.add(cO & 0xFFF, cO >> 12); bw.add(cM & 0xFFF, cM >> 12); bw.add(cL & 0xFFF, cL >> 12);
+            const u32 lb = c_LLbits[llc[k]], mb = c_MLbits[mlc[k]], ob = ofc[k];
+            bw.add(llv[k] & ((1u << lb) - 1), lb);
+            bw.add(mlb[k] & ((1u << mb) - 1), mb);
+            bw.add(ofv[k] & (ob >= 32 ? 0xFFFFFFFFu : ((1u << ob) - 1)), ob);
+          }
+        }
+        bw.finish();
+        u32 total = carryBits + tot;
+        if (lastTile) {
+          if (tid == 0) {
+            LaneBitW fw; fw.init(S.stage, total);
+            fw.add(S.finalState[2] & ((1u << tlog[2]) - 1), tlog[2]);
+            fw.add(S.finalState[1] & ((1u << tlog[1]) - 1), tlog[1]);
+            fw.add(S.finalState[0] & ((1u << tlog[0]) - 1), tlog[0]);
+            fw.add(1, 1);
+            fw.finish();
+          }
+          total += tlog[0] + tlog[1] + tlog[2] + 1;
+        }
+        __syncthreads();
+        const u32 nbytes = lastTile ? (total + 7) >> 3 : total >> 3;
+        flush_stage(S, op + bytesOut, nbytes);
+        carryBits = lastTile ? 0 : (total & 7);
+        carryVal = (S.stage[nbytes >> 2] >> (8 * (nbytes & 3))) & ((1u << carryBits) - 1);
+        bytesOut += nbytes;
+        __syncthreads();
+      }
+      op += bytesOut;
+      if (tblErr) uncompressible = true;
+      if (lastNCount && (op - lastNCount) < 4) uncompressible = true;
+    }
+    cSize = uncompressible ? 0 : (u32)(op - blk);
+    const u32 minGainB = (L >> (strategy >= 8 ? strategy - 1 : 6)) + 2;
+    if (cSize && cSize >= L - minGainB) cSize = 0;
+    if (!first && cSize < 25) {
+      // RLE block (never the first of a frame): all bytes of the block equal
+      const u8 b0 = src[bs]; u32 diff = 0;
+      for (u32 i = tid; i < L; i += ENT_THREADS) diff |= src[bs + i] != b0;
+      if (!__syncthreads_or((int)diff)) { cSize = 1; if (tid == 0) blk[0] = b0; }
+    }
+  }
+  __syncthreads();
+
+  // ---------------------------------------------------------------- block header, state confirmation, frame tail
+  u32 blockBytes;
+  if (cSize == 0) {
+    for (u32 i = tid; i < L; i += ENT_THREADS) blk[i] = src[bs + i];
+    if (tid == 0) { const u32 h = (u32)last + (0u << 1) + (L << 3); op0[0] = (u8)h; op0[1] = (u8)(h >> 8); op0[2] = (u8)(h >> 16); }
+    blockBytes = 3 + L;
+  } else if (cSize == 1) {
+    if (tid == 0) { const u32 h = (u32)last + (1u << 1) + (L << 3); op0[0] = (u8)h; op0[1] = (u8)(h >> 8); op0[2] = (u8)(h >> 16); }
+    blockBytes = 4;
+  } else {
+    if (tid == 0) { const u32 h = (u32)last + (2u << 1) + (cSize << 3); op0[0] = (u8)h; op0[1] = (u8)(h >> 8); op0[2] = (u8)(h >> 16); }
+    blockBytes = 3 + cSize;
+    if (!last) {
+      // a compressed block confirms repcodes + entropy tables for the next block (A.4.2 / A.4.8)
+      if (tid == 0) { st->rep[0] = bo->rep[0]; st->rep[1] = bo->rep[1]; st->rep[2] = bo->rep[2]; }
+      if (newHuf) {
+        st->hufNbBits[tid] = (u32)tid <= newHufMaxSym ? S.hNb[tid] : 0; st->hufVal[tid] = S.hVal[tid];
+        if (tid == 0) { st->hufRepeat = 1; st->hufMaxSym = newHufMaxSym; }
+      }
+      if (nbSeq) {
+        for (int k = 0; k < 3; k++) {
+          u32* dstT = (u32*)(k == 0 ? &st->ll : k == 1 ? &st->of : &st->ml);
+          const u32* srcT = (const u32*)&S.ct[k];
+          for (u32 i = tid; i < sizeof(ZraFseCTable) / 4; i += ENT_THREADS) dstT[i] = srcT[i];
+        }
+        if (tid == 0) { st->llRepeat = S.nextRepeat[0]; st->ofRepeat = S.nextRepeat[1]; st->mlRepeat = S.nextRepeat[2]; }
+      }
+    }
+  }
+  (void)newHufLog;
+  if (tid == 0) {
+    u32 pos = outPos + blockBytes;
+    if (last) {
+      if (a.checksum) { st32(slot + pos, a.contentCk[f]); pos += 4; }
+      a.sizes[f] = pos;
+    }
+    st->outPos = pos;
+  }
+}

@@ -1,0 +1,299 @@
+// zra_amd — ENCODE stage 1 for gfx950: the match finder (sequence producer) of zstd 1.4.9, bit-exact.
+//
+// Replaces the match-finding ~78-97 % of the reference's per-frame ZSTD_compress2 work (zra.cpp:219,331).
+// One independent frame per workgroup; the workgroup is a single 64-lane wave. The greedy/lazy parse is a
+// strict dependency chain (every table insertion depends on where the previous match ended), so one lane walks
+// it while the whole wave clears the hash tables with coalesced 16-byte stores; throughput comes from thousands
+// of frames in flight (up to 32 waves per CU), not from SIMD inside a frame. Hash tables live in HBM/L2 scratch
+// (64 KiB frames at level 3 need 384 KiB: more than the 160 KiB LDS).
+// Rules restated from SURVEY.md Appendix A.4.3 (validated there against libzstd 1.4.9).
+#include "zra_dev.h"
+#include "zra_kernels.h"
+
+using namespace zra_dev;
+
+namespace {
+
+__device__ __forceinline__ u32 hash4(const u8* p, u32 bits) { return (ld32(p) * 2654435761u) >> (32 - bits); }
+__device__ __forceinline__ u32 hash5(const u8* p, u32 bits) { return (u32)(((ld64(p) << 24) * 889523592379ULL) >> (64 - bits)); }
+__device__ __forceinline__ u32 hash6(const u8* p, u32 bits) { return (u32)(((ld64(p) << 16) * 227718039650203ULL) >> (64 - bits)); }
+__device__ __forceinline__ u32 hash7(const u8* p, u32 bits) { return (u32)(((ld64(p) << 8) * 58295818150454627ULL) >> (64 - bits)); }
+__device__ __forceinline__ u32 hash8(const u8* p, u32 bits) { return (u32)((ld64(p) * 0xCF1BBCDCB7A56463ULL) >> (64 - bits)); }
+__device__ __forceinline__ u32 hashN(const u8* p, u32 bits, u32 mls) {
+  switch (mls) { case 5: return hash5(p, bits); case 6: return hash6(p, bits); case 7: return hash7(p, bits); case 8: return hash8(p, bits); default: return hash4(p, bits); }
+}
+// common-prefix length of src[a..] and src[b..] (b < a), a limited to `end`
+__device__ __forceinline__ u32 count_eq(const u8* src, u32 a, u32 b, u32 end) {
+  u32 l = 0;
+  while (a + l + 8 <= end) {
+    u64 d = ld64(src + a + l) ^ ld64(src + b + l);
+    if (d) return l + ((u32)__builtin_ctzll(d) >> 3);
+    l += 8;
+  }
+  while (a + l < end && src[a + l] == src[b + l]) l++;
+  return l;
+}
+
+struct Emit {
+  u64* seqs; u32 n;
+  __device__ __forceinline__ void put(u32 ll, u32 ml, u32 offVal) { seqs[n++] = (u64)ll | ((u64)ml << 20) | ((u64)offVal << 40); }
+};
+
+__device__ __forceinline__ u32 mf_prologue(u32 bs, u32& o1, u32& o2, u32& saved) {
+  u32 ip = bs + (bs == 0), maxRep = ip;
+  saved = 0;
+  if (o2 > maxRep) { saved = o2; o2 = 0; }
+  if (o1 > maxRep) { saved = o1; o1 = 0; }
+  return ip;
+}
+
+// ---- A.4.3 "fast" (levels 1-2)
+__device__ u32 mf_fast(const ZraEncParams& P, u32* T, const u8* src, u32 bs, u32 be, u32* rep, Emit& E) {
+  const u32 hlog = P.hashLog, mls = P.minMatch;
+  const u32 step0 = P.targetLength + (P.targetLength == 0) + 1;
+  u32 o1 = rep[0], o2 = rep[1], saved;
+  u32 anchor = bs;
+  const u32 ilimit = be - 8;
+  u32 ip0 = mf_prologue(bs, o1, o2, saved), ip1 = ip0 + 1;
+  while (ip1 < ilimit) {
+    const u32 ip2 = ip0 + 2, top = ip0;
+    const u32 h0 = hashN(src + ip0, hlog, mls), h1 = hashN(src + ip1, hlog, mls);
+    const u32 m0 = T[h0], m1 = T[h1];
+    u32 match, ml, offVal;
+    T[h0] = ip0 + 1; T[h1] = ip1 + 1;
+    if (o1 > 0 && ld32(src + ip2 - o1) == ld32(src + ip2)) {
+      const u32 back = src[ip2 - 1] == src[ip2 - o1 - 1];
+      ip0 = ip2 - back; match = ip2 - o1 - back; ml = 4 + back; offVal = 1;
+    } else {
+      if (m0 > 1 && ld32(src + m0 - 1) == ld32(src + ip0)) match = m0 - 1;
+      else if (m1 > 1 && ld32(src + m1 - 1) == ld32(src + ip1)) { ip0 = ip1; match = m1 - 1; }
+      else { const u32 st = ((ip0 - anchor) >> 7) + step0; ip0 += st; ip1 += st; continue; }
+      o2 = o1; o1 = ip0 - match; offVal = o1 + 3; ml = 4;
+      while (ip0 > anchor && match > 0 && src[ip0 - 1] == src[match - 1]) { ip0--; match--; ml++; }
+    }
+    ml += count_eq(src, ip0 + ml, match + ml, be);
+    E.put(ip0 - anchor, ml, offVal);
+    ip0 += ml; anchor = ip0;
+    if (ip0 <= ilimit) {
+      T[hashN(src + top + 2, hlog, mls)] = top + 3;
+      T[hashN(src + ip0 - 2, hlog, mls)] = ip0 - 1;
+      if (o2 > 0) {
+        while (ip0 <= ilimit && ld32(src + ip0) == ld32(src + ip0 - o2)) {
+          const u32 rl = count_eq(src, ip0 + 4, ip0 + 4 - o2, be) + 4;
+          const u32 t = o2; o2 = o1; o1 = t;
+          T[hashN(src + ip0, hlog, mls)] = ip0 + 1;
+          E.put(0, rl, 1);
+          ip0 += rl; anchor = ip0;
+        }
+      }
+    }
+    ip1 = ip0 + 1;
+  }
+  rep[0] = o1 ? o1 : saved; rep[1] = o2 ? o2 : saved;
+  return be - anchor;
+}
+
+// ---- A.4.3 "dfast" (level 3-4): long table keyed by 8 bytes, short table keyed by minMatch bytes
+__device__ u32 mf_dfast(const ZraEncParams& P, u32* HL, u32* HS, const u8* src, u32 bs, u32 be, u32* rep, Emit& E) {
+  const u32 hlog = P.hashLog, clog = P.chainLog, mls = P.minMatch;
+  u32 o1 = rep[0], o2 = rep[1], saved;
+  u32 anchor = bs;
+  const u32 ilimit = be - 8;
+  u32 ip = mf_prologue(bs, o1, o2, saved);
+  while (ip < ilimit) {
+    const u32 top = ip;
+    const u64 v8 = ld64(src + ip);
+    const u32 hL = (u32)((v8 * 0xCF1BBCDCB7A56463ULL) >> (64 - hlog));
+    const u32 hS = mls == 5 ? (u32)(((v8 << 24) * 889523592379ULL) >> (64 - clog)) : hashN(src + ip, clog, mls);
+    const u32 curr = ip + 1;
+    const u32 mL = HL[hL], mS = HS[hS];
+    HL[hL] = curr; HS[hS] = curr;
+    u32 ml, offVal;
+    if (o1 > 0 && ld32(src + ip + 1 - o1) == ld32(src + ip + 1)) {
+      ml = count_eq(src, ip + 5, ip + 5 - o1, be) + 4; ip++; offVal = 1;
+    } else {
+      u32 m;
+      if (mL > 1 && ld64(src + mL - 1) == v8) {
+        m = mL - 1; ml = count_eq(src, ip + 8, m + 8, be) + 8;
+      } else if (mS > 1 && ld32(src + mS - 1) == (u32)v8) {
+        const u32 h3 = hash8(src + ip + 1, hlog), m3 = HL[h3];
+        HL[h3] = curr + 1;
+        if (m3 > 1 && ld64(src + m3 - 1) == ld64(src + ip + 1)) { m = m3 - 1; ip++; ml = count_eq(src, ip + 8, m + 8, be) + 8; }
+        else { m = mS - 1; ml = count_eq(src, ip + 4, m + 4, be) + 4; }
+      } else { ip += ((ip - anchor) >> 8) + 1; continue; }
+      const u32 off = ip - m;
+      while (ip > anchor && m > 0 && src[ip - 1] == src[m - 1]) { ip--; m--; ml++; }
+      o2 = o1; o1 = off; offVal = off + 3;
+    }
+    E.put(ip - anchor, ml, offVal);
+    ip += ml; anchor = ip;
+    if (ip <= ilimit) {
+      const u32 q = top + 2;
+      HL[hash8(src + q, hlog)] = q + 1;
+      HL[hash8(src + ip - 2, hlog)] = ip - 1;
+      HS[hashN(src + q, clog, mls)] = q + 1;
+      HS[hashN(src + ip - 1, clog, mls)] = ip;
+      while (ip <= ilimit && o2 > 0 && ld32(src + ip) == ld32(src + ip - o2)) {
+        const u32 rl = count_eq(src, ip + 4, ip + 4 - o2, be) + 4;
+        const u32 t = o2; o2 = o1; o1 = t;
+        HS[hashN(src + ip, clog, mls)] = ip + 1;
+        HL[hash8(src + ip, hlog)] = ip + 1;
+        E.put(0, rl, 1);
+        ip += rl; anchor = ip;
+      }
+    }
+  }
+  rep[0] = o1 ? o1 : saved; rep[1] = o2 ? o2 : saved;
+  return be - anchor;
+}
+
+// ---- A.4.3 hash chain (greedy depth 0 / lazy 1 / lazy2 2)
+struct HC {
+  u32* hashT; u32* chainT; u32 hlog, mls, cmask, chainSize, searchLog, nextToUpdate;
+  __device__ u32 search(const u8* src, u32 ip, u32 be, u32& offCode) {
+    const u32 target = ip + 1;
+    for (u32 idx = nextToUpdate; idx < target; idx++) {
+      const u32 h = hashN(src + idx - 1, hlog, mls);
+      chainT[idx & cmask] = hashT[h];
+      hashT[h] = idx;
+    }
+    nextToUpdate = target;
+    u32 mi = hashT[hashN(src + ip, hlog, mls)];
+    const u32 curr = target, minChain = curr > chainSize ? curr - chainSize : 0;
+    int attempts = 1 << searchLog;
+    u32 ml = 3;
+    offCode = 999999999u;
+    for (; mi >= 1 && attempts > 0; attempts--) {
+      const u32 m = mi - 1;
+      u32 cur = 0;
+      if (src[m + ml] == src[ip + ml]) cur = count_eq(src, ip, m, be);
+      if (cur > ml) { ml = cur; offCode = curr - mi + 2; if (ip + cur == be) break; }
+      if (mi <= minChain) break;
+      mi = chainT[mi & cmask];
+    }
+    return ml;
+  }
+};
+
+__device__ u32 mf_lazy(HC& H, const u8* src, u32 bs, u32 be, u32* rep, Emit& E, int depth) {
+  u32 o1 = rep[0], o2 = rep[1], saved;
+  u32 anchor = bs;
+  const u32 ilimit = be - 8;
+  u32 ip = mf_prologue(bs, o1, o2, saved);
+  while (ip < ilimit) {
+    u32 ml = 0, start = ip + 1, off = 0; bool stored = false;
+    if (o1 > 0 && ld32(src + ip + 1 - o1) == ld32(src + ip + 1)) {
+      ml = count_eq(src, ip + 5, ip + 5 - o1, be) + 4;
+      if (depth == 0) stored = true;
+    }
+    if (!stored) {
+      u32 oc2; u32 m2 = H.search(src, ip, be, oc2);
+      if (m2 > ml) { ml = m2; start = ip; off = oc2; }
+      if (ml < 4) { ip += ((ip - anchor) >> 8) + 1; continue; }
+      if (depth >= 1) {
+        while (ip < ilimit) {
+          ip++;
+          if (off && o1 > 0 && ld32(src + ip) == ld32(src + ip - o1)) {
+            const u32 mr = count_eq(src, ip + 4, ip + 4 - o1, be) + 4;
+            const int g2 = (int)(mr * 3), g1 = (int)(ml * 3 - hb32(off + 1) + 1);
+            if (mr >= 4 && g2 > g1) { ml = mr; off = 0; start = ip; }
+          }
+          {
+            m2 = H.search(src, ip, be, oc2);
+            const int g2 = (int)(m2 * 4 - hb32(oc2 + 1)), g1 = (int)(ml * 4 - hb32(off + 1) + 4);
+            if (m2 >= 4 && g2 > g1) { ml = m2; off = oc2; start = ip; continue; }
+          }
+          if (depth == 2 && ip < ilimit) {
+            ip++;
+            if (off && o1 > 0 && ld32(src + ip) == ld32(src + ip - o1)) {
+              const u32 mr = count_eq(src, ip + 4, ip + 4 - o1, be) + 4;
+              const int g2 = (int)(mr * 4), g1 = (int)(ml * 4 - hb32(off + 1) + 1);
+              if (mr >= 4 && g2 > g1) { ml = mr; off = 0; start = ip; }
+            }
+            {
+              m2 = H.search(src, ip, be, oc2);
+              const int g2 = (int)(m2 * 4 - hb32(oc2 + 1)), g1 = (int)(ml * 4 - hb32(off + 1) + 7);
+              if (m2 >= 4 && g2 > g1) { ml = m2; off = oc2; start = ip; continue; }
+            }
+          }
+          break;
+        }
+      }
+      if (off) {
+        const u32 ro = off - 2;
+        while (start > anchor && start > ro && src[start - 1] == src[start - ro - 1]) { start--; ml++; }
+        o2 = o1; o1 = ro;
+      }
+    }
+    E.put(start - anchor, ml, off ? off + 1 : 1);
+    anchor = ip = start + ml;
+    while (ip <= ilimit && o2 > 0 && ld32(src + ip) == ld32(src + ip - o2)) {
+      const u32 rl = count_eq(src, ip + 4, ip + 4 - o2, be) + 4;
+      const u32 t = o2; o2 = o1; o1 = t;
+      E.put(0, rl, 1);
+      ip += rl; anchor = ip;
+    }
+  }
+  rep[0] = o1 ? o1 : saved; rep[1] = o2 ? o2 : saved;
+  return be - anchor;
+}
+
+}  // namespace
+
+// One wave per frame; `block` = index of the <=128 KiB block being parsed in this round (A.4.2 driver).
+extern "C" __global__ void __launch_bounds__(64)
+zra_mf_kernel(ZraEncArgs a, u32 block) {
+  const u32 f = blockIdx.x;
+  const int lane = threadIdx.x;
+  const u64 fstart = (u64)(a.firstFrame + f) * a.frameSize;
+  const u64 remaining = a.inSize - fstart;
+  const u32 fsize = (u32)(remaining < a.frameSize ? remaining : a.frameSize);
+  const ZraEncParams& P = (fsize == a.frameSize) ? a.full : a.tail;   // the short last frame has its own cparams (A.4.1)
+  const u32 blockSize = P.blockSize;
+  const u32 bs = block * blockSize;
+  if (bs >= fsize && !(fsize == 0 && block == 0)) return;
+  const u32 be = min(fsize, bs + blockSize);
+  const u8* src = a.in + fstart;
+  ZraEncFrameState* st = &a.state[f];
+  u32* hashT = a.tables + (size_t)f * a.tableStride;
+  u32* chainT = hashT + ((size_t)1 << P.hashLog);
+
+  if (block == 0) {
+    // fresh frame: zeroed tables, repcodes {1,4,8}, nextToUpdate 1 (A.4.8); 16-byte coalesced clears by the whole wave
+    const size_t words = ((size_t)1 << P.hashLog) + ((size_t)1 << P.chainLog);
+    uint4* t4 = (uint4*)hashT;
+    for (size_t i = lane; i < words / 4; i += 64) t4[i] = make_uint4(0, 0, 0, 0);
+    for (size_t i = (words / 4) * 4 + lane; i < words; i += 64) hashT[i] = 0;
+    if (lane == 0) { st->rep[0] = 1; st->rep[1] = 4; st->rep[2] = 8; st->nextToUpdate = 1; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  }
+  if (lane != 0) return;
+
+  const u32 L = be - bs;
+  ZraEncBlockOut* bo = &a.blockOut[f];
+  bo->nbSeq = 0; bo->lastLL = L; bo->skip = 1;
+  if (L < 7) return;                                   // too small to compress (A.4.2) -> raw block
+  bo->skip = 0;
+  Emit E; E.seqs = a.seqs + (size_t)f * a.seqStride; E.n = 0;
+  u32 rep[3] = {st->rep[0], st->rep[1], st->rep[2]};
+  // limited update after a very long match (A.4.3 hash chain prologue; harmless for the other finders)
+  u32 ntu = st->nextToUpdate;
+  {
+    const u32 cur = bs + 1;
+    if (cur > ntu + 384) { const u32 d = cur - ntu - 384; ntu = cur - (d < 192 ? d : 192); }
+  }
+  u32 lastLL;
+  if (P.strategy == 1) lastLL = mf_fast(P, hashT, src, bs, be, rep, E);
+  else if (P.strategy == 2) lastLL = mf_dfast(P, hashT, chainT, src, bs, be, rep, E);
+  else {
+    HC H; H.hashT = hashT; H.chainT = chainT; H.hlog = P.hashLog; H.mls = P.minMatch < 4 ? 4 : P.minMatch > 6 ? 6 : P.minMatch;
+    H.chainSize = 1u << P.chainLog; H.cmask = H.chainSize - 1; H.searchLog = P.searchLog; H.nextToUpdate = ntu;
+    lastLL = mf_lazy(H, src, bs, be, rep, E, (int)P.strategy - 3);
+    ntu = H.nextToUpdate;
+  }
+  st->nextToUpdate = ntu;
+  bo->nbSeq = E.n; bo->lastLL = lastLL;
+  bo->rep[0] = rep[0]; bo->rep[1] = rep[1]; bo->rep[2] = rep[2];   // confirmed by stage 2 only if the block is emitted compressed
+}

@@ -1,0 +1,91 @@
+// zra_amd — host engine: owns one HIP device, one stream and a grow-only scratch pool, and drives the
+// decode / encode kernels. Internal C++ interface used by the C ABI (zra_capi.cpp) and zra_hip.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstddef>
+#include <vector>
+#include "zra_kernels.h"
+
+namespace zra_eng {
+
+struct Status { int zra; int zstd; };   // mirrors ZraStatus (kept free of the public header here)
+enum : int { kSuccess = 0, kZStdError = 1, kVersionLow = 2, kHeaderInvalid = 3, kHeaderIncomplete = 4, kOutOfBounds = 5,
+             kOutputTooSmall = 6, kCompressedTooLarge = 7, kFrameSizeMismatch = 8 };
+inline Status ok() { return {kSuccess, 0}; }
+inline Status zerr(int code) { return {kZStdError, (int)(int8_t)code}; }   // i8 narrowing like zra.cpp:440
+
+// grow-only device allocation
+struct DevBuf {
+  void* p = nullptr; size_t cap = 0;
+  bool reserve(size_t n);
+  void release();
+  template <typename T> T* as() const { return (T*)p; }
+};
+
+// parsed fixed header (host side; zra.cpp:141-163 semantics)
+struct HeaderInfo {
+  uint16_t version; uint32_t size; uint64_t uncompressedSize; uint32_t frameSize, metaOffset, metaSize, seekTableOffset, seekTableSize;
+  uint32_t frames() const { return seekTableSize / 5 ? seekTableSize / 5 - 1 : 0; }
+};
+// parse the 38 fixed bytes; returns a ZRA status code (0 ok)
+int parse_fixed_header(const uint8_t* fixed38, HeaderInfo* h);
+
+class Engine {
+ public:
+  static Status create(Engine** out, int device);
+  ~Engine();
+  hipStream_t stream() const { return stream_; }
+  Status sync();
+  double last_kernel_ms() const { return lastKernelMs_; }
+
+  // ---- decode
+  // Decode nFrames frames described by device job arrays. Synchronises and returns the first failing frame's code.
+  Status decode_jobs(const uint8_t* dBody, uint64_t bodySize, const uint64_t* dFrameOff, uint8_t* dOut,
+                     const uint64_t* dOutOff, const uint32_t* dExpect, uint32_t nFrames, uint32_t offStride = 1);
+  // Whole archive resident on the device (header + body), output on the device.
+  Status decompress_device(const uint8_t* dArc, size_t arcSize, uint8_t* dOut, size_t outCap);
+  // Batched random access, archive + output on the device, query arrays on the host.
+  Status decompress_ra_batch(const uint8_t* dArc, size_t arcSize, uint8_t* dOut, const uint64_t* hOff, const uint64_t* hSize,
+                             const uint64_t* hOutOff, size_t nq);
+  // Host-walked frame list (reference semantics of DecompressBuffer: seek table not consulted). hFrameOff has nFrames+1 entries
+  // relative to dBody; frames are assumed to regenerate frameSize bytes each (last: the remainder of total).
+  Status decompress_frames_host_list(const uint8_t* dBody, uint64_t bodySize, const std::vector<uint64_t>& hFrameOff,
+                                     uint8_t* dOut, uint64_t total, uint32_t frameSize);
+
+  // ---- encode (zra_encode.hip)
+  // Compress frames of `frameSize` from dIn (inSize bytes) into a packed body at dBody; per-frame sizes (u64) to dSizes.
+  Status compress_frames(const uint8_t* dIn, size_t inSize, uint8_t* dBody, uint64_t* dSizes, size_t* bodySize,
+                         int level, uint32_t frameSize, bool checksum);
+  Status compress_impl(const uint8_t* dIn, size_t inSize, uint8_t* dBody, uint64_t bodyBase0, uint8_t* dEntries, uint64_t* dSizes,
+                       size_t* bodySize, int level, uint32_t frameSize, bool checksum);
+  // Full archive (header + table + body) on the device.
+  Status compress_device(const uint8_t* dIn, size_t inSize, uint8_t* dOut, size_t* outSize, int level, uint32_t frameSize, bool checksum);
+
+  // ---- host-pointer helpers (H2D -> kernels -> D2H) behind the reference-compatible C/C++ API
+  Status compress_host(const uint8_t* hIn, size_t n, uint8_t* hOut, size_t* outSize, int level, uint32_t frameSize, bool checksum);
+  Status compress_frames_host(const uint8_t* hIn, size_t n, uint8_t* hBody, std::vector<uint64_t>& sizes, size_t* bodySize,
+                              int level, uint32_t frameSize, bool checksum);
+  // frames given as (start,end) pairs inside hSpan; frame i regenerates min(frameSize, total - i*frameSize) bytes;
+  // bytes [skip, skip+size) of the concatenated output are returned in hOut
+  Status decode_host(const uint8_t* hSpan, size_t spanSize, const std::vector<uint64_t>& starts, const std::vector<uint64_t>& ends,
+                     uint32_t frameSize, uint64_t total, uint8_t* hOut, size_t skip, size_t size);
+
+  int device() const { return device_; }
+  int num_cus() const { return numCUs_; }
+
+ private:
+  Engine() = default;
+  int device_ = 0, numCUs_ = 0;
+  hipStream_t stream_ = nullptr;
+  hipEvent_t ev0_ = nullptr, ev1_ = nullptr;
+  double lastKernelMs_ = 0;
+  // decode scratch
+  DevBuf litScratch_, queue_, status_, produced_, frameMeta_, frameOff_, outOff_, expect_, result_, temp_, qmeta_;
+  // encode scratch (see zra_encode.hip)
+  DevBuf encTables_, encSeqs_, encSlots_, encSizes_, encMisc_, encLits_, encCk_, encScan_;
+  DevBuf hostIn_, hostOut_;
+  friend struct EncodeImpl;
+};
+
+}  // namespace zra_eng

@@ -1,0 +1,314 @@
+// zra_amd — host engine implementation (decode side + shared utility kernels).
+#include "zra_engine.h"
+#include "zra_dev.h"
+#include "zra_format.h"
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+
+extern "C" __global__ void zra_decode_frames_kernel(ZraDecodeArgs a);
+
+using namespace zra_dev;
+
+namespace zra_fmt {
+uint32_t crc32(uint32_t crc, const void* data, size_t n) {
+  static uint32_t T[8][256];
+  static bool init = false;
+  if (!init) {
+    for (uint32_t i = 0; i < 256; i++) {
+      uint32_t c = i;
+      for (int k = 0; k < 8; k++) c = (c & 1) ? (0xEDB88320u ^ (c >> 1)) : (c >> 1);
+      T[0][i] = c;
+    }
+    for (uint32_t i = 0; i < 256; i++)
+      for (int t = 1; t < 8; t++) T[t][i] = (T[t - 1][i] >> 8) ^ T[0][T[t - 1][i] & 0xFF];
+    init = true;
+  }
+  const uint8_t* p = (const uint8_t*)data;
+  crc = ~crc;
+  while (n >= 8) {
+    uint32_t a = rd32(p) ^ crc, b = rd32(p + 4);
+    crc = T[7][a & 0xFF] ^ T[6][(a >> 8) & 0xFF] ^ T[5][(a >> 16) & 0xFF] ^ T[4][a >> 24] ^
+          T[3][b & 0xFF] ^ T[2][(b >> 8) & 0xFF] ^ T[1][(b >> 16) & 0xFF] ^ T[0][b >> 24];
+    p += 8; n -= 8;
+  }
+  while (n--) crc = T[0][(crc ^ *p++) & 0xFF] ^ (crc >> 8);
+  return ~crc;
+}
+}  // namespace zra_fmt
+
+// =================================================================================================
+// utility kernels
+// =================================================================================================
+namespace {
+
+// seek table (5-byte entries inside the archive) -> u64 frame offsets + trivial output layout
+__global__ void zra_jobs_from_seektable_kernel(const u8* table, u32 nFrames, u32 frameSize, u64 total,
+                                               u64* frameOff, u64* outOff, u32* expect) {
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i <= nFrames) {
+    const u8* e = table + (size_t)i * 5;
+    frameOff[i] = (u64)ld32(e) | ((u64)e[4] << 32);
+  }
+  if (i < nFrames) {
+    u64 o = (u64)i * frameSize;
+    outOff[i] = o;
+    u64 rem = total - o;
+    expect[i] = (u32)(rem < frameSize ? rem : frameSize);
+  }
+}
+
+// content-checksum verification of decoded frames: 4 lanes per frame (16 frames per wave)
+__global__ void zra_xxh64_verify_kernel(const u8* out, const u64* outOff, const u32* expect, const u32* frameMeta, u32* status, u32 nFrames) {
+  const u32 gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const u32 f = gid >> 2; const int j = gid & 3;
+  const bool active = f < nFrames && frameMeta[2 * (size_t)f] && status[f] == 0;
+  const u8* p = active ? out + outOff[f] : out;
+  const u32 n = active ? expect[f] : 0;
+  const u64 h = zra_xxh64_quad(p, n, j);
+  if (active && j == 0 && (u32)h != frameMeta[2 * (size_t)f + 1]) status[f] = ZE_CHECKSUM_WRONG;
+}
+
+// result[0] = min over failing frames of (frame << 8 | code); ~0 when all succeeded
+__global__ void zra_first_error_kernel(const u32* status, u32 nFrames, unsigned long long* result) {
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nFrames && status[i]) atomicMin(result, ((unsigned long long)i << 8) | (status[i] & 0xFF));
+}
+
+// random-access gather: query q copies size[q] bytes temp+src[q] -> out+dst[q]; one workgroup per query slice
+__global__ void zra_gather_kernel(const u8* temp, u8* out, const u64* qmeta, u32 nq) {
+  const u32 q = blockIdx.x;
+  if (q >= nq) return;
+  const u64 src = qmeta[3 * (size_t)q], dst = qmeta[3 * (size_t)q + 1], n = qmeta[3 * (size_t)q + 2];
+  const u8* s = temp + src; u8* d = out + dst;
+  const u64 n8 = n >> 3;
+  for (u64 i = threadIdx.x; i < n8; i += blockDim.x) st64(d + 8 * i, ld64(s + 8 * i));
+  for (u64 i = (n8 << 3) + threadIdx.x; i < n; i += blockDim.x) d[i] = s[i];
+}
+
+}  // namespace
+
+// =================================================================================================
+namespace zra_eng {
+
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { last_hip_error = e_; return zerr(1); } } while (0)
+static thread_local hipError_t last_hip_error = hipSuccess;
+
+bool DevBuf::reserve(size_t n) {
+  if (n <= cap) return true;
+  if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+  size_t want = n + n / 8 + 256;
+  if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; cap = 0; return false; }
+  cap = want;
+  return true;
+}
+void DevBuf::release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+
+int parse_fixed_header(const uint8_t* b, HeaderInfo* h) {
+  using namespace zra_fmt;
+  if (rd32(b + 8) != kZraMagic || rd16(b + 12) > kVersion) return kHeaderInvalid;   // zra.cpp:144-145
+  h->version = rd16(b + 12);
+  h->size = rd32(b + 4) + 8;
+  h->uncompressedSize = rd64(b + 18);
+  h->frameSize = rd32(b + 30);
+  h->metaOffset = (uint32_t)kFixedSize;
+  h->metaSize = rd32(b + 34);
+  h->seekTableOffset = h->metaOffset + h->metaSize;
+  h->seekTableSize = rd32(b + 26) * (uint32_t)kEntrySize;
+  if (h->version != 1) return kVersionLow;                                           // zra.cpp:156-162
+  return 0;
+}
+
+Status Engine::create(Engine** out, int device) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return zerr(1);
+  HIPCHK(hipSetDevice(device));
+  Engine* e = new Engine();
+  e->device_ = device;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete e; return zerr(1); }
+  e->numCUs_ = prop.multiProcessorCount;
+  if (hipStreamCreateWithFlags(&e->stream_, hipStreamNonBlocking) != hipSuccess) { delete e; return zerr(1); }
+  if (hipEventCreate(&e->ev0_) != hipSuccess || hipEventCreate(&e->ev1_) != hipSuccess) { delete e; return zerr(1); }
+  *out = e;
+  return ok();
+}
+
+Engine::~Engine() {
+  (void)hipSetDevice(device_);
+  if (stream_) (void)hipStreamSynchronize(stream_);
+  for (DevBuf* b : {&litScratch_, &queue_, &status_, &produced_, &frameMeta_, &frameOff_, &outOff_, &expect_, &result_, &temp_, &qmeta_,
+                    &encTables_, &encSeqs_, &encSlots_, &encSizes_, &encMisc_, &encLits_, &encCk_, &encScan_, &hostIn_, &hostOut_})
+    b->release();
+  if (ev0_) (void)hipEventDestroy(ev0_);
+  if (ev1_) (void)hipEventDestroy(ev1_);
+  if (stream_) (void)hipStreamDestroy(stream_);
+}
+
+Status Engine::sync() { HIPCHK(hipSetDevice(device_)); HIPCHK(hipStreamSynchronize(stream_)); return ok(); }
+
+Status Engine::decode_jobs(const uint8_t* dBody, uint64_t bodySize, const uint64_t* dFrameOff, uint8_t* dOut,
+                           const uint64_t* dOutOff, const uint32_t* dExpect, uint32_t nFrames, uint32_t offStride) {
+  if (nFrames == 0) return ok();
+  HIPCHK(hipSetDevice(device_));
+  int perCU = 0;
+  HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, zra_decode_frames_kernel, 256, 0));
+  if (perCU < 1) perCU = 1;
+  uint32_t grid = (uint32_t)std::min<uint64_t>(nFrames, (uint64_t)numCUs_ * perCU);
+  if (!litScratch_.reserve((size_t)grid * ZRA_LIT_STRIDE) || !queue_.reserve(64) || !status_.reserve((size_t)nFrames * 4) ||
+      !produced_.reserve((size_t)nFrames * 4) || !frameMeta_.reserve((size_t)nFrames * 8) || !result_.reserve(64))
+    return zerr(64 /* memory_allocation */);
+  HIPCHK(hipMemsetAsync(queue_.p, 0, 64, stream_));
+  HIPCHK(hipMemsetAsync(result_.p, 0xFF, 64, stream_));
+  ZraDecodeArgs a;
+  a.body = dBody; a.bodySize = bodySize; a.frameOff = dFrameOff; a.out = dOut; a.outOff = dOutOff; a.outCap = dExpect; a.outExpect = dExpect;
+  a.nFrames = nFrames; a.offStride = offStride; a.queue = queue_.as<uint32_t>(); a.litScratch = litScratch_.as<uint8_t>();
+  a.status = status_.as<uint32_t>(); a.produced = produced_.as<uint32_t>(); a.frameMeta = frameMeta_.as<uint32_t>();
+  HIPCHK(hipEventRecord(ev0_, stream_));
+  hipLaunchKernelGGL(zra_decode_frames_kernel, dim3(grid), dim3(256), 0, stream_, a);
+  HIPCHK(hipEventRecord(ev1_, stream_));
+  const uint32_t tb = 256;
+  hipLaunchKernelGGL(zra_xxh64_verify_kernel, dim3((nFrames * 4 + tb - 1) / tb), dim3(tb), 0, stream_, dOut, dOutOff, dExpect,
+                     frameMeta_.as<uint32_t>(), status_.as<uint32_t>(), nFrames);
+  hipLaunchKernelGGL(zra_first_error_kernel, dim3((nFrames + tb - 1) / tb), dim3(tb), 0, stream_, status_.as<uint32_t>(), nFrames,
+                     result_.as<unsigned long long>());
+  unsigned long long res = 0;
+  HIPCHK(hipMemcpyAsync(&res, result_.p, 8, hipMemcpyDeviceToHost, stream_));
+  HIPCHK(hipStreamSynchronize(stream_));
+  HIPCHK(hipGetLastError());
+  float ms = 0;
+  if (hipEventElapsedTime(&ms, ev0_, ev1_) == hipSuccess) lastKernelMs_ = ms;
+  if (res != ~0ull) return zerr((int)(res & 0xFF));
+  return ok();
+}
+
+Status Engine::decompress_device(const uint8_t* dArc, size_t arcSize, uint8_t* dOut, size_t outCap) {
+  HIPCHK(hipSetDevice(device_));
+  if (arcSize <= zra_fmt::kFixedSize) return {kOutOfBounds, 0};          // BufferView reader quirk, zra.cpp:166
+  uint8_t fixed[zra_fmt::kFixedSize];
+  HIPCHK(hipMemcpyAsync(fixed, dArc, sizeof(fixed), hipMemcpyDeviceToHost, stream_));
+  HIPCHK(hipStreamSynchronize(stream_));
+  HeaderInfo h;
+  if (int e = parse_fixed_header(fixed, &h)) return {e, 0};
+  if (arcSize < h.size) return {kOutOfBounds, 0};                          // zra.cpp:169-170
+  if (outCap < h.uncompressedSize) return {kOutputTooSmall, 0};            // zra.cpp:245-246
+  const uint32_t nFrames = h.frames();
+  if (nFrames == 0 || h.frameSize == 0) return ok();
+  if ((uint64_t)h.seekTableOffset + h.seekTableSize > h.size) return {kHeaderInvalid, 0};
+  if (!frameOff_.reserve(((size_t)nFrames + 1) * 8) || !outOff_.reserve((size_t)nFrames * 8) || !expect_.reserve((size_t)nFrames * 4))
+    return zerr(64);
+  hipLaunchKernelGGL(zra_jobs_from_seektable_kernel, dim3((nFrames + 256) / 256), dim3(256), 0, stream_, dArc + h.seekTableOffset,
+                     nFrames, h.frameSize, h.uncompressedSize, frameOff_.as<uint64_t>(), outOff_.as<uint64_t>(), expect_.as<uint32_t>());
+  return decode_jobs(dArc + h.size, arcSize - h.size, frameOff_.as<uint64_t>(), dOut, outOff_.as<uint64_t>(), expect_.as<uint32_t>(), nFrames);
+}
+
+Status Engine::decompress_frames_host_list(const uint8_t* dBody, uint64_t bodySize, const std::vector<uint64_t>& hFrameOff,
+                                           uint8_t* dOut, uint64_t total, uint32_t frameSize) {
+  HIPCHK(hipSetDevice(device_));
+  const uint32_t nFrames = (uint32_t)(hFrameOff.size() - 1);
+  if (nFrames == 0) return ok();
+  std::vector<uint64_t> oo(nFrames); std::vector<uint32_t> ex(nFrames);
+  for (uint32_t i = 0; i < nFrames; i++) {
+    uint64_t o = (uint64_t)i * frameSize;
+    oo[i] = o;
+    ex[i] = o >= total ? 0 : (uint32_t)std::min<uint64_t>(frameSize, total - o);
+  }
+  if (!frameOff_.reserve(((size_t)nFrames + 1) * 8) || !outOff_.reserve((size_t)nFrames * 8) || !expect_.reserve((size_t)nFrames * 4))
+    return zerr(64);
+  HIPCHK(hipMemcpyAsync(frameOff_.p, hFrameOff.data(), ((size_t)nFrames + 1) * 8, hipMemcpyHostToDevice, stream_));
+  HIPCHK(hipMemcpyAsync(outOff_.p, oo.data(), (size_t)nFrames * 8, hipMemcpyHostToDevice, stream_));
+  HIPCHK(hipMemcpyAsync(expect_.p, ex.data(), (size_t)nFrames * 4, hipMemcpyHostToDevice, stream_));
+  HIPCHK(hipStreamSynchronize(stream_));   // host vectors go out of scope
+  return decode_jobs(dBody, bodySize, frameOff_.as<uint64_t>(), dOut, outOff_.as<uint64_t>(), expect_.as<uint32_t>(), nFrames);
+}
+
+Status Engine::decompress_ra_batch(const uint8_t* dArc, size_t arcSize, uint8_t* dOut, const uint64_t* hOff, const uint64_t* hSize,
+                                   const uint64_t* hOutOff, size_t nq) {
+  HIPCHK(hipSetDevice(device_));
+  if (arcSize <= zra_fmt::kFixedSize) return {kOutOfBounds, 0};
+  uint8_t fixed[zra_fmt::kFixedSize];
+  HIPCHK(hipMemcpyAsync(fixed, dArc, sizeof(fixed), hipMemcpyDeviceToHost, stream_));
+  HIPCHK(hipStreamSynchronize(stream_));
+  HeaderInfo h;
+  if (int e = parse_fixed_header(fixed, &h)) return {e, 0};
+  if (arcSize < h.size) return {kOutOfBounds, 0};
+  const uint32_t nFrames = h.frames();
+  const uint64_t fs = h.frameSize;
+  for (size_t q = 0; q < nq; q++)
+    if (hOff[q] + hSize[q] >= h.uncompressedSize) return {kOutOfBounds, 0};   // ">=" quirk, zra.cpp:260
+  if (nq == 0 || fs == 0) return ok();
+  // seek table to the host once (5 B/frame) so jobs can be built without device round trips
+  std::vector<uint8_t> table((size_t)h.seekTableSize);
+  HIPCHK(hipMemcpyAsync(table.data(), dArc + h.seekTableOffset, table.size(), hipMemcpyDeviceToHost, stream_));
+  HIPCHK(hipStreamSynchronize(stream_));
+  // touched-frame map -> dense slot numbering (no sort: a query's frames are consecutive, so are their slots)
+  std::vector<uint32_t> slot((size_t)nFrames + 1, 0);
+  for (size_t q = 0; q < nq; q++) {
+    if (hSize[q] == 0) continue;
+    uint64_t f0 = hOff[q] / fs, f1 = (hOff[q] + hSize[q] - 1) / fs;
+    for (uint64_t f = f0; f <= f1; f++) slot[f] = 1;
+  }
+  // queries bucketed by first frame (counting sort over frames keeps this O(nq + nFrames))
+  std::vector<size_t> order(nq);
+  {
+    std::vector<uint32_t> head((size_t)nFrames + 2, 0);
+    for (size_t q = 0; q < nq; q++) head[std::min<uint64_t>(hOff[q] / fs, nFrames) + 1]++;
+    for (size_t f = 0; f <= nFrames; f++) head[f + 1] += head[f];
+    for (size_t q = 0; q < nq; q++) order[head[std::min<uint64_t>(hOff[q] / fs, nFrames)]++] = q;
+  }
+  // passes bounded by a temp budget (decoded frames per pass); a pass is cut only where no taken query straddles
+  const uint64_t budgetFrames = std::max<uint64_t>(1, (4ull << 30) / fs);
+  std::vector<uint64_t> se, jobOut, qmeta, frameSlot;
+  std::vector<uint32_t> jobExp;
+  size_t qi = 0;
+  while (qi < nq) {
+    se.clear(); jobOut.clear(); jobExp.clear(); qmeta.clear(); frameSlot.clear();
+    const uint64_t fstart = hOff[order[qi]] / fs;
+    uint64_t nslots = 0, maxFrameEnd = fstart, fcur = fstart;
+    size_t qj = qi;
+    for (; qj < nq; qj++) {
+      const size_t q = order[qj];
+      const uint64_t f0 = hOff[q] / fs, f1 = hSize[q] ? (hOff[q] + hSize[q] - 1) / fs : f0;
+      if (nslots >= budgetFrames && f0 >= maxFrameEnd) break;
+      for (; fcur <= f1 && fcur < nFrames; fcur++) {
+        if (!slot[fcur]) { frameSlot.push_back(~0ull); continue; }
+        frameSlot.push_back(nslots);
+        se.push_back(zra_fmt::entry_get(&table[fcur * 5]));          // frame start inside the body
+        se.push_back(zra_fmt::entry_get(&table[(fcur + 1) * 5]));    // frame end
+        jobOut.push_back(nslots * fs);
+        jobExp.push_back((uint32_t)std::min<uint64_t>(fs, h.uncompressedSize - fcur * fs));
+        nslots++;
+      }
+      if (hSize[q]) {
+        qmeta.push_back(frameSlot[f0 - fstart] * fs + hOff[q] % fs);
+        qmeta.push_back(hOutOff[q]);
+        qmeta.push_back(hSize[q]);
+      }
+      maxFrameEnd = std::max(maxFrameEnd, f1 + 1);
+    }
+    const uint32_t nj = (uint32_t)nslots;
+    if (nj) {
+      if (!temp_.reserve((size_t)nj * fs + 64) || !frameOff_.reserve(se.size() * 8) || !outOff_.reserve((size_t)nj * 8) ||
+          !expect_.reserve((size_t)nj * 4) || !qmeta_.reserve(qmeta.size() * 8 + 8))
+        return zerr(64);
+      HIPCHK(hipMemcpyAsync(frameOff_.p, se.data(), se.size() * 8, hipMemcpyHostToDevice, stream_));
+      HIPCHK(hipMemcpyAsync(outOff_.p, jobOut.data(), (size_t)nj * 8, hipMemcpyHostToDevice, stream_));
+      HIPCHK(hipMemcpyAsync(expect_.p, jobExp.data(), (size_t)nj * 4, hipMemcpyHostToDevice, stream_));
+      if (!qmeta.empty()) HIPCHK(hipMemcpyAsync(qmeta_.p, qmeta.data(), qmeta.size() * 8, hipMemcpyHostToDevice, stream_));
+      HIPCHK(hipStreamSynchronize(stream_));
+      // frames of a pass are not adjacent in the body: each job carries its own (start, end) pair -> offset stride 2
+      Status s = decode_jobs(dArc + h.size, arcSize - h.size, frameOff_.as<uint64_t>(), temp_.as<uint8_t>(), outOff_.as<uint64_t>(),
+                             expect_.as<uint32_t>(), nj, 2);
+      if (s.zra) return s;
+      const uint32_t nqPass = (uint32_t)(qmeta.size() / 3);
+      if (nqPass) {
+        hipLaunchKernelGGL(zra_gather_kernel, dim3(nqPass), dim3(256), 0, stream_, temp_.as<uint8_t>(), dOut, qmeta_.as<uint64_t>(), nqPass);
+        HIPCHK(hipStreamSynchronize(stream_));
+      }
+    }
+    qi = qj;
+  }
+  return ok();
+}
+
+}  // namespace zra_eng
