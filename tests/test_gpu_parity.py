@@ -1,0 +1,240 @@
+"""GPU parity tests (run with -m gpu on the MI355X box). Every call goes through the C ABI of libzra_amd.so (ctypes); results are
+compared with the CPU oracle (oracle/, bit-exact: integer/byte work, no tolerance) on the same seeded inputs, with the committed
+golden fixtures, and — at BASELINE sizes — through size-independent properties (round trip, idempotence, seek-table invariants)."""
+import base64
+import ctypes
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import corpus as C
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def gens():
+    return {"A": C.gen_A(1 << 19), "B": C.gen_B(1 << 19), "C": C.gen_C(1 << 20), "D": C.gen_D(1 << 20), "E": C.gen_E(1 << 20),
+            "F": C.gen_struct(1 << 19), "G": C.gen_alpha4(1 << 18), "H": C.gen_litrle(1 << 19), "L": C.gen_loglike(1 << 20)}
+
+
+def test_extension_is_loaded_and_gpu_visible(zra):
+    assert zra.load().ZraHipDeviceCount() >= 1
+    assert os.path.exists(zra.LIB_PATH)
+
+
+@pytest.mark.parametrize("level,fs", [(3, 65536), (0, 16384), (3, 16384), (1, 65536), (2, 65536), (4, 65536), (5, 65536), (6, 65536), (7, 65536),
+                                      (9, 65536), (10, 65536), (3, 262144), (9, 262144), (5, 262144), (3, 100000), (3, 4096), (1, 200000)])
+def test_compress_buffer_bit_exact(zra, gens, level, fs):
+    for name, d in gens.items():
+        d = d[: 5 * fs + 777] if fs >= 65536 else d[: 37 * fs + 11]
+        st, ref = O.zra_compress(d, level, fs, True)
+        if st != (0, 0):
+            # strategy outside the engine's set (e.g. btlazy2 for a short last frame at level 9): must be refused, not faked
+            with pytest.raises(zra.ZraError) as e:
+                zra.CompressBuffer(d, level, fs, True)
+            assert (e.value.zra, e.value.zstd) == st
+            continue
+        arc = zra.CompressBuffer(d, level, fs, True)
+        assert arc == ref, (name, level, fs, len(arc), len(ref))
+        assert zra.DecompressBuffer(arc) == d
+
+
+def test_compress_edge_cases(zra):
+    assert zra.CompressBuffer(b"abcdefghij", 3, 4, True) == open(os.path.join(GOLD, "g1_abcdefghij_fs4.zra"), "rb").read()
+    assert zra.CompressBuffer(b"", 3, 65536, True) == open(os.path.join(GOLD, "g1_empty_fs65536.zra"), "rb").read()
+    for d, fs, ck in ((b"a", 16384, True), (b"ab" * 3, 65536, False), (b"z" * 7, 4, True), (bytes(range(256)) * 3, 256, False), (b"q" * 65537, 65536, True)):
+        st, ref = O.zra_compress(d, 3, fs, ck)
+        assert zra.CompressBuffer(d, 3, fs, ck) == ref
+        assert zra.DecompressBuffer(ref) == d
+    # reference quirk: non-empty meta in the in-memory call changes header fields + CRC only (zra.cpp:202-205)
+    d = C.gen_C(100000)
+    st, ref = O.zra_compress(d, 3, 16384, True, 5)
+    assert zra.CompressBuffer(d, 3, 16384, True, b"12345") == ref
+    # levels the engine does not implement are refused with parameter_unsupported, never served by a CPU codec
+    with pytest.raises(zra.ZraError) as e:
+        zra.CompressBuffer(d, 19, 16384, True)
+    assert (e.value.zra, e.value.zstd) == (1, 40)
+    # output buffer too small is detected before any work (zra.cpp:196-198)
+    L = zra.load()
+    osz = ctypes.c_size_t(0)
+    assert L.ZraGetCompressedOutputBufferSize(len(d), 16384) > 0
+
+
+def test_golden_frames_decode_on_gpu(zra):
+    gensm = {"C": C.gen_C(1 << 20), "D": C.gen_D(1 << 20), "E": C.gen_E(1 << 20), "F": C.gen_struct(1 << 19), "G": C.gen_alpha4(1 << 18),
+             "H": C.gen_litrle(1 << 19), "L": C.gen_loglike(1 << 20), "A": C.gen_A(1 << 18), "B": C.gen_B(1 << 18)}
+    for fr in json.load(open(os.path.join(GOLD, "frames.json"))):
+        data = gensm[fr["gen"]][fr["off"]: fr["off"] + fr["n"]]
+        frame = base64.b64decode(fr["frame_b64"])
+        arc = zra.stitch_header([len(frame)], len(data), max(len(data), 1)) + frame     # one-frame archive around the dependency's frame
+        assert zra.DecompressBuffer(arc) == data, fr["level"]
+    for name in ("A_zeros.l3.zra", "A_zeros.l9.zra"):
+        assert zra.DecompressBuffer(open(os.path.join(GOLD, name), "rb").read()) == bytes(1 << 20)
+
+
+def test_error_table_on_gpu(zra):
+    e = json.load(open(os.path.join(GOLD, "errors.json")))
+    data = C.gen_E(1 << 20)[e["input"]["off"]: e["input"]["off"] + e["input"]["n"]]
+    arc = zra.CompressBuffer(data, e["level"], e["frame_size"], True)
+    assert hashlib.sha256(arc).hexdigest() == e["archive_sha256"]
+    L = zra.load()
+    for row in e["mutations"]:
+        m = row["mutation"]
+        a = bytearray(arc)
+        if m["pos"] is not None:
+            a[m["pos"]] ^= m["xor"]
+        if m["set"]:
+            a[m["set"][0]: m["set"][0] + 2] = bytes(m["set"][1:])
+        if m["trunc"] is not None:
+            a = a[: m["trunc"]]
+        out = ctypes.create_string_buffer(len(data) + 16)
+        st = L.ZraDecompressBuffer(ctypes.create_string_buffer(bytes(a), len(a)), len(a), out).tup()
+        assert list(st) == row["full"], (m["name"], st, row["full"])
+        if st == (0, 0):
+            assert out.raw[: len(data)] == data
+    for r in e["ra_bounds"]:
+        out = ctypes.create_string_buffer(max(r["size"], 1))
+        st = L.ZraDecompressRA(ctypes.create_string_buffer(arc, len(arc)), len(arc), out, r["offset"], r["size"]).tup()
+        assert list(st) == r["status"], r
+        if st == (0, 0):
+            assert out.raw[: r["size"]] == data[r["offset"]: r["offset"] + r["size"]]
+
+
+def test_decompress_ra_vs_bruteforce(zra):
+    data = C.gen_loglike(700000)
+    rng = np.random.RandomState(3)
+    for level, fs in ((3, 65536), (3, 16384), (9, 262144)):
+        st, arc = O.zra_compress(data, level, fs, True)
+        qs = [(0, 1), (fs - 1, 2), (fs, fs), (fs + 1, 2 * fs), (1234, 500000), (len(data) - 2, 1), (3 * fs - 5, 5), (0, len(data) - 1)]
+        qs += [(int(o), int(s)) for o, s in zip(rng.randint(0, len(data) - 70000, 20), rng.randint(1, 69999, 20))]
+        for off, size in qs:
+            if off + size >= len(data):
+                continue
+            assert zra.DecompressRA(arc, off, size) == data[off: off + size], (fs, off, size)
+
+
+def test_streaming_objects(zra):
+    L = zra.load()
+    data = C.gen_E(1 << 20)[200000:200000 + 16384 * 9 + 1000]
+    meta = b"meta-bytes"
+    st, ref_nometa = O.zra_compress(data, 3, 16384, True)
+    # ---- Compressor: chunks of 3 frames, last chunk ragged; body chunks + deferred header == in-memory archive (no meta)
+    for m in (b"", meta):
+        c = ctypes.c_void_p()
+        mb = ctypes.create_string_buffer(m, len(m)) if m else None
+        assert L.ZraCreateCompressor(ctypes.byref(c), len(data), 3, 16384, True, mb, len(m)).tup() == (0, 0)
+        body = b""
+        pos = 0
+        while pos < len(data):
+            chunk = data[pos: pos + 3 * 16384]
+            out = ctypes.create_string_buffer(L.ZraGetOutputBufferSizeWithCompressor(c, len(chunk)))
+            osz = ctypes.c_size_t(0)
+            assert L.ZraCompressWithCompressor(c, ctypes.create_string_buffer(chunk, len(chunk)), len(chunk), out, ctypes.byref(osz)).tup() == (0, 0)
+            body += out.raw[: osz.value]
+            pos += len(chunk)
+        hsz = L.ZraGetHeaderSizeWithCompressor(c)
+        hb = ctypes.create_string_buffer(hsz)
+        assert L.ZraGetHeaderWithCompressor(c, hb).tup() == (0, 0)
+        arc = hb.raw[:hsz] + body
+        if not m:
+            assert arc == ref_nometa
+        L.ZraDeleteCompressor(c)
+        # mismatch: a non-final chunk that is not a frame multiple
+        c2 = ctypes.c_void_p()
+        assert L.ZraCreateCompressor(ctypes.byref(c2), len(data), 3, 16384, True, None, 0).tup() == (0, 0)
+        out = ctypes.create_string_buffer(L.ZraGetOutputBufferSizeWithCompressor(c2, 20000))
+        osz = ctypes.c_size_t(0)
+        assert L.ZraCompressWithCompressor(c2, ctypes.create_string_buffer(data[:20000], 20000), 20000, out, ctypes.byref(osz)).tup() == (8, 0)
+        L.ZraDeleteCompressor(c2)
+
+        # ---- Decompressor / FullDecompressor over the archive via read callbacks
+        def rd(off, size, outp, arc=arc):
+            ctypes.memmove(outp, arc[off: off + size], size)
+        cb = zra.READ_FN(rd)
+        d = ctypes.c_void_p()
+        assert L.ZraCreateDecompressor(ctypes.byref(d), cb, 1 << 20).tup() == (0, 0)
+        h = L.ZraGetHeaderWithDecompressor(d)
+        assert L.ZraGetUncompressedSizeWithHeader(h) == len(data) and L.ZraGetMetadataSize(h) == len(m)
+        if m:
+            mbuf = ctypes.create_string_buffer(len(m))
+            L.ZraGetMetadata(h, mbuf)
+            assert mbuf.raw == m
+        for off, size in ((0, 100), (16000, 1000), (5, len(data) - 5), (len(data) - 1, 1), (16384 * 2, 16384)):
+            out = ctypes.create_string_buffer(size)
+            assert L.ZraDecompressWithDecompressor(d, off, size, out).tup() == (0, 0)   # ">" bound: last byte IS reachable here (zra.cpp:370)
+            assert out.raw == data[off: off + size]
+        out = ctypes.create_string_buffer(16)
+        assert L.ZraDecompressWithDecompressor(d, len(data) - 1, 2, out).tup() == (5, 0)
+        L.ZraDeleteDecompressor(d)
+        fd = ctypes.c_void_p()
+        assert L.ZraCreateFullDecompressor(ctypes.byref(fd), cb, 0).tup() == (0, 0)
+        got = b""
+        cap = 16384 * 4 + 100
+        out = ctypes.create_string_buffer(cap)
+        while True:
+            osz = ctypes.c_size_t(0)
+            assert L.ZraDecompressWithFullDecompressor(fd, out, cap, ctypes.byref(osz)).tup() == (0, 0)
+            if osz.value == 0:
+                break
+            got += out.raw[: osz.value]
+        assert got == data
+        small = ctypes.create_string_buffer(100)
+        osz = ctypes.c_size_t(0)
+        assert L.ZraDecompressWithFullDecompressor(fd, small, 100, ctypes.byref(osz)).tup() == (6, 0)
+        L.ZraDeleteFullDecompressor(fd)
+
+
+def test_device_api_at_baseline_size_properties(zra, gpu_engine):
+    """BASELINE config C2: 1 GiB, frameSize 64 KiB, level 3 on one MI355X — device-resident, checked through properties + sampled oracle parity."""
+    import torch
+    dev = torch.device("cuda", 0)
+    base = np.frombuffer(C.gen_E(1 << 20) + C.gen_loglike(1 << 20) + C.gen_struct(1 << 19) + C.gen_D(1 << 19), dtype=np.uint8)
+    N = 1 << 30
+    fs = 65536
+    d_in = torch.from_numpy(base.copy()).to(dev).repeat(N // len(base) + 1)[:N].contiguous()
+    bound = zra.GetOutputBufferSize(N, fs)
+    d_arc = torch.empty(bound + 64, dtype=torch.uint8, device=dev)
+    n1 = gpu_engine.compress(d_in.data_ptr(), N, d_arc.data_ptr(), 3, fs, True)
+    arc_head = d_arc[: 38 + 5 * (N // fs + 1)].cpu().numpy().tobytes()
+    # seek-table invariants: monotone, starts at 0, sentinel == body size, CRC-32 of the header matches
+    nent = N // fs + 1
+    ent = np.array([int.from_bytes(arc_head[38 + 5 * i: 43 + 5 * i], "little") for i in range(nent)], dtype=np.int64)
+    assert ent[0] == 0 and np.all(np.diff(ent) > 0) and ent[-1] == n1 - len(arc_head)
+    import zlib
+    assert int.from_bytes(arc_head[14:18], "little") == zlib.crc32(arc_head[18:], zlib.crc32(arc_head[:14]))
+    # idempotence: same bytes on a second pass
+    d_arc2 = torch.empty(bound + 64, dtype=torch.uint8, device=dev)
+    n2 = gpu_engine.compress(d_in.data_ptr(), N, d_arc2.data_ptr(), 3, fs, True)
+    assert n1 == n2 and torch.equal(d_arc[:n1], d_arc2[:n2])
+    del d_arc2
+    # sampled bit-exactness: the corpus repeats every len(base) bytes, so the first 3.5 MiB of frames are checked against the oracle
+    nchk = len(base) // fs
+    st, ref = O.zra_compress(base.tobytes()[: nchk * fs], 3, fs, True)
+    refbody = ref[38 + 5 * (nchk + 1):]
+    got = d_arc[len(arc_head): len(arc_head) + len(refbody)].cpu().numpy().tobytes()
+    assert got == refbody
+    # round trip
+    d_out = torch.empty(N, dtype=torch.uint8, device=dev)
+    gpu_engine.decompress(d_arc.data_ptr(), n1, d_out.data_ptr(), N)
+    assert torch.equal(d_out, d_in)
+    # batched random access == slices of the input
+    rng = np.random.RandomState(42)
+    q = 20000
+    offs = rng.randint(0, N - 70000, size=q).astype(np.uint64)
+    sizes = rng.choice([1, 100, 4096, 65536, 70000 - 1], size=q).astype(np.uint64)
+    oo = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.uint64)
+    d_ra = torch.zeros(int(sizes.sum()) + 64, dtype=torch.uint8, device=dev)
+    gpu_engine.decompress_ra_batch(d_arc.data_ptr(), n1, d_ra.data_ptr(), offs, sizes, oo)
+    for i in rng.randint(0, q, size=300):
+        o, s, w = int(offs[i]), int(sizes[i]), int(oo[i])
+        assert torch.equal(d_ra[w: w + s], d_in[o: o + s]), i
+    # RA bound quirk is kept in the batched call too
+    with pytest.raises(zra.ZraError) as e:
+        gpu_engine.decompress_ra_batch(d_arc.data_ptr(), n1, d_ra.data_ptr(), np.array([N - 10], dtype=np.uint64), np.array([10], dtype=np.uint64), np.array([0], dtype=np.uint64))
+    assert e.value.zra == 5

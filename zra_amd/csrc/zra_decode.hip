@@ -375,7 +375,7 @@ zra_decode_frames_kernel(ZraDecodeArgs a) {
           u32 payload = S.blkType == 1 ? 1 : S.blkSize;
           if (S.blkType == 3) S.err = ZE_CORRUPTION;
           else if (payload > srcSize - pos) S.err = ZE_SRCSIZE_WRONG;
-          else if (S.blkType == 2 && S.blkSize > BLOCK_MAX) S.err = ZE_CORRUPTION;
+          else if (S.blkType == 2 && S.blkSize >= BLOCK_MAX) S.err = ZE_SRCSIZE_WRONG;   // the constant, not the window-derived maximum (as the dependency's one-shot decoder)
           else if (S.blkType != 2 && S.blkSize > dstCap - S.produced) S.err = ZE_DSTSIZE_TOOSMALL;
           S.blkPos = pos;
         }
