@@ -5,6 +5,7 @@
 #include "zra_dev.h"
 #include "zra_format.h"
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -163,7 +164,11 @@ Status Engine::compress_impl(const uint8_t* dIn, size_t inSize, uint8_t* dBody, 
     const uint32_t rounds = (uint32_t)((firstFrameSize + P0.blockSize - 1) / P0.blockSize);
     HIPCHK(hipEventRecord(ev0_, stream_));
     for (uint32_t blk = 0; blk < rounds; blk++) {
-      hipLaunchKernelGGL(zra_mf_kernel, dim3(nb), dim3(64), 0, stream_, a, blk);
+      {
+        // occupancy experiment knob (bring-up): dynamic LDS per workgroup caps the frames in flight per CU
+        static const int dynLds = std::getenv("ZRA_MF_LDS") ? std::atoi(std::getenv("ZRA_MF_LDS")) : 0;
+        hipLaunchKernelGGL(zra_mf_kernel, dim3(nb), dim3(64), dynLds, stream_, a, blk);
+      }
       hipLaunchKernelGGL(zra_entropy_kernel, dim3(nb), dim3(256), 0, stream_, a, blk);
     }
     HIPCHK(hipEventRecord(ev1_, stream_));
