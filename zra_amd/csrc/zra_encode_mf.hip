@@ -238,6 +238,154 @@ __device__ u32 mf_lazy(HC& H, const u8* src, u32 bs, u32 be, u32* rep, Emit& E, 
   return be - anchor;
 }
 
+
+// ================================================================================================
+// Wave-cooperative dfast (A.4.3), bit-exact with the serial formulation above.
+//
+// The serial parse visits positions ip, ip+s, ip+2s, ... (s = 1 + literal-run/256) and at each one (a) looks two hash
+// buckets up, (b) inserts the position, (c) tests three candidates; only a hit changes control flow. So up to 64 consecutive
+// visit positions are evaluated at once, one per lane: all bucket reads, candidate reads and compares of a batch share ONE
+// memory round trip each instead of one per position. Exactness: a lane's speculative lookup equals the serial one unless an
+// EARLIER lane of the batch inserts into one of its buckets; an LDS scatter (atomicMax of epoch|reversed-lane) finds the first
+// lane with such an earlier bucket-mate (conservatively, buckets folded to 10 bits) and the batch is cut there. Lanes up to
+// the first hit commit their inserts (no two share a bucket, so store order is irrelevant); the hit lane's match is then
+// handled wave-uniformly with wave-wide forward/backward length counts.
+__device__ __forceinline__ u32 rfl(u32 v) { return (u32)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ u64 rfl64(u64 v) { return (u64)rfl((u32)v) | ((u64)rfl((u32)(v >> 32)) << 32); }
+__device__ __forceinline__ u32 bcast(u32 v, u32 l) { return (u32)__builtin_amdgcn_readlane((int)v, (int)l); }
+__device__ __forceinline__ u64 bcast64(u64 v, u32 l) { return (u64)bcast((u32)v, l) | ((u64)bcast((u32)(v >> 32), l) << 32); }
+
+// common prefix of src[a..] and src[b..] (b < a), a limited to end; 64 lanes x 8 bytes per round trip
+__device__ __forceinline__ u32 wave_count_eq(const u8* src, u32 a, u32 b, u32 end, int lane) {
+  u32 total = 0;
+  for (;;) {
+    const u32 off = total + (u32)lane * 8;
+    u32 eq;                                     // equal leading bytes in this lane's 8-byte window
+    bool stop;
+    if (a + off + 8 <= end) {
+      const u64 d = ld64(src + a + off) ^ ld64(src + b + off);
+      eq = d ? ((u32)__builtin_ctzll(d) >> 3) : 8;
+      stop = d != 0;
+    } else {
+      eq = 0;
+      while (a + off + eq < end && src[a + off + eq] == src[b + off + eq]) eq++;
+      stop = true;                              // reaches the block end (or mismatches) inside this window
+    }
+    const u64 m = __ballot(stop);
+    if (m) { const u32 l = (u32)__builtin_ctzll(m); return total + 8 * l + bcast(eq, l); }
+    total += 512;
+  }
+}
+// backward extension: number of k >= 0 with ip-1-k >= anchor, m-1-k >= 0 and equal bytes
+__device__ __forceinline__ u32 wave_count_back(const u8* src, u32 ip, u32 m, u32 anchor, int lane) {
+  const u32 lim = min(ip - anchor, m);
+  u32 total = 0;
+  for (;;) {
+    const u32 k = total + (u32)lane;
+    const bool ok = k < lim && src[ip - 1 - k] == src[m - 1 - k];
+    const u64 bad = ~__ballot(ok);
+    if (bad) return total + (u32)__builtin_ctzll(bad);
+    total += 64;
+  }
+}
+
+__device__ u32 mf_dfast_wave(const ZraEncParams& P, u32* HL, u32* HS, const u8* src, u32 bs, u32 be, u32* rep, u64* seqs, u32* nOut,
+                             u32* dupL, u32* dupS, int lane) {
+  const u32 hlog = P.hashLog, clog = P.chainLog, mls = P.minMatch;
+  u32 o1 = rep[0], o2 = rep[1], saved;
+  u32 anchor = bs, nseq = 0;
+  const u32 ilimit = be - 8;
+  u32 ip = mf_prologue(bs, o1, o2, saved);
+  u32 W = 8, epoch = 1;
+  auto hashS64 = [&](u64 v) -> u32 {
+    switch (mls) {
+      case 5: return (u32)(((v << 24) * 889523592379ULL) >> (64 - clog));
+      case 6: return (u32)(((v << 16) * 227718039650203ULL) >> (64 - clog));
+      case 7: return (u32)(((v << 8) * 58295818150454627ULL) >> (64 - clog));
+      default: return ((u32)v * 2654435761u) >> (32 - clog);
+    }
+  };
+  auto hashL64 = [&](u64 v) -> u32 { return (u32)((v * 0xCF1BBCDCB7A56463ULL) >> (64 - hlog)); };
+  while (ip < ilimit) {
+    const u32 run = ip - anchor, s = (run >> 8) + 1;
+    u32 nAct = min(W, min((256 * s - run + s - 1) / s, (ilimit - ip + s - 1) / s));
+    bool active = (u32)lane < nAct;
+    const u32 p = ip + (u32)lane * s;
+    const u64 v8 = active ? ld64(src + p) : 0;
+    const u32 hL = hashL64(v8), hS = hashS64(v8);
+    u32 mL = 0, mS = 0;
+    if (active) { mL = HL[hL]; mS = HS[hS]; }
+    if (nAct > 1) {
+      const u32 tag = (epoch << 6) | (63u - (u32)lane);
+      if (active) { atomicMax(&dupL[hL & 1023], tag); atomicMax(&dupS[hS & 1023], tag); }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+      const bool earlier = active && (((dupL[hL & 1023] & 63u) != 63u - (u32)lane) || ((dupS[hS & 1023] & 63u) != 63u - (u32)lane));
+      const u64 cut = __ballot(earlier);
+      if (cut) { nAct = (u32)__builtin_ctzll(cut); active = (u32)lane < nAct; }
+      epoch++;
+    }
+    const bool repHit = active && o1 > 0 && ld32(src + p + 1 - o1) == (u32)(v8 >> 8);
+    const bool longHit = active && mL > 1 && ld64(src + mL - 1) == v8;
+    const bool shortHit = active && mS > 1 && ld32(src + mS - 1) == (u32)v8;
+    const u64 hm = __ballot(repHit || longHit || shortHit);
+    const u32 f = hm ? (u32)__builtin_ctzll(hm) : nAct - 1;
+    if (active && (u32)lane <= f) { HL[hL] = p + 1; HS[hS] = p + 1; }
+    if (!hm) { ip += nAct * s; W = min(64u, W * 2); continue; }
+    W = min(64u, max(4u, 2 * (f + 1)));
+    // ---- the hit lane's values, wave-uniform from here on
+    const u32 top = ip + f * s;
+    const u64 v8f = bcast64(v8, f);
+    const u32 mLf = bcast(mL, f), mSf = bcast(mS, f);
+    const bool isRep = (__ballot(repHit) >> f) & 1, isLong = (__ballot(longHit) >> f) & 1;
+    const u32 curr = top + 1;
+    ip = top;
+    u32 ml, offVal;
+    if (isRep) {
+      ml = wave_count_eq(src, ip + 5, ip + 5 - o1, be, lane) + 4; ip++; offVal = 1;
+    } else {
+      u32 m;
+      if (isLong) { m = mLf - 1; ml = wave_count_eq(src, ip + 8, m + 8, be, lane) + 8; }
+      else {
+        const u64 v9 = rfl64(ld64(src + ip + 1));
+        const u32 h3 = hashL64(v9);
+        const u32 m3 = rfl(HL[h3]);
+        if (lane == 0) HL[h3] = curr + 1;
+        if (m3 > 1 && rfl64(ld64(src + m3 - 1)) == v9) { m = m3 - 1; ip++; ml = wave_count_eq(src, ip + 8, m + 8, be, lane) + 8; }
+        else { m = mSf - 1; ml = wave_count_eq(src, ip + 4, m + 4, be, lane) + 4; }
+      }
+      const u32 off = ip - m;
+      const u32 back = wave_count_back(src, ip, m, anchor, lane);
+      ip -= back; ml += back;
+      o2 = o1; o1 = off; offVal = off + 3;
+    }
+    (void)v8f;
+    if (lane == 0) seqs[nseq] = (u64)(ip - anchor) | ((u64)ml << 20) | ((u64)offVal << 40);
+    nseq++;
+    ip += ml; anchor = ip;
+    if (ip <= ilimit) {
+      // complementary insertions (order per table preserved: q first, then ip-2 / ip-1)
+      const u32 q = top + 2;
+      if (lane == 0) HL[hashL64(ld64(src + q))] = q + 1;
+      if (lane == 1) HS[hashS64(ld64(src + q))] = q + 1;
+      if (lane == 0) HL[hashL64(ld64(src + ip - 2))] = ip - 1;
+      if (lane == 1) HS[hashS64(ld64(src + ip - 1))] = ip;
+      while (ip <= ilimit && o2 > 0 && rfl(ld32(src + ip)) == rfl(ld32(src + ip - o2))) {
+        const u32 rl = wave_count_eq(src, ip + 4, ip + 4 - o2, be, lane) + 4;
+        const u32 t = o2; o2 = o1; o1 = t;
+        const u64 vi = ld64(src + ip);
+        if (lane == 0) HS[hashS64(vi)] = ip + 1;
+        if (lane == 1) HL[hashL64(vi)] = ip + 1;
+        if (lane == 0) seqs[nseq] = (u64)0 | ((u64)rl << 20) | ((u64)1 << 40);
+        nseq++;
+        ip += rl; anchor = ip;
+      }
+    }
+  }
+  rep[0] = o1 ? o1 : saved; rep[1] = o2 ? o2 : saved;
+  *nOut = nseq;
+  return be - anchor;
+}
+
 }  // namespace
 
 // One wave per frame; `block` = index of the <=128 KiB block being parsed in this round (A.4.2 driver).
@@ -269,24 +417,36 @@ zra_mf_kernel(ZraEncArgs a, u32 block) {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   }
-  if (lane != 0) return;
-
   const u32 L = be - bs;
   ZraEncBlockOut* bo = &a.blockOut[f];
-  bo->nbSeq = 0; bo->lastLL = L; bo->skip = 1;
-  if (L < 7) return;                                   // too small to compress (A.4.2) -> raw block
-  bo->skip = 0;
-  Emit E; E.seqs = a.seqs + (size_t)f * a.seqStride; E.n = 0;
+  if (L < 7) {                                         // too small to compress (A.4.2) -> raw block
+    if (lane == 0) { bo->nbSeq = 0; bo->lastLL = L; bo->skip = 1; }
+    return;
+  }
+  u64* seqs = a.seqs + (size_t)f * a.seqStride;
   u32 rep[3] = {st->rep[0], st->rep[1], st->rep[2]};
+  u32 lastLL, nseq = 0;
+  if (P.strategy == 2) {
+    __shared__ u32 dupL[1024], dupS[1024];
+    for (int i = lane; i < 1024; i += 64) { dupL[i] = 0; dupS[i] = 0; }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    lastLL = mf_dfast_wave(P, hashT, chainT, src, bs, be, rep, seqs, &nseq, dupL, dupS, lane);
+    if (lane == 0) {
+      bo->nbSeq = nseq; bo->lastLL = lastLL; bo->skip = 0;
+      bo->rep[0] = rep[0]; bo->rep[1] = rep[1]; bo->rep[2] = rep[2];
+    }
+    return;
+  }
+  if (lane != 0) return;
+  bo->skip = 0;
+  Emit E; E.seqs = seqs; E.n = 0;
   // limited update after a very long match (A.4.3 hash chain prologue; harmless for the other finders)
   u32 ntu = st->nextToUpdate;
   {
     const u32 cur = bs + 1;
     if (cur > ntu + 384) { const u32 d = cur - ntu - 384; ntu = cur - (d < 192 ? d : 192); }
   }
-  u32 lastLL;
   if (P.strategy == 1) lastLL = mf_fast(P, hashT, src, bs, be, rep, E);
-  else if (P.strategy == 2) lastLL = mf_dfast(P, hashT, chainT, src, bs, be, rep, E);
   else {
     HC H; H.hashT = hashT; H.chainT = chainT; H.hlog = P.hashLog; H.mls = P.minMatch < 4 ? 4 : P.minMatch > 6 ? 6 : P.minMatch;
     H.chainSize = 1u << P.chainLog; H.cmask = H.chainSize - 1; H.searchLog = P.searchLog; H.nextToUpdate = ntu;
