@@ -289,7 +289,8 @@ __device__ __forceinline__ u32 wave_count_back(const u8* src, u32 ip, u32 m, u32
   }
 }
 
-__device__ u32 mf_dfast_wave(const ZraEncParams& P, u32* HL, u32* HS, const u8* src, u32 bs, u32 be, u32* rep, u64* seqs, u32* nOut,
+template <typename T>
+__device__ u32 mf_dfast_wave(const ZraEncParams& P, T* HL, T* HS, const u8* src, u32 bs, u32 be, u32* rep, u64* seqs, u32* nOut,
                              u32* dupL, u32* dupS, int lane) {
   const u32 hlog = P.hashLog, clog = P.chainLog, mls = P.minMatch;
   u32 o1 = rep[0], o2 = rep[1], saved;
@@ -317,9 +318,9 @@ __device__ u32 mf_dfast_wave(const ZraEncParams& P, u32* HL, u32* HS, const u8* 
     if (active) { mL = HL[hL]; mS = HS[hS]; }
     if (nAct > 1) {
       const u32 tag = (epoch << 6) | (63u - (u32)lane);
-      if (active) { atomicMax(&dupL[hL & 1023], tag); atomicMax(&dupS[hS & 1023], tag); }
+      if (active) { atomicMax(&dupL[hL & 511], tag); atomicMax(&dupS[hS & 511], tag); }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-      const bool earlier = active && (((dupL[hL & 1023] & 63u) != 63u - (u32)lane) || ((dupS[hS & 1023] & 63u) != 63u - (u32)lane));
+      const bool earlier = active && (((dupL[hL & 511] & 63u) != 63u - (u32)lane) || ((dupS[hS & 511] & 63u) != 63u - (u32)lane));
       const u64 cut = __ballot(earlier);
       if (cut) { nAct = (u32)__builtin_ctzll(cut); active = (u32)lane < nAct; }
       epoch++;
@@ -329,7 +330,7 @@ __device__ u32 mf_dfast_wave(const ZraEncParams& P, u32* HL, u32* HS, const u8* 
     const bool shortHit = active && mS > 1 && ld32(src + mS - 1) == (u32)v8;
     const u64 hm = __ballot(repHit || longHit || shortHit);
     const u32 f = hm ? (u32)__builtin_ctzll(hm) : nAct - 1;
-    if (active && (u32)lane <= f) { HL[hL] = p + 1; HS[hS] = p + 1; }
+    if (active && (u32)lane <= f) { HL[hL] = (T)(p + 1); HS[hS] = (T)(p + 1); }
     if (!hm) { ip += nAct * s; W = min(64u, W * 2); continue; }
     W = min(64u, max(4u, 2 * (f + 1)));
     // ---- the hit lane's values, wave-uniform from here on
@@ -349,7 +350,7 @@ __device__ u32 mf_dfast_wave(const ZraEncParams& P, u32* HL, u32* HS, const u8* 
         const u64 v9 = rfl64(ld64(src + ip + 1));
         const u32 h3 = hashL64(v9);
         const u32 m3 = rfl(HL[h3]);
-        if (lane == 0) HL[h3] = curr + 1;
+        if (lane == 0) HL[h3] = (T)(curr + 1);
         if (m3 > 1 && rfl64(ld64(src + m3 - 1)) == v9) { m = m3 - 1; ip++; ml = wave_count_eq(src, ip + 8, m + 8, be, lane) + 8; }
         else { m = mSf - 1; ml = wave_count_eq(src, ip + 4, m + 4, be, lane) + 4; }
       }
@@ -365,16 +366,16 @@ __device__ u32 mf_dfast_wave(const ZraEncParams& P, u32* HL, u32* HS, const u8* 
     if (ip <= ilimit) {
       // complementary insertions (order per table preserved: q first, then ip-2 / ip-1)
       const u32 q = top + 2;
-      if (lane == 0) HL[hashL64(ld64(src + q))] = q + 1;
-      if (lane == 1) HS[hashS64(ld64(src + q))] = q + 1;
-      if (lane == 0) HL[hashL64(ld64(src + ip - 2))] = ip - 1;
-      if (lane == 1) HS[hashS64(ld64(src + ip - 1))] = ip;
+      if (lane == 0) HL[hashL64(ld64(src + q))] = (T)(q + 1);
+      if (lane == 1) HS[hashS64(ld64(src + q))] = (T)(q + 1);
+      if (lane == 0) HL[hashL64(ld64(src + ip - 2))] = (T)(ip - 1);
+      if (lane == 1) HS[hashS64(ld64(src + ip - 1))] = (T)ip;
       while (ip <= ilimit && o2 > 0 && rfl(ld32(src + ip)) == rfl(ld32(src + ip - o2))) {
         const u32 rl = wave_count_eq(src, ip + 4, ip + 4 - o2, be, lane) + 4;
         const u32 t = o2; o2 = o1; o1 = t;
         const u64 vi = ld64(src + ip);
-        if (lane == 0) HS[hashS64(vi)] = ip + 1;
-        if (lane == 1) HL[hashL64(vi)] = ip + 1;
+        if (lane == 0) HS[hashS64(vi)] = (T)(ip + 1);
+        if (lane == 1) HL[hashL64(vi)] = (T)(ip + 1);
         if (lane == 0) seqs[nseq] = (u64)0 | ((u64)rl << 20) | ((u64)1 << 40);
         nseq++;
         ip += rl; anchor = ip;
@@ -406,9 +407,13 @@ zra_mf_kernel(ZraEncArgs a, u32 block) {
   u32* hashT = a.tables + (size_t)f * a.tableStride;
   u32* chainT = hashT + ((size_t)1 << P.hashLog);
 
+  // frames that are one block of <= 64 KiB keep 16-bit table entries (index = position+1 <= 65529 fits): half the table
+  // footprint in HBM/L2 and half the clear traffic; everything else uses 32-bit entries
+  const bool narrow = P.strategy == 2 && fsize <= 65536;
   if (block == 0) {
     // fresh frame: zeroed tables, repcodes {1,4,8}, nextToUpdate 1 (A.4.8); 16-byte coalesced clears by the whole wave
-    const size_t words = ((size_t)1 << P.hashLog) + ((size_t)1 << P.chainLog);
+    const size_t entries = ((size_t)1 << P.hashLog) + ((size_t)1 << P.chainLog);
+    const size_t words = narrow ? entries / 2 : entries;
     uint4* t4 = (uint4*)hashT;
     for (size_t i = lane; i < words / 4; i += 64) t4[i] = make_uint4(0, 0, 0, 0);
     for (size_t i = (words / 4) * 4 + lane; i < words; i += 64) hashT[i] = 0;
@@ -427,10 +432,11 @@ zra_mf_kernel(ZraEncArgs a, u32 block) {
   u32 rep[3] = {st->rep[0], st->rep[1], st->rep[2]};
   u32 lastLL, nseq = 0;
   if (P.strategy == 2) {
-    __shared__ u32 dupL[1024], dupS[1024];
-    for (int i = lane; i < 1024; i += 64) { dupL[i] = 0; dupS[i] = 0; }
+    __shared__ u32 dupL[512], dupS[512];
+    for (int i = lane; i < 512; i += 64) { dupL[i] = 0; dupS[i] = 0; }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-    lastLL = mf_dfast_wave(P, hashT, chainT, src, bs, be, rep, seqs, &nseq, dupL, dupS, lane);
+    if (narrow) lastLL = mf_dfast_wave<u16>(P, (u16*)hashT, (u16*)hashT + ((size_t)1 << P.hashLog), src, bs, be, rep, seqs, &nseq, dupL, dupS, lane);
+    else lastLL = mf_dfast_wave<u32>(P, hashT, chainT, src, bs, be, rep, seqs, &nseq, dupL, dupS, lane);
     if (lane == 0) {
       bo->nbSeq = nseq; bo->lastLL = lastLL; bo->skip = 0;
       bo->rep[0] = rep[0]; bo->rep[1] = rep[1]; bo->rep[2] = rep[2];
