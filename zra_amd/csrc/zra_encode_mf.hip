@@ -289,7 +289,7 @@ __device__ __forceinline__ u32 wave_count_back(const u8* src, u32 ip, u32 m, u32
   }
 }
 
-template <typename T>
+template <typename T, bool TAG>
 __device__ u32 mf_dfast_wave(const ZraEncParams& P, T* HL, T* HS, const u8* src, u32 bs, u32 be, u32* rep, u64* seqs, u32* nOut,
                              u32* dupL, u32* dupS, int lane) {
   const u32 hlog = P.hashLog, clog = P.chainLog, mls = P.minMatch;
@@ -307,6 +307,11 @@ __device__ u32 mf_dfast_wave(const ZraEncParams& P, T* HL, T* HS, const u8* src,
     }
   };
   auto hashL64 = [&](u64 v) -> u32 { return (u32)((v * 0xCF1BBCDCB7A56463ULL) >> (64 - hlog)); };
+  // TAG mode (32-bit entries, positions < 65536): the upper half of an entry carries 16 more hash bits of the bytes the
+  // candidate test compares (8 for the long table, 4 for the short one); a tag mismatch proves the candidate test would
+  // fail, so the random read of the candidate's bytes is skipped. Results are unchanged.
+  auto tagL64 = [&](u64 v) -> u32 { return TAG ? ((u32)((v * 0xCF1BBCDCB7A56463ULL) >> (48 - hlog)) & 0xFFFFu) << 16 : 0u; };
+  auto tagS64 = [&](u64 v) -> u32 { return TAG ? (((u32)v * 2654435761u) >> 16) << 16 : 0u; };
   while (ip < ilimit) {
     const u32 run = ip - anchor, s = (run >> 8) + 1;
     u32 nAct = min(W, min((256 * s - run + s - 1) / s, (ilimit - ip + s - 1) / s));
@@ -314,8 +319,14 @@ __device__ u32 mf_dfast_wave(const ZraEncParams& P, T* HL, T* HS, const u8* src,
     const u32 p = ip + (u32)lane * s;
     const u64 v8 = active ? ld64(src + p) : 0;
     const u32 hL = hashL64(v8), hS = hashS64(v8);
+    const u32 tL = tagL64(v8), tS = tagS64(v8);
     u32 mL = 0, mS = 0;
-    if (active) { mL = HL[hL]; mS = HS[hS]; }
+    bool tagLok = true, tagSok = true;
+    if (active) {
+      const u32 rL = HL[hL], rS = HS[hS];
+      if (TAG) { mL = rL & 0xFFFFu; mS = rS & 0xFFFFu; tagLok = (rL & 0xFFFF0000u) == tL; tagSok = (rS & 0xFFFF0000u) == tS; }
+      else { mL = rL; mS = rS; }
+    }
     if (nAct > 1) {
       const u32 tag = (epoch << 6) | (63u - (u32)lane);
       if (active) { atomicMax(&dupL[hL & 511], tag); atomicMax(&dupS[hS & 511], tag); }
@@ -326,11 +337,11 @@ __device__ u32 mf_dfast_wave(const ZraEncParams& P, T* HL, T* HS, const u8* src,
       epoch++;
     }
     const bool repHit = active && o1 > 0 && ld32(src + p + 1 - o1) == (u32)(v8 >> 8);
-    const bool longHit = active && mL > 1 && ld64(src + mL - 1) == v8;
-    const bool shortHit = active && mS > 1 && ld32(src + mS - 1) == (u32)v8;
+    const bool longHit = active && mL > 1 && tagLok && ld64(src + mL - 1) == v8;
+    const bool shortHit = active && mS > 1 && tagSok && ld32(src + mS - 1) == (u32)v8;
     const u64 hm = __ballot(repHit || longHit || shortHit);
     const u32 f = hm ? (u32)__builtin_ctzll(hm) : nAct - 1;
-    if (active && (u32)lane <= f) { HL[hL] = (T)(p + 1); HS[hS] = (T)(p + 1); }
+    if (active && (u32)lane <= f) { HL[hL] = (T)((p + 1) | tL); HS[hS] = (T)((p + 1) | tS); }
     if (!hm) { ip += nAct * s; W = min(64u, W * 2); continue; }
     W = min(64u, max(4u, 2 * (f + 1)));
     // ---- the hit lane's values, wave-uniform from here on
@@ -349,9 +360,11 @@ __device__ u32 mf_dfast_wave(const ZraEncParams& P, T* HL, T* HS, const u8* src,
       else {
         const u64 v9 = rfl64(ld64(src + ip + 1));
         const u32 h3 = hashL64(v9);
-        const u32 m3 = rfl(HL[h3]);
-        if (lane == 0) HL[h3] = (T)(curr + 1);
-        if (m3 > 1 && rfl64(ld64(src + m3 - 1)) == v9) { m = m3 - 1; ip++; ml = wave_count_eq(src, ip + 8, m + 8, be, lane) + 8; }
+        const u32 r3 = rfl(HL[h3]);
+        const u32 m3 = TAG ? (r3 & 0xFFFFu) : r3;
+        const bool tag3ok = !TAG || (r3 & 0xFFFF0000u) == tagL64(v9);
+        if (lane == 0) HL[h3] = (T)((curr + 1) | tagL64(v9));
+        if (m3 > 1 && tag3ok && rfl64(ld64(src + m3 - 1)) == v9) { m = m3 - 1; ip++; ml = wave_count_eq(src, ip + 8, m + 8, be, lane) + 8; }
         else { m = mSf - 1; ml = wave_count_eq(src, ip + 4, m + 4, be, lane) + 4; }
       }
       const u32 off = ip - m;
@@ -366,16 +379,18 @@ __device__ u32 mf_dfast_wave(const ZraEncParams& P, T* HL, T* HS, const u8* src,
     if (ip <= ilimit) {
       // complementary insertions (order per table preserved: q first, then ip-2 / ip-1)
       const u32 q = top + 2;
-      if (lane == 0) HL[hashL64(ld64(src + q))] = (T)(q + 1);
-      if (lane == 1) HS[hashS64(ld64(src + q))] = (T)(q + 1);
-      if (lane == 0) HL[hashL64(ld64(src + ip - 2))] = (T)(ip - 1);
-      if (lane == 1) HS[hashS64(ld64(src + ip - 1))] = (T)ip;
+      { const u64 vq = ld64(src + q);
+        if (lane == 0) HL[hashL64(vq)] = (T)((q + 1) | tagL64(vq));
+        if (lane == 1) HS[hashS64(vq)] = (T)((q + 1) | tagS64(vq)); }
+      { const u64 va = ld64(src + ip - 2), vb = va >> 8 | ((u64)src[ip + 6] << 56);
+        if (lane == 0) HL[hashL64(va)] = (T)((ip - 1) | tagL64(va));
+        if (lane == 1) HS[hashS64(vb)] = (T)(ip | tagS64(vb)); }
       while (ip <= ilimit && o2 > 0 && rfl(ld32(src + ip)) == rfl(ld32(src + ip - o2))) {
         const u32 rl = wave_count_eq(src, ip + 4, ip + 4 - o2, be, lane) + 4;
         const u32 t = o2; o2 = o1; o1 = t;
         const u64 vi = ld64(src + ip);
-        if (lane == 0) HS[hashS64(vi)] = (T)(ip + 1);
-        if (lane == 1) HL[hashL64(vi)] = (T)(ip + 1);
+        if (lane == 0) HS[hashS64(vi)] = (T)((ip + 1) | tagS64(vi));
+        if (lane == 1) HL[hashL64(vi)] = (T)((ip + 1) | tagL64(vi));
         if (lane == 0) seqs[nseq] = (u64)0 | ((u64)rl << 20) | ((u64)1 << 40);
         nseq++;
         ip += rl; anchor = ip;
@@ -409,7 +424,8 @@ zra_mf_kernel(ZraEncArgs a, u32 block) {
 
   // frames that are one block of <= 64 KiB keep 16-bit table entries (index = position+1 <= 65529 fits): half the table
   // footprint in HBM/L2 and half the clear traffic; everything else uses 32-bit entries
-  const bool narrow = P.strategy == 2 && fsize <= 65536;
+  const bool narrow = false;   // 16-bit entries superseded by tagged 32-bit entries (see mf_dfast_wave TAG mode)
+  const bool tagged = P.strategy == 2 && fsize <= 65536;
   if (block == 0) {
     // fresh frame: zeroed tables, repcodes {1,4,8}, nextToUpdate 1 (A.4.8); 16-byte coalesced clears by the whole wave
     const size_t entries = ((size_t)1 << P.hashLog) + ((size_t)1 << P.chainLog);
@@ -435,8 +451,8 @@ zra_mf_kernel(ZraEncArgs a, u32 block) {
     __shared__ u32 dupL[512], dupS[512];
     for (int i = lane; i < 512; i += 64) { dupL[i] = 0; dupS[i] = 0; }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-    if (narrow) lastLL = mf_dfast_wave<u16>(P, (u16*)hashT, (u16*)hashT + ((size_t)1 << P.hashLog), src, bs, be, rep, seqs, &nseq, dupL, dupS, lane);
-    else lastLL = mf_dfast_wave<u32>(P, hashT, chainT, src, bs, be, rep, seqs, &nseq, dupL, dupS, lane);
+    if (tagged) lastLL = mf_dfast_wave<u32, true>(P, hashT, chainT, src, bs, be, rep, seqs, &nseq, dupL, dupS, lane);
+    else lastLL = mf_dfast_wave<u32, false>(P, hashT, chainT, src, bs, be, rep, seqs, &nseq, dupL, dupS, lane);
     if (lane == 0) {
       bo->nbSeq = nseq; bo->lastLL = lastLL; bo->skip = 0;
       bo->rep[0] = rep[0]; bo->rep[1] = rep[1]; bo->rep[2] = rep[2];
