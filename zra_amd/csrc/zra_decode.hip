@@ -1,16 +1,15 @@
-// zra_amd — frame DECODE kernels for gfx950 (MI355X).
+// zra_amd — frame DECODE kernel for gfx950 (MI355X).
 //
-// Replaces the reference's per-frame ZSTD_decompressDCtx work (zra.cpp:249,280,289,293,397,406,410,435):
-// one independent zstd frame per workgroup (256 threads = 4 waves), persistent grid with an atomic
-// frame queue. Format per RFC 8878 / SURVEY.md Appendix A.1-A.3.
-//
-// Wave specialisation inside a workgroup, per compressed block:
-//   wave 0          : FSE sequence decode (inherently serial bit chain) -> chunk ring in LDS
-//   waves 2,3       : position scan + literal copies of the previous chunk (fully parallel)
-//   wave 1          : match copies of the chunk before that (dependency order, 64 lanes per copy)
-// so the three stages of sequence execution overlap as a 3-deep pipeline over 512-sequence chunks.
-// Huffman literal streams (4 backward bitstreams) are decoded by 4 lanes concurrently with the first
-// sequence chunk. Decode tables live in LDS; the output window is the destination buffer in HBM/L2.
+// Replaces the reference's per-frame ZSTD_decompressDCtx work (zra.cpp:249,280,289,293,397,406,410,435).
+// One independent zstd frame per workgroup; the workgroup is ONE 64-lane wave and keeps only ~17 KiB of LDS (Huffman +
+// FSE decode tables, a 64-sequence batch), so 8-9 frames are in flight per CU (persistent grid, atomic frame queue):
+// decoding is a chain of dependent memory round trips, and frames in flight are what hides them.
+// Per compressed block:  lane 0 parses headers; all lanes build the tables; 4 lanes decode the 4 Huffman streams;
+// then batches of 64 sequences: lane 0 walks the FSE bit chain (inherently serial), a wave prefix-scan turns
+// (litLength, matchLength) into output positions, every lane copies ITS sequence's literals, and match copies run in
+// dependency rounds: a lane is ready once its source range ends before the first unfinished match destination, so
+// independent matches of a batch execute in the same round trip. The output window is the destination buffer (HBM/L2).
+// Format per RFC 8878 / SURVEY.md Appendix A.1-A.3.
 #include "zra_dev.h"
 #include "zra_kernels.h"
 
@@ -18,8 +17,8 @@ using namespace zra_dev;
 
 namespace {
 
-constexpr int DEC_THREADS = 256;
-constexpr int CHUNK = 512;          // sequences per pipeline chunk
+constexpr int DEC_THREADS = 64;
+constexpr int BATCH = 64;           // sequences decoded + executed per round (one per lane)
 constexpr u32 BLOCK_MAX = 128u << 10;
 
 __constant__ u32 c_ll_base[36] = {0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,18,20,22,24,28,32,40,48,64,128,256,512,1024,2048,4096,8192,16384,32768,65536};
@@ -42,20 +41,15 @@ struct __attribute__((aligned(16))) DecShared {
   u64 llT[512];
   u64 mlT[512];
   u64 ofT[256];
-  u16 huf[2048];            // sym | nbBits<<8
-  u32 seqLL[3][CHUNK];
-  u32 seqML[3][CHUNK];
-  u32 seqOF[3][CHUNK];
-  u32 seqOut[3][CHUNK];     // output position (block-relative) where the sequence's literals start
-  u32 seqLit[3][CHUNK];     // literal-buffer position of the sequence's literals
-  u32 chunkN[3];            // sequences in ring slot
+  u16 huf[2048];            // sym | nbBits<<8 ; doubles as scratch while a tree description is parsed
+  u32 seqLL[BATCH], seqML[BATCH], seqOF[BATCH];
   short norm[256];          // scratch: normalised counts while building a table
   u8 weights[256];
   u8 spread[512];
   u32 rankStart[16];
-  // per-frame / per-block control words (written by thread 0, read after a barrier)
+  // control words (written by lane 0, read by the wave after a wave sync)
   u32 err;
-  u32 frame;                // frame index taken from the queue
+  u32 frame;
   u32 blkType, blkSize, blkLast, blkPos;
   u32 litType, litRegen, litComp, litHdr, litStreams, litRle;
   u32 hufValid, hufMaxBits, hufNSym;
@@ -63,13 +57,16 @@ struct __attribute__((aligned(16))) DecShared {
   u32 llLog, mlLog, ofLog, llValid, mlValid, ofValid;
   u32 rep[3];
   u32 streamOff[4], streamLen[4];
-  // sequence-decode carried state (wave 0 lane 0 only, kept here between chunks)
-  u32 sLL, sML, sOF;
-  i32 brPos;
-  u32 decoded;              // sequences decoded so far in this block
-  u32 outBase, litBase;     // running output / literal positions for the scan stage
+  u32 tl, ms, used;
   u32 produced;             // bytes produced in this frame so far
 };
+
+// wave-level sync: LDS and global traffic of the wave is complete and visible to its other lanes
+__device__ __forceinline__ void wsync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
 
 // ---------------------------------------------------------------------------------------------
 // FSE table description (A.3) -> norm[] ; single thread. returns bytes consumed, 0 on corruption
@@ -159,6 +156,7 @@ __device__ __forceinline__ void copy_bytes(u8* dst, const u8* src, u32 n, int t,
   for (u32 i = t; i < n8; i += nthreads) st64(dst + 8 * i, ld64(src + 8 * i));
   for (u32 i = (n8 << 3) + t; i < n; i += nthreads) dst[i] = src[i];
 }
+__device__ __forceinline__ u32 bcast_u32(u32 v, u32 l) { return (u32)__builtin_amdgcn_readlane((int)v, (int)l); }
 __device__ __forceinline__ void fill_bytes(u8* dst, u8 v, u32 n, int t, int nthreads) {
   u64 vv = 0x0101010101010101ull * v;
   u32 n8 = n >> 3;
@@ -207,9 +205,9 @@ __device__ void parse_literals_header(DecShared& S, const u8* src, u32 n, const 
       u32 maxSym = 255, tl;
       u32 h = read_ncount(S.norm, &maxSym, &tl, p + 1, hbyte, 6, lim);
       if (!h) { S.err = ZE_CORRUPTION; return; }
-      // small serial FSE decode of the weights (<= 255 symbols); table (<= 64 cells) in the idle chunk ring
-      u64* const wt = (u64*)S.seqLL[0];
-      u16* const next = (u16*)S.seqML[0];
+      // small serial FSE decode of the weights (<= 255 symbols); table (<= 64 cells) in the not-yet-filled Huffman table
+      u64* const wt = (u64*)S.huf;                 // 64 cells max (accuracy <= 6)
+      u16* const next = S.huf + 1024;
       {
         u32 size = 1u << tl, mask = size - 1, high = size - 1, step = (size >> 1) + (size >> 3) + 3, pos = 0;
         for (u32 s = 0; s <= maxSym; s++) { next[s] = S.norm[s] == -1 ? 1 : (u16)S.norm[s]; if (S.norm[s] == -1) S.spread[high--] = (u8)s; }
@@ -320,14 +318,14 @@ __device__ void seq_table_parse(DecShared& S, int kind, u32 mode, const u8* p, u
 extern "C" __global__ void __launch_bounds__(DEC_THREADS)
 zra_decode_frames_kernel(ZraDecodeArgs a) {
   __shared__ DecShared S;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int lane = threadIdx.x;
   u8* const litScratch = a.litScratch + (size_t)blockIdx.x * ZRA_LIT_STRIDE;
 
   for (;;) {
-    if (tid == 0) S.frame = atomicAdd(a.queue, 1u);
-    __syncthreads();
+    if (lane == 0) S.frame = atomicAdd(a.queue, 1u);
+    wsync();
     const u32 f = S.frame;
-    __syncthreads();
+    wsync();
     if (f >= a.nFrames) return;
 
     const u64 so = a.frameOff[(size_t)f * a.offStride], se = a.frameOff[(size_t)f * a.offStride + 1];
@@ -337,7 +335,7 @@ zra_decode_frames_kernel(ZraDecodeArgs a) {
     u8* const dst = a.out + a.outOff[f];
     const u32 dstCap = a.outCap[f];
 
-    if (tid == 0) {
+    if (lane == 0) {
       S.err = 0; S.produced = 0; S.hufValid = 0; S.llValid = S.mlValid = S.ofValid = 0;
       S.rep[0] = 1; S.rep[1] = 4; S.rep[2] = 8; S.blkLast = 0;
       // ---- frame header (A.1)
@@ -361,15 +359,14 @@ zra_decode_frames_kernel(ZraDecodeArgs a) {
       S.blkPos = hs;
       a.frameMeta[2 * (size_t)f] = checksum;   // [2f] = has checksum, [2f+1] = stored checksum (set at frame end)
     }
-    __syncthreads();
+    wsync();
 
     // ------------------------------------------------------------------ block loop
     for (;;) {
-      // every thread samples the loop condition BEFORE thread 0 may overwrite blkLast/err for the next block
-      const bool done = S.err || S.blkLast;
-      __syncthreads();
+      const bool done = S.err || S.blkLast;    // sampled by every lane before lane 0 may overwrite it
+      wsync();
       if (done) break;
-      if (tid == 0) {
+      if (lane == 0) {
         u32 pos = S.blkPos;
         if (srcSize - pos < 3) S.err = ZE_SRCSIZE_WRONG;
         else {
@@ -384,30 +381,24 @@ zra_decode_frames_kernel(ZraDecodeArgs a) {
           S.blkPos = pos;
         }
       }
-      __syncthreads();
+      wsync();
       if (S.err) break;
-      const u32 btype = S.blkType, bsize = S.blkSize, bpos = S.blkPos;
-      u8* const out = dst + S.produced;          // this block's output start
-      const u32 outCap = dstCap - S.produced;
+      const u32 btype = S.blkType, bsize = S.blkSize, bpos = S.blkPos, produced0 = S.produced;
+      u8* const out = dst + produced0;           // this block's output start
+      const u32 outCap = dstCap - produced0;
 
-      if (btype == 0) {
-        copy_bytes(out, src + bpos, bsize, tid, DEC_THREADS);
-        __syncthreads();
-        if (tid == 0) { S.produced += bsize; S.blkPos = bpos + bsize; }
-        __syncthreads();
-        continue;
-      }
-      if (btype == 1) {
-        fill_bytes(out, src[bpos], bsize, tid, DEC_THREADS);
-        __syncthreads();
-        if (tid == 0) { S.produced += bsize; S.blkPos = bpos + 1; }
-        __syncthreads();
+      if (btype == 0 || btype == 1) {
+        if (btype == 0) copy_bytes(out, src + bpos, bsize, lane, DEC_THREADS);
+        else fill_bytes(out, src[bpos], bsize, lane, DEC_THREADS);
+        wsync();
+        if (lane == 0) { S.produced = produced0 + bsize; S.blkPos = bpos + (btype == 0 ? bsize : 1); }
+        wsync();
         continue;
       }
 
       // ------------------------------------------------------------ compressed block
       const u8* const blk = src + bpos;
-      if (tid == 0) {
+      if (lane == 0) {
         S.litStreams = 1; S.litRle = 0;
         parse_literals_header(S, blk, bsize, lim);
         if (!S.err) {
@@ -415,258 +406,223 @@ zra_decode_frames_kernel(ZraDecodeArgs a) {
           parse_seq_header(S, blk + S.seqPos, bsize - S.seqPos);
         }
       }
-      __syncthreads();
+      wsync();
       if (S.err) break;
 
-      // ---- Huffman decode table fill (all threads): cells ordered by weight, then symbol
+      // ---- Huffman decode table fill: cells ordered by weight, then symbol
       if (S.litType == 2 && S.hufValid == 2) {
         const u32 nSym = S.hufNSym, maxBits = S.hufMaxBits;
-        // each thread owns one symbol: its start = rankStart[w] + (#earlier symbols of same weight) << (w-1)
-        for (u32 s = tid; s < nSym; s += DEC_THREADS) {
-          u32 w = S.weights[s];
+        for (u32 sy = lane; sy < nSym; sy += DEC_THREADS) {
+          u32 w = S.weights[sy];
           if (w == 0) continue;
           u32 before = 0;
-          for (u32 t = 0; t < s; t++) before += (S.weights[t] == w);
+          for (u32 t = 0; t < sy; t++) before += (S.weights[t] == w);
           u32 len = 1u << (w - 1), start = S.rankStart[w] + before * len;
-          u16 e = (u16)(s | ((maxBits + 1 - w) << 8));
+          u16 e = (u16)(sy | ((maxBits + 1 - w) << 8));
           for (u32 c = 0; c < len; c++) S.huf[start + c] = e;
         }
+        wsync();
+        if (lane == 0) S.hufValid = 1;
       }
-      // ---- sequence decode tables: thread 0 parses each description, wave 0 builds it
+      // ---- sequence decode tables: lane 0 parses each description, the wave builds it
       const u32 nbSeq = S.nbSeq;
       if (nbSeq) {
-        for (int kind = 0; kind < 3; kind++) {
-          // wire order is LL, OF, ML
-          const int k = kind == 0 ? 0 : kind == 1 ? 2 : 1;
+        bool bad = false;
+        for (int kind = 0; kind < 3 && !bad; kind++) {
+          const int k = kind == 0 ? 0 : kind == 1 ? 2 : 1;          // wire order is LL, OF, ML
           const u32 mode = k == 0 ? (S.seqModes >> 6) : k == 2 ? ((S.seqModes >> 4) & 3) : ((S.seqModes >> 2) & 3);
-          __shared__ u32 tl, ms, used;
-          if (tid == 0) {
-            tl = ms = used = 0;
+          if (lane == 0) {
+            u32 tl = 0, ms = 0, used = 0;
             seq_table_parse(S, k, mode, blk + S.seqPos, bsize - S.seqPos, &tl, &ms, &used, lim);
-            S.seqPos += used;
+            S.seqPos += used; S.tl = tl; S.ms = ms;
             if (mode == 3) { u32 v = k == 0 ? S.llValid : k == 1 ? S.mlValid : S.ofValid; if (!v) S.err = ZE_CORRUPTION; }
           }
-          __syncthreads();
-          if (S.err) break;
+          wsync();
+          if (S.err) { bad = true; break; }
           u64* table = k == 0 ? S.llT : k == 1 ? S.mlT : S.ofT;
+          const u32 tl = S.tl, ms = S.ms;
           if (mode == 1) {
-            if (tid == 0) {
-              u32 s = ms;
-              table[0] = k == 0 ? mk_seqsym(c_ll_base[s], c_ll_bits[s], 0, 0) : k == 1 ? mk_seqsym(c_ml_base[s], c_ml_bits[s], 0, 0) : mk_seqsym(1u << s, s, 0, 0);
-            }
-          } else if (mode != 3 && wave == 0) {
-            build_fse_dtable(table, S.norm, ms, tl, k, S.spread, lane);
-          }
-          if (tid == 0 && mode != 3) {
+            if (lane == 0) table[0] = k == 0 ? mk_seqsym(c_ll_base[ms], c_ll_bits[ms], 0, 0) : k == 1 ? mk_seqsym(c_ml_base[ms], c_ml_bits[ms], 0, 0) : mk_seqsym(1u << ms, ms, 0, 0);
+          } else if (mode != 3) build_fse_dtable(table, S.norm, ms, tl, k, S.spread, lane);
+          if (lane == 0 && mode != 3) {
             if (k == 0) { S.llLog = tl; S.llValid = 1; } else if (k == 1) { S.mlLog = tl; S.mlValid = 1; } else { S.ofLog = tl; S.ofValid = 1; }
           }
-          __syncthreads();
+          wsync();
         }
-        if (S.err) break;
+        if (bad) break;
       }
-      __syncthreads();
 
-      // ---- literals: raw -> point into the source; RLE -> fill scratch; Huffman -> 4 lanes of wave 1
+      // ---- literals: raw -> point into the source; RLE -> fill scratch; Huffman -> up to 4 lanes, one per stream
       const u32 litType = S.litType, regen = S.litRegen;
       const u8* lit = litScratch;
       if (litType == 0) lit = blk + S.litHdr;
-      else if (litType == 1) fill_bytes(litScratch, (u8)S.litRle, regen, tid, DEC_THREADS);
-
-      if (tid == 0) {
-        S.decoded = 0; S.outBase = 0; S.litBase = 0; S.chunkN[0] = S.chunkN[1] = S.chunkN[2] = 0;
-        if (S.hufValid == 2) S.hufValid = 1;
+      else if (litType == 1) fill_bytes(litScratch, (u8)S.litRle, regen, lane, DEC_THREADS);
+      else {
+        const u32 nStreams = S.litStreams;
+        if ((u32)lane < nStreams) {
+          const u32 seg = nStreams == 1 ? regen : (regen + 3) / 4;
+          const u32 myLen = nStreams == 1 ? regen : (lane < 3 ? seg : regen - 3 * seg);
+          u8* o = litScratch + (size_t)lane * seg;
+          BitR hb;
+          bool bad = hb.init(blk + S.streamOff[lane], S.streamLen[lane], lim) != 0;
+          if (!bad) {
+            const int mb = (int)S.hufMaxBits;
+            u32 i = 0;
+            for (; i + 4 <= myLen; i += 4) {        // 4 symbols per window reload (4*11 = 44 <= 56 guaranteed bits)
+              hb.ensure(4 * mb);
+              u32 packed = 0;
+#pragma unroll
+              for (int k = 0; k < 4; k++) {
+                u32 e = S.huf[hb.peek(mb)];
+                packed |= (e & 0xFF) << (8 * k);
+                hb.skip((int)(e >> 8));
+              }
+              st32(o + i, packed);
+            }
+            for (; i < myLen; i++) { hb.ensure(mb); u32 e = S.huf[hb.peek(mb)]; o[i] = (u8)e; hb.skip((int)(e >> 8)); }
+            if (hb.pos != 0) bad = true;
+          }
+          if (bad) S.err = ZE_CORRUPTION;
+        }
       }
+      wsync();
+      if (S.err) break;
 
-      // sequence bitstream init (wave 0 lane 0 keeps the reader in registers across chunks)
+      // ---- sequences: batches of 64 (lane 0 decodes, the wave executes)
       BitR br; br.base = blk; br.lim = lim; br.pos = 0; br.wlo = 0; br.w = 0;
       u32 sLL = 0, sML = 0, sOF = 0;
       u32 rep0 = S.rep[0], rep1 = S.rep[1], rep2 = S.rep[2];
-      if (tid == 0 && nbSeq) {
+      if (lane == 0 && nbSeq) {
         if (br.init(blk + S.seqPos, bsize - S.seqPos, lim)) S.err = ZE_CORRUPTION;
         else {
           sLL = br.read((int)S.llLog); sOF = br.read((int)S.ofLog); sML = br.read((int)S.mlLog);
           if (br.pos < 0) S.err = ZE_CORRUPTION;
         }
       }
-      __syncthreads();
+      wsync();
       if (S.err) break;
-
-      // ---- pipeline over chunks. iteration t: wave0 decodes chunk t, waves 2-3 scan+copy literals of
-      //      chunk t-1, wave 1 copies matches of chunk t-2. (+ Huffman literal decode before chunk 0's literals)
-      const u32 nChunks = (nbSeq + CHUNK - 1) / CHUNK;
-      const bool hufLits = litType >= 2;
-      for (u32 t = 0; t < nChunks + 2 || (t == 0); t++) {
-        // -------- stage A: wave 0 lane 0 — FSE sequence decode of chunk t
-        if (wave == 0) {
-          if (lane == 0 && t < nChunks) {
-            const int slot = t % 3;
-            const u32 first = t * CHUNK, cnt = min((u32)CHUNK, nbSeq - first);
-            u32 bad = 0;
-            for (u32 i = 0; i < cnt; i++) {
-              const u64 eL = S.llT[sLL], eM = S.mlT[sML], eO = S.ofT[sOF];
-              const u32 ofBits = (u32)(eO >> 32) & 0xFF, mlBits = (u32)(eM >> 32) & 0xFF, llBits = (u32)(eL >> 32) & 0xFF;
-              if (ofBits > 31) { bad = 1; break; }
-              u32 offVal = (u32)eO + br.read((int)ofBits);
-              br.ensure((int)(mlBits + llBits));
-              u32 ml = (u32)eM + (mlBits ? br.peek((int)mlBits) : 0); br.skip((int)mlBits);
-              u32 ll = (u32)eL + (llBits ? br.peek((int)llBits) : 0); br.skip((int)llBits);
-              if (first + i + 1 < nbSeq) {
-                const int nL = (int)((eL >> 40) & 0xFF), nM = (int)((eM >> 40) & 0xFF), nO = (int)((eO >> 40) & 0xFF);
-                br.ensure(nL + nM + nO);
-                sLL = (u32)(eL >> 48) + (nL ? br.peek(nL) : 0); br.skip(nL);
-                sML = (u32)(eM >> 48) + (nM ? br.peek(nM) : 0); br.skip(nM);
-                sOF = (u32)(eO >> 48) + (nO ? br.peek(nO) : 0); br.skip(nO);
-              }
-              if (br.pos < 0) { bad = 1; break; }
-              // repcode resolution (A.3)
-              u32 off;
-              if (offVal > 3) { off = offVal - 3; rep2 = rep1; rep1 = rep0; rep0 = off; }
-              else {
-                u32 idx = offVal + (ll == 0);
-                if (idx == 1) off = rep0;
-                else {
-                  off = idx == 2 ? rep1 : idx == 3 ? rep2 : rep0 - 1;
-                  if (off == 0) { bad = 1; break; }
-                  if (idx != 2) rep2 = rep1;
-                  rep1 = rep0; rep0 = off;
-                }
-              }
-              S.seqLL[slot][i] = ll; S.seqML[slot][i] = ml; S.seqOF[slot][i] = off;
-            }
-            if (!bad && first + cnt == nbSeq && br.pos != 0) bad = 1;
-            if (bad) S.err = ZE_CORRUPTION;
-            S.chunkN[slot] = cnt;
-          }
-        }
-        // -------- Huffman literal streams: wave 1 lanes 0..3, during iteration 0 only
-        else if (wave == 1 && t == 0 && hufLits) {
-          const u32 nStreams = S.litStreams;
-          if ((u32)lane < nStreams) {
-            const u32 seg = nStreams == 1 ? regen : (regen + 3) / 4;
-            const u32 myLen = nStreams == 1 ? regen : (lane < 3 ? seg : regen - 3 * seg);
-            u8* o = litScratch + (size_t)lane * seg;
-            BitR hb;
-            bool bad = hb.init(blk + S.streamOff[lane], S.streamLen[lane], lim) != 0;
-            if (!bad) {
-              const int mb = (int)S.hufMaxBits;
-              u32 i = 0;
-              // 4 symbols per window reload (4*11 = 44 <= 56 guaranteed bits)
-              for (; i + 4 <= myLen; i += 4) {
-                hb.ensure(4 * mb);
-                u32 packed = 0;
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                  // peek may straddle below bit 0 only in the last symbols; ensure() handles zeros
-                  u32 e = S.huf[hb.peek(mb)];
-                  packed |= (e & 0xFF) << (8 * k);
-                  hb.skip((int)(e >> 8));
-                }
-                st32(o + i, packed);
-              }
-              for (; i < myLen; i++) {
-                hb.ensure(mb);
-                u32 e = S.huf[hb.peek(mb)];
-                o[i] = (u8)e;
-                hb.skip((int)(e >> 8));
-              }
-              if (hb.pos != 0) bad = true;
-            }
-            if (bad) S.err = ZE_CORRUPTION;
-          }
-        }
-        // -------- stage C: wave 1 — matches of chunk t-2 (dependency order; 64 lanes per copy)
-        if (wave == 1 && t >= 2 && t - 2 < nChunks) {
-          const int slot = (t - 2) % 3;
-          const u32 cnt = S.chunkN[slot];
+      u32 outBase = 0, litBase = 0;              // running positions (wave-uniform)
+      bool fail = false;
+      for (u32 first = 0; first < nbSeq; first += BATCH) {
+        const u32 cnt = min((u32)BATCH, nbSeq - first);
+        // -------- stage A: lane 0 — FSE sequence decode of this batch
+        if (lane == 0) {
+          u32 bad = 0;
           for (u32 i = 0; i < cnt; i++) {
-            const u32 ml = S.seqML[slot][i], off = S.seqOF[slot][i];
-            const u32 d = S.seqOut[slot][i] + S.seqLL[slot][i];
-            if (d > outCap || off > S.produced + d || ml > outCap - d) { if (lane == 0) S.err = (d <= outCap && off > S.produced + d) ? ZE_CORRUPTION : ZE_DSTSIZE_TOOSMALL; break; }
-            u8* dp = out + d; const u8* sp = dp - off;
-            if (off >= ml) { for (u32 k = lane; k < ml; k += WAVE) dp[k] = sp[k]; }
-            else { for (u32 k = lane; k < ml; k += WAVE) dp[k] = sp[k % off]; }
-            // later sequences may read what this one wrote
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-          }
-        }
-        // -------- stage B: waves 2,3 — scan + literal copies of chunk t-1
-        if (wave >= 2 && t >= 1 && t - 1 < nChunks) {
-          const int slot = (t - 1) % 3;
-          const u32 cnt = S.chunkN[slot];
-          const int t2 = tid - 128;                      // 0..127
-          // exclusive scan of (ll+ml) and ll over the chunk: 4 sequences per thread, then wave scans
-          u32 llv[4], tot[4], sLLsum = 0, sTot = 0;
-#pragma unroll
-          for (int k = 0; k < 4; k++) {
-            const u32 i = (u32)t2 * 4 + k;
-            llv[k] = i < cnt ? S.seqLL[slot][i] : 0;
-            tot[k] = i < cnt ? llv[k] + S.seqML[slot][i] : 0;
-            sLLsum += llv[k]; sTot += tot[k];
-          }
-          u32 incL = wave_incl_scan(sLLsum), incT = wave_incl_scan(sTot);
-          // a workgroup barrier here would involve waves 0/1 mid-stage, so wave 3 re-derives wave 2's total itself
-          u32 baseL = S.litBase, baseT = S.outBase;
-          if (wave == 3) {
-            // recompute the total of the first 256 sequences (wave 2's share)
-            u32 aL = 0, aT = 0;
-            for (u32 i = lane; i < min(cnt, 256u); i += WAVE) { aL += S.seqLL[slot][i]; aT += S.seqLL[slot][i] + S.seqML[slot][i]; }
-            baseL += wave_sum(aL); baseT += wave_sum(aT);
-          }
-          u32 exL = baseL + incL - sLLsum, exT = baseT + incT - sTot;
-#pragma unroll
-          for (int k = 0; k < 4; k++) {
-            const u32 i = (u32)t2 * 4 + k;
-            if (i < cnt) {
-              S.seqOut[slot][i] = exT; S.seqLit[slot][i] = exL;
-              const u32 ll = llv[k];
-              if (ll) {
-                if (exL > regen || ll > regen - exL) S.err = ZE_CORRUPTION;
-                else if (exT > outCap || ll > outCap - exT) S.err = ZE_DSTSIZE_TOOSMALL;
-                else { const u8* lp = lit + exL; u8* op = out + exT; for (u32 b = 0; b < ll; b++) op[b] = lp[b]; }
-              }
-              exT += tot[k]; exL += llv[k];
+            const u64 eL = S.llT[sLL], eM = S.mlT[sML], eO = S.ofT[sOF];
+            const u32 ofBits = (u32)(eO >> 32) & 0xFF, mlBits = (u32)(eM >> 32) & 0xFF, llBits = (u32)(eL >> 32) & 0xFF;
+            if (ofBits > 31) { bad = 1; break; }
+            u32 offVal = (u32)eO + br.read((int)ofBits);
+            br.ensure((int)(mlBits + llBits));
+            u32 ml = (u32)eM + (mlBits ? br.peek((int)mlBits) : 0); br.skip((int)mlBits);
+            u32 ll = (u32)eL + (llBits ? br.peek((int)llBits) : 0); br.skip((int)llBits);
+            if (first + i + 1 < nbSeq) {
+              const int nL = (int)((eL >> 40) & 0xFF), nM = (int)((eM >> 40) & 0xFF), nO = (int)((eO >> 40) & 0xFF);
+              br.ensure(nL + nM + nO);
+              sLL = (u32)(eL >> 48) + (nL ? br.peek(nL) : 0); br.skip(nL);
+              sML = (u32)(eM >> 48) + (nM ? br.peek(nM) : 0); br.skip(nM);
+              sOF = (u32)(eO >> 48) + (nO ? br.peek(nO) : 0); br.skip(nO);
             }
+            if (br.pos < 0) { bad = 1; break; }
+            u32 off;                                   // repcode resolution (A.3)
+            if (offVal > 3) { off = offVal - 3; rep2 = rep1; rep1 = rep0; rep0 = off; }
+            else {
+              u32 idx = offVal + (ll == 0);
+              if (idx == 1) off = rep0;
+              else {
+                off = idx == 2 ? rep1 : idx == 3 ? rep2 : rep0 - 1;
+                if (off == 0) { bad = 1; break; }
+                if (idx != 2) rep2 = rep1;
+                rep1 = rep0; rep0 = off;
+              }
+            }
+            S.seqLL[i] = ll; S.seqML[i] = ml; S.seqOF[i] = off;
+          }
+          if (!bad && first + cnt == nbSeq && br.pos != 0) bad = 1;
+          if (bad) S.err = ZE_CORRUPTION;
+        }
+        wsync();
+        if (S.err) { fail = true; break; }
+        // -------- stage B: positions by wave prefix scan; every lane copies its sequence's literals
+        const bool act = (u32)lane < cnt;
+        const u32 ll = act ? S.seqLL[lane] : 0, ml = act ? S.seqML[lane] : 0, off = act ? S.seqOF[lane] : 1;
+        const u32 tot = ll + ml;
+        const u32 incT = wave_incl_scan(tot), incL = wave_incl_scan(ll);
+        const u32 oStart = outBase + incT - tot, lStart = litBase + incL - ll;
+        const u32 mdst = oStart + ll;
+        u32 e = 0;
+        if (act) {
+          if (lStart > regen || ll > regen - lStart) e = ZE_CORRUPTION;
+          else if (oStart > outCap || tot > outCap - oStart) e = ZE_DSTSIZE_TOOSMALL;
+          else if (off > produced0 + mdst) e = ZE_CORRUPTION;
+        }
+        const u64 em = __ballot(e != 0);
+        if (em) { if ((u32)lane == (u32)__builtin_ctzll(em)) S.err = e; wsync(); fail = true; break; }
+        {
+          const u8* lp = lit + lStart; u8* op = out + oStart;
+          const bool longLit = ll > 32;
+          if (!longLit) for (u32 b = 0; b < ll; b++) op[b] = lp[b];
+          u64 lm = __ballot(longLit);
+          while (lm) {                               // long literal runs: the whole wave copies, coalesced
+            const u32 j = (u32)__builtin_ctzll(lm); lm &= lm - 1;
+            const u32 jl = bcast_u32(ll, j), jo = bcast_u32(oStart, j), js = bcast_u32(lStart, j);
+            copy_bytes(out + jo, lit + js, jl, lane, DEC_THREADS);
           }
         }
-        __syncthreads();
-        // advance running bases after stage B of chunk t-1 (thread 0; totals recomputed cheaply by wave 0 is avoided:
-        // the last thread of the scan wrote nothing, so recompute here from the chunk in LDS)
-        if (t >= 1 && t - 1 < nChunks) {
-          const int slot = (t - 1) % 3;
-          const u32 cnt = S.chunkN[slot];
-          if (wave == 0) {
-            u32 aL = 0, aT = 0;
-            for (u32 i = lane; i < cnt; i += WAVE) { aL += S.seqLL[slot][i]; aT += S.seqLL[slot][i] + S.seqML[slot][i]; }
-            aL = wave_sum(aL); aT = wave_sum(aT);
-            if (lane == 0) { S.litBase += aL; S.outBase += aT; }
+        wsync();
+        // -------- stage C: match copies in dependency rounds
+        {
+          const u32 msrc = mdst - off;
+          const u32 msrcEnd = min(msrc + ml, mdst);
+          u64 pending = __ballot(act);
+          while (pending) {
+            const u32 fnd = (u32)__builtin_ctzll(pending);
+            const u32 frontier = bcast_u32(mdst, fnd);
+            const bool mine = (pending >> lane) & 1;
+            const bool ready = mine && (msrcEnd <= frontier || (u32)lane == fnd);
+            const bool longM = ready && ml > 64;
+            if (ready && !longM) {
+              u8* dp = out + mdst; const u8* sp = dp - off;
+              if (off >= ml) {                           // no overlap: 8-byte moves + byte tail
+                u32 k = 0;
+                for (; k + 8 <= ml; k += 8) st64(dp + k, ld64(sp + k));
+                for (; k < ml; k++) dp[k] = sp[k];
+              } else {                                   // overlapping match = period `off`: read only bytes in front of the destination
+                u32 j = 0;
+                for (u32 k = 0; k < ml; k++) { dp[k] = sp[j]; j = j + 1 == off ? 0 : j + 1; }
+              }
+            }
+            u64 lmk = __ballot(longM);
+            while (lmk) {                            // long matches: the whole wave copies (period-safe modular source)
+              const u32 j = (u32)__builtin_ctzll(lmk); lmk &= lmk - 1;
+              const u32 jml = bcast_u32(ml, j), jd = bcast_u32(mdst, j), jof = bcast_u32(off, j);
+              u8* dp = out + jd; const u8* sp = dp - jof;
+              if (jof >= jml) { for (u32 k = lane; k < jml; k += WAVE) dp[k] = sp[k]; }
+              else { for (u32 k = lane; k < jml; k += WAVE) dp[k] = sp[k % jof]; }
+            }
+            pending &= ~__ballot(ready);
+            wsync();
           }
         }
-        __syncthreads();
-        if (S.err) break;
-        if (nChunks == 0) break;
+        outBase += bcast_u32(incT, 63); litBase += bcast_u32(incL, 63);
       }
-      if (S.err) break;
+      if (fail || S.err) break;
 
       // ---- block tail: remaining literals
-      {
-        const u32 lb = S.litBase, ob = S.outBase;
-        if (lb > regen) { if (tid == 0) S.err = ZE_CORRUPTION; }
-        else if (ob > outCap || regen - lb > outCap - ob) { if (tid == 0) S.err = ZE_DSTSIZE_TOOSMALL; }
-        else copy_bytes(out + ob, lit + lb, regen - lb, tid, DEC_THREADS);
-        __syncthreads();
-        if (tid == 0 && !S.err) {
-          S.produced += ob + (regen - lb);
-          S.blkPos = bpos + bsize;
-          S.rep[0] = rep0; S.rep[1] = rep1; S.rep[2] = rep2;
-        }
+      if (litBase > regen) { if (lane == 0) S.err = ZE_CORRUPTION; }
+      else if (outBase > outCap || regen - litBase > outCap - outBase) { if (lane == 0) S.err = ZE_DSTSIZE_TOOSMALL; }
+      else copy_bytes(out + outBase, lit + litBase, regen - litBase, lane, DEC_THREADS);
+      wsync();
+      if (lane == 0 && !S.err) {
+        S.produced = produced0 + outBase + (regen - litBase);
+        S.blkPos = bpos + bsize;
+        S.rep[0] = rep0; S.rep[1] = rep1; S.rep[2] = rep2;
       }
-      __syncthreads();
+      wsync();
     }
 
     // ------------------------------------------------------------------ frame end
-    if (tid == 0) {
+    if (lane == 0) {
       u32 err = S.err;
       if (!err) {
         u32 pos = S.blkPos;
@@ -680,6 +636,6 @@ zra_decode_frames_kernel(ZraDecodeArgs a) {
       a.status[f] = err;
       a.produced[f] = S.produced;
     }
-    __syncthreads();
+    wsync();
   }
 }

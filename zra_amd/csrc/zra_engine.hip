@@ -152,7 +152,7 @@ Status Engine::decode_jobs(const uint8_t* dBody, uint64_t bodySize, const uint64
   if (nFrames == 0) return ok();
   HIPCHK(hipSetDevice(device_));
   int perCU = 0;
-  HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, zra_decode_frames_kernel, 256, 0));
+  HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, zra_decode_frames_kernel, 64, 0));
   if (perCU < 1) perCU = 1;
   uint32_t grid = (uint32_t)std::min<uint64_t>(nFrames, (uint64_t)numCUs_ * perCU);
   if (!litScratch_.reserve((size_t)grid * ZRA_LIT_STRIDE) || !queue_.reserve(64) || !status_.reserve((size_t)nFrames * 4) ||
@@ -165,7 +165,7 @@ Status Engine::decode_jobs(const uint8_t* dBody, uint64_t bodySize, const uint64
   a.nFrames = nFrames; a.offStride = offStride; a.queue = queue_.as<uint32_t>(); a.litScratch = litScratch_.as<uint8_t>();
   a.status = status_.as<uint32_t>(); a.produced = produced_.as<uint32_t>(); a.frameMeta = frameMeta_.as<uint32_t>();
   HIPCHK(hipEventRecord(ev0_, stream_));
-  hipLaunchKernelGGL(zra_decode_frames_kernel, dim3(grid), dim3(256), 0, stream_, a);
+  hipLaunchKernelGGL(zra_decode_frames_kernel, dim3(grid), dim3(64), 0, stream_, a);
   HIPCHK(hipEventRecord(ev1_, stream_));
   const uint32_t tb = 256;
   hipLaunchKernelGGL(zra_xxh64_verify_kernel, dim3((nFrames * 4 + tb - 1) / tb), dim3(tb), 0, stream_, dOut, dOutOff, dExpect,
