@@ -189,6 +189,7 @@ def main():
     comp_ms = []
     ra_ms = []
     mf_ms = []
+    dec_stats = []
     arc_size = 0
 
     def step():
@@ -196,13 +197,13 @@ def main():
         t0 = time.perf_counter()
         if world == 1:
             arc_size = eng.compress(d_in.data_ptr(), N, d_arc.data_ptr(), args.level, fs, True)
-            mf_ms.append(eng.last_kernel_ms())
+            mf_ms.append(eng.kernel_stats())
         else:
             # sharded: local frames -> packed local body + sizes; all-gather sizes; header stitched on every rank;
             # bodies gathered (variable length) to rank 0 behind the stitched header
             d_sizes = torch.empty(nframes, dtype=torch.int64, device=dev)
             body_len = eng.compress_frames(d_in.data_ptr(), N, d_arc.data_ptr(), d_sizes.data_ptr(), args.level, fs, True)
-            mf_ms.append(eng.last_kernel_ms())
+            mf_ms.append(eng.kernel_stats())
             from zra_amd import sharding
             root, hdr, bases, totals = sharding.gather_archive(d_arc[:body_len], d_sizes, N * world, fs, getattr(step, "root", None))
             if rank == 0:
@@ -213,6 +214,7 @@ def main():
         # RA over this rank's own shard (the archive stays sharded for serving; queries are routed to the owner)
         if world == 1:
             eng.decompress_ra_batch(d_arc.data_ptr(), arc_size, d_ra.data_ptr(), offs, sizes, oofs)
+            dec_stats.append(eng.kernel_stats())
         else:
             # local archive for serving = local header + local body (cheap host stitch of local sizes)
             lsz = d_sizes.cpu().numpy().astype(np.uint64)
@@ -225,6 +227,7 @@ def main():
             loc[: len(lh)] = torch.frombuffer(bytearray(lh), dtype=torch.uint8).to(dev)
             loc[len(lh): need] = d_arc[: need - len(lh)]
             eng.decompress_ra_batch(loc.data_ptr(), need, d_ra.data_ptr(), offs, sizes, oofs)
+            dec_stats.append(eng.kernel_stats())
         torch.cuda.synchronize()
         t2 = time.perf_counter()
         comp_ms.append((t1 - t0) * 1e3)
@@ -232,7 +235,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    comp_ms.clear(); ra_ms.clear(); mf_ms.clear()
+    comp_ms.clear(); ra_ms.clear(); mf_ms.clear(); dec_stats.clear()
     sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -256,16 +259,23 @@ def main():
         moved = (N + q * qb) * world
         value = moved / GiB / (elapsed / args.steps)
         ratio = N / max(1, (arc_size if world == 1 else arc_size / world))
-        # roofline of the dominant kernel (match finder + entropy stage rounds of one CompressBuffer call, HIP-event timed on
-        # the engine's stream): algorithmic bytes = N_in + C_out
-        kms = float(np.mean(mf_ms)) if mf_ms else 0.0
-        alg_bytes = N + (arc_size if world == 1 else arc_size / world)
-        achieved = alg_bytes / 1e9 / (kms / 1e3) if kms > 0 else 0.0
+        # roofline of the dominant kernel = the match finder (zra_mf_kernel): per-launch duration from HIP events recorded on the
+        # engine's stream around each launch; algorithmic bytes = N_in + C_out of the frames of that launch (SURVEY §8d:
+        # 65536*(1+1/ratio) per 64 KiB frame x frames per launch)
+        st = mf_ms[-1] if mf_ms else dict(mf_ms=0, mf_launches=0, ent_ms=0, ent_launches=0)
+        c_out = (arc_size if world == 1 else arc_size / world)
+        alg_bytes = N + c_out
+        launches = max(1, st["mf_launches"])
+        mf_launch_ms = float(np.mean([x["mf_ms"] / max(1, x["mf_launches"]) for x in mf_ms])) if mf_ms else 0.0
+        ent_launch_ms = float(np.mean([x["ent_ms"] / max(1, x["ent_launches"]) for x in mf_ms])) if mf_ms else 0.0
+        dec_launch_ms = float(np.mean([x["dec_ms"] / max(1, x["dec_launches"]) for x in dec_stats])) if dec_stats else 0.0
+        alg_per_launch = alg_bytes / launches
+        achieved = alg_per_launch / 1e9 / (mf_launch_ms / 1e3) if mf_launch_ms > 0 else 0.0
         traffic = None
         tpath = os.path.join(HERE, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                traffic = json.load(open(tpath)).get("zra_mf_kernel_hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         line = {
@@ -281,9 +291,10 @@ def main():
             "compress_gibs": round(N * world / GiB / (np.mean(comp_ms) / 1e3), 3),
             "ra_gibs_returned": round(q * qb * world / GiB / (np.mean(ra_ms) / 1e3), 3),
             "ra_us_per_query": round(np.mean(ra_ms) * 1e3 / q, 3),
-            "roofline": {"bound": "hbm", "kernel": "zra_mf_kernel+zra_entropy_kernel (CompressBuffer rounds)", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "frac_of_measured_6290": round(achieved / 6290.0, 5),
-                         "traffic": traffic, "kernel_ms_per_call": round(kms, 3), "algorithmic_bytes_per_call": int(alg_bytes)},
+            "roofline": {"bound": "hbm", "kernel": "zra_mf_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "frac_of_measured_6290": round(achieved / 6290.0, 5), "traffic": traffic,
+                         "launch_ms": round(mf_launch_ms, 3), "launches_per_call": launches, "algorithmic_bytes_per_launch": int(alg_per_launch),
+                         "other_kernels_launch_ms": {"zra_entropy_kernel": round(ent_launch_ms, 3), "zra_decode_frames_kernel": round(dec_launch_ms, 3)}},
             "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)

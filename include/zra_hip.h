@@ -60,6 +60,9 @@ ZRA_EXPORT ZraStatus ZraHipStitchHeader(const uint64_t* hFrameSizes, size_t nFra
 
 /** Last per-call timing of the dominant kernel on the engine's stream, measured with HIP events (milliseconds; 0 if none). */
 ZRA_EXPORT double ZraHipLastKernelMs(ZraHipEngine* engine);
+/** HIP-event timings (ms) and launch counts of the kernels of the LAST call on this engine, measured on the engine's stream:
+ *  out6 = {match-finder ms, launches, entropy-stage ms, launches, decode ms, launches}. */
+ZRA_EXPORT void ZraHipGetKernelStats(ZraHipEngine* engine, double* out6);
 
 #ifdef __cplusplus
 }

@@ -82,6 +82,7 @@ def load():
         "ZraHipSynchronize": (S, [vp]),
         "ZraHipGetStream": (vp, [vp]),
         "ZraHipLastKernelMs": (ctypes.c_double, [vp]),
+        "ZraHipGetKernelStats": (None, [vp, ctypes.POINTER(ctypes.c_double)]),
         "ZraHipCompressBuffer": (S, [vp, vp, sz, vp, szp, ctypes.c_int8, u32, ctypes.c_bool]),
         "ZraHipDecompressBuffer": (S, [vp, vp, sz, vp, sz]),
         "ZraHipDecompressRABatch": (S, [vp, vp, sz, vp, u64p, u64p, u64p, sz]),
@@ -105,7 +106,7 @@ C_ABI_SYMBOLS = [
     "ZraDecompressWithDecompressor", "ZraCreateFullDecompressor", "ZraDeleteFullDecompressor", "ZraGetHeaderWithFullDecompressor",
     "ZraDecompressWithFullDecompressor",
 ]
-HIP_ABI_SYMBOLS = ["ZraHipDeviceCount", "ZraHipCreateEngine", "ZraHipDestroyEngine", "ZraHipSynchronize", "ZraHipGetStream", "ZraHipLastKernelMs",
+HIP_ABI_SYMBOLS = ["ZraHipDeviceCount", "ZraHipCreateEngine", "ZraHipDestroyEngine", "ZraHipSynchronize", "ZraHipGetStream", "ZraHipLastKernelMs", "ZraHipGetKernelStats",
                    "ZraHipCompressBuffer", "ZraHipDecompressBuffer", "ZraHipDecompressRABatch", "ZraHipCompressFrames", "ZraHipStitchHeader"]
 
 
@@ -175,6 +176,12 @@ class Engine:
 
     def last_kernel_ms(self):
         return self.L.ZraHipLastKernelMs(self.h)
+
+    def kernel_stats(self):
+        """{mf_ms, mf_launches, ent_ms, ent_launches, dec_ms, dec_launches} of the last call (HIP events on the engine stream)."""
+        a = (ctypes.c_double * 6)()
+        self.L.ZraHipGetKernelStats(self.h, a)
+        return dict(mf_ms=a[0], mf_launches=int(a[1]), ent_ms=a[2], ent_launches=int(a[3]), dec_ms=a[4], dec_launches=int(a[5]))
 
     def compress(self, d_in, in_size, d_out, level=3, frame_size=65536, checksum=True):
         osz = ctypes.c_size_t(0)

@@ -439,6 +439,7 @@ void ZraHipDestroyEngine(ZraHipEngine* engine) { if (engine) { delete engine->e;
 ZraStatus ZraHipSynchronize(ZraHipEngine* engine) { return mk(engine->e->sync()); }
 void* ZraHipGetStream(ZraHipEngine* engine) { return (void*)engine->e->stream(); }
 double ZraHipLastKernelMs(ZraHipEngine* engine) { return engine->e->last_kernel_ms(); }
+void ZraHipGetKernelStats(ZraHipEngine* engine, double* out6) { engine->e->kernel_stats(out6); }
 
 ZraStatus ZraHipCompressBuffer(ZraHipEngine* engine, const void* dIn, size_t inSize, void* dOut, size_t* outSize, int8_t level, uint32_t frameSize, bool checksum) {
   return mk(engine->e->compress_device((const uint8_t*)dIn, inSize, (uint8_t*)dOut, outSize, level, frameSize, checksum));

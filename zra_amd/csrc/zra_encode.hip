@@ -140,6 +140,7 @@ Status Engine::compress_impl(const uint8_t* dIn, size_t inSize, uint8_t* dBody, 
   ZraEncArgs a{};
   a.in = dIn; a.inSize = inSize; a.frameSize = frameSize; a.checksum = checksum ? 1 : 0;
   a.full = full; a.tail = tail;
+  { static const int tune = std::getenv("ZRA_MF_TUNE") ? std::atoi(std::getenv("ZRA_MF_TUNE")) : 0; a.mfTune = (uint32_t)tune; }
   a.tables = encTables_.as<uint32_t>(); a.tableStride = tableWords;
   a.seqs = encSeqs_.as<uint64_t>(); a.seqStride = seqStride;
   a.lits = encLits_.as<uint8_t>(); a.litStride = litStride;
@@ -153,6 +154,7 @@ Status Engine::compress_impl(const uint8_t* dIn, size_t inSize, uint8_t* dBody, 
 
   uint64_t bodyOff = 0;
   double kernelMs = 0;
+  kstats_[0] = kstats_[1] = kstats_[2] = kstats_[3] = 0;
   for (uint64_t f0 = 0; f0 < nFramesTotal; f0 += B) {
     const uint32_t nb = (uint32_t)std::min<uint64_t>(B, nFramesTotal - f0);
     a.firstFrame = (uint32_t)f0; a.nFrames = nb;
@@ -162,16 +164,18 @@ Status Engine::compress_impl(const uint8_t* dIn, size_t inSize, uint8_t* dBody, 
     const uint64_t firstFrameSize = std::min<uint64_t>(frameSize, inSize - f0 * frameSize);
     const ZraEncParams& P0 = firstFrameSize == frameSize ? full : tail;
     const uint32_t rounds = (uint32_t)((firstFrameSize + P0.blockSize - 1) / P0.blockSize);
-    HIPCHK(hipEventRecord(ev0_, stream_));
+    const uint32_t timedRounds = std::min<uint32_t>(rounds, 8);
     for (uint32_t blk = 0; blk < rounds; blk++) {
+      if (blk < timedRounds) HIPCHK(hipEventRecord(evR_[2 * blk], stream_));
       {
         // occupancy experiment knob (bring-up): dynamic LDS per workgroup caps the frames in flight per CU
         static const int dynLds = std::getenv("ZRA_MF_LDS") ? std::atoi(std::getenv("ZRA_MF_LDS")) : 0;
         hipLaunchKernelGGL(zra_mf_kernel, dim3(nb), dim3(64), dynLds, stream_, a, blk);
       }
+      if (blk < timedRounds) HIPCHK(hipEventRecord(evR_[2 * blk + 1], stream_));
       hipLaunchKernelGGL(zra_entropy_kernel, dim3(nb), dim3(256), 0, stream_, a, blk);
     }
-    HIPCHK(hipEventRecord(ev1_, stream_));
+    HIPCHK(hipEventRecord(evR_[2 * timedRounds], stream_));
     hipLaunchKernelGGL(zra_scan_sizes_kernel, dim3(1), dim3(1024), 0, stream_, a.sizes, nb, dOffsets, dTotal);
     hipLaunchKernelGGL(zra_gather_frames_kernel, dim3(nb), dim3(256), 0, stream_, a.slots, slotStride, a.sizes, dOffsets, dBody,
                        bodyBase0 + bodyOff, dEntries ? dEntries : nullptr, (u32)f0, dSizes);
@@ -179,10 +183,11 @@ Status Engine::compress_impl(const uint8_t* dIn, size_t inSize, uint8_t* dBody, 
     HIPCHK(hipMemcpyAsync(&total, dTotal, 8, hipMemcpyDeviceToHost, stream_));
     HIPCHK(hipStreamSynchronize(stream_));
     HIPCHK(hipGetLastError());
-    float ms = 0;
-    if (hipEventElapsedTime(&ms, ev0_, ev1_) == hipSuccess) kernelMs += ms;
-    // entries written by the gather kernel hold absolute (bodyBase0-including) offsets; fix-up is avoided by passing
-    // bodyBase0 only through `body` pointer arithmetic below
+    for (uint32_t r = 0; r < timedRounds; r++) {
+      float m1 = 0, m2 = 0;
+      if (hipEventElapsedTime(&m1, evR_[2 * r], evR_[2 * r + 1]) == hipSuccess) { kstats_[0] += m1; kstats_[1] += 1; kernelMs += m1; }
+      if (hipEventElapsedTime(&m2, evR_[2 * r + 1], evR_[2 * r + 2]) == hipSuccess) { kstats_[2] += m2; kstats_[3] += 1; kernelMs += m2; }
+    }
     bodyOff += total;
   }
   lastKernelMs_ = kernelMs;

@@ -291,7 +291,7 @@ __device__ __forceinline__ u32 wave_count_back(const u8* src, u32 ip, u32 m, u32
 
 template <typename T, bool TAG>
 __device__ u32 mf_dfast_wave(const ZraEncParams& P, T* HL, T* HS, const u8* src, u32 bs, u32 be, u32* rep, u64* seqs, u32* nOut,
-                             u32* dupL, u32* dupS, int lane) {
+                             u32* dupL, u32* dupS, int lane, u32 tune) {
   const u32 hlog = P.hashLog, clog = P.chainLog, mls = P.minMatch;
   u32 o1 = rep[0], o2 = rep[1], saved;
   u32 anchor = bs, nseq = 0;
@@ -342,8 +342,8 @@ __device__ u32 mf_dfast_wave(const ZraEncParams& P, T* HL, T* HS, const u8* src,
     const u64 hm = __ballot(repHit || longHit || shortHit);
     const u32 f = hm ? (u32)__builtin_ctzll(hm) : nAct - 1;
     if (active && (u32)lane <= f) { HL[hL] = (T)((p + 1) | tL); HS[hS] = (T)((p + 1) | tS); }
-    if (!hm) { ip += nAct * s; W = min(64u, W * 2); continue; }
-    W = min(64u, max(4u, 2 * (f + 1)));
+    if (!hm) { ip += nAct * s; W = tune == 3 ? 64u : tune == 4 ? 16u : min(64u, W * 2); continue; }
+    W = tune == 1 ? min(64u, max(2u, f + 2)) : tune == 2 ? min(64u, max(8u, 4 * (f + 1))) : tune == 3 ? 64u : tune == 4 ? 16u : tune == 5 ? min(64u, max(4u, f + 4)) : min(64u, max(4u, 2 * (f + 1)));
     // ---- the hit lane's values, wave-uniform from here on
     const u32 top = ip + f * s;
     const u64 v8f = bcast64(v8, f);
@@ -451,8 +451,8 @@ zra_mf_kernel(ZraEncArgs a, u32 block) {
     __shared__ u32 dupL[512], dupS[512];
     for (int i = lane; i < 512; i += 64) { dupL[i] = 0; dupS[i] = 0; }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-    if (tagged) lastLL = mf_dfast_wave<u32, true>(P, hashT, chainT, src, bs, be, rep, seqs, &nseq, dupL, dupS, lane);
-    else lastLL = mf_dfast_wave<u32, false>(P, hashT, chainT, src, bs, be, rep, seqs, &nseq, dupL, dupS, lane);
+    if (tagged) lastLL = mf_dfast_wave<u32, true>(P, hashT, chainT, src, bs, be, rep, seqs, &nseq, dupL, dupS, lane, a.mfTune);
+    else lastLL = mf_dfast_wave<u32, false>(P, hashT, chainT, src, bs, be, rep, seqs, &nseq, dupL, dupS, lane, a.mfTune);
     if (lane == 0) {
       bo->nbSeq = nseq; bo->lastLL = lastLL; bo->skip = 0;
       bo->rep[0] = rep[0]; bo->rep[1] = rep[1]; bo->rep[2] = rep[2];

@@ -38,6 +38,8 @@ class Engine {
   hipStream_t stream() const { return stream_; }
   Status sync();
   double last_kernel_ms() const { return lastKernelMs_; }
+  // HIP-event timings of the last call on the engine's stream: {mf ms, mf launches, entropy ms, entropy launches, decode ms, decode launches}
+  void kernel_stats(double out[6]) const { for (int i = 0; i < 6; i++) out[i] = kstats_[i]; }
 
   // ---- decode
   // Decode nFrames frames described by device job arrays. Synchronises and returns the first failing frame's code.
@@ -80,6 +82,8 @@ class Engine {
   hipStream_t stream_ = nullptr;
   hipEvent_t ev0_ = nullptr, ev1_ = nullptr;
   double lastKernelMs_ = 0;
+  double kstats_[6] = {0, 0, 0, 0, 0, 0};
+  hipEvent_t evR_[17] = {nullptr};   // per-round events of one encode batch: e[2r] before mf, e[2r+1] between, e[2r+2] after entropy
   // decode scratch
   DevBuf litScratch_, queue_, status_, produced_, frameMeta_, frameOff_, outOff_, expect_, result_, temp_, qmeta_;
   // encode scratch (see zra_encode.hip)

@@ -130,6 +130,7 @@ Status Engine::create(Engine** out, int device) {
   e->numCUs_ = prop.multiProcessorCount;
   if (hipStreamCreateWithFlags(&e->stream_, hipStreamNonBlocking) != hipSuccess) { delete e; return zerr(1); }
   if (hipEventCreate(&e->ev0_) != hipSuccess || hipEventCreate(&e->ev1_) != hipSuccess) { delete e; return zerr(1); }
+  for (auto& ev : e->evR_) if (hipEventCreate(&ev) != hipSuccess) { delete e; return zerr(1); }
   *out = e;
   return ok();
 }
@@ -140,6 +141,7 @@ Engine::~Engine() {
   for (DevBuf* b : {&litScratch_, &queue_, &status_, &produced_, &frameMeta_, &frameOff_, &outOff_, &expect_, &result_, &temp_, &qmeta_,
                     &encTables_, &encSeqs_, &encSlots_, &encSizes_, &encMisc_, &encLits_, &encCk_, &encScan_, &hostIn_, &hostOut_})
     b->release();
+  for (auto& ev : evR_) if (ev) (void)hipEventDestroy(ev);
   if (ev0_) (void)hipEventDestroy(ev0_);
   if (ev1_) (void)hipEventDestroy(ev1_);
   if (stream_) (void)hipStreamDestroy(stream_);
@@ -177,13 +179,14 @@ Status Engine::decode_jobs(const uint8_t* dBody, uint64_t bodySize, const uint64
   HIPCHK(hipStreamSynchronize(stream_));
   HIPCHK(hipGetLastError());
   float ms = 0;
-  if (hipEventElapsedTime(&ms, ev0_, ev1_) == hipSuccess) lastKernelMs_ = ms;
+  if (hipEventElapsedTime(&ms, ev0_, ev1_) == hipSuccess) { lastKernelMs_ = ms; kstats_[4] += ms; kstats_[5] += 1; }
   if (res != ~0ull) return zerr((int)(res & 0xFF));
   return ok();
 }
 
 Status Engine::decompress_device(const uint8_t* dArc, size_t arcSize, uint8_t* dOut, size_t outCap) {
   HIPCHK(hipSetDevice(device_));
+  kstats_[4] = kstats_[5] = 0;
   if (arcSize <= zra_fmt::kFixedSize) return {kOutOfBounds, 0};          // BufferView reader quirk, zra.cpp:166
   uint8_t fixed[zra_fmt::kFixedSize];
   HIPCHK(hipMemcpyAsync(fixed, dArc, sizeof(fixed), hipMemcpyDeviceToHost, stream_));
@@ -225,6 +228,7 @@ Status Engine::decompress_frames_host_list(const uint8_t* dBody, uint64_t bodySi
 Status Engine::decompress_ra_batch(const uint8_t* dArc, size_t arcSize, uint8_t* dOut, const uint64_t* hOff, const uint64_t* hSize,
                                    const uint64_t* hOutOff, size_t nq) {
   HIPCHK(hipSetDevice(device_));
+  kstats_[4] = kstats_[5] = 0;
   if (arcSize <= zra_fmt::kFixedSize) return {kOutOfBounds, 0};
   uint8_t fixed[zra_fmt::kFixedSize];
   HIPCHK(hipMemcpyAsync(fixed, dArc, sizeof(fixed), hipMemcpyDeviceToHost, stream_));
