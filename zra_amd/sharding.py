@@ -14,9 +14,15 @@ def shard_range(nframes, rank, world):
     return (nframes * rank) // world, (nframes * (rank + 1)) // world
 
 
+def _comm_device(t):
+    """RCCL moves device tensors directly; the gloo backend (CPU tests, single-GPU dry runs) gets host staging."""
+    return torch.device("cpu") if dist.get_backend() == "gloo" else t.device
+
+
 def allgather_sizes(local_sizes, group=None):
-    """local_sizes: int64 tensor [n_local] on the communication device. Returns the list of per-rank size tensors (rank order)."""
+    """local_sizes: int64 tensor [n_local]. Returns the list of per-rank size tensors (rank order)."""
     world = dist.get_world_size(group)
+    local_sizes = local_sizes.to(_comm_device(local_sizes))
     n = torch.tensor([local_sizes.numel()], dtype=torch.int64, device=local_sizes.device)
     counts = [torch.zeros_like(n) for _ in range(world)]
     dist.all_gather(counts, n, group=group)
@@ -52,13 +58,20 @@ def gather_archive(local_body, local_sizes, uncompressed_size, frame_size, root_
             root_buffer = torch.empty(need, dtype=torch.uint8, device=local_body.device)
         root_buffer[:hlen] = torch.frombuffer(bytearray(header), dtype=torch.uint8).to(local_body.device)
         root_buffer[hlen: hlen + int(totals[0])] = local_body[: int(totals[0])]
+        staged = _comm_device(root_buffer) != root_buffer.device
         reqs = []
         for r in range(1, world):
             if int(totals[r]):
-                reqs.append(dist.irecv(root_buffer[hlen + int(bases[r]): hlen + int(bases[r]) + int(totals[r])], src=r, group=group))
+                dst = root_buffer[hlen + int(bases[r]): hlen + int(bases[r]) + int(totals[r])]
+                if staged:
+                    tmp = torch.empty(int(totals[r]), dtype=torch.uint8)
+                    dist.recv(tmp, src=r, group=group)
+                    dst.copy_(tmp)
+                else:
+                    reqs.append(dist.irecv(dst, src=r, group=group))
         for q in reqs:
             q.wait()
         return root_buffer[:need], header, bases, totals
     if int(totals[rank]):
-        dist.send(local_body[: int(totals[rank])].contiguous(), dst=0, group=group)
+        dist.send(local_body[: int(totals[rank])].contiguous().to(_comm_device(local_body)), dst=0, group=group)
     return None, header, bases, totals
