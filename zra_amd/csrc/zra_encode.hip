@@ -27,12 +27,13 @@ __global__ void zra_content_ck_kernel(const u8* in, u64 inSize, u32 frameSize, u
   if (active && j == 0) ck[f] = (u32)h;
 }
 
-// ---- exclusive scan of the batch's frame sizes (single workgroup, 1024 threads, chunked) -> offsets + total
-__global__ void __launch_bounds__(1024) zra_scan_sizes_kernel(const u64* sizes, u32 n, u64* offsets, u64* total) {
+// ---- exclusive scan of the batch's frame sizes (single workgroup, 1024 threads, chunked). The running body offset lives on the
+//      device (`running`), so batches chain without a host round trip: offsets[i] = *running + local prefix; *running += total.
+__global__ void __launch_bounds__(1024) zra_scan_sizes_kernel(const u64* sizes, u32 n, u64* offsets, u64* running) {
   __shared__ u64 wsum[16];
   __shared__ u64 carry;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (tid == 0) carry = 0;
+  if (tid == 0) carry = *running;
   __syncthreads();
   for (u32 base = 0; base < n; base += 1024) {
     const u32 i = base + tid;
@@ -47,7 +48,7 @@ __global__ void __launch_bounds__(1024) zra_scan_sizes_kernel(const u64* sizes, 
     if (tid == 0) carry += tot;
     __syncthreads();
   }
-  if (tid == 0) *total = carry;
+  if (tid == 0) *running = carry;
 }
 
 // ---- gather: frame f of the batch moves from its slot to body + bodyBase + offsets[f] (one workgroup per frame);
@@ -55,7 +56,8 @@ __global__ void __launch_bounds__(1024) zra_scan_sizes_kernel(const u64* sizes, 
 __global__ void zra_gather_frames_kernel(const u8* slots, u64 slotStride, const u64* sizes, const u64* offsets, u8* body, u64 bodyBase,
                                          u8* entries, u32 firstFrame, u64* sizesOut) {
   const u32 f = blockIdx.x;
-  const u64 n = sizes[f], off = bodyBase + offsets[f];
+  const u64 n = sizes[f], off = offsets[f];   // offsets are absolute within the body (running offset folded in by the scan)
+  (void)bodyBase;
   const u8* s = slots + (size_t)f * slotStride; u8* d = body + off;
   // slots are 16-byte aligned; destination is arbitrary: align on the source, let the stores be unaligned
   const u64 n16 = n >> 4;
@@ -129,69 +131,99 @@ Status Engine::compress_impl(const uint8_t* dIn, size_t inSize, uint8_t* dBody, 
   const uint64_t litStride = ((uint64_t)maxBlock + 64 + 15) & ~15ull;
   const uint32_t maxBlocksPerFrame = (std::min<uint64_t>(frameSize, inSize) + std::min(full.blockSize, tail.blockSize) - 1) / std::min(full.blockSize, tail.blockSize);
   const uint64_t slotStride = (zra_fmt::compress_bound(frameSize) + 1024 + 4 * (uint64_t)maxBlocksPerFrame + 15) & ~15ull;
-  const uint64_t perFrame = tableWords * 4 + seqStride * 8 + litStride + slotStride + sizeof(ZraEncFrameState) + 64;
-  const uint64_t budget = 12ull << 30;
-  const uint32_t B = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>({nFramesTotal, budget / perFrame, 16384ull}));
-  if (!encTables_.reserve(B * tableWords * 4) || !encSeqs_.reserve(B * seqStride * 8) || !encLits_.reserve(B * litStride) ||
-      !encSlots_.reserve(B * slotStride) || !encMisc_.reserve(B * (sizeof(ZraEncFrameState) + sizeof(ZraEncBlockOut))) ||
-      !encCk_.reserve((size_t)B * 4) || !encSizes_.reserve((size_t)B * 16) || !encScan_.reserve(64))
-    return zerr(64);
+  const uint64_t perFrame = tableWords * 4 + seqStride * 8 + litStride + slotStride + sizeof(ZraEncFrameState) + sizeof(ZraEncBlockOut) + 64;
+  // Two scratch contexts: the match finder of batch k+1 (stream A) overlaps the entropy stage + gather of batch k (stream B);
+  // both kernels are latency-bound, so they share the CUs almost for free. 8 GiB of scratch per context.
+  const uint64_t budget = 8ull << 30;
+  uint32_t B = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>({nFramesTotal, budget / perFrame, 16384ull}));
+  if (B > 1024) B &= ~1023u;
+  const int nCtx = nFramesTotal > B ? 2 : 1;
+  for (int c = 0; c < nCtx; c++) {
+    EncCtx& x = encCtx_[c];
+    if (!x.tables.reserve(B * tableWords * 4) || !x.seqs.reserve(B * seqStride * 8) || !x.lits.reserve(B * litStride) ||
+        !x.slots.reserve(B * slotStride) || !x.misc.reserve(B * (sizeof(ZraEncFrameState) + sizeof(ZraEncBlockOut))) ||
+        !x.ck.reserve((size_t)B * 4) || !x.sizes.reserve((size_t)B * 16))
+      return zerr(64);
+  }
+  if (!encScan_.reserve(64)) return zerr(64);
+  uint64_t* dRunning = encScan_.as<uint64_t>();
+  HIPCHK(hipMemsetAsync(dRunning, 0, 8, stream2_));
 
-  ZraEncArgs a{};
-  a.in = dIn; a.inSize = inSize; a.frameSize = frameSize; a.checksum = checksum ? 1 : 0;
-  a.full = full; a.tail = tail;
-  { static const int tune = std::getenv("ZRA_MF_TUNE") ? std::atoi(std::getenv("ZRA_MF_TUNE")) : 0; a.mfTune = (uint32_t)tune; }
-  a.tables = encTables_.as<uint32_t>(); a.tableStride = tableWords;
-  a.seqs = encSeqs_.as<uint64_t>(); a.seqStride = seqStride;
-  a.lits = encLits_.as<uint8_t>(); a.litStride = litStride;
-  a.slots = encSlots_.as<uint8_t>(); a.slotStride = slotStride;
-  a.state = encMisc_.as<ZraEncFrameState>();
-  a.blockOut = (ZraEncBlockOut*)(encMisc_.as<uint8_t>() + (size_t)B * sizeof(ZraEncFrameState));
-  a.contentCk = encCk_.as<uint32_t>();
-  a.sizes = encSizes_.as<uint64_t>();
-  uint64_t* dOffsets = encSizes_.as<uint64_t>() + B;
-  uint64_t* dTotal = encScan_.as<uint64_t>();
+  ZraEncArgs base{};
+  base.in = dIn; base.inSize = inSize; base.frameSize = frameSize; base.checksum = checksum ? 1 : 0;
+  base.full = full; base.tail = tail;
+  { static const int tune = std::getenv("ZRA_MF_TUNE") ? std::atoi(std::getenv("ZRA_MF_TUNE")) : 0; base.mfTune = (uint32_t)tune; }
+  base.tableStride = tableWords; base.seqStride = seqStride; base.litStride = litStride; base.slotStride = slotStride;
 
-  uint64_t bodyOff = 0;
-  double kernelMs = 0;
-  kstats_[0] = kstats_[1] = kstats_[2] = kstats_[3] = 0;
-  for (uint64_t f0 = 0; f0 < nFramesTotal; f0 += B) {
+  // event pool: [2 per mf launch on stream A] [2 per entropy launch on stream B]; dependencies mfDone / entDone per context
+  size_t evNext = 0;
+  auto ev = [&]() -> hipEvent_t {
+    if (evNext == evPool_.size()) { hipEvent_t e = nullptr; if (hipEventCreate(&e) != hipSuccess) return nullptr; evPool_.push_back(e); }
+    return evPool_[evNext++];
+  };
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> mfSpans, entSpans;
+  hipEvent_t entDone[2] = {nullptr, nullptr};
+  // make stream B's first use wait for whatever the caller queued on stream A (inputs produced on the engine stream)
+  { hipEvent_t e0 = ev(); if (!e0) return zerr(1); HIPCHK(hipEventRecord(e0, stream_)); HIPCHK(hipStreamWaitEvent(stream2_, e0, 0)); }
+
+  uint64_t batchIdx = 0;
+  for (uint64_t f0 = 0; f0 < nFramesTotal; f0 += B, batchIdx++) {
     const uint32_t nb = (uint32_t)std::min<uint64_t>(B, nFramesTotal - f0);
+    const int c = (int)(batchIdx % nCtx);
+    EncCtx& x = encCtx_[c];
+    ZraEncArgs a = base;
     a.firstFrame = (uint32_t)f0; a.nFrames = nb;
+    a.tables = x.tables.as<uint32_t>(); a.seqs = x.seqs.as<uint64_t>(); a.lits = x.lits.as<uint8_t>(); a.slots = x.slots.as<uint8_t>();
+    a.state = x.misc.as<ZraEncFrameState>();
+    a.blockOut = (ZraEncBlockOut*)(x.misc.as<uint8_t>() + (size_t)B * sizeof(ZraEncFrameState));
+    a.contentCk = x.ck.as<uint32_t>();
+    a.sizes = x.sizes.as<uint64_t>();
+    uint64_t* dOffsets = x.sizes.as<uint64_t>() + B;
     if (checksum)
-      hipLaunchKernelGGL(zra_content_ck_kernel, dim3((nb * 4 + 255) / 256), dim3(256), 0, stream_, dIn, (u64)inSize, frameSize, (u32)f0, nb, a.contentCk);
+      hipLaunchKernelGGL(zra_content_ck_kernel, dim3((nb * 4 + 255) / 256), dim3(256), 0, stream2_, dIn, (u64)inSize, frameSize, (u32)f0, nb, a.contentCk);
     // frames of this batch: how many block rounds? (a short last frame may need fewer)
     const uint64_t firstFrameSize = std::min<uint64_t>(frameSize, inSize - f0 * frameSize);
     const ZraEncParams& P0 = firstFrameSize == frameSize ? full : tail;
     const uint32_t rounds = (uint32_t)((firstFrameSize + P0.blockSize - 1) / P0.blockSize);
-    const uint32_t timedRounds = std::min<uint32_t>(rounds, 8);
+    // the context's scratch is free once the entropy stage + gather of its previous batch are done
+    if (entDone[c]) HIPCHK(hipStreamWaitEvent(stream_, entDone[c], 0));
     for (uint32_t blk = 0; blk < rounds; blk++) {
-      if (blk < timedRounds) HIPCHK(hipEventRecord(evR_[2 * blk], stream_));
+      hipEvent_t m0 = ev(), m1 = ev(), e1 = ev();
+      if (!m0 || !m1 || !e1) return zerr(1);
+      HIPCHK(hipEventRecord(m0, stream_));
       {
         // occupancy experiment knob (bring-up): dynamic LDS per workgroup caps the frames in flight per CU
         static const int dynLds = std::getenv("ZRA_MF_LDS") ? std::atoi(std::getenv("ZRA_MF_LDS")) : 0;
         hipLaunchKernelGGL(zra_mf_kernel, dim3(nb), dim3(64), dynLds, stream_, a, blk);
       }
-      if (blk < timedRounds) HIPCHK(hipEventRecord(evR_[2 * blk + 1], stream_));
-      hipLaunchKernelGGL(zra_entropy_kernel, dim3(nb), dim3(256), 0, stream_, a, blk);
+      HIPCHK(hipEventRecord(m1, stream_));
+      mfSpans.push_back({m0, m1});
+      HIPCHK(hipStreamWaitEvent(stream2_, m1, 0));
+      hipEvent_t e0 = ev(); if (!e0) return zerr(1);
+      HIPCHK(hipEventRecord(e0, stream2_));
+      hipLaunchKernelGGL(zra_entropy_kernel, dim3(nb), dim3(256), 0, stream2_, a, blk);
+      HIPCHK(hipEventRecord(e1, stream2_));
+      entSpans.push_back({e0, e1});
+      if (blk + 1 < rounds) HIPCHK(hipStreamWaitEvent(stream_, e1, 0));   // next block's match finder needs the confirmed state
     }
-    HIPCHK(hipEventRecord(evR_[2 * timedRounds], stream_));
-    hipLaunchKernelGGL(zra_scan_sizes_kernel, dim3(1), dim3(1024), 0, stream_, a.sizes, nb, dOffsets, dTotal);
-    hipLaunchKernelGGL(zra_gather_frames_kernel, dim3(nb), dim3(256), 0, stream_, a.slots, slotStride, a.sizes, dOffsets, dBody,
-                       bodyBase0 + bodyOff, dEntries ? dEntries : nullptr, (u32)f0, dSizes);
-    uint64_t total = 0;
-    HIPCHK(hipMemcpyAsync(&total, dTotal, 8, hipMemcpyDeviceToHost, stream_));
-    HIPCHK(hipStreamSynchronize(stream_));
-    HIPCHK(hipGetLastError());
-    for (uint32_t r = 0; r < timedRounds; r++) {
-      float m1 = 0, m2 = 0;
-      if (hipEventElapsedTime(&m1, evR_[2 * r], evR_[2 * r + 1]) == hipSuccess) { kstats_[0] += m1; kstats_[1] += 1; kernelMs += m1; }
-      if (hipEventElapsedTime(&m2, evR_[2 * r + 1], evR_[2 * r + 2]) == hipSuccess) { kstats_[2] += m2; kstats_[3] += 1; kernelMs += m2; }
-    }
-    bodyOff += total;
+    hipLaunchKernelGGL(zra_scan_sizes_kernel, dim3(1), dim3(1024), 0, stream2_, a.sizes, nb, dOffsets, dRunning);
+    hipLaunchKernelGGL(zra_gather_frames_kernel, dim3(nb), dim3(256), 0, stream2_, a.slots, slotStride, a.sizes, dOffsets, dBody,
+                       bodyBase0, dEntries ? dEntries : nullptr, (u32)f0, dSizes);
+    hipEvent_t done = ev(); if (!done) return zerr(1);
+    HIPCHK(hipEventRecord(done, stream2_));
+    entDone[c] = done;
   }
+  uint64_t total = 0;
+  HIPCHK(hipMemcpyAsync(&total, dRunning, 8, hipMemcpyDeviceToHost, stream2_));
+  HIPCHK(hipStreamSynchronize(stream2_));
+  HIPCHK(hipStreamSynchronize(stream_));
+  HIPCHK(hipGetLastError());
+  double kernelMs = 0;
+  kstats_[0] = kstats_[1] = kstats_[2] = kstats_[3] = 0;
+  for (auto& sp : mfSpans) { float m = 0; if (hipEventElapsedTime(&m, sp.first, sp.second) == hipSuccess) { kstats_[0] += m; kstats_[1] += 1; kernelMs += m; } }
+  for (auto& sp : entSpans) { float m = 0; if (hipEventElapsedTime(&m, sp.first, sp.second) == hipSuccess) { kstats_[2] += m; kstats_[3] += 1; } }
   lastKernelMs_ = kernelMs;
-  *bodySize = bodyOff;
+  *bodySize = total;
   return ok();
 }
 

@@ -87,7 +87,11 @@ class Engine {
   // decode scratch
   DevBuf litScratch_, queue_, status_, produced_, frameMeta_, frameOff_, outOff_, expect_, result_, temp_, qmeta_;
   // encode scratch (see zra_encode.hip)
-  DevBuf encTables_, encSeqs_, encSlots_, encSizes_, encMisc_, encLits_, encCk_, encScan_;
+  struct EncCtx { DevBuf tables, seqs, lits, slots, misc, ck, sizes; };
+  EncCtx encCtx_[2];
+  DevBuf encScan_;
+  hipStream_t stream2_ = nullptr;          // entropy stage / gather stream (overlaps the match finder on stream_)
+  std::vector<hipEvent_t> evPool_;
   DevBuf hostIn_, hostOut_;
   friend struct EncodeImpl;
 };

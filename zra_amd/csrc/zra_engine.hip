@@ -129,6 +129,7 @@ Status Engine::create(Engine** out, int device) {
   if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete e; return zerr(1); }
   e->numCUs_ = prop.multiProcessorCount;
   if (hipStreamCreateWithFlags(&e->stream_, hipStreamNonBlocking) != hipSuccess) { delete e; return zerr(1); }
+  if (hipStreamCreateWithFlags(&e->stream2_, hipStreamNonBlocking) != hipSuccess) { delete e; return zerr(1); }
   if (hipEventCreate(&e->ev0_) != hipSuccess || hipEventCreate(&e->ev1_) != hipSuccess) { delete e; return zerr(1); }
   for (auto& ev : e->evR_) if (hipEventCreate(&ev) != hipSuccess) { delete e; return zerr(1); }
   *out = e;
@@ -139,8 +140,11 @@ Engine::~Engine() {
   (void)hipSetDevice(device_);
   if (stream_) (void)hipStreamSynchronize(stream_);
   for (DevBuf* b : {&litScratch_, &queue_, &status_, &produced_, &frameMeta_, &frameOff_, &outOff_, &expect_, &result_, &temp_, &qmeta_,
-                    &encTables_, &encSeqs_, &encSlots_, &encSizes_, &encMisc_, &encLits_, &encCk_, &encScan_, &hostIn_, &hostOut_})
+                    &encScan_, &hostIn_, &hostOut_})
     b->release();
+  for (auto& x : encCtx_) for (DevBuf* b : {&x.tables, &x.seqs, &x.lits, &x.slots, &x.misc, &x.ck, &x.sizes}) b->release();
+  for (auto ev : evPool_) (void)hipEventDestroy(ev);
+  if (stream2_) { (void)hipStreamSynchronize(stream2_); (void)hipStreamDestroy(stream2_); }
   for (auto& ev : evR_) if (ev) (void)hipEventDestroy(ev);
   if (ev0_) (void)hipEventDestroy(ev0_);
   if (ev1_) (void)hipEventDestroy(ev1_);
