@@ -118,3 +118,16 @@ def test_compute_calls_fail_loudly_without_gpu(zra):
         zra.DecompressBuffer(arc)
     with pytest.raises(zra.ZraError):
         zra.Engine(0)
+
+
+def test_reference_cli_builds_against_our_headers_and_library(tmp_path):
+    """Source compatibility of include/zra.hpp: the reference's own programs/zratool.cpp compiles and links UNMODIFIED against
+    this repo's headers + libzra_amd.so (compile/link only — running it needs a GPU). Skipped where /root/reference is absent."""
+    import subprocess
+    src = "/root/reference/programs/zratool.cpp"
+    if not os.path.exists(src):
+        pytest.skip("/root/reference not present on this box")
+    out = str(tmp_path / "ref_zratool")
+    subprocess.check_call(["g++", "-std=c++17", "-I" + os.path.join(ROOT, "include"), src, "-o", out,
+                           "-L" + os.path.join(ROOT, "zra_amd"), "-lzra_amd", "-Wl,-rpath," + os.path.join(ROOT, "zra_amd"), "-Wl,-rpath,/opt/rocm/lib"])
+    assert os.path.exists(out)

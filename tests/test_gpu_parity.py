@@ -238,3 +238,28 @@ def test_device_api_at_baseline_size_properties(zra, gpu_engine):
     with pytest.raises(zra.ZraError) as e:
         gpu_engine.decompress_ra_batch(d_arc.data_ptr(), n1, d_ra.data_ptr(), np.array([N - 10], dtype=np.uint64), np.array([10], dtype=np.uint64), np.array([0], dtype=np.uint64))
     assert e.value.zra == 5
+
+
+def test_cli_tool_and_stock_zstd_interop(zra, tmp_path):
+    """zratool counterpart (zra_amd/tools/zratool_amd, argv order of zratool.cpp:100-105) + the on-disk format is a stock zstd stream
+    (README.md:16 of the reference): `zstd -d` of an archive we wrote restores the input."""
+    import shutil
+    import subprocess
+    tool = os.path.join(os.path.dirname(zra.LIB_PATH), "tools", "zratool_amd")
+    assert os.path.exists(tool), "build() must produce the CLI"
+    data = C.gen_E(1 << 20)[100000:100000 + 700001]
+    src = tmp_path / "in.bin"
+    src.write_bytes(data)
+    st, ref = O.zra_compress(data, 3, 16384, True)
+    for mode, out in (("imc", "a.zra"), ("c", "b.zra")):
+        subprocess.check_call([tool, mode, str(src), str(tmp_path / out), "3", "16384"], stdout=subprocess.DEVNULL)
+        assert (tmp_path / out).read_bytes() == ref, mode           # streaming == in-memory == oracle bytes
+    for mode, out in (("imd", "a.out"), ("d", "b.out")):
+        subprocess.check_call([tool, mode, str(tmp_path / "a.zra"), str(tmp_path / out)], stdout=subprocess.DEVNULL)
+        assert (tmp_path / out).read_bytes() == data, mode
+    txt = subprocess.check_output([tool, "b", str(src), str(tmp_path / "bench.zra"), "3", "65536"]).decode()
+    assert "MISMATCH" not in txt and "==" in txt
+    zstd = shutil.which("zstd") or ("/opt/conda/bin/zstd" if os.path.exists("/opt/conda/bin/zstd") else None)
+    if zstd:
+        out = subprocess.check_output([zstd, "-d", "-c", str(tmp_path / "a.zra")])
+        assert out == data

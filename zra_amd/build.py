@@ -13,7 +13,7 @@ def needs_build():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", f) for f in ("zra.h", "zra.hpp", "zra_hip.h")]
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "tools", "zratool_amd.cpp")] + [os.path.join(HERE, "..", "include", f) for f in ("zra.h", "zra.hpp", "zra_hip.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
@@ -39,6 +39,10 @@ def build(force=False, verbose=False):
             raise RuntimeError("hipcc failed on " + s)
     link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     subprocess.check_call(link)
+    # command-line counterpart of the reference's zratool (C++ API consumer)
+    tool = os.path.join(HERE, "tools", "zratool_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-I" + os.path.join(HERE, "..", "include"), os.path.join(HERE, "tools", "zratool_amd.cpp"),
+                           "-o", tool, "-L" + HERE, "-lzra_amd", "-Wl,-rpath," + HERE, "-Wl,-rpath,/opt/rocm/lib"])
     return LIB
 
 
