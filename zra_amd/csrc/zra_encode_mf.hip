@@ -402,6 +402,148 @@ __device__ u32 mf_dfast_wave(const ZraEncParams& P, T* HL, T* HS, const u8* src,
   return be - anchor;
 }
 
+
+// ================================================================================================
+// Window-resolve dfast: the batch formulation above, taken one step further. A window of up to 64 consecutive parse
+// positions is looked up ONCE (one table-gather round trip + one tag-filtered candidate round trip), then the parse is
+// resolved INSIDE the window: after a match the positions behind it are still in registers, so the next sequences of the
+// window need no further trip to the tables. This is exact because no two lanes of a window share a bucket (exactly
+// verified: the LDS scatter only flags suspects, flagged lanes are compared against all earlier lanes), so inserts made while
+// resolving the window (visited positions, the ip+1 long probe, the complementary and repcode insertions — all positions of
+// the window) can never change what another lane of the window would have read. Rep-offset tests depend on the parse state
+// and are re-evaluated per sequence (a cached, sequential read).
+template <typename T, bool TAG>
+__device__ u32 mf_dfast_window(const ZraEncParams& P, T* HL, T* HS, const u8* src, u32 bs, u32 be, u32* rep, u64* seqs, u32* nOut,
+                               u32* dupL, u32* dupS, int lane) {
+  const u32 hlog = P.hashLog, clog = P.chainLog, mls = P.minMatch;
+  u32 o1 = rep[0], o2 = rep[1], saved;
+  u32 anchor = bs, nseq = 0;
+  const u32 ilimit = be - 8;
+  u32 ip = mf_prologue(bs, o1, o2, saved);
+  u32 epoch = 1;
+  auto hashS64 = [&](u64 v) -> u32 {
+    switch (mls) {
+      case 5: return (u32)(((v << 24) * 889523592379ULL) >> (64 - clog));
+      case 6: return (u32)(((v << 16) * 227718039650203ULL) >> (64 - clog));
+      case 7: return (u32)(((v << 8) * 58295818150454627ULL) >> (64 - clog));
+      default: return ((u32)v * 2654435761u) >> (32 - clog);
+    }
+  };
+  auto hashL64 = [&](u64 v) -> u32 { return (u32)((v * 0xCF1BBCDCB7A56463ULL) >> (64 - hlog)); };
+  auto tagL64 = [&](u64 v) -> u32 { return TAG ? ((u32)((v * 0xCF1BBCDCB7A56463ULL) >> (48 - hlog)) & 0xFFFFu) << 16 : 0u; };
+  auto tagS64 = [&](u64 v) -> u32 { return TAG ? (((u32)v * 2654435761u) >> 16) << 16 : 0u; };
+  while (ip < ilimit) {
+    // ---------------------------------------------------------------- window build
+    const u32 wip = ip;
+    const u32 run = ip - anchor, s = (run >> 8) + 1;
+    u32 nAct = min(64u, min((256 * s - run + s - 1) / s, (ilimit - ip + s - 1) / s));
+    bool active = (u32)lane < nAct;
+    const u32 p = wip + (u32)lane * s;
+    const u64 v8 = active ? ld64(src + p) : 0;
+    const u32 hL = hashL64(v8), hS = hashS64(v8);
+    const u32 tL = tagL64(v8), tS = tagS64(v8);
+    if (nAct > 1) {
+      const u32 tag = (epoch << 6) | (63u - (u32)lane);
+      if (active) { atomicMax(&dupL[hL & 511], tag); atomicMax(&dupS[hS & 511], tag); }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+      const bool suspect = active && (((dupL[hL & 511] & 63u) != 63u - (u32)lane) || ((dupS[hS & 511] & 63u) != 63u - (u32)lane));
+      u64 sm = __ballot(suspect);
+      while (sm) {                                   // exact check of the suspects, in ascending lane order
+        const u32 i = (u32)__builtin_ctzll(sm); sm &= sm - 1;
+        const u32 hLi = bcast(hL, i), hSi = bcast(hS, i);
+        if (__ballot((u32)lane < i && (hL == hLi || hS == hSi))) { nAct = i; active = (u32)lane < nAct; break; }
+      }
+      epoch++;
+    }
+    u32 mL = 0, mS = 0;
+    bool tagLok = true, tagSok = true;
+    if (active) {
+      const u32 rL = HL[hL], rS = HS[hS];
+      if (TAG) { mL = rL & 0xFFFFu; mS = rS & 0xFFFFu; tagLok = (rL & 0xFFFF0000u) == tL; tagSok = (rS & 0xFFFF0000u) == tS; }
+      else { mL = rL; mS = rS; }
+    }
+    // candidate tests that do not depend on the parse state
+    const bool longHit = active && mL > 1 && tagLok && ld64(src + mL - 1) == v8;
+    const bool shortHit = active && mS > 1 && tagSok && ld32(src + mS - 1) == (u32)v8;
+    // insert position `pos` into the long / short table; bucket + tag come from the window's registers when pos is in it
+    auto insert = [&](u32 pos, bool doL, bool doS) {
+      u32 hl, hs, tl, ts;
+      if (s == 1 && pos >= wip && pos - wip < nAct) {
+        const u32 l = pos - wip;
+        hl = bcast(hL, l); hs = bcast(hS, l); tl = bcast(tL, l); ts = bcast(tS, l);
+      } else {
+        const u64 v = rfl64(ld64(src + pos));
+        hl = hashL64(v); hs = hashS64(v); tl = tagL64(v); ts = tagS64(v);
+      }
+      if (lane == 0 && doL) HL[hl] = (T)((pos + 1) | tl);
+      if (lane == 1 && doS) HS[hs] = (T)((pos + 1) | ts);
+    };
+    // ---------------------------------------------------------------- resolve the window
+    u32 cur = 0;
+    for (;;) {
+      const bool live = active && (u32)lane >= cur;
+      const bool repHit = live && o1 > 0 && ld32(src + p + 1 - o1) == (u32)(v8 >> 8);
+      const u64 hm = __ballot(live && (repHit || longHit || shortHit));
+      const u32 f = hm ? (u32)__builtin_ctzll(hm) : nAct - 1;
+      if (live && (u32)lane <= f) { HL[hL] = (T)((p + 1) | tL); HS[hS] = (T)((p + 1) | tS); }   // visited positions
+      if (!hm) { ip = wip + nAct * s; break; }
+      const u32 top = wip + f * s;
+      const u32 mLf = bcast(mL, f), mSf = bcast(mS, f);
+      const bool isRep = (__ballot(repHit) >> f) & 1, isLong = (__ballot(longHit) >> f) & 1;
+      const u32 curr = top + 1;
+      ip = top;
+      u32 ml, offVal;
+      if (isRep) {
+        ml = wave_count_eq(src, ip + 5, ip + 5 - o1, be, lane) + 4; ip++; offVal = 1;
+      } else {
+        u32 m;
+        if (isLong) { m = mLf - 1; ml = wave_count_eq(src, ip + 8, m + 8, be, lane) + 8; }
+        else {
+          // short hit: probe the long table at ip+1 (A.4.3 case 3) — lane f+1 already holds that lookup when it is in the window
+          u64 v9; u32 h3, m3, t3; bool tag3ok;
+          if (s == 1 && f + 1 < nAct) {
+            v9 = bcast64(v8, f + 1); h3 = bcast(hL, f + 1); m3 = bcast(mL, f + 1); t3 = bcast(tL, f + 1);
+            tag3ok = (__ballot(tagLok) >> (f + 1)) & 1;
+          } else {
+            v9 = rfl64(ld64(src + ip + 1)); h3 = hashL64(v9); t3 = tagL64(v9);
+            const u32 r3 = rfl((u32)HL[h3]);
+            m3 = TAG ? (r3 & 0xFFFFu) : r3;
+            tag3ok = !TAG || (r3 & 0xFFFF0000u) == t3;
+          }
+          if (lane == 0) HL[h3] = (T)((curr + 1) | t3);
+          if (m3 > 1 && tag3ok && rfl64(ld64(src + m3 - 1)) == v9) { m = m3 - 1; ip++; ml = wave_count_eq(src, ip + 8, m + 8, be, lane) + 8; }
+          else { m = mSf - 1; ml = wave_count_eq(src, ip + 4, m + 4, be, lane) + 4; }
+        }
+        const u32 off = ip - m;
+        const u32 back = wave_count_back(src, ip, m, anchor, lane);
+        ip -= back; ml += back;
+        o2 = o1; o1 = off; offVal = off + 3;
+      }
+      if (lane == 0) seqs[nseq] = (u64)(ip - anchor) | ((u64)ml << 20) | ((u64)offVal << 40);
+      nseq++;
+      ip += ml; anchor = ip;
+      if (ip <= ilimit) {
+        insert(top + 2, true, true);                  // complementary insertions (order per table: q first)
+        insert(ip - 2, true, false);
+        insert(ip - 1, false, true);
+        while (ip <= ilimit && o2 > 0 && rfl(ld32(src + ip)) == rfl(ld32(src + ip - o2))) {
+          const u32 rl = wave_count_eq(src, ip + 4, ip + 4 - o2, be, lane) + 4;
+          const u32 t = o2; o2 = o1; o1 = t;
+          insert(ip, true, true);
+          if (lane == 0) seqs[nseq] = (u64)0 | ((u64)rl << 20) | ((u64)1 << 40);
+          nseq++;
+          ip += rl; anchor = ip;
+        }
+      }
+      if (s != 1 || ip >= wip + nAct || ip >= ilimit) break;    // left the window: build the next one at ip
+      cur = ip - wip;
+    }
+  }
+  rep[0] = o1 ? o1 : saved; rep[1] = o2 ? o2 : saved;
+  *nOut = nseq;
+  return be - anchor;
+}
+
 }  // namespace
 
 // One wave per frame; `block` = index of the <=128 KiB block being parsed in this round (A.4.2 driver).
@@ -451,8 +593,11 @@ zra_mf_kernel(ZraEncArgs a, u32 block) {
     __shared__ u32 dupL[512], dupS[512];
     for (int i = lane; i < 512; i += 64) { dupL[i] = 0; dupS[i] = 0; }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-    if (tagged) lastLL = mf_dfast_wave<u32, true>(P, hashT, chainT, src, bs, be, rep, seqs, &nseq, dupL, dupS, lane, a.mfTune);
-    else lastLL = mf_dfast_wave<u32, false>(P, hashT, chainT, src, bs, be, rep, seqs, &nseq, dupL, dupS, lane, a.mfTune);
+    if (a.mfTune == 9) {                             // previous formulation (one batch per sequence), kept for A/B measurements
+      if (tagged) lastLL = mf_dfast_wave<u32, true>(P, hashT, chainT, src, bs, be, rep, seqs, &nseq, dupL, dupS, lane, 0);
+      else lastLL = mf_dfast_wave<u32, false>(P, hashT, chainT, src, bs, be, rep, seqs, &nseq, dupL, dupS, lane, 0);
+    } else if (tagged) lastLL = mf_dfast_window<u32, true>(P, hashT, chainT, src, bs, be, rep, seqs, &nseq, dupL, dupS, lane);
+    else lastLL = mf_dfast_window<u32, false>(P, hashT, chainT, src, bs, be, rep, seqs, &nseq, dupL, dupS, lane);
     if (lane == 0) {
       bo->nbSeq = nseq; bo->lastLL = lastLL; bo->skip = 0;
       bo->rep[0] = rep[0]; bo->rep[1] = rep[1]; bo->rep[2] = rep[2];
