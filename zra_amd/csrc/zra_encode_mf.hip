@@ -479,10 +479,15 @@ __device__ u32 mf_dfast_window(const ZraEncParams& P, T* HL, T* HS, const u8* sr
       if (lane == 1 && doS) HS[hs] = (T)((pos + 1) | ts);
     };
     // ---------------------------------------------------------------- resolve the window
+    // Per sequence the dependent round trips are kept to two: (1) forward count + backward extension + the NEXT sequence's
+    // rep-offset gather are issued together, (2) the immediate-repcode test. The rep gather is speculative on o1 (redone if
+    // the repcode loop swaps the offsets).
     u32 cur = 0;
+    u32 repFor = 0xFFFFFFFFu, repVal = 0;            // repVal = ld32(src + p + 1 - repFor), gathered ahead of time
     for (;;) {
       const bool live = active && (u32)lane >= cur;
-      const bool repHit = live && o1 > 0 && ld32(src + p + 1 - o1) == (u32)(v8 >> 8);
+      if (repFor != o1) { repVal = (active && o1 > 0 && p + 1 >= o1) ? ld32(src + p + 1 - o1) : 0; repFor = o1; }
+      const bool repHit = live && o1 > 0 && p + 1 >= o1 && repVal == (u32)(v8 >> 8);
       const u64 hm = __ballot(live && (repHit || longHit || shortHit));
       const u32 f = hm ? (u32)__builtin_ctzll(hm) : nAct - 1;
       if (live && (u32)lane <= f) { HL[hL] = (T)((p + 1) | tL); HS[hS] = (T)((p + 1) | tS); }   // visited positions
@@ -492,33 +497,55 @@ __device__ u32 mf_dfast_window(const ZraEncParams& P, T* HL, T* HS, const u8* sr
       const bool isRep = (__ballot(repHit) >> f) & 1, isLong = (__ballot(longHit) >> f) & 1;
       const u32 curr = top + 1;
       ip = top;
-      u32 ml, offVal;
-      if (isRep) {
-        ml = wave_count_eq(src, ip + 5, ip + 5 - o1, be, lane) + 4; ip++; offVal = 1;
-      } else {
-        u32 m;
-        if (isLong) { m = mLf - 1; ml = wave_count_eq(src, ip + 8, m + 8, be, lane) + 8; }
-        else {
-          // short hit: probe the long table at ip+1 (A.4.3 case 3) — lane f+1 already holds that lookup when it is in the window
-          u64 v9; u32 h3, m3, t3; bool tag3ok;
-          if (s == 1 && f + 1 < nAct) {
-            v9 = bcast64(v8, f + 1); h3 = bcast(hL, f + 1); m3 = bcast(mL, f + 1); t3 = bcast(tL, f + 1);
-            tag3ok = (__ballot(tagLok) >> (f + 1)) & 1;
-          } else {
-            v9 = rfl64(ld64(src + ip + 1)); h3 = hashL64(v9); t3 = tagL64(v9);
-            const u32 r3 = rfl((u32)HL[h3]);
-            m3 = TAG ? (r3 & 0xFFFFu) : r3;
-            tag3ok = !TAG || (r3 & 0xFFFF0000u) == t3;
-          }
-          if (lane == 0) HL[h3] = (T)((curr + 1) | t3);
-          if (m3 > 1 && tag3ok && rfl64(ld64(src + m3 - 1)) == v9) { m = m3 - 1; ip++; ml = wave_count_eq(src, ip + 8, m + 8, be, lane) + 8; }
-          else { m = mSf - 1; ml = wave_count_eq(src, ip + 4, m + 4, be, lane) + 4; }
+      // ---- which match: start position `ip`, source `m`, bytes already known equal `known`
+      u32 m, known, offVal;
+      if (isRep) { ip = top + 1; m = ip - o1; known = 4; offVal = 1; }
+      else if (isLong) { m = mLf - 1; known = 8; offVal = 0; }
+      else {
+        // short hit: probe the long table at ip+1 (A.4.3 case 3) — lane f+1 already holds that lookup when it is in the window
+        u64 v9; u32 h3, m3, t3; bool tag3ok;
+        if (s == 1 && f + 1 < nAct) {
+          v9 = bcast64(v8, f + 1); h3 = bcast(hL, f + 1); m3 = bcast(mL, f + 1); t3 = bcast(tL, f + 1);
+          tag3ok = (__ballot(tagLok) >> (f + 1)) & 1;
+        } else {
+          v9 = rfl64(ld64(src + ip + 1)); h3 = hashL64(v9); t3 = tagL64(v9);
+          const u32 r3 = rfl((u32)HL[h3]);
+          m3 = TAG ? (r3 & 0xFFFFu) : r3;
+          tag3ok = !TAG || (r3 & 0xFFFF0000u) == t3;
         }
-        const u32 off = ip - m;
-        const u32 back = wave_count_back(src, ip, m, anchor, lane);
-        ip -= back; ml += back;
+        if (lane == 0) HL[h3] = (T)((curr + 1) | t3);
+        if (m3 > 1 && tag3ok && rfl64(ld64(src + m3 - 1)) == v9) { m = m3 - 1; ip = top + 1; known = 8; }
+        else { m = mSf - 1; known = 4; }
+        offVal = 0;
+      }
+      const u32 off = ip - m;
+      const u32 o1n = isRep ? o1 : off;             // o1 after this sequence (unless the repcode loop swaps)
+      // ---- issue together: forward compare (64 x 8 B), backward compare (64 x 1 B), next rep gather
+      const u32 fa = ip + known + 8 * (u32)lane, fb = m + known + 8 * (u32)lane;
+      const bool fv = fa + 8 <= be;
+      const u64 xa = fv ? ld64(src + fa) : 0, xb = fv ? ld64(src + fb) : 0;
+      const u32 lim = isRep ? 0u : min(ip - anchor, m);
+      const bool bv = (u32)lane < lim;
+      const u32 ya = bv ? src[ip - 1 - lane] : 0u, yb = bv ? src[m - 1 - lane] : 1u;
+      const u32 rnext = (active && o1n > 0 && p + 1 >= o1n) ? ld32(src + p + 1 - o1n) : 0;
+      u32 ml;
+      {
+        const u64 d = xa ^ xb;
+        const u32 eq = d ? ((u32)__builtin_ctzll(d) >> 3) : 8;
+        const u64 stop = __ballot(!fv || d != 0);
+        const u32 l = stop ? (u32)__builtin_ctzll(stop) : 64u;
+        const bool clean = stop && ((__ballot(fv) >> l) & 1);       // first stopping lane compared a full 8-byte word
+        if (clean) ml = known + 8 * l + bcast(eq, l);
+        else ml = known + wave_count_eq(src, ip + known, m + known, be, lane);   // block end inside the window, or > 512 equal bytes
+      }
+      u32 back = 0;
+      if (!isRep) {
+        const u64 bad = ~__ballot(bv && ya == yb);
+        back = bad ? (u32)__builtin_ctzll(bad) : wave_count_back(src, ip, m, anchor, lane);
         o2 = o1; o1 = off; offVal = off + 3;
       }
+      ip -= back; ml += back;
+      repVal = rnext; repFor = o1n;
       if (lane == 0) seqs[nseq] = (u64)(ip - anchor) | ((u64)ml << 20) | ((u64)offVal << 40);
       nseq++;
       ip += ml; anchor = ip;
@@ -526,7 +553,10 @@ __device__ u32 mf_dfast_window(const ZraEncParams& P, T* HL, T* HS, const u8* sr
         insert(top + 2, true, true);                  // complementary insertions (order per table: q first)
         insert(ip - 2, true, false);
         insert(ip - 1, false, true);
-        while (ip <= ilimit && o2 > 0 && rfl(ld32(src + ip)) == rfl(ld32(src + ip - o2))) {
+        for (;;) {
+          if (!(ip <= ilimit && o2 > 0)) break;
+          const u32 here = (s == 1 && ip >= wip && ip - wip < nAct) ? (u32)bcast64(v8, ip - wip) : rfl(ld32(src + ip));
+          if (here != rfl(ld32(src + ip - o2))) break;
           const u32 rl = wave_count_eq(src, ip + 4, ip + 4 - o2, be, lane) + 4;
           const u32 t = o2; o2 = o1; o1 = t;
           insert(ip, true, true);
