@@ -282,7 +282,8 @@ def main():
         tpath = os.path.join(HERE, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("zra_mf_kernel_hbm_bytes_per_launch")
+                # PMC-measured HBM bytes per frame (FETCH_SIZE + WRITE_SIZE passes, profiles/) x frames of one launch
+                traffic = int(json.load(open(tpath)).get("zra_mf_kernel_hbm_bytes_per_frame") * (nframes / launches))
             except Exception:
                 traffic = None
         line = {
