@@ -459,7 +459,7 @@ zra_decode_frames_kernel(ZraDecodeArgs a) {
       else if (litType == 1) fill_bytes(litScratch, (u8)S.litRle, regen, lane, DEC_THREADS);
       else {
         const u32 nStreams = S.litStreams;
-        if ((u32)lane < nStreams) {
+        if ((u32)lane < nStreams && !(a.debugSkip & 4)) {
           const u32 seg = nStreams == 1 ? regen : (regen + 3) / 4;
           const u32 myLen = nStreams == 1 ? regen : (lane < 3 ? seg : regen - 3 * seg);
           u8* o = litScratch + (size_t)lane * seg;
@@ -513,15 +513,16 @@ zra_decode_frames_kernel(ZraDecodeArgs a) {
             const u32 ofBits = (u32)(eO >> 32) & 0xFF, mlBits = (u32)(eM >> 32) & 0xFF, llBits = (u32)(eL >> 32) & 0xFF;
             if (ofBits > 31) { bad = 1; break; }
             u32 offVal = (u32)eO + br.read((int)ofBits);
-            br.ensure((int)(mlBits + llBits));
-            u32 ml = (u32)eM + (mlBits ? br.peek((int)mlBits) : 0); br.skip((int)mlBits);
-            u32 ll = (u32)eL + (llBits ? br.peek((int)llBits) : 0); br.skip((int)llBits);
+            // match-length and literal-length extra bits in one extraction (<= 32 bits; ML was written first = upper part)
+            const u32 both = br.read((int)(mlBits + llBits));
+            const u32 ml = (u32)eM + (both >> llBits), ll = (u32)eL + (both & ((1u << llBits) - 1));
             if (first + i + 1 < nbSeq) {
               const int nL = (int)((eL >> 40) & 0xFF), nM = (int)((eM >> 40) & 0xFF), nO = (int)((eO >> 40) & 0xFF);
-              br.ensure(nL + nM + nO);
-              sLL = (u32)(eL >> 48) + (nL ? br.peek(nL) : 0); br.skip(nL);
-              sML = (u32)(eM >> 48) + (nM ? br.peek(nM) : 0); br.skip(nM);
-              sOF = (u32)(eO >> 48) + (nO ? br.peek(nO) : 0); br.skip(nO);
+              // LL, ML, OF state bits in one extraction (<= 26 bits): LL is read first = topmost
+              const u32 st = br.read(nL + nM + nO);
+              sLL = (u32)(eL >> 48) + (st >> (nM + nO));
+              sML = (u32)(eM >> 48) + ((st >> nO) & ((1u << nM) - 1));
+              sOF = (u32)(eO >> 48) + (st & ((1u << nO) - 1));
             }
             if (br.pos < 0) { bad = 1; break; }
             u32 off;                                   // repcode resolution (A.3)
@@ -561,7 +562,7 @@ zra_decode_frames_kernel(ZraDecodeArgs a) {
         {
           const u8* lp = lit + lStart; u8* op = out + oStart;
           const bool longLit = ll > 32;
-          if (!longLit) for (u32 b = 0; b < ll; b++) op[b] = lp[b];
+          if (!longLit && !(a.debugSkip & 2)) for (u32 b = 0; b < ll; b++) op[b] = lp[b];
           u64 lm = __ballot(longLit);
           while (lm) {                               // long literal runs: the whole wave copies, coalesced
             const u32 j = (u32)__builtin_ctzll(lm); lm &= lm - 1;
@@ -574,7 +575,7 @@ zra_decode_frames_kernel(ZraDecodeArgs a) {
         {
           const u32 msrc = mdst - off;
           const u32 msrcEnd = min(msrc + ml, mdst);
-          u64 pending = __ballot(act);
+          u64 pending = (a.debugSkip & 1) ? 0ull : __ballot(act);
           while (pending) {
             const u32 fnd = (u32)__builtin_ctzll(pending);
             const u32 frontier = bcast_u32(mdst, fnd);

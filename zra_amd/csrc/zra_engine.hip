@@ -4,6 +4,7 @@
 #include "zra_format.h"
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 extern "C" __global__ void zra_decode_frames_kernel(ZraDecodeArgs a);
@@ -169,6 +170,7 @@ Status Engine::decode_jobs(const uint8_t* dBody, uint64_t bodySize, const uint64
   ZraDecodeArgs a;
   a.body = dBody; a.bodySize = bodySize; a.frameOff = dFrameOff; a.out = dOut; a.outOff = dOutOff; a.outCap = dExpect; a.outExpect = dExpect;
   a.nFrames = nFrames; a.offStride = offStride; a.queue = queue_.as<uint32_t>(); a.litScratch = litScratch_.as<uint8_t>();
+  { static const int skip = std::getenv("ZRA_DEC_SKIP") ? std::atoi(std::getenv("ZRA_DEC_SKIP")) : 0; a.debugSkip = (uint32_t)skip; }
   a.status = status_.as<uint32_t>(); a.produced = produced_.as<uint32_t>(); a.frameMeta = frameMeta_.as<uint32_t>();
   HIPCHK(hipEventRecord(ev0_, stream_));
   hipLaunchKernelGGL(zra_decode_frames_kernel, dim3(grid), dim3(64), 0, stream_, a);

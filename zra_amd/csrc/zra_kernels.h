@@ -21,6 +21,7 @@ struct ZraDecodeArgs {
   uint32_t* status;          // [nFrames] zstd error code per frame (0 = ok)
   uint32_t* produced;        // [nFrames] bytes regenerated
   uint32_t* frameMeta;       // [2*nFrames] {has checksum, stored checksum}
+  uint32_t debugSkip;        // bring-up timing knob (ZRA_DEC_SKIP): 1 skip match copies, 2 skip literal copies, 4 skip Huffman decode; 0 in production
 };
 
 // ------------------------------------------------------------------------------------------------ encode
