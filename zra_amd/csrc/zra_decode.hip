@@ -38,10 +38,17 @@ __device__ __forceinline__ u64 mk_seqsym(u32 baseValue, u32 addBits, u32 nbBits,
 }
 
 struct __attribute__((aligned(16))) DecShared {
-  u64 llT[512];
+  // The Huffman literal table is only live while the literal streams are decoded, the LL table only while sequences are decoded:
+  // they share 4 KiB. What is needed to rebuild either one for a later block of the same frame (treeless literals, repeat-mode
+  // LL table) is kept below (weights / llNorm), so 12 frames fit a CU's LDS instead of 9.
+  union {
+    u64 llT[512];
+    u16 huf[2048];          // sym | nbBits<<8 ; doubles as scratch while a tree description is parsed
+  };
   u64 mlT[512];
   u64 ofT[256];
-  u16 huf[2048];            // sym | nbBits<<8 ; doubles as scratch while a tree description is parsed
+  short llNorm[36];         // normalised counts of the last non-RLE LL table (rebuild on repeat mode)
+  u32 llSaveLog, llSaveMax, llSaveRle;   // llSaveRle: 0 = FSE table described by llNorm, else 1 + RLE symbol
   u32 seqLL[BATCH], seqML[BATCH], seqOF[BATCH];
   short norm[256];          // scratch: normalised counts while building a table
   u8 weights[256];
@@ -315,7 +322,7 @@ __device__ void seq_table_parse(DecShared& S, int kind, u32 mode, const u8* p, u
 }  // namespace
 
 // =================================================================================================
-extern "C" __global__ void __launch_bounds__(DEC_THREADS)
+extern "C" __global__ void __launch_bounds__(DEC_THREADS, 3)   // 3 waves/SIMD = the 12 frames per CU the LDS footprint admits
 zra_decode_frames_kernel(ZraDecodeArgs a) {
   __shared__ DecShared S;
   const int lane = threadIdx.x;
@@ -410,7 +417,7 @@ zra_decode_frames_kernel(ZraDecodeArgs a) {
       if (S.err) break;
 
       // ---- Huffman decode table fill: cells ordered by weight, then symbol
-      if (S.litType == 2 && S.hufValid == 2) {
+      if (S.litType >= 2) {                              // new table, or treeless: rebuilt from the kept weights (LDS shared with llT)
         const u32 nSym = S.hufNSym, maxBits = S.hufMaxBits;
         for (u32 sy = lane; sy < nSym; sy += DEC_THREADS) {
           u32 w = S.weights[sy];
@@ -423,35 +430,9 @@ zra_decode_frames_kernel(ZraDecodeArgs a) {
         }
         wsync();
         if (lane == 0) S.hufValid = 1;
+        wsync();
       }
-      // ---- sequence decode tables: lane 0 parses each description, the wave builds it
       const u32 nbSeq = S.nbSeq;
-      if (nbSeq) {
-        bool bad = false;
-        for (int kind = 0; kind < 3 && !bad; kind++) {
-          const int k = kind == 0 ? 0 : kind == 1 ? 2 : 1;          // wire order is LL, OF, ML
-          const u32 mode = k == 0 ? (S.seqModes >> 6) : k == 2 ? ((S.seqModes >> 4) & 3) : ((S.seqModes >> 2) & 3);
-          if (lane == 0) {
-            u32 tl = 0, ms = 0, used = 0;
-            seq_table_parse(S, k, mode, blk + S.seqPos, bsize - S.seqPos, &tl, &ms, &used, lim);
-            S.seqPos += used; S.tl = tl; S.ms = ms;
-            if (mode == 3) { u32 v = k == 0 ? S.llValid : k == 1 ? S.mlValid : S.ofValid; if (!v) S.err = ZE_CORRUPTION; }
-          }
-          wsync();
-          if (S.err) { bad = true; break; }
-          u64* table = k == 0 ? S.llT : k == 1 ? S.mlT : S.ofT;
-          const u32 tl = S.tl, ms = S.ms;
-          if (mode == 1) {
-            if (lane == 0) table[0] = k == 0 ? mk_seqsym(c_ll_base[ms], c_ll_bits[ms], 0, 0) : k == 1 ? mk_seqsym(c_ml_base[ms], c_ml_bits[ms], 0, 0) : mk_seqsym(1u << ms, ms, 0, 0);
-          } else if (mode != 3) build_fse_dtable(table, S.norm, ms, tl, k, S.spread, lane);
-          if (lane == 0 && mode != 3) {
-            if (k == 0) { S.llLog = tl; S.llValid = 1; } else if (k == 1) { S.mlLog = tl; S.mlValid = 1; } else { S.ofLog = tl; S.ofValid = 1; }
-          }
-          wsync();
-        }
-        if (bad) break;
-      }
-
       // ---- literals: raw -> point into the source; RLE -> fill scratch; Huffman -> up to 4 lanes, one per stream
       const u32 litType = S.litType, regen = S.litRegen;
       const u8* lit = litScratch;
@@ -487,6 +468,43 @@ zra_decode_frames_kernel(ZraDecodeArgs a) {
       }
       wsync();
       if (S.err) break;
+
+      // ---- sequence decode tables: lane 0 parses each description, the wave builds it
+      if (nbSeq) {
+        bool bad = false;
+        for (int kind = 0; kind < 3 && !bad; kind++) {
+          const int k = kind == 0 ? 0 : kind == 1 ? 2 : 1;          // wire order is LL, OF, ML
+          const u32 mode = k == 0 ? (S.seqModes >> 6) : k == 2 ? ((S.seqModes >> 4) & 3) : ((S.seqModes >> 2) & 3);
+          if (lane == 0) {
+            u32 tl = 0, ms = 0, used = 0;
+            seq_table_parse(S, k, mode, blk + S.seqPos, bsize - S.seqPos, &tl, &ms, &used, lim);
+            S.seqPos += used; S.tl = tl; S.ms = ms;
+            if (mode == 3) { u32 v = k == 0 ? S.llValid : k == 1 ? S.mlValid : S.ofValid; if (!v) S.err = ZE_CORRUPTION; }
+          }
+          wsync();
+          if (S.err) { bad = true; break; }
+          u64* table = k == 0 ? S.llT : k == 1 ? S.mlT : S.ofT;
+          const u32 tl = S.tl, ms = S.ms;
+          if (mode == 1) {
+            if (lane == 0) table[0] = k == 0 ? mk_seqsym(c_ll_base[ms], c_ll_bits[ms], 0, 0) : k == 1 ? mk_seqsym(c_ml_base[ms], c_ml_bits[ms], 0, 0) : mk_seqsym(1u << ms, ms, 0, 0);
+            if (k == 0 && lane == 0) S.llSaveRle = 1 + ms;
+          } else if (mode != 3) {
+            build_fse_dtable(table, S.norm, ms, tl, k, S.spread, lane);
+            if (k == 0) {                                  // remember how to rebuild it (its LDS is reused by the next Huffman table)
+              if ((u32)lane <= ms) S.llNorm[lane] = S.norm[lane];
+              if (lane == 0) { S.llSaveLog = tl; S.llSaveMax = ms; S.llSaveRle = 0; }
+            }
+          } else if (k == 0) {                             // repeat mode: the literal decode of this block overwrote the table
+            if (S.llSaveRle) { if (lane == 0) { const u32 sy = S.llSaveRle - 1; table[0] = mk_seqsym(c_ll_base[sy], c_ll_bits[sy], 0, 0); } }
+            else build_fse_dtable(table, S.llNorm, S.llSaveMax, S.llSaveLog, 0, S.spread, lane);
+          }
+          if (lane == 0 && mode != 3) {
+            if (k == 0) { S.llLog = tl; S.llValid = 1; } else if (k == 1) { S.mlLog = tl; S.mlValid = 1; } else { S.ofLog = tl; S.ofValid = 1; }
+          }
+          wsync();
+        }
+        if (bad) break;
+      }
 
       // ---- sequences: batches of 64 (lane 0 decodes, the wave executes)
       BitR br; br.base = blk; br.lim = lim; br.pos = 0; br.wlo = 0; br.w = 0;
