@@ -212,6 +212,8 @@ Status Engine::compress_impl(const uint8_t* dIn, size_t inSize, uint8_t* dBody, 
     hipEvent_t done = ev(); if (!done) return zerr(1);
     HIPCHK(hipEventRecord(done, stream2_));
     entDone[c] = done;
+    { static const bool serial = std::getenv("ZRA_ENC_SERIAL") != nullptr;   // bring-up knob: no mf/entropy overlap (per-kernel timing in isolation)
+      if (serial) HIPCHK(hipStreamWaitEvent(stream_, done, 0)); }
   }
   uint64_t total = 0;
   HIPCHK(hipMemcpyAsync(&total, dRunning, 8, hipMemcpyDeviceToHost, stream2_));

@@ -414,7 +414,7 @@ __device__ u32 mf_dfast_wave(const ZraEncParams& P, T* HL, T* HS, const u8* src,
 // and are re-evaluated per sequence (a cached, sequential read).
 template <typename T, bool TAG>
 __device__ u32 mf_dfast_window(const ZraEncParams& P, T* HL, T* HS, const u8* src, u32 bs, u32 be, u32* rep, u64* seqs, u32* nOut,
-                               u32* dupL, u32* dupS, int lane) {
+                               u32* dupL, u32* dupS, int lane, u32 wcap) {
   const u32 hlog = P.hashLog, clog = P.chainLog, mls = P.minMatch;
   u32 o1 = rep[0], o2 = rep[1], saved;
   u32 anchor = bs, nseq = 0;
@@ -436,7 +436,7 @@ __device__ u32 mf_dfast_window(const ZraEncParams& P, T* HL, T* HS, const u8* sr
     // ---------------------------------------------------------------- window build
     const u32 wip = ip;
     const u32 run = ip - anchor, s = (run >> 8) + 1;
-    u32 nAct = min(64u, min((256 * s - run + s - 1) / s, (ilimit - ip + s - 1) / s));
+    u32 nAct = min(wcap, min((256 * s - run + s - 1) / s, (ilimit - ip + s - 1) / s));
     bool active = (u32)lane < nAct;
     const u32 p = wip + (u32)lane * s;
     const u64 v8 = active ? ld64(src + p) : 0;
@@ -623,11 +623,12 @@ zra_mf_kernel(ZraEncArgs a, u32 block) {
     __shared__ u32 dupL[512], dupS[512];
     for (int i = lane; i < 512; i += 64) { dupL[i] = 0; dupS[i] = 0; }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    const u32 wcap = (a.mfTune >= 8 && a.mfTune <= 64 && a.mfTune != 9) ? a.mfTune : 64u;   // window width (bring-up knob ZRA_MF_TUNE=8..64)
     if (a.mfTune == 9) {                             // previous formulation (one batch per sequence), kept for A/B measurements
       if (tagged) lastLL = mf_dfast_wave<u32, true>(P, hashT, chainT, src, bs, be, rep, seqs, &nseq, dupL, dupS, lane, 0);
       else lastLL = mf_dfast_wave<u32, false>(P, hashT, chainT, src, bs, be, rep, seqs, &nseq, dupL, dupS, lane, 0);
-    } else if (tagged) lastLL = mf_dfast_window<u32, true>(P, hashT, chainT, src, bs, be, rep, seqs, &nseq, dupL, dupS, lane);
-    else lastLL = mf_dfast_window<u32, false>(P, hashT, chainT, src, bs, be, rep, seqs, &nseq, dupL, dupS, lane);
+    } else if (tagged) lastLL = mf_dfast_window<u32, true>(P, hashT, chainT, src, bs, be, rep, seqs, &nseq, dupL, dupS, lane, wcap);
+    else lastLL = mf_dfast_window<u32, false>(P, hashT, chainT, src, bs, be, rep, seqs, &nseq, dupL, dupS, lane, wcap);
     if (lane == 0) {
       bo->nbSeq = nseq; bo->lastLL = lastLL; bo->skip = 0;
       bo->rep[0] = rep[0]; bo->rep[1] = rep[1]; bo->rep[2] = rep[2];
