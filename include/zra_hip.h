@@ -64,6 +64,10 @@ ZRA_EXPORT double ZraHipLastKernelMs(ZraHipEngine* engine);
  *  out6 = {match-finder ms, launches, entropy-stage ms, launches, decode ms, launches}. */
 ZRA_EXPORT void ZraHipGetKernelStats(ZraHipEngine* engine, double* out6);
 
+/** Bring-up aid (not a product entry point): the match finder's sequences {litLength | matchLength<<20 | offsetValue<<40} left in
+ *  scratch for frame `frame` of the last compress call's last batch (last block of the frame); meta3 = {nbSeq, lastLL, skip}. */
+ZRA_EXPORT uint32_t ZraHipDebugReadSeqs(ZraHipEngine* engine, uint32_t frame, uint64_t* out, uint32_t cap, uint32_t* meta3);
+
 #ifdef __cplusplus
 }
 #endif

@@ -7,6 +7,7 @@ There is NO CPU codec here: without the built extension or without a GPU the com
 """
 import ctypes
 import os
+import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libzra_amd.so")
@@ -41,6 +42,15 @@ def load():
         return _lib
     if not os.path.exists(LIB_PATH):
         raise ImportError("zra_amd: %s is missing — run `python -c 'import __graft_entry__ as g; g.build()'` (hipcc, gfx950)" % LIB_PATH)
+    # PyTorch-ROCm bundles its own libamdhip64 with the same soname as /opt/rocm's: whichever is loaded first serves both.
+    # torch only finds its GPUs through its own copy, so when torch is installed it goes first (tests and bench.py use both).
+    if "torch" not in sys.modules and not os.environ.get("ZRA_NO_TORCH_PRELOAD"):
+        try:
+            import importlib.util
+            if importlib.util.find_spec("torch") is not None:
+                import torch  # noqa: F401
+        except Exception:
+            pass
     L = ctypes.CDLL(LIB_PATH)
     sz, vp, u32, u64p = ctypes.c_size_t, ctypes.c_void_p, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint64)
     szp = ctypes.POINTER(ctypes.c_size_t)
@@ -107,7 +117,7 @@ C_ABI_SYMBOLS = [
     "ZraDecompressWithFullDecompressor",
 ]
 HIP_ABI_SYMBOLS = ["ZraHipDeviceCount", "ZraHipCreateEngine", "ZraHipDestroyEngine", "ZraHipSynchronize", "ZraHipGetStream", "ZraHipLastKernelMs", "ZraHipGetKernelStats",
-                   "ZraHipCompressBuffer", "ZraHipDecompressBuffer", "ZraHipDecompressRABatch", "ZraHipCompressFrames", "ZraHipStitchHeader"]
+                   "ZraHipCompressBuffer", "ZraHipDecompressBuffer", "ZraHipDecompressRABatch", "ZraHipCompressFrames", "ZraHipStitchHeader", "ZraHipDebugReadSeqs"]
 
 
 def _chk(st, what=""):
@@ -182,6 +192,13 @@ class Engine:
         a = (ctypes.c_double * 6)()
         self.L.ZraHipGetKernelStats(self.h, a)
         return dict(mf_ms=a[0], mf_launches=int(a[1]), ent_ms=a[2], ent_launches=int(a[3]), dec_ms=a[4], dec_launches=int(a[5]))
+
+    def debug_read_seqs(self, frame, cap=65536):
+        """bring-up: [(litLength, matchLength, offsetValue)] of `frame` in the last batch + (nbSeq, lastLL, skip)."""
+        buf = (ctypes.c_uint64 * cap)(); meta = (ctypes.c_uint32 * 3)()
+        self.L.ZraHipDebugReadSeqs.restype = ctypes.c_uint32
+        n = self.L.ZraHipDebugReadSeqs(self.h, ctypes.c_uint32(frame), buf, ctypes.c_uint32(cap), meta)
+        return [(int(v) & 0xFFFFF, (int(v) >> 20) & 0xFFFFF, int(v) >> 40) for v in buf[:n]], tuple(meta)
 
     def compress(self, d_in, in_size, d_out, level=3, frame_size=65536, checksum=True):
         osz = ctypes.c_size_t(0)

@@ -29,6 +29,7 @@ def build(force=False, verbose=False):
         objs.append(o)
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-x", "hip",
                "-I" + os.path.join(HERE, "..", "include"), "-I" + CSRC, "-c", os.path.join(CSRC, s), "-o", o]
+        cmd[3:3] = os.environ.get("ZRA_EXTRA_CFLAGS", "").split()      # bring-up only, e.g. -DZRA_MF_PROFILE
         if verbose:
             print(" ".join(cmd))
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

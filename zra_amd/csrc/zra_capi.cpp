@@ -440,6 +440,7 @@ ZraStatus ZraHipSynchronize(ZraHipEngine* engine) { return mk(engine->e->sync())
 void* ZraHipGetStream(ZraHipEngine* engine) { return (void*)engine->e->stream(); }
 double ZraHipLastKernelMs(ZraHipEngine* engine) { return engine->e->last_kernel_ms(); }
 void ZraHipGetKernelStats(ZraHipEngine* engine, double* out6) { engine->e->kernel_stats(out6); }
+uint32_t ZraHipDebugReadSeqs(ZraHipEngine* engine, uint32_t frame, uint64_t* out, uint32_t cap, uint32_t* meta3) { return engine->e->debug_read_seqs(frame, out, cap, meta3); }
 
 ZraStatus ZraHipCompressBuffer(ZraHipEngine* engine, const void* dIn, size_t inSize, void* dOut, size_t* outSize, int8_t level, uint32_t frameSize, bool checksum) {
   return mk(engine->e->compress_device((const uint8_t*)dIn, inSize, (uint8_t*)dOut, outSize, level, frameSize, checksum));

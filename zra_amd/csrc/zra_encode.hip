@@ -9,7 +9,8 @@
 #include <cstring>
 #include <vector>
 
-extern "C" __global__ void zra_mf_kernel(ZraEncArgs a, uint32_t block);
+extern "C" __global__ void zra_mf_kernel(ZraEncArgs a, uint32_t block, uint32_t only);
+extern "C" __global__ void zra_mf_dfast_kernel(ZraEncArgs a, uint32_t block);
 extern "C" __global__ void zra_entropy_kernel(ZraEncArgs a, uint32_t block);
 
 using namespace zra_dev;
@@ -152,7 +153,8 @@ Status Engine::compress_impl(const uint8_t* dIn, size_t inSize, uint8_t* dBody, 
   ZraEncArgs base{};
   base.in = dIn; base.inSize = inSize; base.frameSize = frameSize; base.checksum = checksum ? 1 : 0;
   base.full = full; base.tail = tail;
-  { static const int tune = std::getenv("ZRA_MF_TUNE") ? std::atoi(std::getenv("ZRA_MF_TUNE")) : 0; base.mfTune = (uint32_t)tune; }
+  { const char* t = std::getenv("ZRA_MF_TUNE"); base.mfTune = t ? (uint32_t)std::atoi(t) : 0u; }   // bring-up knob, read per call
+  dbgSeqStride_ = seqStride; dbgB_ = (uint32_t)B;
   base.tableStride = tableWords; base.seqStride = seqStride; base.litStride = litStride; base.slotStride = slotStride;
 
   // event pool: [2 per mf launch on stream A] [2 per entropy launch on stream B]; dependencies mfDone / entDone per context
@@ -192,9 +194,24 @@ Status Engine::compress_impl(const uint8_t* dIn, size_t inSize, uint8_t* dBody, 
       if (!m0 || !m1 || !e1) return zerr(1);
       HIPCHK(hipEventRecord(m0, stream_));
       {
-        // occupancy experiment knob (bring-up): dynamic LDS per workgroup caps the frames in flight per CU
+        // occupancy experiment knob (bring-up): extra dynamic LDS per workgroup caps the frames in flight per CU
         static const int dynLds = std::getenv("ZRA_MF_LDS") ? std::atoi(std::getenv("ZRA_MF_LDS")) : 0;
-        hipLaunchKernelGGL(zra_mf_kernel, dim3(nb), dim3(64), dynLds, stream_, a, blk);
+        // dfast batches (levels 3-4) run the lean window-resolve kernel; a short last frame whose cparams select another
+        // strategy is parsed by the generic kernel in a second single-frame launch
+        const bool hasTail = tailSize && f0 + nb == nFramesTotal;
+        if (full.strategy == 2 && a.mfTune != 7) {
+          // LDS geometry of the bucket filter: 1 bit per 2^shL long-table buckets, 1 bit per 2^shS short-table buckets, and the
+          // duplicate-detection slots. Default 2 KiB + 4 KiB + 4 KiB at hashLog 16 / chainLog 15 (16 frames per CU).
+          uint32_t shL = 1, shS = 0, dupLog = 10;
+          if (const char* f = std::getenv("ZRA_MF_FILTER")) { unsigned x = 1, y = 0, z = 10; if (std::sscanf(f, "%u,%u,%u", &x, &y, &z) >= 1) { shL = x & 15; shS = y & 15; dupLog = z & 15; } }
+          a.mfFilter = shL | (shS << 4) | (dupLog << 8);
+          const uint32_t hl = std::max(full.hashLog, tail.hashLog), cl = std::max(full.chainLog, tail.chainLog);
+          const size_t filterBytes = (2u << dupLog) + (((size_t)1 << hl) >> shL) / 8 + (((size_t)1 << cl) >> shS) / 8 + 64;
+          hipLaunchKernelGGL(zra_mf_dfast_kernel, dim3(nb), dim3(64), filterBytes + dynLds, stream_, a, blk);
+          if (hasTail && tail.strategy != 2) hipLaunchKernelGGL(zra_mf_kernel, dim3(nb), dim3(64), 0, stream_, a, blk, (uint32_t)(nb - 1));
+        } else {
+          hipLaunchKernelGGL(zra_mf_kernel, dim3(nb), dim3(64), dynLds, stream_, a, blk, 0xFFFFFFFFu);
+        }
       }
       HIPCHK(hipEventRecord(m1, stream_));
       mfSpans.push_back({m0, m1});
@@ -227,6 +244,19 @@ Status Engine::compress_impl(const uint8_t* dIn, size_t inSize, uint8_t* dBody, 
   lastKernelMs_ = kernelMs;
   *bodySize = total;
   return ok();
+}
+
+uint32_t Engine::debug_read_seqs(uint32_t frame, uint64_t* out, uint32_t cap, uint32_t meta[3]) {
+  if (!dbgB_ || frame >= dbgB_) return 0;
+  hipSetDevice(device_);
+  hipDeviceSynchronize();
+  EncCtx& x = encCtx_[0];
+  ZraEncBlockOut bo{};
+  hipMemcpy(&bo, x.misc.as<uint8_t>() + (size_t)dbgB_ * sizeof(ZraEncFrameState) + (size_t)frame * sizeof(ZraEncBlockOut), sizeof(bo), hipMemcpyDeviceToHost);
+  meta[0] = bo.nbSeq; meta[1] = bo.lastLL; meta[2] = bo.skip;
+  const uint32_t n = bo.nbSeq < cap ? bo.nbSeq : cap;
+  if (n) hipMemcpy(out, x.seqs.as<uint64_t>() + (size_t)frame * dbgSeqStride_, (size_t)n * 8, hipMemcpyDeviceToHost);
+  return n;
 }
 
 Status Engine::compress_device(const uint8_t* dIn, size_t inSize, uint8_t* dOut, size_t* outSize, int level, uint32_t frameSize, bool checksum) {

@@ -12,6 +12,21 @@
 
 using namespace zra_dev;
 
+// Phase timing for bring-up (build with -DZRA_MF_PROFILE; never in the shipped library): per-phase s_memtime sums of lane 0
+// of every wave, accumulated into zra_mf_prof[] (read with hipMemcpyFromSymbol through ZraHipDebugReadMfProfile).
+#ifdef ZRA_MF_PROFILE
+__device__ unsigned long long zra_mf_prof[24];
+#define PROF_DECL u64 pt_[20]; for (int k_ = 0; k_ < 20; k_++) pt_[k_] = 0; u64 pl_ = __builtin_amdgcn_s_memtime();
+#define PROF(k) { __builtin_amdgcn_s_waitcnt(0); const u64 n_ = __builtin_amdgcn_s_memtime(); pt_[k] += n_ - pl_; pl_ = n_; }
+#define PROF_CNT(k) { pt_[k]++; }
+#define PROF_END { if (lane == 0) for (int k_ = 0; k_ < 20; k_++) atomicAdd(&zra_mf_prof[k_], pt_[k_]); }
+#else
+#define PROF_DECL
+#define PROF(k)
+#define PROF_CNT(k)
+#define PROF_END
+#endif
+
 namespace {
 
 __device__ __forceinline__ u32 hash4(const u8* p, u32 bits) { return (ld32(p) * 2654435761u) >> (32 - bits); }
@@ -88,60 +103,6 @@ __device__ u32 mf_fast(const ZraEncParams& P, u32* T, const u8* src, u32 bs, u32
       }
     }
     ip1 = ip0 + 1;
-  }
-  rep[0] = o1 ? o1 : saved; rep[1] = o2 ? o2 : saved;
-  return be - anchor;
-}
-
-// ---- A.4.3 "dfast" (level 3-4): long table keyed by 8 bytes, short table keyed by minMatch bytes
-__device__ u32 mf_dfast(const ZraEncParams& P, u32* HL, u32* HS, const u8* src, u32 bs, u32 be, u32* rep, Emit& E) {
-  const u32 hlog = P.hashLog, clog = P.chainLog, mls = P.minMatch;
-  u32 o1 = rep[0], o2 = rep[1], saved;
-  u32 anchor = bs;
-  const u32 ilimit = be - 8;
-  u32 ip = mf_prologue(bs, o1, o2, saved);
-  while (ip < ilimit) {
-    const u32 top = ip;
-    const u64 v8 = ld64(src + ip);
-    const u32 hL = (u32)((v8 * 0xCF1BBCDCB7A56463ULL) >> (64 - hlog));
-    const u32 hS = mls == 5 ? (u32)(((v8 << 24) * 889523592379ULL) >> (64 - clog)) : hashN(src + ip, clog, mls);
-    const u32 curr = ip + 1;
-    const u32 mL = HL[hL], mS = HS[hS];
-    HL[hL] = curr; HS[hS] = curr;
-    u32 ml, offVal;
-    if (o1 > 0 && ld32(src + ip + 1 - o1) == ld32(src + ip + 1)) {
-      ml = count_eq(src, ip + 5, ip + 5 - o1, be) + 4; ip++; offVal = 1;
-    } else {
-      u32 m;
-      if (mL > 1 && ld64(src + mL - 1) == v8) {
-        m = mL - 1; ml = count_eq(src, ip + 8, m + 8, be) + 8;
-      } else if (mS > 1 && ld32(src + mS - 1) == (u32)v8) {
-        const u32 h3 = hash8(src + ip + 1, hlog), m3 = HL[h3];
-        HL[h3] = curr + 1;
-        if (m3 > 1 && ld64(src + m3 - 1) == ld64(src + ip + 1)) { m = m3 - 1; ip++; ml = count_eq(src, ip + 8, m + 8, be) + 8; }
-        else { m = mS - 1; ml = count_eq(src, ip + 4, m + 4, be) + 4; }
-      } else { ip += ((ip - anchor) >> 8) + 1; continue; }
-      const u32 off = ip - m;
-      while (ip > anchor && m > 0 && src[ip - 1] == src[m - 1]) { ip--; m--; ml++; }
-      o2 = o1; o1 = off; offVal = off + 3;
-    }
-    E.put(ip - anchor, ml, offVal);
-    ip += ml; anchor = ip;
-    if (ip <= ilimit) {
-      const u32 q = top + 2;
-      HL[hash8(src + q, hlog)] = q + 1;
-      HL[hash8(src + ip - 2, hlog)] = ip - 1;
-      HS[hashN(src + q, clog, mls)] = q + 1;
-      HS[hashN(src + ip - 1, clog, mls)] = ip;
-      while (ip <= ilimit && o2 > 0 && ld32(src + ip) == ld32(src + ip - o2)) {
-        const u32 rl = count_eq(src, ip + 4, ip + 4 - o2, be) + 4;
-        const u32 t = o2; o2 = o1; o1 = t;
-        HS[hashN(src + ip, clog, mls)] = ip + 1;
-        HL[hash8(src + ip, hlog)] = ip + 1;
-        E.put(0, rl, 1);
-        ip += rl; anchor = ip;
-      }
-    }
   }
   rep[0] = o1 ? o1 : saved; rep[1] = o2 ? o2 : saved;
   return be - anchor;
@@ -289,122 +250,8 @@ __device__ __forceinline__ u32 wave_count_back(const u8* src, u32 ip, u32 m, u32
   }
 }
 
-template <typename T, bool TAG>
-__device__ u32 mf_dfast_wave(const ZraEncParams& P, T* HL, T* HS, const u8* src, u32 bs, u32 be, u32* rep, u64* seqs, u32* nOut,
-                             u32* dupL, u32* dupS, int lane, u32 tune) {
-  const u32 hlog = P.hashLog, clog = P.chainLog, mls = P.minMatch;
-  u32 o1 = rep[0], o2 = rep[1], saved;
-  u32 anchor = bs, nseq = 0;
-  const u32 ilimit = be - 8;
-  u32 ip = mf_prologue(bs, o1, o2, saved);
-  u32 W = 8, epoch = 1;
-  auto hashS64 = [&](u64 v) -> u32 {
-    switch (mls) {
-      case 5: return (u32)(((v << 24) * 889523592379ULL) >> (64 - clog));
-      case 6: return (u32)(((v << 16) * 227718039650203ULL) >> (64 - clog));
-      case 7: return (u32)(((v << 8) * 58295818150454627ULL) >> (64 - clog));
-      default: return ((u32)v * 2654435761u) >> (32 - clog);
-    }
-  };
-  auto hashL64 = [&](u64 v) -> u32 { return (u32)((v * 0xCF1BBCDCB7A56463ULL) >> (64 - hlog)); };
-  // TAG mode (32-bit entries, positions < 65536): the upper half of an entry carries 16 more hash bits of the bytes the
-  // candidate test compares (8 for the long table, 4 for the short one); a tag mismatch proves the candidate test would
-  // fail, so the random read of the candidate's bytes is skipped. Results are unchanged.
-  auto tagL64 = [&](u64 v) -> u32 { return TAG ? ((u32)((v * 0xCF1BBCDCB7A56463ULL) >> (48 - hlog)) & 0xFFFFu) << 16 : 0u; };
-  auto tagS64 = [&](u64 v) -> u32 { return TAG ? (((u32)v * 2654435761u) >> 16) << 16 : 0u; };
-  while (ip < ilimit) {
-    const u32 run = ip - anchor, s = (run >> 8) + 1;
-    u32 nAct = min(W, min((256 * s - run + s - 1) / s, (ilimit - ip + s - 1) / s));
-    bool active = (u32)lane < nAct;
-    const u32 p = ip + (u32)lane * s;
-    const u64 v8 = active ? ld64(src + p) : 0;
-    const u32 hL = hashL64(v8), hS = hashS64(v8);
-    const u32 tL = tagL64(v8), tS = tagS64(v8);
-    u32 mL = 0, mS = 0;
-    bool tagLok = true, tagSok = true;
-    if (active) {
-      const u32 rL = HL[hL], rS = HS[hS];
-      if (TAG) { mL = rL & 0xFFFFu; mS = rS & 0xFFFFu; tagLok = (rL & 0xFFFF0000u) == tL; tagSok = (rS & 0xFFFF0000u) == tS; }
-      else { mL = rL; mS = rS; }
-    }
-    if (nAct > 1) {
-      const u32 tag = (epoch << 6) | (63u - (u32)lane);
-      if (active) { atomicMax(&dupL[hL & 511], tag); atomicMax(&dupS[hS & 511], tag); }
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-      const bool earlier = active && (((dupL[hL & 511] & 63u) != 63u - (u32)lane) || ((dupS[hS & 511] & 63u) != 63u - (u32)lane));
-      const u64 cut = __ballot(earlier);
-      if (cut) { nAct = (u32)__builtin_ctzll(cut); active = (u32)lane < nAct; }
-      epoch++;
-    }
-    const bool repHit = active && o1 > 0 && ld32(src + p + 1 - o1) == (u32)(v8 >> 8);
-    const bool longHit = active && mL > 1 && tagLok && ld64(src + mL - 1) == v8;
-    const bool shortHit = active && mS > 1 && tagSok && ld32(src + mS - 1) == (u32)v8;
-    const u64 hm = __ballot(repHit || longHit || shortHit);
-    const u32 f = hm ? (u32)__builtin_ctzll(hm) : nAct - 1;
-    if (active && (u32)lane <= f) { HL[hL] = (T)((p + 1) | tL); HS[hS] = (T)((p + 1) | tS); }
-    if (!hm) { ip += nAct * s; W = tune == 3 ? 64u : tune == 4 ? 16u : min(64u, W * 2); continue; }
-    W = tune == 1 ? min(64u, max(2u, f + 2)) : tune == 2 ? min(64u, max(8u, 4 * (f + 1))) : tune == 3 ? 64u : tune == 4 ? 16u : tune == 5 ? min(64u, max(4u, f + 4)) : min(64u, max(4u, 2 * (f + 1)));
-    // ---- the hit lane's values, wave-uniform from here on
-    const u32 top = ip + f * s;
-    const u64 v8f = bcast64(v8, f);
-    const u32 mLf = bcast(mL, f), mSf = bcast(mS, f);
-    const bool isRep = (__ballot(repHit) >> f) & 1, isLong = (__ballot(longHit) >> f) & 1;
-    const u32 curr = top + 1;
-    ip = top;
-    u32 ml, offVal;
-    if (isRep) {
-      ml = wave_count_eq(src, ip + 5, ip + 5 - o1, be, lane) + 4; ip++; offVal = 1;
-    } else {
-      u32 m;
-      if (isLong) { m = mLf - 1; ml = wave_count_eq(src, ip + 8, m + 8, be, lane) + 8; }
-      else {
-        const u64 v9 = rfl64(ld64(src + ip + 1));
-        const u32 h3 = hashL64(v9);
-        const u32 r3 = rfl(HL[h3]);
-        const u32 m3 = TAG ? (r3 & 0xFFFFu) : r3;
-        const bool tag3ok = !TAG || (r3 & 0xFFFF0000u) == tagL64(v9);
-        if (lane == 0) HL[h3] = (T)((curr + 1) | tagL64(v9));
-        if (m3 > 1 && tag3ok && rfl64(ld64(src + m3 - 1)) == v9) { m = m3 - 1; ip++; ml = wave_count_eq(src, ip + 8, m + 8, be, lane) + 8; }
-        else { m = mSf - 1; ml = wave_count_eq(src, ip + 4, m + 4, be, lane) + 4; }
-      }
-      const u32 off = ip - m;
-      const u32 back = wave_count_back(src, ip, m, anchor, lane);
-      ip -= back; ml += back;
-      o2 = o1; o1 = off; offVal = off + 3;
-    }
-    (void)v8f;
-    if (lane == 0) seqs[nseq] = (u64)(ip - anchor) | ((u64)ml << 20) | ((u64)offVal << 40);
-    nseq++;
-    ip += ml; anchor = ip;
-    if (ip <= ilimit) {
-      // complementary insertions (order per table preserved: q first, then ip-2 / ip-1)
-      const u32 q = top + 2;
-      { const u64 vq = ld64(src + q);
-        if (lane == 0) HL[hashL64(vq)] = (T)((q + 1) | tagL64(vq));
-        if (lane == 1) HS[hashS64(vq)] = (T)((q + 1) | tagS64(vq)); }
-      { const u64 va = ld64(src + ip - 2), vb = va >> 8 | ((u64)src[ip + 6] << 56);
-        if (lane == 0) HL[hashL64(va)] = (T)((ip - 1) | tagL64(va));
-        if (lane == 1) HS[hashS64(vb)] = (T)(ip | tagS64(vb)); }
-      while (ip <= ilimit && o2 > 0 && rfl(ld32(src + ip)) == rfl(ld32(src + ip - o2))) {
-        const u32 rl = wave_count_eq(src, ip + 4, ip + 4 - o2, be, lane) + 4;
-        const u32 t = o2; o2 = o1; o1 = t;
-        const u64 vi = ld64(src + ip);
-        if (lane == 0) HS[hashS64(vi)] = (T)((ip + 1) | tagS64(vi));
-        if (lane == 1) HL[hashL64(vi)] = (T)((ip + 1) | tagL64(vi));
-        if (lane == 0) seqs[nseq] = (u64)0 | ((u64)rl << 20) | ((u64)1 << 40);
-        nseq++;
-        ip += rl; anchor = ip;
-      }
-    }
-  }
-  rep[0] = o1 ? o1 : saved; rep[1] = o2 ? o2 : saved;
-  *nOut = nseq;
-  return be - anchor;
-}
-
-
 // ================================================================================================
-// Window-resolve dfast: the batch formulation above, taken one step further. A window of up to 64 consecutive parse
+// Window-resolve dfast (first formulation, kept for A/B runs with ZRA_MF_TUNE=7 and for the generic kernel). A window of up to 64 consecutive parse
 // positions is looked up ONCE (one table-gather round trip + one tag-filtered candidate round trip), then the parse is
 // resolved INSIDE the window: after a match the positions behind it are still in registers, so the next sequences of the
 // window need no further trip to the tables. This is exact because no two lanes of a window share a bucket (exactly
@@ -421,6 +268,7 @@ __device__ u32 mf_dfast_window(const ZraEncParams& P, T* HL, T* HS, const u8* sr
   const u32 ilimit = be - 8;
   u32 ip = mf_prologue(bs, o1, o2, saved);
   u32 epoch = 1;
+  PROF_DECL
   auto hashS64 = [&](u64 v) -> u32 {
     switch (mls) {
       case 5: return (u32)(((v << 24) * 889523592379ULL) >> (64 - clog));
@@ -440,6 +288,7 @@ __device__ u32 mf_dfast_window(const ZraEncParams& P, T* HL, T* HS, const u8* sr
     bool active = (u32)lane < nAct;
     const u32 p = wip + (u32)lane * s;
     const u64 v8 = active ? ld64(src + p) : 0;
+    PROF(0) PROF_CNT(12)
     const u32 hL = hashL64(v8), hS = hashS64(v8);
     const u32 tL = tagL64(v8), tS = tagS64(v8);
     if (nAct > 1) {
@@ -455,6 +304,7 @@ __device__ u32 mf_dfast_window(const ZraEncParams& P, T* HL, T* HS, const u8* sr
       }
       epoch++;
     }
+    PROF(1)
     u32 mL = 0, mS = 0;
     bool tagLok = true, tagSok = true;
     if (active) {
@@ -462,9 +312,11 @@ __device__ u32 mf_dfast_window(const ZraEncParams& P, T* HL, T* HS, const u8* sr
       if (TAG) { mL = rL & 0xFFFFu; mS = rS & 0xFFFFu; tagLok = (rL & 0xFFFF0000u) == tL; tagSok = (rS & 0xFFFF0000u) == tS; }
       else { mL = rL; mS = rS; }
     }
+    PROF(2)
     // candidate tests that do not depend on the parse state
     const bool longHit = active && mL > 1 && tagLok && ld64(src + mL - 1) == v8;
     const bool shortHit = active && mS > 1 && tagSok && ld32(src + mS - 1) == (u32)v8;
+    PROF(3)
     // insert position `pos` into the long / short table; bucket + tag come from the window's registers when pos is in it
     auto insert = [&](u32 pos, bool doL, bool doS) {
       u32 hl, hs, tl, ts;
@@ -472,6 +324,7 @@ __device__ u32 mf_dfast_window(const ZraEncParams& P, T* HL, T* HS, const u8* sr
         const u32 l = pos - wip;
         hl = bcast(hL, l); hs = bcast(hS, l); tl = bcast(tL, l); ts = bcast(tS, l);
       } else {
+        PROF_CNT(14)
         const u64 v = rfl64(ld64(src + pos));
         hl = hashL64(v); hs = hashS64(v); tl = tagL64(v); ts = tagS64(v);
       }
@@ -491,6 +344,7 @@ __device__ u32 mf_dfast_window(const ZraEncParams& P, T* HL, T* HS, const u8* sr
       const u64 hm = __ballot(live && (repHit || longHit || shortHit));
       const u32 f = hm ? (u32)__builtin_ctzll(hm) : nAct - 1;
       if (live && (u32)lane <= f) { HL[hL] = (T)((p + 1) | tL); HS[hS] = (T)((p + 1) | tS); }   // visited positions
+      PROF(4)
       if (!hm) { ip = wip + nAct * s; break; }
       const u32 top = wip + f * s;
       const u32 mLf = bcast(mL, f), mSf = bcast(mS, f);
@@ -508,6 +362,7 @@ __device__ u32 mf_dfast_window(const ZraEncParams& P, T* HL, T* HS, const u8* sr
           v9 = bcast64(v8, f + 1); h3 = bcast(hL, f + 1); m3 = bcast(mL, f + 1); t3 = bcast(tL, f + 1);
           tag3ok = (__ballot(tagLok) >> (f + 1)) & 1;
         } else {
+          PROF_CNT(15)
           v9 = rfl64(ld64(src + ip + 1)); h3 = hashL64(v9); t3 = tagL64(v9);
           const u32 r3 = rfl((u32)HL[h3]);
           m3 = TAG ? (r3 & 0xFFFFu) : r3;
@@ -518,6 +373,7 @@ __device__ u32 mf_dfast_window(const ZraEncParams& P, T* HL, T* HS, const u8* sr
         else { m = mSf - 1; known = 4; }
         offVal = 0;
       }
+      PROF(5)
       const u32 off = ip - m;
       const u32 o1n = isRep ? o1 : off;             // o1 after this sequence (unless the repcode loop swaps)
       // ---- issue together: forward compare (64 x 8 B), backward compare (64 x 1 B), next rep gather
@@ -528,6 +384,7 @@ __device__ u32 mf_dfast_window(const ZraEncParams& P, T* HL, T* HS, const u8* sr
       const bool bv = (u32)lane < lim;
       const u32 ya = bv ? src[ip - 1 - lane] : 0u, yb = bv ? src[m - 1 - lane] : 1u;
       const u32 rnext = (active && o1n > 0 && p + 1 >= o1n) ? ld32(src + p + 1 - o1n) : 0;
+      PROF(6)
       u32 ml;
       {
         const u64 d = xa ^ xb;
@@ -549,14 +406,17 @@ __device__ u32 mf_dfast_window(const ZraEncParams& P, T* HL, T* HS, const u8* sr
       if (lane == 0) seqs[nseq] = (u64)(ip - anchor) | ((u64)ml << 20) | ((u64)offVal << 40);
       nseq++;
       ip += ml; anchor = ip;
+      PROF(7) PROF_CNT(13)
       if (ip <= ilimit) {
         insert(top + 2, true, true);                  // complementary insertions (order per table: q first)
         insert(ip - 2, true, false);
         insert(ip - 1, false, true);
+        PROF(8)
         for (;;) {
           if (!(ip <= ilimit && o2 > 0)) break;
           const u32 here = (s == 1 && ip >= wip && ip - wip < nAct) ? (u32)bcast64(v8, ip - wip) : rfl(ld32(src + ip));
           if (here != rfl(ld32(src + ip - o2))) break;
+          PROF_CNT(16)
           const u32 rl = wave_count_eq(src, ip + 4, ip + 4 - o2, be, lane) + 4;
           const u32 t = o2; o2 = o1; o1 = t;
           insert(ip, true, true);
@@ -565,10 +425,286 @@ __device__ u32 mf_dfast_window(const ZraEncParams& P, T* HL, T* HS, const u8* sr
           ip += rl; anchor = ip;
         }
       }
+      PROF(9)
       if (s != 1 || ip >= wip + nAct || ip >= ilimit) break;    // left the window: build the next one at ip
       cur = ip - wip;
     }
   }
+  PROF(10) PROF_END
+  rep[0] = o1 ? o1 : saved; rep[1] = o2 ? o2 : saved;
+  *nOut = nseq;
+  return be - anchor;
+}
+
+
+// ================================================================================================
+// Lean window-resolve dfast. Same algorithm as mf_dfast_window, re-laid-out for instruction count: rocprofv3 shows the match
+// finder is bound by instruction issue (7 waves per SIMD x ~1.7 M instructions per frame), not by HBM. Differences:
+//   * every in-window insertion (visited positions, the ip+1 long probe, the complementary insertions) is "lane q-wip stores its
+//     own (bucket, value)": one exec-masked store per table and sequence, masks built on the scalar unit;
+//   * the ip+1 long probe of a short hit is lane f+1's own long-table test (already evaluated at window build);
+//   * the immediate-repcode test after a match reuses the rep gather of the previous offset (o2 == old o1) — no load;
+//   * out-of-window work of a sequence (insertions behind the match end, repcode test) is one 6-lane load + one vector hash;
+//   * sequences are collected in a register (lane = index & 63) and stored 64 at a time;
+//   * duplicate-bucket detection uses byte-wide LDS slots (2048 per table, no epochs, no atomics);
+//   * tags use all bits above the index (ib = bits needed for position+1), so every dfast frame size is tagged.
+__device__ __forceinline__ u32 wlane(u32 old, u32 val, u32 l) {
+  val = rfl(val); l = rfl(l);
+  asm("" : "+s"(val)); asm("" : "+s"(l));              // keep both operands in SGPRs (no literals in VOP3 on gfx9)
+  asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(old) : "s"(val), "s"(l) : "m0");
+  return old;
+}
+__device__ __forceinline__ bool lane_in(u64 mask) { return __builtin_amdgcn_inverse_ballot_w64(mask); }
+__device__ __forceinline__ u64 bit64(u32 i) { return 1ull << i; }
+
+template <u32 MLS>
+struct DfHash {
+  u32 shL, shS, shT, ib, tagMask;
+  __device__ __forceinline__ void init(u32 hlog, u32 clog, u32 ibits) {
+    ib = ibits; tagMask = ~((1u << ib) - 1u); shL = 64 - hlog; shS = (MLS == 4 ? 32 : 64) - clog; shT = shL - (32 - ib);
+  }
+  // bucket indices and tags (tag = the hash bits just below the bucket bits, moved above the index bits)
+  __device__ __forceinline__ void both(u64 v, u32& bL, u32& bS, u32& tL, u32& tS) const {
+    const u64 pl = v * 0xCF1BBCDCB7A56463ULL;
+    bL = (u32)(pl >> shL); tL = (u32)(pl >> shT) << ib;
+    const u32 p4 = (u32)v * 2654435761u;
+    tS = p4 & tagMask;
+    if (MLS == 5) bS = (u32)(((v << 24) * 889523592379ULL) >> shS);
+    else if (MLS == 6) bS = (u32)(((v << 16) * 227718039650203ULL) >> shS);
+    else if (MLS == 7) bS = (u32)(((v << 8) * 58295818150454627ULL) >> shS);
+    else bS = p4 >> shS;
+  }
+};
+
+// LDS working set of one frame's parse: duplicate-bucket scratch + the bucket filter (1 bit per 2^sh buckets)
+struct LeanLds {
+  u8* dup; u32 dupSlots; u32* bmL; u32* bmS; u32 shL, shS;
+  __device__ __forceinline__ void markL(u32 b) const { const u32 g = b >> shL; atomicOr(&bmL[g >> 5], 1u << (g & 31)); }
+  __device__ __forceinline__ void markS(u32 b) const { const u32 g = b >> shS; atomicOr(&bmS[g >> 5], 1u << (g & 31)); }
+};
+
+template <u32 MLS>
+__device__ u32 mf_dfast_lean(const ZraEncParams& P, u32* HL, u32* HS, const u8* src, u32 bs, u32 be, u32* rep, u64* seqs, u32* nOut,
+                             const LeanLds& W, int lane, u32 ib) {
+  DfHash<MLS> H; H.init(P.hashLog, P.chainLog, ib);
+  const u32 idxMask = ~H.tagMask;
+  // block-level scalars arrive in VGPRs (vector loads of the frame state): pin them to SGPRs once so that the whole
+  // parse state stays on the scalar unit instead of being dragged onto the VALU
+  bs = rfl(bs); be = rfl(be);
+  u32 o1 = rfl(rep[0]), o2 = rfl(rep[1]), saved;
+  u32 anchor = bs, nseq = 0;
+  const u32 ilimit = be - 8;
+  u32 ip = mf_prologue(bs, o1, o2, saved);
+  u32 sqLo = 0, sqHi = 0;                              // pending sequences, lane = index & 63
+  u8* const dL = W.dup; u8* const dS = W.dup + W.dupSlots;
+  const u32 dmask = W.dupSlots - 1;
+  u32* const bmL = W.bmL; u32* const bmS = W.bmS;
+  PROF_DECL
+  auto emit = [&](u32 ll, u32 ml, u32 offVal) {
+    const u64 q = (u64)ll | ((u64)ml << 20) | ((u64)offVal << 40);
+    sqLo = wlane(sqLo, (u32)q, nseq & 63); sqHi = wlane(sqHi, (u32)(q >> 32), nseq & 63);
+    nseq++;
+    if ((nseq & 63) == 0) seqs[nseq - 64 + (u32)lane] = (u64)sqLo | ((u64)sqHi << 32);
+  };
+  // scalar insertion of one position (rare paths only)
+  auto insert_slow = [&](u32 pos, bool doL, bool doS) {
+    if (lane == 0) {
+      u32 bl, bs_, tl, ts; H.both(ld64(src + pos), bl, bs_, tl, ts);
+      if (doL) { HL[bl] = (pos + 1) | tl; W.markL(bl); }
+      if (doS) { HS[bs_] = (pos + 1) | ts; W.markS(bs_); }
+    }
+  };
+  while (ip < ilimit) {
+    // ---------------------------------------------------------------- window build
+    const u32 wip = ip, run = ip - anchor;
+    u32 s = 1, nAct;
+    if (run < 256) nAct = min(min(64u, 256u - run), ilimit - ip);
+    else { s = (run >> 8) + 1; nAct = min(64u, min((256 * s - run + s - 1) / s, (ilimit - ip + s - 1) / s)); }
+    bool active = (u32)lane < nAct;
+    const u32 p = wip + (u32)lane * s;
+    const u64 v8 = active ? ld64(src + p) : 0;
+    // rep gather for the current o1 (independent of the tables: in flight together with them)
+    u32 repFor = o1;
+    bool rv = active && o1 > 0 && p + 1 >= o1;
+    u32 repVal = rv ? ld32(src + p + 1 - o1) : 0;
+    PROF(0) PROF_CNT(12)
+    u32 bL, bS, tL, tS; H.both(v8, bL, bS, tL, tS);
+    if (nAct > 1) {
+      if (active) { dL[bL & dmask] = (u8)lane; dS[bS & dmask] = (u8)lane; }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+      const bool suspect = active && (dL[bL & dmask] != (u8)lane || dS[bS & dmask] != (u8)lane);
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+      u64 sm = __ballot(suspect);
+      u32 cut = nAct;
+      while (sm) {                                   // exact check of the suspects (a slot collision is not yet a bucket collision)
+        const u32 i = (u32)__builtin_ctzll(sm); sm &= sm - 1;
+        if (i >= cut) break;
+        const u32 bLi = bcast(bL, i), bSi = bcast(bS, i);
+        const u64 cm = __ballot(active && (u32)lane != i && (bL == bLi || bS == bSi));
+        if (cm) { const u32 lo = (u32)__builtin_ctzll(cm); cut = min(cut, max(lo, i)); }
+      }
+      nAct = cut; active = (u32)lane < nAct;
+    }
+    PROF(1)
+    // LDS filter: a clear bit means no position of this frame was ever inserted into the bucket (group) -> no table read
+    const u32 gL = bL >> W.shL, gS = bS >> W.shS;
+    const u32 wL = gL >> 5, wS = gS >> 5, qL = 1u << (gL & 31), qS = 1u << (gS & 31);
+    u32 mL = 0, mS = 0;
+    if (active) {
+      const bool needL = (bmL[wL] & qL) != 0, needS = (bmS[wS] & qS) != 0;
+      const u32 rL = needL ? HL[bL] : 0u, rS = needS ? HS[bS] : 0u;
+      mL = ((rL & H.tagMask) == tL) ? (rL & idxMask) : 0u;
+      mS = ((rS & H.tagMask) == tS) ? (rS & idxMask) : 0u;
+    }
+    PROF(2)
+    const u64 LH = __ballot(active && mL > 1 && ld64(src + mL - 1) == v8);
+    const u64 SH = __ballot(active && mS > 1 && ld32(src + mS - 1) == (u32)v8);
+    const u32 valL = (p + 1) | tL, valS = (p + 1) | tS;
+    const u32 v8s = (u32)(v8 >> 8);
+    const u64 AM = nAct >= 64 ? ~0ull : (bit64(nAct) - 1);
+    u64 RH = __ballot(rv && repVal == v8s);
+    u32 repOld = 0, repOldFor = 0xFFFFFFFFu; u64 ROV = 0;   // the gather for the previous o1 (== o2 after a non-rep match)
+    u64 RV = __ballot(rv);
+    PROF(3)
+    // ---------------------------------------------------------------- resolve the window
+    u32 cur = 0;
+    for (;;) {
+      if (repFor != o1) {                             // only after the repcode loop swapped the offsets
+        rv = active && o1 > 0 && p + 1 >= o1;
+        repVal = rv ? ld32(src + p + 1 - o1) : 0; repFor = o1;
+        RH = __ballot(rv && repVal == v8s); RV = __ballot(rv);
+      }
+      const u64 live = AM & (~0ull << cur);
+      const u64 hm = (RH | LH | SH) & live;
+      if (!hm) {
+        if (lane_in(live)) { HL[bL] = valL; HS[bS] = valS; atomicOr(&bmL[wL], qL); atomicOr(&bmS[wS], qS); }
+        ip = wip + nAct * s; PROF(4)
+        break;
+      }
+      const u32 f = (u32)__builtin_ctzll(hm);
+      u64 mkL = live & ((bit64(f) << 1) - 1), mkS = mkL;          // visited positions cur..f
+      const u32 top = wip + f * s;
+      const bool isRep = (RH >> f) & 1, isLong = (LH >> f) & 1;
+      ip = top;
+      u32 m, known, offVal = 1;
+      if (isRep) { ip = top + 1; m = ip - o1; known = 4; }
+      else if (isLong) { m = bcast(mL, f) - 1; known = 8; }
+      else {
+        // short hit: long-table probe at ip+1 (A.4.3 case 3). In the window this IS lane f+1's long test.
+        bool hit3; u32 m3;
+        if (s == 1 && f + 1 < nAct) { hit3 = (LH >> (f + 1)) & 1; m3 = bcast(mL, f + 1); mkL |= bit64(f + 1); }
+        else {
+          PROF_CNT(15)
+          // the probed bucket is not covered by the window's no-duplicate guarantee: commit the visited positions first
+          if (lane_in(mkL)) { HL[bL] = valL; atomicOr(&bmL[wL], qL); }
+          if (lane_in(mkS)) { HS[bS] = valS; atomicOr(&bmS[wS], qS); }
+          mkL = 0; mkS = 0;
+          u32 m3v = 0; bool h3v = false;                // rare: done on lane 0's vector path (keeps the parse state scalar)
+          if (lane == 0) {
+            const u64 v9 = ld64(src + top + 1);
+            u32 b3, bx, t3, tx; H.both(v9, b3, bx, t3, tx);
+            const u32 r3 = HL[b3];
+            m3v = ((r3 & H.tagMask) == t3) ? (r3 & idxMask) : 0u;
+            HL[b3] = (top + 2) | t3; W.markL(b3);
+            h3v = m3v > 1 && ld64(src + m3v - 1) == v9;
+          }
+          hit3 = __ballot(h3v) & 1; m3 = bcast(m3v, 0);
+        }
+        if (hit3) { m = m3 - 1; ip = top + 1; known = 8; }
+        else { m = bcast(mS, f) - 1; known = 4; }
+      }
+      PROF(5)
+      const u32 off = ip - m;
+      // ---- issue together: forward compare (64 x 8 B), backward compare (64 x 1 B), rep gather for the next o1
+      const u32 fa = ip + known + 8 * (u32)lane, fb = m + known + 8 * (u32)lane;
+      const bool fv = fa + 8 <= be;
+      const u64 xa = fv ? ld64(src + fa) : 0, xb = fv ? ld64(src + fb) : 0;
+      const u32 lim = isRep ? 0u : min(ip - anchor, m);
+      u32 ya = 0, yb = 1;
+      if (lim) { const bool bv = (u32)lane < lim; ya = bv ? src[ip - 1 - lane] : 0u; yb = bv ? src[m - 1 - lane] : 1u; }
+      u32 rnext = 0; bool rvn = false;
+      if (!isRep) { rvn = active && p + 1 >= off; rnext = rvn ? ld32(src + p + 1 - off) : 0; }
+      u32 ml;
+      {
+        const u64 d = xa ^ xb;
+        const u32 eq = d ? ((u32)__builtin_ctzll(d) >> 3) : 8;
+        const u64 stop = __ballot(!fv || d != 0);
+        const u32 l = stop ? (u32)__builtin_ctzll(stop) : 64u;
+        const bool clean = stop && ((__ballot(fv) >> l) & 1);       // first stopping lane compared a full 8-byte word
+        if (clean) ml = known + 8 * l + bcast(eq, l);
+        else ml = known + wave_count_eq(src, ip + known, m + known, be, lane);   // block end inside the window, or > 512 equal bytes
+      }
+      PROF(6)
+      if (!isRep) {
+        u32 back = 0;
+        if (lim) {
+          const u64 bad = ~__ballot(ya == yb);
+          back = bad ? (u32)__builtin_ctzll(bad) : wave_count_back(src, ip, m, anchor, lane);
+        }
+        ip -= back; ml += back;
+        o2 = o1; o1 = off; offVal = off + 3;
+        repOld = repVal; ROV = RV; repOldFor = repFor;
+        repVal = rnext; repFor = off; RV = __ballot(rvn); RH = __ballot(rvn && rnext == v8s);
+      }
+      emit(ip - anchor, ml, offVal);
+      ip += ml; anchor = ip;
+      PROF(7) PROF_CNT(13)
+      if (ip > ilimit) {
+        if (lane_in(mkL)) { HL[bL] = valL; atomicOr(&bmL[wL], qL); }
+        if (lane_in(mkS)) { HS[bS] = valS; atomicOr(&bmS[wS], qS); }
+        break;
+      }
+      // ---- complementary insertions (top+2 into both tables, then ip-2 long / ip-1 short) and the immediate repcode test
+      const u32 relE = ip - wip;                       // >= 4
+      const bool in2 = s == 1 && f + 2 < nAct;          // top+2 in the window
+      const bool inE = s == 1 && relE - 1 < nAct;       // ip-1 (and ip-2) in the window
+      const bool inI = s == 1 && relE < nAct;           // ip itself in the window
+      if (in2) { mkL |= bit64(f + 2); mkS |= bit64(f + 2); }
+      if (s == 1 && relE - 2 < nAct) mkL |= bit64(relE - 2);
+      if (inE) mkS |= bit64(relE - 1);
+      if (lane_in(mkL)) { HL[bL] = valL; atomicOr(&bmL[wL], qL); }
+      if (lane_in(mkS)) { HS[bS] = valS; atomicOr(&bmS[wS], qS); }
+      u32 here = 0, there = 1;
+      const bool thereIn = inI && repOldFor == o2 && ((ROV >> (relE - 1)) & 1);   // src[ip - o2] == old rep gather of lane ip-1-wip
+      if (in2 && inE && (o2 == 0 || thereIn)) {
+        if (o2) { here = bcast((u32)v8, relE); there = bcast(repOld, relE - 1); }
+      } else {
+        // lanes 0..3: insertions (pos, table) = (top+2,L) (top+2,S) (ip-2,L) (ip-1,S); lane 4: src[ip]; lane 5: src[ip-o2]
+        PROF_CNT(14)
+        const u32 ipos = lane < 2 ? top + 2 : lane == 2 ? ip - 2 : lane == 3 ? ip - 1 : lane == 4 ? ip : ip - o2;
+        const u64 x = lane < 6 ? ld64(src + ipos) : 0;
+        u32 xbL, xbS, xtL, xtS; H.both(x, xbL, xbS, xtL, xtS);
+        u32* const tp = (lane & 1) ? HS + xbS : HL + xbL;
+        const u32 tv = (ipos + 1) | ((lane & 1) ? xtS : xtL);
+        if (lane < 4) { if (lane & 1) W.markS(xbS); else W.markL(xbL); }     // (a superset of the stores below: harmless)
+        if (!in2 && lane < 2) *tp = tv;                                    // top+2 first ...
+        asm volatile("" ::: "memory");                                     // two instructions: lanes 0/2 (1/3) may hit the same bucket
+        const u64 later = (s == 1 && relE - 2 < nAct ? 0ull : 4ull) | (inE ? 0ull : 8ull);
+        if (lane_in(later)) *tp = tv;                                      // ... then ip-2 / ip-1 (same-bucket order per table)
+        here = bcast((u32)x, 4); there = o2 ? bcast((u32)x, 5) : here + 1;
+        if (o2 == 0) { here = 0; there = 1; }
+      }
+      PROF(8)
+      if (here == there) {
+        // immediate repcode sequences (rare): scalar walk
+        for (;;) {
+          PROF_CNT(16)
+          const u32 rl = wave_count_eq(src, ip + 4, ip + 4 - o2, be, lane) + 4;
+          const u32 t = o2; o2 = o1; o1 = t;
+          insert_slow(ip, true, true);
+          emit(0, rl, 1);
+          ip += rl; anchor = ip;
+          if (!(ip <= ilimit && o2 > 0)) break;
+          if (rfl(ld32(src + ip)) != rfl(ld32(src + ip - o2))) break;
+        }
+      }
+      PROF(9)
+      if (s != 1 || ip >= wip + nAct || ip >= ilimit) break;    // left the window: build the next one at ip
+      cur = ip - wip;
+    }
+  }
+  if (nseq & 63) { if ((u32)lane < (nseq & 63)) seqs[(nseq & ~63u) + (u32)lane] = (u64)sqLo | ((u64)sqHi << 32); }
+  PROF(10) PROF_END
   rep[0] = o1 ? o1 : saved; rep[1] = o2 ? o2 : saved;
   *nOut = nseq;
   return be - anchor;
@@ -576,58 +712,120 @@ __device__ u32 mf_dfast_window(const ZraEncParams& P, T* HL, T* HS, const u8* sr
 
 }  // namespace
 
-// One wave per frame; `block` = index of the <=128 KiB block being parsed in this round (A.4.2 driver).
-extern "C" __global__ void __launch_bounds__(64)
-zra_mf_kernel(ZraEncArgs a, u32 block) {
+// ---- per-frame setup shared by the match-finder kernels: which block of which frame, cleared tables on a fresh frame
+struct MfFrame {
+  const ZraEncParams* P; const u8* src; ZraEncFrameState* st; ZraEncBlockOut* bo; u32* hashT; u32* chainT; u64* seqs;
+  u32 fsize, bs, be;
+};
+// returns false when this workgroup has nothing to parse (block beyond the frame, or a block too small to compress)
+__device__ __forceinline__ bool mf_frame_setup(const ZraEncArgs& a, u32 block, int lane, MfFrame& F) {
   const u32 f = blockIdx.x;
-  const int lane = threadIdx.x;
   const u64 fstart = (u64)(a.firstFrame + f) * a.frameSize;
   const u64 remaining = a.inSize - fstart;
-  const u32 fsize = (u32)(remaining < a.frameSize ? remaining : a.frameSize);
-  const ZraEncParams& P = (fsize == a.frameSize) ? a.full : a.tail;   // the short last frame has its own cparams (A.4.1)
-  const u32 blockSize = P.blockSize;
-  const u32 bs = block * blockSize;
-  if (bs >= fsize && !(fsize == 0 && block == 0)) return;
-  const u32 be = min(fsize, bs + blockSize);
-  const u8* src = a.in + fstart;
-  ZraEncFrameState* st = &a.state[f];
-  u32* hashT = a.tables + (size_t)f * a.tableStride;
-  u32* chainT = hashT + ((size_t)1 << P.hashLog);
-
-  // frames that are one block of <= 64 KiB keep 16-bit table entries (index = position+1 <= 65529 fits): half the table
-  // footprint in HBM/L2 and half the clear traffic; everything else uses 32-bit entries
-  const bool narrow = false;   // 16-bit entries superseded by tagged 32-bit entries (see mf_dfast_wave TAG mode)
-  const bool tagged = P.strategy == 2 && fsize <= 65536;
+  F.fsize = (u32)(remaining < a.frameSize ? remaining : a.frameSize);
+  F.P = (F.fsize == a.frameSize) ? &a.full : &a.tail;                  // the short last frame has its own cparams (A.4.1)
+  const u32 blockSize = F.P->blockSize;
+  F.bs = block * blockSize;
+  if (F.bs >= F.fsize && !(F.fsize == 0 && block == 0)) return false;
+  F.be = min(F.fsize, F.bs + blockSize);
+  F.src = a.in + fstart;
+  F.st = &a.state[f];
+  F.hashT = a.tables + (size_t)f * a.tableStride;
+  F.chainT = F.hashT + ((size_t)1 << F.P->hashLog);
+  F.bo = &a.blockOut[f];
+  F.seqs = a.seqs + (size_t)f * a.seqStride;
   if (block == 0) {
     // fresh frame: zeroed tables, repcodes {1,4,8}, nextToUpdate 1 (A.4.8); 16-byte coalesced clears by the whole wave
-    const size_t entries = ((size_t)1 << P.hashLog) + ((size_t)1 << P.chainLog);
-    const size_t words = narrow ? entries / 2 : entries;
-    uint4* t4 = (uint4*)hashT;
+    const size_t words = ((size_t)1 << F.P->hashLog) + ((size_t)1 << F.P->chainLog);
+    uint4* t4 = (uint4*)F.hashT;
     for (size_t i = lane; i < words / 4; i += 64) t4[i] = make_uint4(0, 0, 0, 0);
-    for (size_t i = (words / 4) * 4 + lane; i < words; i += 64) hashT[i] = 0;
-    if (lane == 0) { st->rep[0] = 1; st->rep[1] = 4; st->rep[2] = 8; st->nextToUpdate = 1; }
+    for (size_t i = (words / 4) * 4 + lane; i < words; i += 64) F.hashT[i] = 0;
+    if (lane == 0) { F.st->rep[0] = 1; F.st->rep[1] = 4; F.st->rep[2] = 8; F.st->nextToUpdate = 1; }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   }
-  const u32 L = be - bs;
-  ZraEncBlockOut* bo = &a.blockOut[f];
-  if (L < 7) {                                         // too small to compress (A.4.2) -> raw block
-    if (lane == 0) { bo->nbSeq = 0; bo->lastLL = L; bo->skip = 1; }
-    return;
+  if (F.be - F.bs < 7) {                               // too small to compress (A.4.2) -> raw block
+    if (lane == 0) { F.bo->nbSeq = 0; F.bo->lastLL = F.be - F.bs; F.bo->skip = 1; }
+    return false;
   }
-  u64* seqs = a.seqs + (size_t)f * a.seqStride;
+  return true;
+}
+
+// Match finder for strategy 2 (dfast, levels 3-4): one wave per frame, lean window-resolve parse. Launched when the batch's
+// full-size frames use dfast; a short last frame with another strategy is left to zra_mf_kernel (second launch, `only`).
+extern "C" __global__ void __launch_bounds__(64)
+zra_mf_dfast_kernel(ZraEncArgs a, u32 block) {
+  const int lane = threadIdx.x;
+  MfFrame F;
+#ifdef ZRA_MF_PROFILE
+  const u64 kt0_ = __builtin_amdgcn_s_memtime();
+#endif
+  if (a.full.strategy != a.tail.strategy && blockIdx.x == a.nFrames - 1) {
+    // is this the short last frame of the whole input? then zra_mf_kernel handles it
+    const u64 fstart = (u64)(a.firstFrame + blockIdx.x) * a.frameSize;
+    if (a.inSize - fstart < a.frameSize) return;
+  }
+  if (!mf_frame_setup(a, block, lane, F)) return;
+#ifdef ZRA_MF_PROFILE
+  __builtin_amdgcn_s_waitcnt(0);
+  if (lane == 0) atomicAdd(&zra_mf_prof[20], __builtin_amdgcn_s_memtime() - kt0_);
+#endif
+  // dynamic LDS: [dup bytes 2 x dupSlots][filter L][filter S]; geometry chosen by the host (a.mfFilter: shL | shS<<4 | log2(dupSlots)<<8)
+  extern __shared__ u32 dynLds[];
+  LeanLds W;
+  W.shL = a.mfFilter & 15; W.shS = (a.mfFilter >> 4) & 15; W.dupSlots = 1u << ((a.mfFilter >> 8) & 15);
+  W.dup = (u8*)dynLds;
+  W.bmL = dynLds + (2 * W.dupSlots) / 4;
+  const u32 wordsL = ((1u << F.P->hashLog) >> W.shL) / 32, wordsS = ((1u << F.P->chainLog) >> W.shS) / 32;
+  W.bmS = W.bmL + wordsL;
+  {
+    // block 0 starts with empty tables (all bits clear); later blocks of a frame inherit tables filled by earlier launches
+    const u32 fill = block == 0 ? 0u : 0xFFFFFFFFu;
+    for (u32 i = lane; i < wordsL + wordsS; i += 64) W.bmL[i] = fill;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  }
+  u32 rep[3] = {F.st->rep[0], F.st->rep[1], F.st->rep[2]};
+  u32 lastLL, nseq = 0;
+  const u32 ib = 32 - __builtin_clz(F.fsize - 1);      // bits for position+1 < fsize (fsize >= 7 here)
+  switch (F.P->minMatch) {
+    case 5: lastLL = mf_dfast_lean<5>(*F.P, F.hashT, F.chainT, F.src, F.bs, F.be, rep, F.seqs, &nseq, W, lane, ib); break;
+    case 6: lastLL = mf_dfast_lean<6>(*F.P, F.hashT, F.chainT, F.src, F.bs, F.be, rep, F.seqs, &nseq, W, lane, ib); break;
+    case 7: lastLL = mf_dfast_lean<7>(*F.P, F.hashT, F.chainT, F.src, F.bs, F.be, rep, F.seqs, &nseq, W, lane, ib); break;
+    default: lastLL = mf_dfast_lean<4>(*F.P, F.hashT, F.chainT, F.src, F.bs, F.be, rep, F.seqs, &nseq, W, lane, ib); break;
+  }
+  if (lane == 0) {
+    F.bo->nbSeq = nseq; F.bo->lastLL = lastLL; F.bo->skip = 0;
+    F.bo->rep[0] = rep[0]; F.bo->rep[1] = rep[1]; F.bo->rep[2] = rep[2];
+  }
+#ifdef ZRA_MF_PROFILE
+  __builtin_amdgcn_s_waitcnt(0);
+  if (lane == 0) { atomicAdd(&zra_mf_prof[21], __builtin_amdgcn_s_memtime() - kt0_); atomicAdd(&zra_mf_prof[22], 1ull); }
+#endif
+}
+
+// Match finder for the other strategies (fast, greedy, lazy, lazy2: one lane walks the parse) and, with ZRA_MF_TUNE=7, the
+// first window-resolve dfast formulation (kept for A/B measurements). `only` = 0xFFFFFFFF: every frame of the batch;
+// otherwise just that frame (the short last frame whose strategy differs from the batch's).
+extern "C" __global__ void __launch_bounds__(64)
+zra_mf_kernel(ZraEncArgs a, u32 block, u32 only) {
+  const int lane = threadIdx.x;
+  if (only != 0xFFFFFFFFu && blockIdx.x != only) return;
+  MfFrame F;
+  if (!mf_frame_setup(a, block, lane, F)) return;
+  const ZraEncParams& P = *F.P;
+  const u8* src = F.src; ZraEncFrameState* st = F.st; ZraEncBlockOut* bo = F.bo;
+  u32* hashT = F.hashT; u32* chainT = F.chainT; u64* seqs = F.seqs;
+  const u32 bs = F.bs, be = F.be;
   u32 rep[3] = {st->rep[0], st->rep[1], st->rep[2]};
   u32 lastLL, nseq = 0;
   if (P.strategy == 2) {
-    __shared__ u32 dupL[512], dupS[512];
+    __shared__ u32 dupAll[1024];
+    u32* const dupL = dupAll; u32* const dupS = dupAll + 512;
     for (int i = lane; i < 512; i += 64) { dupL[i] = 0; dupS[i] = 0; }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-    const u32 wcap = (a.mfTune >= 8 && a.mfTune <= 64 && a.mfTune != 9) ? a.mfTune : 64u;   // window width (bring-up knob ZRA_MF_TUNE=8..64)
-    if (a.mfTune == 9) {                             // previous formulation (one batch per sequence), kept for A/B measurements
-      if (tagged) lastLL = mf_dfast_wave<u32, true>(P, hashT, chainT, src, bs, be, rep, seqs, &nseq, dupL, dupS, lane, 0);
-      else lastLL = mf_dfast_wave<u32, false>(P, hashT, chainT, src, bs, be, rep, seqs, &nseq, dupL, dupS, lane, 0);
-    } else if (tagged) lastLL = mf_dfast_window<u32, true>(P, hashT, chainT, src, bs, be, rep, seqs, &nseq, dupL, dupS, lane, wcap);
+    const u32 wcap = (a.mfTune >= 8 && a.mfTune <= 64) ? a.mfTune : 64u;   // window width (bring-up knob)
+    if (F.fsize <= 65536) lastLL = mf_dfast_window<u32, true>(P, hashT, chainT, src, bs, be, rep, seqs, &nseq, dupL, dupS, lane, wcap);
     else lastLL = mf_dfast_window<u32, false>(P, hashT, chainT, src, bs, be, rep, seqs, &nseq, dupL, dupS, lane, wcap);
     if (lane == 0) {
       bo->nbSeq = nseq; bo->lastLL = lastLL; bo->skip = 0;
@@ -655,3 +853,11 @@ zra_mf_kernel(ZraEncArgs a, u32 block) {
   bo->nbSeq = E.n; bo->lastLL = lastLL;
   bo->rep[0] = rep[0]; bo->rep[1] = rep[1]; bo->rep[2] = rep[2];   // confirmed by stage 2 only if the block is emitted compressed
 }
+
+#ifdef ZRA_MF_PROFILE
+// bring-up only: copies (and optionally clears) the phase counters
+extern "C" __attribute__((visibility("default"))) void ZraHipDebugReadMfProfile(unsigned long long* out24, int reset) {
+  (void)hipMemcpyFromSymbol(out24, HIP_SYMBOL(zra_mf_prof), sizeof(unsigned long long) * 24);
+  if (reset) { unsigned long long z[24] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(zra_mf_prof), z, sizeof(z)); }
+}
+#endif

@@ -40,6 +40,9 @@ class Engine {
   double last_kernel_ms() const { return lastKernelMs_; }
   // HIP-event timings of the last call on the engine's stream: {mf ms, mf launches, entropy ms, entropy launches, decode ms, decode launches}
   void kernel_stats(double out[6]) const { for (int i = 0; i < 6; i++) out[i] = kstats_[i]; }
+  // bring-up: sequences {ll | ml<<20 | offVal<<40} the match finder left in scratch context 0 for frame `frame` of the LAST batch
+  // (last block of the frame); returns the count, meta = {nbSeq, lastLL, skip}
+  uint32_t debug_read_seqs(uint32_t frame, uint64_t* out, uint32_t cap, uint32_t meta[3]);
 
   // ---- decode
   // Decode nFrames frames described by device job arrays. Synchronises and returns the first failing frame's code.
@@ -93,6 +96,7 @@ class Engine {
   hipStream_t stream2_ = nullptr;          // entropy stage / gather stream (overlaps the match finder on stream_)
   std::vector<hipEvent_t> evPool_;
   DevBuf hostIn_, hostOut_;
+  uint64_t dbgSeqStride_ = 0; uint32_t dbgB_ = 0;
   friend struct EncodeImpl;
 };
 
