@@ -266,7 +266,7 @@ def main():
         moved = (N + q * qb) * world
         value = moved / GiB / (elapsed / args.steps)
         ratio = N / max(1, (arc_size if world == 1 else arc_size / world))
-        # roofline of the dominant kernel = the match finder (zra_mf_kernel): per-launch duration from HIP events recorded on the
+        # roofline of the dominant kernel = the match finder (zra_mf_dfast_kernel at levels 3-4): per-launch duration from HIP events recorded on the
         # engine's stream around each launch; algorithmic bytes = N_in + C_out of the frames of that launch (SURVEY §8d:
         # 65536*(1+1/ratio) per 64 KiB frame x frames per launch)
         st = mf_ms[-1] if mf_ms else dict(mf_ms=0, mf_launches=0, ent_ms=0, ent_launches=0)
@@ -299,7 +299,7 @@ def main():
             "compress_gibs": round(N * world / GiB / (np.mean(comp_ms) / 1e3), 3),
             "ra_gibs_returned": round(q * qb * world / GiB / (np.mean(ra_ms) / 1e3), 3),
             "ra_us_per_query": round(np.mean(ra_ms) * 1e3 / q, 3),
-            "roofline": {"bound": "hbm", "kernel": "zra_mf_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "zra_mf_dfast_kernel" if args.level in (3, 4) else "zra_mf_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "frac_of_measured_6290": round(achieved / 6290.0, 5), "traffic": traffic,
                          "launch_ms": round(mf_launch_ms, 3), "launches_per_call": launches, "algorithmic_bytes_per_launch": int(alg_per_launch),
                          "other_kernels_launch_ms": {"zra_entropy_kernel": round(ent_launch_ms, 3), "zra_decode_frames_kernel": round(dec_launch_ms, 3)}},

@@ -1,6 +1,7 @@
 // zra_amd — host side of the ENCODE path: zstd 1.4.9 parameter selection, scratch layout in HBM, the
 // block-round driver (A.4.2) over batches of frames, and the seek-table build (device scan + gather).
 // Replaces the loop body of the reference's CompressBuffer / Compressor::Compress (zra.cpp:216-225, 329-338).
+#include <cstdio>
 #include "zra_engine.h"
 #include "zra_dev.h"
 #include "zra_format.h"
@@ -9,7 +10,7 @@
 #include <cstring>
 #include <vector>
 
-extern "C" __global__ void zra_mf_kernel(ZraEncArgs a, uint32_t block, uint32_t only);
+extern "C" __global__ void zra_mf_kernel(ZraEncArgs a, uint32_t block, uint32_t only, uint32_t onlySlot);
 extern "C" __global__ void zra_mf_dfast_kernel(ZraEncArgs a, uint32_t block);
 extern "C" __global__ void zra_entropy_kernel(ZraEncArgs a, uint32_t block);
 
@@ -133,6 +134,19 @@ Status Engine::compress_impl(const uint8_t* dIn, size_t inSize, uint8_t* dBody, 
   const uint32_t maxBlocksPerFrame = (std::min<uint64_t>(frameSize, inSize) + std::min(full.blockSize, tail.blockSize) - 1) / std::min(full.blockSize, tail.blockSize);
   const uint64_t slotStride = (zra_fmt::compress_bound(frameSize) + 1024 + 4 * (uint64_t)maxBlocksPerFrame + 15) & ~15ull;
   const uint64_t perFrame = tableWords * 4 + seqStride * 8 + litStride + slotStride + sizeof(ZraEncFrameState) + sizeof(ZraEncBlockOut) + 64;
+  // ---------------------------------------------------------------------------------------------------------------------
+  // Persistent pipeline (dfast, single-block frames: levels 3-4 up to 128 KiB frames — the headline configuration).
+  // ONE match-finder launch per super-batch: `nSlots` resident waves pull frames from a queue, each wave owns one hash-table
+  // slot (tables are per resident wave, not per frame). Finished frames are counted per sub-batch; the entropy stage, scan and
+  // gather of a sub-batch are released on stream B by hipStreamWaitValue32 on that counter — no per-batch launch tails in the
+  // DRAM-bound match finder, and the entropy stage runs under it in small pieces.
+  {
+    const char* tuneEnv = std::getenv("ZRA_MF_TUNE");
+    const bool persist = maxBlocksPerFrame == 1 && full.strategy == 2 && !(tuneEnv && std::atoi(tuneEnv) == 7) && !std::getenv("ZRA_MF_NOPERSIST");
+    if (persist)
+      return compress_persistent(dIn, inSize, dBody, bodyBase0, dEntries, dSizes, bodySize, frameSize, checksum, full, tail,
+                                 tableWords, seqStride, litStride, slotStride);
+  }
   // Two scratch contexts: the match finder of batch k+1 (stream A) overlaps the entropy stage + gather of batch k (stream B);
   // both kernels are latency-bound, so they share the CUs almost for free. 8 GiB of scratch per context.
   const uint64_t budget = 8ull << 30;
@@ -201,16 +215,16 @@ Status Engine::compress_impl(const uint8_t* dIn, size_t inSize, uint8_t* dBody, 
         const bool hasTail = tailSize && f0 + nb == nFramesTotal;
         if (full.strategy == 2 && a.mfTune != 7) {
           // LDS geometry of the bucket filter: 1 bit per 2^shL long-table buckets, 1 bit per 2^shS short-table buckets, and the
-          // duplicate-detection slots. Default 2 KiB + 4 KiB + 4 KiB at hashLog 16 / chainLog 15 (16 frames per CU).
-          uint32_t shL = 1, shS = 0, dupLog = 10;
-          if (const char* f = std::getenv("ZRA_MF_FILTER")) { unsigned x = 1, y = 0, z = 10; if (std::sscanf(f, "%u,%u,%u", &x, &y, &z) >= 1) { shL = x & 15; shS = y & 15; dupLog = z & 15; } }
+          // duplicate-detection slots. Default 2 KiB + 4 KiB + 2 KiB at hashLog 16 / chainLog 15 (20 frames per CU); sweep in profiles/r01_mf_occupancy_sweep.log.
+          uint32_t shL = 1, shS = 1, dupLog = 10;
+          if (const char* f = std::getenv("ZRA_MF_FILTER")) { unsigned x = 1, y = 1, z = 10; if (std::sscanf(f, "%u,%u,%u", &x, &y, &z) >= 1) { shL = x & 15; shS = y & 15; dupLog = z & 15; } }
           a.mfFilter = shL | (shS << 4) | (dupLog << 8);
           const uint32_t hl = std::max(full.hashLog, tail.hashLog), cl = std::max(full.chainLog, tail.chainLog);
           const size_t filterBytes = (2u << dupLog) + (((size_t)1 << hl) >> shL) / 8 + (((size_t)1 << cl) >> shS) / 8 + 64;
           hipLaunchKernelGGL(zra_mf_dfast_kernel, dim3(nb), dim3(64), filterBytes + dynLds, stream_, a, blk);
-          if (hasTail && tail.strategy != 2) hipLaunchKernelGGL(zra_mf_kernel, dim3(nb), dim3(64), 0, stream_, a, blk, (uint32_t)(nb - 1));
+          if (hasTail && tail.strategy != 2) hipLaunchKernelGGL(zra_mf_kernel, dim3(1), dim3(64), 0, stream_, a, blk, (uint32_t)(nb - 1), (uint32_t)(nb - 1));
         } else {
-          hipLaunchKernelGGL(zra_mf_kernel, dim3(nb), dim3(64), dynLds, stream_, a, blk, 0xFFFFFFFFu);
+          hipLaunchKernelGGL(zra_mf_kernel, dim3(nb), dim3(64), dynLds, stream_, a, blk, 0xFFFFFFFFu, 0u);
         }
       }
       HIPCHK(hipEventRecord(m1, stream_));
@@ -242,6 +256,138 @@ Status Engine::compress_impl(const uint8_t* dIn, size_t inSize, uint8_t* dBody, 
   for (auto& sp : mfSpans) { float m = 0; if (hipEventElapsedTime(&m, sp.first, sp.second) == hipSuccess) { kstats_[0] += m; kstats_[1] += 1; kernelMs += m; } }
   for (auto& sp : entSpans) { float m = 0; if (hipEventElapsedTime(&m, sp.first, sp.second) == hipSuccess) { kstats_[2] += m; kstats_[3] += 1; } }
   lastKernelMs_ = kernelMs;
+  *bodySize = total;
+  return ok();
+}
+
+Status Engine::compress_persistent(const uint8_t* dIn, size_t inSize, uint8_t* dBody, uint64_t bodyBase0, uint8_t* dEntries, uint64_t* dSizes,
+                                   size_t* bodySize, uint32_t frameSize, bool checksum, const ZraEncParams& full, const ZraEncParams& tail,
+                                   uint64_t tableWords, uint64_t seqStride, uint64_t litStride, uint64_t slotStride) {
+  const uint64_t nFramesTotal = (inSize + frameSize - 1) / frameSize;
+  const size_t tailSize = inSize % frameSize;
+  static const uint32_t wavesPerCU = std::getenv("ZRA_MF_WAVES") ? (uint32_t)std::atoi(std::getenv("ZRA_MF_WAVES")) : 16u;
+  static const uint32_t SB = std::getenv("ZRA_ENC_SUB") ? (uint32_t)std::atoi(std::getenv("ZRA_ENC_SUB")) : 8192u;   // frames per sub-batch
+  const uint32_t nSlots = (uint32_t)std::min<uint64_t>((uint64_t)numCUs_ * wavesPerCU, nFramesTotal);
+  // per-frame scratch that lives from the match finder to the entropy stage: sequences + block record + checksum + size/offset
+  const uint64_t perFrame = seqStride * 8 + sizeof(ZraEncFrameState) + sizeof(ZraEncBlockOut) + 4 + 16 + 8;
+  const uint64_t budget = 24ull << 30;
+  uint64_t SBIG = std::max<uint64_t>(1, std::min<uint64_t>(nFramesTotal, budget / perFrame));
+  if (SBIG > SB) SBIG -= SBIG % SB;
+  const int nCtx = nFramesTotal > SBIG ? 2 : 1;
+  const uint64_t nSuper = (nFramesTotal + SBIG - 1) / SBIG;
+  const uint64_t subsPerSuper = (SBIG + SB - 1) / SB;
+  EncCtx& sh = encCtx_[0];                       // shared: table slots, and the literal / slot buffers of ONE sub-batch (stream B is in order)
+  const uint64_t subFrames = std::min<uint64_t>(SB, SBIG);
+  if (!sh.tables.reserve((size_t)nSlots * tableWords * 4) || !sh.lits.reserve(subFrames * litStride) || !sh.slots.reserve(subFrames * slotStride)) return zerr(64);
+  for (int c = 0; c < nCtx; c++) {
+    EncCtx& x = encCtx_[c];
+    if (!x.seqs.reserve(SBIG * seqStride * 8) || !x.misc.reserve(SBIG * (sizeof(ZraEncFrameState) + sizeof(ZraEncBlockOut))) ||
+        !x.ck.reserve((size_t)SBIG * 4) || !x.sizes.reserve((size_t)SBIG * 16))
+      return zerr(64);
+  }
+  // counters: [u64 running offset][u32 queue per super-batch][u32 done per sub-batch]
+  const size_t cntBytes = 16 + 4 * (size_t)(nSuper + nSuper * subsPerSuper + 4);
+  if (!encScan_.reserve(cntBytes)) return zerr(64);
+  uint64_t* dRunning = encScan_.as<uint64_t>();
+  uint32_t* dQueue = (uint32_t*)(encScan_.as<uint8_t>() + 16);
+  uint32_t* dDone = dQueue + nSuper;
+  HIPCHK(hipMemsetAsync(encScan_.as<uint8_t>(), 0, cntBytes, stream_));
+
+  ZraEncArgs base{};
+  base.in = dIn; base.inSize = inSize; base.frameSize = frameSize; base.checksum = checksum ? 1 : 0;
+  base.full = full; base.tail = tail;
+  { const char* t = std::getenv("ZRA_MF_TUNE"); base.mfTune = t ? (uint32_t)std::atoi(t) : 0u; }
+  dbgSeqStride_ = seqStride; dbgB_ = (uint32_t)SBIG;
+  base.tableStride = tableWords; base.seqStride = seqStride; base.litStride = litStride; base.slotStride = slotStride;
+  // LDS geometry of the bucket filter: 1 bit per 2^shL long-table buckets, 1 bit per 2^shS short-table buckets, and the
+  // duplicate-detection slots (2 KiB + 4 KiB + 2 KiB at hashLog 16 / chainLog 15; sweep in profiles/r01_mf_occupancy_sweep.log)
+  uint32_t shL = 1, shS = 1, dupLog = 10;
+  if (const char* f = std::getenv("ZRA_MF_FILTER")) { unsigned x = 1, y = 1, z = 10; if (std::sscanf(f, "%u,%u,%u", &x, &y, &z) >= 1) { shL = x & 15; shS = y & 15; dupLog = z & 15; } }
+  base.mfFilter = shL | (shS << 4) | (dupLog << 8);
+  const uint32_t hl = std::max(full.hashLog, tail.hashLog), cl = std::max(full.chainLog, tail.chainLog);
+  const size_t filterBytes = (2u << dupLog) + (((size_t)1 << hl) >> shL) / 8 + (((size_t)1 << cl) >> shS) / 8 + 64;
+
+  size_t evNext = 0;
+  auto ev = [&]() -> hipEvent_t {
+    if (evNext == evPool_.size()) { hipEvent_t e = nullptr; if (hipEventCreate(&e) != hipSuccess) return nullptr; evPool_.push_back(e); }
+    return evPool_[evNext++];
+  };
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> mfSpans, entSpans;
+  hipEvent_t superDone[2] = {nullptr, nullptr};
+  // stream B starts after the counters are cleared and after whatever the caller queued on the engine stream
+  { hipEvent_t e0 = ev(); if (!e0) return zerr(1); HIPCHK(hipEventRecord(e0, stream_)); HIPCHK(hipStreamWaitEvent(stream2_, e0, 0)); }
+
+  for (uint64_t S = 0; S < nSuper; S++) {
+    const uint64_t F0 = S * SBIG;
+    const uint32_t n = (uint32_t)std::min<uint64_t>(SBIG, nFramesTotal - F0);
+    const int c = (int)(S % nCtx);
+    EncCtx& x = encCtx_[c];
+    ZraEncArgs a = base;
+    a.firstFrame = (uint32_t)F0; a.nFrames = n;
+    a.tables = sh.tables.as<uint32_t>(); a.lits = sh.lits.as<uint8_t>(); a.slots = sh.slots.as<uint8_t>();
+    a.seqs = x.seqs.as<uint64_t>();
+    a.state = x.misc.as<ZraEncFrameState>();
+    a.blockOut = (ZraEncBlockOut*)(x.misc.as<uint8_t>() + (size_t)SBIG * sizeof(ZraEncFrameState));
+    a.contentCk = x.ck.as<uint32_t>();
+    a.sizes = x.sizes.as<uint64_t>();
+    a.mfQueue = dQueue + S; a.mfDone = dDone + S * subsPerSuper; a.mfSubFrames = SB;
+    // the context's per-frame scratch is free once the last sub-batch that used it has been gathered
+    if (superDone[c]) HIPCHK(hipStreamWaitEvent(stream_, superDone[c], 0));
+    hipEvent_t m0 = ev(), m1 = ev();
+    if (!m0 || !m1) return zerr(1);
+    HIPCHK(hipEventRecord(m0, stream_));
+    hipLaunchKernelGGL(zra_mf_dfast_kernel, dim3(std::min<uint32_t>(n, nSlots)), dim3(64), filterBytes, stream_, a, 0u);
+    HIPCHK(hipEventRecord(m1, stream_));
+    mfSpans.push_back({m0, m1});
+    // a short last frame whose cparams select another strategy: parsed by the generic kernel (table slot 0 is free by then)
+    const bool oddTail = tailSize && F0 + n == nFramesTotal && tail.strategy != 2;
+    hipEvent_t tailEv = nullptr;
+    if (oddTail) {
+      ZraEncArgs at = a; at.mfQueue = nullptr;
+      hipLaunchKernelGGL(zra_mf_kernel, dim3(1), dim3(64), 0, stream_, at, 0u, (uint32_t)(n - 1), 0u);
+      tailEv = ev(); if (!tailEv) return zerr(1);
+      HIPCHK(hipEventRecord(tailEv, stream_));
+    }
+    if (checksum)
+      hipLaunchKernelGGL(zra_content_ck_kernel, dim3((n * 4 + 255) / 256), dim3(256), 0, stream2_, dIn, (u64)inSize, frameSize, (u32)F0, n, a.contentCk);
+    const uint32_t nSub = (n + SB - 1) / SB;
+    for (uint32_t j = 0; j < nSub; j++) {
+      const uint32_t j0 = j * SB, nbj = std::min<uint32_t>(SB, n - j0);
+      const bool hasOdd = oddTail && j == nSub - 1;
+      HIPCHK(hipStreamWaitValue32(stream2_, a.mfDone + j, nbj - (hasOdd ? 1u : 0u), hipStreamWaitValueGte, 0xFFFFFFFFu));
+      if (hasOdd) HIPCHK(hipStreamWaitEvent(stream2_, tailEv, 0));
+      ZraEncArgs aj = a;
+      aj.firstFrame = (uint32_t)(F0 + j0); aj.nFrames = nbj;
+      aj.seqs = a.seqs + (size_t)j0 * seqStride; aj.state = a.state + j0; aj.blockOut = a.blockOut + j0;
+      aj.contentCk = a.contentCk + j0; aj.sizes = a.sizes + j0;
+      uint64_t* dOffsets = x.sizes.as<uint64_t>() + SBIG + j0;
+      hipEvent_t e0 = ev(), e1 = ev(); if (!e0 || !e1) return zerr(1);
+      HIPCHK(hipEventRecord(e0, stream2_));
+      hipLaunchKernelGGL(zra_entropy_kernel, dim3(nbj), dim3(256), 0, stream2_, aj, 0u);
+      HIPCHK(hipEventRecord(e1, stream2_));
+      entSpans.push_back({e0, e1});
+      hipLaunchKernelGGL(zra_scan_sizes_kernel, dim3(1), dim3(1024), 0, stream2_, aj.sizes, nbj, dOffsets, dRunning);
+      hipLaunchKernelGGL(zra_gather_frames_kernel, dim3(nbj), dim3(256), 0, stream2_, aj.slots, slotStride, aj.sizes, dOffsets, dBody,
+                         bodyBase0, dEntries ? dEntries : nullptr, (u32)(F0 + j0), dSizes);
+    }
+    hipEvent_t done = ev(); if (!done) return zerr(1);
+    HIPCHK(hipEventRecord(done, stream2_));
+    superDone[c] = done;
+  }
+  uint64_t total = 0;
+  HIPCHK(hipMemcpyAsync(&total, dRunning, 8, hipMemcpyDeviceToHost, stream2_));
+  HIPCHK(hipStreamSynchronize(stream2_));
+  HIPCHK(hipStreamSynchronize(stream_));
+  HIPCHK(hipGetLastError());
+  double kernelMs = 0;
+  kstats_[0] = kstats_[1] = kstats_[2] = kstats_[3] = 0;
+  for (auto& sp : mfSpans) { float m = 0; if (hipEventElapsedTime(&m, sp.first, sp.second) == hipSuccess) { kstats_[0] += m; kstats_[1] += 1; kernelMs += m; } }
+  for (auto& sp : entSpans) { float m = 0; if (hipEventElapsedTime(&m, sp.first, sp.second) == hipSuccess) { kstats_[2] += m; kstats_[3] += 1; } }
+  lastKernelMs_ = kernelMs;
+  if (std::getenv("ZRA_ENC_TRACE")) {                 // bring-up: timeline relative to the first match-finder launch
+    for (auto& sp : mfSpans) { float a0 = 0, a1 = 0; hipEventElapsedTime(&a0, mfSpans[0].first, sp.first); hipEventElapsedTime(&a1, mfSpans[0].first, sp.second); std::fprintf(stderr, "mf  %8.2f .. %8.2f ms\n", a0, a1); }
+    for (auto& sp : entSpans) { float a0 = 0, a1 = 0; hipEventElapsedTime(&a0, mfSpans[0].first, sp.first); hipEventElapsedTime(&a1, mfSpans[0].first, sp.second); std::fprintf(stderr, "ent %8.2f .. %8.2f ms\n", a0, a1); }
+  }
   *bodySize = total;
   return ok();
 }

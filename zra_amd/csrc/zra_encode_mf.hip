@@ -718,8 +718,7 @@ struct MfFrame {
   u32 fsize, bs, be;
 };
 // returns false when this workgroup has nothing to parse (block beyond the frame, or a block too small to compress)
-__device__ __forceinline__ bool mf_frame_setup(const ZraEncArgs& a, u32 block, int lane, MfFrame& F) {
-  const u32 f = blockIdx.x;
+__device__ __forceinline__ bool mf_frame_setup(const ZraEncArgs& a, u32 block, int lane, MfFrame& F, u32 f, u32 tableSlot) {
   const u64 fstart = (u64)(a.firstFrame + f) * a.frameSize;
   const u64 remaining = a.inSize - fstart;
   F.fsize = (u32)(remaining < a.frameSize ? remaining : a.frameSize);
@@ -730,7 +729,7 @@ __device__ __forceinline__ bool mf_frame_setup(const ZraEncArgs& a, u32 block, i
   F.be = min(F.fsize, F.bs + blockSize);
   F.src = a.in + fstart;
   F.st = &a.state[f];
-  F.hashT = a.tables + (size_t)f * a.tableStride;
+  F.hashT = a.tables + (size_t)tableSlot * a.tableStride;
   F.chainT = F.hashT + ((size_t)1 << F.P->hashLog);
   F.bo = &a.blockOut[f];
   F.seqs = a.seqs + (size_t)f * a.seqStride;
@@ -757,62 +756,80 @@ __device__ __forceinline__ bool mf_frame_setup(const ZraEncArgs& a, u32 block, i
 extern "C" __global__ void __launch_bounds__(64)
 zra_mf_dfast_kernel(ZraEncArgs a, u32 block) {
   const int lane = threadIdx.x;
-  MfFrame F;
-#ifdef ZRA_MF_PROFILE
-  const u64 kt0_ = __builtin_amdgcn_s_memtime();
-#endif
-  if (a.full.strategy != a.tail.strategy && blockIdx.x == a.nFrames - 1) {
-    // is this the short last frame of the whole input? then zra_mf_kernel handles it
-    const u64 fstart = (u64)(a.firstFrame + blockIdx.x) * a.frameSize;
-    if (a.inSize - fstart < a.frameSize) return;
-  }
-  if (!mf_frame_setup(a, block, lane, F)) return;
-#ifdef ZRA_MF_PROFILE
-  __builtin_amdgcn_s_waitcnt(0);
-  if (lane == 0) atomicAdd(&zra_mf_prof[20], __builtin_amdgcn_s_memtime() - kt0_);
-#endif
   // dynamic LDS: [dup bytes 2 x dupSlots][filter L][filter S]; geometry chosen by the host (a.mfFilter: shL | shS<<4 | log2(dupSlots)<<8)
   extern __shared__ u32 dynLds[];
   LeanLds W;
   W.shL = a.mfFilter & 15; W.shS = (a.mfFilter >> 4) & 15; W.dupSlots = 1u << ((a.mfFilter >> 8) & 15);
   W.dup = (u8*)dynLds;
   W.bmL = dynLds + (2 * W.dupSlots) / 4;
-  const u32 wordsL = ((1u << F.P->hashLog) >> W.shL) / 32, wordsS = ((1u << F.P->chainLog) >> W.shS) / 32;
-  W.bmS = W.bmL + wordsL;
-  {
-    // block 0 starts with empty tables (all bits clear); later blocks of a frame inherit tables filled by earlier launches
-    const u32 fill = block == 0 ? 0u : 0xFFFFFFFFu;
-    for (u32 i = lane; i < wordsL + wordsS; i += 64) W.bmL[i] = fill;
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-  }
-  u32 rep[3] = {F.st->rep[0], F.st->rep[1], F.st->rep[2]};
-  u32 lastLL, nseq = 0;
-  const u32 ib = 32 - __builtin_clz(F.fsize - 1);      // bits for position+1 < fsize (fsize >= 7 here)
-  switch (F.P->minMatch) {
-    case 5: lastLL = mf_dfast_lean<5>(*F.P, F.hashT, F.chainT, F.src, F.bs, F.be, rep, F.seqs, &nseq, W, lane, ib); break;
-    case 6: lastLL = mf_dfast_lean<6>(*F.P, F.hashT, F.chainT, F.src, F.bs, F.be, rep, F.seqs, &nseq, W, lane, ib); break;
-    case 7: lastLL = mf_dfast_lean<7>(*F.P, F.hashT, F.chainT, F.src, F.bs, F.be, rep, F.seqs, &nseq, W, lane, ib); break;
-    default: lastLL = mf_dfast_lean<4>(*F.P, F.hashT, F.chainT, F.src, F.bs, F.be, rep, F.seqs, &nseq, W, lane, ib); break;
-  }
-  if (lane == 0) {
-    F.bo->nbSeq = nseq; F.bo->lastLL = lastLL; F.bo->skip = 0;
-    F.bo->rep[0] = rep[0]; F.bo->rep[1] = rep[1]; F.bo->rep[2] = rep[2];
-  }
+  const bool persistent = a.mfQueue != nullptr;
+  for (;;) {
+    u32 f = blockIdx.x;
+    if (persistent) {
+      u32 t = 0;
+      if (lane == 0) t = atomicAdd(a.mfQueue, 1u);
+      f = rfl(t);
+      if (f >= a.nFrames) return;
+    }
 #ifdef ZRA_MF_PROFILE
-  __builtin_amdgcn_s_waitcnt(0);
-  if (lane == 0) { atomicAdd(&zra_mf_prof[21], __builtin_amdgcn_s_memtime() - kt0_); atomicAdd(&zra_mf_prof[22], 1ull); }
+    const u64 kt0_ = __builtin_amdgcn_s_memtime();
 #endif
+    bool mine = true;
+    if (a.full.strategy != a.tail.strategy && f == a.nFrames - 1) {
+      // the short last frame of the whole input with another strategy is parsed by zra_mf_kernel (and signalled by the host)
+      const u64 fstart = (u64)(a.firstFrame + f) * a.frameSize;
+      if (a.inSize - fstart < a.frameSize) mine = false;
+    }
+    MfFrame F;
+    if (mine && mf_frame_setup(a, block, lane, F, f, persistent ? blockIdx.x : f)) {
+#ifdef ZRA_MF_PROFILE
+      __builtin_amdgcn_s_waitcnt(0);
+      if (lane == 0) atomicAdd(&zra_mf_prof[20], __builtin_amdgcn_s_memtime() - kt0_);
+#endif
+      const u32 wordsL = ((1u << F.P->hashLog) >> W.shL) / 32, wordsS = ((1u << F.P->chainLog) >> W.shS) / 32;
+      W.bmS = W.bmL + wordsL;
+      {
+        // block 0 starts with empty tables (all bits clear); later blocks of a frame inherit tables filled by earlier launches
+        const u32 fill = block == 0 ? 0u : 0xFFFFFFFFu;
+        for (u32 i = lane; i < wordsL + wordsS; i += 64) W.bmL[i] = fill;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+      }
+      u32 rep[3] = {F.st->rep[0], F.st->rep[1], F.st->rep[2]};
+      u32 lastLL, nseq = 0;
+      const u32 ib = 32 - __builtin_clz(F.fsize - 1);  // bits for position+1 < fsize (fsize >= 7 here)
+      switch (F.P->minMatch) {
+        case 5: lastLL = mf_dfast_lean<5>(*F.P, F.hashT, F.chainT, F.src, F.bs, F.be, rep, F.seqs, &nseq, W, lane, ib); break;
+        case 6: lastLL = mf_dfast_lean<6>(*F.P, F.hashT, F.chainT, F.src, F.bs, F.be, rep, F.seqs, &nseq, W, lane, ib); break;
+        case 7: lastLL = mf_dfast_lean<7>(*F.P, F.hashT, F.chainT, F.src, F.bs, F.be, rep, F.seqs, &nseq, W, lane, ib); break;
+        default: lastLL = mf_dfast_lean<4>(*F.P, F.hashT, F.chainT, F.src, F.bs, F.be, rep, F.seqs, &nseq, W, lane, ib); break;
+      }
+      if (lane == 0) {
+        F.bo->nbSeq = nseq; F.bo->lastLL = lastLL; F.bo->skip = 0;
+        F.bo->rep[0] = rep[0]; F.bo->rep[1] = rep[1]; F.bo->rep[2] = rep[2];
+      }
+#ifdef ZRA_MF_PROFILE
+      __builtin_amdgcn_s_waitcnt(0);
+      if (lane == 0) { atomicAdd(&zra_mf_prof[21], __builtin_amdgcn_s_memtime() - kt0_); atomicAdd(&zra_mf_prof[22], 1ull); }
+#endif
+    }
+    if (!persistent) return;
+    if (mine) {
+      // publish: every store of this frame (sequences, block record) is visible device-wide before the counter moves
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      if (lane == 0) atomicAdd(&a.mfDone[f / a.mfSubFrames], 1u);
+    }
+  }
 }
 
 // Match finder for the other strategies (fast, greedy, lazy, lazy2: one lane walks the parse) and, with ZRA_MF_TUNE=7, the
 // first window-resolve dfast formulation (kept for A/B measurements). `only` = 0xFFFFFFFF: every frame of the batch;
-// otherwise just that frame (the short last frame whose strategy differs from the batch's).
+// otherwise just that frame (the short last frame whose strategy differs from the batch's), launched as one workgroup.
 extern "C" __global__ void __launch_bounds__(64)
-zra_mf_kernel(ZraEncArgs a, u32 block, u32 only) {
+zra_mf_kernel(ZraEncArgs a, u32 block, u32 only, u32 onlySlot) {
   const int lane = threadIdx.x;
-  if (only != 0xFFFFFFFFu && blockIdx.x != only) return;
+  const bool all = only == 0xFFFFFFFFu;             // otherwise a single-workgroup launch for frame `only` on table slot `onlySlot`
   MfFrame F;
-  if (!mf_frame_setup(a, block, lane, F)) return;
+  if (!mf_frame_setup(a, block, lane, F, all ? blockIdx.x : only, all ? blockIdx.x : onlySlot)) return;
   const ZraEncParams& P = *F.P;
   const u8* src = F.src; ZraEncFrameState* st = F.st; ZraEncBlockOut* bo = F.bo;
   u32* hashT = F.hashT; u32* chainT = F.chainT; u64* seqs = F.seqs;

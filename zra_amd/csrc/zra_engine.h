@@ -62,6 +62,9 @@ class Engine {
   // Compress frames of `frameSize` from dIn (inSize bytes) into a packed body at dBody; per-frame sizes (u64) to dSizes.
   Status compress_frames(const uint8_t* dIn, size_t inSize, uint8_t* dBody, uint64_t* dSizes, size_t* bodySize,
                          int level, uint32_t frameSize, bool checksum);
+  Status compress_persistent(const uint8_t* dIn, size_t inSize, uint8_t* dBody, uint64_t bodyBase0, uint8_t* dEntries, uint64_t* dSizes,
+                             size_t* bodySize, uint32_t frameSize, bool checksum, const struct ZraEncParams& full, const struct ZraEncParams& tail,
+                             uint64_t tableWords, uint64_t seqStride, uint64_t litStride, uint64_t slotStride);
   Status compress_impl(const uint8_t* dIn, size_t inSize, uint8_t* dBody, uint64_t bodyBase0, uint8_t* dEntries, uint64_t* dSizes,
                        size_t* bodySize, int level, uint32_t frameSize, bool checksum);
   // Full archive (header + table + body) on the device.

@@ -80,4 +80,11 @@ struct ZraEncArgs {
   ZraEncBlockOut* blockOut;// [nFrames]
   uint32_t* contentCk;     // [nFrames] XXH64 low 32 bits of each frame's input
   uint64_t* sizes;         // [nFrames] final frame sizes (written with the last block)
+  // persistent match-finder launch (single-block frames): workgroups pull frame indices from `mfQueue`, use the hash-table slot
+  // of their workgroup (tables = nSlots * tableStride) and count finished frames per sub-batch of `mfSubFrames` frames in
+  // mfDone[] (the entropy stage of a sub-batch is released by a stream wait on its counter). mfQueue == nullptr: one workgroup
+  // per frame, tables per frame.
+  uint32_t* mfQueue;
+  uint32_t* mfDone;
+  uint32_t mfSubFrames;
 };
