@@ -35,7 +35,7 @@ static struct {
 int zo_libzstd_load(const char* path) {
   if (Z.h) return 0;
   const char* cands[] = {path, "/opt/conda/lib/libzstd.so.1.4.9", "libzstd.so.1.4.9", "/usr/lib/x86_64-linux-gnu/libzstd.so.1.4.8", "libzstd.so.1", NULL};
-  for (int i = 0; i < 5 && !Z.h; i++) if (cands[i]) Z.h = dlopen(cands[i], RTLD_NOW | RTLD_LOCAL);
+  for (int i = 0; i < 5 && !Z.h; i++) if (cands[i]) Z.h = dlopen(cands[i], RTLD_NOW | RTLD_LOCAL | RTLD_DEEPBIND);   /* DEEPBIND: a profiler's preloaded zstd must not interpose on 1.4.9's own calls */
   if (!Z.h) return -1;
   Z.compress2 = (fn_compress2)dlsym(Z.h, "ZSTD_compress2");
   Z.setparam = (fn_setparam)dlsym(Z.h, "ZSTD_CCtx_setParameter");

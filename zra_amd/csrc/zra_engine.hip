@@ -130,13 +130,7 @@ Status Engine::create(Engine** out, int device) {
   if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete e; return zerr(1); }
   e->numCUs_ = prop.multiProcessorCount;
   if (hipStreamCreateWithFlags(&e->stream_, hipStreamNonBlocking) != hipSuccess) { delete e; return zerr(1); }
-  {
-    // the entropy / gather stream gets the highest priority: its short workgroups take the slots that finishing match-finder
-    // waves free, so a batch's entropy stage completes under the next batch's (DRAM-bound) match finder instead of trailing it
-    int lo = 0, hi = 0;
-    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-    if (hipStreamCreateWithPriority(&e->stream2_, hipStreamNonBlocking, hi) != hipSuccess) { delete e; return zerr(1); }
-  }
+  if (hipStreamCreateWithFlags(&e->stream2_, hipStreamNonBlocking) != hipSuccess) { delete e; return zerr(1); }
   if (hipEventCreate(&e->ev0_) != hipSuccess || hipEventCreate(&e->ev1_) != hipSuccess) { delete e; return zerr(1); }
   for (auto& ev : e->evR_) if (hipEventCreate(&ev) != hipSuccess) { delete e; return zerr(1); }
   *out = e;
