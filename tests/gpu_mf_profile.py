@@ -21,3 +21,11 @@ tot = v[21] / nf
 print("frames %d  total/frame %.0f memtime ticks; clear %.0f" % (nf, tot, v[20] / nf))
 for i, nm in enumerate(names): print("  %-40s %10.0f  %5.1f %%" % (nm, v[i] / nf, 100.0 * v[i] / max(v[21], 1)))
 print("  windows/frame %.0f  seqs/frame %.0f  out-of-window insert loads %.0f  probe loads %.0f  rep-loop seqs %.0f" % (v[12] / nf, v[13] / nf, v[14] / nf, v[15] / nf, v[16] / nf))
+
+if hasattr(lib, "ZraHipDebugReadEntProfile"):
+    eb = (ctypes.c_ulonglong * 16)(); lib.ZraHipDebugReadEntProfile(eb, 0); e = list(eb); ne = max(e[15], 1)
+    en = ["0 literal gather + histogram", "1 huffman decision + tree", "2 literal emit (stream packing)", "3 seq code histograms", "4 FSE table selection/build",
+          "5 tile load", "6 FSE chains (3 lanes)", "7 tile pack + flush", "8 tail"]
+    tot = sum(e[:9])
+    print("entropy kernel: frames %d (two compress calls)  ticks/frame %.0f" % (ne, tot / ne))
+    for i, nm in enumerate(en): print("  %-40s %10.0f  %5.1f %%" % (nm, e[i] / ne, 100.0 * e[i] / max(tot, 1)))

@@ -17,9 +17,11 @@ using namespace zra_dev;
 namespace {
 
 constexpr int ENT_THREADS = 256;
-constexpr int SEQ_TILE = 1024;     // sequences per packing tile (4 per thread)
+constexpr int SEQ_TILE = 512;      // sequences per packing tile
+constexpr int SEQ_PER = SEQ_TILE / ENT_THREADS;   // ... per thread
 constexpr int SYM_TILE = 4096;     // literal symbols per packing tile (16 per thread)
-constexpr int STAGE_WORDS = 4096;  // 16 KiB LDS bit-staging buffer
+constexpr int STAGE_WORDS = 1536;  // 6 KiB LDS bit-staging buffer: 512 sequences x 90 bits, 4096 literals x 11 bits, 512 x 3 queue words
+static_assert(STAGE_WORDS >= ((7 + SEQ_TILE * 90 + 28) >> 5) + 2 && STAGE_WORDS >= ((7 + SYM_TILE * 11 + 1) >> 5) + 2 && STAGE_WORDS >= 3 * SEQ_TILE, "staging tile too small");
 
 __constant__ u8 c_LLcode[64] = {0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,16,17,17,18,18,19,19,20,20,20,20,21,21,21,21,22,22,22,22,22,22,22,22,
                                 23,23,23,23,23,23,23,23,24,24,24,24,24,24,24,24,24,24,24,24,24,24,24,24};
@@ -39,27 +41,35 @@ __device__ __forceinline__ u32 ll_code(u32 v) { return v > 63 ? hb32(v) + 19 : c
 __device__ __forceinline__ u32 ml_code(u32 mlBase) { return mlBase > 127 ? hb32(mlBase) + 36 : c_MLcode[mlBase]; }
 __device__ __forceinline__ u32 hb32z(u32 x) { return x ? hb32(x) : 0; }
 
-struct __attribute__((aligned(16))) EncShared {
-  u32 stage[STAGE_WORDS];
+// LDS of one frame-block (~20 KiB: up to 7 workgroups per CU). The literal-phase arrays and the sequence-phase arrays are never
+// live at the same time and share storage.
+struct EncLitPhase {
   u32 hist[4][256];
-  u32 cnt[3][64];
   // Huffman construction (index 0 of node* is the sentinel "huffNode[-1]")
   u32 nodeCount[514];
   u16 nodeParent[514];
   u8 nodeBits[514];
   u8 nodeByte[256];
-  u8 hNb[256];
-  u16 hVal[256];
   u8 weights[256];
   u8 hufHdr[192];
-  // FSE
-  ZraFseCTable ct[3];        // 0 LL, 1 OF, 2 ML (next-block tables)
+  short wNorm[16];            // FSE description of the Huffman weights (tableLog <= 6)
+  u8 wSpread[64];
+};
+struct EncSeqPhase {
+  u32 cnt[3][64];
   short norm[3][64];
   u8 spread[3][512];
   u8 ncount[3][192];
-  u32 ncountSize[3], mode[3], nextRepeat[3], tblErr[3];
   u8 codes[3][SEQ_TILE];
   u16 chain[3][SEQ_TILE];
+};
+struct __attribute__((aligned(16))) EncShared {
+  u32 stage[STAGE_WORDS];
+  union { EncLitPhase lit; EncSeqPhase seq; };
+  u8 hNb[256];
+  u16 hVal[256];
+  ZraFseCTable ct[3];        // 0 LL, 1 OF, 2 ML (next-block tables)
+  u32 ncountSize[3], mode[3], nextRepeat[3], tblErr[3];
   u32 finalState[3];
   u32 wsum[16];
   u32 longCount;
@@ -273,7 +283,7 @@ __device__ __forceinline__ u32 fse_encode(const ZraFseCTable* ct, u32& state, u3
 // =============================================================================== Huffman (A.4.5)
 // depth limiter on the sorted node arrays (positions 0..lastNonNull, +1 offset in LDS arrays); one lane
 __device__ u32 huf_set_max_height(EncShared& S, u32 lastNonNull, u32 maxNbBits) {
-  u8* nb = S.nodeBits + 1; const u32* cnt = S.nodeCount + 1;
+  u8* nb = S.lit.nodeBits + 1; const u32* cnt = S.lit.nodeCount + 1;
   const u32 largestBits = nb[lastNonNull];
   if (largestBits <= maxNbBits) return largestBits;
   int totalCost = 0;
@@ -319,9 +329,9 @@ __device__ u32 huf_set_max_height(EncShared& S, u32 lastNonNull, u32 maxNbBits) 
   return maxNbBits;
 }
 
-// FSE-compress the weight string (one lane). 0 = not compressible, 1 = single symbol. Uses S.ct[0]/S.spread[0]/S.norm[0] as scratch.
+// FSE-compress the weight string (one lane). 0 = not compressible, 1 = single symbol. Uses S.ct[0]/S.seq.spread[0]/S.seq.norm[0] as scratch.
 __device__ u32 huf_compress_weights(EncShared& S, u8* dst, u32 cap, const u8* w, u32 n) {
-  u32 count[13]; short* norm = S.norm[0];
+  u32 count[13]; short* norm = S.lit.wNorm;
   u32 maxSym = 0, maxCount = 0;
   if (n <= 1) return 0;
   for (int s = 0; s < 13; s++) count[s] = 0;
@@ -336,7 +346,7 @@ __device__ u32 huf_compress_weights(EncShared& S, u8* dst, u32 cap, const u8* w,
   if (!h || h > cap) return 0;
   for (u32 i = 0; i < h; i++) dst[i] = tmp[i];
   ZraFseCTable* ct = &S.ct[0];
-  if (fse_build_ctable(ct, norm, maxSym, t, S.spread[0])) return 0;
+  if (fse_build_ctable(ct, norm, maxSym, t, S.lit.wSpread)) return 0;
   if (n <= 2) return 0;
   // two interleaved states, symbols consumed from the end (A.4.5 "weight serialisation")
   u64 acc = 0; u32 nacc = 0, pos = h;
@@ -358,9 +368,9 @@ __device__ u32 huf_compress_weights(EncShared& S, u8* dst, u32 cap, const u8* w,
   return pos;
 }
 
-// HUF_writeCTable into S.hufHdr (one lane); returns size, 0 on failure
+// HUF_writeCTable into S.lit.hufHdr (one lane); returns size, 0 on failure
 __device__ u32 huf_write_ctable(EncShared& S, u32 maxSym, u32 log) {
-  u8* w = S.weights; u8* dst = S.hufHdr;
+  u8* w = S.lit.weights; u8* dst = S.lit.hufHdr;
   for (u32 n = 0; n < maxSym; n++) w[n] = S.hNb[n] ? (u8)(log + 1 - S.hNb[n]) : 0;
   const u32 h = huf_compress_weights(S, dst + 1, 190, w, maxSym);
   if (h > 1 && h < maxSym / 2) { dst[0] = (u8)h; return h + 1; }
@@ -475,9 +485,19 @@ __device__ u32 select_encoding(u32* repeatMode, const u32* count, u32 max, u32 m
 }  // namespace
 
 // =================================================================================================
-extern "C" __global__ void __launch_bounds__(ENT_THREADS)
+#ifdef ZRA_MF_PROFILE
+__device__ unsigned long long zra_ent_prof[16];
+#define EPROF(k) { __syncthreads(); if (threadIdx.x == 0) { __builtin_amdgcn_s_waitcnt(0); const u64 n_ = __builtin_amdgcn_s_memtime(); atomicAdd(&zra_ent_prof[k], n_ - ept_); ept_ = n_; } }
+#else
+#define EPROF(k)
+#endif
+
+extern "C" __global__ void __launch_bounds__(ENT_THREADS, 7)
 zra_entropy_kernel(ZraEncArgs a, u32 block) {
   __shared__ EncShared S;
+#ifdef ZRA_MF_PROFILE
+  u64 ept_ = __builtin_amdgcn_s_memtime();
+#endif
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const u32 f = blockIdx.x;
   const u64 fstart = (u64)(a.firstFrame + f) * a.frameSize;
@@ -511,14 +531,14 @@ zra_entropy_kernel(ZraEncArgs a, u32 block) {
     u8* lits = a.lits + (size_t)f * a.litStride;
 
     // ------------------------------------------------------------ phase 1: gather literals + histogram
-    for (int i = tid; i < 4 * 256; i += ENT_THREADS) (&S.hist[0][0])[i] = 0;
+    for (int i = tid; i < 4 * 256; i += ENT_THREADS) (&S.lit.hist[0][0])[i] = 0;
     u32 litBase = 0, srcBase = bs;
     __syncthreads();
     for (u32 t0 = 0; t0 < nbSeq; t0 += SEQ_TILE) {
-      u32 llv[4], mlv[4], tl = 0, tt = 0;
+      u32 llv[SEQ_PER], mlv[SEQ_PER], tl = 0, tt = 0;
 #pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const u32 i = t0 + 4 * tid + k;
+      for (int k = 0; k < SEQ_PER; k++) {
+        const u32 i = t0 + SEQ_PER * tid + k;
         const u64 q = i < nbSeq ? seqs[i] : 0;
         llv[k] = (u32)q & 0xFFFFF; mlv[k] = (u32)(q >> 20) & 0xFFFFF;
         tl += llv[k]; tt += llv[k] + mlv[k];
@@ -529,13 +549,13 @@ zra_entropy_kernel(ZraEncArgs a, u32 block) {
       const u32 exT = block_excl_scan(S, tt, &totT);
       u32 lp = litBase + exL, sp = srcBase + exT;
 #pragma unroll
-      for (int k = 0; k < 4; k++) {
+      for (int k = 0; k < SEQ_PER; k++) {
         const u32 ll = llv[k];
         if (ll >= 32) {                              // long run: queue for the whole workgroup
           const u32 e = atomicAdd(&S.longCount, 1u);
           S.stage[3 * e] = lp; S.stage[3 * e + 1] = sp; S.stage[3 * e + 2] = ll;
         } else {
-          for (u32 b = 0; b < ll; b++) { const u8 c = src[sp + b]; lits[lp + b] = c; atomicAdd(&S.hist[wave][c], 1u); }
+          for (u32 b = 0; b < ll; b++) { const u8 c = src[sp + b]; lits[lp + b] = c; atomicAdd(&S.lit.hist[wave][c], 1u); }
         }
         lp += ll; sp += ll + mlv[k];
       }
@@ -543,18 +563,19 @@ zra_entropy_kernel(ZraEncArgs a, u32 block) {
       const u32 nLong = S.longCount;
       for (u32 e = 0; e < nLong; e++) {
         const u32 lp2 = S.stage[3 * e], sp2 = S.stage[3 * e + 1], ll2 = S.stage[3 * e + 2];
-        for (u32 b = tid; b < ll2; b += ENT_THREADS) { const u8 c = src[sp2 + b]; lits[lp2 + b] = c; atomicAdd(&S.hist[wave][c], 1u); }
+        for (u32 b = tid; b < ll2; b += ENT_THREADS) { const u8 c = src[sp2 + b]; lits[lp2 + b] = c; atomicAdd(&S.lit.hist[wave][c], 1u); }
       }
       litBase += totL; srcBase += totT;
       __syncthreads();
     }
     const u32 lastLL = bo->lastLL;
-    for (u32 b = tid; b < lastLL; b += ENT_THREADS) { const u8 c = src[be - lastLL + b]; lits[litBase + b] = c; atomicAdd(&S.hist[wave][c], 1u); }
+    for (u32 b = tid; b < lastLL; b += ENT_THREADS) { const u8 c = src[be - lastLL + b]; lits[litBase + b] = c; atomicAdd(&S.lit.hist[wave][c], 1u); }
     const u32 n = litBase + lastLL;           // literal count of the block
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 
+    EPROF(0)
     // ------------------------------------------------------------ phase 2: literals section (A.4.5)
     u32 litSec = 0;
     {
@@ -563,9 +584,9 @@ zra_entropy_kernel(ZraEncArgs a, u32 block) {
       u32 ssz[4] = {0, 0, 0, 0};
       const u8* nbTab = S.hNb; const u16* valTab = S.hVal;
       if (n > 63) {
-        const u32 cntS = S.hist[0][tid] + S.hist[1][tid] + S.hist[2][tid] + S.hist[3][tid];
+        const u32 cntS = S.lit.hist[0][tid] + S.lit.hist[1][tid] + S.lit.hist[2][tid] + S.lit.hist[3][tid];
         __syncthreads();
-        S.hist[0][tid] = cntS;
+        S.lit.hist[0][tid] = cntS;
         const u32 largest = block_max(S, cntS);
         const u32 maxSym = block_max(S, cntS ? (u32)tid : 0u);
         u32 c = 0;                                  // compressed size candidate; 0 = not compressible
@@ -585,12 +606,12 @@ zra_entropy_kernel(ZraEncArgs a, u32 block) {
             const u32 log = fse_optimal_tablelog(11, n, maxSym, 1);
             if ((u32)tid <= maxSym) {
               u32 rank = 0;
-              for (u32 t = 0; t <= maxSym; t++) { const u32 ct = S.hist[0][t]; rank += (ct > cntS) || (ct == cntS && t < (u32)tid); }
-              S.nodeCount[1 + rank] = cntS; S.nodeByte[rank] = (u8)tid;
+              for (u32 t = 0; t <= maxSym; t++) { const u32 ct = S.lit.hist[0][t]; rank += (ct > cntS) || (ct == cntS && t < (u32)tid); }
+              S.lit.nodeCount[1 + rank] = cntS; S.lit.nodeByte[rank] = (u8)tid;
             }
             __syncthreads();
             if (tid == 0) {
-              u32* cntN = S.nodeCount + 1; u16* par = S.nodeParent + 1; u8* nbN = S.nodeBits + 1;
+              u32* cntN = S.lit.nodeCount + 1; u16* par = S.lit.nodeParent + 1; u8* nbN = S.lit.nodeBits + 1;
               int nonNull = (int)maxSym;
               while (cntN[nonNull] == 0) nonNull--;
               const int START = 256;
@@ -599,7 +620,7 @@ zra_entropy_kernel(ZraEncArgs a, u32 block) {
               par[lowS] = par[lowS - 1] = (u16)nodeNb;
               nodeNb++; lowS -= 2;
               for (int k = nodeNb; k <= nodeRoot; k++) cntN[k] = 1u << 30;
-              S.nodeCount[0] = 1u << 31;
+              S.lit.nodeCount[0] = 1u << 31;
               while (nodeNb <= nodeRoot) {
                 const int n1 = (cntN[lowS] < cntN[lowN]) ? lowS-- : lowN++;
                 const int n2 = (cntN[lowS] < cntN[lowN]) ? lowS-- : lowN++;
@@ -616,7 +637,7 @@ zra_entropy_kernel(ZraEncArgs a, u32 block) {
               for (int k = 0; k <= nonNull; k++) nbPerRank[nbN[k]]++;
               { u16 mn = 0; for (int k = (int)maxBits; k > 0; k--) { valPerRank[k] = mn; mn += nbPerRank[k]; mn >>= 1; } }
               for (int k = 0; k < 256; k++) S.hNb[k] = 0;
-              for (u32 k = 0; k <= maxSym; k++) S.hNb[S.nodeByte[k]] = k <= (u32)nonNull ? nbN[k] : 0;
+              for (u32 k = 0; k <= maxSym; k++) S.hNb[S.lit.nodeByte[k]] = k <= (u32)nonNull ? nbN[k] : 0;
               for (u32 k = 0; k <= maxSym; k++) S.hVal[k] = valPerRank[S.hNb[k]]++;
               S.sc[0] = maxBits;
               S.sc[1] = huf_write_ctable(S, maxSym, maxBits);
@@ -654,6 +675,7 @@ zra_entropy_kernel(ZraEncArgs a, u32 block) {
         else if (c == 1) mode = 1;
         else mode = useOld ? 3 : 2;
       }
+      EPROF(1)
       // ---- emit
       if (mode < 2) {
         const u32 fl = 1 + (n > 31) + (n > 4095);
@@ -673,7 +695,7 @@ zra_entropy_kernel(ZraEncArgs a, u32 block) {
           else if (lh == 4) st32(blk, mode + (2 << 2) + (n << 4) + (c << 18));
           else { st32(blk, mode + (3 << 2) + (n << 4) + (c << 22)); blk[4] = (u8)(c >> 10); }
         }
-        for (u32 i = tid; i < hSize; i += ENT_THREADS) blk[lh + i] = S.hufHdr[i];
+        for (u32 i = tid; i < hSize; i += ENT_THREADS) blk[lh + i] = S.lit.hufHdr[i];
         u8* sp = blk + lh + hSize;
         if (streams == 4) {
           if (tid == 0) { sp[0] = (u8)ssz[0]; sp[1] = (u8)(ssz[0] >> 8); sp[2] = (u8)ssz[1]; sp[3] = (u8)(ssz[1] >> 8); sp[4] = (u8)ssz[2]; sp[5] = (u8)(ssz[2] >> 8); }
@@ -691,6 +713,7 @@ zra_entropy_kernel(ZraEncArgs a, u32 block) {
     }
     __syncthreads();
 
+    EPROF(2)
     // ------------------------------------------------------------ phase 3: sequences section (A.4.7)
     u8* op = blk + litSec;
     if (tid == 0) {
@@ -703,22 +726,23 @@ zra_entropy_kernel(ZraEncArgs a, u32 block) {
     if (nbSeq) {
       u8* const seqHead = op++;
       // ---- pass A: code histograms
-      for (int i = tid; i < 3 * 64; i += ENT_THREADS) (&S.cnt[0][0])[i] = 0;
+      for (int i = tid; i < 3 * 64; i += ENT_THREADS) (&S.seq.cnt[0][0])[i] = 0;
       __syncthreads();
       for (u32 i = tid; i < nbSeq; i += ENT_THREADS) {
         const u64 q = seqs[i];
         const u32 ll = (u32)q & 0xFFFFF, ml = (u32)(q >> 20) & 0xFFFFF, ov = (u32)(q >> 40);
-        atomicAdd(&S.cnt[0][ll_code(ll)], 1u);
-        atomicAdd(&S.cnt[1][hb32(ov)], 1u);
-        atomicAdd(&S.cnt[2][ml_code(ml - 3)], 1u);
+        atomicAdd(&S.seq.cnt[0][ll_code(ll)], 1u);
+        atomicAdd(&S.seq.cnt[1][hb32(ov)], 1u);
+        atomicAdd(&S.seq.cnt[2][ml_code(ml - 3)], 1u);
       }
       __syncthreads();
+      EPROF(3)
       // ---- table selection + construction: wave k lane 0 handles stream k (0 LL, 1 OF, 2 ML)
       if (wave < 3 && lane == 0) {
         const int k = wave;
         const u32 maxSymK = k == 0 ? 35 : k == 1 ? 31 : 52, FSELog = k == 1 ? 8 : 9, defLog = k == 1 ? 5 : 6, defMax = k == 0 ? 35 : k == 1 ? 28 : 52;
         const short* defNorm = k == 0 ? c_LLdef : k == 1 ? c_OFdef : c_MLdef;
-        u32* count = S.cnt[k];
+        u32* count = S.seq.cnt[k];
         u32 mx = 0, most = 0;
         for (u32 s = 0; s <= maxSymK; s++) { if (count[s]) mx = s; if (count[s] > most) most = count[s]; }
         const u64 qLast = seqs[nbSeq - 1];
@@ -726,19 +750,19 @@ zra_entropy_kernel(ZraEncArgs a, u32 block) {
         const ZraFseCTable* prevCT = k == 0 ? &st->ll : k == 1 ? &st->of : &st->ml;
         u32 repeatMode = first ? 0 : (k == 0 ? st->llRepeat : k == 1 ? st->ofRepeat : st->mlRepeat);
         const bool defaultAllowed = k != 1 || mx <= 28;
-        const u32 mode = select_encoding(&repeatMode, count, mx, most, nbSeq, FSELog, prevCT, defNorm, defLog, defaultAllowed, strategy, S.norm[k]);
+        const u32 mode = select_encoding(&repeatMode, count, mx, most, nbSeq, FSELog, prevCT, defNorm, defLog, defaultAllowed, strategy, S.seq.norm[k]);
         S.mode[k] = mode; S.nextRepeat[k] = repeatMode; S.ncountSize[k] = 0; S.tblErr[k] = 0;
         ZraFseCTable* ct = &S.ct[k];
-        if (mode == 1) { ct->rle = 1; ct->tableLog = 0; ct->maxSym = mx; S.ncount[k][0] = (u8)mx; S.ncountSize[k] = 1; }
-        else if (mode == 0) { for (u32 s = 0; s <= defMax; s++) S.norm[k][s] = defNorm[s]; if (fse_build_ctable(ct, S.norm[k], defMax, defLog, S.spread[k])) S.tblErr[k] = 1; }
+        if (mode == 1) { ct->rle = 1; ct->tableLog = 0; ct->maxSym = mx; S.seq.ncount[k][0] = (u8)mx; S.ncountSize[k] = 1; }
+        else if (mode == 0) { for (u32 s = 0; s <= defMax; s++) S.seq.norm[k][s] = defNorm[s]; if (fse_build_ctable(ct, S.seq.norm[k], defMax, defLog, S.seq.spread[k])) S.tblErr[k] = 1; }
         else if (mode == 2) {
           u32 n1 = nbSeq;
           const u32 tl = fse_optimal_tablelog(FSELog, nbSeq, mx, 2);
           if (count[lastCode] > 1) { count[lastCode]--; n1--; }
-          if (fse_normalize(S.norm[k], tl, count, n1, mx, n1 >= 2048) <= 0) S.tblErr[k] = 1;
+          if (fse_normalize(S.seq.norm[k], tl, count, n1, mx, n1 >= 2048) <= 0) S.tblErr[k] = 1;
           else {
-            const u32 h = fse_write_ncount(S.ncount[k], S.norm[k], mx, tl);
-            if (!h || fse_build_ctable(ct, S.norm[k], mx, tl, S.spread[k])) S.tblErr[k] = 1;
+            const u32 h = fse_write_ncount(S.seq.ncount[k], S.seq.norm[k], mx, tl);
+            if (!h || fse_build_ctable(ct, S.seq.norm[k], mx, tl, S.seq.spread[k])) S.tblErr[k] = 1;
             S.ncountSize[k] = h;
           }
         }
@@ -759,9 +783,10 @@ zra_entropy_kernel(ZraEncArgs a, u32 block) {
       for (int k = 0; k < 3; k++) {
         const u32 sz = S.ncountSize[k];
         if (S.mode[k] == 2) lastNCount = op;
-        for (u32 i = tid; i < sz; i += ENT_THREADS) op[i] = S.ncount[k][i];
+        for (u32 i = tid; i < sz; i += ENT_THREADS) op[i] = S.seq.ncount[k][i];
         op += sz;
       }
+      EPROF(4)
       // ---- pass B: FSE state chains (3 lanes) + parallel packing, 1024 sequences per tile, last sequence first
       u32 state = 0;                       // wave 0 lanes 0..2 carry their stream's state across tiles
       u32 carryBits = 0, carryVal = 0, bytesOut = 0;
@@ -771,42 +796,44 @@ zra_entropy_kernel(ZraEncArgs a, u32 block) {
         const bool lastTile = t0 + cntT == nbSeq;
         const u32 zw = ((7 + cntT * 90 + 28) >> 5) + 2;
         for (u32 i = tid; i < zw; i += ENT_THREADS) S.stage[i] = (i == 0) ? carryVal : 0;
-        u32 llv[4], mlb[4], ofv[4], llc[4], mlc[4], ofc[4];
+        u32 llv[SEQ_PER], mlb[SEQ_PER], ofv[SEQ_PER], llc[SEQ_PER], mlc[SEQ_PER], ofc[SEQ_PER];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-          const u32 rl = 4 * tid + k;                 // reversed local index
+        for (int k = 0; k < SEQ_PER; k++) {
+          const u32 rl = SEQ_PER * tid + k;                 // reversed local index
           if (rl < cntT) {
             const u64 q = seqs[nbSeq - 1 - (t0 + rl)];
             llv[k] = (u32)q & 0xFFFFF; mlb[k] = ((u32)(q >> 20) & 0xFFFFF) - 3; ofv[k] = (u32)(q >> 40);
             llc[k] = ll_code(llv[k]); mlc[k] = ml_code(mlb[k]); ofc[k] = hb32(ofv[k]);
-            S.codes[0][rl] = (u8)llc[k]; S.codes[1][rl] = (u8)ofc[k]; S.codes[2][rl] = (u8)mlc[k];
+            S.seq.codes[0][rl] = (u8)llc[k]; S.seq.codes[1][rl] = (u8)ofc[k]; S.seq.codes[2][rl] = (u8)mlc[k];
           } else { llv[k] = mlb[k] = ofv[k] = llc[k] = mlc[k] = ofc[k] = 0; }
         }
         __syncthreads();
+        EPROF(5)
         if (wave == 0 && lane < 3) {
           const ZraFseCTable* ct = &S.ct[lane];
           for (u32 rl = 0; rl < cntT; rl++) {
-            const u32 code = S.codes[lane][rl];
-            if (t0 + rl == 0) { state = fse_init_state(ct, code); S.chain[lane][rl] = 0; }
-            else { u32 bits; const u32 nb = fse_encode(ct, state, code, bits); S.chain[lane][rl] = (u16)((nb << 12) | bits); }
+            const u32 code = S.seq.codes[lane][rl];
+            if (t0 + rl == 0) { state = fse_init_state(ct, code); S.seq.chain[lane][rl] = 0; }
+            else { u32 bits; const u32 nb = fse_encode(ct, state, code, bits); S.seq.chain[lane][rl] = (u16)((nb << 12) | bits); }
           }
           if (lastTile) S.finalState[lane] = state;
         }
         __syncthreads();
+        EPROF(6)
         u32 nbits = 0;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-          const u32 rl = 4 * tid + k;
-          if (rl < cntT) nbits += (S.chain[0][rl] >> 12) + (S.chain[1][rl] >> 12) + (S.chain[2][rl] >> 12) + c_LLbits[llc[k]] + c_MLbits[mlc[k]] + ofc[k];
+        for (int k = 0; k < SEQ_PER; k++) {
+          const u32 rl = SEQ_PER * tid + k;
+          if (rl < cntT) nbits += (S.seq.chain[0][rl] >> 12) + (S.seq.chain[1][rl] >> 12) + (S.seq.chain[2][rl] >> 12) + c_LLbits[llc[k]] + c_MLbits[mlc[k]] + ofc[k];
         }
         u32 tot;
         const u32 ex = block_excl_scan(S, nbits, &tot);
         LaneBitW bw; bw.init(S.stage, carryBits + ex);
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-          const u32 rl = 4 * tid + k;
+        for (int k = 0; k < SEQ_PER; k++) {
+          const u32 rl = SEQ_PER * tid + k;
           if (rl < cntT) {
-            const u32 cO = S.chain[1][rl], cM = S.chain[2][rl], cL = S.chain[0][rl];
+            const u32 cO = S.seq.chain[1][rl], cM = S.seq.chain[2][rl], cL = S.seq.chain[0][rl];
             bw.add(cO & 0xFFF, cO >> 12); bw.add(cM & 0xFFF, cM >> 12); bw.add(cL & 0xFFF, cL >> 12);
             const u32 lb = c_LLbits[llc[k]], mb = c_MLbits[mlc[k]], ob = ofc[k];
             bw.add(llv[k] & ((1u << lb) - 1), lb);
@@ -834,6 +861,7 @@ zra_entropy_kernel(ZraEncArgs a, u32 block) {
         carryVal = (S.stage[nbytes >> 2] >> (8 * (nbytes & 3))) & ((1u << carryBits) - 1);
         bytesOut += nbytes;
         __syncthreads();
+        EPROF(7)
       }
       op += bytesOut;
       if (tblErr) uncompressible = true;
@@ -881,6 +909,10 @@ zra_entropy_kernel(ZraEncArgs a, u32 block) {
     }
   }
   (void)newHufLog;
+  EPROF(8)
+#ifdef ZRA_MF_PROFILE
+  if (tid == 0) atomicAdd(&zra_ent_prof[15], 1ull);
+#endif
   if (tid == 0) {
     u32 pos = outPos + blockBytes;
     if (last) {
@@ -890,3 +922,10 @@ zra_entropy_kernel(ZraEncArgs a, u32 block) {
     st->outPos = pos;
   }
 }
+
+#ifdef ZRA_MF_PROFILE
+extern "C" __attribute__((visibility("default"))) void ZraHipDebugReadEntProfile(unsigned long long* out16, int reset) {
+  (void)hipMemcpyFromSymbol(out16, HIP_SYMBOL(zra_ent_prof), sizeof(unsigned long long) * 16);
+  if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(zra_ent_prof), z, sizeof(z)); }
+}
+#endif
