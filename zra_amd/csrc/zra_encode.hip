@@ -29,28 +29,21 @@ __global__ void zra_content_ck_kernel(const u8* in, u64 inSize, u32 frameSize, u
   if (active && j == 0) ck[f] = (u32)h;
 }
 
-// ---- exclusive scan of the batch's frame sizes (single workgroup, 1024 threads, chunked). The running body offset lives on the
-//      device (`running`), so batches chain without a host round trip: offsets[i] = *running + local prefix; *running += total.
-__global__ void __launch_bounds__(1024) zra_scan_sizes_kernel(const u64* sizes, u32 n, u64* offsets, u64* running) {
-  __shared__ u64 wsum[16];
-  __shared__ u64 carry;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (tid == 0) carry = *running;
-  __syncthreads();
-  for (u32 base = 0; base < n; base += 1024) {
-    const u32 i = base + tid;
-    u64 v = i < n ? sizes[i] : 0, inc = v;
-    for (int d = 1; d < 64; d <<= 1) { u64 t = __shfl_up(inc, d, 64); if (lane >= d) inc += t; }
-    if (lane == 63) wsum[wave] = inc;
-    __syncthreads();
-    u64 wbase = 0, tot = 0;
-    for (int w = 0; w < 16; w++) { if (w < wave) wbase += wsum[w]; tot += wsum[w]; }
-    if (i < n) offsets[i] = carry + wbase + inc - v;
-    __syncthreads();
-    if (tid == 0) carry += tot;
-    __syncthreads();
+// ---- exclusive scan of the batch's frame sizes: ONE wave (a 1024-thread workgroup cannot be placed while the persistent match
+//      finder holds wave slots on every SIMD; a single wave fits anywhere). The running body offset lives on the device
+//      (`running`), so batches chain without a host round trip: offsets[i] = *running + local prefix; *running += total.
+__global__ void __launch_bounds__(64) zra_scan_sizes_kernel(const u64* sizes, u32 n, u64* offsets, u64* running) {
+  const int lane = threadIdx.x;
+  u64 carry = *running;
+  for (u32 base = 0; base < n; base += 64) {
+    const u32 i = base + lane;
+    const u64 v = i < n ? sizes[i] : 0;
+    u64 inc = v;
+    for (int d = 1; d < 64; d <<= 1) { const u64 t = __shfl_up(inc, d, 64); if (lane >= d) inc += t; }
+    if (i < n) offsets[i] = carry + inc - v;
+    carry += __shfl(inc, 63, 64);
   }
-  if (tid == 0) *running = carry;
+  if (lane == 0) *running = carry;
 }
 
 // ---- gather: frame f of the batch moves from its slot to body + bodyBase + offsets[f] (one workgroup per frame);
@@ -237,7 +230,7 @@ Status Engine::compress_impl(const uint8_t* dIn, size_t inSize, uint8_t* dBody, 
       entSpans.push_back({e0, e1});
       if (blk + 1 < rounds) HIPCHK(hipStreamWaitEvent(stream_, e1, 0));   // next block's match finder needs the confirmed state
     }
-    hipLaunchKernelGGL(zra_scan_sizes_kernel, dim3(1), dim3(1024), 0, stream2_, a.sizes, nb, dOffsets, dRunning);
+    hipLaunchKernelGGL(zra_scan_sizes_kernel, dim3(1), dim3(64), 0, stream2_, a.sizes, nb, dOffsets, dRunning);
     hipLaunchKernelGGL(zra_gather_frames_kernel, dim3(nb), dim3(256), 0, stream2_, a.slots, slotStride, a.sizes, dOffsets, dBody,
                        bodyBase0, dEntries ? dEntries : nullptr, (u32)f0, dSizes);
     hipEvent_t done = ev(); if (!done) return zerr(1);
@@ -300,9 +293,11 @@ Status Engine::compress_persistent(const uint8_t* dIn, size_t inSize, uint8_t* d
   dbgSeqStride_ = seqStride; dbgB_ = (uint32_t)SBIG;
   base.tableStride = tableWords; base.seqStride = seqStride; base.litStride = litStride; base.slotStride = slotStride;
   // LDS geometry of the bucket filter: 1 bit per 2^shL long-table buckets, 1 bit per 2^shS short-table buckets, and the
-  // duplicate-detection slots (2 KiB + 4 KiB + 2 KiB at hashLog 16 / chainLog 15; sweep in profiles/r01_mf_occupancy_sweep.log)
-  uint32_t shL = 1, shS = 1, dupLog = 10;
-  if (const char* f = std::getenv("ZRA_MF_FILTER")) { unsigned x = 1, y = 1, z = 10; if (std::sscanf(f, "%u,%u,%u", &x, &y, &z) >= 1) { shL = x & 15; shS = y & 15; dupLog = z & 15; } }
+  // duplicate-detection slots (1 KiB + 4 KiB + 2 KiB at hashLog 16 / chainLog 15). 16 resident waves per CU x 7 KiB leave LDS and
+  // wave slots for two entropy-stage workgroups per CU, which is what lets stream B run under the match finder (sweeps in
+  // profiles/r01_mf_occupancy_sweep.log)
+  uint32_t shL = 1, shS = 1, dupLog = 9;
+  if (const char* f = std::getenv("ZRA_MF_FILTER")) { unsigned x = 1, y = 1, z = 9; if (std::sscanf(f, "%u,%u,%u", &x, &y, &z) >= 1) { shL = x & 15; shS = y & 15; dupLog = z & 15; } }
   base.mfFilter = shL | (shS << 4) | (dupLog << 8);
   const uint32_t hl = std::max(full.hashLog, tail.hashLog), cl = std::max(full.chainLog, tail.chainLog);
   const size_t filterBytes = (2u << dupLog) + (((size_t)1 << hl) >> shL) / 8 + (((size_t)1 << cl) >> shS) / 8 + 64;
@@ -366,7 +361,7 @@ Status Engine::compress_persistent(const uint8_t* dIn, size_t inSize, uint8_t* d
       hipLaunchKernelGGL(zra_entropy_kernel, dim3(nbj), dim3(256), 0, stream2_, aj, 0u);
       HIPCHK(hipEventRecord(e1, stream2_));
       entSpans.push_back({e0, e1});
-      hipLaunchKernelGGL(zra_scan_sizes_kernel, dim3(1), dim3(1024), 0, stream2_, aj.sizes, nbj, dOffsets, dRunning);
+      hipLaunchKernelGGL(zra_scan_sizes_kernel, dim3(1), dim3(64), 0, stream2_, aj.sizes, nbj, dOffsets, dRunning);
       hipLaunchKernelGGL(zra_gather_frames_kernel, dim3(nbj), dim3(256), 0, stream2_, aj.slots, slotStride, aj.sizes, dOffsets, dBody,
                          bodyBase0, dEntries ? dEntries : nullptr, (u32)(F0 + j0), dSizes);
     }
