@@ -233,6 +233,7 @@ def main():
                 step.loc = loc
             loc[: len(lh)] = torch.frombuffer(bytearray(lh), dtype=torch.uint8).to(dev)
             loc[len(lh): need] = d_arc[: need - len(lh)]
+            torch.cuda.synchronize()               # torch's copy stream -> the engine's streams
             eng.decompress_ra_batch(loc.data_ptr(), need, d_ra.data_ptr(), offs, sizes, oofs)
             dec_stats.append(eng.kernel_stats())
         torch.cuda.synchronize()

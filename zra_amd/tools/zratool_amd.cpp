@@ -6,6 +6,7 @@
 //   imc : in-memory CompressBuffer          imd : in-memory DecompressBuffer
 //   b   : benchmark of all four + one random-access query with a memcmp check
 #include <zra.hpp>
+#include <zra.h>
 
 #include <chrono>
 #include <cstdio>
@@ -121,6 +122,21 @@ int main(int argc, char** argv) {
       n = stream_decompress(argv[3], tmp.c_str());
       m = ms_since(t);
       std::printf("streaming decompress : %8.1f ms  %8.1f MB/s  (%zu bytes)\n", m, in.size() / 1e3 / m, n);
+      {
+        // steady state of the drop-in C ABI (caller-owned buffers, scratch already allocated): what a long-running host sees
+        std::vector<zra::u8> obuf(ZraGetCompressedOutputBufferSize(in.size(), frameSize)), rbuf(in.size());
+        for (int rep = 0; rep < 3; rep++) {
+          size_t osz = 0;
+          t = Clock::now();
+          ZraStatus st = ZraCompressBuffer(in.data(), in.size(), obuf.data(), &osz, level, frameSize, true, nullptr, 0);
+          const double mc = ms_since(t);
+          t = Clock::now();
+          ZraStatus sd = ZraDecompressBuffer(obuf.data(), osz, rbuf.data());
+          const double md = ms_since(t);
+          std::printf("C ABI rep %d: compress %8.1f ms %8.1f MB/s (status %d)   decompress %8.1f ms %8.1f MB/s (status %d, %s)\n", rep, mc,
+                      in.size() / 1e3 / mc, (int)st.zra, md, in.size() / 1e3 / md, (int)sd.zra, std::memcmp(rbuf.data(), in.data(), in.size()) == 0 ? "ok" : "MISMATCH");
+        }
+      }
       if (in.size() > 4096) {
         const size_t off = in.size() / 3, len = std::min<size_t>(in.size() - off - 1, 1 << 20);
         t = Clock::now();
