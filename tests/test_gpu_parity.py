@@ -45,6 +45,33 @@ def test_compress_buffer_bit_exact(zra, gens, level, fs):
         assert zra.DecompressBuffer(arc) == d
 
 
+@pytest.mark.parametrize("nframes,tail", [(1, 0), (8191, 0), (8192, 0), (8193, 5), (16385, 1023), (20000, 0)])
+def test_persistent_pipeline_sub_batch_boundaries(zra, nframes, tail):
+    """The dfast path is ONE persistent match-finder launch whose finished frames are counted per sub-batch of 8192 frames
+    (zra_encode.hip: compress_persistent); frame counts around those boundaries, with and without a ragged last frame."""
+    fs = 1024
+    n = nframes * fs + tail
+    src = (C.gen_loglike(1 << 20) + C.gen_struct(1 << 19) + C.gen_D(1 << 19))
+    d = (src * (n // len(src) + 1))[:n]
+    st, ref = O.zra_compress(d, 3, fs, True)
+    assert st == (0, 0)
+    arc = zra.CompressBuffer(d, 3, fs, True)
+    assert arc == ref
+    assert zra.DecompressBuffer(arc) == d
+
+
+@pytest.mark.parametrize("level,fs,tail", [(4, 65536, 5000), (4, 65536, 16384), (4, 131072, 777), (3, 131072, 20000)])
+def test_short_last_frame_with_other_cparams(zra, gens, level, fs, tail):
+    """The short last frame gets its own cparams (A.4.1) — at level 4 even another strategy (greedy below 16 KiB): the persistent
+    dfast launch leaves that frame to the generic kernel and the entropy stage waits for both."""
+    for name in ("C", "E", "L"):
+        d = gens[name][: 3 * fs + tail]
+        st, ref = O.zra_compress(d, level, fs, True)
+        assert st == (0, 0)
+        arc = zra.CompressBuffer(d, level, fs, True)
+        assert arc == ref, (name, level, fs, tail)
+
+
 def test_compress_edge_cases(zra):
     assert zra.CompressBuffer(b"abcdefghij", 3, 4, True) == open(os.path.join(GOLD, "g1_abcdefghij_fs4.zra"), "rb").read()
     assert zra.CompressBuffer(b"", 3, 65536, True) == open(os.path.join(GOLD, "g1_empty_fs65536.zra"), "rb").read()
