@@ -105,13 +105,29 @@ def cpu_baseline(sample, frame_size, level, nq, qsize, seed=42):
     for o in offs:
         fn(abuf, len(arc), obuf, qsize, int(o), qsize)
     t3 = time.perf_counter()
+    # (ii) of SURVEY §8d: best-case CPU, NOT the reference (which is single-threaded): frames statically partitioned over T threads,
+    # one libzstd context per thread (ctypes releases the GIL). Bounded: every thread compresses a 64 MiB slice.
+    import threading
+    T = max(1, min(64, (os.cpu_count() or 1)))
+    sl = min(len(data), 64 << 20) // frame_size * frame_size
+    piece = data[:sl]
+    def work():
+        O.zra_compress(piece, level, frame_size, True, 0, backend)
+    th = [threading.Thread(target=work) for _ in range(T)]
+    t4 = time.perf_counter()
+    for x in th: x.start()
+    for x in th: x.join()
+    t5 = time.perf_counter()
+    mt = T * sl / GiB / (t5 - t4)
     comp = len(data) / GiB / (t1 - t0)
     ra = nq * qsize / GiB / (t3 - t2)
     combined = (len(data) + nq * qsize) / GiB / ((t1 - t0) + (t3 - t2))
     return {"value": round(combined, 4), "unit": "GiB/s", "cores": 1, "kind": "port",
             "sample": "%d MiB of the same corpus: CompressBuffer L%d/%d KiB + %d DecompressRA queries of %d B; container port (oracle/zo_zra.c) over %s"
                       % (len(data) >> 20, level, frame_size >> 10, nq, qsize, "libzstd " + O.lib().zo_libzstd_version().decode() if backend == "zl" else "the oracle's C restatement"),
-            "compress_gibs": round(comp, 4), "ra_gibs": round(ra, 4), "ra_us_per_query": round((t3 - t2) / nq * 1e6, 1)}, arc
+            "compress_gibs": round(comp, 4), "ra_gibs": round(ra, 4), "ra_us_per_query": round((t3 - t2) / nq * 1e6, 1),
+            "best_case_all_threads": {"compress_gibs": round(mt, 3), "threads": T, "host_cpus": os.cpu_count(),
+                                      "note": "not the reference (single-threaded): %d threads x %d MiB, one libzstd context each" % (T, sl >> 20)}}, arc
 
 
 def main():
@@ -262,6 +278,23 @@ def main():
         if not torch.equal(d_ra[int(oofs[i]): int(oofs[i]) + qb], d_in[o: o + qb]):
             raise SystemExit("RA result mismatch at query %d" % i)
 
+    # SURVEY §8d RA size classes (outside the timed region, single rank): 64 KiB unaligned (touches 2 frames) and 1 MiB queries
+    ra_classes = {}
+    if world == 1:
+        for qsz, nq2 in ((65536, 100000), (1 << 20, 8000)):
+            o2 = rng.randint(0, N - qsz - 1, size=nq2).astype(np.uint64)
+            s2 = np.full(nq2, qsz, dtype=np.uint64); oo2 = (np.arange(nq2, dtype=np.uint64) * qsz)
+            d2 = torch.empty(nq2 * qsz, dtype=torch.uint8, device=dev)
+            eng.decompress_ra_batch(d_arc.data_ptr(), arc_size, d2.data_ptr(), o2, s2, oo2)     # warm
+            torch.cuda.synchronize(); tq = time.perf_counter()
+            eng.decompress_ra_batch(d_arc.data_ptr(), arc_size, d2.data_ptr(), o2, s2, oo2)
+            torch.cuda.synchronize(); dq = time.perf_counter() - tq
+            k = int(rng.randint(0, nq2))
+            if not torch.equal(d2[k * qsz:(k + 1) * qsz], d_in[int(o2[k]): int(o2[k]) + qsz]):
+                raise SystemExit("RA size-class result mismatch")
+            ra_classes["%d_KiB" % (qsz >> 10)] = {"queries": nq2, "us_per_query": round(dq / nq2 * 1e6, 3), "gibs_returned": round(nq2 * qsz / GiB / dq, 3)}
+            del d2
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         moved = (N + q * qb) * world
@@ -300,6 +333,7 @@ def main():
             "compress_gibs": round(N * world / GiB / (np.mean(comp_ms) / 1e3), 3),
             "ra_gibs_returned": round(q * qb * world / GiB / (np.mean(ra_ms) / 1e3), 3),
             "ra_us_per_query": round(np.mean(ra_ms) * 1e3 / q, 3),
+            "ra_size_classes": ra_classes,
             "roofline": {"bound": "hbm", "kernel": "zra_mf_dfast_kernel" if args.level in (3, 4) else "zra_mf_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "frac_of_measured_6290": round(achieved / 6290.0, 5), "traffic": traffic,
                          "launch_ms": round(mf_launch_ms, 3), "launches_per_call": launches, "algorithmic_bytes_per_launch": int(alg_per_launch),
