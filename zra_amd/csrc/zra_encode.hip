@@ -135,7 +135,18 @@ Status Engine::compress_impl(const uint8_t* dIn, size_t inSize, uint8_t* dBody, 
   // DRAM-bound match finder, and the entropy stage runs under it in small pieces.
   {
     const char* tuneEnv = std::getenv("ZRA_MF_TUNE");
-    const bool persist = maxBlocksPerFrame == 1 && full.strategy == 2 && !(tuneEnv && std::atoi(tuneEnv) == 7) && !std::getenv("ZRA_MF_NOPERSIST");
+    bool persist = maxBlocksPerFrame == 1 && full.strategy == 2 && !(tuneEnv && std::atoi(tuneEnv) == 7) && !std::getenv("ZRA_MF_NOPERSIST");
+    if (persist && waitValueOk_ == 0) {
+      // the pipeline needs stream memory operations on plain device memory; probe once (a wait that is already satisfied), and
+      // use the batch path below on runtimes without them
+      if (!encScan_.reserve(64)) return zerr(64);
+      bool okProbe = hipMemsetAsync(encScan_.p, 0, 64, stream2_) == hipSuccess &&
+                     hipStreamWaitValue32(stream2_, encScan_.p, 0, hipStreamWaitValueGte, 0xFFFFFFFFu) == hipSuccess &&
+                     hipStreamSynchronize(stream2_) == hipSuccess;
+      if (!okProbe) (void)hipGetLastError();
+      waitValueOk_ = okProbe ? 1 : -1;
+    }
+    if (waitValueOk_ < 0) persist = false;
     if (persist)
       return compress_persistent(dIn, inSize, dBody, bodyBase0, dEntries, dSizes, bodySize, frameSize, checksum, full, tail,
                                  tableWords, seqStride, litStride, slotStride);

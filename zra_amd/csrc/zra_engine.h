@@ -100,6 +100,7 @@ class Engine {
   std::vector<hipEvent_t> evPool_;
   DevBuf hostIn_, hostOut_;
   uint64_t dbgSeqStride_ = 0; uint32_t dbgB_ = 0;
+  int waitValueOk_ = 0;                    // 0 unknown, 1 hipStreamWaitValue32 works on device memory, -1 it does not (batch path)
   friend struct EncodeImpl;
 };
 

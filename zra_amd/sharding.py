@@ -59,7 +59,7 @@ def gather_archive(local_body, local_sizes, uncompressed_size, frame_size, root_
         root_buffer[:hlen] = torch.frombuffer(bytearray(header), dtype=torch.uint8).to(local_body.device)
         root_buffer[hlen: hlen + int(totals[0])] = local_body[: int(totals[0])]
         staged = _comm_device(root_buffer) != root_buffer.device
-        reqs = []
+        ops = []
         for r in range(1, world):
             if int(totals[r]):
                 dst = root_buffer[hlen + int(bases[r]): hlen + int(bases[r]) + int(totals[r])]
@@ -68,9 +68,11 @@ def gather_archive(local_body, local_sizes, uncompressed_size, frame_size, root_
                     dist.recv(tmp, src=r, group=group)
                     dst.copy_(tmp)
                 else:
-                    reqs.append(dist.irecv(dst, src=r, group=group))
-        for q in reqs:
-            q.wait()
+                    ops.append(dist.P2POp(dist.irecv, dst, r, group))
+        if ops:
+            # one RCCL group: the 7 inbound transfers run concurrently, each on its own point-to-point xGMI link
+            for q in dist.batch_isend_irecv(ops):
+                q.wait()
         return root_buffer[:need], header, bases, totals
     if int(totals[rank]):
         dist.send(local_body[: int(totals[rank])].contiguous().to(_comm_device(local_body)), dst=0, group=group)
