@@ -72,6 +72,25 @@ def test_short_last_frame_with_other_cparams(zra, gens, level, fs, tail):
         assert arc == ref, (name, level, fs, tail)
 
 
+@pytest.mark.parametrize("level,fs", [(1, 65536), (3, 65536), (3, 16384), (4, 131072), (5, 65536), (7, 65536), (9, 65536)])
+def test_match_finder_sequences_equal_the_oracle(zra, gpu_engine, gens, level, fs):
+    """Stage-level pin: the sequences {litLength, matchLength, offsetValue} the HIP match finder leaves for the entropy
+    stage, frame by frame, against the oracle's match finder — independent of the entropy coder. Single-block frames."""
+    import torch
+    dev = torch.device("cuda", 0)
+    for name in ("C", "E", "D", "F"):
+        d = gens[name][: 6 * fs]
+        d = d[: len(d) // fs * fs]
+        t = torch.from_numpy(np.frombuffer(d, dtype=np.uint8).copy()).to(dev)
+        out = torch.empty(zra.GetOutputBufferSize(len(d), fs) + 64, dtype=torch.uint8, device=dev)
+        gpu_engine.compress(t.data_ptr(), len(d), out.data_ptr(), level, fs, True)
+        for f in range(len(d) // fs):
+            seqs, (nb, last_ll, skip) = gpu_engine.debug_read_seqs(f)
+            ref = O.sequences(d[f * fs:(f + 1) * fs], level)          # the oracle appends the block's last literals as (ll, 0, 0)
+            assert not skip and len(seqs) == nb
+            assert seqs + [(last_ll, 0, 0)] == ref, (name, level, fs, f)
+
+
 def test_compress_edge_cases(zra):
     assert zra.CompressBuffer(b"abcdefghij", 3, 4, True) == open(os.path.join(GOLD, "g1_abcdefghij_fs4.zra"), "rb").read()
     assert zra.CompressBuffer(b"", 3, 65536, True) == open(os.path.join(GOLD, "g1_empty_fs65536.zra"), "rb").read()
