@@ -617,7 +617,9 @@ __device__ u32 mf_dfast_lean(const ZraEncParams& P, u32* HL, u32* HS, const u8* 
       const u32 off = ip - m;
       // ---- issue together: forward compare (64 x 8 B), backward compare (64 x 1 B), rep gather for the next o1
       const u32 fa = ip + known + 8 * (u32)lane, fb = m + known + 8 * (u32)lane;
-      const bool fv = fa + 8 <= be;
+      // 16 lanes x 8 B: matches are ~10 bytes on average, and every 64-byte line of the match source is a likely DRAM request
+      // (the kernel is bound by the DRAM request rate); longer matches take the wave_count_eq loop below
+      const bool fv = (u32)lane < 16 && fa + 8 <= be;
       const u64 xa = fv ? ld64(src + fa) : 0, xb = fv ? ld64(src + fb) : 0;
       const u32 lim = isRep ? 0u : min(ip - anchor, m);
       u32 ya = 0, yb = 1;
