@@ -274,8 +274,9 @@ Status Engine::compress_persistent(const uint8_t* dIn, size_t inSize, uint8_t* d
   const uint32_t nSlots = (uint32_t)std::min<uint64_t>((uint64_t)numCUs_ * wavesPerCU, nFramesTotal);
   // per-frame scratch that lives from the match finder to the entropy stage: sequences + block record + checksum + size/offset
   const uint64_t perFrame = seqStride * 8 + sizeof(ZraEncFrameState) + sizeof(ZraEncBlockOut) + 4 + 16 + 8;
-  const uint64_t budget = 24ull << 30;
+  const uint64_t budget = 8ull << 30;              // per context; launch length is not critical (sweep in the log: 16 K ... 128 K frames within noise)
   uint64_t SBIG = std::max<uint64_t>(1, std::min<uint64_t>(nFramesTotal, budget / perFrame));
+  if (const char* e = std::getenv("ZRA_ENC_SUPER")) SBIG = std::max<uint64_t>(1, std::min<uint64_t>(SBIG, (uint64_t)std::atoll(e)));   // bring-up knob
   if (SBIG > SB) SBIG -= SBIG % SB;
   const int nCtx = nFramesTotal > SBIG ? 2 : 1;
   const uint64_t nSuper = (nFramesTotal + SBIG - 1) / SBIG;
