@@ -555,7 +555,16 @@ zra_entropy_kernel(ZraEncArgs a, u32 block) {
           const u32 e = atomicAdd(&S.longCount, 1u);
           S.stage[3 * e] = lp; S.stage[3 * e + 1] = sp; S.stage[3 * e + 2] = ll;
         } else {
-          for (u32 b = 0; b < ll; b++) { const u8 c = src[sp + b]; lits[lp + b] = c; atomicAdd(&S.lit.hist[wave][c], 1u); }
+          // up to 31 bytes: four independent 8-byte loads in flight instead of a byte-by-byte chain of global round trips
+          // (under the match finder's DRAM load a round trip costs microseconds); stores and histogram come from registers
+          const u8* const se = src + fsize;
+          u64 w[4];
+#pragma unroll
+          for (int q = 0; q < 4; q++) w[q] = 8u * q < ll ? ld64_safe(src + sp + 8 * q, se) : 0;
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            for (u32 b = 8u * q; b < ll && b < 8u * q + 8; b++) { const u8 c = (u8)(w[q] >> (8 * (b & 7))); lits[lp + b] = c; atomicAdd(&S.lit.hist[wave][c], 1u); }
+          }
         }
         lp += ll; sp += ll + mlv[k];
       }
