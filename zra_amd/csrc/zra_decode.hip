@@ -32,27 +32,37 @@ __constant__ short c_ml_defnorm[53] = {1,4,3,2,2,2,2,2,2,1,1,1,1,1,1,1,1,1,1,1,1
                                        1,1,1,1,1,1,1,1,1,1,1,1,1,1,-1,-1,-1,-1,-1,-1,-1};
 __constant__ short c_of_defnorm[29] = {1,1,1,1,1,1,2,2,2,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,-1,-1,-1,-1,-1};
 
-// decode-table entry for LL / ML / OF (8 bytes): baseValue | nbAddBits<<32 | nbBits<<40 | nextBase<<48
+// FSE decode cell of the Huffman-weight table (8 bytes): symbol | nbBits<<40 | nextBase<<48
 __device__ __forceinline__ u64 mk_seqsym(u32 baseValue, u32 addBits, u32 nbBits, u32 nextBase) {
   return (u64)baseValue | ((u64)addBits << 32) | ((u64)nbBits << 40) | ((u64)nextBase << 48);
 }
+// decode-table cell for LL / ML / OF (4 bytes): symbol | extraBits<<8 | nbBits<<16 | nextBase<<20. Everything that positions
+// the bit reader (extra bits, state bits) is in the cell; the base value is looked up by symbol off that chain. 4-byte cells
+// (2 KiB per 512-cell table instead of 4) are what lets 20 frames share a CU's LDS: the decoder is latency-bound and its
+// throughput is proportional to the frames in flight (profiles/r01_mf_occupancy_sweep.log, decode sweep).
+__device__ __forceinline__ u32 mk_cell(u32 sym, u32 addBits, u32 nbBits, u32 nextBase) {
+  return sym | (addBits << 8) | (nbBits << 16) | (nextBase << 20);
+}
 
 struct __attribute__((aligned(16))) DecShared {
-  // The Huffman literal table is only live while the literal streams are decoded, the LL table only while sequences are decoded:
-  // they share 4 KiB. What is needed to rebuild either one for a later block of the same frame (treeless literals, repeat-mode
-  // LL table) is kept below (weights / llNorm), so 12 frames fit a CU's LDS instead of 9.
+  // The Huffman literal table is only live while the literal streams are decoded, the LL and ML tables only while sequences are
+  // decoded: they share 4 KiB. What is needed to rebuild them for a later block of the same frame (treeless literals, repeat-mode
+  // tables) is kept below (weights / llNorm / mlNorm).
   union {
-    u64 llT[512];
+    struct { u32 llT[512]; u32 mlT[512]; };
     u16 huf[2048];          // sym | nbBits<<8 ; doubles as scratch while a tree description is parsed
   };
-  u64 mlT[512];
-  u64 ofT[256];
-  short llNorm[36];         // normalised counts of the last non-RLE LL table (rebuild on repeat mode)
-  u32 llSaveLog, llSaveMax, llSaveRle;   // llSaveRle: 0 = FSE table described by llNorm, else 1 + RLE symbol
-  u32 seqLL[BATCH], seqML[BATCH], seqOF[BATCH];
-  short norm[256];          // scratch: normalised counts while building a table
+  u32 ofT[256];
+  u32 llBase[36], mlBase[53];   // base values by symbol (copied from constant memory once per workgroup)
+  short llNorm[36];         // normalised counts of the last non-RLE LL / ML table (rebuild on repeat mode)
+  short mlNorm[53];
+  u32 llSaveLog, llSaveMax, llSaveRle;   // xxSaveRle: 0 = FSE table described by xxNorm, else 1 + RLE symbol
+  u32 mlSaveLog, mlSaveMax, mlSaveRle;
+  union {
+    struct { short norm[256]; u8 spread[512]; };      // scratch while a table is described / built
+    struct { u32 seqLL[BATCH], seqML[BATCH], seqOF[BATCH]; };   // one batch of decoded sequences
+  };
   u8 weights[256];
-  u8 spread[512];
   u32 rankStart[16];
   // control words (written by lane 0, read by the wave after a wave sync)
   u32 err;
@@ -121,7 +131,7 @@ __device__ u32 read_ncount(short* norm, u32* maxSymIO, u32* tableLogOut, const u
 
 // Build an FSE decode table from norm[] (single wave; lanes cooperate on the final fill).
 // kind: 0 = LL, 1 = ML, 2 = OF
-__device__ void build_fse_dtable(u64* table, const short* norm, u32 maxSym, u32 tableLog, int kind, u8* spread, int lane) {
+__device__ void build_fse_dtable(u32* table, const short* norm, u32 maxSym, u32 tableLog, int kind, u8* spread, int lane) {
   u32 size = 1u << tableLog, mask = size - 1;
   if (lane == 0) {
     u32 high = size - 1, step = (size >> 1) + (size >> 3) + 3, pos = 0;
@@ -145,11 +155,7 @@ __device__ void build_fse_dtable(u64* table, const short* norm, u32 maxSym, u32 
       if (spread[u] != s) continue;
       u32 nbBits = tableLog - hb32(x);
       u32 nextBase = (x << nbBits) - size;
-      u64 e;
-      if (kind == 0) e = mk_seqsym(c_ll_base[s], c_ll_bits[s], nbBits, nextBase);
-      else if (kind == 1) e = mk_seqsym(c_ml_base[s], c_ml_bits[s], nbBits, nextBase);
-      else e = mk_seqsym(1u << s, s, nbBits, nextBase);
-      table[u] = e;
+      table[u] = mk_cell(s, kind == 0 ? c_ll_bits[s] : kind == 1 ? c_ml_bits[s] : s, nbBits, nextBase);
       x++;
     }
   }
@@ -322,11 +328,13 @@ __device__ void seq_table_parse(DecShared& S, int kind, u32 mode, const u8* p, u
 }  // namespace
 
 // =================================================================================================
-extern "C" __global__ void __launch_bounds__(DEC_THREADS, 3)   // 3 waves/SIMD = the 12 frames per CU the LDS footprint admits
+extern "C" __global__ void __launch_bounds__(DEC_THREADS, 5)   // 5 waves/SIMD = 20 frames per CU (7.3 KiB of LDS each)
 zra_decode_frames_kernel(ZraDecodeArgs a) {
   __shared__ DecShared S;
   const int lane = threadIdx.x;
   u8* const litScratch = a.litScratch + (size_t)blockIdx.x * ZRA_LIT_STRIDE;
+  if (lane < 36) S.llBase[lane] = c_ll_base[lane];
+  if (lane < 53) S.mlBase[lane] = c_ml_base[lane];
 
   for (;;) {
     if (lane == 0) S.frame = atomicAdd(a.queue, 1u);
@@ -483,20 +491,28 @@ zra_decode_frames_kernel(ZraDecodeArgs a) {
           }
           wsync();
           if (S.err) { bad = true; break; }
-          u64* table = k == 0 ? S.llT : k == 1 ? S.mlT : S.ofT;
+          u32* table = k == 0 ? S.llT : k == 1 ? S.mlT : S.ofT;
           const u32 tl = S.tl, ms = S.ms;
           if (mode == 1) {
-            if (lane == 0) table[0] = k == 0 ? mk_seqsym(c_ll_base[ms], c_ll_bits[ms], 0, 0) : k == 1 ? mk_seqsym(c_ml_base[ms], c_ml_bits[ms], 0, 0) : mk_seqsym(1u << ms, ms, 0, 0);
+            if (lane == 0) table[0] = mk_cell(ms, k == 0 ? c_ll_bits[ms] : k == 1 ? c_ml_bits[ms] : ms, 0, 0);
             if (k == 0 && lane == 0) S.llSaveRle = 1 + ms;
+            if (k == 1 && lane == 0) S.mlSaveRle = 1 + ms;
           } else if (mode != 3) {
             build_fse_dtable(table, S.norm, ms, tl, k, S.spread, lane);
-            if (k == 0) {                                  // remember how to rebuild it (its LDS is reused by the next Huffman table)
+            // remember how to rebuild LL / ML (their LDS is reused by the next block's Huffman table)
+            if (k == 0) {
               if ((u32)lane <= ms) S.llNorm[lane] = S.norm[lane];
               if (lane == 0) { S.llSaveLog = tl; S.llSaveMax = ms; S.llSaveRle = 0; }
+            } else if (k == 1) {
+              if ((u32)lane <= ms) S.mlNorm[lane] = S.norm[lane];
+              if (lane == 0) { S.mlSaveLog = tl; S.mlSaveMax = ms; S.mlSaveRle = 0; }
             }
           } else if (k == 0) {                             // repeat mode: the literal decode of this block overwrote the table
-            if (S.llSaveRle) { if (lane == 0) { const u32 sy = S.llSaveRle - 1; table[0] = mk_seqsym(c_ll_base[sy], c_ll_bits[sy], 0, 0); } }
+            if (S.llSaveRle) { if (lane == 0) { const u32 sy = S.llSaveRle - 1; table[0] = mk_cell(sy, c_ll_bits[sy], 0, 0); } }
             else build_fse_dtable(table, S.llNorm, S.llSaveMax, S.llSaveLog, 0, S.spread, lane);
+          } else if (k == 1) {
+            if (S.mlSaveRle) { if (lane == 0) { const u32 sy = S.mlSaveRle - 1; table[0] = mk_cell(sy, c_ml_bits[sy], 0, 0); } }
+            else build_fse_dtable(table, S.mlNorm, S.mlSaveMax, S.mlSaveLog, 1, S.spread, lane);
           }
           if (lane == 0 && mode != 3) {
             if (k == 0) { S.llLog = tl; S.llValid = 1; } else if (k == 1) { S.mlLog = tl; S.mlValid = 1; } else { S.ofLog = tl; S.ofValid = 1; }
@@ -527,20 +543,21 @@ zra_decode_frames_kernel(ZraDecodeArgs a) {
         if (lane == 0) {
           u32 bad = 0;
           for (u32 i = 0; i < cnt; i++) {
-            const u64 eL = S.llT[sLL], eM = S.mlT[sML], eO = S.ofT[sOF];
-            const u32 ofBits = (u32)(eO >> 32) & 0xFF, mlBits = (u32)(eM >> 32) & 0xFF, llBits = (u32)(eL >> 32) & 0xFF;
+            const u32 eL = S.llT[sLL], eM = S.mlT[sML], eO = S.ofT[sOF];
+            const u32 ofBits = (eO >> 8) & 0xFF, mlBits = (eM >> 8) & 0xFF, llBits = (eL >> 8) & 0xFF;
             if (ofBits > 31) { bad = 1; break; }
-            u32 offVal = (u32)eO + br.read((int)ofBits);
+            const u32 baseL = S.llBase[eL & 0xFF], baseM = S.mlBase[eM & 0xFF];   // by symbol; not on the bit-position chain
+            u32 offVal = (1u << ofBits) + br.read((int)ofBits);
             // match-length and literal-length extra bits in one extraction (<= 32 bits; ML was written first = upper part)
             const u32 both = br.read((int)(mlBits + llBits));
-            const u32 ml = (u32)eM + (both >> llBits), ll = (u32)eL + (both & ((1u << llBits) - 1));
+            const u32 ml = baseM + (both >> llBits), ll = baseL + (both & ((1u << llBits) - 1));
             if (first + i + 1 < nbSeq) {
-              const int nL = (int)((eL >> 40) & 0xFF), nM = (int)((eM >> 40) & 0xFF), nO = (int)((eO >> 40) & 0xFF);
+              const int nL = (int)((eL >> 16) & 0xF), nM = (int)((eM >> 16) & 0xF), nO = (int)((eO >> 16) & 0xF);
               // LL, ML, OF state bits in one extraction (<= 26 bits): LL is read first = topmost
               const u32 st = br.read(nL + nM + nO);
-              sLL = (u32)(eL >> 48) + (st >> (nM + nO));
-              sML = (u32)(eM >> 48) + ((st >> nO) & ((1u << nM) - 1));
-              sOF = (u32)(eO >> 48) + (st & ((1u << nO) - 1));
+              sLL = (eL >> 20) + (st >> (nM + nO));
+              sML = (eM >> 20) + ((st >> nO) & ((1u << nM) - 1));
+              sOF = (eO >> 20) + (st & ((1u << nO) - 1));
             }
             if (br.pos < 0) { bad = 1; break; }
             u32 off;                                   // repcode resolution (A.3)

@@ -161,6 +161,7 @@ Status Engine::decode_jobs(const uint8_t* dBody, uint64_t bodySize, const uint64
   int perCU = 0;
   HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, zra_decode_frames_kernel, 64, 0));
   if (perCU < 1) perCU = 1;
+  { static const int cap = std::getenv("ZRA_DEC_WAVES") ? std::atoi(std::getenv("ZRA_DEC_WAVES")) : 0; if (cap > 0 && cap < perCU) perCU = cap; }   // bring-up: occupancy sweep
   uint32_t grid = (uint32_t)std::min<uint64_t>(nFrames, (uint64_t)numCUs_ * perCU);
   if (!litScratch_.reserve((size_t)grid * ZRA_LIT_STRIDE) || !queue_.reserve(64) || !status_.reserve((size_t)nFrames * 4) ||
       !produced_.reserve((size_t)nFrames * 4) || !frameMeta_.reserve((size_t)nFrames * 8) || !result_.reserve(64))
