@@ -328,7 +328,7 @@ __device__ void seq_table_parse(DecShared& S, int kind, u32 mode, const u8* p, u
 }  // namespace
 
 // =================================================================================================
-extern "C" __global__ void __launch_bounds__(DEC_THREADS, 5)   // 5 waves/SIMD = 20 frames per CU (7.3 KiB of LDS each)
+extern "C" __global__ void __launch_bounds__(DEC_THREADS, 6)   // 6 waves/SIMD; LDS (7 KiB per frame) admits 22 frames per CU
 zra_decode_frames_kernel(ZraDecodeArgs a) {
   __shared__ DecShared S;
   const int lane = threadIdx.x;
