@@ -85,7 +85,7 @@ static size_t mf_fast(cctx* c, const u8* src, size_t bs, size_t be, u32 rep[3]) 
   u32* T = c->hashTable; u32 hlog = c->cp.hashLog, mls = c->cp.minMatch;
   u32 tl = c->cp.targetLength; size_t step0 = tl + (tl == 0) + 1;
   u32 o1 = rep[0], o2 = rep[1], saved;
-  size_t anchor = bs, ilimit = be - 8;
+  size_t anchor = bs, ilimit = be >= 8 ? be - 8 : 0;   /* a 7-byte first block: iend-8 lies before the start, nothing is searched */
   size_t ip0 = mf_prologue(bs, &o1, &o2, &saved), ip1 = ip0 + 1;
   while (ip1 < ilimit) {
     size_t ip2 = ip0 + 2, top = ip0;
@@ -129,7 +129,7 @@ static size_t mf_dfast(cctx* c, const u8* src, size_t bs, size_t be, u32 rep[3])
   u32* HL = c->hashTable; u32* HS = c->chainTable;
   u32 hlog = c->cp.hashLog, clog = c->cp.chainLog, mls = c->cp.minMatch;
   u32 o1 = rep[0], o2 = rep[1], saved;
-  size_t anchor = bs, ilimit = be - 8;
+  size_t anchor = bs, ilimit = be >= 8 ? be - 8 : 0;   /* a 7-byte first block: iend-8 lies before the start, nothing is searched */
   size_t ip = mf_prologue(bs, &o1, &o2, &saved);
   while (ip < ilimit) {
     size_t top = ip, ml; u32 offVal;
@@ -203,7 +203,7 @@ static size_t hc_search(cctx* c, const u8* src, size_t ip, size_t be, u32* offCo
 
 static size_t mf_lazy(cctx* c, const u8* src, size_t bs, size_t be, u32 rep[3], int depth) {
   u32 o1 = rep[0], o2 = rep[1], saved;
-  size_t anchor = bs, ilimit = be - 8;
+  size_t anchor = bs, ilimit = be >= 8 ? be - 8 : 0;   /* a 7-byte first block: iend-8 lies before the start, nothing is searched */
   size_t ip = mf_prologue(bs, &o1, &o2, &saved);
   while (ip < ilimit) {
     size_t ml = 0, start = ip + 1; u32 off = 0; int stored = 0;

@@ -91,6 +91,75 @@ def test_match_finder_sequences_equal_the_oracle(zra, gpu_engine, gens, level, f
             assert seqs + [(last_ll, 0, 0)] == ref, (name, level, fs, f)
 
 
+def _random_input(rng, n):
+    """Synthetic LZ-style data: literal runs of varying entropy interleaved with copies of earlier spans (incl. overlapping ones)."""
+    out = bytearray()
+    alpha = rng.choice([2, 4, 16, 64, 256])
+    while len(out) < n:
+        r = rng.rand()
+        if r < 0.35 or len(out) < 8:
+            k = int(rng.choice([1, 3, 7, 20, 100, 700]))
+            out += bytes(rng.randint(0, alpha, size=k).astype(np.uint8).tolist())
+        elif r < 0.85:
+            off = int(min(len(out), rng.choice([1, 2, 3, 4, 8, 17, 64, 300, 5000, 70000])))
+            off = max(1, min(off, len(out)))
+            k = int(rng.choice([3, 4, 5, 8, 12, 40, 300, 3000]))
+            st = len(out) - off
+            for i in range(k):
+                out.append(out[st + i])
+        elif r < 0.93:
+            out += bytes([int(rng.randint(0, 256))]) * int(rng.choice([5, 40, 600, 9000]))
+        else:
+            alpha = rng.choice([2, 4, 16, 64, 256])
+    return bytes(out[:n])
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_randomised_differential_compress(zra, seed):
+    """Differential test against the oracle on seeded synthetic LZ data: random sizes, frame sizes and levels (25 cases per seed)."""
+    rng = np.random.RandomState(1000 + seed)
+    for case in range(25):
+        fs = int(rng.choice([1024, 4096, 16384, 65536, 65536, 131072, 262144, 50000]))
+        n = int(rng.choice([0, 1, 6, 7, 8, 100, fs - 1, fs, fs + 1, 3 * fs + 17, int(rng.randint(1, 6 * fs))]))
+        n = min(n, 600000)
+        level = int(rng.choice([1, 2, 3, 3, 3, 4, 5, 6, 7, 8, 9, 10]))
+        d = _random_input(rng, n)
+        st, ref = O.zra_compress(d, level, fs, bool(case & 1))
+        if st != (0, 0):
+            with pytest.raises(zra.ZraError) as e:
+                zra.CompressBuffer(d, level, fs, bool(case & 1))
+            assert (e.value.zra, e.value.zstd) == st
+            continue
+        arc = zra.CompressBuffer(d, level, fs, bool(case & 1))
+        assert arc == ref, (seed, case, n, fs, level)
+        assert zra.DecompressBuffer(arc) == d, (seed, case, n, fs, level)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_randomised_differential_decode(zra, seed):
+    """Decoder against archives written by the real libzstd at levels the encoder never produces (negative, btopt, btultra):
+    full decode and random-access reads on seeded synthetic LZ data (20 cases per seed)."""
+    if not O.have_libzstd():
+        pytest.skip("libzstd 1.4.x not present")
+    rng = np.random.RandomState(5000 + seed)
+    for case in range(20):
+        fs = int(rng.choice([1024, 4096, 16384, 65536, 131072, 262144, 1 << 20, 50000]))
+        n = int(rng.choice([1, 7, 100, fs, fs + 1, 2 * fs + 17, int(rng.randint(1, 4 * fs))]))
+        n = min(n, 1500000)
+        level = int(rng.choice([-5, -1, 1, 3, 6, 9, 12, 13, 16, 19, 22]))
+        d = _random_input(rng, n)
+        st, arc = O.zra_compress(d, level, fs, bool(case & 1), 0, "zl")
+        assert st == (0, 0)
+        assert zra.DecompressBuffer(arc) == d, (seed, case, n, fs, level)
+        if n > 2:
+            for _ in range(3):
+                off = int(rng.randint(0, n - 1)); sz = int(rng.randint(1, n - off))
+                if off + sz >= n:
+                    sz = n - off - 1
+                if sz > 0:
+                    assert zra.DecompressRA(arc, off, sz) == d[off:off + sz], (seed, case, off, sz)
+
+
 def test_compress_edge_cases(zra):
     assert zra.CompressBuffer(b"abcdefghij", 3, 4, True) == open(os.path.join(GOLD, "g1_abcdefghij_fs4.zra"), "rb").read()
     assert zra.CompressBuffer(b"", 3, 65536, True) == open(os.path.join(GOLD, "g1_empty_fs65536.zra"), "rb").read()

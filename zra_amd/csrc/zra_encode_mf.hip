@@ -68,7 +68,7 @@ __device__ u32 mf_fast(const ZraEncParams& P, u32* T, const u8* src, u32 bs, u32
   const u32 step0 = P.targetLength + (P.targetLength == 0) + 1;
   u32 o1 = rep[0], o2 = rep[1], saved;
   u32 anchor = bs;
-  const u32 ilimit = be - 8;
+  const u32 ilimit = be >= 8 ? be - 8 : 0;            // a 7-byte first block: iend-8 lies before the start, nothing is searched
   u32 ip0 = mf_prologue(bs, o1, o2, saved), ip1 = ip0 + 1;
   while (ip1 < ilimit) {
     const u32 ip2 = ip0 + 2, top = ip0;
@@ -139,7 +139,7 @@ struct HC {
 __device__ u32 mf_lazy(HC& H, const u8* src, u32 bs, u32 be, u32* rep, Emit& E, int depth) {
   u32 o1 = rep[0], o2 = rep[1], saved;
   u32 anchor = bs;
-  const u32 ilimit = be - 8;
+  const u32 ilimit = be >= 8 ? be - 8 : 0;            // a 7-byte first block: iend-8 lies before the start, nothing is searched
   u32 ip = mf_prologue(bs, o1, o2, saved);
   while (ip < ilimit) {
     u32 ml = 0, start = ip + 1, off = 0; bool stored = false;
@@ -265,7 +265,7 @@ __device__ u32 mf_dfast_window(const ZraEncParams& P, T* HL, T* HS, const u8* sr
   const u32 hlog = P.hashLog, clog = P.chainLog, mls = P.minMatch;
   u32 o1 = rep[0], o2 = rep[1], saved;
   u32 anchor = bs, nseq = 0;
-  const u32 ilimit = be - 8;
+  const u32 ilimit = be >= 8 ? be - 8 : 0;            // a 7-byte first block: iend-8 lies before the start, nothing is searched
   u32 ip = mf_prologue(bs, o1, o2, saved);
   u32 epoch = 1;
   PROF_DECL
@@ -493,7 +493,7 @@ __device__ u32 mf_dfast_lean(const ZraEncParams& P, u32* HL, u32* HS, const u8* 
   bs = rfl(bs); be = rfl(be);
   u32 o1 = rfl(rep[0]), o2 = rfl(rep[1]), saved;
   u32 anchor = bs, nseq = 0;
-  const u32 ilimit = be - 8;
+  const u32 ilimit = be >= 8 ? be - 8 : 0;            // a 7-byte first block: iend-8 lies before the start, nothing is searched
   u32 ip = mf_prologue(bs, o1, o2, saved);
   u32 sqLo = 0, sqHi = 0;                              // pending sequences, lane = index & 63
   u8* const dL = W.dup; u8* const dS = W.dup + W.dupSlots;
