@@ -234,6 +234,64 @@ def test_decompress_ra_vs_bruteforce(zra):
             assert zra.DecompressRA(arc, off, size) == data[off: off + size], (fs, off, size)
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_randomised_streaming_objects(zra, seed):
+    """Compressor fed with random chunkings, Decompressor with random reads and cache sizes, FullDecompressor with random buffer
+    sizes — all against the oracle's in-memory archive / the original bytes (zra.cpp:304-436 semantics)."""
+    L = zra.load()
+    rng = np.random.RandomState(9000 + seed)
+    for case in range(4):
+        fs = int(rng.choice([1024, 4096, 16384, 65536]))
+        nfr = int(rng.randint(1, 40))
+        n = nfr * fs - int(rng.choice([0, 0, 1, fs // 2, fs - 1]))
+        level = int(rng.choice([1, 3, 3, 5, 9]))
+        data = _random_input(rng, n)
+        st, ref = O.zra_compress(data, level, fs, True)
+        if st != (0, 0):
+            continue
+        c = ctypes.c_void_p()
+        assert L.ZraCreateCompressor(ctypes.byref(c), len(data), level, fs, True, None, 0).tup() == (0, 0)
+        body = b""; pos = 0
+        while pos < len(data):
+            k = int(rng.randint(1, 9)) * fs
+            chunk = data[pos: pos + k]
+            out = ctypes.create_string_buffer(L.ZraGetOutputBufferSizeWithCompressor(c, len(chunk)))
+            osz = ctypes.c_size_t(0)
+            assert L.ZraCompressWithCompressor(c, ctypes.create_string_buffer(chunk, len(chunk)), len(chunk), out, ctypes.byref(osz)).tup() == (0, 0)
+            body += out.raw[: osz.value]; pos += len(chunk)
+        hsz = L.ZraGetHeaderSizeWithCompressor(c)
+        hb = ctypes.create_string_buffer(hsz)
+        assert L.ZraGetHeaderWithCompressor(c, hb).tup() == (0, 0)
+        L.ZraDeleteCompressor(c)
+        arc = hb.raw[:hsz] + body
+        assert arc == ref, (seed, case, n, fs, level)
+
+        def rd(off, size, outp, arc=arc):
+            ctypes.memmove(outp, arc[off: off + size], size)
+        cb = zra.READ_FN(rd)
+        d = ctypes.c_void_p()
+        assert L.ZraCreateDecompressor(ctypes.byref(d), cb, int(rng.choice([1, 4096, 1 << 20]))).tup() == (0, 0)
+        for _ in range(6):
+            off = int(rng.randint(0, n)); size = int(rng.randint(1, n - off + 1))
+            out = ctypes.create_string_buffer(size)
+            assert L.ZraDecompressWithDecompressor(d, off, size, out).tup() == (0, 0)
+            assert out.raw == data[off: off + size], (seed, case, off, size)
+        L.ZraDeleteDecompressor(d)
+        fd = ctypes.c_void_p()
+        assert L.ZraCreateFullDecompressor(ctypes.byref(fd), cb, 0).tup() == (0, 0)
+        cap = int(rng.randint(1, 7)) * fs + int(rng.randint(0, fs))
+        out = ctypes.create_string_buffer(cap)
+        got = b""
+        for _ in range(10000):
+            osz = ctypes.c_size_t(0)
+            assert L.ZraDecompressWithFullDecompressor(fd, out, cap, ctypes.byref(osz)).tup() == (0, 0)
+            if osz.value == 0:
+                break
+            got += out.raw[: osz.value]
+        L.ZraDeleteFullDecompressor(fd)
+        assert got == data, (seed, case, n, fs, cap)
+
+
 def test_streaming_objects(zra):
     L = zra.load()
     data = C.gen_E(1 << 20)[200000:200000 + 16384 * 9 + 1000]
