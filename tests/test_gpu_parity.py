@@ -292,6 +292,37 @@ def test_randomised_streaming_objects(zra, seed):
         assert got == data, (seed, case, n, fs, cap)
 
 
+@pytest.mark.parametrize("seed", range(4))
+def test_randomised_batched_random_access(zra, gpu_engine, seed):
+    """ZraHipDecompressRABatch: random mixes of tiny, frame-straddling and multi-frame queries (duplicates and overlaps included)
+    against slices of the original; one out-of-bounds query fails the whole call with OutOfBoundsAccess (zra.cpp:260 rule)."""
+    import torch
+    dev = torch.device("cuda", 0)
+    rng = np.random.RandomState(7000 + seed)
+    fs = int(rng.choice([4096, 16384, 65536]))
+    n = int(rng.randint(20, 200)) * fs + int(rng.randint(0, fs))
+    data = _random_input(rng, n)
+    d_in = torch.from_numpy(np.frombuffer(data, dtype=np.uint8).copy()).to(dev)
+    d_arc = torch.empty(zra.GetOutputBufferSize(n, fs) + 64, dtype=torch.uint8, device=dev)
+    asz = gpu_engine.compress(d_in.data_ptr(), n, d_arc.data_ptr(), 3, fs, True)
+    nq = 3000
+    sizes = rng.choice([1, 2, 100, fs - 1, fs, fs + 1, 3 * fs + 5, 20 * fs], size=nq).astype(np.int64)
+    sizes = np.minimum(sizes, n - 2)
+    offs = np.array([rng.randint(0, n - int(sz) - 1) for sz in sizes], dtype=np.int64)
+    offs[:50] = offs[50:100]; sizes[:50] = sizes[50:100]                       # exact duplicates
+    oofs = np.concatenate([[0], np.cumsum(sizes)[:-1]])
+    d_out = torch.zeros(int(sizes.sum()), dtype=torch.uint8, device=dev)
+    gpu_engine.decompress_ra_batch(d_arc.data_ptr(), asz, d_out.data_ptr(), offs, sizes, oofs)
+    host = d_out.cpu().numpy().tobytes()
+    for i in range(nq):
+        o, sz, oo = int(offs[i]), int(sizes[i]), int(oofs[i])
+        assert host[oo: oo + sz] == data[o: o + sz], (seed, i, o, sz)
+    bad_offs = offs.copy(); bad_offs[7] = n - int(sizes[7])                    # offset + size == uncompressedSize -> refused
+    with pytest.raises(zra.ZraError) as e:
+        gpu_engine.decompress_ra_batch(d_arc.data_ptr(), asz, d_out.data_ptr(), bad_offs, sizes, oofs)
+    assert e.value.zra == 5
+
+
 def test_streaming_objects(zra):
     L = zra.load()
     data = C.gen_E(1 << 20)[200000:200000 + 16384 * 9 + 1000]
