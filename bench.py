@@ -188,7 +188,7 @@ def main():
     # ---- bit-exactness gate + CPU baseline (rank 0): first 1 GiB of the same corpus through the CPU path
     cpu = None
     gate = "skipped"
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:      # N=1 only (bench contract); N>1 runs reuse the N=1 gate
         samp = min(N, 1 << 30)
         cpu, cpu_arc = cpu_baseline(np.resize(base, samp), fs, args.level, 50000, qb)
         d_s = d_in[:samp]
