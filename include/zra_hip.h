@@ -64,6 +64,14 @@ ZRA_EXPORT double ZraHipLastKernelMs(ZraHipEngine* engine);
  *  out6 = {match-finder ms, launches, entropy-stage ms, launches, decode ms, launches}. */
 ZRA_EXPORT void ZraHipGetKernelStats(ZraHipEngine* engine, double* out6);
 
+/* ---- opt-in integrity options (default 0: bit- and error-compatible with the reference, quirks included) ---- */
+#define ZRA_HIP_OPT_VERIFY_HEADER_CRC 1u     /* Header constructors check the CRC-32 the reference writes but never reads (zra.cpp:128-133) */
+#define ZRA_HIP_OPT_INCLUSIVE_RA_BOUND 2u    /* DecompressRA accepts offset+size == uncompressedSize (reference: '>=', zra.cpp:260) */
+#define ZRA_HIP_OPT_STORE_META_IN_MEMORY 4u  /* in-memory CompressBuffer stores `meta` like the streaming Compressor (reference: zra.cpp:202-205) */
+/** Process-wide; affects the zra.h / zra.hpp entry points. */
+ZRA_EXPORT void ZraHipSetOptions(uint32_t mask);
+ZRA_EXPORT uint32_t ZraHipGetOptions(void);
+
 /** Bring-up aid (not a product entry point): the match finder's sequences {litLength | matchLength<<20 | offsetValue<<40} left in
  *  scratch for frame `frame` of the last compress call's last batch (last block of the frame); meta3 = {nbSeq, lastLL, skip}. */
 ZRA_EXPORT uint32_t ZraHipDebugReadSeqs(ZraHipEngine* engine, uint32_t frame, uint64_t* out, uint32_t cap, uint32_t* meta3);

@@ -323,6 +323,49 @@ def test_randomised_batched_random_access(zra, gpu_engine, seed):
     assert e.value.zra == 5
 
 
+def test_opt_in_integrity_options(zra):
+    """header CRC verification, inclusive RA bound and in-memory meta storage are OFF by default (reference-compatible,
+    quirks covered by the tests above) and change exactly those behaviours when switched on."""
+    L = zra.load()
+    L.ZraHipSetOptions.argtypes = [ctypes.c_uint32]; L.ZraHipGetOptions.restype = ctypes.c_uint32
+    d = C.gen_C(1 << 18)
+    arc = zra.CompressBuffer(d, 3, 65536, True)
+    flipped = bytearray(arc); flipped[40] ^= 1; flipped = bytes(flipped)          # one seek-table bit: CRC no longer matches
+    assert L.ZraHipGetOptions() == 0
+    try:
+        # default: CRC never checked (zra.cpp:141-163), last byte unreachable through DecompressRA (zra.cpp:260)
+        zra.DecompressRA(arc, 0, 10)
+        with pytest.raises(zra.ZraError) as e:
+            zra.DecompressRA(arc, len(d) - 10, 10)
+        assert e.value.zra == 5
+        L.ZraHipSetOptions(1)
+        assert zra.DecompressBuffer(arc) == d                                       # intact header still opens
+        with pytest.raises(zra.ZraError) as e:
+            zra.DecompressRA(flipped, 0, 10)
+        assert e.value.zra == 3                                                     # HeaderInvalid
+        L.ZraHipSetOptions(2)
+        assert zra.DecompressRA(arc, len(d) - 10, 10) == d[-10:]
+        with pytest.raises(zra.ZraError) as e:
+            zra.DecompressRA(arc, len(d) - 10, 11)
+        assert e.value.zra == 5
+        L.ZraHipSetOptions(4)
+        out = ctypes.create_string_buffer(zra.GetOutputBufferSize(len(d), 65536) + 16)
+        osz = ctypes.c_size_t(0)
+        meta = b"0123456789abcdef"
+        st = L.ZraCompressBuffer(ctypes.create_string_buffer(d, len(d)), len(d), out, ctypes.byref(osz), 3, 65536, True, ctypes.create_string_buffer(meta, len(meta)), len(meta))
+        assert st.tup() == (0, 0)
+        with_meta = out.raw[: osz.value]
+        assert len(with_meta) == len(arc) + len(meta) and with_meta[38:38 + len(meta)] == meta
+        L.ZraHipSetOptions(1)                                                       # and that archive has a valid CRC and decodes
+        assert zra.DecompressBuffer(with_meta) == d
+        h = ctypes.c_void_p()
+        assert L.ZraCreateHeader2(ctypes.byref(h), ctypes.create_string_buffer(with_meta, len(with_meta)), len(with_meta)).tup() == (0, 0)
+        assert L.ZraGetMetadataSize(h) == len(meta)
+        L.ZraDeleteHeader(h)
+    finally:
+        L.ZraHipSetOptions(0)
+
+
 def test_streaming_objects(zra):
     L = zra.load()
     data = C.gen_E(1 << 20)[200000:200000 + 16384 * 9 + 1000]

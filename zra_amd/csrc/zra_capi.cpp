@@ -7,6 +7,7 @@
 #include "zra_engine.h"
 #include "zra_format.h"
 
+#include <atomic>
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
@@ -88,6 +89,12 @@ int walk_frames(const zra::u8* body, size_t n, std::vector<uint64_t>& starts, st
 }
 }  // namespace
 
+namespace {
+// Opt-in integrity options (default 0 = reference-compatible, quirks included). Set through ZraHipSetOptions.
+std::atomic<uint32_t> g_options{0};
+enum : uint32_t { kOptVerifyHeaderCrc = 1, kOptInclusiveRaBound = 2, kOptStoreMetaInMemory = 4 };
+}  // namespace
+
 namespace zra {
   // ------------------------------------------------------------------ errors (zra.cpp:46-86)
   Exception::Exception(StatusCode code, i32 zstdCode) : code(code), zstdCode(zstdCode) {}
@@ -127,6 +134,13 @@ namespace zra {
     version = h.version; size = h.size; uncompressedSize = h.uncompressedSize; frameSize = h.frameSize;
     metaOffset = h.metaOffset; metaSize = h.metaSize; seekTableOffset = h.seekTableOffset; seekTableSize = h.seekTableSize;
     if (e) throw Exception(static_cast<StatusCode>(e));
+    if (g_options.load() & kOptVerifyHeaderCrc) {
+      // the reference writes the CRC-32 (zra.cpp:128-133,231,346) and never checks it; opt-in check on open
+      if (size < fmt::kFixedSize) throw Exception(StatusCode::HeaderInvalid);
+      Buffer rest(size - fmt::kFixedSize);
+      if (!rest.empty()) readFunction(fmt::kFixedSize, rest.size(), rest.data());
+      if (fmt::header_hash(fixed, rest.data()) != fmt::rd32(fixed + 14)) throw Exception(StatusCode::HeaderInvalid);
+    }
   }
 
   // The reference captures the view by reference (dangling for temporaries, zra.cpp:165); we keep a copy of the
@@ -152,11 +166,20 @@ namespace zra {
   size_t CompressBuffer(const BufferView& input, const BufferView& output, i8 level, u32 frameSize, bool checksum, const BufferView& meta) {
     u32 tableSize = fmt::table_size(input.size, frameSize);
     size_t need = fmt::kFixedSize + (size_t)tableSize * fmt::kEntrySize + fmt::compress_bound(frameSize) * (size_t)(tableSize - 1);
+    const bool storeMeta = meta.size && (g_options.load() & kOptStoreMetaInMemory);
+    if (storeMeta) need += meta.size;
     if (output.size < need) throw Exception(StatusCode::OutputBufferTooSmall);   // meta not counted, zra.cpp:196
     std::lock_guard<std::mutex> lk(g_mu);
     size_t outSize = 0;
     check(default_engine().compress_host(input.data, input.size, output.data, &outSize, level, frameSize, checksum));
-    if (meta.size) {
+    if (storeMeta) {
+      // opt-in fix of the quirk below: the archive the streaming Compressor would write (meta stored, table behind it)
+      std::memmove(output.data + fmt::kFixedSize + meta.size, output.data + fmt::kFixedSize, outSize - fmt::kFixedSize);
+      std::memcpy(output.data + fmt::kFixedSize, meta.data, meta.size);
+      fmt::write_fixed(output.data, input.size, tableSize, frameSize, (u32)meta.size);
+      fmt::wr32(output.data + 14, fmt::header_hash(output.data, output.data + fmt::kFixedSize));
+      outSize += meta.size;
+    } else if (meta.size) {
       // reference quirk (zra.cpp:202-205,231): meta is counted in headerSize/metaSize but never stored, the table stays at
       // +38, and the CRC then runs meta.size bytes into the body. Reproduced bit-for-bit.
       fmt::write_fixed(output.data, input.size, tableSize, frameSize, (u32)meta.size);
@@ -166,7 +189,7 @@ namespace zra {
   }
 
   Buffer CompressBuffer(const BufferView& buffer, i8 level, u32 frameSize, bool checksum, const BufferView& meta) {
-    Buffer output(GetOutputBufferSize(buffer.size, frameSize));   // meta not counted, zra.cpp:237
+    Buffer output(GetOutputBufferSize(buffer.size, frameSize, (g_options.load() & kOptStoreMetaInMemory) ? (u32)meta.size : 0));   // meta not counted, zra.cpp:237
     output.resize(CompressBuffer(buffer, output, level, frameSize, checksum, meta));
     output.shrink_to_fit();
     return output;
@@ -215,7 +238,9 @@ namespace zra {
 
   void DecompressRA(const BufferView& input, const BufferView& output, size_t offset, size_t size) {
     Header header(input);
-    if (offset + size >= header.uncompressedSize) throw Exception(StatusCode::OutOfBoundsAccess);   // ">=", zra.cpp:260
+    const bool inclusive = g_options.load() & kOptInclusiveRaBound;      // opt-in: the last byte becomes reachable, as in Decompressor
+    if (inclusive ? offset + size > header.uncompressedSize : offset + size >= header.uncompressedSize)
+      throw Exception(StatusCode::OutOfBoundsAccess);   // ">=", zra.cpp:260
     if (output.size < size) throw Exception(StatusCode::OutputBufferTooSmall);
     const u64 q = offset / header.frameSize, r = offset % header.frameSize;
     const u64 n = (r + size) / header.frameSize, t = (r + size) % header.frameSize;
@@ -375,7 +400,10 @@ size_t ZraGetCompressedOutputBufferSize(size_t inputSize, size_t frameSize) { re
 
 ZraStatus ZraCompressBuffer(void* in, size_t inSize, void* out, size_t* outSize, int8_t level, uint32_t frameSize, bool checksum, void* meta, size_t metaSize) {
   return guarded([&] {
-    *outSize = zra::CompressBuffer(zra::BufferView(in, inSize), zra::BufferView(out, zra::GetOutputBufferSize(inSize, frameSize)), level, frameSize,
+    // the wrapper assumes `out` holds ZraGetCompressedOutputBufferSize(inSize, frameSize) bytes (zra.cpp:510) — plus metaSize when the
+    // opt-in meta storage is on (the caller then sizes the buffer with the metaSize argument of that function)
+    const size_t cap = zra::GetOutputBufferSize(inSize, frameSize, (g_options.load() & kOptStoreMetaInMemory) ? (zra::u32)metaSize : 0);
+    *outSize = zra::CompressBuffer(zra::BufferView(in, inSize), zra::BufferView(out, cap), level, frameSize,
                                    checksum, zra::BufferView(meta, metaSize));
   });
 }
@@ -439,6 +467,8 @@ void ZraHipDestroyEngine(ZraHipEngine* engine) { if (engine) { delete engine->e;
 ZraStatus ZraHipSynchronize(ZraHipEngine* engine) { return mk(engine->e->sync()); }
 void* ZraHipGetStream(ZraHipEngine* engine) { return (void*)engine->e->stream(); }
 double ZraHipLastKernelMs(ZraHipEngine* engine) { return engine->e->last_kernel_ms(); }
+void ZraHipSetOptions(uint32_t mask) { g_options.store(mask); }
+uint32_t ZraHipGetOptions(void) { return g_options.load(); }
 void ZraHipGetKernelStats(ZraHipEngine* engine, double* out6) { engine->e->kernel_stats(out6); }
 uint32_t ZraHipDebugReadSeqs(ZraHipEngine* engine, uint32_t frame, uint64_t* out, uint32_t cap, uint32_t* meta3) { return engine->e->debug_read_seqs(frame, out, cap, meta3); }
 
