@@ -11,7 +11,7 @@
 #include <vector>
 
 extern "C" __global__ void zra_mf_kernel(ZraEncArgs a, uint32_t block, uint32_t only, uint32_t onlySlot);
-extern "C" __global__ void zra_mf_dfast_kernel(ZraEncArgs a, uint32_t block);
+extern "C" __global__ void zra_mf_dfast_kernel(ZraEncArgs a, uint32_t block, uint32_t only, uint32_t onlySlot);
 extern "C" __global__ void zra_entropy_kernel(ZraEncArgs a, uint32_t block);
 
 using namespace zra_dev;
@@ -134,8 +134,7 @@ Status Engine::compress_impl(const uint8_t* dIn, size_t inSize, uint8_t* dBody, 
   // gather of a sub-batch are released on stream B by hipStreamWaitValue32 on that counter — no per-batch launch tails in the
   // DRAM-bound match finder, and the entropy stage runs under it in small pieces.
   {
-    const char* tuneEnv = std::getenv("ZRA_MF_TUNE");
-    bool persist = maxBlocksPerFrame == 1 && full.strategy == 2 && !(tuneEnv && std::atoi(tuneEnv) == 7) && !std::getenv("ZRA_MF_NOPERSIST");
+    bool persist = maxBlocksPerFrame == 1 && full.strategy == 2 && !std::getenv("ZRA_MF_NOPERSIST");
     if (persist && waitValueOk_ == 0) {
       // the pipeline needs stream memory operations on plain device memory; probe once (a wait that is already satisfied), and
       // use the batch path below on runtimes without them
@@ -171,7 +170,6 @@ Status Engine::compress_impl(const uint8_t* dIn, size_t inSize, uint8_t* dBody, 
   ZraEncArgs base{};
   base.in = dIn; base.inSize = inSize; base.frameSize = frameSize; base.checksum = checksum ? 1 : 0;
   base.full = full; base.tail = tail;
-  { const char* t = std::getenv("ZRA_MF_TUNE"); base.mfTune = t ? (uint32_t)std::atoi(t) : 0u; }   // bring-up knob, read per call
   dbgSeqStride_ = seqStride; dbgB_ = (uint32_t)B;
   base.tableStride = tableWords; base.seqStride = seqStride; base.litStride = litStride; base.slotStride = slotStride;
 
@@ -217,18 +215,19 @@ Status Engine::compress_impl(const uint8_t* dIn, size_t inSize, uint8_t* dBody, 
         // dfast batches (levels 3-4) run the lean window-resolve kernel; a short last frame whose cparams select another
         // strategy is parsed by the generic kernel in a second single-frame launch
         const bool hasTail = tailSize && f0 + nb == nFramesTotal;
-        if (full.strategy == 2 && a.mfTune != 7) {
-          // LDS geometry of the bucket filter: 1 bit per 2^shL long-table buckets, 1 bit per 2^shS short-table buckets, and the
-          // duplicate-detection slots. Default 2 KiB + 4 KiB + 2 KiB at hashLog 16 / chainLog 15 (20 frames per CU); sweep in profiles/r01_mf_occupancy_sweep.log.
-          uint32_t shL = 1, shS = 1, dupLog = 10;
-          if (const char* f = std::getenv("ZRA_MF_FILTER")) { unsigned x = 1, y = 1, z = 10; if (std::sscanf(f, "%u,%u,%u", &x, &y, &z) >= 1) { shL = x & 15; shS = y & 15; dupLog = z & 15; } }
-          a.mfFilter = shL | (shS << 4) | (dupLog << 8);
-          const uint32_t hl = std::max(full.hashLog, tail.hashLog), cl = std::max(full.chainLog, tail.chainLog);
-          const size_t filterBytes = (2u << dupLog) + (((size_t)1 << hl) >> shL) / 8 + (((size_t)1 << cl) >> shS) / 8 + 64;
-          hipLaunchKernelGGL(zra_mf_dfast_kernel, dim3(nb), dim3(64), filterBytes + dynLds, stream_, a, blk);
-          if (hasTail && tail.strategy != 2) hipLaunchKernelGGL(zra_mf_kernel, dim3(1), dim3(64), 0, stream_, a, blk, (uint32_t)(nb - 1), (uint32_t)(nb - 1));
+        // LDS geometry of the dfast kernel's bucket filter (see compress_persistent)
+        uint32_t shL = 1, shS = 1, dupLog = 9;
+        if (const char* f = std::getenv("ZRA_MF_FILTER")) { unsigned x = 1, y = 1, z = 9; if (std::sscanf(f, "%u,%u,%u", &x, &y, &z) >= 1) { shL = x & 15; shS = y & 15; dupLog = z & 15; } }
+        a.mfFilter = shL | (shS << 4) | (dupLog << 8);
+        const uint32_t hl = std::max(full.hashLog, tail.hashLog), cl = std::max(full.chainLog, tail.chainLog);
+        const size_t filterBytes = (2u << dupLog) + (((size_t)1 << hl) >> shL) / 8 + (((size_t)1 << cl) >> shS) / 8 + 64;
+        const bool oddTail = hasTail && (tail.strategy == 2) != (full.strategy == 2);
+        if (full.strategy == 2) {
+          hipLaunchKernelGGL(zra_mf_dfast_kernel, dim3(nb), dim3(64), filterBytes + dynLds, stream_, a, blk, 0xFFFFFFFFu, 0u);
+          if (oddTail) hipLaunchKernelGGL(zra_mf_kernel, dim3(1), dim3(64), 0, stream_, a, blk, (uint32_t)(nb - 1), (uint32_t)(nb - 1));
         } else {
           hipLaunchKernelGGL(zra_mf_kernel, dim3(nb), dim3(64), dynLds, stream_, a, blk, 0xFFFFFFFFu, 0u);
+          if (oddTail) hipLaunchKernelGGL(zra_mf_dfast_kernel, dim3(1), dim3(64), filterBytes, stream_, a, blk, (uint32_t)(nb - 1), (uint32_t)(nb - 1));
         }
       }
       HIPCHK(hipEventRecord(m1, stream_));
@@ -301,7 +300,6 @@ Status Engine::compress_persistent(const uint8_t* dIn, size_t inSize, uint8_t* d
   ZraEncArgs base{};
   base.in = dIn; base.inSize = inSize; base.frameSize = frameSize; base.checksum = checksum ? 1 : 0;
   base.full = full; base.tail = tail;
-  { const char* t = std::getenv("ZRA_MF_TUNE"); base.mfTune = t ? (uint32_t)std::atoi(t) : 0u; }
   dbgSeqStride_ = seqStride; dbgB_ = (uint32_t)SBIG;
   base.tableStride = tableWords; base.seqStride = seqStride; base.litStride = litStride; base.slotStride = slotStride;
   // LDS geometry of the bucket filter: 1 bit per 2^shL long-table buckets, 1 bit per 2^shS short-table buckets, and the
@@ -343,7 +341,7 @@ Status Engine::compress_persistent(const uint8_t* dIn, size_t inSize, uint8_t* d
     hipEvent_t m0 = ev(), m1 = ev();
     if (!m0 || !m1) return zerr(1);
     HIPCHK(hipEventRecord(m0, stream_));
-    hipLaunchKernelGGL(zra_mf_dfast_kernel, dim3(std::min<uint32_t>(n, nSlots)), dim3(64), filterBytes, stream_, a, 0u);
+    hipLaunchKernelGGL(zra_mf_dfast_kernel, dim3(std::min<uint32_t>(n, nSlots)), dim3(64), filterBytes, stream_, a, 0u, 0xFFFFFFFFu, 0u);
     HIPCHK(hipEventRecord(m1, stream_));
     mfSpans.push_back({m0, m1});
     // a short last frame whose cparams select another strategy: parsed by the generic kernel (table slot 0 is free by then)

@@ -251,195 +251,12 @@ __device__ __forceinline__ u32 wave_count_back(const u8* src, u32 ip, u32 m, u32
 }
 
 // ================================================================================================
-// Window-resolve dfast (first formulation, kept for A/B runs with ZRA_MF_TUNE=7 and for the generic kernel). A window of up to 64 consecutive parse
-// positions is looked up ONCE (one table-gather round trip + one tag-filtered candidate round trip), then the parse is
-// resolved INSIDE the window: after a match the positions behind it are still in registers, so the next sequences of the
-// window need no further trip to the tables. This is exact because no two lanes of a window share a bucket (exactly
-// verified: the LDS scatter only flags suspects, flagged lanes are compared against all earlier lanes), so inserts made while
-// resolving the window (visited positions, the ip+1 long probe, the complementary and repcode insertions — all positions of
-// the window) can never change what another lane of the window would have read. Rep-offset tests depend on the parse state
-// and are re-evaluated per sequence (a cached, sequential read).
-template <typename T, bool TAG>
-__device__ u32 mf_dfast_window(const ZraEncParams& P, T* HL, T* HS, const u8* src, u32 bs, u32 be, u32* rep, u64* seqs, u32* nOut,
-                               u32* dupL, u32* dupS, int lane, u32 wcap) {
-  const u32 hlog = P.hashLog, clog = P.chainLog, mls = P.minMatch;
-  u32 o1 = rep[0], o2 = rep[1], saved;
-  u32 anchor = bs, nseq = 0;
-  const u32 ilimit = be >= 8 ? be - 8 : 0;            // a 7-byte first block: iend-8 lies before the start, nothing is searched
-  u32 ip = mf_prologue(bs, o1, o2, saved);
-  u32 epoch = 1;
-  PROF_DECL
-  auto hashS64 = [&](u64 v) -> u32 {
-    switch (mls) {
-      case 5: return (u32)(((v << 24) * 889523592379ULL) >> (64 - clog));
-      case 6: return (u32)(((v << 16) * 227718039650203ULL) >> (64 - clog));
-      case 7: return (u32)(((v << 8) * 58295818150454627ULL) >> (64 - clog));
-      default: return ((u32)v * 2654435761u) >> (32 - clog);
-    }
-  };
-  auto hashL64 = [&](u64 v) -> u32 { return (u32)((v * 0xCF1BBCDCB7A56463ULL) >> (64 - hlog)); };
-  auto tagL64 = [&](u64 v) -> u32 { return TAG ? ((u32)((v * 0xCF1BBCDCB7A56463ULL) >> (48 - hlog)) & 0xFFFFu) << 16 : 0u; };
-  auto tagS64 = [&](u64 v) -> u32 { return TAG ? (((u32)v * 2654435761u) >> 16) << 16 : 0u; };
-  while (ip < ilimit) {
-    // ---------------------------------------------------------------- window build
-    const u32 wip = ip;
-    const u32 run = ip - anchor, s = (run >> 8) + 1;
-    u32 nAct = min(wcap, min((256 * s - run + s - 1) / s, (ilimit - ip + s - 1) / s));
-    bool active = (u32)lane < nAct;
-    const u32 p = wip + (u32)lane * s;
-    const u64 v8 = active ? ld64(src + p) : 0;
-    PROF(0) PROF_CNT(12)
-    const u32 hL = hashL64(v8), hS = hashS64(v8);
-    const u32 tL = tagL64(v8), tS = tagS64(v8);
-    if (nAct > 1) {
-      const u32 tag = (epoch << 6) | (63u - (u32)lane);
-      if (active) { atomicMax(&dupL[hL & 511], tag); atomicMax(&dupS[hS & 511], tag); }
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-      const bool suspect = active && (((dupL[hL & 511] & 63u) != 63u - (u32)lane) || ((dupS[hS & 511] & 63u) != 63u - (u32)lane));
-      u64 sm = __ballot(suspect);
-      while (sm) {                                   // exact check of the suspects, in ascending lane order
-        const u32 i = (u32)__builtin_ctzll(sm); sm &= sm - 1;
-        const u32 hLi = bcast(hL, i), hSi = bcast(hS, i);
-        if (__ballot((u32)lane < i && (hL == hLi || hS == hSi))) { nAct = i; active = (u32)lane < nAct; break; }
-      }
-      epoch++;
-    }
-    PROF(1)
-    u32 mL = 0, mS = 0;
-    bool tagLok = true, tagSok = true;
-    if (active) {
-      const u32 rL = HL[hL], rS = HS[hS];
-      if (TAG) { mL = rL & 0xFFFFu; mS = rS & 0xFFFFu; tagLok = (rL & 0xFFFF0000u) == tL; tagSok = (rS & 0xFFFF0000u) == tS; }
-      else { mL = rL; mS = rS; }
-    }
-    PROF(2)
-    // candidate tests that do not depend on the parse state
-    const bool longHit = active && mL > 1 && tagLok && ld64(src + mL - 1) == v8;
-    const bool shortHit = active && mS > 1 && tagSok && ld32(src + mS - 1) == (u32)v8;
-    PROF(3)
-    // insert position `pos` into the long / short table; bucket + tag come from the window's registers when pos is in it
-    auto insert = [&](u32 pos, bool doL, bool doS) {
-      u32 hl, hs, tl, ts;
-      if (s == 1 && pos >= wip && pos - wip < nAct) {
-        const u32 l = pos - wip;
-        hl = bcast(hL, l); hs = bcast(hS, l); tl = bcast(tL, l); ts = bcast(tS, l);
-      } else {
-        PROF_CNT(14)
-        const u64 v = rfl64(ld64(src + pos));
-        hl = hashL64(v); hs = hashS64(v); tl = tagL64(v); ts = tagS64(v);
-      }
-      if (lane == 0 && doL) HL[hl] = (T)((pos + 1) | tl);
-      if (lane == 1 && doS) HS[hs] = (T)((pos + 1) | ts);
-    };
-    // ---------------------------------------------------------------- resolve the window
-    // Per sequence the dependent round trips are kept to two: (1) forward count + backward extension + the NEXT sequence's
-    // rep-offset gather are issued together, (2) the immediate-repcode test. The rep gather is speculative on o1 (redone if
-    // the repcode loop swaps the offsets).
-    u32 cur = 0;
-    u32 repFor = 0xFFFFFFFFu, repVal = 0;            // repVal = ld32(src + p + 1 - repFor), gathered ahead of time
-    for (;;) {
-      const bool live = active && (u32)lane >= cur;
-      if (repFor != o1) { repVal = (active && o1 > 0 && p + 1 >= o1) ? ld32(src + p + 1 - o1) : 0; repFor = o1; }
-      const bool repHit = live && o1 > 0 && p + 1 >= o1 && repVal == (u32)(v8 >> 8);
-      const u64 hm = __ballot(live && (repHit || longHit || shortHit));
-      const u32 f = hm ? (u32)__builtin_ctzll(hm) : nAct - 1;
-      if (live && (u32)lane <= f) { HL[hL] = (T)((p + 1) | tL); HS[hS] = (T)((p + 1) | tS); }   // visited positions
-      PROF(4)
-      if (!hm) { ip = wip + nAct * s; break; }
-      const u32 top = wip + f * s;
-      const u32 mLf = bcast(mL, f), mSf = bcast(mS, f);
-      const bool isRep = (__ballot(repHit) >> f) & 1, isLong = (__ballot(longHit) >> f) & 1;
-      const u32 curr = top + 1;
-      ip = top;
-      // ---- which match: start position `ip`, source `m`, bytes already known equal `known`
-      u32 m, known, offVal;
-      if (isRep) { ip = top + 1; m = ip - o1; known = 4; offVal = 1; }
-      else if (isLong) { m = mLf - 1; known = 8; offVal = 0; }
-      else {
-        // short hit: probe the long table at ip+1 (A.4.3 case 3) — lane f+1 already holds that lookup when it is in the window
-        u64 v9; u32 h3, m3, t3; bool tag3ok;
-        if (s == 1 && f + 1 < nAct) {
-          v9 = bcast64(v8, f + 1); h3 = bcast(hL, f + 1); m3 = bcast(mL, f + 1); t3 = bcast(tL, f + 1);
-          tag3ok = (__ballot(tagLok) >> (f + 1)) & 1;
-        } else {
-          PROF_CNT(15)
-          v9 = rfl64(ld64(src + ip + 1)); h3 = hashL64(v9); t3 = tagL64(v9);
-          const u32 r3 = rfl((u32)HL[h3]);
-          m3 = TAG ? (r3 & 0xFFFFu) : r3;
-          tag3ok = !TAG || (r3 & 0xFFFF0000u) == t3;
-        }
-        if (lane == 0) HL[h3] = (T)((curr + 1) | t3);
-        if (m3 > 1 && tag3ok && rfl64(ld64(src + m3 - 1)) == v9) { m = m3 - 1; ip = top + 1; known = 8; }
-        else { m = mSf - 1; known = 4; }
-        offVal = 0;
-      }
-      PROF(5)
-      const u32 off = ip - m;
-      const u32 o1n = isRep ? o1 : off;             // o1 after this sequence (unless the repcode loop swaps)
-      // ---- issue together: forward compare (64 x 8 B), backward compare (64 x 1 B), next rep gather
-      const u32 fa = ip + known + 8 * (u32)lane, fb = m + known + 8 * (u32)lane;
-      const bool fv = fa + 8 <= be;
-      const u64 xa = fv ? ld64(src + fa) : 0, xb = fv ? ld64(src + fb) : 0;
-      const u32 lim = isRep ? 0u : min(ip - anchor, m);
-      const bool bv = (u32)lane < lim;
-      const u32 ya = bv ? src[ip - 1 - lane] : 0u, yb = bv ? src[m - 1 - lane] : 1u;
-      const u32 rnext = (active && o1n > 0 && p + 1 >= o1n) ? ld32(src + p + 1 - o1n) : 0;
-      PROF(6)
-      u32 ml;
-      {
-        const u64 d = xa ^ xb;
-        const u32 eq = d ? ((u32)__builtin_ctzll(d) >> 3) : 8;
-        const u64 stop = __ballot(!fv || d != 0);
-        const u32 l = stop ? (u32)__builtin_ctzll(stop) : 64u;
-        const bool clean = stop && ((__ballot(fv) >> l) & 1);       // first stopping lane compared a full 8-byte word
-        if (clean) ml = known + 8 * l + bcast(eq, l);
-        else ml = known + wave_count_eq(src, ip + known, m + known, be, lane);   // block end inside the window, or > 512 equal bytes
-      }
-      u32 back = 0;
-      if (!isRep) {
-        const u64 bad = ~__ballot(bv && ya == yb);
-        back = bad ? (u32)__builtin_ctzll(bad) : wave_count_back(src, ip, m, anchor, lane);
-        o2 = o1; o1 = off; offVal = off + 3;
-      }
-      ip -= back; ml += back;
-      repVal = rnext; repFor = o1n;
-      if (lane == 0) seqs[nseq] = (u64)(ip - anchor) | ((u64)ml << 20) | ((u64)offVal << 40);
-      nseq++;
-      ip += ml; anchor = ip;
-      PROF(7) PROF_CNT(13)
-      if (ip <= ilimit) {
-        insert(top + 2, true, true);                  // complementary insertions (order per table: q first)
-        insert(ip - 2, true, false);
-        insert(ip - 1, false, true);
-        PROF(8)
-        for (;;) {
-          if (!(ip <= ilimit && o2 > 0)) break;
-          const u32 here = (s == 1 && ip >= wip && ip - wip < nAct) ? (u32)bcast64(v8, ip - wip) : rfl(ld32(src + ip));
-          if (here != rfl(ld32(src + ip - o2))) break;
-          PROF_CNT(16)
-          const u32 rl = wave_count_eq(src, ip + 4, ip + 4 - o2, be, lane) + 4;
-          const u32 t = o2; o2 = o1; o1 = t;
-          insert(ip, true, true);
-          if (lane == 0) seqs[nseq] = (u64)0 | ((u64)rl << 20) | ((u64)1 << 40);
-          nseq++;
-          ip += rl; anchor = ip;
-        }
-      }
-      PROF(9)
-      if (s != 1 || ip >= wip + nAct || ip >= ilimit) break;    // left the window: build the next one at ip
-      cur = ip - wip;
-    }
-  }
-  PROF(10) PROF_END
-  rep[0] = o1 ? o1 : saved; rep[1] = o2 ? o2 : saved;
-  *nOut = nseq;
-  return be - anchor;
-}
-
-
-// ================================================================================================
-// Lean window-resolve dfast. Same algorithm as mf_dfast_window, re-laid-out for instruction count: rocprofv3 shows the match
-// finder is bound by instruction issue (7 waves per SIMD x ~1.7 M instructions per frame), not by HBM. Differences:
+// Window-resolve dfast. A window of up to 64 consecutive parse positions is looked up ONCE (one table-gather round trip + one
+// tag-filtered candidate round trip), then the parse is resolved INSIDE the window: after a match the positions behind it are still
+// in registers, so the next sequences of the window need no further trip to the tables. This is exact because no two lanes of a
+// window share a bucket (exactly verified: the LDS scatter only flags suspects, flagged lanes are compared against all other lanes
+// and the window is cut at the first duplicate), so inserts made while resolving the window can never change what another lane of
+// the window would have read. Rep-offset tests depend on the parse state and are re-evaluated per sequence. Layout choices:
 //   * every in-window insertion (visited positions, the ip+1 long probe, the complementary insertions) is "lane q-wip stores its
 //     own (bucket, value)": one exec-masked store per table and sequence, masks built on the scalar unit;
 //   * the ip+1 long probe of a short hit is lane f+1's own long-table test (already evaluated at window build);
@@ -756,7 +573,7 @@ __device__ __forceinline__ bool mf_frame_setup(const ZraEncArgs& a, u32 block, i
 // Match finder for strategy 2 (dfast, levels 3-4): one wave per frame, lean window-resolve parse. Launched when the batch's
 // full-size frames use dfast; a short last frame with another strategy is left to zra_mf_kernel (second launch, `only`).
 extern "C" __global__ void __launch_bounds__(64)
-zra_mf_dfast_kernel(ZraEncArgs a, u32 block) {
+zra_mf_dfast_kernel(ZraEncArgs a, u32 block, u32 only, u32 onlySlot) {
   const int lane = threadIdx.x;
   // dynamic LDS: [dup bytes 2 x dupSlots][filter L][filter S]; geometry chosen by the host (a.mfFilter: shL | shS<<4 | log2(dupSlots)<<8)
   extern __shared__ u32 dynLds[];
@@ -766,7 +583,7 @@ zra_mf_dfast_kernel(ZraEncArgs a, u32 block) {
   W.bmL = dynLds + (2 * W.dupSlots) / 4;
   const bool persistent = a.mfQueue != nullptr;
   for (;;) {
-    u32 f = blockIdx.x;
+    u32 f = only == 0xFFFFFFFFu ? blockIdx.x : only;   // `only`: a single-workgroup launch for that frame on table slot `onlySlot`
     if (persistent) {
       u32 t = 0;
       if (lane == 0) t = atomicAdd(a.mfQueue, 1u);
@@ -777,13 +594,15 @@ zra_mf_dfast_kernel(ZraEncArgs a, u32 block) {
     const u64 kt0_ = __builtin_amdgcn_s_memtime();
 #endif
     bool mine = true;
-    if (a.full.strategy != a.tail.strategy && f == a.nFrames - 1) {
-      // the short last frame of the whole input with another strategy is parsed by zra_mf_kernel (and signalled by the host)
+    {
+      // frames whose cparams select another strategy (only the short last frame of the input can differ from the rest) are parsed
+      // by zra_mf_kernel, launched for that frame by the host
       const u64 fstart = (u64)(a.firstFrame + f) * a.frameSize;
-      if (a.inSize - fstart < a.frameSize) mine = false;
+      const ZraEncParams& Pf = (a.inSize - fstart < a.frameSize) ? a.tail : a.full;
+      if (Pf.strategy != 2) mine = false;
     }
     MfFrame F;
-    if (mine && mf_frame_setup(a, block, lane, F, f, persistent ? blockIdx.x : f)) {
+    if (mine && mf_frame_setup(a, block, lane, F, f, persistent ? blockIdx.x : only == 0xFFFFFFFFu ? f : onlySlot)) {
 #ifdef ZRA_MF_PROFILE
       __builtin_amdgcn_s_waitcnt(0);
       if (lane == 0) atomicAdd(&zra_mf_prof[20], __builtin_amdgcn_s_memtime() - kt0_);
@@ -823,9 +642,8 @@ zra_mf_dfast_kernel(ZraEncArgs a, u32 block) {
   }
 }
 
-// Match finder for the other strategies (fast, greedy, lazy, lazy2: one lane walks the parse) and, with ZRA_MF_TUNE=7, the
-// first window-resolve dfast formulation (kept for A/B measurements). `only` = 0xFFFFFFFF: every frame of the batch;
-// otherwise just that frame (the short last frame whose strategy differs from the batch's), launched as one workgroup.
+// Match finder for the other strategies (fast, greedy, lazy, lazy2: one lane walks the parse). `only` = 0xFFFFFFFF: every frame
+// of the batch; otherwise just that frame (the short last frame whose strategy differs from the batch's), launched as one workgroup.
 extern "C" __global__ void __launch_bounds__(64)
 zra_mf_kernel(ZraEncArgs a, u32 block, u32 only, u32 onlySlot) {
   const int lane = threadIdx.x;
@@ -838,20 +656,7 @@ zra_mf_kernel(ZraEncArgs a, u32 block, u32 only, u32 onlySlot) {
   const u32 bs = F.bs, be = F.be;
   u32 rep[3] = {st->rep[0], st->rep[1], st->rep[2]};
   u32 lastLL, nseq = 0;
-  if (P.strategy == 2) {
-    __shared__ u32 dupAll[1024];
-    u32* const dupL = dupAll; u32* const dupS = dupAll + 512;
-    for (int i = lane; i < 512; i += 64) { dupL[i] = 0; dupS[i] = 0; }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-    const u32 wcap = (a.mfTune >= 8 && a.mfTune <= 64) ? a.mfTune : 64u;   // window width (bring-up knob)
-    if (F.fsize <= 65536) lastLL = mf_dfast_window<u32, true>(P, hashT, chainT, src, bs, be, rep, seqs, &nseq, dupL, dupS, lane, wcap);
-    else lastLL = mf_dfast_window<u32, false>(P, hashT, chainT, src, bs, be, rep, seqs, &nseq, dupL, dupS, lane, wcap);
-    if (lane == 0) {
-      bo->nbSeq = nseq; bo->lastLL = lastLL; bo->skip = 0;
-      bo->rep[0] = rep[0]; bo->rep[1] = rep[1]; bo->rep[2] = rep[2];
-    }
-    return;
-  }
+  if (P.strategy == 2) return;                      // dfast frames belong to zra_mf_dfast_kernel
   if (lane != 0) return;
   bo->skip = 0;
   Emit E; E.seqs = seqs; E.n = 0;

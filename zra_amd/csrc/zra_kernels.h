@@ -66,7 +66,6 @@ struct ZraEncArgs {
   uint32_t nFrames;        // frames in the batch
   uint32_t checksum;
   uint32_t mfFilter;       // dfast kernel LDS geometry: filterShiftLong | filterShiftShort<<4 | log2(dupSlots)<<8
-  uint32_t mfTune;         // bring-up knob: speculation-width policy of the wave match finder
   ZraEncParams full, tail; // parameters of full-size frames / of the short last frame
   uint32_t* tables;        // nFrames * tableStride u32
   uint64_t tableStride;    // words per frame
