@@ -547,9 +547,20 @@ zra_decode_frames_kernel(ZraDecodeArgs a) {
             const u32 ofBits = (eO >> 8) & 0xFF, mlBits = (eM >> 8) & 0xFF, llBits = (eL >> 8) & 0xFF;
             if (ofBits > 31) { bad = 1; break; }
             const u32 baseL = S.llBase[eL & 0xFF], baseM = S.mlBase[eM & 0xFF];   // by symbol; not on the bit-position chain
-            u32 offVal = (1u << ofBits) + br.read((int)ofBits);
-            // match-length and literal-length extra bits in one extraction (<= 32 bits; ML was written first = upper part)
-            const u32 both = br.read((int)(mlBits + llBits));
+            // offset, match-length and literal-length extra bits in ONE extraction when they fit the 57 bits a reload guarantees
+            // (always, for windows <= 128 KiB); bitstream order: OF, ML, LL = topmost ... lowest
+            const u32 lm = mlBits + llBits, t1 = ofBits + lm;
+            u32 offVal, both;
+            if (t1 <= 56) {
+              br.ensure((int)t1);
+              const u64 x = (br.w >> (br.pos - (i32)t1 - br.wlo)) & ((1ull << t1) - 1);
+              br.pos -= (i32)t1;
+              offVal = (1u << ofBits) + (u32)(x >> lm);
+              both = (u32)(x & ((1ull << lm) - 1));
+            } else {
+              offVal = (1u << ofBits) + br.read((int)ofBits);
+              both = br.read((int)lm);
+            }
             const u32 ml = baseM + (both >> llBits), ll = baseL + (both & ((1u << llBits) - 1));
             if (first + i + 1 < nbSeq) {
               const int nL = (int)((eL >> 16) & 0xF), nM = (int)((eM >> 16) & 0xF), nO = (int)((eO >> 16) & 0xF);
