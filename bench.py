@@ -127,6 +127,8 @@ def cpu_baseline(sample, frame_size, level, nq, qsize, seed=42):
                       % (len(data) >> 20, level, frame_size >> 10, nq, qsize, "libzstd " + O.lib().zo_libzstd_version().decode() if backend == "zl" else "the oracle's C restatement"),
             "compress_gibs": round(comp, 4), "ra_gibs": round(ra, 4), "ra_us_per_query": round((t3 - t2) / nq * 1e6, 1),
             "best_case_all_threads": {"compress_gibs": round(mt, 3), "threads": T, "host_cpus": os.cpu_count(),
+                                      "cpus_allowed": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None,
+                                      "cgroup_cpu_max": (open("/sys/fs/cgroup/cpu.max").read().strip() if os.path.exists("/sys/fs/cgroup/cpu.max") else None),
                                       "note": "not the reference (single-threaded): %d threads x %d MiB, one libzstd context each" % (T, sl >> 20)}}, arc
 
 
