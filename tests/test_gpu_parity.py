@@ -366,6 +366,38 @@ def test_opt_in_integrity_options(zra):
         L.ZraHipSetOptions(0)
 
 
+def test_two_engines_on_two_threads(zra, gens):
+    """One ZraHipEngine per thread: two engines compress and decode different inputs concurrently on the same GPU
+    (their persistent match-finder launches and entropy stages interleave) and both stay bit-exact."""
+    import threading
+    import torch
+    dev = torch.device("cuda", 0)
+    jobs = [("E", 3, 65536), ("L", 4, 131072)]
+    results = {}
+
+    def work(idx, name, level, fs):
+        eng = zra.Engine(0)
+        d = (gens[name] * 24)[: 20 * 1024 * 1024]
+        t = torch.from_numpy(np.frombuffer(d, dtype=np.uint8).copy()).to(dev)
+        out = torch.empty(zra.GetOutputBufferSize(len(d), fs) + 64, dtype=torch.uint8, device=dev)
+        back = torch.empty(len(d), dtype=torch.uint8, device=dev)
+        ok = True
+        for _ in range(4):
+            n = eng.compress(t.data_ptr(), len(d), out.data_ptr(), level, fs, True)
+            eng.decompress(out.data_ptr(), n, back.data_ptr(), len(d))
+            ok = ok and bool(torch.equal(back, t))
+        results[idx] = (bytes(out[:n].cpu().numpy()), d, level, fs, ok)
+
+    th = [threading.Thread(target=work, args=(i,) + j) for i, j in enumerate(jobs)]
+    for x in th: x.start()
+    for x in th: x.join()
+    assert len(results) == 2
+    for arc, d, level, fs, ok in results.values():
+        assert ok
+        st, ref = O.zra_compress(d, level, fs, True)
+        assert arc == ref
+
+
 def test_streaming_objects(zra):
     L = zra.load()
     data = C.gen_E(1 << 20)[200000:200000 + 16384 * 9 + 1000]
