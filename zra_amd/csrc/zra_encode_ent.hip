@@ -495,6 +495,9 @@ __device__ unsigned long long zra_ent_prof[16];
 extern "C" __global__ void __launch_bounds__(ENT_THREADS, 7)
 zra_entropy_kernel(ZraEncArgs a, u32 block) {
   __shared__ EncShared S;
+  // This stage runs beside the persistent match finder, which is DRAM-bound but fills most issue slots; the one-lane serial
+  // sections here are latency-critical. Raise the wave's issue priority so they are not queued behind match-finder waves.
+  __builtin_amdgcn_s_setprio(3);
 #ifdef ZRA_MF_PROFILE
   u64 ept_ = __builtin_amdgcn_s_memtime();
 #endif
