@@ -822,11 +822,28 @@ zra_entropy_kernel(ZraEncArgs a, u32 block) {
         __syncthreads();
         EPROF(5)
         if (wave == 0 && lane < 3) {
+          // The state chain is the one dependency that cannot be broken: state -> stateTable[(state >> nb) + dfs] -> state. Everything
+          // else a step needs (the symbol, its deltaNbBits / deltaFindState) is loaded one and two steps ahead, so a step costs one LDS
+          // round trip instead of four dependent ones.
           const ZraFseCTable* ct = &S.ct[lane];
-          for (u32 rl = 0; rl < cntT; rl++) {
-            const u32 code = S.seq.codes[lane][rl];
-            if (t0 + rl == 0) { state = fse_init_state(ct, code); S.seq.chain[lane][rl] = 0; }
-            else { u32 bits; const u32 nb = fse_encode(ct, state, code, bits); S.seq.chain[lane][rl] = (u16)((nb << 12) | bits); }
+          const u8* const cd = S.seq.codes[lane];
+          u16* const ch = S.seq.chain[lane];
+          u32 rl = 0;
+          if (t0 == 0) { state = fse_init_state(ct, cd[0]); ch[0] = 0; rl = 1; }      // the block's last sequence: init only
+          if (ct->rle) { for (; rl < cntT; rl++) ch[rl] = 0; }
+          else if (rl < cntT) {
+            const u32 last = cntT - 1;
+            u32 sym1 = cd[min(rl + 1, last)];
+            u32 dnb = ct->deltaNbBits[cd[rl]]; i32 dfs = ct->deltaFindState[cd[rl]];
+            for (; rl < cntT; rl++) {
+              const u32 nb = (state + dnb) >> 16;
+              const u32 bits = state & ((1u << nb) - 1);
+              state = ct->stateTable[(state >> nb) + dfs];                              // critical load first
+              const u32 dnbN = ct->deltaNbBits[sym1]; const i32 dfsN = ct->deltaFindState[sym1];   // parameters of step rl+1
+              const u32 sym2 = cd[min(rl + 2, last)];                                  // symbol of step rl+2
+              ch[rl] = (u16)((nb << 12) | bits);
+              dnb = dnbN; dfs = dfsN; sym1 = sym2;
+            }
           }
           if (lastTile) S.finalState[lane] = state;
         }
