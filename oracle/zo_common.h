@@ -24,6 +24,8 @@ enum {
   ZO_E_WINDOW_TOO_LARGE = 16,
   ZO_E_CORRUPTION = 20,
   ZO_E_CHECKSUM_WRONG = 22,
+  ZO_E_DICT_CORRUPTED = 30,
+  ZO_E_DICT_WRONG = 32,
   ZO_E_PARAM_UNSUPPORTED = 40,
   ZO_E_DSTSIZE_TOOSMALL = 70,
   ZO_E_SRCSIZE_WRONG = 72,

@@ -164,13 +164,14 @@ static size_t decode_block(dctx* d, u8* out, size_t outCap, const u8* frameOut, 
         if (idx == 1) off = d->rep[0];
         else {
           off = idx == 2 ? d->rep[1] : idx == 3 ? d->rep[2] : d->rep[0] - 1;
-          if (off == 0) FAIL(ZO_E_CORRUPTION);
+          off += !off;                                  /* zstd 1.4.9: "offset == 0 means corruption, but force offset to 1" (no error) */
           if (idx != 2) d->rep[2] = d->rep[1];
           d->rep[1] = d->rep[0]; d->rep[0] = off;
         }
       }
-      if (ll > litSize - litPos) FAIL(ZO_E_CORRUPTION);
+      /* ZSTD_execSequenceEnd order: destination room first, then the literal buffer, then the offset */
       if ((size_t)ll + ml > outCap - produced) FAIL(ZO_E_DSTSIZE_TOOSMALL);
+      if (ll > litSize - litPos) FAIL(ZO_E_CORRUPTION);
       memcpy(out + produced, lit + litPos, ll); produced += ll; litPos += ll;
       if (off > (size_t)(out + produced - frameOut)) FAIL(ZO_E_CORRUPTION);
       for (u32 k = 0; k < ml; k++) out[produced + k] = out[produced + k - off];
@@ -187,7 +188,7 @@ static size_t decode_block(dctx* d, u8* out, size_t outCap, const u8* frameOut, 
 }
 
 /* parse the frame header; returns header size or error. */
-static size_t parse_frame_header(const u8* src, size_t n, size_t* blockMax, int* checksum) {
+static size_t parse_frame_header(const u8* src, size_t n, size_t* blockMax, int* checksum, u64* contentSize) {
   if (n < 5) return ZO_ERR(ZO_E_SRCSIZE_WRONG);
   if (rd32(src) != 0xFD2FB528u) return ZO_ERR(ZO_E_PREFIX_UNKNOWN);
   unsigned fhd = src[4], did = fhd & 3, ss = (fhd >> 5) & 1, fcs = fhd >> 6;
@@ -206,14 +207,23 @@ static size_t parse_frame_header(const u8* src, size_t n, size_t* blockMax, int*
     window = fcs == 0 ? q[0] : fcs == 1 ? (u64)rd16(q) + 256 : fcs == 2 ? rd32(q) : rd64(q);
   }
   if (window > (1ULL << 27) + 1 && !ss) return ZO_ERR(ZO_E_WINDOW_TOO_LARGE);
+  {
+    /* frame content size (RFC 8878 3.1.1.1.4): absent (-1) or 1/2/4/8 bytes, the 2-byte form is biased by 256; a non-zero
+       dictionary id cannot be honoured (the reference never loads one): dictionary_wrong, as ZSTD_decompressFrame reports it */
+    const u8* q = src + 5 + !ss;
+    u32 dict = did == 0 ? 0 : did == 1 ? q[0] : did == 2 ? rd16(q) : rd32(q);
+    if (dict) return ZO_ERR(ZO_E_DICT_WRONG);
+    q += didSize[did];
+    *contentSize = fcsSize == 0 ? (u64)-1 : fcsSize == 1 ? q[0] : fcsSize == 2 ? (u64)rd16(q) + 256 : fcsSize == 4 ? rd32(q) : rd64(q);
+  }
   *blockMax = window < (128u << 10) ? (size_t)window : (128u << 10);
   *checksum = (fhd >> 2) & 1;
   return hs;
 }
 
 static size_t decode_frame(u8* dst, size_t cap, const u8* src, size_t n, size_t* consumed) {
-  size_t blockMax; int checksum;
-  size_t hs = parse_frame_header(src, n, &blockMax, &checksum);
+  size_t blockMax; int checksum; u64 contentSize;
+  size_t hs = parse_frame_header(src, n, &blockMax, &checksum, &contentSize);
   if (ZO_ISERR(hs)) return hs;
   (void)blockMax;
   const u8* p = src + hs; size_t rem = n - hs, produced = 0;
@@ -245,6 +255,7 @@ static size_t decode_frame(u8* dst, size_t cap, const u8* src, size_t n, size_t*
     if (last) break;
   }
   free(d);
+  if (contentSize != (u64)-1 && contentSize != produced) return ZO_ERR(ZO_E_CORRUPTION);   /* declared size first, then the checksum */
   if (checksum) {
     if (rem < 4) return ZO_ERR(ZO_E_CHECKSUM_WRONG);
     if (rd32(p) != (u32)zo_xxh64(dst, produced, 0)) return ZO_ERR(ZO_E_CHECKSUM_WRONG);
@@ -284,8 +295,8 @@ size_t zo_find_frame_size(const void* srcv, size_t n) {
     size_t skip = (size_t)rd32(src + 4) + 8;
     return skip > n ? ZO_ERR(ZO_E_SRCSIZE_WRONG) : skip;
   }
-  size_t blockMax; int checksum;
-  size_t hs = parse_frame_header(src, n, &blockMax, &checksum);
+  size_t blockMax; int checksum; u64 contentSize;
+  size_t hs = parse_frame_header(src, n, &blockMax, &checksum, &contentSize);
   if (ZO_ISERR(hs)) return hs;
   const u8* p = src + hs; size_t rem = n - hs;
   for (;;) {

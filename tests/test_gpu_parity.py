@@ -160,6 +160,38 @@ def test_randomised_differential_decode(zra, seed):
                     assert zra.DecompressRA(arc, off, sz) == d[off:off + sz], (seed, case, off, sz)
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_randomised_corruption_statuses(zra, seed):
+    """Mutated archives (bit flips, byte overwrites, truncation): DecompressBuffer must report the oracle's (zra, zstd) status — and the
+    oracle's bytes when the mutation is harmless — and must never hang or fault (50 cases per seed)."""
+    rng = np.random.RandomState(3000 + seed)
+    for case in range(50):
+        fs = int(rng.choice([1024, 4096, 16384, 65536]))
+        n = int(rng.randint(1, 5 * fs))
+        level = int(rng.choice([1, 3, 3, 5, 9]))
+        d = _random_input(rng, n)
+        st, arc = O.zra_compress(d, level, fs, bool(case & 1))
+        if st != (0, 0):
+            continue                                   # cparams outside the restated set for this size (refused, not faked)
+        a = bytearray(arc)
+        for _ in range(int(rng.choice([1, 1, 1, 2, 5]))):
+            mode = rng.rand()
+            if mode < 0.7: a[int(rng.randint(38, len(a)))] ^= 1 << int(rng.randint(0, 8))
+            elif mode < 0.85: a[int(rng.randint(0, len(a)))] = int(rng.randint(0, 256))
+            else: a = a[: int(rng.randint(38, len(a)))]
+            if len(a) < 44:
+                break
+        a = bytes(a)
+        if len(a) < 38 or int.from_bytes(a[18:26], "little") > (1 << 24):
+            continue                                   # header size field mutated to something huge: the C wrapper trusts it (zra.cpp:519)
+        want, wbytes = O.zra_decompress(a, int.from_bytes(a[18:26], "little"))
+        try:
+            got = zra.DecompressBuffer(a)
+            assert want == (0, 0) and got == wbytes, (seed, case, want)
+        except zra.ZraError as e:
+            assert (e.zra, e.zstd) == want, (seed, case, want, (e.zra, e.zstd))
+
+
 def test_compress_edge_cases(zra):
     assert zra.CompressBuffer(b"abcdefghij", 3, 4, True) == open(os.path.join(GOLD, "g1_abcdefghij_fs4.zra"), "rb").read()
     assert zra.CompressBuffer(b"", 3, 65536, True) == open(os.path.join(GOLD, "g1_empty_fs65536.zra"), "rb").read()

@@ -42,6 +42,7 @@ const char* zstd_error_string(int code) {   // ZSTD_getErrorString of zstd 1.4.9
     case 20: return "Corrupted block detected";
     case 22: return "Restored data doesn't match checksum";
     case 30: return "Dictionary is corrupted";
+    case 32: return "Dictionary mismatch";
     case 40: return "Unsupported parameter";
     case 42: return "Parameter is out of bound";
     case 64: return "Allocation error : not enough memory";
@@ -55,8 +56,12 @@ const char* zstd_error_string(int code) {   // ZSTD_getErrorString of zstd 1.4.9
 // whole body does (zra.cpp:249): skippable frames are skipped, the seek table is NOT consulted.
 // offs receives frame boundaries (n+1 entries for n data frames, contiguous runs only: a skippable frame in the
 // middle is reported through `gaps`). Returns 0 or the zstd error code of the walk.
-int walk_frames(const zra::u8* body, size_t n, std::vector<uint64_t>& starts, std::vector<uint64_t>& ends) {
+// *brokenAt: start of the frame inside which a header/block walk error occurred (its magic was fine), else ~0: the sequential
+// reference would still decode that frame's leading blocks before it reaches the broken part, so the caller hands the device the
+// span [brokenAt, n) as a last job and lets the decoder report whichever error comes first in block order.
+int walk_frames(const zra::u8* body, size_t n, std::vector<uint64_t>& starts, std::vector<uint64_t>& ends, uint64_t* brokenAt) {
   size_t pos = 0; bool more = false;
+  *brokenAt = ~0ull;
   while (n - pos >= 5) {
     uint32_t magic = fmt::rd32(body + pos);
     if ((magic & 0xFFFFFFF0u) == 0x184D2A50u) {
@@ -69,19 +74,31 @@ int walk_frames(const zra::u8* body, size_t n, std::vector<uint64_t>& starts, st
     const size_t f0 = pos;
     unsigned fhd = body[pos + 4], did = fhd & 3, ss = (fhd >> 5) & 1, fcs = fhd >> 6;
     size_t hs = 5 + !ss + (did == 3 ? 4 : did) + (fcs == 0 ? ss : fcs == 1 ? 2 : fcs == 2 ? 4 : 8);
-    if (n - pos < hs) return 72;
+    if (n - pos < hs) { *brokenAt = f0; return 72; }
+    // the header checks ZSTD_decompressFrame makes before it looks at any block (same order as the device decoder)
+    if (fhd & 8) { *brokenAt = f0; return 14; }
+    if (!ss) {
+      unsigned b = body[pos + 5], wl = 10 + (b >> 3);
+      if (wl > 31) { *brokenAt = f0; return 14; }
+      if (((1ull << wl) + ((1ull << wl) >> 3) * (b & 7)) > (1ull << 27) + 1) { *brokenAt = f0; return 16; }
+    }
+    {
+      const zra::u8* q = body + pos + 5 + !ss;
+      uint32_t dict = did == 0 ? 0u : did == 1 ? (uint32_t)q[0] : did == 2 ? (uint32_t)(q[0] | (q[1] << 8)) : fmt::rd32(q);
+      if (dict) { *brokenAt = f0; return 32; }
+    }
     pos += hs;
     for (;;) {
-      if (n - pos < 3) return 72;
+      if (n - pos < 3) { *brokenAt = f0; return 72; }
       uint32_t bh = (uint32_t)body[pos] | ((uint32_t)body[pos + 1] << 8) | ((uint32_t)body[pos + 2] << 16);
       pos += 3;
       unsigned type = (bh >> 1) & 3; size_t bs = type == 1 ? 1 : (bh >> 3);
-      if (type == 3) return 20;
-      if (bs > n - pos) return 72;
+      if (type == 3) { *brokenAt = f0; return 20; }
+      if (bs > n - pos) { *brokenAt = f0; return 72; }
       pos += bs;
       if (bh & 1) break;
     }
-    if (fhd & 4) { if (n - pos < 4) return 22; pos += 4; }
+    if (fhd & 4) { if (n - pos < 4) { *brokenAt = f0; return 22; } pos += 4; }
     starts.push_back(f0); ends.push_back(pos);
     more = true;
   }
@@ -202,11 +219,13 @@ namespace zra {
     // decode them all in parallel on the device.
     const u8* body = input.data + header.size; const size_t bodySize = input.size - header.size;
     std::vector<uint64_t> starts, ends;
-    int walkErr = walk_frames(body, bodySize, starts, ends);
+    uint64_t brokenAt = ~0ull;
+    int walkErr = walk_frames(body, bodySize, starts, ends, &brokenAt);
+    if (walkErr && brokenAt != ~0ull) { starts.push_back(brokenAt); ends.push_back(bodySize); }
     std::lock_guard<std::mutex> lk(g_mu);
     // frames complete before a walk error are still decoded (their errors come first, as in the sequential reference)
     const u64 avail = std::min<u64>(header.uncompressedSize, (u64)starts.size() * header.frameSize);
-    zra_eng::Status s = default_engine().decode_host(body, bodySize, starts, ends, header.frameSize, header.uncompressedSize, output.data, 0, (size_t)avail);
+    zra_eng::Status s = default_engine().decode_host(body, bodySize, starts, ends, header.frameSize, header.uncompressedSize, output.data, 0, (size_t)avail, true);
     check(s);
     if (walkErr) throw Exception(StatusCode::ZStdError, walkErr);
     if (avail < header.uncompressedSize && false) throw Exception(StatusCode::ZStdError, 72);

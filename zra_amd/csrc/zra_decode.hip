@@ -76,6 +76,9 @@ struct __attribute__((aligned(16))) DecShared {
   u32 streamOff[4], streamLen[4];
   u32 tl, ms, used;
   u32 produced;             // bytes produced in this frame so far
+  u32 seqHdrErr;            // error of the sequences header, raised after the literal stage
+  u32 batchValid;           // sequences of the current batch decoded before the bitstream went bad (== batch size when it did not)
+  u32 fcsLo, fcsHi, fcsHave;   // Frame_Content_Size when the header declares one (checked at the frame end, before the checksum)
 };
 
 // wave-level sync: LDS and global traffic of the wave is complete and visible to its other lanes
@@ -370,6 +373,19 @@ zra_decode_frames_kernel(ZraDecodeArgs a) {
           else if (((1ull << wl) + ((1ull << wl) >> 3) * (b & 7)) > (1ull << 27) + 1) S.err = ZE_WINDOW_TOO_LARGE;
         }
         checksum = (fhd >> 2) & 1;
+        S.fcsHave = 0;
+        if (!S.err) {
+          // a dictionary id cannot be honoured (the reference never loads one): dictionary_wrong, as ZSTD_decompressFrame reports it;
+          // the declared content size (1/2/4/8 bytes, the 2-byte form biased by 256) must equal what the frame regenerates
+          const u8* q = src + 5 + !ss;
+          const u32 dict = did == 0 ? 0u : did == 1 ? (u32)q[0] : did == 2 ? (u32)ld16(q) : ld32(q);
+          if (dict) S.err = ZE_DICT_WRONG;
+          q += didSize;
+          if (fcsSize) {
+            const u64 v = fcsSize == 1 ? (u64)q[0] : fcsSize == 2 ? (u64)ld16(q) + 256 : fcsSize == 4 ? (u64)ld32(q) : ld64(q);
+            S.fcsLo = (u32)v; S.fcsHi = (u32)(v >> 32); S.fcsHave = 1;
+          }
+        }
       }
       S.blkPos = hs;
       a.frameMeta[2 * (size_t)f] = checksum;   // [2f] = has checksum, [2f+1] = stored checksum (set at frame end)
@@ -416,9 +432,14 @@ zra_decode_frames_kernel(ZraDecodeArgs a) {
       if (lane == 0) {
         S.litStreams = 1; S.litRle = 0;
         parse_literals_header(S, blk, bsize, lim);
+        S.seqHdrErr = 0;
         if (!S.err) {
+          // the sequences header is parsed now (its fields steer the literal stage's scratch), but an error in it is only raised
+          // after the literals have been decoded: the reference decodes the literals section first (ZSTD_decodeLiteralsBlock)
           S.seqPos = S.litHdr + S.litComp;
           parse_seq_header(S, blk + S.seqPos, bsize - S.seqPos);
+          S.seqHdrErr = S.err; S.err = 0;
+          if (S.seqHdrErr) S.nbSeq = 0;
         }
       }
       wsync();
@@ -476,6 +497,7 @@ zra_decode_frames_kernel(ZraDecodeArgs a) {
       }
       wsync();
       if (S.err) break;
+      if (S.seqHdrErr) { wsync(); if (lane == 0) S.err = S.seqHdrErr; wsync(); break; }
 
       // ---- sequence decode tables: lane 0 parses each description, the wave builds it
       if (nbSeq) {
@@ -538,14 +560,16 @@ zra_decode_frames_kernel(ZraDecodeArgs a) {
       u32 outBase = 0, litBase = 0;              // running positions (wave-uniform)
       bool fail = false;
       for (u32 first = 0; first < nbSeq; first += BATCH) {
-        const u32 cnt = min((u32)BATCH, nbSeq - first);
+        const u32 cntAll = min((u32)BATCH, nbSeq - first);
         // -------- stage A: lane 0 — FSE sequence decode of this batch
         if (lane == 0) {
-          u32 bad = 0;
-          for (u32 i = 0; i < cnt; i++) {
+          // A malformed sequence stops the decode, but the sequences before it are still executed first: the reference decodes and
+          // executes one sequence at a time, so an execution error of an earlier sequence wins over the decode error of a later one
+          u32 bad = 0, valid = cntAll;
+          for (u32 i = 0; i < cntAll; i++) {
             const u32 eL = S.llT[sLL], eM = S.mlT[sML], eO = S.ofT[sOF];
             const u32 ofBits = (eO >> 8) & 0xFF, mlBits = (eM >> 8) & 0xFF, llBits = (eL >> 8) & 0xFF;
-            if (ofBits > 31) { bad = 1; break; }
+            if (ofBits > 31) { bad = 1; valid = i; break; }
             const u32 baseL = S.llBase[eL & 0xFF], baseM = S.mlBase[eM & 0xFF];   // by symbol; not on the bit-position chain
             // offset, match-length and literal-length extra bits in ONE extraction when they fit the 57 bits a reload guarantees
             // (always, for windows <= 128 KiB); bitstream order: OF, ML, LL = topmost ... lowest
@@ -570,7 +594,7 @@ zra_decode_frames_kernel(ZraDecodeArgs a) {
               sML = (eM >> 20) + ((st >> nO) & ((1u << nM) - 1));
               sOF = (eO >> 20) + (st & ((1u << nO) - 1));
             }
-            if (br.pos < 0) { bad = 1; break; }
+            if (br.pos < 0) { bad = 1; valid = i; break; }
             u32 off;                                   // repcode resolution (A.3)
             if (offVal > 3) { off = offVal - 3; rep2 = rep1; rep1 = rep0; rep0 = off; }
             else {
@@ -578,18 +602,20 @@ zra_decode_frames_kernel(ZraDecodeArgs a) {
               if (idx == 1) off = rep0;
               else {
                 off = idx == 2 ? rep1 : idx == 3 ? rep2 : rep0 - 1;
-                if (off == 0) { bad = 1; break; }
+                off += !off;                               // zstd 1.4.9 forces a zero offset to 1 (no error)
                 if (idx != 2) rep2 = rep1;
                 rep1 = rep0; rep0 = off;
               }
             }
             S.seqLL[i] = ll; S.seqML[i] = ml; S.seqOF[i] = off;
           }
-          if (!bad && first + cnt == nbSeq && br.pos != 0) bad = 1;
-          if (bad) S.err = ZE_CORRUPTION;
+          if (!bad && first + cntAll == nbSeq && br.pos != 0) bad = 1;     // checked after the last sequence has been executed
+          S.batchValid = bad ? (valid | 0x80000000u) : valid;
         }
         wsync();
-        if (S.err) { fail = true; break; }
+        const u32 bv = S.batchValid;
+        const bool chainBad = bv >> 31;
+        const u32 cnt = bv & 0x7FFFFFFFu;
         // -------- stage B: positions by wave prefix scan; every lane copies its sequence's literals
         const bool act = (u32)lane < cnt;
         const u32 ll = act ? S.seqLL[lane] : 0, ml = act ? S.seqML[lane] : 0, off = act ? S.seqOF[lane] : 1;
@@ -599,8 +625,9 @@ zra_decode_frames_kernel(ZraDecodeArgs a) {
         const u32 mdst = oStart + ll;
         u32 e = 0;
         if (act) {
-          if (lStart > regen || ll > regen - lStart) e = ZE_CORRUPTION;
-          else if (oStart > outCap || tot > outCap - oStart) e = ZE_DSTSIZE_TOOSMALL;
+          // ZSTD_execSequenceEnd order: destination room first, then the literal buffer, then the offset
+          if (oStart > outCap || tot > outCap - oStart) e = ZE_DSTSIZE_TOOSMALL;
+          else if (lStart > regen || ll > regen - lStart) e = ZE_CORRUPTION;
           else if (off > produced0 + mdst) e = ZE_CORRUPTION;
         }
         const u64 em = __ballot(e != 0);
@@ -652,6 +679,7 @@ zra_decode_frames_kernel(ZraDecodeArgs a) {
           }
         }
         outBase += bcast_u32(incT, 63); litBase += bcast_u32(incL, 63);
+        if (chainBad) { if (lane == 0) S.err = ZE_CORRUPTION; wsync(); fail = true; break; }
       }
       if (fail || S.err) break;
 
@@ -673,12 +701,12 @@ zra_decode_frames_kernel(ZraDecodeArgs a) {
       u32 err = S.err;
       if (!err) {
         u32 pos = S.blkPos;
-        if (a.frameMeta[2 * (size_t)f]) {
+        if (S.fcsHave && (S.fcsHi != 0 || S.fcsLo != S.produced)) err = ZE_CORRUPTION;   // declared size first, then the checksum
+        if (!err && a.frameMeta[2 * (size_t)f]) {
           if (srcSize - pos < 4) err = ZE_CHECKSUM_WRONG;
           else { a.frameMeta[2 * (size_t)f + 1] = ld32(src + pos); pos += 4; }
         }
         if (!err && pos != srcSize) err = ZE_SRCSIZE_WRONG;          // seek table and frame walk disagree
-        if (!err && S.produced != a.outExpect[f]) err = ZE_CORRUPTION; // frame does not regenerate frameSize bytes
       }
       a.status[f] = err;
       a.produced[f] = S.produced;

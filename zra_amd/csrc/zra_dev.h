@@ -15,7 +15,7 @@ typedef int32_t i32;
 // zstd error codes surfaced through ZraStatus.zstd (reference zra.cpp:19-23, zstd_errors.h of 1.4.9)
 enum : u32 {
   ZE_OK = 0, ZE_GENERIC = 1, ZE_PREFIX_UNKNOWN = 10, ZE_FRAMEPARAM_UNSUPPORTED = 14, ZE_WINDOW_TOO_LARGE = 16,
-  ZE_CORRUPTION = 20, ZE_CHECKSUM_WRONG = 22, ZE_DICT_CORRUPTED = 30, ZE_PARAM_UNSUPPORTED = 40,
+  ZE_CORRUPTION = 20, ZE_CHECKSUM_WRONG = 22, ZE_DICT_CORRUPTED = 30, ZE_DICT_WRONG = 32, ZE_PARAM_UNSUPPORTED = 40,
   ZE_DSTSIZE_TOOSMALL = 70, ZE_SRCSIZE_WRONG = 72,
 };
 

@@ -471,7 +471,7 @@ Status Engine::compress_frames_host(const uint8_t* hIn, size_t n, uint8_t* hBody
 }
 
 Status Engine::decode_host(const uint8_t* hSpan, size_t spanSize, const std::vector<uint64_t>& starts, const std::vector<uint64_t>& ends,
-                           uint32_t frameSize, uint64_t total, uint8_t* hOut, size_t skip, size_t size) {
+                           uint32_t frameSize, uint64_t total, uint8_t* hOut, size_t skip, size_t size, bool wholeArchive) {
   HIPCHK(hipSetDevice(device_));
   const uint32_t nFrames = (uint32_t)starts.size();
   if (nFrames == 0) return ok();
@@ -483,7 +483,7 @@ Status Engine::decode_host(const uint8_t* hSpan, size_t spanSize, const std::vec
     oo[i] = o;
     ex[i] = o >= total ? 0 : (uint32_t)std::min<uint64_t>(frameSize, total - o);
   }
-  if (!hostIn_.reserve(spanSize + 64) || !hostOut_.reserve((size_t)nFrames * frameSize + 64) || !frameOff_.reserve(se.size() * 8) ||
+  if (!hostIn_.reserve(spanSize + 64) || !hostOut_.reserve(std::max<size_t>((size_t)nFrames * frameSize, wholeArchive ? (size_t)total : 0) + 64) || !frameOff_.reserve(se.size() * 8) ||
       !outOff_.reserve((size_t)nFrames * 8) || !expect_.reserve((size_t)nFrames * 4))
     return zerr(64);
   HIPCHK(hipMemcpyAsync(hostIn_.p, hSpan, spanSize, hipMemcpyHostToDevice, stream_));
@@ -492,9 +492,11 @@ Status Engine::decode_host(const uint8_t* hSpan, size_t spanSize, const std::vec
   HIPCHK(hipMemcpyAsync(expect_.p, ex.data(), (size_t)nFrames * 4, hipMemcpyHostToDevice, stream_));
   HIPCHK(hipStreamSynchronize(stream_));
   Status s = decode_jobs(hostIn_.as<uint8_t>(), spanSize, frameOff_.as<uint64_t>(), hostOut_.as<uint8_t>(), outOff_.as<uint64_t>(),
-                         expect_.as<uint32_t>(), nFrames, 2);
+                         expect_.as<uint32_t>(), nFrames, 2, wholeArchive ? total : 0);
   if (s.zra) return s;
   if (skip + size > (uint64_t)nFrames * frameSize) return {kOutOfBounds, 0};
+  // frames that regenerated less than their slots (corrupted archive, sequential tail): only what was written reaches the caller
+  if (wholeArchive && lastProducedTotal_ != ~0ull) size = lastProducedTotal_ > skip ? (size_t)std::min<uint64_t>(size, lastProducedTotal_ - skip) : 0;
   if (size) HIPCHK(hipMemcpyAsync(hOut, hostOut_.as<uint8_t>() + skip, size, hipMemcpyDeviceToHost, stream_));
   HIPCHK(hipStreamSynchronize(stream_));
   return ok();

@@ -47,7 +47,8 @@ class Engine {
   // ---- decode
   // Decode nFrames frames described by device job arrays. Synchronises and returns the first failing frame's code.
   Status decode_jobs(const uint8_t* dBody, uint64_t bodySize, const uint64_t* dFrameOff, uint8_t* dOut,
-                     const uint64_t* dOutOff, const uint32_t* dExpect, uint32_t nFrames, uint32_t offStride = 1);
+                     const uint64_t* dOutOff, const uint32_t* dExpect, uint32_t nFrames, uint32_t offStride = 1, uint64_t seqTotal = 0);
+  Status decode_launch(const struct ZraDecodeArgs& a, const uint32_t* dExpect, unsigned long long* res);
   // Whole archive resident on the device (header + body), output on the device.
   Status decompress_device(const uint8_t* dArc, size_t arcSize, uint8_t* dOut, size_t outCap);
   // Batched random access, archive + output on the device, query arrays on the host.
@@ -77,7 +78,7 @@ class Engine {
   // frames given as (start,end) pairs inside hSpan; frame i regenerates min(frameSize, total - i*frameSize) bytes;
   // bytes [skip, skip+size) of the concatenated output are returned in hOut
   Status decode_host(const uint8_t* hSpan, size_t spanSize, const std::vector<uint64_t>& starts, const std::vector<uint64_t>& ends,
-                     uint32_t frameSize, uint64_t total, uint8_t* hOut, size_t skip, size_t size);
+                     uint32_t frameSize, uint64_t total, uint8_t* hOut, size_t skip, size_t size, bool wholeArchive = false);
 
   int device() const { return device_; }
   int num_cus() const { return numCUs_; }
@@ -98,8 +99,9 @@ class Engine {
   DevBuf encScan_;
   hipStream_t stream2_ = nullptr;          // entropy stage / gather stream (overlaps the match finder on stream_)
   std::vector<hipEvent_t> evPool_;
-  DevBuf hostIn_, hostOut_;
+  DevBuf hostIn_, hostOut_, seqScratch_;
   uint64_t dbgSeqStride_ = 0; uint32_t dbgB_ = 0;
+  uint64_t lastProducedTotal_ = ~0ull;     // whole-archive decode that fell back to the sequential tail: bytes actually regenerated
   int waitValueOk_ = 0;                    // 0 unknown, 1 hipStreamWaitValue32 works on device memory, -1 it does not (batch path)
   friend struct EncodeImpl;
 };

@@ -60,14 +60,24 @@ __global__ void zra_jobs_from_seektable_kernel(const u8* table, u32 nFrames, u32
 }
 
 // content-checksum verification of decoded frames: 4 lanes per frame (16 frames per wave)
-__global__ void zra_xxh64_verify_kernel(const u8* out, const u64* outOff, const u32* expect, const u32* frameMeta, u32* status, u32 nFrames) {
+// Frame end, in the order of ZSTD_decompressFrame: content checksum over the bytes the frame actually regenerated, then (ours, the
+// frames being decoded side by side into fixed slots) the regenerated size against the slot: ZE_SIZE_MISMATCH is not a zstd code —
+// the caller either re-decodes sequentially from that frame (whole-archive decode: one multi-frame zstd call in the reference packs
+// frames back to back whatever they regenerate) or reports corruption_detected.
+constexpr u32 ZE_SIZE_MISMATCH = 255;
+__global__ void zra_xxh64_verify_kernel(const u8* out, const u64* outOff, const u32* expect, const u32* produced, const u32* frameMeta,
+                                        u32* status, u32 nFrames) {
   const u32 gid = blockIdx.x * blockDim.x + threadIdx.x;
   const u32 f = gid >> 2; const int j = gid & 3;
-  const bool active = f < nFrames && frameMeta[2 * (size_t)f] && status[f] == 0;
+  const bool live = f < nFrames && status[f] == 0;
+  const bool active = live && frameMeta[2 * (size_t)f];
   const u8* p = active ? out + outOff[f] : out;
-  const u32 n = active ? expect[f] : 0;
+  const u32 n = active ? produced[f] : 0;
   const u64 h = zra_xxh64_quad(p, n, j);
-  if (active && j == 0 && (u32)h != frameMeta[2 * (size_t)f + 1]) status[f] = ZE_CHECKSUM_WRONG;
+  if (live && j == 0) {
+    if (active && (u32)h != frameMeta[2 * (size_t)f + 1]) status[f] = ZE_CHECKSUM_WRONG;
+    else if (expect && produced[f] != expect[f]) status[f] = ZE_SIZE_MISMATCH;
+  }
 }
 
 // result[0] = min over failing frames of (frame << 8 | code); ~0 when all succeeded
@@ -141,7 +151,7 @@ Engine::~Engine() {
   (void)hipSetDevice(device_);
   if (stream_) (void)hipStreamSynchronize(stream_);
   for (DevBuf* b : {&litScratch_, &queue_, &status_, &produced_, &frameMeta_, &frameOff_, &outOff_, &expect_, &result_, &temp_, &qmeta_,
-                    &encScan_, &hostIn_, &hostOut_})
+                    &encScan_, &hostIn_, &hostOut_, &seqScratch_})
     b->release();
   for (auto& x : encCtx_) for (DevBuf* b : {&x.tables, &x.seqs, &x.lits, &x.slots, &x.misc, &x.ck, &x.sizes}) b->release();
   for (auto ev : evPool_) (void)hipEventDestroy(ev);
@@ -154,40 +164,80 @@ Engine::~Engine() {
 
 Status Engine::sync() { HIPCHK(hipSetDevice(device_)); HIPCHK(hipStreamSynchronize(stream_)); return ok(); }
 
-Status Engine::decode_jobs(const uint8_t* dBody, uint64_t bodySize, const uint64_t* dFrameOff, uint8_t* dOut,
-                           const uint64_t* dOutOff, const uint32_t* dExpect, uint32_t nFrames, uint32_t offStride) {
-  if (nFrames == 0) return ok();
-  HIPCHK(hipSetDevice(device_));
+// One launch of the decode kernel + frame-end checks over `nFrames` jobs; returns (first failing frame << 8 | code) or ~0.
+Status Engine::decode_launch(const ZraDecodeArgs& a0, const uint32_t* dExpect, unsigned long long* res) {
+  ZraDecodeArgs a = a0;
   int perCU = 0;
   HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, zra_decode_frames_kernel, 64, 0));
   if (perCU < 1) perCU = 1;
   { static const int cap = std::getenv("ZRA_DEC_WAVES") ? std::atoi(std::getenv("ZRA_DEC_WAVES")) : 0; if (cap > 0 && cap < perCU) perCU = cap; }   // bring-up: occupancy sweep
+  const uint32_t nFrames = a.nFrames;
   uint32_t grid = (uint32_t)std::min<uint64_t>(nFrames, (uint64_t)numCUs_ * perCU);
   if (!litScratch_.reserve((size_t)grid * ZRA_LIT_STRIDE) || !queue_.reserve(64) || !status_.reserve((size_t)nFrames * 4) ||
       !produced_.reserve((size_t)nFrames * 4) || !frameMeta_.reserve((size_t)nFrames * 8) || !result_.reserve(64))
     return zerr(64 /* memory_allocation */);
   HIPCHK(hipMemsetAsync(queue_.p, 0, 64, stream_));
   HIPCHK(hipMemsetAsync(result_.p, 0xFF, 64, stream_));
-  ZraDecodeArgs a;
-  a.body = dBody; a.bodySize = bodySize; a.frameOff = dFrameOff; a.out = dOut; a.outOff = dOutOff; a.outCap = dExpect; a.outExpect = dExpect;
-  a.nFrames = nFrames; a.offStride = offStride; a.queue = queue_.as<uint32_t>(); a.litScratch = litScratch_.as<uint8_t>();
+  a.queue = queue_.as<uint32_t>(); a.litScratch = litScratch_.as<uint8_t>();
   { static const int skip = std::getenv("ZRA_DEC_SKIP") ? std::atoi(std::getenv("ZRA_DEC_SKIP")) : 0; a.debugSkip = (uint32_t)skip; }
   a.status = status_.as<uint32_t>(); a.produced = produced_.as<uint32_t>(); a.frameMeta = frameMeta_.as<uint32_t>();
   HIPCHK(hipEventRecord(ev0_, stream_));
   hipLaunchKernelGGL(zra_decode_frames_kernel, dim3(grid), dim3(64), 0, stream_, a);
   HIPCHK(hipEventRecord(ev1_, stream_));
   const uint32_t tb = 256;
-  hipLaunchKernelGGL(zra_xxh64_verify_kernel, dim3((nFrames * 4 + tb - 1) / tb), dim3(tb), 0, stream_, dOut, dOutOff, dExpect,
-                     frameMeta_.as<uint32_t>(), status_.as<uint32_t>(), nFrames);
+  hipLaunchKernelGGL(zra_xxh64_verify_kernel, dim3((nFrames * 4 + tb - 1) / tb), dim3(tb), 0, stream_, a.out, a.outOff, dExpect,
+                     produced_.as<uint32_t>(), frameMeta_.as<uint32_t>(), status_.as<uint32_t>(), nFrames);
   hipLaunchKernelGGL(zra_first_error_kernel, dim3((nFrames + tb - 1) / tb), dim3(tb), 0, stream_, status_.as<uint32_t>(), nFrames,
                      result_.as<unsigned long long>());
-  unsigned long long res = 0;
-  HIPCHK(hipMemcpyAsync(&res, result_.p, 8, hipMemcpyDeviceToHost, stream_));
+  HIPCHK(hipMemcpyAsync(res, result_.p, 8, hipMemcpyDeviceToHost, stream_));
   HIPCHK(hipStreamSynchronize(stream_));
   HIPCHK(hipGetLastError());
   float ms = 0;
   if (hipEventElapsedTime(&ms, ev0_, ev1_) == hipSuccess) { lastKernelMs_ = ms; kstats_[4] += ms; kstats_[5] += 1; }
-  if (res != ~0ull) return zerr((int)(res & 0xFF));
+  return ok();
+}
+
+// seqTotal == 0: every frame owns its slot (random access: the reference decodes the touched frames into frameSize buffers).
+// seqTotal != 0: whole-archive semantics of ONE multi-frame zstd call over `seqTotal` bytes of destination (zra.cpp:249): frames are
+// decoded side by side into their nominal slots; if one regenerates another size than its slot (only possible for a corrupted or
+// foreign archive) everything from that frame on is re-decoded one frame at a time, packed back to back, exactly as the reference
+// would — first error in frame order, dstSize_tooSmall against the whole destination.
+Status Engine::decode_jobs(const uint8_t* dBody, uint64_t bodySize, const uint64_t* dFrameOff, uint8_t* dOut,
+                           const uint64_t* dOutOff, const uint32_t* dExpect, uint32_t nFrames, uint32_t offStride, uint64_t seqTotal) {
+  lastProducedTotal_ = ~0ull;
+  if (nFrames == 0) return ok();
+  HIPCHK(hipSetDevice(device_));
+  ZraDecodeArgs a{};
+  a.body = dBody; a.bodySize = bodySize; a.frameOff = dFrameOff; a.out = dOut; a.outOff = dOutOff; a.outCap = dExpect;
+  a.nFrames = nFrames; a.offStride = offStride;
+  unsigned long long res = 0;
+  Status st = decode_launch(a, dExpect, &res);
+  if (st.zra) return st;
+  if (res == ~0ull) return ok();
+  const uint32_t code = (uint32_t)(res & 0xFF), first = (uint32_t)(res >> 8);
+  const bool resize = code == 255 /* ZE_SIZE_MISMATCH */ || code == 70;
+  if (!seqTotal || !resize) return zerr(code == 255 ? 20 : (int)code);
+  // ---- sequential tail from frame `first`
+  uint64_t cur = 0;
+  HIPCHK(hipMemcpyAsync(&cur, dOutOff + first, 8, hipMemcpyDeviceToHost, stream_));
+  HIPCHK(hipStreamSynchronize(stream_));
+  if (!seqScratch_.reserve(64)) return zerr(64);
+  uint64_t* dCur = seqScratch_.as<uint64_t>(); uint32_t* dCap = (uint32_t*)(seqScratch_.as<uint8_t>() + 16);
+  for (uint32_t f = first; f < nFrames; f++) {
+    const uint32_t cap = (uint32_t)std::min<uint64_t>(seqTotal > cur ? seqTotal - cur : 0, 0xFFFFFF00u);
+    HIPCHK(hipMemcpyAsync(dCur, &cur, 8, hipMemcpyHostToDevice, stream_));
+    HIPCHK(hipMemcpyAsync(dCap, &cap, 4, hipMemcpyHostToDevice, stream_));
+    ZraDecodeArgs b = a;
+    b.frameOff = dFrameOff + (size_t)f * offStride; b.outOff = dCur; b.outCap = dCap; b.nFrames = 1;
+    st = decode_launch(b, nullptr, &res);
+    if (st.zra) return st;
+    if (res != ~0ull) return zerr((int)(res & 0xFF));
+    uint32_t got = 0;
+    HIPCHK(hipMemcpyAsync(&got, produced_.p, 4, hipMemcpyDeviceToHost, stream_));
+    HIPCHK(hipStreamSynchronize(stream_));
+    cur += got;
+  }
+  lastProducedTotal_ = cur;
   return ok();
 }
 
@@ -209,7 +259,7 @@ Status Engine::decompress_device(const uint8_t* dArc, size_t arcSize, uint8_t* d
     return zerr(64);
   hipLaunchKernelGGL(zra_jobs_from_seektable_kernel, dim3((nFrames + 256) / 256), dim3(256), 0, stream_, dArc + h.seekTableOffset,
                      nFrames, h.frameSize, h.uncompressedSize, frameOff_.as<uint64_t>(), outOff_.as<uint64_t>(), expect_.as<uint32_t>());
-  return decode_jobs(dArc + h.size, arcSize - h.size, frameOff_.as<uint64_t>(), dOut, outOff_.as<uint64_t>(), expect_.as<uint32_t>(), nFrames);
+  return decode_jobs(dArc + h.size, arcSize - h.size, frameOff_.as<uint64_t>(), dOut, outOff_.as<uint64_t>(), expect_.as<uint32_t>(), nFrames, 1, outCap);
 }
 
 Status Engine::decompress_frames_host_list(const uint8_t* dBody, uint64_t bodySize, const std::vector<uint64_t>& hFrameOff,
