@@ -152,7 +152,15 @@ Status Engine::compress_impl(const uint8_t* dIn, size_t inSize, uint8_t* dBody, 
   }
   // Two scratch contexts: the match finder of batch k+1 (stream A) overlaps the entropy stage + gather of batch k (stream B);
   // both kernels are latency-bound, so they share the CUs almost for free. 8 GiB of scratch per context.
-  const uint64_t budget = 8ull << 30;
+  // scratch per context: enough for one frame per resident wave (32 per CU) of the one-lane finders, whose throughput is frames in
+  // flight / frame latency (level 9 @ 256 KiB needs 3.6 MiB per frame); bring-up knob ZRA_ENC_BUDGET_GIB
+  uint64_t budget = 8ull << 30;
+  if (const char* e = std::getenv("ZRA_ENC_BUDGET_GIB")) budget = (uint64_t)std::atoi(e) << 30;
+  else if (full.strategy != 2) {
+    // measured at level 9 @ 256 KiB (4 GiB input): 8 GiB -> 0.33 GiB/s, 16 -> 0.58, 32 -> 0.71, 64 -> 0.93 (all frames resident)
+    size_t freeB = 0, totalB = 0;
+    if (hipMemGetInfo(&freeB, &totalB) == hipSuccess) budget = std::min<uint64_t>(64ull << 30, std::max<uint64_t>(budget, (uint64_t)(freeB * 0.35)));
+  }
   uint32_t B = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>({nFramesTotal, budget / perFrame, 16384ull}));
   if (B > 1024) B &= ~1023u;
   const int nCtx = nFramesTotal > B ? 2 : 1;
