@@ -10,7 +10,7 @@
 #include <cstring>
 #include <vector>
 
-extern "C" __global__ void zra_mf_kernel(ZraEncArgs a, uint32_t block, uint32_t only, uint32_t onlySlot);
+extern "C" __global__ void zra_mf_kernel(ZraEncArgs a, uint32_t block, uint32_t only, uint32_t onlySlot, uint32_t perWave);
 extern "C" __global__ void zra_mf_dfast_kernel(ZraEncArgs a, uint32_t block, uint32_t only, uint32_t onlySlot);
 extern "C" __global__ void zra_entropy_kernel(ZraEncArgs a, uint32_t block);
 
@@ -161,7 +161,7 @@ Status Engine::compress_impl(const uint8_t* dIn, size_t inSize, uint8_t* dBody, 
     size_t freeB = 0, totalB = 0;
     if (hipMemGetInfo(&freeB, &totalB) == hipSuccess) budget = std::min<uint64_t>(64ull << 30, std::max<uint64_t>(budget, (uint64_t)(freeB * 0.35)));
   }
-  uint32_t B = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>({nFramesTotal, budget / perFrame, 16384ull}));
+  uint32_t B = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>({nFramesTotal, budget / perFrame, full.strategy == 2 ? 16384ull : 65536ull}));
   if (B > 1024) B &= ~1023u;
   const int nCtx = nFramesTotal > B ? 2 : 1;
   for (int c = 0; c < nCtx; c++) {
@@ -232,9 +232,14 @@ Status Engine::compress_impl(const uint8_t* dIn, size_t inSize, uint8_t* dBody, 
         const bool oddTail = hasTail && (tail.strategy == 2) != (full.strategy == 2);
         if (full.strategy == 2) {
           hipLaunchKernelGGL(zra_mf_dfast_kernel, dim3(nb), dim3(64), filterBytes + dynLds, stream_, a, blk, 0xFFFFFFFFu, 0u);
-          if (oddTail) hipLaunchKernelGGL(zra_mf_kernel, dim3(1), dim3(64), 0, stream_, a, blk, (uint32_t)(nb - 1), (uint32_t)(nb - 1));
+          if (oddTail) hipLaunchKernelGGL(zra_mf_kernel, dim3(1), dim3(64), 0, stream_, a, blk, (uint32_t)(nb - 1), (uint32_t)(nb - 1), 1u);
         } else {
-          hipLaunchKernelGGL(zra_mf_kernel, dim3(nb), dim3(64), dynLds, stream_, a, blk, 0xFFFFFFFFu, 0u);
+          // frames per wave: as many as it takes to have every frame of the batch resident at once (32 waves per CU)
+          static const int pwEnv = std::getenv("ZRA_MF_PERWAVE") ? std::atoi(std::getenv("ZRA_MF_PERWAVE")) : 0;
+          // (lazy2's deep chain searches diverge too much: 0.84 GiB/s with 1 frame per wave, 0.64 with 2, 0.50 with 4; fast gains 9.4 -> 14.5)
+          uint32_t perWave = pwEnv > 0 ? (uint32_t)pwEnv : full.strategy >= 5 ? 1u
+                           : std::min<uint32_t>(8u, std::max<uint32_t>(1u, (nb + (uint32_t)numCUs_ * 32 - 1) / ((uint32_t)numCUs_ * 32)));
+          hipLaunchKernelGGL(zra_mf_kernel, dim3((nb + perWave - 1) / perWave), dim3(64), dynLds, stream_, a, blk, 0xFFFFFFFFu, 0u, perWave);
           if (oddTail) hipLaunchKernelGGL(zra_mf_dfast_kernel, dim3(1), dim3(64), filterBytes, stream_, a, blk, (uint32_t)(nb - 1), (uint32_t)(nb - 1));
         }
       }
@@ -357,7 +362,7 @@ Status Engine::compress_persistent(const uint8_t* dIn, size_t inSize, uint8_t* d
     hipEvent_t tailEv = nullptr;
     if (oddTail) {
       ZraEncArgs at = a; at.mfQueue = nullptr;
-      hipLaunchKernelGGL(zra_mf_kernel, dim3(1), dim3(64), 0, stream_, at, 0u, (uint32_t)(n - 1), 0u);
+      hipLaunchKernelGGL(zra_mf_kernel, dim3(1), dim3(64), 0, stream_, at, 0u, (uint32_t)(n - 1), 0u, 1u);
       tailEv = ev(); if (!tailEv) return zerr(1);
       HIPCHK(hipEventRecord(tailEv, stream_));
     }

@@ -642,22 +642,32 @@ zra_mf_dfast_kernel(ZraEncArgs a, u32 block, u32 only, u32 onlySlot) {
   }
 }
 
-// Match finder for the other strategies (fast, greedy, lazy, lazy2: one lane walks the parse). `only` = 0xFFFFFFFF: every frame
-// of the batch; otherwise just that frame (the short last frame whose strategy differs from the batch's), launched as one workgroup.
+// Match finder for the other strategies (fast, greedy, lazy, lazy2). The parse of a frame is one dependent pointer chase (hash head
+// -> chain -> candidate bytes), so a frame gets ONE lane and throughput is frames in flight / frame latency: a wave carries `perWave`
+// frames in its first lanes (SIMT across frames: divergent, but the lanes' memory round trips overlap), and the whole wave clears
+// their tables. `only` = 0xFFFFFFFF: every frame of the batch; otherwise just that frame (the short last frame whose strategy differs
+// from the batch's), launched as one workgroup on table slot `onlySlot`.
 extern "C" __global__ void __launch_bounds__(64)
-zra_mf_kernel(ZraEncArgs a, u32 block, u32 only, u32 onlySlot) {
+zra_mf_kernel(ZraEncArgs a, u32 block, u32 only, u32 onlySlot, u32 perWave) {
   const int lane = threadIdx.x;
-  const bool all = only == 0xFFFFFFFFu;             // otherwise a single-workgroup launch for frame `only` on table slot `onlySlot`
-  MfFrame F;
-  if (!mf_frame_setup(a, block, lane, F, all ? blockIdx.x : only, all ? blockIdx.x : onlySlot)) return;
+  const bool all = only == 0xFFFFFFFFu;
+  if (!all) perWave = 1;
+  // cooperative per-frame setup (table clears), one frame after the other; every lane keeps the descriptor of "its" frame
+  MfFrame F; bool mine = false;
+  for (u32 k = 0; k < perWave; k++) {
+    const u32 f = all ? blockIdx.x * perWave + k : only;
+    if (f >= a.nFrames) break;
+    MfFrame G;
+    const bool go = mf_frame_setup(a, block, lane, G, f, all ? f : onlySlot);
+    if ((u32)lane == k) { F = G; mine = go && G.P->strategy != 2; }      // dfast frames belong to zra_mf_dfast_kernel
+  }
+  if (!mine) return;
   const ZraEncParams& P = *F.P;
   const u8* src = F.src; ZraEncFrameState* st = F.st; ZraEncBlockOut* bo = F.bo;
   u32* hashT = F.hashT; u32* chainT = F.chainT; u64* seqs = F.seqs;
   const u32 bs = F.bs, be = F.be;
   u32 rep[3] = {st->rep[0], st->rep[1], st->rep[2]};
-  u32 lastLL, nseq = 0;
-  if (P.strategy == 2) return;                      // dfast frames belong to zra_mf_dfast_kernel
-  if (lane != 0) return;
+  u32 lastLL;
   bo->skip = 0;
   Emit E; E.seqs = seqs; E.n = 0;
   // limited update after a very long match (A.4.3 hash chain prologue; harmless for the other finders)
