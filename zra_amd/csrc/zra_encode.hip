@@ -159,7 +159,7 @@ Status Engine::compress_impl(const uint8_t* dIn, size_t inSize, uint8_t* dBody, 
   else if (full.strategy != 2) {
     // measured at level 9 @ 256 KiB (4 GiB input): 8 GiB -> 0.33 GiB/s, 16 -> 0.58, 32 -> 0.71, 64 -> 0.93 (all frames resident)
     size_t freeB = 0, totalB = 0;
-    if (hipMemGetInfo(&freeB, &totalB) == hipSuccess) budget = std::min<uint64_t>(64ull << 30, std::max<uint64_t>(budget, (uint64_t)(freeB * 0.35)));
+    if (hipMemGetInfo(&freeB, &totalB) == hipSuccess) budget = std::min<uint64_t>(64ull << 30, std::max<uint64_t>(budget, (uint64_t)(freeB * 0.25)));
   }
   uint32_t B = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>({nFramesTotal, budget / perFrame, full.strategy == 2 ? 16384ull : 65536ull}));
   if (B > 1024) B &= ~1023u;
