@@ -403,8 +403,8 @@ Status Engine::compress_persistent(const uint8_t* dIn, size_t inSize, uint8_t* d
   for (auto& sp : entSpans) { float m = 0; if (hipEventElapsedTime(&m, sp.first, sp.second) == hipSuccess) { kstats_[2] += m; kstats_[3] += 1; } }
   lastKernelMs_ = kernelMs;
   if (std::getenv("ZRA_ENC_TRACE")) {                 // bring-up: timeline relative to the first match-finder launch
-    for (auto& sp : mfSpans) { float a0 = 0, a1 = 0; hipEventElapsedTime(&a0, mfSpans[0].first, sp.first); hipEventElapsedTime(&a1, mfSpans[0].first, sp.second); std::fprintf(stderr, "mf  %8.2f .. %8.2f ms\n", a0, a1); }
-    for (auto& sp : entSpans) { float a0 = 0, a1 = 0; hipEventElapsedTime(&a0, mfSpans[0].first, sp.first); hipEventElapsedTime(&a1, mfSpans[0].first, sp.second); std::fprintf(stderr, "ent %8.2f .. %8.2f ms\n", a0, a1); }
+    for (auto& sp : mfSpans) { float a0 = 0, a1 = 0; (void)hipEventElapsedTime(&a0, mfSpans[0].first, sp.first); (void)hipEventElapsedTime(&a1, mfSpans[0].first, sp.second); std::fprintf(stderr, "mf  %8.2f .. %8.2f ms\n", a0, a1); }
+    for (auto& sp : entSpans) { float a0 = 0, a1 = 0; (void)hipEventElapsedTime(&a0, mfSpans[0].first, sp.first); (void)hipEventElapsedTime(&a1, mfSpans[0].first, sp.second); std::fprintf(stderr, "ent %8.2f .. %8.2f ms\n", a0, a1); }
   }
   *bodySize = total;
   return ok();
@@ -412,14 +412,14 @@ Status Engine::compress_persistent(const uint8_t* dIn, size_t inSize, uint8_t* d
 
 uint32_t Engine::debug_read_seqs(uint32_t frame, uint64_t* out, uint32_t cap, uint32_t meta[3]) {
   if (!dbgB_ || frame >= dbgB_) return 0;
-  hipSetDevice(device_);
-  hipDeviceSynchronize();
+  (void)hipSetDevice(device_);
+  (void)hipDeviceSynchronize();
   EncCtx& x = encCtx_[0];
   ZraEncBlockOut bo{};
-  hipMemcpy(&bo, x.misc.as<uint8_t>() + (size_t)dbgB_ * sizeof(ZraEncFrameState) + (size_t)frame * sizeof(ZraEncBlockOut), sizeof(bo), hipMemcpyDeviceToHost);
+  (void)hipMemcpy(&bo, x.misc.as<uint8_t>() + (size_t)dbgB_ * sizeof(ZraEncFrameState) + (size_t)frame * sizeof(ZraEncBlockOut), sizeof(bo), hipMemcpyDeviceToHost);
   meta[0] = bo.nbSeq; meta[1] = bo.lastLL; meta[2] = bo.skip;
   const uint32_t n = bo.nbSeq < cap ? bo.nbSeq : cap;
-  if (n) hipMemcpy(out, x.seqs.as<uint64_t>() + (size_t)frame * dbgSeqStride_, (size_t)n * 8, hipMemcpyDeviceToHost);
+  if (n) (void)hipMemcpy(out, x.seqs.as<uint64_t>() + (size_t)frame * dbgSeqStride_, (size_t)n * 8, hipMemcpyDeviceToHost);
   return n;
 }
 

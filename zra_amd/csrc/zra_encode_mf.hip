@@ -212,9 +212,7 @@ __device__ u32 mf_lazy(HC& H, const u8* src, u32 bs, u32 be, u32* rep, Emit& E, 
 // the first hit commit their inserts (no two share a bucket, so store order is irrelevant); the hit lane's match is then
 // handled wave-uniformly with wave-wide forward/backward length counts.
 __device__ __forceinline__ u32 rfl(u32 v) { return (u32)__builtin_amdgcn_readfirstlane((int)v); }
-__device__ __forceinline__ u64 rfl64(u64 v) { return (u64)rfl((u32)v) | ((u64)rfl((u32)(v >> 32)) << 32); }
 __device__ __forceinline__ u32 bcast(u32 v, u32 l) { return (u32)__builtin_amdgcn_readlane((int)v, (int)l); }
-__device__ __forceinline__ u64 bcast64(u64 v, u32 l) { return (u64)bcast((u32)v, l) | ((u64)bcast((u32)(v >> 32), l) << 32); }
 
 // common prefix of src[a..] and src[b..] (b < a), a limited to end; 64 lanes x 8 bytes per round trip
 __device__ __forceinline__ u32 wave_count_eq(const u8* src, u32 a, u32 b, u32 end, int lane) {
@@ -265,12 +263,8 @@ __device__ __forceinline__ u32 wave_count_back(const u8* src, u32 ip, u32 m, u32
 //   * sequences are collected in a register (lane = index & 63) and stored 64 at a time;
 //   * duplicate-bucket detection uses byte-wide LDS slots (2048 per table, no epochs, no atomics);
 //   * tags use all bits above the index (ib = bits needed for position+1), so every dfast frame size is tagged.
-__device__ __forceinline__ u32 wlane(u32 old, u32 val, u32 l) {
-  val = rfl(val); l = rfl(l);
-  asm("" : "+s"(val)); asm("" : "+s"(l));              // keep both operands in SGPRs (no literals in VOP3 on gfx9)
-  asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(old) : "s"(val), "s"(l) : "m0");
-  return old;
-}
+// lane l of `old` := val (val and l wave-uniform); a compare + select — v_writelane would need M0 for the lane select on gfx9
+__device__ __forceinline__ u32 wlane(u32 old, u32 val, u32 l) { return (threadIdx.x & 63u) == l ? val : old; }
 __device__ __forceinline__ bool lane_in(u64 mask) { return __builtin_amdgcn_inverse_ballot_w64(mask); }
 __device__ __forceinline__ u64 bit64(u32 i) { return 1ull << i; }
 
