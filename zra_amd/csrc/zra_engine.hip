@@ -4,6 +4,8 @@
 #include "zra_format.h"
 #include <algorithm>
 #include <cstdio>
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
@@ -286,6 +288,9 @@ Status Engine::decompress_ra_batch(const uint8_t* dArc, size_t arcSize, uint8_t*
                                    const uint64_t* hOutOff, size_t nq) {
   HIPCHK(hipSetDevice(device_));
   kstats_[4] = kstats_[5] = 0;
+  static const bool traceRa = std::getenv("ZRA_RA_TRACE") != nullptr;   // bring-up: host-side time of the batch set-up
+  const auto tr0 = std::chrono::steady_clock::now();
+  auto trace = [&](const char* what) { if (traceRa) std::fprintf(stderr, "ra %-18s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tr0).count()); };
   if (arcSize <= zra_fmt::kFixedSize) return {kOutOfBounds, 0};
   uint8_t fixed[zra_fmt::kFixedSize];
   HIPCHK(hipMemcpyAsync(fixed, dArc, sizeof(fixed), hipMemcpyDeviceToHost, stream_));
@@ -317,37 +322,50 @@ Status Engine::decompress_ra_batch(const uint8_t* dArc, size_t arcSize, uint8_t*
     for (size_t f = 0; f <= nFrames; f++) head[f + 1] += head[f];
     for (size_t q = 0; q < nq; q++) order[head[std::min<uint64_t>(hOff[q] / fs, nFrames)]++] = q;
   }
+  // dense numbering of the touched frames: pre[f] = touched frames before f (a query's frames are consecutive, so are their slots)
+  std::vector<uint32_t> pre((size_t)nFrames + 2, 0);
+  for (size_t f = 0; f <= nFrames; f++) pre[f + 1] = pre[f] + slot[f];
+  trace("set-up done");
   // passes bounded by a temp budget (decoded frames per pass); a pass is cut only where no taken query straddles
   const uint64_t budgetFrames = std::max<uint64_t>(1, (4ull << 30) / fs);
-  std::vector<uint64_t> se, jobOut, qmeta, frameSlot;
+  std::vector<uint64_t> se, jobOut, qmeta;
   std::vector<uint32_t> jobExp;
   size_t qi = 0;
   while (qi < nq) {
-    se.clear(); jobOut.clear(); jobExp.clear(); qmeta.clear(); frameSlot.clear();
     const uint64_t fstart = hOff[order[qi]] / fs;
-    uint64_t nslots = 0, maxFrameEnd = fstart, fcur = fstart;
-    size_t qj = qi;
+    uint64_t maxFrameEnd = fstart;
+    size_t qj = qi, nTaken = 0;
     for (; qj < nq; qj++) {
       const size_t q = order[qj];
       const uint64_t f0 = hOff[q] / fs, f1 = hSize[q] ? (hOff[q] + hSize[q] - 1) / fs : f0;
-      if (nslots >= budgetFrames && f0 >= maxFrameEnd) break;
-      for (; fcur <= f1 && fcur < nFrames; fcur++) {
-        if (!slot[fcur]) { frameSlot.push_back(~0ull); continue; }
-        frameSlot.push_back(nslots);
-        se.push_back(zra_fmt::entry_get(&table[fcur * 5]));          // frame start inside the body
-        se.push_back(zra_fmt::entry_get(&table[(fcur + 1) * 5]));    // frame end
-        jobOut.push_back(nslots * fs);
-        jobExp.push_back((uint32_t)std::min<uint64_t>(fs, h.uncompressedSize - fcur * fs));
-        nslots++;
-      }
-      if (hSize[q]) {
-        qmeta.push_back(frameSlot[f0 - fstart] * fs + hOff[q] % fs);
-        qmeta.push_back(hOutOff[q]);
-        qmeta.push_back(hSize[q]);
-      }
+      if ((uint64_t)(pre[std::min<uint64_t>(maxFrameEnd, nFrames)] - pre[fstart]) >= budgetFrames && f0 >= maxFrameEnd) break;
       maxFrameEnd = std::max(maxFrameEnd, f1 + 1);
+      nTaken += hSize[q] != 0;
+    }
+    const uint64_t fend = std::min<uint64_t>(maxFrameEnd, nFrames);
+    const uint64_t nslots = pre[fend] - pre[fstart];
+    se.resize((size_t)nslots * 2); jobOut.resize((size_t)nslots); jobExp.resize((size_t)nslots); qmeta.resize(nTaken * 3);
+    for (uint64_t f = fstart; f < fend; f++) {
+      if (!slot[f]) continue;
+      const uint64_t k = pre[f] - pre[fstart];
+      se[2 * k] = zra_fmt::entry_get(&table[f * 5]);                 // frame start inside the body
+      se[2 * k + 1] = zra_fmt::entry_get(&table[(f + 1) * 5]);       // frame end
+      jobOut[k] = k * fs;
+      jobExp[k] = (uint32_t)std::min<uint64_t>(fs, h.uncompressedSize - f * fs);
+    }
+    {
+      size_t w = 0;
+      for (size_t j = qi; j < qj; j++) {
+        const size_t q = order[j];
+        if (!hSize[q]) continue;
+        const uint64_t f0 = hOff[q] / fs;
+        qmeta[w++] = (uint64_t)(pre[f0] - pre[fstart]) * fs + hOff[q] % fs;
+        qmeta[w++] = hOutOff[q];
+        qmeta[w++] = hSize[q];
+      }
     }
     const uint32_t nj = (uint32_t)nslots;
+    trace("pass built");
     if (nj) {
       if (!temp_.reserve((size_t)nj * fs + 64) || !frameOff_.reserve(se.size() * 8) || !outOff_.reserve((size_t)nj * 8) ||
           !expect_.reserve((size_t)nj * 4) || !qmeta_.reserve(qmeta.size() * 8 + 8))
@@ -360,6 +378,7 @@ Status Engine::decompress_ra_batch(const uint8_t* dArc, size_t arcSize, uint8_t*
       // frames of a pass are not adjacent in the body: each job carries its own (start, end) pair -> offset stride 2
       Status s = decode_jobs(dArc + h.size, arcSize - h.size, frameOff_.as<uint64_t>(), temp_.as<uint8_t>(), outOff_.as<uint64_t>(),
                              expect_.as<uint32_t>(), nj, 2);
+      trace("pass decoded");
       if (s.zra) return s;
       const uint32_t nqPass = (uint32_t)(qmeta.size() / 3);
       if (nqPass) {
