@@ -327,7 +327,7 @@ Status Engine::decompress_ra_batch(const uint8_t* dArc, size_t arcSize, uint8_t*
   for (size_t f = 0; f <= nFrames; f++) pre[f + 1] = pre[f] + slot[f];
   trace("set-up done");
   // passes bounded by a temp budget (decoded frames per pass); a pass is cut only where no taken query straddles
-  const uint64_t budgetFrames = std::max<uint64_t>(1, (4ull << 30) / fs);
+  const uint64_t budgetFrames = std::max<uint64_t>(1, (8ull << 30) / fs);   // 8 GiB of decoded frames per pass
   std::vector<uint64_t> se, jobOut, qmeta;
   std::vector<uint32_t> jobExp;
   size_t qi = 0;
