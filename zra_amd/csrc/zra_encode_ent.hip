@@ -54,6 +54,11 @@ struct EncLitPhase {
   u8 hufHdr[192];
   short wNorm[16];            // FSE description of the Huffman weights (tableLog <= 6)
   u8 wSpread[64];
+  // small work arrays of the one-lane sections: in LDS, because a per-thread array that is indexed dynamically lives in scratch
+  // (HBM-backed private memory) and every access then costs a memory round trip
+  u32 wCount[16], wCumul[16], rankLast[16];
+  u16 nbPerRank[16], valPerRank[16];
+  u8 ncTmp[192];
 };
 struct EncSeqPhase {
   u32 cnt[3][64];
@@ -62,6 +67,7 @@ struct EncSeqPhase {
   u8 ncount[3][192];
   u8 codes[3][SEQ_TILE];
   u16 chain[3][SEQ_TILE];
+  u32 cumul[3][56];           // fse_build_ctable work array (LDS, not scratch)
 };
 struct __attribute__((aligned(16))) EncShared {
   u32 stage[STAGE_WORDS];
@@ -241,10 +247,9 @@ __device__ u32 fse_write_ncount(u8* out, const short* norm, u32 maxSym, u32 t) {
 }
 
 // serial (one lane) encoding-table build: spread, state table, per-symbol transforms
-__device__ int fse_build_ctable(ZraFseCTable* ct, const short* norm, u32 maxSym, u32 t, u8* cell) {
+__device__ int fse_build_ctable(ZraFseCTable* ct, const short* norm, u32 maxSym, u32 t, u8* cell, u32* cumul) {
   const u32 size = 1u << t, mask = size - 1, step = (size >> 1) + (size >> 3) + 3;
   u32 high = size - 1, pos = 0;
-  u32 cumul[54];
   ct->tableLog = t; ct->maxSym = maxSym; ct->rle = 0;
   cumul[0] = 0;
   for (u32 u = 1; u <= maxSym + 1; u++) cumul[u] = cumul[u - 1] + (norm[u - 1] == -1 ? 1u : (u32)norm[u - 1]);
@@ -293,7 +298,7 @@ __device__ u32 huf_set_max_height(EncShared& S, u32 lastNonNull, u32 maxNbBits) 
   while (nb[n] == maxNbBits) n--;
   totalCost >>= (largestBits - maxNbBits);
   const u32 none = 0xF0F0F0F0u;
-  u32 rankLast[14];
+  u32* const rankLast = S.lit.rankLast;
   for (int i = 0; i < 14; i++) rankLast[i] = none;
   {
     u32 cur = maxNbBits;
@@ -331,7 +336,7 @@ __device__ u32 huf_set_max_height(EncShared& S, u32 lastNonNull, u32 maxNbBits) 
 
 // FSE-compress the weight string (one lane). 0 = not compressible, 1 = single symbol. Uses S.ct[0]/S.seq.spread[0]/S.seq.norm[0] as scratch.
 __device__ u32 huf_compress_weights(EncShared& S, u8* dst, u32 cap, const u8* w, u32 n) {
-  u32 count[13]; short* norm = S.lit.wNorm;
+  u32* const count = S.lit.wCount; short* norm = S.lit.wNorm;
   u32 maxSym = 0, maxCount = 0;
   if (n <= 1) return 0;
   for (int s = 0; s < 13; s++) count[s] = 0;
@@ -341,12 +346,12 @@ __device__ u32 huf_compress_weights(EncShared& S, u8* dst, u32 cap, const u8* w,
   if (maxCount == 1) return 0;
   const u32 t = fse_optimal_tablelog(6, n, maxSym, 2);
   if (fse_normalize(norm, t, count, n, maxSym, false) <= 0) return 0;
-  u8 tmp[192];
+  u8* const tmp = S.lit.ncTmp;
   const u32 h = fse_write_ncount(tmp, norm, maxSym, t);
   if (!h || h > cap) return 0;
   for (u32 i = 0; i < h; i++) dst[i] = tmp[i];
   ZraFseCTable* ct = &S.ct[0];
-  if (fse_build_ctable(ct, norm, maxSym, t, S.lit.wSpread)) return 0;
+  if (fse_build_ctable(ct, norm, maxSym, t, S.lit.wSpread, S.lit.wCumul)) return 0;
   if (n <= 2) return 0;
   // two interleaved states, symbols consumed from the end (A.4.5 "weight serialisation")
   u64 acc = 0; u32 nacc = 0, pos = h;
@@ -452,7 +457,7 @@ __device__ u32 fse_bit_cost(const ZraFseCTable* ct, const u32* count, u32 max) {
 
 // mode: 0 predefined, 1 rle, 2 compressed, 3 repeat
 __device__ u32 select_encoding(u32* repeatMode, const u32* count, u32 max, u32 mostFrequent, u32 nbSeq, u32 FSELog, const ZraFseCTable* prevCT,
-                               const short* defNorm, u32 defLog, bool defaultAllowed, u32 strategy, short* normScratch) {
+                               const short* defNorm, u32 defLog, bool defaultAllowed, u32 strategy, short* normScratch, u8* ncScratch) {
   if (mostFrequent == nbSeq) { *repeatMode = 0; return (defaultAllowed && nbSeq <= 2) ? 0 : 1; }
   if (strategy < 4) {
     if (defaultAllowed) {
@@ -469,8 +474,7 @@ __device__ u32 select_encoding(u32* repeatMode, const u32* count, u32 max, u32 m
     {
       const u32 tl = fse_optimal_tablelog(FSELog, nbSeq, max, 2);
       if (fse_normalize(normScratch, tl, count, nbSeq, max, nbSeq >= 2048) > 0) {
-        u8 tmp[192];
-        const u32 r = fse_write_ncount(tmp, normScratch, max, tl);
+        const u32 r = fse_write_ncount(ncScratch, normScratch, max, tl);
         if (r) nc = r;
       }
     }
@@ -644,7 +648,7 @@ zra_entropy_kernel(ZraEncArgs a, u32 block) {
               for (int k = nodeRoot - 1; k >= START; k--) nbN[k] = nbN[par[k]] + 1;
               for (int k = 0; k <= nonNull; k++) nbN[k] = nbN[par[k]] + 1;
               const u32 maxBits = huf_set_max_height(S, (u32)nonNull, log);
-              u16 nbPerRank[14], valPerRank[14];
+              u16* const nbPerRank = S.lit.nbPerRank; u16* const valPerRank = S.lit.valPerRank;
               for (int k = 0; k < 14; k++) nbPerRank[k] = valPerRank[k] = 0;
               for (int k = 0; k <= nonNull; k++) nbPerRank[nbN[k]]++;
               { u16 mn = 0; for (int k = (int)maxBits; k > 0; k--) { valPerRank[k] = mn; mn += nbPerRank[k]; mn >>= 1; } }
@@ -762,11 +766,11 @@ zra_entropy_kernel(ZraEncArgs a, u32 block) {
         const ZraFseCTable* prevCT = k == 0 ? &st->ll : k == 1 ? &st->of : &st->ml;
         u32 repeatMode = first ? 0 : (k == 0 ? st->llRepeat : k == 1 ? st->ofRepeat : st->mlRepeat);
         const bool defaultAllowed = k != 1 || mx <= 28;
-        const u32 mode = select_encoding(&repeatMode, count, mx, most, nbSeq, FSELog, prevCT, defNorm, defLog, defaultAllowed, strategy, S.seq.norm[k]);
+        const u32 mode = select_encoding(&repeatMode, count, mx, most, nbSeq, FSELog, prevCT, defNorm, defLog, defaultAllowed, strategy, S.seq.norm[k], S.seq.ncount[k]);
         S.mode[k] = mode; S.nextRepeat[k] = repeatMode; S.ncountSize[k] = 0; S.tblErr[k] = 0;
         ZraFseCTable* ct = &S.ct[k];
         if (mode == 1) { ct->rle = 1; ct->tableLog = 0; ct->maxSym = mx; S.seq.ncount[k][0] = (u8)mx; S.ncountSize[k] = 1; }
-        else if (mode == 0) { for (u32 s = 0; s <= defMax; s++) S.seq.norm[k][s] = defNorm[s]; if (fse_build_ctable(ct, S.seq.norm[k], defMax, defLog, S.seq.spread[k])) S.tblErr[k] = 1; }
+        else if (mode == 0) { for (u32 s = 0; s <= defMax; s++) S.seq.norm[k][s] = defNorm[s]; if (fse_build_ctable(ct, S.seq.norm[k], defMax, defLog, S.seq.spread[k], S.seq.cumul[k])) S.tblErr[k] = 1; }
         else if (mode == 2) {
           u32 n1 = nbSeq;
           const u32 tl = fse_optimal_tablelog(FSELog, nbSeq, mx, 2);
@@ -774,7 +778,7 @@ zra_entropy_kernel(ZraEncArgs a, u32 block) {
           if (fse_normalize(S.seq.norm[k], tl, count, n1, mx, n1 >= 2048) <= 0) S.tblErr[k] = 1;
           else {
             const u32 h = fse_write_ncount(S.seq.ncount[k], S.seq.norm[k], mx, tl);
-            if (!h || fse_build_ctable(ct, S.seq.norm[k], mx, tl, S.seq.spread[k])) S.tblErr[k] = 1;
+            if (!h || fse_build_ctable(ct, S.seq.norm[k], mx, tl, S.seq.spread[k], S.seq.cumul[k])) S.tblErr[k] = 1;
             S.ncountSize[k] = h;
           }
         }
