@@ -262,11 +262,11 @@ __device__ void parse_literals_header(DecShared& S, const u8* src, u32 n, const 
     S.weights[nw] = (u8)(hb32(rest) + 1);
     S.hufNSym = nw + 1; S.hufMaxBits = maxBits;
     // start cell of each weight class (cells ordered by weight ascending)
-    u32 cnt[13];
-    for (u32 w = 0; w <= 12; w++) cnt[w] = 0;
-    for (u32 i = 0; i <= nw; i++) cnt[S.weights[i]]++;
+    // counts per weight, then turned in place into start cells (kept in LDS: a dynamically indexed local array would live in scratch)
+    for (u32 w = 0; w <= 12; w++) S.rankStart[w] = 0;
+    for (u32 i = 0; i <= nw; i++) S.rankStart[S.weights[i]]++;
     u32 acc = 0;
-    for (u32 w = 1; w <= maxBits; w++) { S.rankStart[w] = acc; acc += cnt[w] << (w - 1); }
+    for (u32 w = 1; w <= maxBits; w++) { const u32 c = S.rankStart[w]; S.rankStart[w] = acc; acc += c << (w - 1); }
     if (acc != (1u << maxBits)) { S.err = ZE_CORRUPTION; return; }
     S.hufValid = 2;   // 2 = new table to be filled by the workgroup
     p += used; rem -= used;
