@@ -29,6 +29,13 @@ ZRA_EXPORT ZraStatus ZraHipCreateEngine(ZraHipEngine** engine, int device);
 ZRA_EXPORT void ZraHipDestroyEngine(ZraHipEngine* engine);
 /** Blocks until all work queued on the engine's stream is complete. */
 ZRA_EXPORT ZraStatus ZraHipSynchronize(ZraHipEngine* engine);
+/** STREAM ORDERING. The engine works on two private non-blocking HIP streams; they are not ordered against the caller's
+ *  streams (nor against the null stream). Inputs (dIn / the archive / device-resident query arrays) must be complete before a
+ *  ZraHip* compute call starts reading them: either synchronise the producing stream, or call ZraHipWaitStream(engine, stream)
+ *  first — it records an event on `producerStream` (a hipStream_t; NULL = the null stream) and makes the engine's streams wait
+ *  for it, with no host synchronisation. Every ZraHip* compute call is host-synchronous on return: its outputs are complete and
+ *  visible to any stream. */
+ZRA_EXPORT ZraStatus ZraHipWaitStream(ZraHipEngine* engine, void* producerStream);
 /** The engine's hipStream_t, as an opaque pointer (for event timing on the stream kernels run on). */
 ZRA_EXPORT void* ZraHipGetStream(ZraHipEngine* engine);
 

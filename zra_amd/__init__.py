@@ -91,6 +91,7 @@ def load():
         "ZraHipDestroyEngine": (None, [vp]),
         "ZraHipSynchronize": (S, [vp]),
         "ZraHipGetStream": (vp, [vp]),
+        "ZraHipWaitStream": (S, [vp, vp]),
         "ZraHipLastKernelMs": (ctypes.c_double, [vp]),
         "ZraHipGetKernelStats": (None, [vp, ctypes.POINTER(ctypes.c_double)]),
         "ZraHipCompressBuffer": (S, [vp, vp, sz, vp, szp, ctypes.c_int8, u32, ctypes.c_bool]),
@@ -116,7 +117,7 @@ C_ABI_SYMBOLS = [
     "ZraDecompressWithDecompressor", "ZraCreateFullDecompressor", "ZraDeleteFullDecompressor", "ZraGetHeaderWithFullDecompressor",
     "ZraDecompressWithFullDecompressor",
 ]
-HIP_ABI_SYMBOLS = ["ZraHipDeviceCount", "ZraHipCreateEngine", "ZraHipDestroyEngine", "ZraHipSynchronize", "ZraHipGetStream", "ZraHipLastKernelMs", "ZraHipGetKernelStats",
+HIP_ABI_SYMBOLS = ["ZraHipDeviceCount", "ZraHipCreateEngine", "ZraHipDestroyEngine", "ZraHipSynchronize", "ZraHipGetStream", "ZraHipWaitStream", "ZraHipLastKernelMs", "ZraHipGetKernelStats",
                    "ZraHipCompressBuffer", "ZraHipDecompressBuffer", "ZraHipDecompressRABatch", "ZraHipCompressFrames", "ZraHipStitchHeader", "ZraHipDebugReadSeqs", "ZraHipSetOptions", "ZraHipGetOptions"]
 
 
@@ -184,6 +185,17 @@ class Engine:
     def stream(self):
         return self.L.ZraHipGetStream(self.h)
 
+    def wait_stream(self, stream_handle=None):
+        """Orders the engine's streams behind work queued on `stream_handle` (a hipStream_t as int; None = the null stream)."""
+        _chk(self.L.ZraHipWaitStream(self.h, ctypes.c_void_p(stream_handle or 0)))
+
+    def _order(self):
+        # inputs are usually torch tensors produced asynchronously on torch's current stream: make the engine wait for that stream
+        # (event wait, no host sync). Plumbing only; C callers use ZraHipWaitStream / their own synchronisation (zra_hip.h).
+        t = sys.modules.get("torch")
+        if t is not None and t.cuda.is_available():
+            self.wait_stream(t.cuda.current_stream().cuda_stream)
+
     def last_kernel_ms(self):
         return self.L.ZraHipLastKernelMs(self.h)
 
@@ -202,10 +214,12 @@ class Engine:
 
     def compress(self, d_in, in_size, d_out, level=3, frame_size=65536, checksum=True):
         osz = ctypes.c_size_t(0)
+        self._order()
         _chk(self.L.ZraHipCompressBuffer(self.h, d_in, in_size, d_out, ctypes.byref(osz), level, frame_size, checksum))
         return osz.value
 
     def decompress(self, d_in, in_size, d_out, out_cap):
+        self._order()
         _chk(self.L.ZraHipDecompressBuffer(self.h, d_in, in_size, d_out, out_cap))
 
     def decompress_ra_batch(self, d_in, in_size, d_out, offsets, sizes, out_offsets):
@@ -214,10 +228,12 @@ class Engine:
         s = np.ascontiguousarray(sizes, dtype=np.uint64)
         oo = np.ascontiguousarray(out_offsets, dtype=np.uint64)
         p = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64))
+        self._order()
         _chk(self.L.ZraHipDecompressRABatch(self.h, d_in, in_size, d_out, p(o), p(s), p(oo), len(o)))
 
     def compress_frames(self, d_in, in_size, d_body, d_sizes, level=3, frame_size=65536, checksum=True):
         bsz = ctypes.c_size_t(0)
+        self._order()
         _chk(self.L.ZraHipCompressFrames(self.h, d_in, in_size, d_body, d_sizes, ctypes.byref(bsz), level, frame_size, checksum))
         return bsz.value
 

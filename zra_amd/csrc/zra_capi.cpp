@@ -11,27 +11,63 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
 #include <mutex>
+#include <vector>
 
 using zra_eng::Engine;
 namespace fmt = zra_fmt;
 
 namespace {
-std::mutex g_mu;          // the default engine is shared by the (re-entrant in the reference) free functions
-Engine* g_engine = nullptr;
-
-Engine& default_engine() {
-  if (!g_engine) {
-    int dev = 0;
-    if (const char* s = std::getenv("ZRA_DEVICE")) dev = std::atoi(s);
-    zra_eng::Status st = Engine::create(&g_engine, dev);
-    if (st.zra) throw zra::Exception(zra::StatusCode::ZStdError, st.zstd ? st.zstd : 1);   // no GPU: fail loudly, no CPU fallback
+// The reference's free functions are re-entrant (a fresh zstd context per call, zra.cpp:209,248,271). Here a call needs an
+// engine (device streams + scratch), so the free functions and the streaming classes borrow one from a small pool: concurrent
+// callers get different engines (up to ZRA_ENGINES, default 4, created on demand) and only wait when all of them are busy.
+class EnginePool {
+ public:
+  class Lease {
+   public:
+    Lease(EnginePool& p, Engine* e) : pool_(p), e_(e) {}
+    ~Lease() { pool_.give_back(e_); }
+    Lease(const Lease&) = delete; Lease& operator=(const Lease&) = delete;
+    Engine* operator->() const { return e_; }
+   private:
+    EnginePool& pool_; Engine* e_;
+  };
+  Engine* take() {
+    std::unique_lock<std::mutex> lk(mu_);
+    for (;;) {
+      if (!idle_.empty()) { Engine* e = idle_.back(); idle_.pop_back(); return e; }
+      if (created_ < limit()) {
+        created_++;
+        lk.unlock();
+        int dev = 0;
+        if (const char* s = std::getenv("ZRA_DEVICE")) dev = std::atoi(s);
+        Engine* e = nullptr;
+        zra_eng::Status st = Engine::create(&e, dev);
+        if (st.zra) {
+          lk.lock(); created_--; cv_.notify_one();
+          throw zra::Exception(zra::StatusCode::ZStdError, st.zstd ? st.zstd : 1);   // no GPU: fail loudly, no CPU fallback
+        }
+        return e;
+      }
+      cv_.wait(lk);
+    }
   }
-  return *g_engine;
-}
+  void give_back(Engine* e) { { std::lock_guard<std::mutex> lk(mu_); idle_.push_back(e); } cv_.notify_one(); }
+ private:
+  static int limit() {
+    static const int n = [] { const char* s = std::getenv("ZRA_ENGINES"); int v = s ? std::atoi(s) : 4; return v < 1 ? 1 : v > 64 ? 64 : v; }();
+    return n;
+  }
+  std::mutex mu_; std::condition_variable cv_;
+  std::vector<Engine*> idle_; int created_ = 0;
+};
+EnginePool g_pool;
+#define LEASE_ENGINE(name) EnginePool::Lease name(g_pool, g_pool.take())
+
 void check(zra_eng::Status s) { if (s.zra) throw zra::Exception(static_cast<zra::StatusCode>(s.zra), s.zstd); }
 
-const char* zstd_error_string(int code) {   // ZSTD_getErrorString of zstd 1.4.9 for the codes this library can emit
+const char* zstd_error_string(int code) {   // ZSTD_getErrorString of zstd 1.4.9, every code of its ZSTD_ErrorCode enum (pinned by tests/test_boundary.py)
   switch (code) {
     case 0: return "No error detected";
     case 1: return "Error (generic)";
@@ -43,11 +79,22 @@ const char* zstd_error_string(int code) {   // ZSTD_getErrorString of zstd 1.4.9
     case 22: return "Restored data doesn't match checksum";
     case 30: return "Dictionary is corrupted";
     case 32: return "Dictionary mismatch";
+    case 34: return "Cannot create Dictionary from provided samples";
     case 40: return "Unsupported parameter";
     case 42: return "Parameter is out of bound";
+    case 44: return "tableLog requires too much memory : unsupported";
+    case 46: return "Unsupported max Symbol Value : too large";
+    case 48: return "Specified maxSymbolValue is too small";
+    case 60: return "Operation not authorized at current processing stage";
+    case 62: return "Context should be init first";
     case 64: return "Allocation error : not enough memory";
+    case 66: return "workSpace buffer is not large enough";
     case 70: return "Destination buffer is too small";
     case 72: return "Src size is incorrect";
+    case 74: return "Operation on NULL destination buffer";
+    case 100: return "Frame index is too large";
+    case 102: return "An I/O error occurred when reading/seeking";
+    case 104: return "Destination buffer is wrong";
     default: return "Unspecified error code";
   }
 }
@@ -186,9 +233,9 @@ namespace zra {
     const bool storeMeta = meta.size && (g_options.load() & kOptStoreMetaInMemory);
     if (storeMeta) need += meta.size;
     if (output.size < need) throw Exception(StatusCode::OutputBufferTooSmall);   // meta not counted, zra.cpp:196
-    std::lock_guard<std::mutex> lk(g_mu);
+    LEASE_ENGINE(eng);
     size_t outSize = 0;
-    check(default_engine().compress_host(input.data, input.size, output.data, &outSize, level, frameSize, checksum));
+    check(eng->compress_host(input.data, input.size, output.data, &outSize, level, frameSize, checksum));
     if (storeMeta) {
       // opt-in fix of the quirk below: the archive the streaming Compressor would write (meta stored, table behind it)
       std::memmove(output.data + fmt::kFixedSize + meta.size, output.data + fmt::kFixedSize, outSize - fmt::kFixedSize);
@@ -222,13 +269,12 @@ namespace zra {
     uint64_t brokenAt = ~0ull;
     int walkErr = walk_frames(body, bodySize, starts, ends, &brokenAt);
     if (walkErr && brokenAt != ~0ull) { starts.push_back(brokenAt); ends.push_back(bodySize); }
-    std::lock_guard<std::mutex> lk(g_mu);
+    LEASE_ENGINE(eng);
     // frames complete before a walk error are still decoded (their errors come first, as in the sequential reference)
     const u64 avail = std::min<u64>(header.uncompressedSize, (u64)starts.size() * header.frameSize);
-    zra_eng::Status s = default_engine().decode_host(body, bodySize, starts, ends, header.frameSize, header.uncompressedSize, output.data, 0, (size_t)avail, true);
+    zra_eng::Status s = eng->decode_host(body, bodySize, starts, ends, header.frameSize, header.uncompressedSize, output.data, 0, (size_t)avail, true);
     check(s);
     if (walkErr) throw Exception(StatusCode::ZStdError, walkErr);
-    if (avail < header.uncompressedSize && false) throw Exception(StatusCode::ZStdError, 72);
   }
 
   Buffer DecompressBuffer(const BufferView& buffer) {
@@ -240,18 +286,24 @@ namespace zra {
   namespace {
     // frames [first, last) of the seek table -> decode -> copy [skip, skip+size) into out (the 3 phases of zra.cpp:279-295
     // collapse to this on a device that decodes all touched frames at once)
-    void ra_decode(const u8* table, const u8* span, u64 spanBase, u64 firstIdx, u64 count, const Header& header, u8* out, size_t skip, size_t size) {
+    void ra_decode(const u8* table, size_t tableBytes, const u8* span, u64 spanAvail, u64 spanBase, u64 firstIdx, u64 count, const Header& header,
+                   u8* out, size_t skip, size_t size) {
+      // an inconsistent header (uncompressedSize beyond what the seek table covers) would index past the table: the reference reads
+      // whatever lies there (zra.cpp:267-268); here it is a HeaderInvalid. Entries that run backwards or past the bytes the caller
+      // handed over are what zstd reports as srcSize_wrong.
+      if ((firstIdx + count + 1) * fmt::kEntrySize > tableBytes) throw Exception(StatusCode::HeaderInvalid);
       std::vector<uint64_t> starts(count), ends(count);
       for (u64 i = 0; i < count; i++) {
-        starts[i] = fmt::entry_get(table + (firstIdx + i) * 5) - spanBase;
-        ends[i] = fmt::entry_get(table + (firstIdx + i + 1) * 5) - spanBase;
+        const u64 a = fmt::entry_get(table + (firstIdx + i) * 5), b = fmt::entry_get(table + (firstIdx + i + 1) * 5);
+        if (a < spanBase || b < a || b - spanBase > spanAvail) throw Exception(StatusCode::ZStdError, 72);
+        starts[i] = a - spanBase; ends[i] = b - spanBase;
       }
       const u64 spanSize = count ? ends[count - 1] : 0;
       // every touched frame but possibly the archive's last regenerates frameSize bytes
       const u64 firstByte = firstIdx * (u64)header.frameSize;
       const u64 total = std::min<u64>(count * (u64)header.frameSize, header.uncompressedSize > firstByte ? header.uncompressedSize - firstByte : 0);
-      std::lock_guard<std::mutex> lk(g_mu);
-      check(default_engine().decode_host(span, spanSize, starts, ends, header.frameSize, total, out, skip, size));
+      LEASE_ENGINE(eng);
+      check(eng->decode_host(span, spanSize, starts, ends, header.frameSize, total, out, skip, size));
     }
   }
 
@@ -265,9 +317,13 @@ namespace zra {
     const u64 n = (r + size) / header.frameSize, t = (r + size) % header.frameSize;
     const u64 count = n + (t ? 1 : 0);
     if (size == 0 || count == 0) return;
+    if ((u64)header.seekTableOffset + header.seekTableSize > header.size) throw Exception(StatusCode::HeaderInvalid);
     const u8* table = input.data + header.seekTableOffset;
+    if ((q + count + 1) * fmt::kEntrySize > header.seekTableSize) throw Exception(StatusCode::HeaderInvalid);
     const u64 base = fmt::entry_get(table + q * 5);
-    ra_decode(table, input.data + header.size + base, base, q, count, header, output.data, r, size);
+    const u64 bodyAvail = input.size - header.size;
+    if (base > bodyAvail) throw Exception(StatusCode::ZStdError, 72);
+    ra_decode(table, header.seekTableSize, input.data + header.size + base, bodyAvail - base, base, q, count, header, output.data, r, size);
   }
 
   Buffer DecompressRA(const BufferView& buffer, size_t offset, size_t size) {
@@ -308,8 +364,8 @@ namespace zra {
     size_t bodySize = 0;
     std::vector<uint64_t> sizes;
     if (input.size) {
-      std::lock_guard<std::mutex> lk(g_mu);
-      check(default_engine().compress_frames_host(input.data, input.size, output.data, sizes, &bodySize, m.level, m.frameSize, m.checksum));
+      LEASE_ENGINE(eng);
+      check(eng->compress_frames_host(input.data, input.size, output.data, sizes, &bodySize, m.level, m.frameSize, m.checksum));
     }
     for (uint64_t c : sizes) {
       fmt::entry_put(m.entry(m.entryIndex++), m.outputOffset);
@@ -346,14 +402,16 @@ namespace zra {
     const u64 n = (r + size) / header.frameSize, t = (r + size) % header.frameSize;
     const u64 count = n + (t ? 1 : 0);
     const u8* table = seekTable.data();
+    if ((q + count + 1) * fmt::kEntrySize > seekTable.size()) throw Exception(StatusCode::HeaderInvalid);
     const u64 base = fmt::entry_get(table + q * 5);
+    if (fmt::entry_get(table + (q + count) * 5) < base) throw Exception(StatusCode::ZStdError, 72);
     const u64 compressedSize = fmt::entry_get(table + (q + count) * 5) - base;
     Buffer own;
     Buffer& in = compressedSize > maxCacheSize ? own : cache;
     in.resize(compressedSize);
     readFunction(header.size + base, compressedSize, in.data());
     if (size == 0 || count == 0) return;
-    ra_decode(table, in.data(), base, q, count, header, output.data, r, size);
+    ra_decode(table, seekTable.size(), in.data(), in.size(), base, q, count, header, output.data, r, size);
   }
   void Decompressor::Decompress(size_t offset, size_t size, Buffer& output) { output.resize(size); Decompress(offset, size, BufferView(output)); }
   Buffer Decompressor::Decompress(size_t offset, size_t size) { Buffer b; Decompress(offset, size, b); return b; }
@@ -368,6 +426,7 @@ namespace zra {
     const size_t stop = std::min(lastIndex, entryIndex + output.size / header.frameSize);
     const u8* table = seekTable.data();
     const u64 base = fmt::entry_get(table + entryIndex * 5);
+    if (fmt::entry_get(table + stop * 5) < base) throw Exception(StatusCode::ZStdError, 72);
     cache.resize(fmt::entry_get(table + stop * 5) - base);
     readFunction(header.size + base, cache.size(), cache.data());
     const size_t first = entryIndex, count = stop - entryIndex;
@@ -375,7 +434,7 @@ namespace zra {
     if (!count) return 0;
     const u64 firstByte = (u64)first * header.frameSize;
     const size_t produced = (size_t)std::min<u64>((u64)count * header.frameSize, header.uncompressedSize - firstByte);
-    ra_decode(table, cache.data(), base, first, count, header, output.data, 0, produced);
+    ra_decode(table, seekTable.size(), cache.data(), cache.size(), base, first, count, header, output.data, 0, produced);
     return produced;
   }
 }  // namespace zra
@@ -484,6 +543,7 @@ ZraStatus ZraHipCreateEngine(ZraHipEngine** engine, int device) {
 }
 void ZraHipDestroyEngine(ZraHipEngine* engine) { if (engine) { delete engine->e; delete engine; } }
 ZraStatus ZraHipSynchronize(ZraHipEngine* engine) { return mk(engine->e->sync()); }
+ZraStatus ZraHipWaitStream(ZraHipEngine* engine, void* producerStream) { return mk(engine->e->wait_stream((hipStream_t)producerStream)); }
 void* ZraHipGetStream(ZraHipEngine* engine) { return (void*)engine->e->stream(); }
 double ZraHipLastKernelMs(ZraHipEngine* engine) { return engine->e->last_kernel_ms(); }
 void ZraHipSetOptions(uint32_t mask) { g_options.store(mask); }

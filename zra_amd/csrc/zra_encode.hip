@@ -108,6 +108,27 @@ Status Engine::compress_frames(const uint8_t* dIn, size_t inSize, uint8_t* dBody
 // bodyBase0) are written to dEntries when non-null; u64 sizes to dSizes when non-null.
 Status Engine::compress_impl(const uint8_t* dIn, size_t inSize, uint8_t* dBody, uint64_t bodyBase0, uint8_t* dEntries, uint64_t* dSizes,
                              size_t* bodySize, int level, uint32_t frameSize, bool checksum) {
+  encCounters_ = nullptr; encCountersBytes_ = 0;
+  Status s = compress_impl_body(dIn, inSize, dBody, bodyBase0, dEntries, dSizes, bodySize, level, frameSize, checksum);
+  if (s.zra) drain_after_error();
+  return s;
+}
+
+// Every error exit of the encode driver funnels through here: nothing of the failed call may still run (the caller is free to
+// release dIn / dOut, and the next call reuses the same scratch and counters). Stream A's persistent match finder ends on its own
+// once its frame queue is exhausted; stream B may sit in a wait-value on a sub-batch counter that will never be reached, so the
+// counters are raised past every target before it is drained.
+void Engine::drain_after_error() {
+  (void)hipGetLastError();
+  (void)hipStreamSynchronize(stream_);
+  if (encCounters_ && encCountersBytes_) (void)hipMemsetAsync(encCounters_, 0x7F, encCountersBytes_, stream_);
+  (void)hipStreamSynchronize(stream_);
+  (void)hipStreamSynchronize(stream2_);
+  (void)hipGetLastError();
+}
+
+Status Engine::compress_impl_body(const uint8_t* dIn, size_t inSize, uint8_t* dBody, uint64_t bodyBase0, uint8_t* dEntries, uint64_t* dSizes,
+                                  size_t* bodySize, int level, uint32_t frameSize, bool checksum) {
   HIPCHK(hipSetDevice(device_));
   *bodySize = 0;
   if (inSize == 0) return ok();
@@ -124,7 +145,11 @@ Status Engine::compress_impl(const uint8_t* dIn, size_t inSize, uint8_t* dBody, 
   const uint32_t maxBlock = std::max(full.blockSize, tail.blockSize);
   const uint64_t seqStride = maxBlock / 4 + 16;
   const uint64_t litStride = ((uint64_t)maxBlock + 64 + 15) & ~15ull;
-  const uint32_t maxBlocksPerFrame = (std::min<uint64_t>(frameSize, inSize) + std::min(full.blockSize, tail.blockSize) - 1) / std::min(full.blockSize, tail.blockSize);
+  // blocks per frame, per size class (a short last frame has its own, smaller, block size but is still one block)
+  const uint64_t fullFrame = std::min<uint64_t>(frameSize, inSize);
+  const uint32_t maxBlocksPerFrame = (uint32_t)std::max<uint64_t>(
+      (nFramesTotal > 1 || !tailSize) ? (fullFrame + full.blockSize - 1) / full.blockSize : 0,
+      tailSize ? (tailSize + tail.blockSize - 1) / tail.blockSize : 0);
   const uint64_t slotStride = (zra_fmt::compress_bound(frameSize) + 1024 + 4 * (uint64_t)maxBlocksPerFrame + 15) & ~15ull;
   const uint64_t perFrame = tableWords * 4 + seqStride * 8 + litStride + slotStride + sizeof(ZraEncFrameState) + sizeof(ZraEncBlockOut) + 64;
   // ---------------------------------------------------------------------------------------------------------------------
@@ -309,6 +334,7 @@ Status Engine::compress_persistent(const uint8_t* dIn, size_t inSize, uint8_t* d
   uint32_t* dQueue = (uint32_t*)(encScan_.as<uint8_t>() + 16);
   uint32_t* dDone = dQueue + nSuper;
   HIPCHK(hipMemsetAsync(encScan_.as<uint8_t>(), 0, cntBytes, stream_));
+  encCounters_ = dDone; encCountersBytes_ = 4 * (size_t)(nSuper * subsPerSuper);
 
   ZraEncArgs base{};
   base.in = dIn; base.inSize = inSize; base.frameSize = frameSize; base.checksum = checksum ? 1 : 0;

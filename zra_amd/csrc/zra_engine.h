@@ -37,6 +37,10 @@ class Engine {
   ~Engine();
   hipStream_t stream() const { return stream_; }
   Status sync();
+  // stream-ordering contract of the device-pointer API: the engine runs on two private non-blocking streams, which do not order
+  // themselves against the caller's streams. Work queued on `producer` before this call completes before anything the engine
+  // launches afterwards (an event wait, no host synchronisation). Outputs are complete when an engine call returns.
+  Status wait_stream(hipStream_t producer);
   double last_kernel_ms() const { return lastKernelMs_; }
   // HIP-event timings of the last call on the engine's stream: {mf ms, mf launches, entropy ms, entropy launches, decode ms, decode launches}
   void kernel_stats(double out[6]) const { for (int i = 0; i < 6; i++) out[i] = kstats_[i]; }
@@ -68,6 +72,9 @@ class Engine {
                              uint64_t tableWords, uint64_t seqStride, uint64_t litStride, uint64_t slotStride);
   Status compress_impl(const uint8_t* dIn, size_t inSize, uint8_t* dBody, uint64_t bodyBase0, uint8_t* dEntries, uint64_t* dSizes,
                        size_t* bodySize, int level, uint32_t frameSize, bool checksum);
+  Status compress_impl_body(const uint8_t* dIn, size_t inSize, uint8_t* dBody, uint64_t bodyBase0, uint8_t* dEntries, uint64_t* dSizes,
+                            size_t* bodySize, int level, uint32_t frameSize, bool checksum);
+  void drain_after_error();
   // Full archive (header + table + body) on the device.
   Status compress_device(const uint8_t* dIn, size_t inSize, uint8_t* dOut, size_t* outSize, int level, uint32_t frameSize, bool checksum);
 
@@ -87,7 +94,7 @@ class Engine {
   Engine() = default;
   int device_ = 0, numCUs_ = 0;
   hipStream_t stream_ = nullptr;
-  hipEvent_t ev0_ = nullptr, ev1_ = nullptr;
+  hipEvent_t ev0_ = nullptr, ev1_ = nullptr, evWait_ = nullptr;
   double lastKernelMs_ = 0;
   double kstats_[6] = {0, 0, 0, 0, 0, 0};
   hipEvent_t evR_[17] = {nullptr};   // per-round events of one encode batch: e[2r] before mf, e[2r+1] between, e[2r+2] after entropy
@@ -102,6 +109,7 @@ class Engine {
   DevBuf hostIn_, hostOut_, seqScratch_;
   uint64_t dbgSeqStride_ = 0; uint32_t dbgB_ = 0;
   uint64_t lastProducedTotal_ = ~0ull;     // whole-archive decode that fell back to the sequential tail: bytes actually regenerated
+  void* encCounters_ = nullptr; size_t encCountersBytes_ = 0;   // sub-batch counters stream B may be waiting on (drain_after_error)
   int waitValueOk_ = 0;                    // 0 unknown, 1 hipStreamWaitValue32 works on device memory, -1 it does not (batch path)
   friend struct EncodeImpl;
 };

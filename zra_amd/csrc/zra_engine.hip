@@ -54,10 +54,12 @@ __global__ void zra_jobs_from_seektable_kernel(const u8* table, u32 nFrames, u32
     frameOff[i] = (u64)ld32(e) | ((u64)e[4] << 32);
   }
   if (i < nFrames) {
+    // a frame whose slot starts at or beyond the declared size gets no room at all (an inflated tableSize or a shrunk
+    // uncompressedSize in a crafted header): the decoder then reports dstSize_tooSmall for it, like the reference's single
+    // multi-frame call running out of destination (zra.cpp:249), and nothing is written past `total`
     u64 o = (u64)i * frameSize;
-    outOff[i] = o;
-    u64 rem = total - o;
-    expect[i] = (u32)(rem < frameSize ? rem : frameSize);
+    outOff[i] = o < total ? o : total;
+    expect[i] = o >= total ? 0u : (u32)(total - o < frameSize ? total - o : frameSize);
   }
 }
 
@@ -143,7 +145,8 @@ Status Engine::create(Engine** out, int device) {
   e->numCUs_ = prop.multiProcessorCount;
   if (hipStreamCreateWithFlags(&e->stream_, hipStreamNonBlocking) != hipSuccess) { delete e; return zerr(1); }
   if (hipStreamCreateWithFlags(&e->stream2_, hipStreamNonBlocking) != hipSuccess) { delete e; return zerr(1); }
-  if (hipEventCreate(&e->ev0_) != hipSuccess || hipEventCreate(&e->ev1_) != hipSuccess) { delete e; return zerr(1); }
+  if (hipEventCreate(&e->ev0_) != hipSuccess || hipEventCreate(&e->ev1_) != hipSuccess ||
+      hipEventCreateWithFlags(&e->evWait_, hipEventDisableTiming) != hipSuccess) { delete e; return zerr(1); }
   for (auto& ev : e->evR_) if (hipEventCreate(&ev) != hipSuccess) { delete e; return zerr(1); }
   *out = e;
   return ok();
@@ -161,10 +164,19 @@ Engine::~Engine() {
   for (auto& ev : evR_) if (ev) (void)hipEventDestroy(ev);
   if (ev0_) (void)hipEventDestroy(ev0_);
   if (ev1_) (void)hipEventDestroy(ev1_);
+  if (evWait_) (void)hipEventDestroy(evWait_);
   if (stream_) (void)hipStreamDestroy(stream_);
 }
 
-Status Engine::sync() { HIPCHK(hipSetDevice(device_)); HIPCHK(hipStreamSynchronize(stream_)); return ok(); }
+Status Engine::sync() { HIPCHK(hipSetDevice(device_)); HIPCHK(hipStreamSynchronize(stream_)); HIPCHK(hipStreamSynchronize(stream2_)); return ok(); }
+
+Status Engine::wait_stream(hipStream_t producer) {
+  HIPCHK(hipSetDevice(device_));
+  HIPCHK(hipEventRecord(evWait_, producer));
+  HIPCHK(hipStreamWaitEvent(stream_, evWait_, 0));
+  HIPCHK(hipStreamWaitEvent(stream2_, evWait_, 0));
+  return ok();
+}
 
 // One launch of the decode kernel + frame-end checks over `nFrames` jobs; returns (first failing frame << 8 | code) or ~0.
 Status Engine::decode_launch(const ZraDecodeArgs& a0, const uint32_t* dExpect, unsigned long long* res) {
@@ -257,6 +269,8 @@ Status Engine::decompress_device(const uint8_t* dArc, size_t arcSize, uint8_t* d
   const uint32_t nFrames = h.frames();
   if (nFrames == 0 || h.frameSize == 0) return ok();
   if ((uint64_t)h.seekTableOffset + h.seekTableSize > h.size) return {kHeaderInvalid, 0};
+  // Frames beyond the declared size get a zero-capacity slot in the job kernel (dstSize_tooSmall, like the reference's
+  // sequential call running out of destination); nothing can be written at or beyond dOut + uncompressedSize <= dOut + outCap.
   if (!frameOff_.reserve(((size_t)nFrames + 1) * 8) || !outOff_.reserve((size_t)nFrames * 8) || !expect_.reserve((size_t)nFrames * 4))
     return zerr(64);
   hipLaunchKernelGGL(zra_jobs_from_seektable_kernel, dim3((nFrames + 256) / 256), dim3(256), 0, stream_, dArc + h.seekTableOffset,
