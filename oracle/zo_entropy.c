@@ -530,10 +530,11 @@ size_t zo_huf_read_weights(u8* weights, unsigned* nSymPtr, unsigned* maxBitsPtr,
   for (unsigned i = 0; i < nw; i++) { if (weights[i] > 11) return 0; total += (1u << weights[i]) >> 1; }
   if (total == 0) return 0;
   unsigned maxBits = hb32(total) + 1;
-  if (maxBits > 11) return 0;
+  if (maxBits > 12) return 0;                              /* HUF_readStats: tableLog > HUF_TABLELOG_MAX (the format allows 11, libzstd 12) */
   u32 rest = (1u << maxBits) - total;
   if (rest == 0 || (rest & (rest - 1))) return 0;
   weights[nw] = (u8)(hb32(rest) + 1);
+  { unsigned r1 = 0; for (unsigned i = 0; i <= nw; i++) r1 += weights[i] == 1; if (r1 < 2) return 0; }   /* "at least 2 elts of rank 1" */
   *nSymPtr = nw + 1;
   *maxBitsPtr = maxBits;
   return used;

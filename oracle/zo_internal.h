@@ -72,7 +72,7 @@ typedef struct {
 } zo_fse_ctable;
 typedef struct { unsigned tableLog; u8 sym[1 << 9]; u8 nbBits[1 << 9]; u16 base[1 << 9]; } zo_fse_dtable;
 typedef struct { unsigned maxSym, tableLog; u8 nbBits[256]; u16 val[256]; } zo_huf_ctable;
-typedef struct { unsigned maxBits; u8 sym[1 << 11]; u8 nbBits[1 << 11]; } zo_huf_dtable;
+typedef struct { unsigned maxBits; u8 sym[1 << 12]; u8 nbBits[1 << 12]; } zo_huf_dtable;   /* HUF_TABLELOG_MAX = 12 */
 
 unsigned zo_fse_optimal_tablelog(unsigned maxLog, size_t n, unsigned maxSym, unsigned minus);
 int zo_fse_normalize(s16* norm, unsigned t, const u32* cnt, size_t total, unsigned maxSym, int useLowProb);

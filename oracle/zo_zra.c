@@ -48,6 +48,8 @@ int zo_libzstd_load(const char* path) {
   return 0;
 }
 const char* zo_libzstd_version(void) { return (Z.h && Z.version) ? Z.version() : ""; }
+/* any other export of the loaded dependency (tests pin internals such as HUF_selectDecoder and ZSTD_getErrorString through it) */
+void* zo_libzstd_symbol(const char* name) { return (zo_libzstd_load(NULL) == 0) ? dlsym(Z.h, name) : NULL; }
 
 /* a per-call codec context, mirroring ZCCtx / ZDCtx (zra.cpp:25-44) */
 typedef struct { int backend; void* cctx; void* dctx; int level, checksum; } codec;
@@ -143,13 +145,20 @@ static int parse_header(hdr* h, const u8* in, size_t n) {
   return 0;
 }
 
+/* bytes the last successful decompress_buffer regenerated on this thread: the reference call returns void and promises
+   uncompressedSize bytes; when a damaged header makes the two differ, only this prefix is defined (tests compare just that) */
+static __thread size_t g_last_produced;
+size_t zo_zra_last_produced(void) { return g_last_produced; }
+
 static zo_status decompress_buffer(int backend, const u8* in, size_t n, u8* out, size_t outCap) {
   hdr h; int e = parse_header(&h, in, n);
   if (e) return st(e, 0);
   if (outCap < h.uncompressedSize) return st(ZRA_OutputTooSmall, 0);
   codec k; int err;
   if (codec_open(&k, backend, 0, 0)) return st(ZRA_ZStdError, ZO_E_GENERIC);
-  codec_decompress(&k, out, outCap, in + h.size, n - h.size, &err);
+  g_last_produced = 0;
+  size_t r = codec_decompress(&k, out, outCap, in + h.size, n - h.size, &err);
+  if (!err) g_last_produced = r;
   codec_close(&k);
   return err ? st(ZRA_ZStdError, err) : st(ZRA_Success, 0);
 }

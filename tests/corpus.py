@@ -112,3 +112,56 @@ def gen_litrle(n=262144):
 ALL = {
     "A": gen_A, "B": gen_B, "C": gen_C, "D": gen_D, "E": gen_E,
 }
+
+
+def random_lz_input(rng, n):
+    """Synthetic LZ-style data: literal runs of varying entropy interleaved with copies of earlier spans (incl. overlapping ones)."""
+    out = bytearray()
+    alpha = rng.choice([2, 4, 16, 64, 256])
+    while len(out) < n:
+        r = rng.rand()
+        if r < 0.35 or len(out) < 8:
+            k = int(rng.choice([1, 3, 7, 20, 100, 700]))
+            out += bytes(rng.randint(0, alpha, size=k).astype(np.uint8).tolist())
+        elif r < 0.85:
+            off = int(min(len(out), rng.choice([1, 2, 3, 4, 8, 17, 64, 300, 5000, 70000])))
+            off = max(1, min(off, len(out)))
+            k = int(rng.choice([3, 4, 5, 8, 12, 40, 300, 3000]))
+            st = len(out) - off
+            for i in range(k):
+                out.append(out[st + i])
+        elif r < 0.93:
+            out += bytes([int(rng.randint(0, 256))]) * int(rng.choice([5, 40, 600, 9000]))
+        else:
+            alpha = rng.choice([2, 4, 16, 64, 256])
+    return bytes(out[:n])
+
+
+def mutated_archives(seed, cases, compress):
+    """Yields (case, damaged archive) for the corruption tests: a valid archive of seeded LZ data (written by `compress(data, level,
+    frameSize, checksum) -> (status, bytes)`), then 1..5 bit flips / byte overwrites / truncations. Archives whose damaged header
+    promises more than 16 MiB are skipped (the reference's C wrapper trusts that field for the caller's buffer, zra.cpp:519)."""
+    rng = np.random.RandomState(3000 + seed)
+    for case in range(cases):
+        fs = int(rng.choice([1024, 4096, 16384, 65536]))
+        n = int(rng.randint(1, 5 * fs))
+        level = int(rng.choice([1, 3, 3, 5, 9]))
+        d = random_lz_input(rng, n)
+        st, arc = compress(d, level, fs, bool(case & 1))
+        if st != (0, 0):
+            continue                                   # cparams outside the restated set for this size (refused, not faked)
+        a = bytearray(arc)
+        for _ in range(int(rng.choice([1, 1, 1, 2, 5]))):
+            mode = rng.rand()
+            if mode < 0.7:
+                a[int(rng.randint(38, len(a)))] ^= 1 << int(rng.randint(0, 8))
+            elif mode < 0.85:
+                a[int(rng.randint(0, len(a)))] = int(rng.randint(0, 256))
+            else:
+                a = a[: int(rng.randint(38, len(a)))]
+            if len(a) < 44:
+                break
+        a = bytes(a)
+        if len(a) < 38 or int.from_bytes(a[18:26], "little") > (1 << 24):
+            continue
+        yield case, a

@@ -107,6 +107,14 @@ def have_libzstd():
     return lib().zo_libzstd_load(None) == 0
 
 
+def libzstd_symbol(name):
+    """address of an export of the loaded dependency (0 when absent)"""
+    L = lib()
+    L.zo_libzstd_symbol.restype = ctypes.c_void_p
+    L.zo_libzstd_symbol.argtypes = [ctypes.c_char_p]
+    return L.zo_libzstd_symbol(name.encode()) or 0
+
+
 def compress_frame(data, level=3, checksum=True, backend="zo"):
     L = lib()
     cap = L.zo_compress_bound(len(data)) + 64
@@ -136,12 +144,17 @@ def zra_compress(data, level=3, frame_size=65536, checksum=True, meta_size=0, ba
     return s.tup(), out.raw[: osz.value]
 
 
-def zra_decompress(arc, cap=None, backend="zo"):
+def zra_decompress(arc, cap=None, backend="zo", defined_only=False):
+    """(status, bytes). defined_only: just the bytes the decoder regenerated (a damaged header may promise more than the frames hold;
+    the reference call returns void, and what lies beyond the regenerated prefix is whatever the buffer held)."""
     L = lib()
     if cap is None:
         cap = int.from_bytes(arc[18:26], "little")
     out = ctypes.create_string_buffer(max(cap, 1))
     s = getattr(L, backend + "_zra_decompress_buffer")(_buf(arc), len(arc), out, cap)
+    if defined_only:
+        L.zo_zra_last_produced.restype = ctypes.c_size_t
+        return s.tup(), out.raw[:min(cap, L.zo_zra_last_produced())]
     return s.tup(), out.raw[:cap]
 
 

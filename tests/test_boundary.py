@@ -131,3 +131,19 @@ def test_reference_cli_builds_against_our_headers_and_library(tmp_path):
     subprocess.check_call(["g++", "-std=c++17", "-I" + os.path.join(ROOT, "include"), src, "-o", out,
                            "-L" + os.path.join(ROOT, "zra_amd"), "-lzra_amd", "-Wl,-rpath," + os.path.join(ROOT, "zra_amd"), "-Wl,-rpath,/opt/rocm/lib"])
     assert os.path.exists(out)
+
+
+def test_zstd_error_strings_match_dependency(zra):
+    """ZraGetErrorString appends ZSTD_getErrorString(code) (zra.cpp:74-78): every code of zstd 1.4.9's enum, against the library."""
+    import ctypes
+    import oracle_lib as O
+    if not O.have_libzstd():
+        pytest.skip("libzstd 1.4.x not present")
+    addr = O.libzstd_symbol("ZSTD_getErrorString")
+    assert addr
+    ref = ctypes.CFUNCTYPE(ctypes.c_char_p, ctypes.c_int)(addr)
+    L = zra.load()
+    for code in range(0, 121):
+        want = b"An error was returned by ZStandard: " + ref(code)
+        got = L.ZraGetErrorString(zra.ZraStatus(1, code))
+        assert got == want, (code, got, want)

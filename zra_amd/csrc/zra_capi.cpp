@@ -95,6 +95,7 @@ const char* zstd_error_string(int code) {   // ZSTD_getErrorString of zstd 1.4.9
     case 100: return "Frame index is too large";
     case 102: return "An I/O error occurred when reading/seeking";
     case 104: return "Destination buffer is wrong";
+    case 105: return "Source buffer is wrong";
     default: return "Unspecified error code";
   }
 }
