@@ -118,17 +118,18 @@ int walk_frames(const zra::u8* body, size_t n, std::vector<uint64_t>& starts, st
       if (skip > n - pos) return 72;
       pos += skip; continue;
     }
-    if (magic != 0xFD2FB528u) return more ? 72 : 10;
+    // ZSTD_decompressFrame + ZSTD_getFrameHeader_advanced of 1.4.9, in their order: the size checks come before the magic number
     const size_t f0 = pos;
+    if (n - pos < 6 + 3) return 72;
     unsigned fhd = body[pos + 4], did = fhd & 3, ss = (fhd >> 5) & 1, fcs = fhd >> 6;
     size_t hs = 5 + !ss + (did == 3 ? 4 : did) + (fcs == 0 ? ss : fcs == 1 ? 2 : fcs == 2 ? 4 : 8);
-    if (n - pos < hs) { *brokenAt = f0; return 72; }
-    // the header checks ZSTD_decompressFrame makes before it looks at any block (same order as the device decoder)
+    if (n - pos < hs + 3) return 72;
+    if (magic != 0xFD2FB528u) return more ? 72 : 10;
+    // the header checks made before any block is looked at (same order as the device decoder)
     if (fhd & 8) { *brokenAt = f0; return 14; }
     if (!ss) {
       unsigned b = body[pos + 5], wl = 10 + (b >> 3);
-      if (wl > 31) { *brokenAt = f0; return 14; }
-      if (((1ull << wl) + ((1ull << wl) >> 3) * (b & 7)) > (1ull << 27) + 1) { *brokenAt = f0; return 16; }
+      if (wl > 31) { *brokenAt = f0; return 16; }
     }
     {
       const zra::u8* q = body + pos + 5 + !ss;

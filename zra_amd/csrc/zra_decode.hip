@@ -1,15 +1,25 @@
-// zra_amd — frame DECODE kernel for gfx950 (MI355X).
+// zra_amd — frame DECODE kernels for gfx950 (MI355X).
 //
 // Replaces the reference's per-frame ZSTD_decompressDCtx work (zra.cpp:249,280,289,293,397,406,410,435).
-// One independent zstd frame per workgroup; the workgroup is ONE 64-lane wave and keeps only ~17 KiB of LDS (Huffman +
-// FSE decode tables, a 64-sequence batch), so 8-9 frames are in flight per CU (persistent grid, atomic frame queue):
-// decoding is a chain of dependent memory round trips, and frames in flight are what hides them.
-// Per compressed block:  lane 0 parses headers; all lanes build the tables; 4 lanes decode the 4 Huffman streams;
-// then batches of 64 sequences: lane 0 walks the FSE bit chain (inherently serial), a wave prefix-scan turns
-// (litLength, matchLength) into output positions, every lane copies ITS sequence's literals, and match copies run in
-// dependency rounds: a lane is ready once its source range ends before the first unfinished match destination, so
-// independent matches of a batch execute in the same round trip. The output window is the destination buffer (HBM/L2).
-// Format per RFC 8878 / SURVEY.md Appendix A.1-A.3.
+// A zstd frame is a chain of serial sections (header parses, the FSE sequence bit chain) around data-parallel ones (table fills,
+// literal and match copies). One wave per frame left 63 lanes idle in the serial sections, and the sequence chain alone was more
+// than half of all instructions. So the work of a frame is split by its SHAPE into three kernels that run once per round
+// (a round = one compressed block of every unfinished frame; 64 KiB ZRA frames take exactly one):
+//
+//   zra_dec_parse_kernel   wave per frame. Frame / block / literal / sequence headers (lane 0), Huffman table fill (wave), the
+//                          Huffman literal streams (one lane per stream) into a bump-allocated literal scratch, the three FSE
+//                          decode tables (built in LDS, stored to the frame's table scratch in HBM). Raw and RLE blocks and
+//                          the frame end are handled on the way; a compressed block is handed on.
+//   zra_dec_chain_kernel   LANE per frame: the FSE sequence chains of 64 frames advance together in the 64 lanes of a wave
+//                          (tables and bitstreams read from L2/HBM, one dependent round trip per sequence, thousands of frames
+//                          in flight per CU). Every check of the reference's sequence loop lives here, in its order, so the
+//                          execute kernel moves bytes without looking at them. Sequences go to a bump-allocated scratch.
+//   zra_dec_exec_kernel    wave per frame: 64 sequences per step — wave scan of the lengths, per-lane literal copies, match copies
+//                          in dependency rounds; then block commit, frame end, and (random access) the query slices.
+//
+// Statuses are results: the control flow restates libzstd 1.4.9's (oracle/zo_decode.c is the CPU twin, pinned against the library
+// on 44,000 damaged archives): its BIT_DStream reader incl. what an over-read returns, both of its Huffman decoders, both of its
+// sequence loops, its check order. Format per RFC 8878 / SURVEY.md Appendix A.1-A.3.
 #include "zra_dev.h"
 #include "zra_kernels.h"
 
@@ -18,7 +28,7 @@ using namespace zra_dev;
 namespace {
 
 constexpr int DEC_THREADS = 64;
-constexpr int BATCH = 64;           // sequences decoded + executed per round (one per lane)
+constexpr int BATCH = 64;           // sequences executed per step (one per lane)
 constexpr u32 BLOCK_MAX = 128u << 10;
 
 __constant__ u32 c_ll_base[36] = {0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,18,20,22,24,28,32,40,48,64,128,256,512,1024,2048,4096,8192,16384,32768,65536};
@@ -31,54 +41,44 @@ __constant__ short c_ll_defnorm[36] = {4,3,2,2,2,2,2,2,2,2,2,2,2,1,1,1,2,2,2,2,2
 __constant__ short c_ml_defnorm[53] = {1,4,3,2,2,2,2,2,2,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,
                                        1,1,1,1,1,1,1,1,1,1,1,1,1,1,-1,-1,-1,-1,-1,-1,-1};
 __constant__ short c_of_defnorm[29] = {1,1,1,1,1,1,2,2,2,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,-1,-1,-1,-1,-1};
+// HUF_selectDecoder of zstd 1.4.9 (algoTime[Q][single|double]): {tableTime, decode256Time}
+__constant__ u16 c_huf_t0[16][2] = {{0,0},{0,0},{38,130},{448,128},{556,128},{714,128},{883,128},{897,128},{926,128},{947,128},{1107,128},{1177,128},{1242,128},{1349,128},{1455,128},{722,128}};
+__constant__ u16 c_huf_t1[16][2] = {{1,1},{1,1},{1313,74},{1353,74},{1353,74},{1418,74},{1437,74},{1515,75},{1613,75},{1729,77},{2083,81},{2379,87},{2415,93},{2644,106},{2422,124},{1891,145}};
 
 // FSE decode cell of the Huffman-weight table (8 bytes): symbol | nbBits<<40 | nextBase<<48
 __device__ __forceinline__ u64 mk_seqsym(u32 baseValue, u32 addBits, u32 nbBits, u32 nextBase) {
   return (u64)baseValue | ((u64)addBits << 32) | ((u64)nbBits << 40) | ((u64)nextBase << 48);
 }
-// decode-table cell for LL / ML / OF (4 bytes): symbol | extraBits<<8 | nbBits<<16 | nextBase<<20. Everything that positions
-// the bit reader (extra bits, state bits) is in the cell; the base value is looked up by symbol off that chain. 4-byte cells
-// (2 KiB per 512-cell table instead of 4) are what lets 20 frames share a CU's LDS: the decoder is latency-bound and its
-// throughput is proportional to the frames in flight (profiles/r01_mf_occupancy_sweep.log, decode sweep).
+// low word of a decode-table cell for LL / ML / OF: symbol | extraBits<<8 | stateBits<<16 | nextBase<<20
 __device__ __forceinline__ u32 mk_cell(u32 sym, u32 addBits, u32 nbBits, u32 nextBase) {
   return sym | (addBits << 8) | (nbBits << 16) | (nextBase << 20);
 }
 
-struct __attribute__((aligned(16))) DecShared {
-  // The Huffman literal table is only live while the literal streams are decoded, the LL and ML tables only while sequences are
-  // decoded: they share 4 KiB. What is needed to rebuild them for a later block of the same frame (treeless literals, repeat-mode
-  // tables) is kept below (weights / llNorm / mlNorm).
+struct __attribute__((aligned(16))) ParseShared {
+  // the Huffman literal table is live while the literal streams are decoded, the staging area while a sequence table is built
   union {
-    struct { u32 llT[512]; u32 mlT[512]; };
-    u16 huf[2048];          // sym | nbBits<<8 ; doubles as scratch while a tree description is parsed
+    u16 huf[2048];          // sym | nbBits<<8 (bit 15: a pair of 12-bit codes, resolved through w1[]); doubles as scratch for the weights
+    u32 stage[1024];        // one FSE table under construction (LL / ML: 512 cells x 2 words; OF: 256 x 1)
   };
-  u32 ofT[256];
-  u32 llBase[36], mlBase[53];   // base values by symbol (copied from constant memory once per workgroup)
-  short llNorm[36];         // normalised counts of the last non-RLE LL / ML table (rebuild on repeat mode)
-  short mlNorm[53];
-  u32 llSaveLog, llSaveMax, llSaveRle;   // xxSaveRle: 0 = FSE table described by xxNorm, else 1 + RLE symbol
-  u32 mlSaveLog, mlSaveMax, mlSaveRle;
-  union {
-    struct { short norm[256]; u8 spread[512]; };      // scratch while a table is described / built
-    struct { u32 seqLL[BATCH], seqML[BATCH], seqOF[BATCH]; };   // one batch of decoded sequences
-  };
+  short norm[256];          // scratch while a table is described
+  u8 spread[512];
   u8 weights[256];
+  u8 w1[256];               // weight-1 symbols in order (only tables of depth 12 need them)
   u32 rankStart[16];
   // control words (written by lane 0, read by the wave after a wave sync)
-  u32 err;
-  u32 frame;
-  u32 blkType, blkSize, blkLast, blkPos;
+  u32 err, job;
+  u32 blkType, blkSize, blkLast, blkPos, hdrPos, frameEnd;
   u32 litType, litRegen, litComp, litHdr, litStreams, litRle;
-  u32 hufValid, hufMaxBits, hufNSym;
+  u32 hufValid, hufMaxBits, hufNSym, hufX2;
   u32 nbSeq, seqPos, seqModes;
-  u32 llLog, mlLog, ofLog, llValid, mlValid, ofValid;
+  u32 llLog, mlLog, ofLog, llValid, mlValid, ofValid, ofShare;
   u32 rep[3];
   u32 streamOff[4], streamLen[4];
   u32 tl, ms, used;
-  u32 produced;             // bytes produced in this frame so far
-  u32 seqHdrErr;            // error of the sequences header, raised after the literal stage
-  u32 batchValid;           // sequences of the current batch decoded before the bitstream went bad (== batch size when it did not)
-  u32 fcsLo, fcsHi, fcsHave;   // Frame_Content_Size when the header declares one (checked at the frame end, before the checksum)
+  u32 produced, seqHdrErr;
+  u32 fcsLo, fcsHi, fcsHave, hasChecksum, bigWindow;
+  u32 litKind, litArg, alloc;
+  u64 litBase, seqBase;
 };
 
 // wave-level sync: LDS and global traffic of the wave is complete and visible to its other lanes
@@ -87,6 +87,7 @@ __device__ __forceinline__ void wsync() {
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
+__device__ __forceinline__ u32 bcast_u32(u32 v, u32 l) { return (u32)__builtin_amdgcn_readlane((int)v, (int)l); }
 
 // ---------------------------------------------------------------------------------------------
 // FSE table description (A.3) -> norm[] ; single thread. returns bytes consumed, 0 on corruption
@@ -132,9 +133,9 @@ __device__ u32 read_ncount(short* norm, u32* maxSymIO, u32* tableLogOut, const u
   return (bitpos + 7) >> 3;
 }
 
-// Build an FSE decode table from norm[] (single wave; lanes cooperate on the final fill).
-// kind: 0 = LL, 1 = ML, 2 = OF
-__device__ void build_fse_dtable(u32* table, const short* norm, u32 maxSym, u32 tableLog, int kind, u8* spread, int lane) {
+// Build an FSE decode table from norm[] into the LDS staging area (single wave; lanes cooperate on the final fill).
+// kind: 0 = LL, 1 = ML (two words per cell: packed fields, base value), 2 = OF (one word per cell)
+__device__ void build_fse_dtable(u32* stage, const short* norm, u32 maxSym, u32 tableLog, int kind, u8* spread, int lane) {
   u32 size = 1u << tableLog, mask = size - 1;
   if (lane == 0) {
     u32 high = size - 1, step = (size >> 1) + (size >> 3) + 3, pos = 0;
@@ -147,18 +148,19 @@ __device__ void build_fse_dtable(u32* table, const short* norm, u32 maxSym, u32 
       }
     }
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  wsync();
   // cell u gets x = next[sym]++ in ascending u. One lane per symbol walks all cells (broadcast LDS reads).
   if ((u32)lane <= maxSym && norm[lane] != 0) {
     const u32 s = (u32)lane;
     u32 x = norm[s] == -1 ? 1u : (u32)norm[s];
+    const u32 add = kind == 0 ? c_ll_bits[s] : kind == 1 ? c_ml_bits[s] : s;
+    const u32 base = kind == 0 ? c_ll_base[s] : kind == 1 ? c_ml_base[s] : 0u;
     for (u32 u = 0; u < size; u++) {
       if (spread[u] != s) continue;
       u32 nbBits = tableLog - hb32(x);
       u32 nextBase = (x << nbBits) - size;
-      table[u] = mk_cell(s, kind == 0 ? c_ll_bits[s] : kind == 1 ? c_ml_bits[s] : s, nbBits, nextBase);
+      if (kind == 2) stage[u] = mk_cell(s, add, nbBits, nextBase);
+      else { stage[2 * u] = mk_cell(s, add, nbBits, nextBase); stage[2 * u + 1] = base; }
       x++;
     }
   }
@@ -167,12 +169,10 @@ __device__ void build_fse_dtable(u32* table, const short* norm, u32 maxSym, u32 
 // ---------------------------------------------------------------------------------------------
 // cooperative byte copy global->global by the calling group of `nthreads` threads (rank `t`)
 __device__ __forceinline__ void copy_bytes(u8* dst, const u8* src, u32 n, int t, int nthreads) {
-  // 16-byte body when both are 16B-aligned relative to each other is not guaranteed; use 8-byte unaligned moves
   u32 n8 = n >> 3;
   for (u32 i = t; i < n8; i += nthreads) st64(dst + 8 * i, ld64(src + 8 * i));
   for (u32 i = (n8 << 3) + t; i < n; i += nthreads) dst[i] = src[i];
 }
-__device__ __forceinline__ u32 bcast_u32(u32 v, u32 l) { return (u32)__builtin_amdgcn_readlane((int)v, (int)l); }
 __device__ __forceinline__ void fill_bytes(u8* dst, u8 v, u32 n, int t, int nthreads) {
   u64 vv = 0x0101010101010101ull * v;
   u32 n8 = n >> 3;
@@ -182,15 +182,16 @@ __device__ __forceinline__ void fill_bytes(u8* dst, u8 v, u32 n, int t, int nthr
 
 // ---------------------------------------------------------------------------------------------
 // literals section header + Huffman tree description; thread 0 only. Sets S.lit* / S.huf* / S.err.
-__device__ void parse_literals_header(DecShared& S, const u8* src, u32 n, const u8* lim) {
-  if (n < 1) { S.err = ZE_CORRUPTION; return; }
+// Check order of ZSTD_decodeLiteralsBlock (zstd_decompress_block.c of 1.4.9).
+__device__ void parse_literals_header(ParseShared& S, const u8* src, u32 n, const u8* lim) {
+  if (n < 3) { S.err = ZE_CORRUPTION; return; }                       // MIN_CBLOCK_SIZE
   u32 b0 = src[0], type = b0 & 3, sf = (b0 >> 2) & 3;
   S.litType = type;
   if (type < 2) {
     u32 size, lh;
     if (sf == 0 || sf == 2) { size = b0 >> 3; lh = 1; }
-    else if (sf == 1) { if (n < 2) { S.err = ZE_CORRUPTION; return; } size = ld16(src) >> 4; lh = 2; }
-    else { if (n < 3) { S.err = ZE_CORRUPTION; return; } size = ld24(src) >> 4; lh = 3; }
+    else if (sf == 1) { size = ld16(src) >> 4; lh = 2; }
+    else { size = ld24(src) >> 4; lh = 3; }
     if (size > BLOCK_MAX) { S.err = ZE_CORRUPTION; return; }
     u32 payload = type == 0 ? size : 1;
     if (lh + payload > n) { S.err = ZE_CORRUPTION; return; }
@@ -198,8 +199,8 @@ __device__ void parse_literals_header(DecShared& S, const u8* src, u32 n, const 
     if (type == 1) S.litRle = src[lh];
     return;
   }
-  u32 need = sf < 2 ? 3 : sf == 2 ? 4 : 5;
-  if (n < need) { S.err = ZE_CORRUPTION; return; }
+  if (type == 3 && !S.hufValid) { S.err = ZE_DICT_CORRUPTED; return; }   // set_repeat without a table, before any size check
+  if (n < 5) { S.err = ZE_CORRUPTION; return; }                          // "we need up to 5 for case 3", whatever the size format
   u32 regen, comp, lh, streams;
   if (sf < 2) { u32 v = ld24(src); regen = (v >> 4) & 0x3FF; comp = v >> 14; lh = 3; streams = sf == 0 ? 1 : 4; }
   else if (sf == 2) { u32 v = ld32(src); regen = (v >> 4) & 0x3FFF; comp = v >> 18; lh = 4; streams = 4; }
@@ -256,27 +257,36 @@ __device__ void parse_literals_header(DecShared& S, const u8* src, u32 n, const 
     for (u32 i = 0; i < nw; i++) { u32 w = S.weights[i]; if (w > 11) { S.err = ZE_CORRUPTION; return; } total += (1u << w) >> 1; }
     if (total == 0) { S.err = ZE_CORRUPTION; return; }
     u32 maxBits = hb32(total) + 1;
-    if (maxBits > 11) { S.err = ZE_CORRUPTION; return; }
+    if (maxBits > 12) { S.err = ZE_CORRUPTION; return; }               // HUF_TABLELOG_MAX of libzstd (the format says 11)
     u32 rest = (1u << maxBits) - total;
     if (rest == 0 || (rest & (rest - 1))) { S.err = ZE_CORRUPTION; return; }
     S.weights[nw] = (u8)(hb32(rest) + 1);
     S.hufNSym = nw + 1; S.hufMaxBits = maxBits;
-    // start cell of each weight class (cells ordered by weight ascending)
     // counts per weight, then turned in place into start cells (kept in LDS: a dynamically indexed local array would live in scratch)
     for (u32 w = 0; w <= 12; w++) S.rankStart[w] = 0;
     for (u32 i = 0; i <= nw; i++) S.rankStart[S.weights[i]]++;
+    if (S.rankStart[1] < 2) { S.err = ZE_CORRUPTION; return; }         // HUF_readStats: "at least 2 elts of rank 1"
     u32 acc = 0;
     for (u32 w = 1; w <= maxBits; w++) { const u32 c = S.rankStart[w]; S.rankStart[w] = acc; acc += c << (w - 1); }
     if (acc != (1u << maxBits)) { S.err = ZE_CORRUPTION; return; }
+    if (used >= rem) { S.err = ZE_CORRUPTION; return; }                // "hSize >= cSrcSize"
     S.hufValid = 2;   // 2 = new table to be filled by the workgroup
+    // which of libzstd's two decoders reads this table (they accept different DAMAGED streams): one stream -> single-symbol;
+    // four streams -> HUF_selectDecoder(regenerated size, compressed size incl. the tree); treeless blocks keep the table's kind
+    if (streams == 4) {
+      const u32 Q = comp >= regen ? 15u : (comp * 16u / regen), D256 = regen >> 8;
+      const u32 d0 = c_huf_t0[Q][0] + c_huf_t0[Q][1] * D256;
+      u32 d1 = c_huf_t1[Q][0] + c_huf_t1[Q][1] * D256;
+      d1 += d1 >> 3;
+      S.hufX2 = d1 < d0;
+    } else S.hufX2 = 0;
     p += used; rem -= used;
-  } else {
-    if (!S.hufValid) { S.err = ZE_DICT_CORRUPTED; return; }
   }
   // stream layout
   u32 base = (u32)(p - src);
   if (streams == 1) { S.streamOff[0] = base; S.streamLen[0] = rem; }
   else {
+    if (regen == 0 && type == 2) { S.err = ZE_CORRUPTION; return; }    // HUF_decompress4X_hufOnly_wksp: dstSize == 0
     if (rem < 10) { S.err = ZE_CORRUPTION; return; }
     u32 s1 = ld16(p), s2 = ld16(p + 2), s3 = ld16(p + 4);
     if (6 + s1 + s2 + s3 > rem) { S.err = ZE_CORRUPTION; return; }
@@ -289,27 +299,24 @@ __device__ void parse_literals_header(DecShared& S, const u8* src, u32 n, const 
   }
 }
 
-// sequences section header (nbSeq, modes, table descriptions -> S.norm per table is consumed immediately
-// by the workgroup, so this only parses nbSeq + modes; tables are parsed one at a time). thread 0.
-__device__ void parse_seq_header(DecShared& S, const u8* p, u32 rem) {
+// sequences section header (nbSeq + modes byte; ZSTD_decodeSeqHeaders). thread 0.
+__device__ void parse_seq_header(ParseShared& S, const u8* p, u32 rem) {
   if (rem < 1) { S.err = ZE_SRCSIZE_WRONG; return; }
   u32 nb = p[0], used;
-  if (nb == 0) { used = 1; if (rem != 1) { S.err = ZE_CORRUPTION; return; } }
+  if (nb == 0) { used = 1; if (rem != 1) { S.err = ZE_SRCSIZE_WRONG; return; } }
   else if (nb < 128) used = 1;
   else if (nb < 255) { if (rem < 2) { S.err = ZE_SRCSIZE_WRONG; return; } nb = ((nb - 128) << 8) + p[1]; used = 2; }
   else { if (rem < 3) { S.err = ZE_SRCSIZE_WRONG; return; } nb = (u32)p[1] + ((u32)p[2] << 8) + 0x7F00; used = 3; }
   S.nbSeq = nb;
   if (nb) {
     if (rem < used + 1) { S.err = ZE_SRCSIZE_WRONG; return; }
-    S.seqModes = p[used]; used++;
-    if (S.seqModes & 3) { S.err = ZE_CORRUPTION; return; }
+    S.seqModes = p[used]; used++;          // the two reserved bits are not looked at by libzstd 1.4.9
   }
   S.seqPos += used;
 }
 
-// one LL/ML/OF table: thread 0 parses (fills S.norm + logs), then wave 0 builds. returns via S fields.
-// kind 0 LL, 1 ML, 2 OF
-__device__ void seq_table_parse(DecShared& S, int kind, u32 mode, const u8* p, u32 rem, u32* tlOut, u32* msOut, u32* usedOut, const u8* lim) {
+// one LL/ML/OF table: thread 0 parses (fills S.norm + logs), then the wave builds.  kind 0 LL, 1 ML, 2 OF
+__device__ void seq_table_parse(ParseShared& S, int kind, u32 mode, const u8* p, u32 rem, u32* tlOut, u32* msOut, u32* usedOut, const u8* lim) {
   const u32 maxSymK = kind == 0 ? 35 : kind == 1 ? 52 : 31;
   const u32 maxALK = kind == 2 ? 8 : 9;
   *usedOut = 0;
@@ -328,77 +335,198 @@ __device__ void seq_table_parse(DecShared& S, int kind, u32 mode, const u8* p, u
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Huffman symbol lookup on 12 bits v (left-aligned code bits): symbol | nbBits<<8
+__device__ __forceinline__ u32 huf_lookup12(const ParseShared& S, u32 v12, u32 mb) {
+  if (mb < 12) return S.huf[v12 >> (12 - mb)] & 0x7FFFu;
+  const u32 e = S.huf[v12 >> 1];
+  if (e & 0x8000u) return (u32)S.w1[v12] | (12u << 8);
+  return e;
+}
+// bits [pos-12, pos) of a backward stream, zeros below bit 0 (BIT_lookBitsFast while bits remain)
+__device__ __forceinline__ u32 peek12(const u8* base, const u8* lim, i32 pos) {
+  const i32 lo = pos - 12;
+  if (lo >= 0) { const u64 w = ld64_safe(base + (lo >> 3), lim); return (u32)(w >> (lo & 7)) & 0xFFFu; }
+  if (pos <= 0) return 0;
+  const u64 w = ld64_safe(base, lim);
+  return (u32)((w << (u32)(-lo)) & 0xFFFu);
+}
+// libzstd's double-symbol decoder (HUF_decodeStreamX2) on ONE stream that the single-symbol rules rejected: a 12-bit lookup yields
+// one symbol or a PAIR (when both codes fit in 12 bits); if the walk ends one output position short, HUF_decodeLastSymbolX2 takes
+// the first symbol of the entry under the cursor and, for a pair entry, skips the bits of both codes clamped to the end of the
+// stream (nothing when no bit is left). Returns true when that decoder accepts the stream; `o` gets the symbols it writes.
+__device__ bool huf_stream_x2(const ParseShared& S, const u8* base, u32 n, const u8* lim, u8* o, u32 regen) {
+  if (n == 0) return false;
+  const u32 last = base[n - 1];
+  if (last == 0) return false;
+  i32 pos = (i32)(n - 1) * 8 + (i32)hb32(last);
+  const u32 mb = S.hufMaxBits;
+  u32 i = 0;
+  while (i + 2 <= regen) {
+    if (pos <= 0) return false;
+    const u32 e1 = huf_lookup12(S, peek12(base, lim, pos), mb), a = e1 >> 8;
+    const u32 e2 = huf_lookup12(S, peek12(base, lim, pos - (i32)a), mb), b = e2 >> 8;
+    o[i] = (u8)e1;
+    if (a + b <= 12) { o[i + 1] = (u8)e2; pos -= (i32)(a + b); i += 2; }
+    else { pos -= (i32)a; i += 1; }
+  }
+  if (i < regen) {
+    if (pos < 0) return false;
+    u32 v1;
+    if (pos > 0) v1 = peek12(base, lim, pos);
+    else {                                         // no bit left: the container's TOP 12 bits come back (shift by 64 & 63 = 0)
+      u64 c = 0; for (u32 k = 0; k < 8 && k < n; k++) c |= (u64)base[k] << (8 * k);
+      v1 = (u32)(c >> 52);
+    }
+    const u32 e1 = huf_lookup12(S, v1, mb), a = e1 >> 8;
+    const u32 v2 = pos > 0 ? peek12(base, lim, pos - (i32)a) : ((v1 << a) & 0xFFFu);
+    const u32 e2 = huf_lookup12(S, v2, mb), b = e2 >> 8;
+    o[i] = (u8)e1;
+    if (a + b <= 12) { if (pos > 0) { pos -= (i32)(a + b); if (pos < 0) pos = 0; } }
+    else pos -= (i32)a;
+  }
+  return pos == 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// frame end (shared by the parse and execute kernels): frame-level checks in the order of ZSTD_decompressFrame, the per-frame
+// result words, and — random access — the query slices of this frame
+__device__ void frame_finish(const ZraDecodeArgs& a, u32 j, const u8* src, u32 srcSize, u32 err, u32 produced, u32 endPos, bool truncated,
+                             u32 fcsHave, u32 fcsLo, u32 fcsHi, u32 hasChecksum, int lane) {
+  if (lane == 0) {
+    u32 ck = 0;
+    if (!err && !truncated) {
+      u32 pos = endPos;
+      if (fcsHave && (fcsHi != 0 || fcsLo != produced)) err = ZE_CORRUPTION;   // declared size first, then the checksum
+      if (!err && hasChecksum) {
+        if (srcSize - pos < 4) err = ZE_CHECKSUM_WRONG;
+        else { ck = ld32(src + pos); pos += 4; }
+      }
+      if (!err && pos != srcSize) err = ZE_SRCSIZE_WRONG;          // seek table and frame walk disagree
+    }
+    a.frameMeta[2 * (size_t)j] = truncated ? 2u : hasChecksum;
+    a.frameMeta[2 * (size_t)j + 1] = ck;
+    a.status[j] = err;
+    a.produced[j] = produced;
+    a.frames[j].done = 1;
+  }
+  err = bcast_u32(err, 0);
+  if (!err && a.pieces) {
+    const u8* const from = a.out + a.outOff[j];
+    const u32 p0 = a.pieceBase[j], p1 = a.pieceBase[j + 1];
+    for (u32 p = p0; p < p1; p++) {
+      const ZraRaPiece q = a.pieces[p];
+      if ((u64)q.srcOff + q.len <= produced) copy_bytes(a.raOut + q.dstOff, from + q.srcOff, q.len, lane, DEC_THREADS);
+    }
+  }
+}
+
 }  // namespace
 
 // =================================================================================================
-extern "C" __global__ void __launch_bounds__(DEC_THREADS, 6)   // 6 waves/SIMD; LDS (7 KiB per frame) admits 22 frames per CU
-zra_decode_frames_kernel(ZraDecodeArgs a) {
-  __shared__ DecShared S;
+// stage 1: parse
+extern "C" __global__ void __launch_bounds__(DEC_THREADS)
+zra_dec_parse_kernel(ZraDecodeArgs a) {
+  __shared__ ParseShared S;
   const int lane = threadIdx.x;
-  u8* const litScratch = a.litScratch + (size_t)blockIdx.x * ZRA_LIT_STRIDE;
-  if (lane < 36) S.llBase[lane] = c_ll_base[lane];
-  if (lane < 53) S.mlBase[lane] = c_ml_base[lane];
 
   for (;;) {
-    if (lane == 0) S.frame = atomicAdd(a.queue, 1u);
+    if (lane == 0) S.job = atomicAdd(&a.counters[ZRA_DC_QPARSE], 1u);
     wsync();
-    const u32 f = S.frame;
+    const u32 qi = S.job;
     wsync();
-    if (f >= a.nFrames) return;
+    if (qi >= a.nActive) return;
+    const u32 j = a.active ? a.active[qi] : qi;
+    const size_t gj = j;
 
-    const u64 so = a.frameOff[(size_t)f * a.offStride], se = a.frameOff[(size_t)f * a.offStride + 1];
+    const u64 so = a.frameOff[gj * a.offStride], se = a.frameOff[gj * a.offStride + 1];
     const u8* const src = a.body + so;
     const u32 srcSize = (u32)(se - so);
     const u8* const lim = a.body + a.bodySize;
-    u8* const dst = a.out + a.outOff[f];
-    const u32 dstCap = a.outCap[f];
+    u8* const dst = a.out + a.outOff[j];
+    const u32 dstCap = a.outCap[j];
+    const u32 limit = a.limit ? a.limit[j] : 0xFFFFFFFFu;
+    ZraDecFrame* const F = &a.frames[j];
 
     if (lane == 0) {
-      S.err = 0; S.produced = 0; S.hufValid = 0; S.llValid = S.mlValid = S.ofValid = 0;
-      S.rep[0] = 1; S.rep[1] = 4; S.rep[2] = 8; S.blkLast = 0;
-      // ---- frame header (A.1)
-      u32 hs = 0, checksum = 0;
-      if (se < so || se > a.bodySize || srcSize < 5) S.err = ZE_SRCSIZE_WRONG;
-      else if (ld32(src) != 0xFD2FB528u) S.err = ZE_PREFIX_UNKNOWN;
-      else {
-        u32 fhd = src[4], did = fhd & 3, ss = (fhd >> 5) & 1, fcs = fhd >> 6;
-        u32 didSize = did == 3 ? 4 : did;
-        u32 fcsSize = fcs == 0 ? ss : fcs == 1 ? 2 : fcs == 2 ? 4 : 8;
-        hs = 5 + !ss + didSize + fcsSize;
-        if (srcSize < hs) S.err = ZE_SRCSIZE_WRONG;
-        else if (fhd & 8) S.err = ZE_FRAMEPARAM_UNSUPPORTED;
-        else if (!ss) {
-          u32 b = src[5], wl = 10 + (b >> 3);
-          if (wl > 31) S.err = ZE_FRAMEPARAM_UNSUPPORTED;
-          else if (((1ull << wl) + ((1ull << wl) >> 3) * (b & 7)) > (1ull << 27) + 1) S.err = ZE_WINDOW_TOO_LARGE;
-        }
-        checksum = (fhd >> 2) & 1;
-        S.fcsHave = 0;
-        if (!S.err) {
-          // a dictionary id cannot be honoured (the reference never loads one): dictionary_wrong, as ZSTD_decompressFrame reports it;
-          // the declared content size (1/2/4/8 bytes, the 2-byte form biased by 256) must equal what the frame regenerates
-          const u8* q = src + 5 + !ss;
-          const u32 dict = did == 0 ? 0u : did == 1 ? (u32)q[0] : did == 2 ? (u32)ld16(q) : ld32(q);
-          if (dict) S.err = ZE_DICT_WRONG;
-          q += didSize;
-          if (fcsSize) {
-            const u64 v = fcsSize == 1 ? (u64)q[0] : fcsSize == 2 ? (u64)ld16(q) + 256 : fcsSize == 4 ? (u64)ld32(q) : ld64(q);
-            S.fcsLo = (u32)v; S.fcsHi = (u32)(v >> 32); S.fcsHave = 1;
+      S.err = 0; S.frameEnd = 0;
+      if (a.round == 0) {
+        S.produced = 0; S.hufValid = 0; S.llValid = S.mlValid = S.ofValid = 0; S.ofShare = 0;
+        S.rep[0] = 1; S.rep[1] = 4; S.rep[2] = 8;
+        // ---- frame header (A.1), check order of ZSTD_decompressFrame + ZSTD_getFrameHeader_advanced: sizes before the magic number
+        u32 hs = 0;
+        S.fcsHave = 0; S.hasChecksum = 0; S.bigWindow = 0;
+        if (se < so || se > a.bodySize || srcSize < 9) S.err = ZE_SRCSIZE_WRONG;
+        else {
+          u32 fhd = src[4], did = fhd & 3, ss = (fhd >> 5) & 1, fcs = fhd >> 6;
+          u32 didSize = did == 3 ? 4 : did;
+          u32 fcsSize = fcs == 0 ? ss : fcs == 1 ? 2 : fcs == 2 ? 4 : 8;
+          hs = 5 + !ss + didSize + fcsSize;
+          if (srcSize < hs + 3) S.err = ZE_SRCSIZE_WRONG;
+          else if (ld32(src) != 0xFD2FB528u) S.err = ZE_PREFIX_UNKNOWN;
+          else if (fhd & 8) S.err = ZE_FRAMEPARAM_UNSUPPORTED;
+          else {
+            u64 window = 0;
+            if (!ss) {
+              u32 b = src[5], wl = 10 + (b >> 3);
+              if (wl > 31) S.err = ZE_WINDOW_TOO_LARGE;                  // windowLog > ZSTD_WINDOWLOG_MAX; the one-shot decoder has no other limit
+              else window = (1ull << wl) + ((1ull << wl) >> 3) * (b & 7);
+            }
+            S.hasChecksum = (fhd >> 2) & 1;
+            if (!S.err) {
+              // a dictionary id cannot be honoured (the reference never loads one): dictionary_wrong, as ZSTD_decompressFrame reports it;
+              // the declared content size (1/2/4/8 bytes, the 2-byte form biased by 256) must equal what the frame regenerates
+              const u8* q = src + 5 + !ss;
+              const u32 dict = did == 0 ? 0u : did == 1 ? (u32)q[0] : did == 2 ? (u32)ld16(q) : ld32(q);
+              if (dict) S.err = ZE_DICT_WRONG;
+              q += didSize;
+              if (fcsSize) {
+                const u64 v = fcsSize == 1 ? (u64)q[0] : fcsSize == 2 ? (u64)ld16(q) + 256 : fcsSize == 4 ? (u64)ld32(q) : ld64(q);
+                S.fcsLo = (u32)v; S.fcsHi = (u32)(v >> 32); S.fcsHave = 1;
+                if (ss) window = v;
+              }
+              S.bigWindow = window > (1ull << 24);                     // selects libzstd's long-offset sequence loop (chain kernel)
+            }
           }
         }
+        S.blkPos = hs;
+      } else {
+        S.produced = F->produced; S.blkPos = F->blkPos;
+        S.hufValid = F->hufValid; S.hufMaxBits = F->hufMaxBits; S.hufNSym = F->hufNSym; S.hufX2 = F->hufX2;
+        S.llValid = F->llValid; S.mlValid = F->mlValid; S.ofValid = F->ofValid; S.llLog = F->llLog; S.mlLog = F->mlLog; S.ofLog = F->ofLog;
+        S.ofShare = F->ofShare;
+        S.rep[0] = F->rep[0]; S.rep[1] = F->rep[1]; S.rep[2] = F->rep[2];
+        S.fcsLo = F->fcsLo; S.fcsHi = F->fcsHi; S.fcsHave = F->fcsHave; S.hasChecksum = F->hasChecksum; S.bigWindow = F->bigWindow;
       }
-      S.blkPos = hs;
-      a.frameMeta[2 * (size_t)f] = checksum;   // [2f] = has checksum, [2f+1] = stored checksum (set at frame end)
     }
     wsync();
-
-    // ------------------------------------------------------------------ block loop
-    for (;;) {
-      const bool done = S.err || S.blkLast;    // sampled by every lane before lane 0 may overwrite it
+    if (a.round != 0 && S.hufValid) {                  // kept Huffman description of the previous block (treeless literals rebuild from it)
+      for (u32 i = lane; i < 256; i += DEC_THREADS) S.weights[i] = F->weights[i];
+      if (lane < 16) S.rankStart[lane] = F->rankStart[lane];
       wsync();
-      if (done) break;
+    }
+
+    // what a frame carries from round to round (lane 0)
+    auto save_persistent = [&](u32 blkPos, u32 produced) {
+      F->blkPos = blkPos; F->produced = produced; F->done = 0;
+      F->hufValid = S.hufValid ? 1u : 0u; F->hufMaxBits = S.hufMaxBits; F->hufNSym = S.hufNSym; F->hufX2 = S.hufX2;
+      F->llValid = S.llValid; F->mlValid = S.mlValid; F->ofValid = S.ofValid; F->llLog = S.llLog; F->mlLog = S.mlLog; F->ofLog = S.ofLog;
+      F->ofShare = S.ofShare;
+      F->rep[0] = S.rep[0]; F->rep[1] = S.rep[1]; F->rep[2] = S.rep[2];
+      F->fcsLo = S.fcsLo; F->fcsHi = S.fcsHi; F->fcsHave = S.fcsHave; F->hasChecksum = S.hasChecksum; F->bigWindow = S.bigWindow;
+    };
+
+    // ------------------------------------------------------------------ block loop: until a compressed block is handed on,
+    //                                                                    the frame ends, or an error stops it
+    bool handed = false, truncated = false;
+    for (;;) {
+      const bool stop = S.err || S.frameEnd;    // sampled by every lane before lane 0 may overwrite it
+      wsync();
+      if (stop) break;
+      if (S.produced >= limit) { truncated = true; break; }        // random access: every byte a query needs exists
       if (lane == 0) {
         u32 pos = S.blkPos;
+        S.hdrPos = pos;
         if (srcSize - pos < 3) S.err = ZE_SRCSIZE_WRONG;
         else {
           u32 bh = ld24(src + pos);
@@ -415,14 +543,13 @@ zra_decode_frames_kernel(ZraDecodeArgs a) {
       wsync();
       if (S.err) break;
       const u32 btype = S.blkType, bsize = S.blkSize, bpos = S.blkPos, produced0 = S.produced;
-      u8* const out = dst + produced0;           // this block's output start
-      const u32 outCap = dstCap - produced0;
 
       if (btype == 0 || btype == 1) {
+        u8* const out = dst + produced0;
         if (btype == 0) copy_bytes(out, src + bpos, bsize, lane, DEC_THREADS);
         else fill_bytes(out, src[bpos], bsize, lane, DEC_THREADS);
         wsync();
-        if (lane == 0) { S.produced = produced0 + bsize; S.blkPos = bpos + (btype == 0 ? bsize : 1); }
+        if (lane == 0) { S.produced = produced0 + bsize; S.blkPos = bpos + (btype == 0 ? bsize : 1); S.frameEnd = S.blkLast; }
         wsync();
         continue;
       }
@@ -430,24 +557,53 @@ zra_decode_frames_kernel(ZraDecodeArgs a) {
       // ------------------------------------------------------------ compressed block
       const u8* const blk = src + bpos;
       if (lane == 0) {
-        S.litStreams = 1; S.litRle = 0;
+        S.litStreams = 1; S.litRle = 0; S.alloc = 1;
         parse_literals_header(S, blk, bsize, lim);
         S.seqHdrErr = 0;
         if (!S.err) {
-          // the sequences header is parsed now (its fields steer the literal stage's scratch), but an error in it is only raised
-          // after the literals have been decoded: the reference decodes the literals section first (ZSTD_decodeLiteralsBlock)
+          // literal scratch of this round (Huffman-coded literals only: raw ones are read in place, RLE ones are a byte)
+          if (S.litType >= 2) {
+            const u64 need = ((u64)S.litRegen + 15) & ~15ull;
+            const u64 at = atomicAdd((unsigned long long*)&a.counters[ZRA_DC_LITCUR], (unsigned long long)need);
+            if (at + need > a.litCap) S.alloc = 0;
+            S.litBase = at; S.litKind = 2;
+          } else if (S.litType == 1) { S.litKind = 1; S.litArg = S.litRle; }
+          else { S.litKind = 0; S.litArg = bpos + S.litHdr; }
+          // the sequences header is parsed now, but an error in it is only raised after the literals have been decoded: the
+          // reference decodes the literals section first (ZSTD_decodeLiteralsBlock, then ZSTD_decodeSeqHeaders)
           S.seqPos = S.litHdr + S.litComp;
           parse_seq_header(S, blk + S.seqPos, bsize - S.seqPos);
           S.seqHdrErr = S.err; S.err = 0;
           if (S.seqHdrErr) S.nbSeq = 0;
+          if (S.alloc && S.nbSeq) {
+            const u64 at = atomicAdd((unsigned long long*)&a.counters[ZRA_DC_SEQCUR], (unsigned long long)S.nbSeq);
+            if (at + S.nbSeq > a.seqCap) S.alloc = 0;
+            S.seqBase = at;
+          }
         }
       }
       wsync();
       if (S.err) break;
+      if (!S.alloc) {
+        // this round's scratch is full: the frame keeps its state as of this block's header and takes the next round (which parses
+        // the block again; what the header parse above left in the Huffman description is what that parse will write again)
+        if (lane == 0) {
+          save_persistent(S.hdrPos, produced0);
+          a.nextActive[atomicAdd(&a.counters[ZRA_DC_NNEXT], 1u)] = j;
+        }
+        if (S.hufValid) {
+          for (u32 i = lane; i < 256; i += DEC_THREADS) F->weights[i] = S.weights[i];
+          if (lane < 16) F->rankStart[lane] = S.rankStart[lane];
+        }
+        handed = true;          // (nothing pending, but the frame is not finished either)
+        wsync();
+        break;
+      }
 
       // ---- Huffman decode table fill: cells ordered by weight, then symbol
-      if (S.litType >= 2) {                              // new table, or treeless: rebuilt from the kept weights (LDS shared with llT)
+      if (S.litType >= 2) {                              // new table, or treeless: rebuilt from the kept weights (LDS shared with the FSE staging)
         const u32 nSym = S.hufNSym, maxBits = S.hufMaxBits;
+        const u32 sh = maxBits == 12 ? 1u : 0u;          // depth 12: cells are indexed by the top 11 bits, the 12-bit codes come in pairs
         for (u32 sy = lane; sy < nSym; sy += DEC_THREADS) {
           u32 w = S.weights[sy];
           if (w == 0) continue;
@@ -455,43 +611,49 @@ zra_decode_frames_kernel(ZraDecodeArgs a) {
           for (u32 t = 0; t < sy; t++) before += (S.weights[t] == w);
           u32 len = 1u << (w - 1), start = S.rankStart[w] + before * len;
           u16 e = (u16)(sy | ((maxBits + 1 - w) << 8));
-          for (u32 c = 0; c < len; c++) S.huf[start + c] = e;
+          if (sh && w == 1) { S.w1[start] = (u8)sy; if (!(before & 1)) S.huf[start >> 1] = 0x8000u | (12u << 8); }
+          else { len >>= sh; start >>= sh; for (u32 c = 0; c < len; c++) S.huf[start + c] = e; }
         }
         wsync();
         if (lane == 0) S.hufValid = 1;
         wsync();
       }
       const u32 nbSeq = S.nbSeq;
-      // ---- literals: raw -> point into the source; RLE -> fill scratch; Huffman -> up to 4 lanes, one per stream
+      // ---- literals: Huffman -> up to 4 lanes, one per stream, into the literal scratch
       const u32 litType = S.litType, regen = S.litRegen;
-      const u8* lit = litScratch;
-      if (litType == 0) lit = blk + S.litHdr;
-      else if (litType == 1) fill_bytes(litScratch, (u8)S.litRle, regen, lane, DEC_THREADS);
-      else {
+      if (litType >= 2) {
+        u8* const litOut = a.lits + S.litBase;
         const u32 nStreams = S.litStreams;
-        if ((u32)lane < nStreams && !(a.debugSkip & 4)) {
+        if ((u32)lane < nStreams) {
           const u32 seg = nStreams == 1 ? regen : (regen + 3) / 4;
           const u32 myLen = nStreams == 1 ? regen : (lane < 3 ? seg : regen - 3 * seg);
-          u8* o = litScratch + (size_t)lane * seg;
+          u8* o = litOut + (size_t)lane * seg;
+          const u8* const sb = blk + S.streamOff[lane]; const u32 sl = S.streamLen[lane];
           BitR hb;
-          bool bad = hb.init(blk + S.streamOff[lane], S.streamLen[lane], lim) != 0;
+          bool bad = hb.init(sb, sl, lim) != 0;
           if (!bad) {
             const int mb = (int)S.hufMaxBits;
             u32 i = 0;
-            for (; i + 4 <= myLen; i += 4) {        // 4 symbols per window reload (4*11 = 44 <= 56 guaranteed bits)
-              hb.ensure(4 * mb);
-              u32 packed = 0;
+            if (mb < 12) {
+              for (; i + 4 <= myLen; i += 4) {        // 4 symbols per window reload (4*11 = 44 <= 56 guaranteed bits)
+                hb.ensure(4 * mb);
+                u32 packed = 0;
 #pragma unroll
-              for (int k = 0; k < 4; k++) {
-                u32 e = S.huf[hb.peek(mb)];
-                packed |= (e & 0xFF) << (8 * k);
-                hb.skip((int)(e >> 8));
+                for (int k = 0; k < 4; k++) {
+                  u32 e = S.huf[hb.peek(mb)];
+                  packed |= (e & 0xFF) << (8 * k);
+                  hb.skip((int)(e >> 8));
+                }
+                st32(o + i, packed);
               }
-              st32(o + i, packed);
+              for (; i < myLen; i++) { hb.ensure(mb); u32 e = S.huf[hb.peek(mb)]; o[i] = (u8)e; hb.skip((int)(e >> 8)); }
+            } else {
+              for (; i < myLen; i++) { hb.ensure(12); const u32 e = huf_lookup12(S, hb.peek(12), 12); o[i] = (u8)e; hb.skip((int)(e >> 8)); }
             }
-            for (; i < myLen; i++) { hb.ensure(mb); u32 e = S.huf[hb.peek(mb)]; o[i] = (u8)e; hb.skip((int)(e >> 8)); }
             if (hb.pos != 0) bad = true;
           }
+          // a stream the single-symbol rules reject may still pass libzstd's double-symbol decoder, if that is the one it would use
+          if (bad && S.hufX2) bad = !huf_stream_x2(S, sb, sl, lim, o, myLen);
           if (bad) S.err = ZE_CORRUPTION;
         }
       }
@@ -499,7 +661,8 @@ zra_decode_frames_kernel(ZraDecodeArgs a) {
       if (S.err) break;
       if (S.seqHdrErr) { wsync(); if (lane == 0) S.err = S.seqHdrErr; wsync(); break; }
 
-      // ---- sequence decode tables: lane 0 parses each description, the wave builds it
+      // ---- sequence decode tables: lane 0 parses each description, the wave builds it in LDS and stores it to the table scratch
+      u32* const T = a.tables + (size_t)j * ZRA_DEC_TBL_WORDS;
       if (nbSeq) {
         bool bad = false;
         for (int kind = 0; kind < 3 && !bad; kind++) {
@@ -513,28 +676,26 @@ zra_decode_frames_kernel(ZraDecodeArgs a) {
           }
           wsync();
           if (S.err) { bad = true; break; }
-          u32* table = k == 0 ? S.llT : k == 1 ? S.mlT : S.ofT;
           const u32 tl = S.tl, ms = S.ms;
+          u32* const G = T + (k == 0 ? ZRA_DEC_TBL_LL : k == 1 ? ZRA_DEC_TBL_ML : ZRA_DEC_TBL_OF);
           if (mode == 1) {
-            if (lane == 0) table[0] = mk_cell(ms, k == 0 ? c_ll_bits[ms] : k == 1 ? c_ml_bits[ms] : ms, 0, 0);
-            if (k == 0 && lane == 0) S.llSaveRle = 1 + ms;
-            if (k == 1 && lane == 0) S.mlSaveRle = 1 + ms;
-          } else if (mode != 3) {
-            build_fse_dtable(table, S.norm, ms, tl, k, S.spread, lane);
-            // remember how to rebuild LL / ML (their LDS is reused by the next block's Huffman table)
-            if (k == 0) {
-              if ((u32)lane <= ms) S.llNorm[lane] = S.norm[lane];
-              if (lane == 0) { S.llSaveLog = tl; S.llSaveMax = ms; S.llSaveRle = 0; }
-            } else if (k == 1) {
-              if ((u32)lane <= ms) S.mlNorm[lane] = S.norm[lane];
-              if (lane == 0) { S.mlSaveLog = tl; S.mlSaveMax = ms; S.mlSaveRle = 0; }
+            if (lane == 0) {
+              if (k == 2) { G[0] = mk_cell(ms, ms, 0, 0); S.ofShare = (ms > 22) ? 256u : 0u; }
+              else { G[0] = mk_cell(ms, k == 0 ? c_ll_bits[ms] : c_ml_bits[ms], 0, 0); G[1] = k == 0 ? c_ll_base[ms] : c_ml_base[ms]; }
             }
-          } else if (k == 0) {                             // repeat mode: the literal decode of this block overwrote the table
-            if (S.llSaveRle) { if (lane == 0) { const u32 sy = S.llSaveRle - 1; table[0] = mk_cell(sy, c_ll_bits[sy], 0, 0); } }
-            else build_fse_dtable(table, S.llNorm, S.llSaveMax, S.llSaveLog, 0, S.spread, lane);
-          } else if (k == 1) {
-            if (S.mlSaveRle) { if (lane == 0) { const u32 sy = S.mlSaveRle - 1; table[0] = mk_cell(sy, c_ml_bits[sy], 0, 0); } }
-            else build_fse_dtable(table, S.mlNorm, S.mlSaveMax, S.mlSaveLog, 1, S.spread, lane);
+          } else if (mode != 3) {
+            build_fse_dtable(S.stage, S.norm, ms, tl, k, S.spread, lane);
+            wsync();
+            const u32 words = (k == 2 ? 1u : 2u) << tl;
+            for (u32 i = lane; i < words; i += DEC_THREADS) G[i] = S.stage[i];
+            if (k == 2) {
+              // share of long offset codes (ZSTD_getLongOffsetsShare): cells whose code needs more than 22 extra bits, scaled to 8 bits
+              u32 cnt = 0;
+              for (u32 i = lane; i < (1u << tl); i += DEC_THREADS) cnt += (S.stage[i] & 0xFF) > 22;
+              cnt = wave_sum(cnt);
+              if (lane == 0) S.ofShare = cnt << (8 - tl);
+            }
+            wsync();
           }
           if (lane == 0 && mode != 3) {
             if (k == 0) { S.llLog = tl; S.llValid = 1; } else if (k == 1) { S.mlLog = tl; S.mlValid = 1; } else { S.ofLog = tl; S.ofValid = 1; }
@@ -544,172 +705,308 @@ zra_decode_frames_kernel(ZraDecodeArgs a) {
         if (bad) break;
       }
 
-      // ---- sequences: batches of 64 (lane 0 decodes, the wave executes)
-      BitR br; br.base = blk; br.lim = lim; br.pos = 0; br.wlo = 0; br.w = 0;
-      u32 sLL = 0, sML = 0, sOF = 0;
-      u32 rep0 = S.rep[0], rep1 = S.rep[1], rep2 = S.rep[2];
-      if (lane == 0 && nbSeq) {
-        if (br.init(blk + S.seqPos, bsize - S.seqPos, lim)) S.err = ZE_CORRUPTION;
-        else {
-          sLL = br.read((int)S.llLog); sOF = br.read((int)S.ofLog); sML = br.read((int)S.mlLog);
-          if (br.pos < 0) S.err = ZE_CORRUPTION;
-        }
+      // ---- hand the block to the chain kernel: persistent state + the block record
+      if (lane == 0) {
+        save_persistent(S.hdrPos, produced0);
+        F->bpos = bpos; F->bsize = bsize; F->blast = S.blkLast;
+        F->litKind = S.litKind; F->litRegen = regen; F->litArg = S.litArg; F->litBase = S.litBase;
+        F->nbSeq = nbSeq; F->seqPos = S.seqPos; F->seqBase = S.seqBase;
+        F->longMode = (S.bigWindow && nbSeq > 4 && S.ofShare >= 7) ? 1u : 0u;
+        a.pending[atomicAdd(&a.counters[ZRA_DC_NPENDING], 1u)] = j;
       }
-      wsync();
-      if (S.err) break;
-      u32 outBase = 0, litBase = 0;              // running positions (wave-uniform)
-      bool fail = false;
-      for (u32 first = 0; first < nbSeq; first += BATCH) {
-        const u32 cntAll = min((u32)BATCH, nbSeq - first);
-        // -------- stage A: lane 0 — FSE sequence decode of this batch
-        if (lane == 0) {
-          // A malformed sequence stops the decode, but the sequences before it are still executed first: the reference decodes and
-          // executes one sequence at a time, so an execution error of an earlier sequence wins over the decode error of a later one
-          u32 bad = 0, valid = cntAll;
-          for (u32 i = 0; i < cntAll; i++) {
-            const u32 eL = S.llT[sLL], eM = S.mlT[sML], eO = S.ofT[sOF];
-            const u32 ofBits = (eO >> 8) & 0xFF, mlBits = (eM >> 8) & 0xFF, llBits = (eL >> 8) & 0xFF;
-            if (ofBits > 31) { bad = 1; valid = i; break; }
-            const u32 baseL = S.llBase[eL & 0xFF], baseM = S.mlBase[eM & 0xFF];   // by symbol; not on the bit-position chain
-            // offset, match-length and literal-length extra bits in ONE extraction when they fit the 57 bits a reload guarantees
-            // (always, for windows <= 128 KiB); bitstream order: OF, ML, LL = topmost ... lowest
-            const u32 lm = mlBits + llBits, t1 = ofBits + lm;
-            u32 offVal, both;
-            if (t1 <= 56) {
-              br.ensure((int)t1);
-              const u64 x = (br.w >> (br.pos - (i32)t1 - br.wlo)) & ((1ull << t1) - 1);
-              br.pos -= (i32)t1;
-              offVal = (1u << ofBits) + (u32)(x >> lm);
-              both = (u32)(x & ((1ull << lm) - 1));
-            } else {
-              offVal = (1u << ofBits) + br.read((int)ofBits);
-              both = br.read((int)lm);
-            }
-            const u32 ml = baseM + (both >> llBits), ll = baseL + (both & ((1u << llBits) - 1));
-            if (first + i + 1 < nbSeq) {
-              const int nL = (int)((eL >> 16) & 0xF), nM = (int)((eM >> 16) & 0xF), nO = (int)((eO >> 16) & 0xF);
-              // LL, ML, OF state bits in one extraction (<= 26 bits): LL is read first = topmost
-              const u32 st = br.read(nL + nM + nO);
-              sLL = (eL >> 20) + (st >> (nM + nO));
-              sML = (eM >> 20) + ((st >> nO) & ((1u << nM) - 1));
-              sOF = (eO >> 20) + (st & ((1u << nO) - 1));
-            }
-            if (br.pos < 0) { bad = 1; valid = i; break; }
-            u32 off;                                   // repcode resolution (A.3)
-            if (offVal > 3) { off = offVal - 3; rep2 = rep1; rep1 = rep0; rep0 = off; }
-            else {
-              u32 idx = offVal + (ll == 0);
-              if (idx == 1) off = rep0;
-              else {
-                off = idx == 2 ? rep1 : idx == 3 ? rep2 : rep0 - 1;
-                off += !off;                               // zstd 1.4.9 forces a zero offset to 1 (no error)
-                if (idx != 2) rep2 = rep1;
-                rep1 = rep0; rep0 = off;
-              }
-            }
-            S.seqLL[i] = ll; S.seqML[i] = ml; S.seqOF[i] = off;
-          }
-          if (!bad && first + cntAll == nbSeq && br.pos != 0) bad = 1;     // checked after the last sequence has been executed
-          S.batchValid = bad ? (valid | 0x80000000u) : valid;
-        }
-        wsync();
-        const u32 bv = S.batchValid;
-        const bool chainBad = bv >> 31;
-        const u32 cnt = bv & 0x7FFFFFFFu;
-        // -------- stage B: positions by wave prefix scan; every lane copies its sequence's literals
-        const bool act = (u32)lane < cnt;
-        const u32 ll = act ? S.seqLL[lane] : 0, ml = act ? S.seqML[lane] : 0, off = act ? S.seqOF[lane] : 1;
-        const u32 tot = ll + ml;
-        const u32 incT = wave_incl_scan(tot), incL = wave_incl_scan(ll);
-        const u32 oStart = outBase + incT - tot, lStart = litBase + incL - ll;
-        const u32 mdst = oStart + ll;
-        u32 e = 0;
-        if (act) {
-          // ZSTD_execSequenceEnd order: destination room first, then the literal buffer, then the offset
-          if (oStart > outCap || tot > outCap - oStart) e = ZE_DSTSIZE_TOOSMALL;
-          else if (lStart > regen || ll > regen - lStart) e = ZE_CORRUPTION;
-          else if (off > produced0 + mdst) e = ZE_CORRUPTION;
-        }
-        const u64 em = __ballot(e != 0);
-        if (em) { if ((u32)lane == (u32)__builtin_ctzll(em)) S.err = e; wsync(); fail = true; break; }
-        {
-          const u8* lp = lit + lStart; u8* op = out + oStart;
-          const bool longLit = ll > 32;
-          if (!longLit && !(a.debugSkip & 2)) for (u32 b = 0; b < ll; b++) op[b] = lp[b];
-          u64 lm = __ballot(longLit);
-          while (lm) {                               // long literal runs: the whole wave copies, coalesced
-            const u32 j = (u32)__builtin_ctzll(lm); lm &= lm - 1;
-            const u32 jl = bcast_u32(ll, j), jo = bcast_u32(oStart, j), js = bcast_u32(lStart, j);
-            copy_bytes(out + jo, lit + js, jl, lane, DEC_THREADS);
-          }
-        }
-        wsync();
-        // -------- stage C: match copies in dependency rounds
-        {
-          const u32 msrc = mdst - off;
-          const u32 msrcEnd = min(msrc + ml, mdst);
-          u64 pending = (a.debugSkip & 1) ? 0ull : __ballot(act);
-          while (pending) {
-            const u32 fnd = (u32)__builtin_ctzll(pending);
-            const u32 frontier = bcast_u32(mdst, fnd);
-            const bool mine = (pending >> lane) & 1;
-            const bool ready = mine && (msrcEnd <= frontier || (u32)lane == fnd);
-            const bool longM = ready && ml > 64;
-            if (ready && !longM) {
-              u8* dp = out + mdst; const u8* sp = dp - off;
-              if (off >= ml) {                           // no overlap: 8-byte moves + byte tail
-                u32 k = 0;
-                for (; k + 8 <= ml; k += 8) st64(dp + k, ld64(sp + k));
-                for (; k < ml; k++) dp[k] = sp[k];
-              } else {                                   // overlapping match = period `off`: read only bytes in front of the destination
-                u32 j = 0;
-                for (u32 k = 0; k < ml; k++) { dp[k] = sp[j]; j = j + 1 == off ? 0 : j + 1; }
-              }
-            }
-            u64 lmk = __ballot(longM);
-            while (lmk) {                            // long matches: the whole wave copies (period-safe modular source)
-              const u32 j = (u32)__builtin_ctzll(lmk); lmk &= lmk - 1;
-              const u32 jml = bcast_u32(ml, j), jd = bcast_u32(mdst, j), jof = bcast_u32(off, j);
-              u8* dp = out + jd; const u8* sp = dp - jof;
-              if (jof >= jml) { for (u32 k = lane; k < jml; k += WAVE) dp[k] = sp[k]; }
-              else { for (u32 k = lane; k < jml; k += WAVE) dp[k] = sp[k % jof]; }
-            }
-            pending &= ~__ballot(ready);
-            wsync();
-          }
-        }
-        outBase += bcast_u32(incT, 63); litBase += bcast_u32(incL, 63);
-        if (chainBad) { if (lane == 0) S.err = ZE_CORRUPTION; wsync(); fail = true; break; }
+      if (S.litType == 2) {                               // a new tree: keep its description for treeless blocks to come
+        for (u32 i = lane; i < 256; i += DEC_THREADS) F->weights[i] = S.weights[i];
+        if (lane < 16) F->rankStart[lane] = S.rankStart[lane];
       }
-      if (fail || S.err) break;
-
-      // ---- block tail: remaining literals
-      if (litBase > regen) { if (lane == 0) S.err = ZE_CORRUPTION; }
-      else if (outBase > outCap || regen - litBase > outCap - outBase) { if (lane == 0) S.err = ZE_DSTSIZE_TOOSMALL; }
-      else copy_bytes(out + outBase, lit + litBase, regen - litBase, lane, DEC_THREADS);
+      handed = true;
       wsync();
-      if (lane == 0 && !S.err) {
-        S.produced = produced0 + outBase + (regen - litBase);
-        S.blkPos = bpos + bsize;
-        S.rep[0] = rep0; S.rep[1] = rep1; S.rep[2] = rep2;
-      }
-      wsync();
+      break;
     }
+    if (!handed) {
+      frame_finish(a, j, src, srcSize, S.err, S.produced, S.blkPos, truncated, S.fcsHave, S.fcsLo, S.fcsHi, S.hasChecksum, lane);
+    }
+    wsync();
+  }
+}
 
-    // ------------------------------------------------------------------ frame end
-    if (lane == 0) {
-      u32 err = S.err;
-      if (!err) {
-        u32 pos = S.blkPos;
-        if (S.fcsHave && (S.fcsHi != 0 || S.fcsLo != S.produced)) err = ZE_CORRUPTION;   // declared size first, then the checksum
-        if (!err && a.frameMeta[2 * (size_t)f]) {
-          if (srcSize - pos < 4) err = ZE_CHECKSUM_WRONG;
-          else { a.frameMeta[2 * (size_t)f + 1] = ld32(src + pos); pos += 4; }
+// =================================================================================================
+// stage 2: the FSE sequence chains, lane = frame
+namespace {
+
+// libzstd's BIT_DStream_t (bitstream.h of 1.4.9), restated field for field: a 64-bit container refilled from the END of the stream
+// towards its start. Exact, because an over-read stream is not an error inside the sequence loop of 1.4.9: the wrapped container
+// bits it then reads decide what the frame finally returns (oracle/zo_decode.c: zds).
+struct Zds {
+  u64 c; u32 bc; u32 ptr;      // ptr: byte offset of the container inside the stream (libzstd: ptr - start)
+  const u8* base;
+  enum : int { UNFINISHED = 0, ENDOFBUFFER = 1, COMPLETED = 2, OVERFLOW = 3 };
+  __device__ __forceinline__ bool init(const u8* b, u32 n) {
+    base = b;
+    if (n < 1) return false;
+    if (n >= 8) { ptr = n - 8; c = ld64(b + ptr); }
+    else { ptr = 0; c = 0; for (u32 i = 0; i < n; i++) c |= (u64)b[i] << (8 * i); }
+    const u32 last = b[n - 1];
+    if (last == 0) return false;
+    bc = 8 - hb32(last);
+    if (n < 8) bc += (8 - n) * 8;
+    return true;
+  }
+  __device__ __forceinline__ u32 read(u32 nb) {           // BIT_readBits: BIT_getMiddleBits(container, 64 - bc - nb, nb)
+    const u32 start = 64u - bc - nb;
+    const u32 v = (u32)(c >> (start & 63)) & ((1u << nb) - 1u);      // nb <= 9 here
+    bc += nb; return v;
+  }
+  __device__ __forceinline__ u32 read_fast(u32 nb) {      // BIT_readBitsFast: nb >= 1
+    const u32 v = (u32)((c << (bc & 63)) >> ((64 - nb) & 63));
+    bc += nb; return v;
+  }
+  __device__ __forceinline__ int reload() {
+    if (bc > 64) return OVERFLOW;
+    if (ptr >= 8) { ptr -= bc >> 3; bc &= 7; c = ld64(base + ptr); return UNFINISHED; }
+    if (ptr == 0) return bc < 64 ? ENDOFBUFFER : COMPLETED;
+    u32 nbBytes = bc >> 3; int r = UNFINISHED;
+    if (ptr < nbBytes) { nbBytes = ptr; r = ENDOFBUFFER; }
+    ptr -= nbBytes; bc -= nbBytes * 8; c = ld64(base + ptr);
+    return r;
+  }
+};
+
+}  // namespace
+
+extern "C" __global__ void __launch_bounds__(DEC_THREADS)
+zra_dec_chain_kernel(ZraDecodeArgs a) {
+  const int lane = threadIdx.x;
+  const u32 nPend = a.counters[ZRA_DC_NPENDING];
+  // per-lane job state
+  bool have = false, drained = false;
+  ZraDecFrame* F = nullptr;
+  const u32* T = nullptr;
+  u64* sq = nullptr;
+  Zds br; br.c = 0; br.bc = 0; br.ptr = 0; br.base = nullptr;
+  u32 sLL = 0, sOF = 0, sML = 0, rep0 = 1, rep1 = 4, rep2 = 8;
+  u32 i = 0, nbSeq = 0, outPos = 0, litPos = 0, outCap = 0, regen = 0, produced0 = 0, limit = 0;
+  u32 longMode = 0, err = 0, jErr = 0xFFFFFFFFu, valid = 0, validOut = 0, validLit = 0, truncated = 0;
+
+  auto finish = [&]() {
+    // tail literals of the block (ZSTD_decompressSequences: "last literal segment")
+    if (!err && !truncated) {
+      if (regen - litPos > outCap - outPos) err = ZE_DSTSIZE_TOOSMALL;
+    }
+    F->chainErr = err; F->nSeqValid = valid; F->seqOut = validOut; F->seqLit = validLit; F->truncated = truncated;
+    F->repOut[0] = rep0; F->repOut[1] = rep1; F->repOut[2] = rep2;
+    have = false;
+  };
+
+  for (;;) {
+    // ---- lanes without a job pull the next pending frame (one atomic per wave)
+    const u64 want = __ballot(!have && !drained);
+    if (want) {
+      u32 base = 0;
+      const u32 cnt = (u32)__builtin_popcountll(want);
+      if (lane == (int)__builtin_ctzll(want)) base = atomicAdd(&a.counters[ZRA_DC_QCHAIN], cnt);
+      base = bcast_u32(base, (u32)__builtin_ctzll(want));
+      if (!have && !drained) {
+        const u32 idx = base + (u32)__builtin_popcountll(want & ((1ull << lane) - 1ull));
+        if (idx >= nPend) drained = true;
+        else {
+          const u32 j = a.pending[idx];
+          const size_t gj = j;
+          F = &a.frames[j];
+          T = a.tables + (size_t)j * ZRA_DEC_TBL_WORDS;
+          const u8* const blk = a.body + a.frameOff[gj * a.offStride] + F->bpos;
+          nbSeq = F->nbSeq; regen = F->litRegen; produced0 = F->produced; longMode = F->longMode;
+          outCap = a.outCap[j] - produced0;
+          limit = a.limit ? a.limit[j] : 0xFFFFFFFFu;
+          sq = a.seqs + F->seqBase;
+          rep0 = F->rep[0]; rep1 = F->rep[1]; rep2 = F->rep[2];
+          i = 0; outPos = 0; litPos = 0; err = 0; jErr = 0xFFFFFFFFu; valid = 0; validOut = 0; validLit = 0; truncated = 0;
+          have = true;
+          if (nbSeq) {
+            if (!br.init(blk + F->seqPos, F->bsize - F->seqPos)) { err = ZE_CORRUPTION; finish(); }
+            else {
+              sLL = br.read(F->llLog); br.reload();
+              sOF = br.read(F->ofLog); br.reload();
+              sML = br.read(F->mlLog); br.reload();
+            }
+          }
         }
-        if (!err && pos != srcSize) err = ZE_SRCSIZE_WRONG;          // seek table and frame walk disagree
       }
-      a.status[f] = err;
-      a.produced[f] = S.produced;
+    }
+    if (!__ballot(have)) break;
+
+    // ---- one step of the lane's frame (no wave-level operation below: lanes are at different points of different frames)
+    if (have) {
+      bool go = true;
+      if (i >= nbSeq) {
+        // all sequences decoded. Short loop: the stream must be consumed (over-read passes); long loop: no such check.
+        if (!err && nbSeq && !longMode && br.reload() < Zds::COMPLETED) err = ZE_CORRUPTION;
+        finish(); go = false;
+      } else if (longMode) {
+        // ZSTD_decompressSequencesLong: the loop condition looks at the stream BEFORE each decode and stops on an over-read; a
+        // sequence is executed four iterations after it was decoded, so an earlier execution error only counts if the loop got there
+        if (br.reload() > Zds::COMPLETED) {
+          if (jErr == 0xFFFFFFFFu || i <= jErr + 4) err = ZE_CORRUPTION;
+          finish(); go = false;
+        } else if (jErr != 0xFFFFFFFFu && i > jErr + 4) { finish(); go = false; }
+      }
+      if (go) {
+        // ZSTD_decodeSequence (64-bit path): offset bits, match-length bits, [reload], literal-length bits, then the three state
+        // updates — always, the last sequence included
+        const uint2 eL = *(const uint2*)(T + ZRA_DEC_TBL_LL + 2 * sLL), eM = *(const uint2*)(T + ZRA_DEC_TBL_ML + 2 * sML);
+        const u32 eO = T[ZRA_DEC_TBL_OF + sOF];
+        const u32 ofBits = (eO >> 8) & 0xFF, mlBits = (eM.x >> 8) & 0xFF, llBits = (eL.x >> 8) & 0xFF;
+        u32 ll = eL.y, ml = eM.y, off;
+        if (ofBits > 1) {
+          off = ((1u << ofBits) - 3u) + br.read_fast(ofBits);
+          rep2 = rep1; rep1 = rep0; rep0 = off;
+        } else {
+          const u32 ll0 = (ll == 0);                       // the BASE value (code 0)
+          if (ofBits == 0) {
+            if (!ll0) off = rep0;
+            else { off = rep1; rep1 = rep0; rep0 = off; }
+          } else {
+            const u32 idx = 1 + ll0 + br.read_fast(1);
+            u32 t = idx == 3 ? rep0 - 1 : idx == 1 ? rep1 : rep2;
+            t += !t;                                        // "0 is not valid; input is corrupted; force offset to 1"
+            if (idx != 1) rep2 = rep1;
+            rep1 = rep0; rep0 = off = t;
+          }
+        }
+        if (mlBits) ml += br.read_fast(mlBits);
+        if (llBits + mlBits + ofBits >= 57 - (9 + 9 + 8)) br.reload();
+        if (llBits) ll += br.read_fast(llBits);
+        sLL = (eL.x >> 20) + br.read((eL.x >> 16) & 0xF);
+        sML = (eM.x >> 20) + br.read((eM.x >> 16) & 0xF);
+        sOF = (eO >> 20) + br.read((eO >> 16) & 0xF);
+        if (!longMode) br.reload();
+        // ZSTD_execSequence / ZSTD_execSequenceEnd, checks only (the execute kernel moves the bytes): destination room, literal
+        // buffer, then — the literals now count as consumed — the offset
+        if (jErr == 0xFFFFFFFFu) {
+          u32 e = 0;
+          if (ll + ml > outCap - outPos) e = ZE_DSTSIZE_TOOSMALL;
+          else if (ll > regen - litPos) e = ZE_CORRUPTION;
+          else if (off > produced0 + outPos + ll) e = ZE_CORRUPTION;
+          if (e) { jErr = i; err = e; if (!longMode) finish(); }
+          else {
+            sq[i] = (u64)ll | ((u64)ml << 18) | ((u64)min(off, 0x0FFFFFFFu) << 36);
+            outPos += ll + ml; litPos += ll;
+            valid = i + 1; validOut = outPos; validLit = litPos;
+            if (produced0 + outPos >= limit) { truncated = 1; finish(); }     // random access: stop at the sequence that covers the last needed byte
+          }
+        }
+        i++;
+      }
+    }
+  }
+}
+
+// =================================================================================================
+// stage 3: execute
+extern "C" __global__ void __launch_bounds__(DEC_THREADS)
+zra_dec_exec_kernel(ZraDecodeArgs a) {
+  __shared__ u32 s_job;
+  const int lane = threadIdx.x;
+  const u32 nPend = a.counters[ZRA_DC_NPENDING];
+  for (;;) {
+    if (lane == 0) s_job = atomicAdd(&a.counters[ZRA_DC_QEXEC], 1u);
+    wsync();
+    const u32 qi = s_job;
+    wsync();
+    if (qi >= nPend) return;
+    const u32 j = a.pending[qi];
+    const size_t gj = j;
+    ZraDecFrame* const F = &a.frames[j];
+    const u64 so = a.frameOff[gj * a.offStride], se = a.frameOff[gj * a.offStride + 1];
+    const u8* const src = a.body + so;
+    const u32 srcSize = (u32)(se - so);
+    const u32 produced0 = F->produced;
+    u8* const out = a.out + a.outOff[j] + produced0;             // this block's output start
+    const u32 litKind = F->litKind, regen = F->litRegen;
+    const u8* const lit = litKind == 2 ? a.lits + F->litBase : src + F->litArg;
+    const u8 rleByte = (u8)F->litArg;
+    const u32 nSeq = F->nSeqValid, chainErr = F->chainErr, truncated = F->truncated;
+    const u64* const sq = a.seqs + F->seqBase;
+
+    u32 outBase = 0, litBase = 0;              // running positions (wave-uniform)
+    for (u32 first = 0; first < nSeq; first += BATCH) {
+      const u32 cnt = min((u32)BATCH, nSeq - first);
+      const bool act = (u32)lane < cnt;
+      const u64 q = act ? sq[first + lane] : (1ull << 36);
+      const u32 ll = (u32)q & 0x3FFFFu, ml = (u32)(q >> 18) & 0x3FFFFu, off = (u32)(q >> 36);
+      const u32 tot = ll + ml;
+      const u32 incT = wave_incl_scan(tot), incL = wave_incl_scan(ll);
+      const u32 oStart = outBase + incT - tot, lStart = litBase + incL - ll;
+      const u32 mdst = oStart + ll;
+      // -------- literals: every lane copies its sequence's run; long runs by the whole wave, coalesced
+      {
+        u8* op = out + oStart;
+        const bool longLit = ll > 32;
+        if (!longLit) {
+          if (litKind == 1) for (u32 b = 0; b < ll; b++) op[b] = rleByte;
+          else { const u8* lp = lit + lStart; for (u32 b = 0; b < ll; b++) op[b] = lp[b]; }
+        }
+        u64 lm = __ballot(longLit);
+        while (lm) {
+          const u32 k = (u32)__builtin_ctzll(lm); lm &= lm - 1;
+          const u32 jl = bcast_u32(ll, k), jo = bcast_u32(oStart, k), js = bcast_u32(lStart, k);
+          if (litKind == 1) fill_bytes(out + jo, rleByte, jl, lane, DEC_THREADS);
+          else copy_bytes(out + jo, lit + js, jl, lane, DEC_THREADS);
+        }
+      }
+      wsync();
+      // -------- match copies in dependency rounds: a lane is ready once its source ends before the first unfinished destination
+      {
+        const u32 msrc = mdst - off;
+        const u32 msrcEnd = min(msrc + ml, mdst);
+        u64 pending = __ballot(act);
+        while (pending) {
+          const u32 fnd = (u32)__builtin_ctzll(pending);
+          const u32 frontier = bcast_u32(mdst, fnd);
+          const bool mine = (pending >> lane) & 1;
+          const bool ready = mine && (msrcEnd <= frontier || (u32)lane == fnd);
+          const bool longM = ready && ml > 64;
+          if (ready && !longM) {
+            u8* dp = out + mdst; const u8* sp = dp - off;
+            if (off >= ml) {                           // no overlap: 8-byte moves + byte tail
+              u32 k = 0;
+              for (; k + 8 <= ml; k += 8) st64(dp + k, ld64(sp + k));
+              for (; k < ml; k++) dp[k] = sp[k];
+            } else {                                   // overlapping match = period `off`: read only bytes in front of the destination
+              u32 p = 0;
+              for (u32 k = 0; k < ml; k++) { dp[k] = sp[p]; p = p + 1 == off ? 0 : p + 1; }
+            }
+          }
+          u64 lmk = __ballot(longM);
+          while (lmk) {                            // long matches: the whole wave copies (period-safe modular source)
+            const u32 k2 = (u32)__builtin_ctzll(lmk); lmk &= lmk - 1;
+            const u32 jml = bcast_u32(ml, k2), jd = bcast_u32(mdst, k2), jof = bcast_u32(off, k2);
+            u8* dp = out + jd; const u8* sp = dp - jof;
+            if (jof >= jml) { for (u32 k = lane; k < jml; k += WAVE) dp[k] = sp[k]; }
+            else { for (u32 k = lane; k < jml; k += WAVE) dp[k] = sp[k % jof]; }
+          }
+          pending &= ~__ballot(ready);
+          wsync();
+        }
+      }
+      outBase += bcast_u32(incT, 63); litBase += bcast_u32(incL, 63);
+    }
+    // ---- block tail: remaining literals (the chain kernel checked the room)
+    u32 blockOut = outBase;
+    if (!chainErr && !truncated) {
+      const u32 tail = regen - litBase;
+      if (litKind == 1) fill_bytes(out + outBase, rleByte, tail, lane, DEC_THREADS);
+      else copy_bytes(out + outBase, lit + litBase, tail, lane, DEC_THREADS);
+      blockOut += tail;
+    }
+    wsync();
+    // ---- commit: a compressed block confirms its repeat offsets; then the frame ends, or takes another round
+    const u32 produced = produced0 + blockOut, endPos = F->bpos + F->bsize;
+    if (chainErr || truncated || F->blast) {
+      frame_finish(a, j, src, srcSize, chainErr, produced, endPos, truncated != 0, F->fcsHave, F->fcsLo, F->fcsHi, F->hasChecksum, lane);
+    } else if (lane == 0) {
+      F->produced = produced; F->blkPos = endPos;
+      F->rep[0] = F->repOut[0]; F->rep[1] = F->repOut[1]; F->rep[2] = F->repOut[2];
+      a.nextActive[atomicAdd(&a.counters[ZRA_DC_NNEXT], 1u)] = j;
     }
     wsync();
   }

@@ -531,7 +531,7 @@ Status Engine::decode_host(const uint8_t* hSpan, size_t spanSize, const std::vec
   HIPCHK(hipMemcpyAsync(expect_.p, ex.data(), (size_t)nFrames * 4, hipMemcpyHostToDevice, stream_));
   HIPCHK(hipStreamSynchronize(stream_));
   Status s = decode_jobs(hostIn_.as<uint8_t>(), spanSize, frameOff_.as<uint64_t>(), hostOut_.as<uint8_t>(), outOff_.as<uint64_t>(),
-                         expect_.as<uint32_t>(), nFrames, 2, wholeArchive ? total : 0);
+                         expect_.as<uint32_t>(), nFrames, frameSize, 2, wholeArchive ? total : 0);
   if (s.zra) return s;
   if (skip + size > (uint64_t)nFrames * frameSize) return {kOutOfBounds, 0};
   // frames that regenerated less than their slots (corrupted archive, sequential tail): only what was written reaches the caller

@@ -50,9 +50,14 @@ class Engine {
 
   // ---- decode
   // Decode nFrames frames described by device job arrays. Synchronises and returns the first failing frame's code.
+  // maxFrameBytes: upper bound of what one frame regenerates (sizes the per-pass scratch); ra: optional random-access extras
+  // (limit / pieceBase / pieces / raOut of ZraDecodeArgs, indexed like the job arrays)
   Status decode_jobs(const uint8_t* dBody, uint64_t bodySize, const uint64_t* dFrameOff, uint8_t* dOut,
-                     const uint64_t* dOutOff, const uint32_t* dExpect, uint32_t nFrames, uint32_t offStride = 1, uint64_t seqTotal = 0);
-  Status decode_launch(const struct ZraDecodeArgs& a, const uint32_t* dExpect, unsigned long long* res);
+                     const uint64_t* dOutOff, const uint32_t* dExpect, uint32_t nFrames, uint32_t maxFrameBytes, uint32_t offStride = 1,
+                     uint64_t seqTotal = 0, const struct ZraDecodeArgs* ra = nullptr);
+  // one pass: jobs [0, a.nFrames) of the arrays in `a` through the parse / chain / execute rounds + frame-end checks;
+  // *res = min over failing jobs of ((jobBase + job) << 8 | code), untouched when none fails
+  Status decode_launch(const struct ZraDecodeArgs& a, const uint32_t* dExpect, uint32_t maxFrameBytes, uint32_t jobBase);
   // Whole archive resident on the device (header + body), output on the device.
   Status decompress_device(const uint8_t* dArc, size_t arcSize, uint8_t* dOut, size_t outCap);
   // Batched random access, archive + output on the device, query arrays on the host.
@@ -99,7 +104,8 @@ class Engine {
   double kstats_[6] = {0, 0, 0, 0, 0, 0};
   hipEvent_t evR_[17] = {nullptr};   // per-round events of one encode batch: e[2r] before mf, e[2r+1] between, e[2r+2] after entropy
   // decode scratch
-  DevBuf litScratch_, queue_, status_, produced_, frameMeta_, frameOff_, outOff_, expect_, result_, temp_, qmeta_;
+  DevBuf decFrames_, decTables_, decLists_, decCounters_, decLits_, decSeqs_;
+  DevBuf status_, produced_, frameMeta_, frameOff_, outOff_, expect_, result_, temp_, qmeta_;
   // encode scratch (see zra_encode.hip)
   struct EncCtx { DevBuf tables, seqs, lits, slots, misc, ck, sizes; };
   EncCtx encCtx_[2];

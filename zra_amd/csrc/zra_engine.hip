@@ -9,7 +9,9 @@
 #include <cstdlib>
 #include <cstring>
 
-extern "C" __global__ void zra_decode_frames_kernel(ZraDecodeArgs a);
+extern "C" __global__ void zra_dec_parse_kernel(ZraDecodeArgs a);
+extern "C" __global__ void zra_dec_chain_kernel(ZraDecodeArgs a);
+extern "C" __global__ void zra_dec_exec_kernel(ZraDecodeArgs a);
 
 using namespace zra_dev;
 
@@ -73,8 +75,8 @@ __global__ void zra_xxh64_verify_kernel(const u8* out, const u64* outOff, const 
                                         u32* status, u32 nFrames) {
   const u32 gid = blockIdx.x * blockDim.x + threadIdx.x;
   const u32 f = gid >> 2; const int j = gid & 3;
-  const bool live = f < nFrames && status[f] == 0;
-  const bool active = live && frameMeta[2 * (size_t)f];
+  const bool live = f < nFrames && status[f] == 0 && frameMeta[2 * (size_t)f] != 2;   // 2: stopped early (random access), nothing to check
+  const bool active = live && frameMeta[2 * (size_t)f] == 1;
   const u8* p = active ? out + outOff[f] : out;
   const u32 n = active ? produced[f] : 0;
   const u64 h = zra_xxh64_quad(p, n, j);
@@ -85,9 +87,9 @@ __global__ void zra_xxh64_verify_kernel(const u8* out, const u64* outOff, const 
 }
 
 // result[0] = min over failing frames of (frame << 8 | code); ~0 when all succeeded
-__global__ void zra_first_error_kernel(const u32* status, u32 nFrames, unsigned long long* result) {
+__global__ void zra_first_error_kernel(const u32* status, u32 nFrames, u32 jobBase, unsigned long long* result) {
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < nFrames && status[i]) atomicMin(result, ((unsigned long long)i << 8) | (status[i] & 0xFF));
+  if (i < nFrames && status[i]) atomicMin(result, ((unsigned long long)(jobBase + i) << 8) | (status[i] & 0xFF));
 }
 
 // random-access gather: query q copies size[q] bytes temp+src[q] -> out+dst[q]; one workgroup per query slice
@@ -155,7 +157,7 @@ Status Engine::create(Engine** out, int device) {
 Engine::~Engine() {
   (void)hipSetDevice(device_);
   if (stream_) (void)hipStreamSynchronize(stream_);
-  for (DevBuf* b : {&litScratch_, &queue_, &status_, &produced_, &frameMeta_, &frameOff_, &outOff_, &expect_, &result_, &temp_, &qmeta_,
+  for (DevBuf* b : {&decFrames_, &decTables_, &decLists_, &decCounters_, &decLits_, &decSeqs_, &status_, &produced_, &frameMeta_, &frameOff_, &outOff_, &expect_, &result_, &temp_, &qmeta_,
                     &encScan_, &hostIn_, &hostOut_, &seqScratch_})
     b->release();
   for (auto& x : encCtx_) for (DevBuf* b : {&x.tables, &x.seqs, &x.lits, &x.slots, &x.misc, &x.ck, &x.sizes}) b->release();
@@ -178,32 +180,58 @@ Status Engine::wait_stream(hipStream_t producer) {
   return ok();
 }
 
-// One launch of the decode kernel + frame-end checks over `nFrames` jobs; returns (first failing frame << 8 | code) or ~0.
-Status Engine::decode_launch(const ZraDecodeArgs& a0, const uint32_t* dExpect, unsigned long long* res) {
+// One pass of the decoder over the jobs of `a0`: rounds of parse -> chain -> execute (a round = one compressed block of every
+// unfinished frame) until no frame is left, then the content checksums and the first-error reduction.
+Status Engine::decode_launch(const ZraDecodeArgs& a0, const uint32_t* dExpect, uint32_t maxFrameBytes, uint32_t jobBase) {
   ZraDecodeArgs a = a0;
-  int perCU = 0;
-  HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, zra_decode_frames_kernel, 64, 0));
-  if (perCU < 1) perCU = 1;
-  { static const int cap = std::getenv("ZRA_DEC_WAVES") ? std::atoi(std::getenv("ZRA_DEC_WAVES")) : 0; if (cap > 0 && cap < perCU) perCU = cap; }   // bring-up: occupancy sweep
-  const uint32_t nFrames = a.nFrames;
-  uint32_t grid = (uint32_t)std::min<uint64_t>(nFrames, (uint64_t)numCUs_ * perCU);
-  if (!litScratch_.reserve((size_t)grid * ZRA_LIT_STRIDE) || !queue_.reserve(64) || !status_.reserve((size_t)nFrames * 4) ||
-      !produced_.reserve((size_t)nFrames * 4) || !frameMeta_.reserve((size_t)nFrames * 8) || !result_.reserve(64))
+  const uint32_t n = a.nFrames;
+  // scratch of a round: Huffman-decoded literals and decoded sequences of one block per frame, bump-allocated on the device
+  const uint64_t perFrame = std::min<uint64_t>((uint64_t)maxFrameBytes + 16, (128u << 10) + 16);
+  const uint64_t litCap = std::max<uint64_t>((uint64_t)n * perFrame, 1u << 20);
+  const uint64_t seqCap = std::max<uint64_t>(litCap / 8, 1u << 20);               // entries of 8 bytes
+  if (!decFrames_.reserve((size_t)n * sizeof(ZraDecFrame)) || !decTables_.reserve((size_t)n * ZRA_DEC_TBL_WORDS * 4) ||
+      !decLists_.reserve((size_t)n * 12 + 64) || !decCounters_.reserve(ZRA_DC_WORDS * 4) || !decLits_.reserve(litCap + 64) ||
+      !decSeqs_.reserve(seqCap * 8 + 64) || !status_.reserve((size_t)n * 4) || !produced_.reserve((size_t)n * 4) ||
+      !frameMeta_.reserve((size_t)n * 8) || !result_.reserve(64))
     return zerr(64 /* memory_allocation */);
-  HIPCHK(hipMemsetAsync(queue_.p, 0, 64, stream_));
-  HIPCHK(hipMemsetAsync(result_.p, 0xFF, 64, stream_));
-  a.queue = queue_.as<uint32_t>(); a.litScratch = litScratch_.as<uint8_t>();
-  { static const int skip = std::getenv("ZRA_DEC_SKIP") ? std::atoi(std::getenv("ZRA_DEC_SKIP")) : 0; a.debugSkip = (uint32_t)skip; }
+  uint32_t* listA = decLists_.as<uint32_t>(); uint32_t* listB = listA + n;
+  a.pending = listA + 2 * (size_t)n;
+  a.counters = decCounters_.as<uint32_t>();
+  a.frames = decFrames_.as<ZraDecFrame>(); a.tables = decTables_.as<uint32_t>();
+  a.lits = decLits_.as<uint8_t>(); a.litCap = litCap; a.seqs = decSeqs_.as<uint64_t>(); a.seqCap = seqCap;
   a.status = status_.as<uint32_t>(); a.produced = produced_.as<uint32_t>(); a.frameMeta = frameMeta_.as<uint32_t>();
+  static const int wavesCap = std::getenv("ZRA_DEC_WAVES") ? std::atoi(std::getenv("ZRA_DEC_WAVES")) : 0;   // bring-up: occupancy sweep
+  int perCUParse = 0, perCUExec = 0;
+  HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCUParse, zra_dec_parse_kernel, 64, 0));
+  HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCUExec, zra_dec_exec_kernel, 64, 0));
+  perCUParse = std::max(1, perCUParse); perCUExec = std::max(1, perCUExec);
+  if (wavesCap > 0) { perCUParse = std::min(perCUParse, wavesCap); perCUExec = std::min(perCUExec, wavesCap); }
   HIPCHK(hipEventRecord(ev0_, stream_));
-  hipLaunchKernelGGL(zra_decode_frames_kernel, dim3(grid), dim3(64), 0, stream_, a);
+  uint32_t nActive = n, round = 0;
+  const uint32_t* active = nullptr;
+  while (nActive) {
+    HIPCHK(hipMemsetAsync(a.counters, 0, ZRA_DC_WORDS * 4, stream_));
+    a.active = active; a.nActive = nActive; a.round = round;
+    a.nextActive = (active == listA) ? listB : listA;
+    const uint32_t gridParse = (uint32_t)std::min<uint64_t>(nActive, (uint64_t)numCUs_ * perCUParse);
+    const uint32_t gridChain = (uint32_t)std::min<uint64_t>((nActive + 63) / 64, (uint64_t)numCUs_ * 8);
+    const uint32_t gridExec = (uint32_t)std::min<uint64_t>(nActive, (uint64_t)numCUs_ * perCUExec);
+    hipLaunchKernelGGL(zra_dec_parse_kernel, dim3(gridParse), dim3(64), 0, stream_, a);
+    hipLaunchKernelGGL(zra_dec_chain_kernel, dim3(gridChain), dim3(64), 0, stream_, a);
+    hipLaunchKernelGGL(zra_dec_exec_kernel, dim3(gridExec), dim3(64), 0, stream_, a);
+    uint32_t next = 0;
+    HIPCHK(hipMemcpyAsync(&next, a.counters + ZRA_DC_NNEXT, 4, hipMemcpyDeviceToHost, stream_));
+    HIPCHK(hipStreamSynchronize(stream_));
+    HIPCHK(hipGetLastError());
+    active = a.nextActive; nActive = next; round++;
+    if (round > (1u << 20)) return zerr(1);          // cannot happen: every round finishes at least one block of some frame
+  }
   HIPCHK(hipEventRecord(ev1_, stream_));
   const uint32_t tb = 256;
-  hipLaunchKernelGGL(zra_xxh64_verify_kernel, dim3((nFrames * 4 + tb - 1) / tb), dim3(tb), 0, stream_, a.out, a.outOff, dExpect,
-                     produced_.as<uint32_t>(), frameMeta_.as<uint32_t>(), status_.as<uint32_t>(), nFrames);
-  hipLaunchKernelGGL(zra_first_error_kernel, dim3((nFrames + tb - 1) / tb), dim3(tb), 0, stream_, status_.as<uint32_t>(), nFrames,
+  hipLaunchKernelGGL(zra_xxh64_verify_kernel, dim3((n * 4 + tb - 1) / tb), dim3(tb), 0, stream_, a.out, a.outOff, dExpect,
+                     produced_.as<uint32_t>(), frameMeta_.as<uint32_t>(), status_.as<uint32_t>(), n);
+  hipLaunchKernelGGL(zra_first_error_kernel, dim3((n + tb - 1) / tb), dim3(tb), 0, stream_, status_.as<uint32_t>(), n, jobBase,
                      result_.as<unsigned long long>());
-  HIPCHK(hipMemcpyAsync(res, result_.p, 8, hipMemcpyDeviceToHost, stream_));
   HIPCHK(hipStreamSynchronize(stream_));
   HIPCHK(hipGetLastError());
   float ms = 0;
@@ -217,16 +245,31 @@ Status Engine::decode_launch(const ZraDecodeArgs& a0, const uint32_t* dExpect, u
 // foreign archive) everything from that frame on is re-decoded one frame at a time, packed back to back, exactly as the reference
 // would — first error in frame order, dstSize_tooSmall against the whole destination.
 Status Engine::decode_jobs(const uint8_t* dBody, uint64_t bodySize, const uint64_t* dFrameOff, uint8_t* dOut,
-                           const uint64_t* dOutOff, const uint32_t* dExpect, uint32_t nFrames, uint32_t offStride, uint64_t seqTotal) {
+                           const uint64_t* dOutOff, const uint32_t* dExpect, uint32_t nFrames, uint32_t maxFrameBytes, uint32_t offStride,
+                           uint64_t seqTotal, const ZraDecodeArgs* ra) {
   lastProducedTotal_ = ~0ull;
   if (nFrames == 0) return ok();
   HIPCHK(hipSetDevice(device_));
+  if (!result_.reserve(64)) return zerr(64);
+  HIPCHK(hipMemsetAsync(result_.p, 0xFF, 64, stream_));
   ZraDecodeArgs a{};
-  a.body = dBody; a.bodySize = bodySize; a.frameOff = dFrameOff; a.out = dOut; a.outOff = dOutOff; a.outCap = dExpect;
-  a.nFrames = nFrames; a.offStride = offStride;
+  if (ra) a = *ra;
+  a.body = dBody; a.bodySize = bodySize; a.out = dOut; a.offStride = offStride;
+  // passes: the per-round scratch (literals + sequences of one block per frame) stays within ~8 GiB
+  const uint64_t perFrame = std::min<uint64_t>((uint64_t)maxFrameBytes + 16, (128u << 10) + 16);
+  static const uint64_t passBytes = std::getenv("ZRA_DEC_PASS_MIB") ? (uint64_t)std::atoll(std::getenv("ZRA_DEC_PASS_MIB")) << 20 : 4ull << 30;
+  const uint32_t passFrames = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(nFrames, passBytes / perFrame));
+  for (uint32_t p0 = 0; p0 < nFrames; p0 += passFrames) {
+    ZraDecodeArgs b = a;
+    b.nFrames = std::min(passFrames, nFrames - p0);
+    b.frameOff = dFrameOff + (size_t)p0 * offStride; b.outOff = dOutOff + p0; b.outCap = dExpect + p0;
+    if (ra) { if (ra->limit) b.limit = ra->limit + p0; if (ra->pieceBase) b.pieceBase = ra->pieceBase + p0; }
+    Status st = decode_launch(b, dExpect + p0, maxFrameBytes, p0);
+    if (st.zra) return st;
+  }
   unsigned long long res = 0;
-  Status st = decode_launch(a, dExpect, &res);
-  if (st.zra) return st;
+  HIPCHK(hipMemcpyAsync(&res, result_.p, 8, hipMemcpyDeviceToHost, stream_));
+  HIPCHK(hipStreamSynchronize(stream_));
   if (res == ~0ull) return ok();
   const uint32_t code = (uint32_t)(res & 0xFF), first = (uint32_t)(res >> 8);
   const bool resize = code == 255 /* ZE_SIZE_MISMATCH */ || code == 70;
@@ -241,14 +284,17 @@ Status Engine::decode_jobs(const uint8_t* dBody, uint64_t bodySize, const uint64
     const uint32_t cap = (uint32_t)std::min<uint64_t>(seqTotal > cur ? seqTotal - cur : 0, 0xFFFFFF00u);
     HIPCHK(hipMemcpyAsync(dCur, &cur, 8, hipMemcpyHostToDevice, stream_));
     HIPCHK(hipMemcpyAsync(dCap, &cap, 4, hipMemcpyHostToDevice, stream_));
+    HIPCHK(hipMemsetAsync(result_.p, 0xFF, 64, stream_));
     ZraDecodeArgs b = a;
     b.frameOff = dFrameOff + (size_t)f * offStride; b.outOff = dCur; b.outCap = dCap; b.nFrames = 1;
-    st = decode_launch(b, nullptr, &res);
+    b.limit = nullptr; b.pieceBase = nullptr; b.pieces = nullptr;
+    Status st = decode_launch(b, nullptr, (uint32_t)std::min<uint64_t>(cap, 0x7FFFFFFFu), f);
     if (st.zra) return st;
-    if (res != ~0ull) return zerr((int)(res & 0xFF));
+    HIPCHK(hipMemcpyAsync(&res, result_.p, 8, hipMemcpyDeviceToHost, stream_));
     uint32_t got = 0;
     HIPCHK(hipMemcpyAsync(&got, produced_.p, 4, hipMemcpyDeviceToHost, stream_));
     HIPCHK(hipStreamSynchronize(stream_));
+    if (res != ~0ull) return zerr((int)(res & 0xFF));
     cur += got;
   }
   lastProducedTotal_ = cur;
@@ -275,7 +321,7 @@ Status Engine::decompress_device(const uint8_t* dArc, size_t arcSize, uint8_t* d
     return zerr(64);
   hipLaunchKernelGGL(zra_jobs_from_seektable_kernel, dim3((nFrames + 256) / 256), dim3(256), 0, stream_, dArc + h.seekTableOffset,
                      nFrames, h.frameSize, h.uncompressedSize, frameOff_.as<uint64_t>(), outOff_.as<uint64_t>(), expect_.as<uint32_t>());
-  return decode_jobs(dArc + h.size, arcSize - h.size, frameOff_.as<uint64_t>(), dOut, outOff_.as<uint64_t>(), expect_.as<uint32_t>(), nFrames, 1, outCap);
+  return decode_jobs(dArc + h.size, arcSize - h.size, frameOff_.as<uint64_t>(), dOut, outOff_.as<uint64_t>(), expect_.as<uint32_t>(), nFrames, h.frameSize, 1, outCap);
 }
 
 Status Engine::decompress_frames_host_list(const uint8_t* dBody, uint64_t bodySize, const std::vector<uint64_t>& hFrameOff,
@@ -295,7 +341,7 @@ Status Engine::decompress_frames_host_list(const uint8_t* dBody, uint64_t bodySi
   HIPCHK(hipMemcpyAsync(outOff_.p, oo.data(), (size_t)nFrames * 8, hipMemcpyHostToDevice, stream_));
   HIPCHK(hipMemcpyAsync(expect_.p, ex.data(), (size_t)nFrames * 4, hipMemcpyHostToDevice, stream_));
   HIPCHK(hipStreamSynchronize(stream_));   // host vectors go out of scope
-  return decode_jobs(dBody, bodySize, frameOff_.as<uint64_t>(), dOut, outOff_.as<uint64_t>(), expect_.as<uint32_t>(), nFrames);
+  return decode_jobs(dBody, bodySize, frameOff_.as<uint64_t>(), dOut, outOff_.as<uint64_t>(), expect_.as<uint32_t>(), nFrames, frameSize);
 }
 
 Status Engine::decompress_ra_batch(const uint8_t* dArc, size_t arcSize, uint8_t* dOut, const uint64_t* hOff, const uint64_t* hSize,
@@ -391,7 +437,7 @@ Status Engine::decompress_ra_batch(const uint8_t* dArc, size_t arcSize, uint8_t*
       HIPCHK(hipStreamSynchronize(stream_));
       // frames of a pass are not adjacent in the body: each job carries its own (start, end) pair -> offset stride 2
       Status s = decode_jobs(dArc + h.size, arcSize - h.size, frameOff_.as<uint64_t>(), temp_.as<uint8_t>(), outOff_.as<uint64_t>(),
-                             expect_.as<uint32_t>(), nj, 2);
+                             expect_.as<uint32_t>(), nj, (uint32_t)fs, 2);
       trace("pass decoded");
       if (s.zra) return s;
       const uint32_t nqPass = (uint32_t)(qmeta.size() / 3);

@@ -3,9 +3,41 @@
 #include <stdint.h>
 #include <stddef.h>
 
-#define ZRA_LIT_STRIDE ((size_t)(128u << 10) + 64)   // per-workgroup Huffman literal scratch (one block max)
+// ------------------------------------------------------------------------------------------------ decode
+// The decoder is three kernels per ROUND (one compressed block of every unfinished frame per round; raw / RLE blocks and the frame
+// ends are consumed by the first kernel on the way):
+//   zra_dec_parse_kernel  wave per frame   headers, Huffman literals -> literal scratch, FSE tables -> per-frame table scratch
+//   zra_dec_chain_kernel  LANE per frame   the serial FSE sequence chain of 64 frames in the 64 lanes of a wave, every check of
+//                                          the reference's sequence loop (its statuses, in its order) -> sequence scratch
+//   zra_dec_exec_kernel   wave per frame   pure data movement: literal + match copies of the validated sequences, frame end,
+//                                          random-access slices
+#define ZRA_DEC_TBL_LL 0u       // 512 cells x 8 B  {sym | extraBits<<8 | stateBits<<16 | nextBase<<20, baseValue}
+#define ZRA_DEC_TBL_ML 1024u    // 512 cells x 8 B
+#define ZRA_DEC_TBL_OF 2048u    // 256 cells x 4 B  (base value = 1 << code)
+#define ZRA_DEC_TBL_WORDS 2304u // u32 words of table scratch per frame
 
-// one launch of zra_decode_frames_kernel decodes nFrames independent zstd frames
+// per-frame decode state; lives in HBM scratch for the whole call (frames take one round per compressed block)
+struct ZraDecFrame {
+  uint32_t blkPos, produced, done;
+  uint32_t hufValid, hufMaxBits, hufNSym, hufX2;       // kept Huffman description (treeless blocks rebuild the table from it)
+  uint32_t llValid, mlValid, ofValid, llLog, mlLog, ofLog, ofShare;   // ofShare: ZSTD_getLongOffsetsShare of the current OF table
+  uint32_t rep[3];
+  uint32_t fcsLo, fcsHi, fcsHave, hasChecksum, bigWindow;
+  // the compressed block handed from the parse kernel to the chain and execute kernels of the same round
+  uint32_t bpos, bsize, blast;
+  uint32_t litKind, litRegen, litArg;                  // 0: raw bytes at frame position litArg; 1: RLE of byte litArg; 2: literal scratch at litBase
+  uint32_t nbSeq, seqPos, longMode;
+  uint64_t litBase, seqBase;
+  // results of the chain kernel
+  uint32_t chainErr, nSeqValid, seqOut, seqLit, truncated;
+  uint32_t repOut[3];
+  uint8_t weights[256];
+  uint32_t rankStart[16];
+};
+
+// one random-access slice: `len` bytes at `srcOff` inside decoded frame job `job` go to raOut + dstOff
+struct ZraRaPiece { uint64_t dstOff; uint32_t srcOff, len; };
+
 struct ZraDecodeArgs {
   const uint8_t* body;       // compressed bytes (all frames)
   uint64_t bodySize;         // readable bytes at body
@@ -14,15 +46,36 @@ struct ZraDecodeArgs {
   uint8_t* out;              // destination base
   const uint64_t* outOff;    // [nFrames] destination offset of each frame
   const uint32_t* outCap;    // [nFrames] destination capacity of each frame
-  const uint32_t* outExpect; // [nFrames] bytes the frame must regenerate
   uint32_t nFrames;
-  uint32_t* queue;           // frame queue head (zeroed before the launch)
-  uint8_t* litScratch;       // gridDim.x * ZRA_LIT_STRIDE bytes
+  // random access (nullptr otherwise): decode may stop once limit[f] bytes exist; finished frames copy their slices out
+  const uint32_t* limit;
+  const uint32_t* pieceBase; // [job+1] first slice of each job
+  const ZraRaPiece* pieces;
+  uint8_t* raOut;
+  // round machinery (device scratch)
+  const uint32_t* active;    // jobs of this round (nullptr in round 0: all of them)
+  uint32_t nActive;
+  uint32_t round;
+  uint32_t* counters;        // see ZRA_DC_* below
+  uint32_t* nextActive;      // jobs that need another round
+  uint32_t* pending;         // jobs with a compressed block waiting for the chain / execute kernels
+  ZraDecFrame* frames;       // [nFrames]
+  uint32_t* tables;          // [nFrames * ZRA_DEC_TBL_WORDS]
+  uint8_t* lits; uint64_t litCap;      // literal scratch (bump-allocated per round)
+  uint64_t* seqs; uint64_t seqCap;     // sequence scratch: litLength | matchLength<<18 | offset<<36
   uint32_t* status;          // [nFrames] zstd error code per frame (0 = ok)
   uint32_t* produced;        // [nFrames] bytes regenerated
-  uint32_t* frameMeta;       // [2*nFrames] {has checksum, stored checksum}
-  uint32_t debugSkip;        // bring-up timing knob (ZRA_DEC_SKIP): 1 skip match copies, 2 skip literal copies, 4 skip Huffman decode; 0 in production
+  uint32_t* frameMeta;       // [2*nFrames] {1 = has checksum / 2 = stopped early (no frame-end checks), stored checksum}
 };
+// counters[]: u32 words, zeroed before every round
+#define ZRA_DC_QPARSE 0
+#define ZRA_DC_QCHAIN 1
+#define ZRA_DC_QEXEC 2
+#define ZRA_DC_NPENDING 3
+#define ZRA_DC_NNEXT 4
+#define ZRA_DC_LITCUR 6      // u64 (words 6,7)
+#define ZRA_DC_SEQCUR 8      // u64 (words 8,9)
+#define ZRA_DC_WORDS 16
 
 // ------------------------------------------------------------------------------------------------ encode
 // effective zstd 1.4.9 compression parameters of one frame size class
