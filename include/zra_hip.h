@@ -49,7 +49,11 @@ ZRA_EXPORT ZraStatus ZraHipDecompressBuffer(ZraHipEngine* engine, const void* dI
 
 /** Batched DecompressRA: query i returns bytes [hOffsets[i], hOffsets[i]+hSizes[i]) of the original data at dOut + hOutOffsets[i].
  *  hOffsets/hSizes/hOutOffsets are HOST arrays of nQueries entries. Bounds rule per query is the reference's
- *  (offset+size >= uncompressedSize -> OutOfBoundsAccess, zra.cpp:260). Synchronous. */
+ *  (offset+size >= uncompressedSize -> OutOfBoundsAccess, zra.cpp:260). Synchronous.
+ *  The frames a batch touches are found and scheduled on the device from the archive's own seek table; every touched frame is
+ *  decoded once, and only as far as the last byte any query needs from it (the reference decodes whole frames, zra.cpp:279-295).
+ *  For a valid archive the bytes are identical. What differs is damage detection: bytes of a frame behind the last one needed, and
+ *  the frame's content checksum, are not looked at. ZRA_HIP_OPT_RA_WHOLE_FRAMES restores whole-frame decode + checksum. */
 ZRA_EXPORT ZraStatus ZraHipDecompressRABatch(ZraHipEngine* engine, const void* dIn, size_t inSize, void* dOut,
                                              const uint64_t* hOffsets, const uint64_t* hSizes, const uint64_t* hOutOffsets, size_t nQueries);
 
@@ -75,7 +79,8 @@ ZRA_EXPORT void ZraHipGetKernelStats(ZraHipEngine* engine, double* out6);
 #define ZRA_HIP_OPT_VERIFY_HEADER_CRC 1u     /* Header constructors check the CRC-32 the reference writes but never reads (zra.cpp:128-133) */
 #define ZRA_HIP_OPT_INCLUSIVE_RA_BOUND 2u    /* DecompressRA accepts offset+size == uncompressedSize (reference: '>=', zra.cpp:260) */
 #define ZRA_HIP_OPT_STORE_META_IN_MEMORY 4u  /* in-memory CompressBuffer stores `meta` like the streaming Compressor (reference: zra.cpp:202-205) */
-/** Process-wide; affects the zra.h / zra.hpp entry points. */
+#define ZRA_HIP_OPT_RA_WHOLE_FRAMES 8u      /* ZraHipDecompressRABatch decodes every touched frame in full and verifies its checksum */
+/** Process-wide; affects the zra.h / zra.hpp entry points (and, for the last flag, ZraHipDecompressRABatch). */
 ZRA_EXPORT void ZraHipSetOptions(uint32_t mask);
 ZRA_EXPORT uint32_t ZraHipGetOptions(void);
 

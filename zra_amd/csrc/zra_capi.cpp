@@ -158,7 +158,7 @@ int walk_frames(const zra::u8* body, size_t n, std::vector<uint64_t>& starts, st
 namespace {
 // Opt-in integrity options (default 0 = reference-compatible, quirks included). Set through ZraHipSetOptions.
 std::atomic<uint32_t> g_options{0};
-enum : uint32_t { kOptVerifyHeaderCrc = 1, kOptInclusiveRaBound = 2, kOptStoreMetaInMemory = 4 };
+enum : uint32_t { kOptVerifyHeaderCrc = 1, kOptInclusiveRaBound = 2, kOptStoreMetaInMemory = 4, kOptRaWholeFrames = 8 };
 }  // namespace
 
 namespace zra {
@@ -561,6 +561,7 @@ ZraStatus ZraHipDecompressBuffer(ZraHipEngine* engine, const void* dIn, size_t i
 }
 ZraStatus ZraHipDecompressRABatch(ZraHipEngine* engine, const void* dIn, size_t inSize, void* dOut, const uint64_t* hOffsets, const uint64_t* hSizes,
                                   const uint64_t* hOutOffsets, size_t nQueries) {
+  engine->e->set_ra_verify_whole_frames((g_options.load() & kOptRaWholeFrames) != 0);
   return mk(engine->e->decompress_ra_batch((const uint8_t*)dIn, inSize, (uint8_t*)dOut, hOffsets, hSizes, hOutOffsets, nQueries));
 }
 ZraStatus ZraHipCompressFrames(ZraHipEngine* engine, const void* dIn, size_t inSize, void* dBody, uint64_t* dSizes, size_t* bodySize, int8_t level,

@@ -391,8 +391,9 @@ __device__ bool huf_stream_x2(const ParseShared& S, const u8* base, u32 n, const
 // ---------------------------------------------------------------------------------------------
 // frame end (shared by the parse and execute kernels): frame-level checks in the order of ZSTD_decompressFrame, the per-frame
 // result words, and — random access — the query slices of this frame
+// (lane / nthreads: rank and size of the calling group)
 __device__ void frame_finish(const ZraDecodeArgs& a, u32 j, const u8* src, u32 srcSize, u32 err, u32 produced, u32 endPos, bool truncated,
-                             u32 fcsHave, u32 fcsLo, u32 fcsHi, u32 hasChecksum, int lane) {
+                             u32 fcsHave, u32 fcsLo, u32 fcsHi, u32 hasChecksum, int lane, int nthreads = DEC_THREADS) {
   if (lane == 0) {
     u32 ck = 0;
     if (!err && !truncated) {
@@ -410,13 +411,21 @@ __device__ void frame_finish(const ZraDecodeArgs& a, u32 j, const u8* src, u32 s
     a.produced[j] = produced;
     a.frames[j].done = 1;
   }
-  err = bcast_u32(err, 0);
-  if (!err && a.pieces) {
-    const u8* const from = a.out + a.outOff[j];
-    const u32 p0 = a.pieceBase[j], p1 = a.pieceBase[j + 1];
-    for (u32 p = p0; p < p1; p++) {
-      const ZraRaPiece q = a.pieces[p];
-      if ((u64)q.srcOff + q.len <= produced) copy_bytes(a.raOut + q.dstOff, from + q.srcOff, q.len, lane, DEC_THREADS);
+  if (a.pieces) {
+    // every thread of the group recomputes `err` (lane 0 only looked at frame-end conditions that cannot hold for a stopped-early frame)
+    if (!err && !truncated) {
+      u32 pos = endPos;
+      if (fcsHave && (fcsHi != 0 || fcsLo != produced)) err = ZE_CORRUPTION;
+      if (!err && hasChecksum) { if (srcSize - pos < 4) err = ZE_CHECKSUM_WRONG; else pos += 4; }
+      if (!err && pos != srcSize) err = ZE_SRCSIZE_WRONG;
+    }
+    if (!err) {
+      const u32 p0 = a.pieceBase[j], p1 = a.pieceBase[j + 1];
+      for (u32 p = p0; p < p1; p++) {
+        const ZraRaPiece q = a.pieces[p];
+        if ((u64)q.srcOff + q.len > produced) continue;
+        copy_bytes(a.raOut + q.dstOff, a.out + a.outOff[j] + q.srcOff, q.len, lane, nthreads);
+      }
     }
   }
 }

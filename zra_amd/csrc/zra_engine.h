@@ -92,6 +92,9 @@ class Engine {
   Status decode_host(const uint8_t* hSpan, size_t spanSize, const std::vector<uint64_t>& starts, const std::vector<uint64_t>& ends,
                      uint32_t frameSize, uint64_t total, uint8_t* hOut, size_t skip, size_t size, bool wholeArchive = false);
 
+  // batched random access: false (default) = a frame is decoded up to the last byte a query needs, so damage behind that byte
+  // and the frame's content checksum go unnoticed; true = whole frames + checksums, the reference's error behaviour
+  void set_ra_verify_whole_frames(bool on) { raVerifyWholeFrames_ = on; }
   int device() const { return device_; }
   int num_cus() const { return numCUs_; }
 
@@ -105,6 +108,8 @@ class Engine {
   hipEvent_t evR_[17] = {nullptr};   // per-round events of one encode batch: e[2r] before mf, e[2r+1] between, e[2r+2] after entropy
   // decode scratch
   DevBuf decFrames_, decTables_, decLists_, decCounters_, decLits_, decSeqs_;
+  DevBuf raPlan_, raLimit_, raPieceBase_, raPieces_;
+  bool raVerifyWholeFrames_ = false;     // batched random access decodes every touched frame in full and checks its checksum
   DevBuf status_, produced_, frameMeta_, frameOff_, outOff_, expect_, result_, temp_, qmeta_;
   // encode scratch (see zra_encode.hip)
   struct EncCtx { DevBuf tables, seqs, lits, slots, misc, ck, sizes; };

@@ -92,15 +92,80 @@ __global__ void zra_first_error_kernel(const u32* status, u32 nFrames, u32 jobBa
   if (i < nFrames && status[i]) atomicMin(result, ((unsigned long long)(jobBase + i) << 8) | (status[i] & 0xFF));
 }
 
-// random-access gather: query q copies size[q] bytes temp+src[q] -> out+dst[q]; one workgroup per query slice
-__global__ void zra_gather_kernel(const u8* temp, u8* out, const u64* qmeta, u32 nq) {
-  const u32 q = blockIdx.x;
-  if (q >= nq) return;
-  const u64 src = qmeta[3 * (size_t)q], dst = qmeta[3 * (size_t)q + 1], n = qmeta[3 * (size_t)q + 2];
-  const u8* s = temp + src; u8* d = out + dst;
-  const u64 n8 = n >> 3;
-  for (u64 i = threadIdx.x; i < n8; i += blockDim.x) st64(d + 8 * i, ld64(s + 8 * i));
-  for (u64 i = (n8 << 3) + threadIdx.x; i < n; i += blockDim.x) d[i] = s[i];
+// ---- batched random access: the jobs of a batch are built on the device from the query arrays and the archive's own seek table
+// (zra.cpp:265-269 per query: first frame offset / frameSize, frames touched, head skip, tail length)
+struct RaPlan {            // device scratch of one batch
+  u32* cnt;                // [nFrames] slices that touch the frame
+  u32* need;               // [nFrames] bytes of the frame the batch needs (max over its slices of the slice end)
+  u32* slot;               // [nFrames] dense number of the frame among the touched ones
+  u32* cursor;             // [nFrames] fill cursor of the frame's slice list
+  u32* totals;             // {touched frames, slices}
+};
+// pass 1: every query marks the frames it touches
+__global__ void zra_ra_count_kernel(const u64* q, u32 nq, u64 fs, RaPlan P) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nq) return;
+  const u64 off = q[3 * (size_t)i], size = q[3 * (size_t)i + 1];
+  if (!size) return;
+  const u64 f0 = off / fs, f1 = (off + size - 1) / fs;
+  for (u64 f = f0; f <= f1; f++) {
+    atomicAdd(&P.cnt[f], 1u);
+    const u32 end = f == f1 ? (u32)((off + size - 1) % fs) + 1 : (u32)fs;
+    atomicMax(&P.need[f], end);
+  }
+}
+// pass 2 (one workgroup): exclusive scans over the frames -> dense slots + slice-list bases, and the decode job of every touched
+// frame: compressed span from the 5-byte seek-table entries, destination slot inside the pass-sized scratch window, bytes to produce
+__global__ void __launch_bounds__(1024) zra_ra_plan_kernel(RaPlan P, u32 nFrames, const u8* table, u64 fs, u64 total, u32 passSlots, u32 fullFrames,
+                                                           u64* frameOff, u64* outOff, u32* outCap, u32* limit, u32* pieceBase) {
+  __shared__ u32 sT[1024], sP[1024];
+  const u32 tid = threadIdx.x;
+  const u32 per = (nFrames + 1023) / 1024;
+  const u32 b0 = tid * per, b1 = min(nFrames, b0 + per);
+  u32 t = 0, p = 0;
+  for (u32 f = b0; f < b1; f++) { const u32 c = P.cnt[f]; t += c != 0; p += c; }
+  sT[tid] = t; sP[tid] = p;
+  __syncthreads();
+  for (u32 d = 1; d < 1024; d <<= 1) {                     // Hillis-Steele inclusive scan of the 1024 partials
+    const u32 xt = tid >= d ? sT[tid - d] : 0, xp = tid >= d ? sP[tid - d] : 0;
+    __syncthreads();
+    sT[tid] += xt; sP[tid] += xp;
+    __syncthreads();
+  }
+  u32 st = sT[tid] - t, sp = sP[tid] - p;                  // exclusive
+  for (u32 f = b0; f < b1; f++) {
+    const u32 c = P.cnt[f];
+    if (!c) continue;
+    P.slot[f] = st;
+    const u8* e = table + (size_t)f * 5;
+    frameOff[2 * (size_t)st] = (u64)ld32(e) | ((u64)e[4] << 32);
+    frameOff[2 * (size_t)st + 1] = (u64)ld32(e + 5) | ((u64)e[9] << 32);
+    const u64 o = (u64)f * fs;
+    const u32 expect = o >= total ? 0u : (u32)(total - o < fs ? total - o : fs);
+    outOff[st] = (u64)(st % passSlots) * fs;
+    outCap[st] = expect;
+    limit[st] = fullFrames ? expect : min(P.need[f], expect);
+    pieceBase[st] = sp;
+    st++; sp += c;
+  }
+  if (tid == 1023) { P.totals[0] = sT[1023]; P.totals[1] = sP[1023]; pieceBase[sT[1023]] = sP[1023]; }
+}
+// pass 3: every query writes its slices into the lists of the frames it touches
+__global__ void zra_ra_fill_kernel(const u64* q, u32 nq, u64 fs, RaPlan P, const u32* pieceBase, ZraRaPiece* pieces) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nq) return;
+  const u64 off = q[3 * (size_t)i], size = q[3 * (size_t)i + 1], dst = q[3 * (size_t)i + 2];
+  if (!size) return;
+  const u64 f0 = off / fs, f1 = (off + size - 1) / fs;
+  u64 done = 0;
+  for (u64 f = f0; f <= f1; f++) {
+    const u32 srcOff = f == f0 ? (u32)(off % fs) : 0u;
+    const u64 len = min<u64>(fs - srcOff, size - done);
+    const u32 at = pieceBase[P.slot[f]] + atomicAdd(&P.cursor[f], 1u);
+    ZraRaPiece pc; pc.dstOff = dst + done; pc.srcOff = srcOff; pc.len = (u32)len;
+    pieces[at] = pc;
+    done += len;
+  }
 }
 
 }  // namespace
@@ -157,7 +222,7 @@ Status Engine::create(Engine** out, int device) {
 Engine::~Engine() {
   (void)hipSetDevice(device_);
   if (stream_) (void)hipStreamSynchronize(stream_);
-  for (DevBuf* b : {&decFrames_, &decTables_, &decLists_, &decCounters_, &decLits_, &decSeqs_, &status_, &produced_, &frameMeta_, &frameOff_, &outOff_, &expect_, &result_, &temp_, &qmeta_,
+  for (DevBuf* b : {&raPlan_, &raLimit_, &raPieceBase_, &raPieces_, &decFrames_, &decTables_, &decLists_, &decCounters_, &decLits_, &decSeqs_, &status_, &produced_, &frameMeta_, &frameOff_, &outOff_, &expect_, &result_, &temp_, &qmeta_,
                     &encScan_, &hostIn_, &hostOut_, &seqScratch_})
     b->release();
   for (auto& x : encCtx_) for (DevBuf* b : {&x.tables, &x.seqs, &x.lits, &x.slots, &x.misc, &x.ck, &x.sizes}) b->release();
@@ -187,8 +252,10 @@ Status Engine::decode_launch(const ZraDecodeArgs& a0, const uint32_t* dExpect, u
   const uint32_t n = a.nFrames;
   // scratch of a round: Huffman-decoded literals and decoded sequences of one block per frame, bump-allocated on the device
   const uint64_t perFrame = std::min<uint64_t>((uint64_t)maxFrameBytes + 16, (128u << 10) + 16);
-  const uint64_t litCap = std::max<uint64_t>((uint64_t)n * perFrame, 1u << 20);
-  const uint64_t seqCap = std::max<uint64_t>(litCap / 8, 1u << 20);               // entries of 8 bytes
+  // sized for what data needs, not for the worst case (a frame whose allocation does not fit simply takes the next round):
+  // Huffman-coded literals rarely exceed half of the output, sequences (8 bytes each) three quarters of it
+  const uint64_t litCap = std::max<uint64_t>((uint64_t)n * perFrame / 2, 1u << 20);
+  const uint64_t seqCap = std::max<uint64_t>((uint64_t)n * perFrame * 3 / 32, 1u << 20);               // entries of 8 bytes
   if (!decFrames_.reserve((size_t)n * sizeof(ZraDecFrame)) || !decTables_.reserve((size_t)n * ZRA_DEC_TBL_WORDS * 4) ||
       !decLists_.reserve((size_t)n * 12 + 64) || !decCounters_.reserve(ZRA_DC_WORDS * 4) || !decLits_.reserve(litCap + 64) ||
       !decSeqs_.reserve(seqCap * 8 + 64) || !status_.reserve((size_t)n * 4) || !produced_.reserve((size_t)n * 4) ||
@@ -255,9 +322,10 @@ Status Engine::decode_jobs(const uint8_t* dBody, uint64_t bodySize, const uint64
   ZraDecodeArgs a{};
   if (ra) a = *ra;
   a.body = dBody; a.bodySize = bodySize; a.out = dOut; a.offStride = offStride;
-  // passes: the per-round scratch (literals + sequences of one block per frame) stays within ~8 GiB
+  // passes: the chain kernel runs one LANE per frame, so a pass wants hundreds of thousands of frames; its per-round scratch
+  // (literals + sequences of one block per frame, ~1.25 bytes per output byte) is what bounds it — 16 GiB of output per pass
   const uint64_t perFrame = std::min<uint64_t>((uint64_t)maxFrameBytes + 16, (128u << 10) + 16);
-  static const uint64_t passBytes = std::getenv("ZRA_DEC_PASS_MIB") ? (uint64_t)std::atoll(std::getenv("ZRA_DEC_PASS_MIB")) << 20 : 4ull << 30;
+  static const uint64_t passBytes = std::getenv("ZRA_DEC_PASS_MIB") ? (uint64_t)std::atoll(std::getenv("ZRA_DEC_PASS_MIB")) << 20 : 16ull << 30;
   const uint32_t passFrames = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(nFrames, passBytes / perFrame));
   for (uint32_t p0 = 0; p0 < nFrames; p0 += passFrames) {
     ZraDecodeArgs b = a;
@@ -348,9 +416,6 @@ Status Engine::decompress_ra_batch(const uint8_t* dArc, size_t arcSize, uint8_t*
                                    const uint64_t* hOutOff, size_t nq) {
   HIPCHK(hipSetDevice(device_));
   kstats_[4] = kstats_[5] = 0;
-  static const bool traceRa = std::getenv("ZRA_RA_TRACE") != nullptr;   // bring-up: host-side time of the batch set-up
-  const auto tr0 = std::chrono::steady_clock::now();
-  auto trace = [&](const char* what) { if (traceRa) std::fprintf(stderr, "ra %-18s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tr0).count()); };
   if (arcSize <= zra_fmt::kFixedSize) return {kOutOfBounds, 0};
   uint8_t fixed[zra_fmt::kFixedSize];
   HIPCHK(hipMemcpyAsync(fixed, dArc, sizeof(fixed), hipMemcpyDeviceToHost, stream_));
@@ -359,94 +424,57 @@ Status Engine::decompress_ra_batch(const uint8_t* dArc, size_t arcSize, uint8_t*
   if (int e = parse_fixed_header(fixed, &h)) return {e, 0};
   if (arcSize < h.size) return {kOutOfBounds, 0};
   const uint32_t nFrames = h.frames();
-  const uint64_t fs = h.frameSize;
+  const uint64_t fs = h.frameSize, U = h.uncompressedSize;
+  // the reference indexes the table with offset / frameSize without looking at tableSize (zra.cpp:265-268); a header whose fields
+  // disagree (size beyond what the table covers, table outside the header) would send it out of bounds — here it is HeaderInvalid
+  if ((uint64_t)h.seekTableOffset + h.seekTableSize > h.size) return {kHeaderInvalid, 0};
+  if (fs && U && (U + fs - 1) / fs != nFrames) return {kHeaderInvalid, 0};
   for (size_t q = 0; q < nq; q++)
-    if (hOff[q] + hSize[q] >= h.uncompressedSize) return {kOutOfBounds, 0};   // ">=" quirk, zra.cpp:260
-  if (nq == 0 || fs == 0) return ok();
-  // seek table to the host once (5 B/frame) so jobs can be built without device round trips
-  std::vector<uint8_t> table((size_t)h.seekTableSize);
-  HIPCHK(hipMemcpyAsync(table.data(), dArc + h.seekTableOffset, table.size(), hipMemcpyDeviceToHost, stream_));
+    if (hSize[q] >= U || hOff[q] >= U - hSize[q]) return {kOutOfBounds, 0};   // offset + size >= uncompressedSize (">=" quirk, zra.cpp:260), overflow-safe
+  if (nq == 0 || fs == 0 || nFrames == 0) return ok();
+  if (nq > 0xFFFFFFF0ull) return zerr(64);
+
+  // queries -> device (offset, size, destination) triples
+  std::vector<uint64_t> hq(3 * nq);
+  for (size_t q = 0; q < nq; q++) { hq[3 * q] = hOff[q]; hq[3 * q + 1] = hSize[q]; hq[3 * q + 2] = hOutOff[q]; }
+  const size_t planWords = 4 * (size_t)nFrames + 16;
+  if (!qmeta_.reserve(hq.size() * 8 + 64) || !raPlan_.reserve(planWords * 4)) return zerr(64);
+  HIPCHK(hipMemcpyAsync(qmeta_.p, hq.data(), hq.size() * 8, hipMemcpyHostToDevice, stream_));
+  HIPCHK(hipMemsetAsync(raPlan_.p, 0, planWords * 4, stream_));
+  RaPlan P;
+  P.cnt = raPlan_.as<uint32_t>(); P.need = P.cnt + nFrames; P.slot = P.need + nFrames; P.cursor = P.slot + nFrames; P.totals = P.cursor + nFrames;
+  const uint64_t* dQ = qmeta_.as<uint64_t>();
+  hipLaunchKernelGGL(zra_ra_count_kernel, dim3((uint32_t)((nq + 255) / 256)), dim3(256), 0, stream_, dQ, (u32)nq, (u64)fs, P);
+  // job arrays sized for "every frame touched"; slices for "every query crosses every frame boundary it can"
+  uint64_t maxPieces = 0;
+  for (size_t q = 0; q < nq; q++) maxPieces += hSize[q] ? (hOff[q] + hSize[q] - 1) / fs - hOff[q] / fs + 1 : 0;
+  const uint64_t tempBudget = 16ull << 30;
+  const uint32_t passSlots = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(nFrames, tempBudget / fs));
+  if (!frameOff_.reserve(((size_t)nFrames + 1) * 16) || !outOff_.reserve((size_t)nFrames * 8) || !expect_.reserve((size_t)nFrames * 4) ||
+      !raLimit_.reserve((size_t)nFrames * 4) || !raPieceBase_.reserve(((size_t)nFrames + 1) * 4) || !raPieces_.reserve((size_t)maxPieces * sizeof(ZraRaPiece) + 64))
+    return zerr(64);
+  hipLaunchKernelGGL(zra_ra_plan_kernel, dim3(1), dim3(1024), 0, stream_, P, nFrames, dArc + h.seekTableOffset, (u64)fs, (u64)U, passSlots,
+                     raVerifyWholeFrames_ ? 1u : 0u, frameOff_.as<uint64_t>(), outOff_.as<uint64_t>(), expect_.as<uint32_t>(), raLimit_.as<uint32_t>(),
+                     raPieceBase_.as<uint32_t>());
+  hipLaunchKernelGGL(zra_ra_fill_kernel, dim3((uint32_t)((nq + 255) / 256)), dim3(256), 0, stream_, dQ, (u32)nq, (u64)fs, P, raPieceBase_.as<uint32_t>(),
+                     raPieces_.as<ZraRaPiece>());
+  uint32_t totals[2] = {0, 0};
+  HIPCHK(hipMemcpyAsync(totals, P.totals, 8, hipMemcpyDeviceToHost, stream_));
   HIPCHK(hipStreamSynchronize(stream_));
-  // touched-frame map -> dense slot numbering (no sort: a query's frames are consecutive, so are their slots)
-  std::vector<uint32_t> slot((size_t)nFrames + 1, 0);
-  for (size_t q = 0; q < nq; q++) {
-    if (hSize[q] == 0) continue;
-    uint64_t f0 = hOff[q] / fs, f1 = (hOff[q] + hSize[q] - 1) / fs;
-    for (uint64_t f = f0; f <= f1; f++) slot[f] = 1;
-  }
-  // queries bucketed by first frame (counting sort over frames keeps this O(nq + nFrames))
-  std::vector<size_t> order(nq);
-  {
-    std::vector<uint32_t> head((size_t)nFrames + 2, 0);
-    for (size_t q = 0; q < nq; q++) head[std::min<uint64_t>(hOff[q] / fs, nFrames) + 1]++;
-    for (size_t f = 0; f <= nFrames; f++) head[f + 1] += head[f];
-    for (size_t q = 0; q < nq; q++) order[head[std::min<uint64_t>(hOff[q] / fs, nFrames)]++] = q;
-  }
-  // dense numbering of the touched frames: pre[f] = touched frames before f (a query's frames are consecutive, so are their slots)
-  std::vector<uint32_t> pre((size_t)nFrames + 2, 0);
-  for (size_t f = 0; f <= nFrames; f++) pre[f + 1] = pre[f] + slot[f];
-  trace("set-up done");
-  // passes bounded by a temp budget (decoded frames per pass); a pass is cut only where no taken query straddles
-  const uint64_t budgetFrames = std::max<uint64_t>(1, (8ull << 30) / fs);   // 8 GiB of decoded frames per pass
-  std::vector<uint64_t> se, jobOut, qmeta;
-  std::vector<uint32_t> jobExp;
-  size_t qi = 0;
-  while (qi < nq) {
-    const uint64_t fstart = hOff[order[qi]] / fs;
-    uint64_t maxFrameEnd = fstart;
-    size_t qj = qi, nTaken = 0;
-    for (; qj < nq; qj++) {
-      const size_t q = order[qj];
-      const uint64_t f0 = hOff[q] / fs, f1 = hSize[q] ? (hOff[q] + hSize[q] - 1) / fs : f0;
-      if ((uint64_t)(pre[std::min<uint64_t>(maxFrameEnd, nFrames)] - pre[fstart]) >= budgetFrames && f0 >= maxFrameEnd) break;
-      maxFrameEnd = std::max(maxFrameEnd, f1 + 1);
-      nTaken += hSize[q] != 0;
-    }
-    const uint64_t fend = std::min<uint64_t>(maxFrameEnd, nFrames);
-    const uint64_t nslots = pre[fend] - pre[fstart];
-    se.resize((size_t)nslots * 2); jobOut.resize((size_t)nslots); jobExp.resize((size_t)nslots); qmeta.resize(nTaken * 3);
-    for (uint64_t f = fstart; f < fend; f++) {
-      if (!slot[f]) continue;
-      const uint64_t k = pre[f] - pre[fstart];
-      se[2 * k] = zra_fmt::entry_get(&table[f * 5]);                 // frame start inside the body
-      se[2 * k + 1] = zra_fmt::entry_get(&table[(f + 1) * 5]);       // frame end
-      jobOut[k] = k * fs;
-      jobExp[k] = (uint32_t)std::min<uint64_t>(fs, h.uncompressedSize - f * fs);
-    }
-    {
-      size_t w = 0;
-      for (size_t j = qi; j < qj; j++) {
-        const size_t q = order[j];
-        if (!hSize[q]) continue;
-        const uint64_t f0 = hOff[q] / fs;
-        qmeta[w++] = (uint64_t)(pre[f0] - pre[fstart]) * fs + hOff[q] % fs;
-        qmeta[w++] = hOutOff[q];
-        qmeta[w++] = hSize[q];
-      }
-    }
-    const uint32_t nj = (uint32_t)nslots;
-    trace("pass built");
-    if (nj) {
-      if (!temp_.reserve((size_t)nj * fs + 64) || !frameOff_.reserve(se.size() * 8) || !outOff_.reserve((size_t)nj * 8) ||
-          !expect_.reserve((size_t)nj * 4) || !qmeta_.reserve(qmeta.size() * 8 + 8))
-        return zerr(64);
-      HIPCHK(hipMemcpyAsync(frameOff_.p, se.data(), se.size() * 8, hipMemcpyHostToDevice, stream_));
-      HIPCHK(hipMemcpyAsync(outOff_.p, jobOut.data(), (size_t)nj * 8, hipMemcpyHostToDevice, stream_));
-      HIPCHK(hipMemcpyAsync(expect_.p, jobExp.data(), (size_t)nj * 4, hipMemcpyHostToDevice, stream_));
-      if (!qmeta.empty()) HIPCHK(hipMemcpyAsync(qmeta_.p, qmeta.data(), qmeta.size() * 8, hipMemcpyHostToDevice, stream_));
-      HIPCHK(hipStreamSynchronize(stream_));
-      // frames of a pass are not adjacent in the body: each job carries its own (start, end) pair -> offset stride 2
-      Status s = decode_jobs(dArc + h.size, arcSize - h.size, frameOff_.as<uint64_t>(), temp_.as<uint8_t>(), outOff_.as<uint64_t>(),
-                             expect_.as<uint32_t>(), nj, (uint32_t)fs, 2);
-      trace("pass decoded");
-      if (s.zra) return s;
-      const uint32_t nqPass = (uint32_t)(qmeta.size() / 3);
-      if (nqPass) {
-        hipLaunchKernelGGL(zra_gather_kernel, dim3(nqPass), dim3(256), 0, stream_, temp_.as<uint8_t>(), dOut, qmeta_.as<uint64_t>(), nqPass);
-        HIPCHK(hipStreamSynchronize(stream_));
-      }
-    }
-    qi = qj;
+  HIPCHK(hipGetLastError());
+  const uint32_t touched = totals[0];
+  if (!touched) return ok();
+  // decode the touched frames, a scratch window of passSlots frames at a time (only frames that are decoded in full — or larger
+  // than what the decoder needs as its match window — actually write there); slices leave for dOut as each frame finishes
+  if (!temp_.reserve((size_t)std::min<uint64_t>(touched, passSlots) * fs + 64)) return zerr(64);
+  ZraDecodeArgs ra{};
+  ra.pieces = raPieces_.as<ZraRaPiece>(); ra.raOut = dOut;
+  for (uint32_t s0 = 0; s0 < touched; s0 += passSlots) {
+    const uint32_t n = std::min(passSlots, touched - s0);
+    ra.limit = raLimit_.as<uint32_t>() + s0; ra.pieceBase = raPieceBase_.as<uint32_t>() + s0;
+    Status st = decode_jobs(dArc + h.size, arcSize - h.size, frameOff_.as<uint64_t>() + 2 * (size_t)s0, temp_.as<uint8_t>(), outOff_.as<uint64_t>() + s0,
+                            expect_.as<uint32_t>() + s0, n, (uint32_t)std::min<uint64_t>(fs, 0xFFFFFFFFu), 2, 0, &ra);
+    if (st.zra) return st;
   }
   return ok();
 }
