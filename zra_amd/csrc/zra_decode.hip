@@ -54,20 +54,25 @@ __device__ __forceinline__ u32 mk_cell(u32 sym, u32 addBits, u32 nbBits, u32 nex
   return sym | (addBits << 8) | (nbBits << 16) | (nextBase << 20);
 }
 
+constexpr u32 STAGE_BYTES = 512;     // header bytes copied to LDS per window (frame + block + literals header + tree description: <= 160)
 struct __attribute__((aligned(16))) ParseShared {
-  // the Huffman literal table is live while the literal streams are decoded, the staging area while a sequence table is built
+  // lane 0 parses headers byte by byte: from HBM that is a dependent round trip per byte (~1-2 us each under load), so the wave
+  // first copies the header region into LDS with one coalesced load (w0: from the block header on; w1: the sequences header)
+  u8 w0[STAGE_BYTES + 16];
+  u8 w1[STAGE_BYTES + 16];
   union {
-    u16 huf[2048];          // sym | nbBits<<8 (bit 15: a pair of 12-bit codes, resolved through w1[]); doubles as scratch for the weights
+    u64 wt[64];             // FSE decode table of the Huffman weights (accuracy <= 6)
     u32 stage[1024];        // one FSE table under construction (LL / ML: 512 cells x 2 words; OF: 256 x 1)
   };
+  u16 wnext[256];           // scratch of the weight-table build
   short norm[256];          // scratch while a table is described
   u8 spread[512];
   u8 weights[256];
-  u8 w1[256];               // weight-1 symbols in order (only tables of depth 12 need them)
+  u16 hufStart[256];        // first decode-table cell of every symbol (cells ordered by weight, then symbol)
   u32 rankStart[16];
   // control words (written by lane 0, read by the wave after a wave sync)
   u32 err, job;
-  u32 blkType, blkSize, blkLast, blkPos, hdrPos, frameEnd;
+  u32 blkType, blkSize, blkLast, blkPos, hdrPos, frameEnd, winPos, winLen;
   u32 litType, litRegen, litComp, litHdr, litStreams, litRle;
   u32 hufValid, hufMaxBits, hufNSym, hufX2;
   u32 nbSeq, seqPos, seqModes;
@@ -75,7 +80,7 @@ struct __attribute__((aligned(16))) ParseShared {
   u32 rep[3];
   u32 streamOff[4], streamLen[4];
   u32 tl, ms, used;
-  u32 produced, seqHdrErr;
+  u32 produced, lateErr;
   u32 fcsLo, fcsHi, fcsHave, hasChecksum, bigWindow;
   u32 litKind, litArg, alloc;
   u64 litBase, seqBase;
@@ -222,9 +227,9 @@ __device__ void parse_literals_header(ParseShared& S, const u8* src, u32 n, cons
       u32 maxSym = 255, tl;
       u32 h = read_ncount(S.norm, &maxSym, &tl, p + 1, hbyte, 6, lim);
       if (!h) { S.err = ZE_CORRUPTION; return; }
-      // small serial FSE decode of the weights (<= 255 symbols); table (<= 64 cells) in the not-yet-filled Huffman table
-      u64* const wt = (u64*)S.huf;                 // 64 cells max (accuracy <= 6)
-      u16* const next = S.huf + 1024;
+      // small serial FSE decode of the weights (<= 255 symbols); table of <= 64 cells
+      u64* const wt = S.wt;
+      u16* const next = S.wnext;
       {
         u32 size = 1u << tl, mask = size - 1, high = size - 1, step = (size >> 1) + (size >> 3) + 3, pos = 0;
         for (u32 s = 0; s <= maxSym; s++) { next[s] = S.norm[s] == -1 ? 1 : (u16)S.norm[s]; if (S.norm[s] == -1) S.spread[high--] = (u8)s; }
@@ -270,7 +275,9 @@ __device__ void parse_literals_header(ParseShared& S, const u8* src, u32 n, cons
     for (u32 w = 1; w <= maxBits; w++) { const u32 c = S.rankStart[w]; S.rankStart[w] = acc; acc += c << (w - 1); }
     if (acc != (1u << maxBits)) { S.err = ZE_CORRUPTION; return; }
     if (used >= rem) { S.err = ZE_CORRUPTION; return; }                // "hSize >= cSrcSize"
-    S.hufValid = 2;   // 2 = new table to be filled by the workgroup
+    // first decode-table cell of every symbol: cells are ordered by weight, then by symbol (the Huffman kernel fills from this)
+    for (u32 i = 0; i <= nw; i++) { const u32 w = S.weights[i]; if (w) { S.hufStart[i] = (u16)S.rankStart[w]; S.rankStart[w] += 1u << (w - 1); } else S.hufStart[i] = 0; }
+    S.hufValid = 2;   // 2 = a new tree (its description goes to the frame record)
     // which of libzstd's two decoders reads this table (they accept different DAMAGED streams): one stream -> single-symbol;
     // four streams -> HUF_selectDecoder(regenerated size, compressed size incl. the tree); treeless blocks keep the table's kind
     if (streams == 4) {
@@ -336,59 +343,6 @@ __device__ void seq_table_parse(ParseShared& S, int kind, u32 mode, const u8* p,
 }
 
 // ---------------------------------------------------------------------------------------------
-// Huffman symbol lookup on 12 bits v (left-aligned code bits): symbol | nbBits<<8
-__device__ __forceinline__ u32 huf_lookup12(const ParseShared& S, u32 v12, u32 mb) {
-  if (mb < 12) return S.huf[v12 >> (12 - mb)] & 0x7FFFu;
-  const u32 e = S.huf[v12 >> 1];
-  if (e & 0x8000u) return (u32)S.w1[v12] | (12u << 8);
-  return e;
-}
-// bits [pos-12, pos) of a backward stream, zeros below bit 0 (BIT_lookBitsFast while bits remain)
-__device__ __forceinline__ u32 peek12(const u8* base, const u8* lim, i32 pos) {
-  const i32 lo = pos - 12;
-  if (lo >= 0) { const u64 w = ld64_safe(base + (lo >> 3), lim); return (u32)(w >> (lo & 7)) & 0xFFFu; }
-  if (pos <= 0) return 0;
-  const u64 w = ld64_safe(base, lim);
-  return (u32)((w << (u32)(-lo)) & 0xFFFu);
-}
-// libzstd's double-symbol decoder (HUF_decodeStreamX2) on ONE stream that the single-symbol rules rejected: a 12-bit lookup yields
-// one symbol or a PAIR (when both codes fit in 12 bits); if the walk ends one output position short, HUF_decodeLastSymbolX2 takes
-// the first symbol of the entry under the cursor and, for a pair entry, skips the bits of both codes clamped to the end of the
-// stream (nothing when no bit is left). Returns true when that decoder accepts the stream; `o` gets the symbols it writes.
-__device__ bool huf_stream_x2(const ParseShared& S, const u8* base, u32 n, const u8* lim, u8* o, u32 regen) {
-  if (n == 0) return false;
-  const u32 last = base[n - 1];
-  if (last == 0) return false;
-  i32 pos = (i32)(n - 1) * 8 + (i32)hb32(last);
-  const u32 mb = S.hufMaxBits;
-  u32 i = 0;
-  while (i + 2 <= regen) {
-    if (pos <= 0) return false;
-    const u32 e1 = huf_lookup12(S, peek12(base, lim, pos), mb), a = e1 >> 8;
-    const u32 e2 = huf_lookup12(S, peek12(base, lim, pos - (i32)a), mb), b = e2 >> 8;
-    o[i] = (u8)e1;
-    if (a + b <= 12) { o[i + 1] = (u8)e2; pos -= (i32)(a + b); i += 2; }
-    else { pos -= (i32)a; i += 1; }
-  }
-  if (i < regen) {
-    if (pos < 0) return false;
-    u32 v1;
-    if (pos > 0) v1 = peek12(base, lim, pos);
-    else {                                         // no bit left: the container's TOP 12 bits come back (shift by 64 & 63 = 0)
-      u64 c = 0; for (u32 k = 0; k < 8 && k < n; k++) c |= (u64)base[k] << (8 * k);
-      v1 = (u32)(c >> 52);
-    }
-    const u32 e1 = huf_lookup12(S, v1, mb), a = e1 >> 8;
-    const u32 v2 = pos > 0 ? peek12(base, lim, pos - (i32)a) : ((v1 << a) & 0xFFFu);
-    const u32 e2 = huf_lookup12(S, v2, mb), b = e2 >> 8;
-    o[i] = (u8)e1;
-    if (a + b <= 12) { if (pos > 0) { pos -= (i32)(a + b); if (pos < 0) pos = 0; } }
-    else pos -= (i32)a;
-  }
-  return pos == 0;
-}
-
-// ---------------------------------------------------------------------------------------------
 // frame end (shared by the parse and execute kernels): frame-level checks in the order of ZSTD_decompressFrame, the per-frame
 // result words, and — random access — the query slices of this frame
 // (lane / nthreads: rank and size of the calling group)
@@ -446,38 +400,57 @@ zra_dec_parse_kernel(ZraDecodeArgs a) {
     wsync();
     if (qi >= a.nActive) return;
     const u32 j = a.active ? a.active[qi] : qi;
-    const size_t gj = j;
 
-    const u64 so = a.frameOff[gj * a.offStride], se = a.frameOff[gj * a.offStride + 1];
+    const u64 so = a.frameOff[(size_t)j * a.offStride], se = a.frameOff[(size_t)j * a.offStride + 1];
     const u8* const src = a.body + so;
-    const u32 srcSize = (u32)(se - so);
-    const u8* const lim = a.body + a.bodySize;
+    const bool spanOk = se >= so && se <= a.bodySize;
+    const u32 srcSize = spanOk ? (u32)(se - so) : 0u;
     u8* const dst = a.out + a.outOff[j];
     const u32 dstCap = a.outCap[j];
     const u32 limit = a.limit ? a.limit[j] : 0xFFFFFFFFu;
     ZraDecFrame* const F = &a.frames[j];
 
+    // copy of [pos, pos + STAGE_BYTES) of the frame (clipped to its end) into an LDS window: one coalesced load for the wave
+    auto stage = [&](u8* w, u32 pos) -> u32 {
+      const u32 avail = pos < srcSize ? min(srcSize - pos, STAGE_BYTES) : 0u;
+      const u32 at = 8u * (u32)lane;
+      u64 v = 0;
+      if (at + 8 <= avail) v = ld64(src + pos + at);
+      else for (u32 k = 0; at + k < avail && k < 8; k++) v |= (u64)src[pos + at + k] << (8 * k);
+      *(u64*)(w + at) = v;
+      if (lane < 2) *(u64*)(w + STAGE_BYTES + 8 * lane) = 0;
+      return avail;
+    };
+    const u32 startPos = a.round == 0 ? 0u : F->blkPos;
+    const u32 staged0 = stage(S.w0, startPos);
+
     if (lane == 0) {
-      S.err = 0; S.frameEnd = 0;
+      S.err = 0; S.frameEnd = 0; S.winPos = startPos; S.winLen = staged0;
       if (a.round == 0) {
         S.produced = 0; S.hufValid = 0; S.llValid = S.mlValid = S.ofValid = 0; S.ofShare = 0;
         S.rep[0] = 1; S.rep[1] = 4; S.rep[2] = 8;
+      }
+    }
+    wsync();
+    if (lane == 0) {
+      if (a.round == 0) {
         // ---- frame header (A.1), check order of ZSTD_decompressFrame + ZSTD_getFrameHeader_advanced: sizes before the magic number
+        const u8* const hsrc = S.w0;          // bytes [0, STAGE_BYTES) of the frame
         u32 hs = 0;
         S.fcsHave = 0; S.hasChecksum = 0; S.bigWindow = 0;
-        if (se < so || se > a.bodySize || srcSize < 9) S.err = ZE_SRCSIZE_WRONG;
+        if (!spanOk || srcSize < 9) S.err = ZE_SRCSIZE_WRONG;
         else {
-          u32 fhd = src[4], did = fhd & 3, ss = (fhd >> 5) & 1, fcs = fhd >> 6;
+          u32 fhd = hsrc[4], did = fhd & 3, ss = (fhd >> 5) & 1, fcs = fhd >> 6;
           u32 didSize = did == 3 ? 4 : did;
           u32 fcsSize = fcs == 0 ? ss : fcs == 1 ? 2 : fcs == 2 ? 4 : 8;
           hs = 5 + !ss + didSize + fcsSize;
           if (srcSize < hs + 3) S.err = ZE_SRCSIZE_WRONG;
-          else if (ld32(src) != 0xFD2FB528u) S.err = ZE_PREFIX_UNKNOWN;
+          else if (ld32(hsrc) != 0xFD2FB528u) S.err = ZE_PREFIX_UNKNOWN;
           else if (fhd & 8) S.err = ZE_FRAMEPARAM_UNSUPPORTED;
           else {
             u64 window = 0;
             if (!ss) {
-              u32 b = src[5], wl = 10 + (b >> 3);
+              u32 b = hsrc[5], wl = 10 + (b >> 3);
               if (wl > 31) S.err = ZE_WINDOW_TOO_LARGE;                  // windowLog > ZSTD_WINDOWLOG_MAX; the one-shot decoder has no other limit
               else window = (1ull << wl) + ((1ull << wl) >> 3) * (b & 7);
             }
@@ -485,7 +458,7 @@ zra_dec_parse_kernel(ZraDecodeArgs a) {
             if (!S.err) {
               // a dictionary id cannot be honoured (the reference never loads one): dictionary_wrong, as ZSTD_decompressFrame reports it;
               // the declared content size (1/2/4/8 bytes, the 2-byte form biased by 256) must equal what the frame regenerates
-              const u8* q = src + 5 + !ss;
+              const u8* q = hsrc + 5 + !ss;
               const u32 dict = did == 0 ? 0u : did == 1 ? (u32)q[0] : did == 2 ? (u32)ld16(q) : ld32(q);
               if (dict) S.err = ZE_DICT_WRONG;
               q += didSize;
@@ -509,16 +482,11 @@ zra_dec_parse_kernel(ZraDecodeArgs a) {
       }
     }
     wsync();
-    if (a.round != 0 && S.hufValid) {                  // kept Huffman description of the previous block (treeless literals rebuild from it)
-      for (u32 i = lane; i < 256; i += DEC_THREADS) S.weights[i] = F->weights[i];
-      if (lane < 16) S.rankStart[lane] = F->rankStart[lane];
-      wsync();
-    }
 
     // what a frame carries from round to round (lane 0)
-    auto save_persistent = [&](u32 blkPos, u32 produced) {
+    auto save_persistent = [&](u32 blkPos, u32 produced, u32 hv, u32 hmb, u32 hns, u32 hx2) {
       F->blkPos = blkPos; F->produced = produced; F->done = 0;
-      F->hufValid = S.hufValid ? 1u : 0u; F->hufMaxBits = S.hufMaxBits; F->hufNSym = S.hufNSym; F->hufX2 = S.hufX2;
+      F->hufValid = hv ? 1u : 0u; F->hufMaxBits = hmb; F->hufNSym = hns; F->hufX2 = hx2;
       F->llValid = S.llValid; F->mlValid = S.mlValid; F->ofValid = S.ofValid; F->llLog = S.llLog; F->mlLog = S.mlLog; F->ofLog = S.ofLog;
       F->ofShare = S.ofShare;
       F->rep[0] = S.rep[0]; F->rep[1] = S.rep[1]; F->rep[2] = S.rep[2];
@@ -533,12 +501,21 @@ zra_dec_parse_kernel(ZraDecodeArgs a) {
       wsync();
       if (stop) break;
       if (S.produced >= limit) { truncated = true; break; }        // random access: every byte a query needs exists
+      // the header window must hold this block's header, literals header and tree description (<= 160 bytes) or reach the frame's end
+      if (S.blkPos < S.winPos || S.blkPos + 160 > S.winPos + S.winLen) {
+        const u32 at = S.blkPos;
+        wsync();
+        const u32 got = stage(S.w0, at);
+        if (lane == 0) { S.winPos = at; S.winLen = got; }
+        wsync();
+      }
+      const u8* const win = S.w0 - S.winPos;     // win + x == LDS copy of frame byte x, for x inside the window
       if (lane == 0) {
         u32 pos = S.blkPos;
         S.hdrPos = pos;
         if (srcSize - pos < 3) S.err = ZE_SRCSIZE_WRONG;
         else {
-          u32 bh = ld24(src + pos);
+          u32 bh = ld24(win + pos);
           S.blkLast = bh & 1; S.blkType = (bh >> 1) & 3; S.blkSize = bh >> 3;
           pos += 3;
           u32 payload = S.blkType == 1 ? 1 : S.blkSize;
@@ -564,11 +541,10 @@ zra_dec_parse_kernel(ZraDecodeArgs a) {
       }
 
       // ------------------------------------------------------------ compressed block
-      const u8* const blk = src + bpos;
+      const u32 hv0 = S.hufValid, hmb0 = S.hufMaxBits, hns0 = S.hufNSym, hx20 = S.hufX2;     // the kept tree as of before this block
       if (lane == 0) {
-        S.litStreams = 1; S.litRle = 0; S.alloc = 1;
-        parse_literals_header(S, blk, bsize, lim);
-        S.seqHdrErr = 0;
+        S.litStreams = 1; S.litRle = 0; S.alloc = 1; S.lateErr = 0; S.nbSeq = 0;
+        parse_literals_header(S, win + bpos, bsize, S.w0 + STAGE_BYTES + 8);
         if (!S.err) {
           // literal scratch of this round (Huffman-coded literals only: raw ones are read in place, RLE ones are a byte)
           if (S.litType >= 2) {
@@ -578,113 +554,58 @@ zra_dec_parse_kernel(ZraDecodeArgs a) {
             S.litBase = at; S.litKind = 2;
           } else if (S.litType == 1) { S.litKind = 1; S.litArg = S.litRle; }
           else { S.litKind = 0; S.litArg = bpos + S.litHdr; }
-          // the sequences header is parsed now, but an error in it is only raised after the literals have been decoded: the
-          // reference decodes the literals section first (ZSTD_decodeLiteralsBlock, then ZSTD_decodeSeqHeaders)
           S.seqPos = S.litHdr + S.litComp;
-          parse_seq_header(S, blk + S.seqPos, bsize - S.seqPos);
-          S.seqHdrErr = S.err; S.err = 0;
-          if (S.seqHdrErr) S.nbSeq = 0;
-          if (S.alloc && S.nbSeq) {
-            const u64 at = atomicAdd((unsigned long long*)&a.counters[ZRA_DC_SEQCUR], (unsigned long long)S.nbSeq);
-            if (at + S.nbSeq > a.seqCap) S.alloc = 0;
-            S.seqBase = at;
-          }
         }
       }
       wsync();
       if (S.err) break;
-      if (!S.alloc) {
-        // this round's scratch is full: the frame keeps its state as of this block's header and takes the next round (which parses
-        // the block again; what the header parse above left in the Huffman description is what that parse will write again)
-        if (lane == 0) {
-          save_persistent(S.hdrPos, produced0);
-          a.nextActive[atomicAdd(&a.counters[ZRA_DC_NNEXT], 1u)] = j;
+      // ---- sequences header + table descriptions, from their own LDS window. Whatever is wrong from here on is raised only after
+      //      the literals have been decoded (the reference decodes the literals section first): it travels as lateErr
+      {
+        const u32 at = bpos + S.seqPos;
+        const u32 got = stage(S.w1, at);
+        (void)got;
+        wsync();
+      }
+      const u8* const sw = S.w1 - S.seqPos;        // sw + x == LDS copy of block byte x, for x from the sequences header on
+      const u8* const swLim = S.w1 + STAGE_BYTES + 8;
+      if (lane == 0) {
+        parse_seq_header(S, sw + S.seqPos, bsize - S.seqPos);
+        if (S.err) { S.lateErr = S.err; S.err = 0; S.nbSeq = 0; }
+        if (S.alloc && S.nbSeq) {
+          const u64 at = atomicAdd((unsigned long long*)&a.counters[ZRA_DC_SEQCUR], (unsigned long long)S.nbSeq);
+          if (at + S.nbSeq > a.seqCap) S.alloc = 0;
+          S.seqBase = at;
         }
-        if (S.hufValid) {
-          for (u32 i = lane; i < 256; i += DEC_THREADS) F->weights[i] = S.weights[i];
-          if (lane < 16) F->rankStart[lane] = S.rankStart[lane];
+      }
+      wsync();
+      if (!S.alloc) {
+        // this round's scratch is full: the frame keeps its state as of this block's header and takes the next round
+        if (lane == 0) {
+          save_persistent(S.hdrPos, produced0, hv0, hmb0, hns0, hx20);
+          a.nextActive[atomicAdd(&a.counters[ZRA_DC_NNEXT], 1u)] = j;
         }
         handed = true;          // (nothing pending, but the frame is not finished either)
         wsync();
         break;
       }
 
-      // ---- Huffman decode table fill: cells ordered by weight, then symbol
-      if (S.litType >= 2) {                              // new table, or treeless: rebuilt from the kept weights (LDS shared with the FSE staging)
-        const u32 nSym = S.hufNSym, maxBits = S.hufMaxBits;
-        const u32 sh = maxBits == 12 ? 1u : 0u;          // depth 12: cells are indexed by the top 11 bits, the 12-bit codes come in pairs
-        for (u32 sy = lane; sy < nSym; sy += DEC_THREADS) {
-          u32 w = S.weights[sy];
-          if (w == 0) continue;
-          u32 before = 0;
-          for (u32 t = 0; t < sy; t++) before += (S.weights[t] == w);
-          u32 len = 1u << (w - 1), start = S.rankStart[w] + before * len;
-          u16 e = (u16)(sy | ((maxBits + 1 - w) << 8));
-          if (sh && w == 1) { S.w1[start] = (u8)sy; if (!(before & 1)) S.huf[start >> 1] = 0x8000u | (12u << 8); }
-          else { len >>= sh; start >>= sh; for (u32 c = 0; c < len; c++) S.huf[start + c] = e; }
-        }
-        wsync();
-        if (lane == 0) S.hufValid = 1;
-        wsync();
-      }
-      const u32 nbSeq = S.nbSeq;
-      // ---- literals: Huffman -> up to 4 lanes, one per stream, into the literal scratch
-      const u32 litType = S.litType, regen = S.litRegen;
-      if (litType >= 2) {
-        u8* const litOut = a.lits + S.litBase;
-        const u32 nStreams = S.litStreams;
-        if ((u32)lane < nStreams) {
-          const u32 seg = nStreams == 1 ? regen : (regen + 3) / 4;
-          const u32 myLen = nStreams == 1 ? regen : (lane < 3 ? seg : regen - 3 * seg);
-          u8* o = litOut + (size_t)lane * seg;
-          const u8* const sb = blk + S.streamOff[lane]; const u32 sl = S.streamLen[lane];
-          BitR hb;
-          bool bad = hb.init(sb, sl, lim) != 0;
-          if (!bad) {
-            const int mb = (int)S.hufMaxBits;
-            u32 i = 0;
-            if (mb < 12) {
-              for (; i + 4 <= myLen; i += 4) {        // 4 symbols per window reload (4*11 = 44 <= 56 guaranteed bits)
-                hb.ensure(4 * mb);
-                u32 packed = 0;
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                  u32 e = S.huf[hb.peek(mb)];
-                  packed |= (e & 0xFF) << (8 * k);
-                  hb.skip((int)(e >> 8));
-                }
-                st32(o + i, packed);
-              }
-              for (; i < myLen; i++) { hb.ensure(mb); u32 e = S.huf[hb.peek(mb)]; o[i] = (u8)e; hb.skip((int)(e >> 8)); }
-            } else {
-              for (; i < myLen; i++) { hb.ensure(12); const u32 e = huf_lookup12(S, hb.peek(12), 12); o[i] = (u8)e; hb.skip((int)(e >> 8)); }
-            }
-            if (hb.pos != 0) bad = true;
-          }
-          // a stream the single-symbol rules reject may still pass libzstd's double-symbol decoder, if that is the one it would use
-          if (bad && S.hufX2) bad = !huf_stream_x2(S, sb, sl, lim, o, myLen);
-          if (bad) S.err = ZE_CORRUPTION;
-        }
-      }
-      wsync();
-      if (S.err) break;
-      if (S.seqHdrErr) { wsync(); if (lane == 0) S.err = S.seqHdrErr; wsync(); break; }
-
       // ---- sequence decode tables: lane 0 parses each description, the wave builds it in LDS and stores it to the table scratch
+      const u32 nbSeq = S.nbSeq, regen = S.litRegen;
       u32* const T = a.tables + (size_t)j * ZRA_DEC_TBL_WORDS;
       if (nbSeq) {
-        bool bad = false;
-        for (int kind = 0; kind < 3 && !bad; kind++) {
+        for (int kind = 0; kind < 3; kind++) {
           const int k = kind == 0 ? 0 : kind == 1 ? 2 : 1;          // wire order is LL, OF, ML
           const u32 mode = k == 0 ? (S.seqModes >> 6) : k == 2 ? ((S.seqModes >> 4) & 3) : ((S.seqModes >> 2) & 3);
           if (lane == 0) {
             u32 tl = 0, ms = 0, used = 0;
-            seq_table_parse(S, k, mode, blk + S.seqPos, bsize - S.seqPos, &tl, &ms, &used, lim);
+            seq_table_parse(S, k, mode, sw + S.seqPos, bsize - S.seqPos, &tl, &ms, &used, swLim);
             S.seqPos += used; S.tl = tl; S.ms = ms;
             if (mode == 3) { u32 v = k == 0 ? S.llValid : k == 1 ? S.mlValid : S.ofValid; if (!v) S.err = ZE_CORRUPTION; }
+            if (S.err) { S.lateErr = S.err; S.err = 0; }
           }
           wsync();
-          if (S.err) { bad = true; break; }
+          if (S.lateErr) break;
           const u32 tl = S.tl, ms = S.ms;
           u32* const G = T + (k == 0 ? ZRA_DEC_TBL_LL : k == 1 ? ZRA_DEC_TBL_ML : ZRA_DEC_TBL_OF);
           if (mode == 1) {
@@ -711,21 +632,23 @@ zra_dec_parse_kernel(ZraDecodeArgs a) {
           }
           wsync();
         }
-        if (bad) break;
       }
 
-      // ---- hand the block to the chain kernel: persistent state + the block record
+      // ---- hand the block on: persistent state + the block record; Huffman-coded literals go through the Huffman kernel first
       if (lane == 0) {
-        save_persistent(S.hdrPos, produced0);
+        save_persistent(S.hdrPos, produced0, S.hufValid, S.hufMaxBits, S.hufNSym, S.hufX2);
         F->bpos = bpos; F->bsize = bsize; F->blast = S.blkLast;
         F->litKind = S.litKind; F->litRegen = regen; F->litArg = S.litArg; F->litBase = S.litBase;
-        F->nbSeq = nbSeq; F->seqPos = S.seqPos; F->seqBase = S.seqBase;
+        F->litStreams = S.litStreams;
+        for (int k = 0; k < 4; k++) { F->streamOff[k] = S.streamOff[k]; F->streamLen[k] = S.streamLen[k]; }
+        F->hufErr = 0; F->lateErr = S.lateErr;
+        F->nbSeq = S.lateErr ? 0u : nbSeq; F->seqPos = S.seqPos; F->seqBase = S.seqBase;
         F->longMode = (S.bigWindow && nbSeq > 4 && S.ofShare >= 7) ? 1u : 0u;
         a.pending[atomicAdd(&a.counters[ZRA_DC_NPENDING], 1u)] = j;
+        if (S.litKind == 2) a.hufJobs[atomicAdd(&a.counters[ZRA_DC_NHUF], 1u)] = j;
       }
-      if (S.litType == 2) {                               // a new tree: keep its description for treeless blocks to come
-        for (u32 i = lane; i < 256; i += DEC_THREADS) F->weights[i] = S.weights[i];
-        if (lane < 16) F->rankStart[lane] = S.rankStart[lane];
+      if (S.litType == 2) {                               // a new tree: its description stays with the frame (treeless blocks reuse it)
+        for (u32 i = lane; i < 256; i += DEC_THREADS) { F->weights[i] = S.weights[i]; F->hufStart[i] = S.hufStart[i]; }
       }
       handed = true;
       wsync();
@@ -735,6 +658,154 @@ zra_dec_parse_kernel(ZraDecodeArgs a) {
       frame_finish(a, j, src, srcSize, S.err, S.produced, S.blkPos, truncated, S.fcsHave, S.fcsLo, S.fcsHi, S.hasChecksum, lane);
     }
     wsync();
+  }
+}
+
+// =================================================================================================
+// stage 1b: Huffman literal streams, lane = stream.
+// A stream is a serial chain (table lookup -> code length -> next bit position); the four streams of a frame gave a wave four busy
+// lanes. Here a wave takes 16 frames: their 16 decode tables are built in LDS (64 KiB) and the 64 streams advance together.
+namespace {
+constexpr int HUF_FRAMES = 16;
+struct __attribute__((aligned(16))) HufShared {
+  u16 tab[HUF_FRAMES][2048];   // sym | nbBits<<8 (bit 15: a pair of 12-bit codes, resolved through w1[])
+  u8 w1[HUF_FRAMES][256];      // weight-1 symbols in order (only tables of depth 12 need them)
+  u32 base;
+};
+// Huffman symbol lookup on 12 bits v (left-aligned code bits): symbol | nbBits<<8
+__device__ __forceinline__ u32 huf_lookup12(const u16* tab, const u8* w1, u32 v12, u32 mb) {
+  if (mb < 12) return tab[v12 >> (12 - mb)] & 0x7FFFu;
+  const u32 e = tab[v12 >> 1];
+  if (e & 0x8000u) return (u32)w1[v12] | (12u << 8);
+  return e;
+}
+// bits [pos-12, pos) of a backward stream, zeros below bit 0 (BIT_lookBitsFast while bits remain)
+__device__ __forceinline__ u32 peek12(const u8* base, const u8* lim, i32 pos) {
+  const i32 lo = pos - 12;
+  if (lo >= 0) { const u64 w = ld64_safe(base + (lo >> 3), lim); return (u32)(w >> (lo & 7)) & 0xFFFu; }
+  if (pos <= 0) return 0;
+  const u64 w = ld64_safe(base, lim);
+  return (u32)((w << (u32)(-lo)) & 0xFFFu);
+}
+// libzstd's double-symbol decoder (HUF_decodeStreamX2) on ONE stream that the single-symbol rules rejected: a 12-bit lookup yields
+// one symbol or a PAIR (when both codes fit in 12 bits); if the walk ends one output position short, HUF_decodeLastSymbolX2 takes
+// the first symbol of the entry under the cursor and, for a pair entry, skips the bits of both codes clamped to the end of the
+// stream (nothing when no bit is left). Returns true when that decoder accepts the stream; `o` gets the symbols it writes.
+__device__ bool huf_stream_x2(const u16* tab, const u8* w1, u32 mb, const u8* base, u32 n, const u8* lim, u8* o, u32 regen) {
+  if (n == 0) return false;
+  const u32 last = base[n - 1];
+  if (last == 0) return false;
+  i32 pos = (i32)(n - 1) * 8 + (i32)hb32(last);
+  u32 i = 0;
+  while (i + 2 <= regen) {
+    if (pos <= 0) return false;
+    const u32 e1 = huf_lookup12(tab, w1, peek12(base, lim, pos), mb), a = e1 >> 8;
+    const u32 e2 = huf_lookup12(tab, w1, peek12(base, lim, pos - (i32)a), mb), b = e2 >> 8;
+    o[i] = (u8)e1;
+    if (a + b <= 12) { o[i + 1] = (u8)e2; pos -= (i32)(a + b); i += 2; }
+    else { pos -= (i32)a; i += 1; }
+  }
+  if (i < regen) {
+    if (pos < 0) return false;
+    u32 v1;
+    if (pos > 0) v1 = peek12(base, lim, pos);
+    else {                                         // no bit left: the container's TOP 12 bits come back (shift by 64 & 63 = 0)
+      u64 c = 0; for (u32 k = 0; k < 8 && k < n; k++) c |= (u64)base[k] << (8 * k);
+      v1 = (u32)(c >> 52);
+    }
+    const u32 e1 = huf_lookup12(tab, w1, v1, mb), a = e1 >> 8;
+    const u32 v2 = pos > 0 ? peek12(base, lim, pos - (i32)a) : ((v1 << a) & 0xFFFu);
+    const u32 e2 = huf_lookup12(tab, w1, v2, mb), b = e2 >> 8;
+    o[i] = (u8)e1;
+    if (a + b <= 12) { if (pos > 0) { pos -= (i32)(a + b); if (pos < 0) pos = 0; } }
+    else pos -= (i32)a;
+  }
+  return pos == 0;
+}
+}  // namespace
+
+extern "C" __global__ void __launch_bounds__(DEC_THREADS)
+zra_dec_huf_kernel(ZraDecodeArgs a) {
+  __shared__ HufShared S;
+  const int lane = threadIdx.x;
+  const u32 nJobs = a.counters[ZRA_DC_NHUF];
+  const u8* const lim = a.body + a.bodySize;
+  for (;;) {
+    wsync();
+    if (lane == 0) S.base = atomicAdd(&a.counters[ZRA_DC_QHUF], (u32)HUF_FRAMES);
+    wsync();
+    const u32 base = S.base;
+    if (base >= nJobs) return;
+    const u32 nHere = min((u32)HUF_FRAMES, nJobs - base);
+    // ---- the tables of this batch, one frame after the other, all lanes on each: lane l owns symbols 4l .. 4l+3
+    for (u32 s = 0; s < nHere; s++) {
+      const ZraDecFrame* const F = &a.frames[a.hufJobs[base + s]];
+      const u32 maxBits = F->hufMaxBits, nSym = F->hufNSym;
+      const u32 sh = maxBits == 12 ? 1u : 0u;          // depth 12: cells are indexed by the top 11 bits, the 12-bit codes come in pairs
+      const u32 w4 = *(const u32*)(F->weights + 4 * lane);
+      const u64 st4 = *(const u64*)(F->hufStart + 4 * lane);
+      u16* const tab = S.tab[s]; u8* const w1 = S.w1[s];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const u32 sy = 4 * (u32)lane + k;
+        const u32 w = sy < nSym ? (w4 >> (8 * k)) & 0xFF : 0u;
+        u32 start = (u32)(st4 >> (16 * k)) & 0xFFFFu, len = w ? 1u << (w - 1) : 0u;
+        const u16 e = (u16)(sy | ((maxBits + 1 - w) << 8));
+        if (sh && w == 1) { w1[start] = (u8)sy; if (!(start & 1)) tab[start >> 1] = (u16)(0x8000u | (12u << 8)); len = 0; }
+        len >>= sh; start >>= sh;
+        // short runs by their own lane, long ones by the whole wave
+        const bool big = len >= 32;
+        if (!big) for (u32 c = 0; c < len; c++) tab[start + c] = e;
+        u64 bm = __ballot(big);
+        while (bm) {
+          const u32 l2 = (u32)__builtin_ctzll(bm); bm &= bm - 1;
+          const u32 bs = bcast_u32(start, l2), bl = bcast_u32(len, l2), be = bcast_u32((u32)e, l2);
+          for (u32 c = lane; c < bl; c += DEC_THREADS) tab[bs + c] = (u16)be;
+        }
+      }
+    }
+    wsync();
+    // ---- the streams: lane -> (frame slot, stream)
+    const u32 slot = (u32)lane >> 2, strm = (u32)lane & 3;
+    if (slot < nHere) {
+      ZraDecFrame* const F = &a.frames[a.hufJobs[base + slot]];
+      const u32 nStreams = F->litStreams, regen = F->litRegen;
+      if (strm < nStreams) {
+        const u32 seg = nStreams == 1 ? regen : (regen + 3) / 4;
+        const u32 myLen = nStreams == 1 ? regen : (strm < 3 ? seg : regen - 3 * seg);
+        u8* o = a.lits + F->litBase + (size_t)strm * seg;
+        const u32 j = a.hufJobs[base + slot];
+        const u8* const blk = a.body + a.frameOff[(size_t)j * a.offStride] + F->bpos;
+        const u8* const sb = blk + F->streamOff[strm]; const u32 sl = F->streamLen[strm];
+        const u16* const tab = S.tab[slot];
+        const int mb = (int)F->hufMaxBits;
+        BitR hb;
+        bool bad = hb.init(sb, sl, lim) != 0;
+        if (!bad) {
+          u32 i = 0;
+          if (mb < 12) {
+            for (; i + 4 <= myLen; i += 4) {        // 4 symbols per window reload (4*11 = 44 <= 56 guaranteed bits)
+              hb.ensure(4 * mb);
+              u32 packed = 0;
+#pragma unroll
+              for (int k = 0; k < 4; k++) {
+                u32 e = tab[hb.peek(mb)];
+                packed |= (e & 0xFF) << (8 * k);
+                hb.skip((int)(e >> 8));
+              }
+              st32(o + i, packed);
+            }
+            for (; i < myLen; i++) { hb.ensure(mb); u32 e = tab[hb.peek(mb)]; o[i] = (u8)e; hb.skip((int)(e >> 8)); }
+          } else {
+            for (; i < myLen; i++) { hb.ensure(12); const u32 e = huf_lookup12(tab, S.w1[slot], hb.peek(12), 12); o[i] = (u8)e; hb.skip((int)(e >> 8)); }
+          }
+          if (hb.pos != 0) bad = true;
+        }
+        // a stream the single-symbol rules reject may still pass libzstd's double-symbol decoder, if that is the one it would use
+        if (bad && F->hufX2) bad = !huf_stream_x2(tab, S.w1[slot], (u32)mb, sb, sl, lim, o, myLen);
+        if (bad) F->hufErr = 1;
+      }
+    }
   }
 }
 
@@ -830,7 +901,10 @@ zra_dec_chain_kernel(ZraDecodeArgs a) {
           rep0 = F->rep[0]; rep1 = F->rep[1]; rep2 = F->rep[2];
           i = 0; outPos = 0; litPos = 0; err = 0; jErr = 0xFFFFFFFFu; valid = 0; validOut = 0; validLit = 0; truncated = 0;
           have = true;
-          if (nbSeq) {
+          // what went wrong before the sequences, in the reference's order: the literal streams, then the sequences header / tables
+          if (F->hufErr) { err = ZE_CORRUPTION; nbSeq = 0; finish(); }
+          else if (F->lateErr) { err = F->lateErr; nbSeq = 0; finish(); }
+          else if (nbSeq) {
             if (!br.init(blk + F->seqPos, F->bsize - F->seqPos)) { err = ZE_CORRUPTION; finish(); }
             else {
               sLL = br.read(F->llLog); br.reload();

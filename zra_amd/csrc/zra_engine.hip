@@ -10,6 +10,7 @@
 #include <cstring>
 
 extern "C" __global__ void zra_dec_parse_kernel(ZraDecodeArgs a);
+extern "C" __global__ void zra_dec_huf_kernel(ZraDecodeArgs a);
 extern "C" __global__ void zra_dec_chain_kernel(ZraDecodeArgs a);
 extern "C" __global__ void zra_dec_exec_kernel(ZraDecodeArgs a);
 
@@ -257,12 +258,12 @@ Status Engine::decode_launch(const ZraDecodeArgs& a0, const uint32_t* dExpect, u
   const uint64_t litCap = std::max<uint64_t>((uint64_t)n * perFrame / 2, 1u << 20);
   const uint64_t seqCap = std::max<uint64_t>((uint64_t)n * perFrame * 3 / 32, 1u << 20);               // entries of 8 bytes
   if (!decFrames_.reserve((size_t)n * sizeof(ZraDecFrame)) || !decTables_.reserve((size_t)n * ZRA_DEC_TBL_WORDS * 4) ||
-      !decLists_.reserve((size_t)n * 12 + 64) || !decCounters_.reserve(ZRA_DC_WORDS * 4) || !decLits_.reserve(litCap + 64) ||
+      !decLists_.reserve((size_t)n * 16 + 64) || !decCounters_.reserve(ZRA_DC_WORDS * 4) || !decLits_.reserve(litCap + 64) ||
       !decSeqs_.reserve(seqCap * 8 + 64) || !status_.reserve((size_t)n * 4) || !produced_.reserve((size_t)n * 4) ||
       !frameMeta_.reserve((size_t)n * 8) || !result_.reserve(64))
     return zerr(64 /* memory_allocation */);
   uint32_t* listA = decLists_.as<uint32_t>(); uint32_t* listB = listA + n;
-  a.pending = listA + 2 * (size_t)n;
+  a.pending = listA + 2 * (size_t)n; a.hufJobs = listA + 3 * (size_t)n;
   a.counters = decCounters_.as<uint32_t>();
   a.frames = decFrames_.as<ZraDecFrame>(); a.tables = decTables_.as<uint32_t>();
   a.lits = decLits_.as<uint8_t>(); a.litCap = litCap; a.seqs = decSeqs_.as<uint64_t>(); a.seqCap = seqCap;
@@ -284,6 +285,7 @@ Status Engine::decode_launch(const ZraDecodeArgs& a0, const uint32_t* dExpect, u
     const uint32_t gridChain = (uint32_t)std::min<uint64_t>((nActive + 63) / 64, (uint64_t)numCUs_ * 8);
     const uint32_t gridExec = (uint32_t)std::min<uint64_t>(nActive, (uint64_t)numCUs_ * perCUExec);
     hipLaunchKernelGGL(zra_dec_parse_kernel, dim3(gridParse), dim3(64), 0, stream_, a);
+    hipLaunchKernelGGL(zra_dec_huf_kernel, dim3((uint32_t)std::min<uint64_t>((nActive + 15) / 16, (uint64_t)numCUs_ * 2)), dim3(64), 0, stream_, a);
     hipLaunchKernelGGL(zra_dec_chain_kernel, dim3(gridChain), dim3(64), 0, stream_, a);
     hipLaunchKernelGGL(zra_dec_exec_kernel, dim3(gridExec), dim3(64), 0, stream_, a);
     uint32_t next = 0;

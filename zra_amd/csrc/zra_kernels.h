@@ -6,7 +6,9 @@
 // ------------------------------------------------------------------------------------------------ decode
 // The decoder is three kernels per ROUND (one compressed block of every unfinished frame per round; raw / RLE blocks and the frame
 // ends are consumed by the first kernel on the way):
-//   zra_dec_parse_kernel  wave per frame   headers, Huffman literals -> literal scratch, FSE tables -> per-frame table scratch
+//   zra_dec_parse_kernel  wave per frame   headers (from an LDS copy of the header bytes), Huffman tree descriptions, FSE tables ->
+//                                          per-frame table scratch
+//   zra_dec_huf_kernel    LANE per stream  Huffman literal streams of 16 frames per wave (their 16 decode tables in LDS) -> literal scratch
 //   zra_dec_chain_kernel  LANE per frame   the serial FSE sequence chain of 64 frames in the 64 lanes of a wave, every check of
 //                                          the reference's sequence loop (its statuses, in its order) -> sequence scratch
 //   zra_dec_exec_kernel   wave per frame   pure data movement: literal + match copies of the validated sequences, frame end,
@@ -26,13 +28,15 @@ struct ZraDecFrame {
   // the compressed block handed from the parse kernel to the chain and execute kernels of the same round
   uint32_t bpos, bsize, blast;
   uint32_t litKind, litRegen, litArg;                  // 0: raw bytes at frame position litArg; 1: RLE of byte litArg; 2: literal scratch at litBase
+  uint32_t litStreams, streamOff[4], streamLen[4];     // Huffman streams (positions relative to the block content)
+  uint32_t hufErr, lateErr;                            // literal-stream failure (Huffman kernel); error of the sections behind the literals (parse kernel)
   uint32_t nbSeq, seqPos, longMode;
   uint64_t litBase, seqBase;
   // results of the chain kernel
   uint32_t chainErr, nSeqValid, seqOut, seqLit, truncated;
   uint32_t repOut[3];
-  uint8_t weights[256];
-  uint32_t rankStart[16];
+  alignas(8) uint8_t weights[256];      // kept Huffman description: weight and first decode-table cell of every symbol
+  alignas(8) uint16_t hufStart[256];
 };
 
 // one random-access slice: `len` bytes at `srcOff` inside decoded frame job `job` go to raOut + dstOff
@@ -59,6 +63,7 @@ struct ZraDecodeArgs {
   uint32_t* counters;        // see ZRA_DC_* below
   uint32_t* nextActive;      // jobs that need another round
   uint32_t* pending;         // jobs with a compressed block waiting for the chain / execute kernels
+  uint32_t* hufJobs;         // ... of those, the ones with Huffman-coded literals
   ZraDecFrame* frames;       // [nFrames]
   uint32_t* tables;          // [nFrames * ZRA_DEC_TBL_WORDS]
   uint8_t* lits; uint64_t litCap;      // literal scratch (bump-allocated per round)
@@ -73,6 +78,8 @@ struct ZraDecodeArgs {
 #define ZRA_DC_QEXEC 2
 #define ZRA_DC_NPENDING 3
 #define ZRA_DC_NNEXT 4
+#define ZRA_DC_NHUF 5
+#define ZRA_DC_QHUF 10
 #define ZRA_DC_LITCUR 6      // u64 (words 6,7)
 #define ZRA_DC_SEQCUR 8      // u64 (words 8,9)
 #define ZRA_DC_WORDS 16
