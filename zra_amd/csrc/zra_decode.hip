@@ -185,6 +185,57 @@ __device__ __forceinline__ void fill_bytes(u8* dst, u8 v, u32 n, int t, int nthr
   for (u32 i = (n8 << 3) + t; i < n; i += nthreads) dst[i] = v;
 }
 
+// Up to 64 bytes, one lane. Two rules shape this: (1) every load is issued before the first store — the compiler cannot do that
+// across a load/store loop (the ranges might alias), and a loop of dependent HBM round trips is what it turns into; (2) as few
+// vector memory INSTRUCTIONS as possible — each one occupies the CU's address unit for the whole wave whatever its width, and the
+// execute kernel is bound by exactly that. So: 8-byte words, the last one placed to END at byte n (it overlaps its neighbour
+// instead of leaving a tail of byte accesses); below 8 bytes the same with 4-, 2-, 1-byte accesses: never more than 2 + 2.
+typedef u16 __attribute__((aligned(1))) u16_a1;
+__device__ __forceinline__ void copy_le64(u8* dp, const u8* sp, u32 n) {
+  if (n >= 8) {
+    u64 w[7];
+    const u32 lastAt = n - 8;
+#pragma unroll
+    for (int c = 0; c < 7; c++) { w[c] = 0; if (8u * c < lastAt) w[c] = ld64(sp + 8 * c); }   // words at 0, 8, ... below the last one
+    const u64 wl = ld64(sp + lastAt);                                                          // the last word ends at byte n
+#pragma unroll
+    for (int c = 0; c < 7; c++) if (8u * c < lastAt) st64(dp + 8 * c, w[c]);
+    st64(dp + lastAt, wl);
+  } else if (n >= 4) {
+    const u32 a0 = ld32(sp), a1 = ld32(sp + n - 4);
+    st32(dp, a0); st32(dp + n - 4, a1);
+  } else if (n >= 2) {
+    const u32 a0 = *(const u16_a1*)sp, a1 = sp[n - 1];
+    *(u16_a1*)dp = (u16)a0; dp[n - 1] = (u8)a1;
+  } else if (n == 1) dp[0] = sp[0];
+}
+// an overlapping match of up to 64 bytes at distance `off` < n: the first period (final bytes in front of the destination) is read
+// once — into registers (period < 8: the repeated pattern is built with shifts) or into the lane's 64-byte LDS slot — and the
+// output is produced from there: no load ever waits for a store of this copy
+__device__ __forceinline__ void copy_periodic_le64(u8* dp, const u8* sp, u32 n, u32 off, u8* slot) {
+  if (off >= 8) {
+    copy_le64(slot, sp, off);                                  // (HBM -> LDS: loads first, then LDS stores)
+    u32 p = 0;
+    for (u32 k = 0; k < n; k++) { dp[k] = slot[p]; p = p + 1 == off ? 0 : p + 1; }
+    return;
+  }
+  u64 raw = 0;
+#pragma unroll
+  for (int b = 0; b < 7; b++) if ((u32)b < off) raw |= (u64)sp[b] << (8 * b);
+  u64 e0 = 0, e1 = 0;                                        // 16 bytes of the repeated pattern
+  for (u32 b = 0; b < 8; b += off) e0 |= raw << (8 * b);
+  { const u32 ph = 8 % off; const u64 rot = ph ? ((raw >> (8 * ph)) | (raw << (8 * (off - ph)))) : raw;
+    const u64 rp = rot & ((1ull << (8 * off)) - 1);
+    for (u32 b = 0; b < 8; b += off) e1 |= rp << (8 * b); }
+  u32 k = 0, ph = 0;
+  for (; k + 8 <= n; k += 8) {
+    const u64 v = ph ? ((e0 >> (8 * ph)) | (e1 << (64 - 8 * ph))) : e0;
+    st64(dp + k, v);
+    ph += 8 % off; if (ph >= off) ph -= off;
+  }
+  if (k < n) { const u64 v = ph ? ((e0 >> (8 * ph)) | (e1 << (64 - 8 * ph))) : e0; for (u32 b = 0; k + b < n; b++) dp[k + b] = (u8)(v >> (8 * b)); }
+}
+
 // ---------------------------------------------------------------------------------------------
 // literals section header + Huffman tree description; thread 0 only. Sets S.lit* / S.huf* / S.err.
 // Check order of ZSTD_decodeLiteralsBlock (zstd_decompress_block.c of 1.4.9).
@@ -984,16 +1035,40 @@ zra_dec_chain_kernel(ZraDecodeArgs a) {
 }
 
 // =================================================================================================
-// stage 3: execute
+// stage 3: execute. 64 sequences per step: wave scan of the lengths, per-lane literal runs, match copies in dependency rounds (a
+// lane is ready once its source ends before the first unfinished destination). Copies issue all their loads before their first
+// store and use as few memory instructions as possible (copy_le64): the kernel is bound by the CU's address unit and by the store
+// drains between rounds. (Measured and dropped: chasing a match's source back through the step's sequences so that it reads final
+// bytes only — sources mostly straddle sequence boundaries, 1.6 % of the matches could be followed.)
+namespace {
+struct __attribute__((aligned(16))) ExecShared {
+  u8 slot[BATCH][64];       // a lane's scratch for the first period of an overlapping match
+  u32 job;
+};
+}  // namespace
+
+#ifdef ZRA_DEC_PROFILE
+__device__ unsigned long long zra_dec_prof[16];
+#define XCNT(k, v) { if (lane == 0) atomicAdd(&zra_dec_prof[k], (unsigned long long)(v)); }
+#define XTIME(k) { __builtin_amdgcn_s_waitcnt(0); const u64 n_ = __builtin_amdgcn_s_memtime(); if (lane == 0) atomicAdd(&zra_dec_prof[k], n_ - xpt_); xpt_ = n_; }
+extern "C" __attribute__((visibility("default"))) void ZraHipDebugReadDecProfile(unsigned long long* out16, int reset) {
+  (void)hipMemcpyFromSymbol(out16, HIP_SYMBOL(zra_dec_prof), sizeof(unsigned long long) * 16);
+  if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(zra_dec_prof), z, sizeof(z)); }
+}
+#else
+#define XCNT(k, v)
+#define XTIME(k)
+#endif
+
 extern "C" __global__ void __launch_bounds__(DEC_THREADS)
 zra_dec_exec_kernel(ZraDecodeArgs a) {
-  __shared__ u32 s_job;
+  __shared__ ExecShared S;
   const int lane = threadIdx.x;
   const u32 nPend = a.counters[ZRA_DC_NPENDING];
   for (;;) {
-    if (lane == 0) s_job = atomicAdd(&a.counters[ZRA_DC_QEXEC], 1u);
+    if (lane == 0) S.job = atomicAdd(&a.counters[ZRA_DC_QEXEC], 1u);
     wsync();
-    const u32 qi = s_job;
+    const u32 qi = S.job;
     wsync();
     if (qi >= nPend) return;
     const u32 j = a.pending[qi];
@@ -1011,24 +1086,32 @@ zra_dec_exec_kernel(ZraDecodeArgs a) {
     const u64* const sq = a.seqs + F->seqBase;
 
     u32 outBase = 0, litBase = 0;              // running positions (wave-uniform)
+#ifdef ZRA_DEC_PROFILE
+    u64 xpt_ = __builtin_amdgcn_s_memtime();
+#endif
+    XCNT(8, 1)
+    u64 qNext = (u32)lane < nSeq ? sq[lane] : (1ull << 36);        // the next step's sequences are always in flight
     for (u32 first = 0; first < nSeq; first += BATCH) {
       const u32 cnt = min((u32)BATCH, nSeq - first);
       const bool act = (u32)lane < cnt;
-      const u64 q = act ? sq[first + lane] : (1ull << 36);
+      const u64 q = qNext;
+      qNext = first + BATCH + (u32)lane < nSeq ? sq[first + BATCH + lane] : (1ull << 36);
       const u32 ll = (u32)q & 0x3FFFFu, ml = (u32)(q >> 18) & 0x3FFFFu, off = (u32)(q >> 36);
       const u32 tot = ll + ml;
       const u32 incT = wave_incl_scan(tot), incL = wave_incl_scan(ll);
       const u32 oStart = outBase + incT - tot, lStart = litBase + incL - ll;
       const u32 mdst = oStart + ll;
-      // -------- literals: every lane copies its sequence's run; long runs by the whole wave, coalesced
+      const u32 stepEnd = outBase + bcast_u32(incT, 63);
+      XTIME(0) XCNT(9, 1) XCNT(10, cnt)
+      // -------- literal runs
       {
         u8* op = out + oStart;
         const bool longLit = ll > 32;
-        if (!longLit) {
+        if (!longLit && ll && !(a.debugSkip & 1)) {
           if (litKind == 1) for (u32 b = 0; b < ll; b++) op[b] = rleByte;
-          else { const u8* lp = lit + lStart; for (u32 b = 0; b < ll; b++) op[b] = lp[b]; }
+          else copy_le64(op, lit + lStart, ll);
         }
-        u64 lm = __ballot(longLit);
+        u64 lm = (a.debugSkip & 8) ? 0ull : __ballot(longLit);
         while (lm) {
           const u32 k = (u32)__builtin_ctzll(lm); lm &= lm - 1;
           const u32 jl = bcast_u32(ll, k), jo = bcast_u32(oStart, k), js = bcast_u32(lStart, k);
@@ -1037,7 +1120,8 @@ zra_dec_exec_kernel(ZraDecodeArgs a) {
         }
       }
       wsync();
-      // -------- match copies in dependency rounds: a lane is ready once its source ends before the first unfinished destination
+      XTIME(2)
+      // -------- the rest: dependency rounds — a lane is ready once its source ends before the first unfinished destination
       {
         const u32 msrc = mdst - off;
         const u32 msrcEnd = min(msrc + ml, mdst);
@@ -1048,16 +1132,10 @@ zra_dec_exec_kernel(ZraDecodeArgs a) {
           const bool mine = (pending >> lane) & 1;
           const bool ready = mine && (msrcEnd <= frontier || (u32)lane == fnd);
           const bool longM = ready && ml > 64;
-          if (ready && !longM) {
+          if (ready && !longM && !(a.debugSkip & 2)) {
             u8* dp = out + mdst; const u8* sp = dp - off;
-            if (off >= ml) {                           // no overlap: 8-byte moves + byte tail
-              u32 k = 0;
-              for (; k + 8 <= ml; k += 8) st64(dp + k, ld64(sp + k));
-              for (; k < ml; k++) dp[k] = sp[k];
-            } else {                                   // overlapping match = period `off`: read only bytes in front of the destination
-              u32 p = 0;
-              for (u32 k = 0; k < ml; k++) { dp[k] = sp[p]; p = p + 1 == off ? 0 : p + 1; }
-            }
+            if (off >= ml) copy_le64(dp, sp, ml);      // no overlap: all loads, then all stores
+            else copy_periodic_le64(dp, sp, ml, off, S.slot[lane]);  // overlapping match = period `off`: only the bytes in front of the destination are read
           }
           u64 lmk = __ballot(longM);
           while (lmk) {                            // long matches: the whole wave copies (period-safe modular source)
@@ -1068,10 +1146,12 @@ zra_dec_exec_kernel(ZraDecodeArgs a) {
             else { for (u32 k = lane; k < jml; k += WAVE) dp[k] = sp[k % jof]; }
           }
           pending &= ~__ballot(ready);
-          wsync();
+          if (!(a.debugSkip & 4)) wsync();
+          XCNT(12, 1)
         }
       }
-      outBase += bcast_u32(incT, 63); litBase += bcast_u32(incL, 63);
+      XTIME(3)
+      outBase = stepEnd; litBase += bcast_u32(incL, 63);
     }
     // ---- block tail: remaining literals (the chain kernel checked the room)
     u32 blockOut = outBase;

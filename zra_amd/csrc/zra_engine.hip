@@ -274,6 +274,7 @@ Status Engine::decode_launch(const ZraDecodeArgs& a0, const uint32_t* dExpect, u
   HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCUExec, zra_dec_exec_kernel, 64, 0));
   perCUParse = std::max(1, perCUParse); perCUExec = std::max(1, perCUExec);
   if (wavesCap > 0) { perCUParse = std::min(perCUParse, wavesCap); perCUExec = std::min(perCUExec, wavesCap); }
+  { static const int skip = std::getenv("ZRA_DEC_SKIP") ? std::atoi(std::getenv("ZRA_DEC_SKIP")) : 0; a.debugSkip = (uint32_t)skip; }
   HIPCHK(hipEventRecord(ev0_, stream_));
   uint32_t nActive = n, round = 0;
   const uint32_t* active = nullptr;

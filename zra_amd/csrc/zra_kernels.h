@@ -71,6 +71,7 @@ struct ZraDecodeArgs {
   uint32_t* status;          // [nFrames] zstd error code per frame (0 = ok)
   uint32_t* produced;        // [nFrames] bytes regenerated
   uint32_t* frameMeta;       // [2*nFrames] {1 = has checksum / 2 = stopped early (no frame-end checks), stored checksum}
+  uint32_t debugSkip;        // bring-up timing knob (ZRA_DEC_SKIP): execute kernel stage ablation; 0 in production
 };
 // counters[]: u32 words, zeroed before every round
 #define ZRA_DC_QPARSE 0
