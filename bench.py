@@ -84,52 +84,112 @@ def synth_corpus(nbytes, seed=1):
     return out
 
 
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(sample, frame_size, level, nq, qsize, seed=42):
     """Reference CPU path timed on the host: ZRA container logic (oracle/zo_zra.c, a port of zra.cpp:194-296) over the real
-    dependency libzstd 1.4.9 when the image has it, else over the oracle's own restatement. 1 thread (the reference is single-threaded)."""
+    dependency libzstd 1.4.9 when the image has it, else over the oracle's own restatement. 1 thread (the reference is single-threaded).
+    The timed spans contain the C calls only: buffers are allocated and touched before, the query loop runs in C."""
     sys.path.insert(0, os.path.join(HERE, "tests"))
     import oracle_lib as O
     backend = "zl" if O.have_libzstd() else "zo"
-    data = sample.tobytes()
-    t0 = time.perf_counter()
-    st, arc = O.zra_compress(data, level, frame_size, True, 0, backend)
-    t1 = time.perf_counter()
-    assert st == (0, 0), st
-    rng = np.random.RandomState(seed)
-    offs = rng.randint(0, len(data) - qsize - 1, size=nq)
     L = O.lib()
-    fn = getattr(L, backend + "_zra_decompress_ra")
-    abuf = (ctypes.c_char * len(arc)).from_buffer_copy(arc)
-    obuf = ctypes.create_string_buffer(qsize)
+    vp, sz = ctypes.c_void_p, ctypes.c_size_t
+    data = np.ascontiguousarray(sample)
+    n = data.size
+    cap = L.zo_zra_output_bound(n, frame_size, 0)
+    out = np.zeros(cap, dtype=np.uint8)                       # touched: no page faults inside the timed call
+    osz = sz(0)
+    fcomp = getattr(L, backend + "_zra_compress_buffer")
+    fcomp.argtypes = [vp, sz, vp, sz, ctypes.POINTER(sz), ctypes.c_int, ctypes.c_uint32, ctypes.c_int, sz]
+    t0 = time.perf_counter()
+    st = fcomp(data.ctypes.data, n, out.ctypes.data, cap, ctypes.byref(osz), level, frame_size, 1, 0)
+    t1 = time.perf_counter()
+    assert st.tup() == (0, 0), st.tup()
+    arc = out[: osz.value].tobytes()
+    rng = np.random.RandomState(seed)
+    offs = np.ascontiguousarray(rng.randint(0, n - qsize - 1, size=nq).astype(np.uint64))
+    fra = getattr(L, backend + "_zra_decompress_ra_many")
+    fra.restype = O.Status
+    fra.argtypes = [vp, sz, vp, sz, vp, sz]
+    abuf = np.frombuffer(arc, dtype=np.uint8)
+    obuf = np.zeros(qsize, dtype=np.uint8)
     t2 = time.perf_counter()
-    for o in offs:
-        fn(abuf, len(arc), obuf, qsize, int(o), qsize)
+    st = fra(abuf.ctypes.data, len(arc), obuf.ctypes.data, qsize, offs.ctypes.data, nq)
     t3 = time.perf_counter()
+    assert st.tup() == (0, 0), st.tup()
     # (ii) of SURVEY §8d: best-case CPU, NOT the reference (which is single-threaded): frames statically partitioned over T threads,
     # one libzstd context per thread (ctypes releases the GIL). Bounded: every thread compresses a 64 MiB slice.
     import threading
     T = max(1, min(64, (os.cpu_count() or 1)))
-    sl = min(len(data), 64 << 20) // frame_size * frame_size
-    piece = data[:sl]
-    def work():
-        O.zra_compress(piece, level, frame_size, True, 0, backend)
-    th = [threading.Thread(target=work) for _ in range(T)]
+    sl = min(n, 64 << 20) // frame_size * frame_size
+    outs = [np.zeros(L.zo_zra_output_bound(sl, frame_size, 0), dtype=np.uint8) for _ in range(T)]
+    def work(k):
+        o = sz(0)
+        fcomp(data.ctypes.data, sl, outs[k].ctypes.data, outs[k].size, ctypes.byref(o), level, frame_size, 1, 0)
+    th = [threading.Thread(target=work, args=(k,)) for k in range(T)]
     t4 = time.perf_counter()
     for x in th: x.start()
     for x in th: x.join()
     t5 = time.perf_counter()
     mt = T * sl / GiB / (t5 - t4)
-    comp = len(data) / GiB / (t1 - t0)
+    comp = n / GiB / (t1 - t0)
     ra = nq * qsize / GiB / (t3 - t2)
-    combined = (len(data) + nq * qsize) / GiB / ((t1 - t0) + (t3 - t2))
+    combined = (n + nq * qsize) / GiB / ((t1 - t0) + (t3 - t2))
     return {"value": round(combined, 4), "unit": "GiB/s", "cores": 1, "kind": "port",
-            "sample": "%d MiB of the same corpus: CompressBuffer L%d/%d KiB + %d DecompressRA queries of %d B; container port (oracle/zo_zra.c) over %s"
-                      % (len(data) >> 20, level, frame_size >> 10, nq, qsize, "libzstd " + O.lib().zo_libzstd_version().decode() if backend == "zl" else "the oracle's C restatement"),
+            "sample": "%d MiB of the same corpus: CompressBuffer L%d/%d KiB + %d DecompressRA queries of %d B; container port (oracle/zo_zra.c) over %s; timed spans = the C calls only"
+                      % (n >> 20, level, frame_size >> 10, nq, qsize, "libzstd " + O.lib().zo_libzstd_version().decode() if backend == "zl" else "the oracle's C restatement"),
             "compress_gibs": round(comp, 4), "ra_gibs": round(ra, 4), "ra_us_per_query": round((t3 - t2) / nq * 1e6, 1),
+            "cpu_model": _cpu_model(), "host_cpus": os.cpu_count(),
             "best_case_all_threads": {"compress_gibs": round(mt, 3), "threads": T, "host_cpus": os.cpu_count(),
                                       "cpus_allowed": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None,
                                       "cgroup_cpu_max": (open("/sys/fs/cgroup/cpu.max").read().strip() if os.path.exists("/sys/fs/cgroup/cpu.max") else None),
                                       "note": "not the reference (single-threaded): %d threads x %d MiB, one libzstd context each" % (T, sl >> 20)}}, arc
+
+
+def ra_latency_probe(Z, eng, d_arc, arc_size, d_in, N, qb, torch):
+    """Latency of small random-access batches (outside the timed region): batch sizes 1 / 64 / 4096 through the device-pointer call
+    (ZraHipDecompressRABatch) and, per query, through the reference's host-pointer call (ZraDecompressRA on a host copy of the archive)."""
+    out = {}
+    rng = np.random.RandomState(7)
+    dev = d_in.device
+    for bs, reps in ((1, 40), (64, 20), (4096, 8)):
+        d_o = torch.empty(bs * qb + 64, dtype=torch.uint8, device=dev)
+        sizes = np.full(bs, qb, dtype=np.uint64); oo = np.arange(bs, dtype=np.uint64) * qb
+        ts = []
+        for r in range(reps + 2):
+            offs = rng.randint(0, N - qb - 1, size=bs).astype(np.uint64)
+            torch.cuda.synchronize(); t = time.perf_counter()
+            eng.decompress_ra_batch(d_arc.data_ptr(), arc_size, d_o.data_ptr(), offs, sizes, oo)
+            ts.append(time.perf_counter() - t)
+        if not torch.equal(d_o[:qb], d_in[int(offs[0]): int(offs[0]) + qb]):
+            raise SystemExit("RA latency probe: wrong bytes")
+        ts = sorted(ts[2:])
+        out["device_batch_%d" % bs] = {"us_per_call_median": round(ts[len(ts) // 2] * 1e6, 1), "us_per_query": round(ts[len(ts) // 2] * 1e6 / bs, 2)}
+    # host-pointer ABI, one query per call (the reference's calling convention); the archive copy to the host is not timed
+    h_arc = d_arc[:arc_size].cpu().numpy()
+    L = Z.load()
+    abuf = ctypes.c_void_p(h_arc.ctypes.data)
+    obuf = ctypes.create_string_buffer(qb)
+    ts = []
+    for r in range(42):
+        o = int(rng.randint(0, N - qb - 1))
+        t = time.perf_counter()
+        st = L.ZraDecompressRA(abuf, arc_size, obuf, o, qb)
+        ts.append(time.perf_counter() - t)
+        if st.zra != 0:
+            raise SystemExit("ZraDecompressRA failed in the latency probe")
+    ts = sorted(ts[2:])
+    out["host_ZraDecompressRA"] = {"us_per_call_median": round(ts[len(ts) // 2] * 1e6, 1)}
+    return out
 
 
 def main():
@@ -297,6 +357,10 @@ def main():
             ra_classes["%d_KiB" % (qsz >> 10)] = {"queries": nq2, "us_per_query": round(dq / nq2 * 1e6, 3), "gibs_returned": round(nq2 * qsz / GiB / dq, 3)}
             del d2
 
+    ra_latency = None
+    if world == 1 and not args.no_cpu_baseline:
+        ra_latency = ra_latency_probe(Z, eng, d_arc, arc_size, d_in, N, qb, torch)
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         moved = (N + q * qb) * world
@@ -336,6 +400,7 @@ def main():
             "ra_gibs_returned": round(q * qb * world / GiB / (np.mean(ra_ms) / 1e3), 3),
             "ra_us_per_query": round(np.mean(ra_ms) * 1e3 / q, 3),
             "ra_size_classes": ra_classes,
+            "ra_latency": ra_latency,
             "roofline": {"bound": "hbm", "kernel": "zra_mf_dfast_kernel" if args.level in (3, 4) else "zra_mf_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "frac_of_measured_6290": round(achieved / 6290.0, 5), "traffic": traffic,
                          "launch_ms": round(mf_launch_ms, 3), "launches_per_call": launches, "algorithmic_bytes_per_launch": int(alg_per_launch),

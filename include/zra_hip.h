@@ -36,6 +36,9 @@ ZRA_EXPORT ZraStatus ZraHipSynchronize(ZraHipEngine* engine);
  *  for it, with no host synchronisation. Every ZraHip* compute call is host-synchronous on return: its outputs are complete and
  *  visible to any stream. */
 ZRA_EXPORT ZraStatus ZraHipWaitStream(ZraHipEngine* engine, void* producerStream);
+/** Returns the engine's scratch allocations to the device. Scratch is grow-only between calls (a level-9 compression of a large
+ *  buffer keeps tens of GiB for its hash-chain tables); a long-running host that is done with such a phase can hand it back. */
+ZRA_EXPORT ZraStatus ZraHipReleaseScratch(ZraHipEngine* engine);
 /** The engine's hipStream_t, as an opaque pointer (for event timing on the stream kernels run on). */
 ZRA_EXPORT void* ZraHipGetStream(ZraHipEngine* engine);
 

@@ -212,6 +212,18 @@ zo_status zl_zra_compress_buffer(const void* in, size_t n, void* out, size_t out
 }
 zo_status zl_zra_decompress_buffer(const void* in, size_t n, void* out, size_t outCap) { return decompress_buffer(1, (const u8*)in, n, (u8*)out, outCap); }
 zo_status zl_zra_decompress_ra(const void* in, size_t n, void* out, size_t outCap, size_t offset, size_t size) { return decompress_ra(1, (const u8*)in, n, (u8*)out, outCap, offset, size); }
+/* nq DecompressRA calls of `size` bytes in one C loop (bench.py's CPU baseline: no per-query interpreter overhead in the timed span);
+   returns the first failing status */
+static zo_status ra_many(int backend, const void* in, size_t n, void* out, size_t size, const u64* offs, size_t nq) {
+  for (size_t q = 0; q < nq; q++) {
+    zo_status s = decompress_ra(backend, (const u8*)in, n, (u8*)out, size, (size_t)offs[q], size);
+    if (s.zra) return s;
+  }
+  return st(ZRA_Success, 0);
+}
+zo_status zo_zra_decompress_ra_many(const void* in, size_t n, void* out, size_t size, const u64* offs, size_t nq) { return ra_many(0, in, n, out, size, offs, nq); }
+zo_status zl_zra_decompress_ra_many(const void* in, size_t n, void* out, size_t size, const u64* offs, size_t nq) { return ra_many(1, in, n, out, size, offs, nq); }
+
 /* raw per-frame access to the dependency, for pinning zo_compress_frame / zo_decompress */
 size_t zl_compress_frame(void* dst, size_t cap, const void* src, size_t n, int level, int checksum) {
   codec k; int err;

@@ -516,25 +516,59 @@ def test_device_api_at_baseline_size_properties(zra, gpu_engine):
 
 
 def test_cli_tool_and_stock_zstd_interop(zra, tmp_path):
-    """zratool counterpart (zra_amd/tools/zratool_amd, argv order of zratool.cpp:100-105) + the on-disk format is a stock zstd stream
-    (README.md:16 of the reference): `zstd -d` of an archive we wrote restores the input."""
+    """zratool counterpart (zra_amd/tools/zratool_amd: the reference's argv and output names, zratool.cpp:98-125) + the on-disk format is a
+    stock zstd stream (README.md:16 of the reference): `zstd -d` of an archive we wrote restores the input."""
     import shutil
     import subprocess
     tool = os.path.join(os.path.dirname(zra.LIB_PATH), "tools", "zratool_amd")
     assert os.path.exists(tool), "build() must produce the CLI"
     data = C.gen_E(1 << 20)[100000:100000 + 700001]
-    src = tmp_path / "in.bin"
-    src.write_bytes(data)
     st, ref = O.zra_compress(data, 3, 16384, True)
-    for mode, out in (("imc", "a.zra"), ("c", "b.zra")):
-        subprocess.check_call([tool, mode, str(src), str(tmp_path / out), "3", "16384"], stdout=subprocess.DEVNULL)
-        assert (tmp_path / out).read_bytes() == ref, mode           # streaming == in-memory == oracle bytes
-    for mode, out in (("imd", "a.out"), ("d", "b.out")):
-        subprocess.check_call([tool, mode, str(tmp_path / "a.zra"), str(tmp_path / out)], stdout=subprocess.DEVNULL)
-        assert (tmp_path / out).read_bytes() == data, mode
-    txt = subprocess.check_output([tool, "b", str(src), str(tmp_path / "bench.zra"), "3", "65536"]).decode()
+    for mode in ("imc", "c"):
+        d = tmp_path / mode
+        d.mkdir()
+        (d / "in.bin").write_bytes(data)
+        out = subprocess.check_output([tool, mode, str(d / "in.bin"), "3", "16384"]).decode()
+        assert (d / "in.bin.zra").read_bytes() == ref, mode           # streaming == in-memory == oracle bytes
+        assert "Output Size (%s)" % (d / "in.bin.zra") in out
+        (d / "in.bin").unlink()
+        subprocess.check_call([tool, "imd" if mode == "imc" else "d", str(d / "in.bin.zra")], stdout=subprocess.DEVNULL)
+        assert (d / "in.bin").read_bytes() == data, mode               # ".zra" removed = the output name (zratool.cpp:90-95)
+    (tmp_path / "b.bin").write_bytes(data)
+    txt = subprocess.check_output([tool, "b", str(tmp_path / "b.bin"), "3", "65536"]).decode()
     assert "MISMATCH" not in txt and "==" in txt
     zstd = shutil.which("zstd") or ("/opt/conda/bin/zstd" if os.path.exists("/opt/conda/bin/zstd") else None)
     if zstd:
-        out = subprocess.check_output([zstd, "-d", "-c", str(tmp_path / "a.zra")])
+        out = subprocess.check_output([zstd, "-d", "-c", str(tmp_path / "c" / "in.bin.zra")])
         assert out == data
+
+
+def test_config_c1_zratool_64mib_incompressible(zra, tmp_path):
+    """BASELINE config C1: zratool compress + decompress of a 64 MiB random dump, frameSize 64 KiB, level 3 — through the CLI counterpart
+    with the reference's argv. Known answers recorded from the reference: every frame is a raw block of 65,549 bytes
+    (13 bytes of overhead), 1,025 seek-table entries, archive 67,127,339 bytes; streaming and in-memory archives are the same bytes."""
+    import shutil
+    import subprocess
+    tool = os.path.join(os.path.dirname(zra.LIB_PATH), "tools", "zratool_amd")
+    N = 64 << 20
+    x = np.random.RandomState(0x5A52).randint(0, 256, size=N, dtype=np.uint8).tobytes()       # (any incompressible bytes give these sizes)
+    archives = {}
+    for mode in ("c", "imc"):
+        d = tmp_path / mode
+        d.mkdir()
+        (d / "dump.bin").write_bytes(x)
+        subprocess.check_call([tool, mode, str(d / "dump.bin"), "3", "65536"], stdout=subprocess.DEVNULL)
+        arc = (d / "dump.bin.zra").read_bytes()
+        archives[mode] = arc
+        assert len(arc) == 67127339
+        assert int.from_bytes(arc[26:30], "little") == 1025 and int.from_bytes(arc[30:34], "little") == 65536
+        ent = np.frombuffer(arc[38:38 + 5 * 1025], dtype=np.uint8).reshape(1025, 5).astype(np.int64)
+        offs = ent[:, 0] | (ent[:, 1] << 8) | (ent[:, 2] << 16) | (ent[:, 3] << 24) | (ent[:, 4] << 32)
+        assert offs[0] == 0 and np.all(np.diff(offs) == 65549)
+        (d / "dump.bin").unlink()
+        subprocess.check_call([tool, "d" if mode == "c" else "imd", str(d / "dump.bin.zra")], stdout=subprocess.DEVNULL)
+        assert (d / "dump.bin").read_bytes() == x
+    assert archives["c"] == archives["imc"]
+    zstd = shutil.which("zstd") or ("/opt/conda/bin/zstd" if os.path.exists("/opt/conda/bin/zstd") else None)
+    if zstd:
+        assert subprocess.check_output([zstd, "-d", "-c", str(tmp_path / "c" / "dump.bin.zra")]) == x

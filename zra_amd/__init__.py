@@ -92,6 +92,7 @@ def load():
         "ZraHipSynchronize": (S, [vp]),
         "ZraHipGetStream": (vp, [vp]),
         "ZraHipWaitStream": (S, [vp, vp]),
+        "ZraHipReleaseScratch": (S, [vp]),
         "ZraHipLastKernelMs": (ctypes.c_double, [vp]),
         "ZraHipGetKernelStats": (None, [vp, ctypes.POINTER(ctypes.c_double)]),
         "ZraHipCompressBuffer": (S, [vp, vp, sz, vp, szp, ctypes.c_int8, u32, ctypes.c_bool]),
@@ -117,7 +118,7 @@ C_ABI_SYMBOLS = [
     "ZraDecompressWithDecompressor", "ZraCreateFullDecompressor", "ZraDeleteFullDecompressor", "ZraGetHeaderWithFullDecompressor",
     "ZraDecompressWithFullDecompressor",
 ]
-HIP_ABI_SYMBOLS = ["ZraHipDeviceCount", "ZraHipCreateEngine", "ZraHipDestroyEngine", "ZraHipSynchronize", "ZraHipGetStream", "ZraHipWaitStream", "ZraHipLastKernelMs", "ZraHipGetKernelStats",
+HIP_ABI_SYMBOLS = ["ZraHipDeviceCount", "ZraHipCreateEngine", "ZraHipDestroyEngine", "ZraHipSynchronize", "ZraHipGetStream", "ZraHipWaitStream", "ZraHipReleaseScratch", "ZraHipLastKernelMs", "ZraHipGetKernelStats",
                    "ZraHipCompressBuffer", "ZraHipDecompressBuffer", "ZraHipDecompressRABatch", "ZraHipCompressFrames", "ZraHipStitchHeader", "ZraHipDebugReadSeqs", "ZraHipSetOptions", "ZraHipGetOptions"]
 
 
@@ -188,6 +189,10 @@ class Engine:
     def wait_stream(self, stream_handle=None):
         """Orders the engine's streams behind work queued on `stream_handle` (a hipStream_t as int; None = the null stream)."""
         _chk(self.L.ZraHipWaitStream(self.h, ctypes.c_void_p(stream_handle or 0)))
+
+    def release_scratch(self):
+        """Hands the engine's (grow-only) scratch back to the device."""
+        _chk(self.L.ZraHipReleaseScratch(self.h))
 
     def _order(self):
         # inputs are usually torch tensors produced asynchronously on torch's current stream: make the engine wait for that stream

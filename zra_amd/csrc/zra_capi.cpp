@@ -545,6 +545,7 @@ ZraStatus ZraHipCreateEngine(ZraHipEngine** engine, int device) {
 }
 void ZraHipDestroyEngine(ZraHipEngine* engine) { if (engine) { delete engine->e; delete engine; } }
 ZraStatus ZraHipSynchronize(ZraHipEngine* engine) { return mk(engine->e->sync()); }
+ZraStatus ZraHipReleaseScratch(ZraHipEngine* engine) { return mk(engine->e->release_scratch()); }
 ZraStatus ZraHipWaitStream(ZraHipEngine* engine, void* producerStream) { return mk(engine->e->wait_stream((hipStream_t)producerStream)); }
 void* ZraHipGetStream(ZraHipEngine* engine) { return (void*)engine->e->stream(); }
 double ZraHipLastKernelMs(ZraHipEngine* engine) { return engine->e->last_kernel_ms(); }

@@ -41,6 +41,9 @@ class Engine {
   // themselves against the caller's streams. Work queued on `producer` before this call completes before anything the engine
   // launches afterwards (an event wait, no host synchronisation). Outputs are complete when an engine call returns.
   Status wait_stream(hipStream_t producer);
+  // gives every scratch allocation of this engine back to the device (they are grow-only otherwise and can reach tens of GiB after a
+  // large level-9 compression); the next call allocates again what it needs
+  Status release_scratch();
   double last_kernel_ms() const { return lastKernelMs_; }
   // HIP-event timings of the last call on the engine's stream: {mf ms, mf launches, entropy ms, entropy launches, decode ms, decode launches}
   void kernel_stats(double out[6]) const { for (int i = 0; i < 6; i++) out[i] = kstats_[i]; }

@@ -220,6 +220,17 @@ Status Engine::create(Engine** out, int device) {
   return ok();
 }
 
+Status Engine::release_scratch() {
+  HIPCHK(hipSetDevice(device_));
+  HIPCHK(hipStreamSynchronize(stream_));
+  HIPCHK(hipStreamSynchronize(stream2_));
+  for (DevBuf* b : {&raPlan_, &raLimit_, &raPieceBase_, &raPieces_, &decFrames_, &decTables_, &decLists_, &decCounters_, &decLits_, &decSeqs_, &status_,
+                    &produced_, &frameMeta_, &frameOff_, &outOff_, &expect_, &result_, &temp_, &qmeta_, &encScan_, &hostIn_, &hostOut_, &seqScratch_})
+    b->release();
+  for (auto& x : encCtx_) for (DevBuf* b : {&x.tables, &x.seqs, &x.lits, &x.slots, &x.misc, &x.ck, &x.sizes}) b->release();
+  return ok();
+}
+
 Engine::~Engine() {
   (void)hipSetDevice(device_);
   if (stream_) (void)hipStreamSynchronize(stream_);
