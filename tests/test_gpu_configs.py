@@ -98,6 +98,11 @@ def test_config_c3_16gib_1m_random_access_queries(zra, gpu_engine):
     d_ra = torch.zeros(Q * qb + 64, dtype=torch.uint8, device=dev)
     gpu_engine.decompress_ra_batch(d_arc.data_ptr(), n1, d_ra.data_ptr(), offs, sizes, oo)
     assert _all_queries_equal(torch, d_ra, d_in, offs, qb)
+    # small batches (per-slice jobs, nothing proportional to the archive's 262,144 frames): 1, 64 and 4096 queries
+    for k in (1, 64, 4096):
+        d_ra[: k * qb].zero_()
+        gpu_engine.decompress_ra_batch(d_arc.data_ptr(), n1, d_ra.data_ptr(), offs[1000:1000 + k], sizes[:k], oo[:k])
+        assert _all_queries_equal(torch, d_ra, d_in, offs[1000:1000 + k], qb)
     # whole-frame mode (reference error behaviour: every touched frame decoded in full, checksums verified) returns the same bytes
     zra.load().ZraHipSetOptions(8)
     try:

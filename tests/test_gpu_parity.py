@@ -313,6 +313,26 @@ def test_randomised_batched_random_access(zra, gpu_engine, seed):
     for i in range(nq):
         o, sz, oo = int(offs[i]), int(sizes[i]), int(oofs[i])
         assert host[oo: oo + sz] == data[o: o + sz], (seed, i, o, sz)
+    # small batches take the per-slice job path (no pass over the archive's frames): 1..12 queries, zero-size ones among them,
+    # also with every touched frame decoded in full and its checksum verified (option bit 8)
+    for whole in (0, 8):
+        zra.load().ZraHipSetOptions(whole)
+        try:
+            for k in (1, 2, 5, 12):
+                sel = rng.choice(nq, size=k, replace=False)
+                so, ss = offs[sel].copy(), np.minimum(sizes[sel], 2 * fs + 3)
+                if k >= 5:
+                    ss[1] = 0
+                so2 = np.concatenate([[0], np.cumsum(ss)[:-1]])
+                d_out[: int(ss.sum()) + 1].fill_(0xEE)
+                gpu_engine.decompress_ra_batch(d_arc.data_ptr(), asz, d_out.data_ptr(), so, ss, so2)
+                host = d_out[: int(ss.sum()) + 1].cpu().numpy().tobytes()
+                for i in range(k):
+                    o, sz, oo = int(so[i]), int(ss[i]), int(so2[i])
+                    assert host[oo: oo + sz] == data[o: o + sz], (seed, whole, k, i, o, sz)
+                assert host[int(ss.sum())] == 0xEE
+        finally:
+            zra.load().ZraHipSetOptions(0)
     bad_offs = offs.copy(); bad_offs[7] = n - int(sizes[7])                    # offset + size == uncompressedSize -> refused
     with pytest.raises(zra.ZraError) as e:
         gpu_engine.decompress_ra_batch(d_arc.data_ptr(), asz, d_out.data_ptr(), bad_offs, sizes, oofs)

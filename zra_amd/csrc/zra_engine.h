@@ -44,6 +44,8 @@ class Engine {
   // gives every scratch allocation of this engine back to the device (they are grow-only otherwise and can reach tens of GiB after a
   // large level-9 compression); the next call allocates again what it needs
   Status release_scratch();
+  std::vector<uint64_t> raHostQ_;
+  int decOccParse_ = 0, decOccExec_ = 0;
   double last_kernel_ms() const { return lastKernelMs_; }
   // HIP-event timings of the last call on the engine's stream: {mf ms, mf launches, entropy ms, entropy launches, decode ms, decode launches}
   void kernel_stats(double out[6]) const { for (int i = 0; i < 6; i++) out[i] = kstats_[i]; }
@@ -60,7 +62,7 @@ class Engine {
                      uint64_t seqTotal = 0, const struct ZraDecodeArgs* ra = nullptr);
   // one pass: jobs [0, a.nFrames) of the arrays in `a` through the parse / chain / execute rounds + frame-end checks;
   // *res = min over failing jobs of ((jobBase + job) << 8 | code), untouched when none fails
-  Status decode_launch(const struct ZraDecodeArgs& a, const uint32_t* dExpect, uint32_t maxFrameBytes, uint32_t jobBase);
+  Status decode_launch(const struct ZraDecodeArgs& a, const uint32_t* dExpect, uint32_t maxFrameBytes, uint32_t jobBase, unsigned long long* hResult);
   // Whole archive resident on the device (header + body), output on the device.
   Status decompress_device(const uint8_t* dArc, size_t arcSize, uint8_t* dOut, size_t outCap);
   // Batched random access, archive + output on the device, query arrays on the host.

@@ -169,6 +169,36 @@ __global__ void zra_ra_fill_kernel(const u64* q, u32 nq, u64 fs, RaPlan P, const
   }
 }
 
+// small batches (far fewer slices than the archive has frames): one decode job per slice, built from the query alone — no pass over
+// the frames of the archive, no count/scan, nothing read back. A frame two slices share is decoded once per slice.
+__global__ void zra_ra_direct_kernel(const u64* q, u32 nq, u32 nPieces, u64 fs, u64 total, const u8* table, u32 fullFrames, u64* frameOff, u64* outOff,
+                                     u32* outCap, u32* limit, u32* pieceBase, ZraRaPiece* pieces) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) pieceBase[nPieces] = nPieces;
+  if (i >= nq) return;
+  const u64 off = q[4 * (size_t)i], size = q[4 * (size_t)i + 1], dst = q[4 * (size_t)i + 2];
+  if (!size) return;
+  const u64 f0 = off / fs, f1 = (off + size - 1) / fs;
+  u32 st = (u32)q[4 * (size_t)i + 3];
+  u64 done = 0;
+  for (u64 f = f0; f <= f1; f++, st++) {
+    const u8* e = table + (size_t)f * 5;
+    frameOff[2 * (size_t)st] = (u64)ld32(e) | ((u64)e[4] << 32);
+    frameOff[2 * (size_t)st + 1] = (u64)ld32(e + 5) | ((u64)e[9] << 32);
+    const u64 o = f * fs;
+    const u32 expect = o >= total ? 0u : (u32)(total - o < fs ? total - o : fs);
+    const u32 srcOff = f == f0 ? (u32)(off % fs) : 0u;
+    const u64 len = min<u64>(fs - srcOff, size - done);
+    outOff[st] = (u64)st * fs;
+    outCap[st] = expect;
+    limit[st] = fullFrames ? expect : min((u32)(srcOff + len), expect);
+    pieceBase[st] = st;
+    ZraRaPiece pc; pc.dstOff = dst + done; pc.srcOff = srcOff; pc.len = (u32)len;
+    pieces[st] = pc;
+    done += len;
+  }
+}
+
 }  // namespace
 
 // =================================================================================================
@@ -259,7 +289,7 @@ Status Engine::wait_stream(hipStream_t producer) {
 
 // One pass of the decoder over the jobs of `a0`: rounds of parse -> chain -> execute (a round = one compressed block of every
 // unfinished frame) until no frame is left, then the content checksums and the first-error reduction.
-Status Engine::decode_launch(const ZraDecodeArgs& a0, const uint32_t* dExpect, uint32_t maxFrameBytes, uint32_t jobBase) {
+Status Engine::decode_launch(const ZraDecodeArgs& a0, const uint32_t* dExpect, uint32_t maxFrameBytes, uint32_t jobBase, unsigned long long* hResult) {
   ZraDecodeArgs a = a0;
   const uint32_t n = a.nFrames;
   // scratch of a round: Huffman-decoded literals and decoded sequences of one block per frame, bump-allocated on the device
@@ -280,10 +310,12 @@ Status Engine::decode_launch(const ZraDecodeArgs& a0, const uint32_t* dExpect, u
   a.lits = decLits_.as<uint8_t>(); a.litCap = litCap; a.seqs = decSeqs_.as<uint64_t>(); a.seqCap = seqCap;
   a.status = status_.as<uint32_t>(); a.produced = produced_.as<uint32_t>(); a.frameMeta = frameMeta_.as<uint32_t>();
   static const int wavesCap = std::getenv("ZRA_DEC_WAVES") ? std::atoi(std::getenv("ZRA_DEC_WAVES")) : 0;   // bring-up: occupancy sweep
-  int perCUParse = 0, perCUExec = 0;
-  HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCUParse, zra_dec_parse_kernel, 64, 0));
-  HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCUExec, zra_dec_exec_kernel, 64, 0));
-  perCUParse = std::max(1, perCUParse); perCUExec = std::max(1, perCUExec);
+  if (!decOccParse_) {
+    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&decOccParse_, zra_dec_parse_kernel, 64, 0));
+    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&decOccExec_, zra_dec_exec_kernel, 64, 0));
+    decOccParse_ = std::max(1, decOccParse_); decOccExec_ = std::max(1, decOccExec_);
+  }
+  int perCUParse = decOccParse_, perCUExec = decOccExec_;
   if (wavesCap > 0) { perCUParse = std::min(perCUParse, wavesCap); perCUExec = std::min(perCUExec, wavesCap); }
   { static const int skip = std::getenv("ZRA_DEC_SKIP") ? std::atoi(std::getenv("ZRA_DEC_SKIP")) : 0; a.debugSkip = (uint32_t)skip; }
   HIPCHK(hipEventRecord(ev0_, stream_));
@@ -313,6 +345,7 @@ Status Engine::decode_launch(const ZraDecodeArgs& a0, const uint32_t* dExpect, u
                      produced_.as<uint32_t>(), frameMeta_.as<uint32_t>(), status_.as<uint32_t>(), n);
   hipLaunchKernelGGL(zra_first_error_kernel, dim3((n + tb - 1) / tb), dim3(tb), 0, stream_, status_.as<uint32_t>(), n, jobBase,
                      result_.as<unsigned long long>());
+  HIPCHK(hipMemcpyAsync(hResult, result_.p, 8, hipMemcpyDeviceToHost, stream_));
   HIPCHK(hipStreamSynchronize(stream_));
   HIPCHK(hipGetLastError());
   float ms = 0;
@@ -341,17 +374,15 @@ Status Engine::decode_jobs(const uint8_t* dBody, uint64_t bodySize, const uint64
   const uint64_t perFrame = std::min<uint64_t>((uint64_t)maxFrameBytes + 16, (128u << 10) + 16);
   static const uint64_t passBytes = std::getenv("ZRA_DEC_PASS_MIB") ? (uint64_t)std::atoll(std::getenv("ZRA_DEC_PASS_MIB")) << 20 : 16ull << 30;
   const uint32_t passFrames = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(nFrames, passBytes / perFrame));
+  unsigned long long res = ~0ull;
   for (uint32_t p0 = 0; p0 < nFrames; p0 += passFrames) {
     ZraDecodeArgs b = a;
     b.nFrames = std::min(passFrames, nFrames - p0);
     b.frameOff = dFrameOff + (size_t)p0 * offStride; b.outOff = dOutOff + p0; b.outCap = dExpect + p0;
     if (ra) { if (ra->limit) b.limit = ra->limit + p0; if (ra->pieceBase) b.pieceBase = ra->pieceBase + p0; }
-    Status st = decode_launch(b, dExpect + p0, maxFrameBytes, p0);
+    Status st = decode_launch(b, dExpect + p0, maxFrameBytes, p0, &res);
     if (st.zra) return st;
   }
-  unsigned long long res = 0;
-  HIPCHK(hipMemcpyAsync(&res, result_.p, 8, hipMemcpyDeviceToHost, stream_));
-  HIPCHK(hipStreamSynchronize(stream_));
   if (res == ~0ull) return ok();
   const uint32_t code = (uint32_t)(res & 0xFF), first = (uint32_t)(res >> 8);
   const bool resize = code == 255 /* ZE_SIZE_MISMATCH */ || code == 70;
@@ -370,9 +401,8 @@ Status Engine::decode_jobs(const uint8_t* dBody, uint64_t bodySize, const uint64
     ZraDecodeArgs b = a;
     b.frameOff = dFrameOff + (size_t)f * offStride; b.outOff = dCur; b.outCap = dCap; b.nFrames = 1;
     b.limit = nullptr; b.pieceBase = nullptr; b.pieces = nullptr;
-    Status st = decode_launch(b, nullptr, (uint32_t)std::min<uint64_t>(cap, 0x7FFFFFFFu), f);
+    Status st = decode_launch(b, nullptr, (uint32_t)std::min<uint64_t>(cap, 0x7FFFFFFFu), f, &res);
     if (st.zra) return st;
-    HIPCHK(hipMemcpyAsync(&res, result_.p, 8, hipMemcpyDeviceToHost, stream_));
     uint32_t got = 0;
     HIPCHK(hipMemcpyAsync(&got, produced_.p, 4, hipMemcpyDeviceToHost, stream_));
     HIPCHK(hipStreamSynchronize(stream_));
@@ -448,35 +478,56 @@ Status Engine::decompress_ra_batch(const uint8_t* dArc, size_t arcSize, uint8_t*
   if (nq == 0 || fs == 0 || nFrames == 0) return ok();
   if (nq > 0xFFFFFFF0ull) return zerr(64);
 
-  // queries -> device (offset, size, destination) triples
-  std::vector<uint64_t> hq(3 * nq);
-  for (size_t q = 0; q < nq; q++) { hq[3 * q] = hOff[q]; hq[3 * q + 1] = hSize[q]; hq[3 * q + 2] = hOutOff[q]; }
-  const size_t planWords = 4 * (size_t)nFrames + 16;
-  if (!qmeta_.reserve(hq.size() * 8 + 64) || !raPlan_.reserve(planWords * 4)) return zerr(64);
-  HIPCHK(hipMemcpyAsync(qmeta_.p, hq.data(), hq.size() * 8, hipMemcpyHostToDevice, stream_));
-  HIPCHK(hipMemsetAsync(raPlan_.p, 0, planWords * 4, stream_));
-  RaPlan P;
-  P.cnt = raPlan_.as<uint32_t>(); P.need = P.cnt + nFrames; P.slot = P.need + nFrames; P.cursor = P.slot + nFrames; P.totals = P.cursor + nFrames;
-  const uint64_t* dQ = qmeta_.as<uint64_t>();
-  hipLaunchKernelGGL(zra_ra_count_kernel, dim3((uint32_t)((nq + 255) / 256)), dim3(256), 0, stream_, dQ, (u32)nq, (u64)fs, P);
-  // job arrays sized for "every frame touched"; slices for "every query crosses every frame boundary it can"
+  // slices: one per frame a query touches
   uint64_t maxPieces = 0;
   for (size_t q = 0; q < nq; q++) maxPieces += hSize[q] ? (hOff[q] + hSize[q] - 1) / fs - hOff[q] / fs + 1 : 0;
+  if (maxPieces == 0) return ok();
   const uint64_t tempBudget = 16ull << 30;
   const uint32_t passSlots = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(nFrames, tempBudget / fs));
-  if (!frameOff_.reserve(((size_t)nFrames + 1) * 16) || !outOff_.reserve((size_t)nFrames * 8) || !expect_.reserve((size_t)nFrames * 4) ||
-      !raLimit_.reserve((size_t)nFrames * 4) || !raPieceBase_.reserve(((size_t)nFrames + 1) * 4) || !raPieces_.reserve((size_t)maxPieces * sizeof(ZraRaPiece) + 64))
+  const bool direct = maxPieces * 8 <= nFrames && maxPieces <= passSlots;
+  const size_t nJobsMax = direct ? (size_t)maxPieces : (size_t)nFrames;
+  if (!frameOff_.reserve((nJobsMax + 1) * 16) || !outOff_.reserve(nJobsMax * 8) || !expect_.reserve(nJobsMax * 4) ||
+      !raLimit_.reserve(nJobsMax * 4) || !raPieceBase_.reserve((nJobsMax + 1) * 4) || !raPieces_.reserve((size_t)maxPieces * sizeof(ZraRaPiece) + 64))
     return zerr(64);
-  hipLaunchKernelGGL(zra_ra_plan_kernel, dim3(1), dim3(1024), 0, stream_, P, nFrames, dArc + h.seekTableOffset, (u64)fs, (u64)U, passSlots,
-                     raVerifyWholeFrames_ ? 1u : 0u, frameOff_.as<uint64_t>(), outOff_.as<uint64_t>(), expect_.as<uint32_t>(), raLimit_.as<uint32_t>(),
-                     raPieceBase_.as<uint32_t>());
-  hipLaunchKernelGGL(zra_ra_fill_kernel, dim3((uint32_t)((nq + 255) / 256)), dim3(256), 0, stream_, dQ, (u32)nq, (u64)fs, P, raPieceBase_.as<uint32_t>(),
-                     raPieces_.as<ZraRaPiece>());
-  uint32_t totals[2] = {0, 0};
-  HIPCHK(hipMemcpyAsync(totals, P.totals, 8, hipMemcpyDeviceToHost, stream_));
-  HIPCHK(hipStreamSynchronize(stream_));
-  HIPCHK(hipGetLastError());
-  const uint32_t touched = totals[0];
+  uint32_t touched = 0;
+  if (direct) {
+    // queries -> device (offset, size, destination, first slice) tuples
+    std::vector<uint64_t>& hq = raHostQ_;            // lives until the decode below has synchronised
+    hq.resize(4 * nq);
+    uint64_t first = 0;
+    for (size_t q = 0; q < nq; q++) {
+      hq[4 * q] = hOff[q]; hq[4 * q + 1] = hSize[q]; hq[4 * q + 2] = hOutOff[q]; hq[4 * q + 3] = first;
+      first += hSize[q] ? (hOff[q] + hSize[q] - 1) / fs - hOff[q] / fs + 1 : 0;
+    }
+    if (!qmeta_.reserve(hq.size() * 8 + 64)) return zerr(64);
+    HIPCHK(hipMemcpyAsync(qmeta_.p, hq.data(), hq.size() * 8, hipMemcpyHostToDevice, stream_));
+    hipLaunchKernelGGL(zra_ra_direct_kernel, dim3((uint32_t)((nq + 255) / 256)), dim3(256), 0, stream_, qmeta_.as<uint64_t>(), (u32)nq, (u32)maxPieces, (u64)fs,
+                       (u64)U, dArc + h.seekTableOffset, raVerifyWholeFrames_ ? 1u : 0u, frameOff_.as<uint64_t>(), outOff_.as<uint64_t>(),
+                       expect_.as<uint32_t>(), raLimit_.as<uint32_t>(), raPieceBase_.as<uint32_t>(), raPieces_.as<ZraRaPiece>());
+    touched = (uint32_t)maxPieces;
+  } else {
+    // queries -> device (offset, size, destination) triples
+    std::vector<uint64_t> hq(3 * nq);
+    for (size_t q = 0; q < nq; q++) { hq[3 * q] = hOff[q]; hq[3 * q + 1] = hSize[q]; hq[3 * q + 2] = hOutOff[q]; }
+    const size_t planWords = 4 * (size_t)nFrames + 16;
+    if (!qmeta_.reserve(hq.size() * 8 + 64) || !raPlan_.reserve(planWords * 4)) return zerr(64);
+    HIPCHK(hipMemcpyAsync(qmeta_.p, hq.data(), hq.size() * 8, hipMemcpyHostToDevice, stream_));
+    HIPCHK(hipMemsetAsync(raPlan_.p, 0, planWords * 4, stream_));
+    RaPlan P;
+    P.cnt = raPlan_.as<uint32_t>(); P.need = P.cnt + nFrames; P.slot = P.need + nFrames; P.cursor = P.slot + nFrames; P.totals = P.cursor + nFrames;
+    const uint64_t* dQ = qmeta_.as<uint64_t>();
+    hipLaunchKernelGGL(zra_ra_count_kernel, dim3((uint32_t)((nq + 255) / 256)), dim3(256), 0, stream_, dQ, (u32)nq, (u64)fs, P);
+    hipLaunchKernelGGL(zra_ra_plan_kernel, dim3(1), dim3(1024), 0, stream_, P, nFrames, dArc + h.seekTableOffset, (u64)fs, (u64)U, passSlots,
+                       raVerifyWholeFrames_ ? 1u : 0u, frameOff_.as<uint64_t>(), outOff_.as<uint64_t>(), expect_.as<uint32_t>(), raLimit_.as<uint32_t>(),
+                       raPieceBase_.as<uint32_t>());
+    hipLaunchKernelGGL(zra_ra_fill_kernel, dim3((uint32_t)((nq + 255) / 256)), dim3(256), 0, stream_, dQ, (u32)nq, (u64)fs, P, raPieceBase_.as<uint32_t>(),
+                       raPieces_.as<ZraRaPiece>());
+    uint32_t totals[2] = {0, 0};
+    HIPCHK(hipMemcpyAsync(totals, P.totals, 8, hipMemcpyDeviceToHost, stream_));
+    HIPCHK(hipStreamSynchronize(stream_));
+    HIPCHK(hipGetLastError());
+    touched = totals[0];
+  }
   if (!touched) return ok();
   // decode the touched frames, a scratch window of passSlots frames at a time (only frames that are decoded in full — or larger
   // than what the decoder needs as its match window — actually write there); slices leave for dOut as each frame finishes
