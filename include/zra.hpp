@@ -125,6 +125,8 @@ namespace zra {
     Buffer seekTable;
     Buffer cache;
     std::size_t entryIndex{0};
+    struct Ahead;                        ///< frames decoded ahead of the caller (one large device batch serves many calls)
+    std::shared_ptr<Ahead> ahead;
    public:
     FullDecompressor(const std::function<void(std::size_t offset, std::size_t size, void* buffer)>& readFunction);
     std::size_t Decompress(const BufferView& output);   ///< returns 0 once everything has been produced

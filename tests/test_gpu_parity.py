@@ -592,3 +592,75 @@ def test_config_c1_zratool_64mib_incompressible(zra, tmp_path):
     zstd = shutil.which("zstd") or ("/opt/conda/bin/zstd" if os.path.exists("/opt/conda/bin/zstd") else None)
     if zstd:
         assert subprocess.check_output([zstd, "-d", "-c", str(tmp_path / "c" / "dump.bin.zra")]) == x
+
+
+def test_host_pointer_calls_chunked_pipeline(zra, monkeypatch):
+    """The host-pointer calls cut large buffers into chunks of whole frames and run copies beside kernels (zra_hostpipe.hip). With the
+    chunk length shrunk to 1 MiB a 7.3 MiB input takes that path: the archive equals the oracle's byte for byte, it decodes back, a
+    damaged archive reports what the dependency reports (the chunked decoder hands a failing archive to the one-piece path), and the
+    streaming FullDecompressor returns the same bytes with and without its decode-ahead window."""
+    monkeypatch.setenv("ZRA_HOST_CHUNK_MIB", "1")
+    L = zra.load()
+    rng = np.random.RandomState(77)
+    for fs, level in ((16384, 3), (65536, 3), (4096, 1)):
+        n = 7 * (1 << 20) + 300 * 1024 + int(rng.randint(1, fs))
+        data = _random_input(rng, n)
+        st, ref = O.zra_compress(data, level, fs, True)
+        assert st == (0, 0)
+        arc = zra.CompressBuffer(data, level, fs, True)
+        assert arc == ref, (fs, level)
+        assert zra.DecompressBuffer(arc) == data
+        # damage in the first, a middle and the last chunk
+        nent = int.from_bytes(arc[26:30], "little")
+        hs = 38 + 5 * nent
+        for pos in (hs + 100, hs + (len(arc) - hs) // 2, len(arc) - 9):
+            bad = bytearray(arc); bad[pos] ^= 0x5A; bad = bytes(bad)
+            want_st, want = O.zra_decompress(bad, backend="zl", defined_only=True)
+            out = ctypes.create_string_buffer(n)
+            got_st = L.ZraDecompressBuffer(ctypes.create_string_buffer(bad, len(bad)), len(bad), out).tup()
+            assert got_st == want_st, (fs, pos, got_st, want_st)
+            assert out.raw[: len(want)] == want, (fs, pos)
+    # FullDecompressor (last archive, 4 KiB frames): window of 1 MiB ahead / no window / window larger than the archive, 10-frame and 3.5-frame buffers
+
+    def rd(off, size, outp, arc=arc):
+        ctypes.memmove(outp, arc[off: off + size], size)
+    cb = zra.READ_FN(rd)
+    for ahead in ("1", "0", "256"):
+        monkeypatch.setenv("ZRA_STREAM_AHEAD_MIB", ahead)
+        for cap in (10 * 4096, 3 * 4096 + 2048):
+            fd = ctypes.c_void_p()
+            assert L.ZraCreateFullDecompressor(ctypes.byref(fd), cb, 0).tup() == (0, 0)
+            out = ctypes.create_string_buffer(cap)
+            got = []
+            for _ in range(100000):
+                osz = ctypes.c_size_t(0)
+                assert L.ZraDecompressWithFullDecompressor(fd, out, cap, ctypes.byref(osz)).tup() == (0, 0)
+                if osz.value == 0:
+                    break
+                got.append(out.raw[: osz.value])
+            L.ZraDeleteFullDecompressor(fd)
+            assert b"".join(got) == data, (ahead, cap)
+    # a frame that fails inside the window is reported by the call that reaches it, after the frames before it were returned
+    bad = bytearray(arc); bad[hs + (len(arc) - hs) // 2] ^= 0x5A; bad = bytes(bad)
+
+    def rdb(off, size, outp):
+        ctypes.memmove(outp, bad[off: off + size], size)
+    cbb = zra.READ_FN(rdb)
+    results = {}
+    for ahead in ("0", "256"):
+        monkeypatch.setenv("ZRA_STREAM_AHEAD_MIB", ahead)
+        fd = ctypes.c_void_p()
+        assert L.ZraCreateFullDecompressor(ctypes.byref(fd), cbb, 0).tup() == (0, 0)
+        cap = 8 * 4096
+        out = ctypes.create_string_buffer(cap)
+        good = 0
+        for _ in range(100000):
+            osz = ctypes.c_size_t(0)
+            stt = L.ZraDecompressWithFullDecompressor(fd, out, cap, ctypes.byref(osz)).tup()
+            if stt != (0, 0) or osz.value == 0:
+                break
+            assert out.raw[: osz.value] == data[good: good + osz.value]
+            good += osz.value
+        L.ZraDeleteFullDecompressor(fd)
+        results[ahead] = (stt, good)
+    assert results["0"] == results["256"] and results["0"][0][0] == 1

@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libzra_amd.so")
-SOURCES = ["zra_decode.hip", "zra_encode_mf.hip", "zra_encode_ent.hip", "zra_encode.hip", "zra_engine.hip", "zra_capi.cpp"]
+SOURCES = ["zra_decode.hip", "zra_encode_mf.hip", "zra_encode_ent.hip", "zra_encode.hip", "zra_engine.hip", "zra_hostpipe.hip", "zra_capi.cpp"]
 
 
 def needs_build():

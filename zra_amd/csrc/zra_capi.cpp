@@ -422,20 +422,62 @@ namespace zra {
   FullDecompressor::FullDecompressor(const std::function<void(size_t, size_t, void*)>& rf)
       : readFunction(rf), header(rf), seekTable(header.GetSeekTable()) {}
 
+  // Frames decoded ahead of the caller. The reference reads and decodes exactly the frames one call returns (zra.cpp:428-435); with the
+  // tool's 10 MB buffers that is a 160-frame device batch per call. Here a call that finds nothing decoded fetches and decodes a
+  // window of ZRA_STREAM_AHEAD_MIB (default 256) in one go and the following calls are served from it. Same bytes, fewer and larger
+  // readFunction calls. If anything in the window fails, the window is dropped and the call decodes exactly its own frames, so an
+  // error surfaces at the call where the reference raises it.
+  struct FullDecompressor::Ahead {
+    Buffer data;                 // decoded frames [first, last) of the seek table
+    size_t first{0}, last{0};
+    bool disabled{false};
+  };
+
   size_t FullDecompressor::Decompress(const BufferView& output) {
     if (output.size < header.frameSize) throw Exception(StatusCode::OutputBufferTooSmall);
     const size_t lastIndex = seekTable.size() / fmt::kEntrySize - 1;
     const size_t stop = std::min(lastIndex, entryIndex + output.size / header.frameSize);
     const u8* table = seekTable.data();
+    const size_t first = entryIndex, count = stop - entryIndex;
+    const u64 firstByte = (u64)first * header.frameSize;
+    const size_t produced = count ? (size_t)std::min<u64>((u64)count * header.frameSize, header.uncompressedSize > firstByte ? header.uncompressedSize - firstByte : 0) : 0;
+    const char* aheadEnv = std::getenv("ZRA_STREAM_AHEAD_MIB");
+    const size_t aheadBytes = (aheadEnv ? (size_t)std::atoll(aheadEnv) : 256) << 20;
+    if (!ahead) ahead = std::make_shared<Ahead>();
+    Ahead& A = *ahead;
+    if (count && aheadBytes && !A.disabled && header.frameSize) {
+      if (!(first >= A.first && stop <= A.last)) {
+        // decode a window that starts at this call's first frame
+        const size_t want = std::max<size_t>(count, aheadBytes / header.frameSize);
+        const size_t wStop = std::min(lastIndex, first + want);
+        bool good = false;
+        try {
+          const u64 base = fmt::entry_get(table + first * 5), end = fmt::entry_get(table + wStop * 5);
+          if (end >= base && wStop > stop) {
+            cache.resize(end - base);
+            readFunction(header.size + base, cache.size(), cache.data());
+            const size_t bytes = (size_t)std::min<u64>((u64)(wStop - first) * header.frameSize, header.uncompressedSize > firstByte ? header.uncompressedSize - firstByte : 0);
+            A.data.resize(bytes);
+            ra_decode(table, seekTable.size(), cache.data(), cache.size(), base, first, wStop - first, header, A.data.data(), 0, bytes);
+            A.first = first; A.last = wStop;
+            good = true;
+          }
+        } catch (const Exception&) { A.disabled = true; }          // the exact path below decides what this call reports
+        if (!good) { A.first = A.last = 0; A.data.clear(); }
+      }
+      if (first >= A.first && stop <= A.last) {
+        std::memcpy(output.data, A.data.data() + (first - A.first) * (size_t)header.frameSize, produced);
+        entryIndex = stop;
+        if (stop == A.last) { A.data.clear(); A.data.shrink_to_fit(); A.first = A.last = 0; }
+        return produced;
+      }
+    }
     const u64 base = fmt::entry_get(table + entryIndex * 5);
     if (fmt::entry_get(table + stop * 5) < base) throw Exception(StatusCode::ZStdError, 72);
     cache.resize(fmt::entry_get(table + stop * 5) - base);
     readFunction(header.size + base, cache.size(), cache.data());
-    const size_t first = entryIndex, count = stop - entryIndex;
     entryIndex = stop;
     if (!count) return 0;
-    const u64 firstByte = (u64)first * header.frameSize;
-    const size_t produced = (size_t)std::min<u64>((u64)count * header.frameSize, header.uncompressedSize - firstByte);
     ra_decode(table, seekTable.size(), cache.data(), cache.size(), base, first, count, header, output.data, 0, produced);
     return produced;
   }

@@ -476,20 +476,7 @@ Status Engine::compress_device(const uint8_t* dIn, size_t inSize, uint8_t* dOut,
 }
 
 // ------------------------------------------------------------------ host-pointer helpers used by the C/C++ API
-Status Engine::compress_host(const uint8_t* hIn, size_t n, uint8_t* hOut, size_t* outSize, int level, uint32_t frameSize, bool checksum) {
-  HIPCHK(hipSetDevice(device_));
-  if (frameSize == 0) return zerr(42);
-  const uint32_t tableSize = zra_fmt::table_size(n, frameSize);
-  const size_t cap = zra_fmt::kFixedSize + (size_t)tableSize * 5 + zra_fmt::compress_bound(frameSize) * (size_t)(tableSize - 1);
-  if (!hostIn_.reserve(n + 64) || !hostOut_.reserve(cap + 64)) return zerr(64);
-  if (n) HIPCHK(hipMemcpyAsync(hostIn_.p, hIn, n, hipMemcpyHostToDevice, stream_));
-  Status s = compress_device(hostIn_.as<uint8_t>(), n, hostOut_.as<uint8_t>(), outSize, level, frameSize, checksum);
-  if (s.zra) return s;
-  HIPCHK(hipMemcpyAsync(hOut, hostOut_.p, *outSize, hipMemcpyDeviceToHost, stream_));
-  HIPCHK(hipStreamSynchronize(stream_));
-  return ok();
-}
-
+// compress_host: zra_hostpipe.hip
 Status Engine::compress_frames_host(const uint8_t* hIn, size_t n, uint8_t* hBody, std::vector<uint64_t>& sizes, size_t* bodySize,
                                     int level, uint32_t frameSize, bool checksum) {
   HIPCHK(hipSetDevice(device_));
@@ -521,6 +508,11 @@ Status Engine::decode_host(const uint8_t* hSpan, size_t spanSize, const std::vec
     const uint64_t o = (uint64_t)i * frameSize;
     oo[i] = o;
     ex[i] = o >= total ? 0 : (uint32_t)std::min<uint64_t>(frameSize, total - o);
+  }
+  if (wholeArchive && skip == 0 && frameSize && (size_t)nFrames >= 2 * std::max<size_t>(1, host_chunk_bytes() / frameSize) && size == std::min<uint64_t>(total, (uint64_t)nFrames * frameSize)) {
+    bool fallBack = false;
+    Status s = decode_host_pipelined(hSpan, starts, ends, frameSize, total, hOut, &fallBack);
+    if (!fallBack) return s;
   }
   if (!hostIn_.reserve(spanSize + 64) || !hostOut_.reserve(std::max<size_t>((size_t)nFrames * frameSize, wholeArchive ? (size_t)total : 0) + 64) || !frameOff_.reserve(se.size() * 8) ||
       !outOff_.reserve((size_t)nFrames * 8) || !expect_.reserve((size_t)nFrames * 4))

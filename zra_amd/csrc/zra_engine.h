@@ -30,6 +30,8 @@ struct HeaderInfo {
 };
 // parse the 38 fixed bytes; returns a ZRA status code (0 ok)
 int parse_fixed_header(const uint8_t* fixed38, HeaderInfo* h);
+// chunk length of the pipelined host-pointer calls (zra_hostpipe.hip); ZRA_HOST_CHUNK_MIB, default 1024
+size_t host_chunk_bytes();
 
 class Engine {
  public:
@@ -44,8 +46,6 @@ class Engine {
   // gives every scratch allocation of this engine back to the device (they are grow-only otherwise and can reach tens of GiB after a
   // large level-9 compression); the next call allocates again what it needs
   Status release_scratch();
-  std::vector<uint64_t> raHostQ_;
-  int decOccParse_ = 0, decOccExec_ = 0;
   double last_kernel_ms() const { return lastKernelMs_; }
   // HIP-event timings of the last call on the engine's stream: {mf ms, mf launches, entropy ms, entropy launches, decode ms, decode launches}
   void kernel_stats(double out[6]) const { for (int i = 0; i < 6; i++) out[i] = kstats_[i]; }
@@ -96,6 +96,9 @@ class Engine {
   // bytes [skip, skip+size) of the concatenated output are returned in hOut
   Status decode_host(const uint8_t* hSpan, size_t spanSize, const std::vector<uint64_t>& starts, const std::vector<uint64_t>& ends,
                      uint32_t frameSize, uint64_t total, uint8_t* hOut, size_t skip, size_t size, bool wholeArchive = false);
+  // whole archive in ~1 GiB chunks, copies beside the kernels (zra_hostpipe.hip); *fallBack: a frame failed, take decode_host
+  Status decode_host_pipelined(const uint8_t* hSpan, const std::vector<uint64_t>& starts, const std::vector<uint64_t>& ends,
+                               uint32_t frameSize, uint64_t total, uint8_t* hOut, bool* fallBack);
 
   // batched random access: false (default) = a frame is decoded up to the last byte a query needs, so damage behind that byte
   // and the frame's content checksum go unnoticed; true = whole frames + checksums, the reference's error behaviour
@@ -114,6 +117,8 @@ class Engine {
   // decode scratch
   DevBuf decFrames_, decTables_, decLists_, decCounters_, decLits_, decSeqs_;
   DevBuf raPlan_, raLimit_, raPieceBase_, raPieces_;
+  std::vector<uint64_t> raHostQ_;        // query tuples of the running batch (host side of an asynchronous copy)
+  int decOccParse_ = 0, decOccExec_ = 0; // resident workgroups per CU of the parse / execute kernels
   bool raVerifyWholeFrames_ = false;     // batched random access decodes every touched frame in full and checks its checksum
   DevBuf status_, produced_, frameMeta_, frameOff_, outOff_, expect_, result_, temp_, qmeta_;
   // encode scratch (see zra_encode.hip)
