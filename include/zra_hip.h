@@ -72,6 +72,74 @@ ZRA_EXPORT ZraStatus ZraHipCompressFrames(ZraHipEngine* engine, const void* dIn,
 ZRA_EXPORT ZraStatus ZraHipStitchHeader(const uint64_t* hFrameSizes, size_t nFramesTotal, uint64_t uncompressedSize,
                                         uint32_t frameSize, void* hHeader, size_t* headerSize);
 
+/* ---- distributed archive: one process per GPU, frames sharded by index (zra_amd/csrc/zra_comm.hip) ----
+ * The reference has no multi-device mode; its frame loop (zra.cpp:216-225) and its lookup (zra.cpp:265-269) are what is split here.
+ * Rank r of `world` owns frames [F*r/world, F*(r+1)/world). All ZraHipComm* calls are COLLECTIVE: every rank of the communicator
+ * makes the same call, and every rank returns the same status (the first failing rank's). */
+typedef struct ZraHipComm ZraHipComm;
+typedef struct ZraHipShard ZraHipShard;
+
+/** Frames [*lo, *hi) owned by `rank`. Pure arithmetic. */
+ZRA_EXPORT void ZraHipShardRange(uint64_t nFrames, int rank, int world, uint64_t* lo, uint64_t* hi);
+/** The rank that owns `frame`. */
+ZRA_EXPORT int ZraHipOwnerOfFrame(uint64_t nFrames, int world, uint64_t frame);
+
+/** One piece of a query after it has been cut at ownership boundaries. */
+typedef struct ZraHipSlice {
+  uint32_t owner;      /* rank that holds the frames of this piece */
+  uint64_t query;      /* index of the query it belongs to */
+  uint64_t offset;     /* first uncompressed byte (offset into the whole archive's content) */
+  uint64_t size;       /* bytes */
+  uint64_t within;     /* where the piece starts inside the query's answer */
+} ZraHipSlice;
+/** Query router: cuts (offset, size) queries at ownership boundaries; slices are written grouped by owner, query order inside an
+ *  owner, and counted per owner in perOwnerCount[world] (may be NULL). Bounds as DecompressRA: any query with
+ *  offset + size >= uncompressedSize fails the call with OutOfBoundsAccess (zra.cpp:260). OutputBufferTooSmall: *nSlices tells the
+ *  capacity needed. Pure host arithmetic — no engine, no GPU. */
+ZRA_EXPORT ZraStatus ZraHipRouteQueries(uint64_t uncompressedSize, uint32_t frameSize, int world, const uint64_t* offsets, const uint64_t* sizes,
+                                        size_t nQueries, ZraHipSlice* slices, size_t sliceCapacity, size_t* nSlices, uint64_t* perOwnerCount);
+
+/** RCCL transport (ncclAllGather, grouped ncclSend/ncclRecv over xGMI). Rank 0 creates the 128-byte
+ *  id and hands it to the other ranks by the host program's own means. */
+ZRA_EXPORT ZraStatus ZraHipCommGetUniqueId(void* id128);
+ZRA_EXPORT ZraStatus ZraHipCommCreateRccl(ZraHipComm** comm, ZraHipEngine* engine, const void* id128, int rank, int world);
+/** Host transport: the exchange steps are handed to two callbacks of the host program (MPI, sockets, ...) on HOST buffers; device
+ *  data is staged. Return 0 for success.
+ *    allgather: every rank contributes `bytes` bytes, recv gets world*bytes in rank order.
+ *    exchange:  one point-to-point round — all sends and receives of this rank; returns when all of them are complete. */
+typedef struct ZraHipHostTransport {
+  void* user;
+  int (*allgather)(void* user, const void* send, void* recv, size_t bytes);
+  int (*exchange)(void* user, int nSend, const int* sendPeer, const void* const* sendBuf, const size_t* sendBytes,
+                  int nRecv, const int* recvPeer, void* const* recvBuf, const size_t* recvBytes);
+} ZraHipHostTransport;
+ZRA_EXPORT ZraStatus ZraHipCommCreateHost(ZraHipComm** comm, ZraHipEngine* engine, const ZraHipHostTransport* transport, int rank, int world);
+ZRA_EXPORT void ZraHipCommDestroy(ZraHipComm* comm);
+
+/** Sharded CompressBuffer (zra.cpp:194-235): dLocal = the uncompressed bytes of this rank's frames, i.e. bytes
+ *  [lo*frameSize, min(totalBytes, hi*frameSize)) of the input with [lo, hi) = ZraHipShardRange(ceil(totalBytes/frameSize), rank, world)
+ *  (InputFrameSizeMismatch if localBytes is not exactly that). Only the frame sizes travel (8 bytes per frame, all-gather): every rank
+ *  ends up with the complete header + seek table and the compressed body of its own frames — a shard. Byte-identical to the archive
+ *  one GPU would write. */
+ZRA_EXPORT ZraStatus ZraHipCommCompress(ZraHipComm* comm, const void* dLocal, size_t localBytes, uint64_t totalBytes, int8_t compressionLevel,
+                                        uint32_t frameSize, bool checksum, ZraHipShard** shard);
+ZRA_EXPORT void ZraHipShardDestroy(ZraHipShard* shard);
+ZRA_EXPORT size_t ZraHipShardHeaderSize(const ZraHipShard* shard);
+/** Header + seek table of the WHOLE archive (host copy, CRC-32 set). */
+ZRA_EXPORT void ZraHipShardGetHeader(const ZraHipShard* shard, void* hHeader);
+/** Size of the whole archive (header + all ranks' frames). */
+ZRA_EXPORT uint64_t ZraHipShardArchiveSize(const ZraHipShard* shard);
+/** This rank's frames: device pointer, their offset inside the archive's body, their length. */
+ZRA_EXPORT void ZraHipShardGetBody(const ZraHipShard* shard, const void** dBody, uint64_t* bodyBase, uint64_t* bodyBytes);
+/** The archive in one piece in dArchive on rank `root` (other ranks pass NULL / 0): world-1 inbound point-to-point messages in one group. */
+ZRA_EXPORT ZraStatus ZraHipCommGatherArchive(ZraHipComm* comm, const ZraHipShard* shard, int root, void* dArchive, size_t archiveCapacity,
+                                             size_t* archiveSize);
+/** Sharded serving (BASELINE config C5): every rank passes its own queries over the WHOLE uncompressed range; slices go to the ranks
+ *  that own the frames, are decoded there (ZraHipDecompressRABatch semantics on the shard) and come back; answer q lands at
+ *  dOut + hOutOffsets[q]. Bounds as DecompressRA (zra.cpp:260). */
+ZRA_EXPORT ZraStatus ZraHipCommServe(ZraHipComm* comm, const ZraHipShard* shard, const uint64_t* hOffsets, const uint64_t* hSizes,
+                                     const uint64_t* hOutOffsets, size_t nQueries, void* dOut);
+
 /** Last per-call timing of the dominant kernel on the engine's stream, measured with HIP events (milliseconds; 0 if none). */
 ZRA_EXPORT double ZraHipLastKernelMs(ZraHipEngine* engine);
 /** HIP-event timings (ms) and launch counts of the kernels of the LAST call on this engine, measured on the engine's stream:

@@ -1,22 +1,76 @@
-"""N>1 path on CPU: world_size-2 gloo processes run the same sharding/stitch/gather code the GPU bench uses
-(zra_amd/sharding.py); the per-frame codec is replaced by the oracle here because there is no GPU in this container."""
+"""N>1 on the CPU: the host-side logic of the distributed archive (include/zra_hip.h: shard ranges, the query router, the header
+stitch) checked directly, and world_size-2 gloo processes that shard an input by frame index, exchange the frame sizes, stitch the seek
+table and serve random-access queries THROUGH THE ROUTER (slices to the owner, bytes back). There is no GPU in this container, so
+the per-frame codec of the two ranks is the oracle; the real kernels run the same flow in tests/test_gpu_multi.py."""
+import ctypes
 import os
 import sys
 
+import numpy as np
 import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+
+
+def test_shard_ranges_and_owner_cover_every_frame():
+    from zra_amd import sharding
+    for F in (0, 1, 2, 7, 8, 9, 1000, 262144, (1 << 32) + 5):
+        for W in (1, 2, 3, 8):
+            prev = 0
+            for r in range(W):
+                lo, hi = sharding.shard_range(F, r, W)
+                assert lo == prev and hi >= lo
+                prev = hi
+                for f in {lo, (lo + hi) // 2, hi - 1} if hi > lo else ():
+                    assert sharding.owner_of_frame(F, W, f) == r, (F, W, r, f)
+            assert prev == F
+
+
+def test_router_cuts_queries_at_ownership_boundaries():
+    """every byte of every query in exactly one slice, the slice's frames all belong to its owner, slices grouped by owner in query
+    order; a query that reaches the last byte is refused like DecompressRA refuses it (zra.cpp:260)"""
+    import zra_amd as Z
+    from zra_amd import sharding
+    rng = np.random.RandomState(5)
+    for case in range(60):
+        fs = int(rng.choice([1024, 4096, 65536]))
+        W = int(rng.choice([1, 2, 3, 8]))
+        U = int(rng.randint(2, 200 * fs))
+        F = (U + fs - 1) // fs
+        nq = int(rng.randint(0, 50))
+        sizes = np.minimum(rng.choice([0, 1, 100, fs, 3 * fs + 7, 40 * fs], size=nq), U - 1).astype(np.uint64)
+        offs = np.array([rng.randint(0, U - int(s)) for s in sizes], dtype=np.uint64)
+        sl, per = sharding.route_queries(U, fs, W, offs, sizes)
+        assert list(sl["owner"]) == sorted(sl["owner"]) and [int((sl["owner"] == r).sum()) for r in range(W)] == [int(x) for x in per]
+        cover = {q: [] for q in range(nq)}
+        for s in sl:
+            lo, hi = sharding.shard_range(F, int(s["owner"]), W)
+            assert s["size"] > 0 and lo * fs <= s["offset"] and s["offset"] + s["size"] <= min(U, hi * fs)
+            cover[int(s["query"])].append((int(s["within"]), int(s["offset"]), int(s["size"])))
+        for q in range(nq):
+            pos = 0
+            for within, off, size in sorted(cover[q]):
+                assert within == pos and off == int(offs[q]) + pos
+                pos += size
+            assert pos == int(sizes[q])
+        for r in range(W):                                  # query order inside an owner
+            qs = list(sl["query"][sl["owner"] == r])
+            assert qs == sorted(qs)
+    with pytest.raises(Z.ZraError) as e:
+        sharding.route_queries(1000, 64, 2, np.array([990], dtype=np.uint64), np.array([10], dtype=np.uint64))
+    assert e.value.zra == 5
 
 
 def _worker(rank, world, port, fs, level, total, q):
     sys.path.insert(0, HERE)
     sys.path.insert(0, os.path.dirname(HERE))
-    import numpy as np
     import corpus as C
     import oracle_lib as O
+    import zra_amd as Z
     from zra_amd import sharding
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -25,27 +79,66 @@ def _worker(rank, world, port, fs, level, total, q):
         data = C.gen_E(1 << 20)[:total]
         nframes = (total + fs - 1) // fs
         lo, hi = sharding.shard_range(nframes, rank, world)
-        body = bytearray()
-        sizes = []
-        for f in range(lo, hi):
-            fr = O.compress_frame(data[f * fs:(f + 1) * fs], level, True)
-            sizes.append(len(fr))
-            body += fr
-        tb = torch.frombuffer(bytearray(body) if body else bytearray(1), dtype=torch.uint8)
-        arc, hdr, bases, totals = sharding.gather_archive(tb, torch.tensor(sizes, dtype=torch.int64), total, fs)
-        if rank == 0:
-            st, ref = O.zra_compress(data, level, fs, True)
-            q.put(bytes(arc.numpy().tobytes()) == ref and st == (0, 0))
-        # every rank holds the full seek table: lookup of an arbitrary frame works everywhere
-        n = int.from_bytes(hdr[26:30], "little")
-        assert n == nframes + 1
+        # --- compress the own frames, exchange the sizes, stitch (what ZraHipCommCompress does with the real kernels)
+        frames = [O.compress_frame(data[f * fs:(f + 1) * fs], level, True) for f in range(lo, hi)]
+        mine = torch.tensor([len(x) for x in frames], dtype=torch.int64)
+        counts = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(counts, torch.tensor([len(frames)], dtype=torch.int64))
+        mx = max(int(c) for c in counts)
+        pad = torch.zeros(mx, dtype=torch.int64); pad[: len(frames)] = mine
+        allsz = [torch.zeros(mx, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(allsz, pad)
+        flat = np.concatenate([a[: int(c)].numpy() for a, c in zip(allsz, counts)]).astype(np.uint64)
+        header = Z.stitch_header(flat, total, fs)
+        st, ref = O.zra_compress(data, level, fs, True)
+        assert st == (0, 0) and header == ref[: len(header)]                       # every rank holds the whole seek table
+        body_base = int(flat[:lo].sum())
+        assert b"".join(frames) == ref[len(header) + body_base: len(header) + body_base + int(mine.sum())]
+        # --- serve: this rank's queries over the whole range, through the router
+        rng = np.random.RandomState(100 + rank)
+        nq = 40
+        sizes = np.minimum(rng.choice([1, 100, fs, 2 * fs + 3, 5 * fs], size=nq), total - 1).astype(np.uint64)
+        offs = np.array([rng.randint(0, total - int(s)) for s in sizes], dtype=np.uint64)
+        offs[0] = max(0, hi * fs - 5) if rank == 0 else max(0, lo * fs - 5); sizes[0] = min(10, total - 1 - int(offs[0]))   # straddles the boundary
+        sl, per = sharding.route_queries(total, fs, world, offs, sizes)
+        asks = [[(int(s["offset"]), int(s["size"])) for s in sl[sl["owner"] == r]] for r in range(world)]
+        box = [None] * world
+        dist.all_gather_object(box, asks)
+        got_asks = [box[s][rank] for s in range(world)]
+        local_arc_body = b"".join(frames)
+        ent = np.concatenate([[0], np.cumsum(flat)]).astype(np.int64)
+
+        def decode_own(off, size):
+            out = b""
+            f = off // fs
+            while len(out) < size:
+                assert lo <= f < hi, "router sent a frame this rank does not own"
+                fr = local_arc_body[int(ent[f]) - body_base: int(ent[f + 1]) - body_base]
+                raw, err = O.decompress(fr, fs)
+                assert err == 0
+                a = off + len(out) - f * fs
+                out += raw[a: a + size - len(out)]
+                f += 1
+            return out
+        answers = [[decode_own(o, s) for (o, s) in got_asks[s_]] for s_ in range(world)]
+        box = [None] * world
+        dist.all_gather_object(box, answers)
+        back = [box[r][rank] for r in range(world)]                                  # what owner r decoded for me
+        res = [bytearray(int(s)) for s in sizes]
+        cur = [0] * world
+        for s in sl:
+            r = int(s["owner"])
+            piece = back[r][cur[r]]; cur[r] += 1
+            res[int(s["query"])][int(s["within"]): int(s["within"]) + int(s["size"])] = piece
+        ok = all(bytes(res[i]) == data[int(offs[i]): int(offs[i]) + int(sizes[i])] for i in range(nq))
+        q.put((rank, ok))
         dist.barrier()
     finally:
         dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("total,fs", [(400000, 65536), (70000, 16384), (65536 * 3, 65536)])
-def test_two_rank_shard_stitch_gather(total, fs):
+def test_two_rank_shard_stitch_route_serve(total, fs):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29500 + (os.getpid() + total) % 2000
@@ -53,6 +146,7 @@ def test_two_rank_shard_stitch_gather(total, fs):
     for p in procs:
         p.start()
     for p in procs:
-        p.join(120)
+        p.join(180)
         assert p.exitcode == 0
-    assert q.get(timeout=5) is True
+    got = sorted(q.get(timeout=5) for _ in range(2))
+    assert got == [(0, True), (1, True)]

@@ -32,6 +32,20 @@ class ZraError(RuntimeError):
 
 READ_FN = ctypes.CFUNCTYPE(None, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_void_p)
 
+
+class ZraHipSlice(ctypes.Structure):
+    """include/zra_hip.h: one piece of a query cut at ownership boundaries"""
+    _fields_ = [("owner", ctypes.c_uint32), ("query", ctypes.c_uint64), ("offset", ctypes.c_uint64), ("size", ctypes.c_uint64), ("within", ctypes.c_uint64)]
+
+
+ALLGATHER_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t)
+EXCHANGE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_size_t),
+                               ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_size_t))
+
+
+class ZraHipHostTransport(ctypes.Structure):
+    _fields_ = [("user", ctypes.c_void_p), ("allgather", ALLGATHER_FN), ("exchange", EXCHANGE_FN)]
+
 _lib = None
 
 
@@ -100,6 +114,22 @@ def load():
         "ZraHipDecompressRABatch": (S, [vp, vp, sz, vp, u64p, u64p, u64p, sz]),
         "ZraHipCompressFrames": (S, [vp, vp, sz, vp, vp, szp, ctypes.c_int8, u32, ctypes.c_bool]),
         "ZraHipStitchHeader": (S, [u64p, sz, ctypes.c_uint64, u32, vp, szp]),
+        # distributed archive
+        "ZraHipShardRange": (None, [ctypes.c_uint64, ctypes.c_int, ctypes.c_int, u64p, u64p]),
+        "ZraHipOwnerOfFrame": (ctypes.c_int, [ctypes.c_uint64, ctypes.c_int, ctypes.c_uint64]),
+        "ZraHipRouteQueries": (S, [ctypes.c_uint64, u32, ctypes.c_int, u64p, u64p, sz, ctypes.POINTER(ZraHipSlice), sz, szp, u64p]),
+        "ZraHipCommGetUniqueId": (S, [vp]),
+        "ZraHipCommCreateRccl": (S, [ctypes.POINTER(vp), vp, vp, ctypes.c_int, ctypes.c_int]),
+        "ZraHipCommCreateHost": (S, [ctypes.POINTER(vp), vp, ctypes.POINTER(ZraHipHostTransport), ctypes.c_int, ctypes.c_int]),
+        "ZraHipCommDestroy": (None, [vp]),
+        "ZraHipCommCompress": (S, [vp, vp, sz, ctypes.c_uint64, ctypes.c_int8, u32, ctypes.c_bool, ctypes.POINTER(vp)]),
+        "ZraHipShardDestroy": (None, [vp]),
+        "ZraHipShardHeaderSize": (sz, [vp]),
+        "ZraHipShardGetHeader": (None, [vp, vp]),
+        "ZraHipShardArchiveSize": (ctypes.c_uint64, [vp]),
+        "ZraHipShardGetBody": (None, [vp, ctypes.POINTER(vp), u64p, u64p]),
+        "ZraHipCommGatherArchive": (S, [vp, vp, ctypes.c_int, vp, sz, szp]),
+        "ZraHipCommServe": (S, [vp, vp, u64p, u64p, u64p, sz, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)          # AttributeError here == a symbol include/*.h declares is not exported
@@ -119,7 +149,10 @@ C_ABI_SYMBOLS = [
     "ZraDecompressWithFullDecompressor",
 ]
 HIP_ABI_SYMBOLS = ["ZraHipDeviceCount", "ZraHipCreateEngine", "ZraHipDestroyEngine", "ZraHipSynchronize", "ZraHipGetStream", "ZraHipWaitStream", "ZraHipReleaseScratch", "ZraHipLastKernelMs", "ZraHipGetKernelStats",
-                   "ZraHipCompressBuffer", "ZraHipDecompressBuffer", "ZraHipDecompressRABatch", "ZraHipCompressFrames", "ZraHipStitchHeader", "ZraHipDebugReadSeqs", "ZraHipSetOptions", "ZraHipGetOptions"]
+                   "ZraHipCompressBuffer", "ZraHipDecompressBuffer", "ZraHipDecompressRABatch", "ZraHipCompressFrames", "ZraHipStitchHeader", "ZraHipDebugReadSeqs", "ZraHipSetOptions", "ZraHipGetOptions",
+                   "ZraHipShardRange", "ZraHipOwnerOfFrame", "ZraHipRouteQueries", "ZraHipCommGetUniqueId", "ZraHipCommCreateRccl", "ZraHipCommCreateHost", "ZraHipCommDestroy",
+                   "ZraHipCommCompress", "ZraHipShardDestroy", "ZraHipShardHeaderSize", "ZraHipShardGetHeader", "ZraHipShardArchiveSize", "ZraHipShardGetBody",
+                   "ZraHipCommGatherArchive", "ZraHipCommServe"]
 
 
 def _chk(st, what=""):

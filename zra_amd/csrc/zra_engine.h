@@ -68,6 +68,8 @@ class Engine {
   // Batched random access, archive + output on the device, query arrays on the host.
   Status decompress_ra_batch(const uint8_t* dArc, size_t arcSize, uint8_t* dOut, const uint64_t* hOff, const uint64_t* hSize,
                              const uint64_t* hOutOff, size_t nq);
+  Status decompress_ra_batch_shard(const uint8_t* dArc, size_t arcSize, const uint8_t* dBody, uint64_t bodyBytes, uint64_t bodyBase, uint8_t* dOut,
+                                   const uint64_t* hOff, const uint64_t* hSize, const uint64_t* hOutOff, size_t nq);
   // Host-walked frame list (reference semantics of DecompressBuffer: seek table not consulted). hFrameOff has nFrames+1 entries
   // relative to dBody; frames are assumed to regenerate frameSize bytes each (last: the remainder of total).
   Status decompress_frames_host_list(const uint8_t* dBody, uint64_t bodySize, const std::vector<uint64_t>& hFrameOff,

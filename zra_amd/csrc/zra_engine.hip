@@ -117,7 +117,16 @@ __global__ void zra_ra_count_kernel(const u64* q, u32 nq, u64 fs, RaPlan P) {
 }
 // pass 2 (one workgroup): exclusive scans over the frames -> dense slots + slice-list bases, and the decode job of every touched
 // frame: compressed span from the 5-byte seek-table entries, destination slot inside the pass-sized scratch window, bytes to produce
-__global__ void __launch_bounds__(1024) zra_ra_plan_kernel(RaPlan P, u32 nFrames, const u8* table, u64 fs, u64 total, u32 passSlots, u32 fullFrames,
+// compressed span of frame f from the 5-byte entries, relative to the body bytes this device holds ([bodyBase, ...) of the archive's
+// body: a shard of a distributed archive holds its own frames only); a span that starts before them comes out inverted (refused as
+// srcSize_wrong by the decoder, like any span outside the buffer)
+__device__ __forceinline__ void ra_frame_span(const u8* table, u64 f, u64 bodyBase, u64* so, u64* se) {
+  const u8* e = table + (size_t)f * 5;
+  const u64 a = (u64)ld32(e) | ((u64)e[4] << 32), b = (u64)ld32(e + 5) | ((u64)e[9] << 32);
+  if (a < bodyBase || b < bodyBase) { *so = 1; *se = 0; }
+  else { *so = a - bodyBase; *se = b - bodyBase; }
+}
+__global__ void __launch_bounds__(1024) zra_ra_plan_kernel(RaPlan P, u32 nFrames, const u8* table, u64 bodyBase, u64 fs, u64 total, u32 passSlots, u32 fullFrames,
                                                            u64* frameOff, u64* outOff, u32* outCap, u32* limit, u32* pieceBase) {
   __shared__ u32 sT[1024], sP[1024];
   const u32 tid = threadIdx.x;
@@ -138,9 +147,7 @@ __global__ void __launch_bounds__(1024) zra_ra_plan_kernel(RaPlan P, u32 nFrames
     const u32 c = P.cnt[f];
     if (!c) continue;
     P.slot[f] = st;
-    const u8* e = table + (size_t)f * 5;
-    frameOff[2 * (size_t)st] = (u64)ld32(e) | ((u64)e[4] << 32);
-    frameOff[2 * (size_t)st + 1] = (u64)ld32(e + 5) | ((u64)e[9] << 32);
+    ra_frame_span(table, f, bodyBase, &frameOff[2 * (size_t)st], &frameOff[2 * (size_t)st + 1]);
     const u64 o = (u64)f * fs;
     const u32 expect = o >= total ? 0u : (u32)(total - o < fs ? total - o : fs);
     outOff[st] = (u64)(st % passSlots) * fs;
@@ -171,7 +178,7 @@ __global__ void zra_ra_fill_kernel(const u64* q, u32 nq, u64 fs, RaPlan P, const
 
 // small batches (far fewer slices than the archive has frames): one decode job per slice, built from the query alone — no pass over
 // the frames of the archive, no count/scan, nothing read back. A frame two slices share is decoded once per slice.
-__global__ void zra_ra_direct_kernel(const u64* q, u32 nq, u32 nPieces, u64 fs, u64 total, const u8* table, u32 fullFrames, u64* frameOff, u64* outOff,
+__global__ void zra_ra_direct_kernel(const u64* q, u32 nq, u32 nPieces, u64 fs, u64 total, const u8* table, u64 bodyBase, u32 fullFrames, u64* frameOff, u64* outOff,
                                      u32* outCap, u32* limit, u32* pieceBase, ZraRaPiece* pieces) {
   const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i == 0) pieceBase[nPieces] = nPieces;
@@ -182,9 +189,7 @@ __global__ void zra_ra_direct_kernel(const u64* q, u32 nq, u32 nPieces, u64 fs, 
   u32 st = (u32)q[4 * (size_t)i + 3];
   u64 done = 0;
   for (u64 f = f0; f <= f1; f++, st++) {
-    const u8* e = table + (size_t)f * 5;
-    frameOff[2 * (size_t)st] = (u64)ld32(e) | ((u64)e[4] << 32);
-    frameOff[2 * (size_t)st + 1] = (u64)ld32(e + 5) | ((u64)e[9] << 32);
+    ra_frame_span(table, f, bodyBase, &frameOff[2 * (size_t)st], &frameOff[2 * (size_t)st + 1]);
     const u64 o = f * fs;
     const u32 expect = o >= total ? 0u : (u32)(total - o < fs ? total - o : fs);
     const u32 srcOff = f == f0 ? (u32)(off % fs) : 0u;
@@ -458,6 +463,13 @@ Status Engine::decompress_frames_host_list(const uint8_t* dBody, uint64_t bodySi
 
 Status Engine::decompress_ra_batch(const uint8_t* dArc, size_t arcSize, uint8_t* dOut, const uint64_t* hOff, const uint64_t* hSize,
                                    const uint64_t* hOutOff, size_t nq) {
+  return decompress_ra_batch_shard(dArc, arcSize, nullptr, 0, 0, dOut, hOff, hSize, hOutOff, nq);
+}
+
+// dBody == nullptr: a whole archive at dArc (header, table, body). Otherwise dArc holds header + table only and dBody the bytes
+// [bodyBase, bodyBase + bodyBytes) of the archive's body — the frames one rank of a distributed archive owns (zra_comm.hip).
+Status Engine::decompress_ra_batch_shard(const uint8_t* dArc, size_t arcSize, const uint8_t* dBody, uint64_t bodyBytes, uint64_t bodyBase, uint8_t* dOut,
+                                         const uint64_t* hOff, const uint64_t* hSize, const uint64_t* hOutOff, size_t nq) {
   HIPCHK(hipSetDevice(device_));
   kstats_[4] = kstats_[5] = 0;
   if (arcSize <= zra_fmt::kFixedSize) return {kOutOfBounds, 0};
@@ -467,6 +479,7 @@ Status Engine::decompress_ra_batch(const uint8_t* dArc, size_t arcSize, uint8_t*
   HeaderInfo h;
   if (int e = parse_fixed_header(fixed, &h)) return {e, 0};
   if (arcSize < h.size) return {kOutOfBounds, 0};
+  if (!dBody) { dBody = dArc + h.size; bodyBytes = arcSize - h.size; bodyBase = 0; }
   const uint32_t nFrames = h.frames();
   const uint64_t fs = h.frameSize, U = h.uncompressedSize;
   // the reference indexes the table with offset / frameSize without looking at tableSize (zra.cpp:265-268); a header whose fields
@@ -502,7 +515,7 @@ Status Engine::decompress_ra_batch(const uint8_t* dArc, size_t arcSize, uint8_t*
     if (!qmeta_.reserve(hq.size() * 8 + 64)) return zerr(64);
     HIPCHK(hipMemcpyAsync(qmeta_.p, hq.data(), hq.size() * 8, hipMemcpyHostToDevice, stream_));
     hipLaunchKernelGGL(zra_ra_direct_kernel, dim3((uint32_t)((nq + 255) / 256)), dim3(256), 0, stream_, qmeta_.as<uint64_t>(), (u32)nq, (u32)maxPieces, (u64)fs,
-                       (u64)U, dArc + h.seekTableOffset, raVerifyWholeFrames_ ? 1u : 0u, frameOff_.as<uint64_t>(), outOff_.as<uint64_t>(),
+                       (u64)U, dArc + h.seekTableOffset, (u64)bodyBase, raVerifyWholeFrames_ ? 1u : 0u, frameOff_.as<uint64_t>(), outOff_.as<uint64_t>(),
                        expect_.as<uint32_t>(), raLimit_.as<uint32_t>(), raPieceBase_.as<uint32_t>(), raPieces_.as<ZraRaPiece>());
     touched = (uint32_t)maxPieces;
   } else {
@@ -517,7 +530,7 @@ Status Engine::decompress_ra_batch(const uint8_t* dArc, size_t arcSize, uint8_t*
     P.cnt = raPlan_.as<uint32_t>(); P.need = P.cnt + nFrames; P.slot = P.need + nFrames; P.cursor = P.slot + nFrames; P.totals = P.cursor + nFrames;
     const uint64_t* dQ = qmeta_.as<uint64_t>();
     hipLaunchKernelGGL(zra_ra_count_kernel, dim3((uint32_t)((nq + 255) / 256)), dim3(256), 0, stream_, dQ, (u32)nq, (u64)fs, P);
-    hipLaunchKernelGGL(zra_ra_plan_kernel, dim3(1), dim3(1024), 0, stream_, P, nFrames, dArc + h.seekTableOffset, (u64)fs, (u64)U, passSlots,
+    hipLaunchKernelGGL(zra_ra_plan_kernel, dim3(1), dim3(1024), 0, stream_, P, nFrames, dArc + h.seekTableOffset, (u64)bodyBase, (u64)fs, (u64)U, passSlots,
                        raVerifyWholeFrames_ ? 1u : 0u, frameOff_.as<uint64_t>(), outOff_.as<uint64_t>(), expect_.as<uint32_t>(), raLimit_.as<uint32_t>(),
                        raPieceBase_.as<uint32_t>());
     hipLaunchKernelGGL(zra_ra_fill_kernel, dim3((uint32_t)((nq + 255) / 256)), dim3(256), 0, stream_, dQ, (u32)nq, (u64)fs, P, raPieceBase_.as<uint32_t>(),
@@ -537,7 +550,7 @@ Status Engine::decompress_ra_batch(const uint8_t* dArc, size_t arcSize, uint8_t*
   for (uint32_t s0 = 0; s0 < touched; s0 += passSlots) {
     const uint32_t n = std::min(passSlots, touched - s0);
     ra.limit = raLimit_.as<uint32_t>() + s0; ra.pieceBase = raPieceBase_.as<uint32_t>() + s0;
-    Status st = decode_jobs(dArc + h.size, arcSize - h.size, frameOff_.as<uint64_t>() + 2 * (size_t)s0, temp_.as<uint8_t>(), outOff_.as<uint64_t>() + s0,
+    Status st = decode_jobs(dBody, bodyBytes, frameOff_.as<uint64_t>() + 2 * (size_t)s0, temp_.as<uint8_t>(), outOff_.as<uint64_t>() + s0,
                             expect_.as<uint32_t>() + s0, n, (uint32_t)std::min<uint64_t>(fs, 0xFFFFFFFFu), 2, 0, &ra);
     if (st.zra) return st;
   }

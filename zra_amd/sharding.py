@@ -1,79 +1,195 @@
-"""Multi-GPU sharding of the compress path: frames are independent, so rank r of W owns the contiguous
-frame range [r*F/W, (r+1)*F/W). The only exchange is (1) an all-gather of the per-rank frame sizes — an exclusive scan of the
-per-rank body totals gives every rank its base offset and every rank can build the full seek table — and (2) a variable-length
-gather of the frame bodies to the root. One process per GPU; backend "nccl" (= RCCL over xGMI) on GPUs, "gloo" in the CPU tests.
-No codec work happens here; tensors are byte buffers.
+"""Several GPUs, one process per GPU: thin Python side of the distributed-archive calls of include/zra_hip.h
+(zra_amd/csrc/zra_comm.hip). Frames are independent, so rank r of W owns the contiguous frame range [F*r/W, F*(r+1)/W); the only
+exchanges are the all-gather of the per-frame sizes after compression, and — for serving — query slices to the owners and the decoded
+bytes back. All of that lives behind the C ABI; this module only
+
+  * creates the communicator: RCCL called directly by the library (`Comm.rccl`: the 128-byte id travels over torch.distributed's
+    store), or the host transport, whose two callbacks are implemented here with torch.distributed (`Comm.torch_dist`: gloo in the
+    CPU tests and the one-GPU dry runs, nccl = RCCL on GPU tensors otherwise);
+  * exposes the router (`route_queries`, pure host arithmetic — no GPU needed).
 """
+import ctypes
+
 import numpy as np
-import torch
-import torch.distributed as dist
+
+import zra_amd as Z
 
 
 def shard_range(nframes, rank, world):
-    """Frames [lo, hi) owned by `rank`."""
-    return (nframes * rank) // world, (nframes * (rank + 1)) // world
+    """Frames [lo, hi) owned by `rank` (ZraHipShardRange)."""
+    lo, hi = ctypes.c_uint64(0), ctypes.c_uint64(0)
+    Z.load().ZraHipShardRange(nframes, rank, world, ctypes.byref(lo), ctypes.byref(hi))
+    return lo.value, hi.value
 
 
-def _comm_device(t):
-    """RCCL moves device tensors directly; the gloo backend (CPU tests, single-GPU dry runs) gets host staging."""
-    return torch.device("cpu") if dist.get_backend() == "gloo" else t.device
+def owner_of_frame(nframes, world, frame):
+    return Z.load().ZraHipOwnerOfFrame(nframes, world, frame)
 
 
-def allgather_sizes(local_sizes, group=None):
-    """local_sizes: int64 tensor [n_local]. Returns the list of per-rank size tensors (rank order)."""
-    world = dist.get_world_size(group)
-    local_sizes = local_sizes.to(_comm_device(local_sizes))
-    n = torch.tensor([local_sizes.numel()], dtype=torch.int64, device=local_sizes.device)
-    counts = [torch.zeros_like(n) for _ in range(world)]
-    dist.all_gather(counts, n, group=group)
-    counts = [int(c.item()) for c in counts]
-    mx = max(counts) if counts else 0
-    padded = torch.zeros(mx, dtype=torch.int64, device=local_sizes.device)
-    padded[: local_sizes.numel()] = local_sizes
-    out = [torch.empty_like(padded) for _ in range(world)]
-    dist.all_gather(out, padded, group=group)
-    return [o[:c] for o, c in zip(out, counts)]
+def _u64p(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64))
 
 
-def stitch(all_sizes, uncompressed_size, frame_size):
-    """All ranks' frame sizes -> (header bytes incl. CRC-32, per-rank base offsets into the body, per-rank totals)."""
-    import zra_amd
-    flat = torch.cat([s.cpu() for s in all_sizes]).numpy().astype(np.uint64)
-    totals = np.array([int(s.sum().item()) for s in all_sizes], dtype=np.uint64)
-    bases = np.concatenate([[0], np.cumsum(totals)[:-1]]).astype(np.uint64)   # exclusive scan of per-rank body sizes
-    header = zra_amd.stitch_header(flat, uncompressed_size, frame_size)
-    return header, bases, totals
+def route_queries(uncompressed_size, frame_size, world, offsets, sizes):
+    """Cuts queries at ownership boundaries (ZraHipRouteQueries). Returns (slices, per_owner_count); slices is a structured array
+    with fields owner, query, offset, size, within, grouped by owner."""
+    L = Z.load()
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64); sizes = np.ascontiguousarray(sizes, dtype=np.uint64)
+    cap = len(offsets) + world + 16
+    per = np.zeros(world, dtype=np.uint64)
+    for _ in range(2):
+        buf = (Z.ZraHipSlice * cap)()
+        n = ctypes.c_size_t(0)
+        st = L.ZraHipRouteQueries(uncompressed_size, frame_size, world, _u64p(offsets), _u64p(sizes), len(offsets), buf, cap, ctypes.byref(n), _u64p(per))
+        if st.zra == 6:
+            cap = n.value
+            continue
+        Z._chk(st, "ZraHipRouteQueries")
+        break
+    out = np.zeros(n.value, dtype=[("owner", np.uint32), ("query", np.uint64), ("offset", np.uint64), ("size", np.uint64), ("within", np.uint64)])
+    for i in range(n.value):
+        out[i] = (buf[i].owner, buf[i].query, buf[i].offset, buf[i].size, buf[i].within)
+    return out, per
 
 
-def gather_archive(local_body, local_sizes, uncompressed_size, frame_size, root_buffer=None, group=None):
-    """local_body: uint8 tensor with this rank's packed frames; local_sizes: int64 [n_local].
-    Returns (archive tensor on rank 0 / None elsewhere, header bytes, bases, totals)."""
-    rank, world = dist.get_rank(group), dist.get_world_size(group)
-    all_sizes = allgather_sizes(local_sizes, group)
-    header, bases, totals = stitch(all_sizes, uncompressed_size, frame_size)
-    hlen = len(header)
-    if rank == 0:
-        need = hlen + int(totals.sum())
-        if root_buffer is None or root_buffer.numel() < need:
-            root_buffer = torch.empty(need, dtype=torch.uint8, device=local_body.device)
-        root_buffer[:hlen] = torch.frombuffer(bytearray(header), dtype=torch.uint8).to(local_body.device)
-        root_buffer[hlen: hlen + int(totals[0])] = local_body[: int(totals[0])]
-        staged = _comm_device(root_buffer) != root_buffer.device
-        ops = []
-        for r in range(1, world):
-            if int(totals[r]):
-                dst = root_buffer[hlen + int(bases[r]): hlen + int(bases[r]) + int(totals[r])]
-                if staged:
-                    tmp = torch.empty(int(totals[r]), dtype=torch.uint8)
-                    dist.recv(tmp, src=r, group=group)
-                    dst.copy_(tmp)
+class Shard:
+    """This rank's part of a distributed archive (ZraHipShard): complete header + seek table, own frames' compressed bytes."""
+
+    def __init__(self, handle):
+        self.h = handle
+        self.L = Z.load()
+
+    def header(self):
+        n = self.L.ZraHipShardHeaderSize(self.h)
+        b = ctypes.create_string_buffer(n)
+        self.L.ZraHipShardGetHeader(self.h, b)
+        return b.raw[:n]
+
+    def archive_size(self):
+        return self.L.ZraHipShardArchiveSize(self.h)
+
+    def body(self):
+        """(device pointer, offset inside the archive's body, bytes) of this rank's frames"""
+        p, base, n = ctypes.c_void_p(), ctypes.c_uint64(0), ctypes.c_uint64(0)
+        self.L.ZraHipShardGetBody(self.h, ctypes.byref(p), ctypes.byref(base), ctypes.byref(n))
+        return p.value or 0, base.value, n.value
+
+    def close(self):
+        if self.h:
+            self.L.ZraHipShardDestroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Comm:
+    """ZraHipComm. All methods are collective."""
+
+    def __init__(self, handle, rank, world, keep=None):
+        self.h, self.rank, self.world, self._keep = handle, rank, world, keep
+        self.L = Z.load()
+
+    # ---- construction
+    @classmethod
+    def rccl(cls, engine, rank, world, group=None):
+        """RCCL called by the library itself; the unique id is broadcast over torch.distributed (any backend)."""
+        import torch.distributed as dist
+        L = Z.load()
+        ident = ctypes.create_string_buffer(128)
+        if rank == 0:
+            Z._chk(L.ZraHipCommGetUniqueId(ident), "ZraHipCommGetUniqueId")
+        box = [ident.raw if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(box, src=0, group=group)
+        ident = ctypes.create_string_buffer(box[0], 128)
+        h = ctypes.c_void_p()
+        Z._chk(L.ZraHipCommCreateRccl(ctypes.byref(h), engine.h, ident, rank, world), "ZraHipCommCreateRccl")
+        return cls(h, rank, world)
+
+    @classmethod
+    def torch_dist(cls, engine, group=None):
+        """Host transport over torch.distributed: gloo moves host buffers as they are, nccl (= RCCL) gets them as device tensors."""
+        import torch
+        import torch.distributed as dist
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        on_gpu = dist.get_backend(group) == "nccl"
+
+        def as_tensor(ptr, n):
+            t = torch.frombuffer((ctypes.c_uint8 * n).from_address(ptr), dtype=torch.uint8) if n else torch.empty(0, dtype=torch.uint8)
+            return t
+
+        def allgather(user, send, recv, nbytes):
+            try:
+                s = as_tensor(send, nbytes); r = as_tensor(recv, nbytes * world)
+                if on_gpu:
+                    sd = s.cuda(); outs = [torch.empty_like(sd) for _ in range(world)]
+                    dist.all_gather(outs, sd, group=group)
+                    r.copy_(torch.cat(outs).cpu())
                 else:
-                    ops.append(dist.P2POp(dist.irecv, dst, r, group))
-        if ops:
-            # one RCCL group: the 7 inbound transfers run concurrently, each on its own point-to-point xGMI link
-            for q in dist.batch_isend_irecv(ops):
-                q.wait()
-        return root_buffer[:need], header, bases, totals
-    if int(totals[rank]):
-        dist.send(local_body[: int(totals[rank])].contiguous().to(_comm_device(local_body)), dst=0, group=group)
-    return None, header, bases, totals
+                    outs = [torch.empty(nbytes, dtype=torch.uint8) for _ in range(world)]
+                    dist.all_gather(outs, s.clone(), group=group)
+                    r.copy_(torch.cat(outs))
+                return 0
+            except Exception as e:          # a Python exception must not unwind through the C frames
+                print("zra_amd.sharding allgather failed:", repr(e))
+                return 1
+
+        def exchange(user, ns, sp, sb, sn, nr, rp, rb, rn):
+            try:
+                ops, back = [], []
+                for i in range(nr):
+                    host = as_tensor(rb[i], rn[i])
+                    t = torch.empty(rn[i], dtype=torch.uint8, device="cuda") if on_gpu else host
+                    back.append((host, t))
+                    ops.append(dist.P2POp(dist.irecv, t, rp[i], group))
+                for i in range(ns):
+                    t = as_tensor(sb[i], sn[i])
+                    ops.append(dist.P2POp(dist.isend, t.cuda() if on_gpu else t.clone(), sp[i], group))
+                if ops:
+                    for q in dist.batch_isend_irecv(ops):
+                        q.wait()
+                if on_gpu:
+                    for host, t in back:
+                        host.copy_(t.cpu())
+                return 0
+            except Exception as e:
+                print("zra_amd.sharding exchange failed:", repr(e))
+                return 1
+
+        tr = Z.ZraHipHostTransport(None, Z.ALLGATHER_FN(allgather), Z.EXCHANGE_FN(exchange))
+        h = ctypes.c_void_p()
+        Z._chk(Z.load().ZraHipCommCreateHost(ctypes.byref(h), engine.h, ctypes.byref(tr), rank, world), "ZraHipCommCreateHost")
+        return cls(h, rank, world, keep=tr)
+
+    # ---- collectives
+    def compress(self, d_local, local_bytes, total_bytes, level, frame_size, checksum=True):
+        """ZraHipCommCompress: d_local = device pointer of this rank's frames' bytes. Returns a Shard."""
+        sh = ctypes.c_void_p()
+        Z._chk(self.L.ZraHipCommCompress(self.h, d_local, local_bytes, total_bytes, level, frame_size, checksum, ctypes.byref(sh)), "ZraHipCommCompress")
+        return Shard(sh)
+
+    def gather_archive(self, shard, root=0, d_archive=0, capacity=0):
+        """ZraHipCommGatherArchive: the archive in one piece on `root` (device pointer + capacity there). Returns its size on the root."""
+        n = ctypes.c_size_t(0)
+        Z._chk(self.L.ZraHipCommGatherArchive(self.h, shard.h, root, d_archive, capacity, ctypes.byref(n)), "ZraHipCommGatherArchive")
+        return n.value
+
+    def serve(self, shard, offsets, sizes, out_offsets, d_out):
+        """ZraHipCommServe: this rank's queries over the whole uncompressed range; answers at d_out + out_offsets[q]."""
+        o = np.ascontiguousarray(offsets, dtype=np.uint64); s = np.ascontiguousarray(sizes, dtype=np.uint64); d = np.ascontiguousarray(out_offsets, dtype=np.uint64)
+        Z._chk(self.L.ZraHipCommServe(self.h, shard.h, _u64p(o), _u64p(s), _u64p(d), len(o), d_out), "ZraHipCommServe")
+
+    def close(self):
+        if self.h:
+            self.L.ZraHipCommDestroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
