@@ -227,6 +227,19 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
     Z.load()
     eng = Z.Engine(local_rank)
+    comm, transport = None, "none"
+    if world > 1:
+        from zra_amd import sharding
+        # RCCL called by the library itself (ncclAllGather / grouped ncclSend+ncclRecv on the engine's stream); the host transport over
+        # torch.distributed is the fallback (and the only choice when every rank sits on one GPU: RCCL refuses duplicate devices)
+        want = os.environ.get("ZRA_BENCH_TRANSPORT", "torch" if one_gpu else "rccl")
+        if want == "rccl":
+            try:
+                comm, transport = sharding.Comm.rccl(eng, rank, world), "rccl (direct)"
+            except Exception as e:
+                sys.stderr.write("bench: direct RCCL communicator failed (%r); falling back to torch.distributed\n" % (e,))
+        if comm is None:
+            comm, transport = sharding.Comm.torch_dist(eng), "torch.distributed/" + dist.get_backend()
 
     fs = args.frame_kib << 10
     N = int(args.size_gib * GiB) // fs * fs            # per-GPU bytes (weak scaling: fixed per rank)
@@ -238,11 +251,11 @@ def main():
     nframes = N // fs
     bound = Z.GetOutputBufferSize(N, fs)
     d_arc = torch.empty(bound + 64, dtype=torch.uint8, device=dev)
-    # RA workload: offsets uniform in [0, N-size-1) from a fixed seed, per rank over its own shard
+    # RA workload: offsets uniform over the whole (all ranks') uncompressed range from a fixed seed; N>1: routed to the owners
     q = args.queries
     qb = args.query_bytes
     rng = np.random.RandomState(42 + rank)
-    offs = rng.randint(0, N - qb - 1, size=q).astype(np.uint64)
+    offs = rng.randint(0, N * world - qb - 1, size=q).astype(np.uint64)
     sizes = np.full(q, qb, dtype=np.uint64)
     oofs = (np.arange(q, dtype=np.uint64) * qb)
     d_ra = torch.empty(q * qb + 64, dtype=torch.uint8, device=dev)
@@ -284,16 +297,17 @@ def main():
             arc_size = eng.compress(d_in.data_ptr(), N, d_arc.data_ptr(), args.level, fs, True)
             mf_ms.append(eng.kernel_stats())
         else:
-            # sharded: local frames -> packed local body + sizes; all-gather sizes; header stitched on every rank;
-            # bodies gathered (variable length) to rank 0 behind the stitched header
-            d_sizes = torch.empty(nframes, dtype=torch.int64, device=dev)
-            body_len = eng.compress_frames(d_in.data_ptr(), N, d_arc.data_ptr(), d_sizes.data_ptr(), args.level, fs, True)
+            # sharded (include/zra_hip.h, distributed archive): local frames through the same kernels, all-gather of the frame sizes,
+            # seek table stitched on every rank, frame bodies gathered to rank 0 behind the header (north_star: "final gather")
+            old = getattr(step, "shard", None)
+            if old is not None:
+                old.close()
+            step.shard = comm.compress(d_in.data_ptr(), N, N * world, args.level, fs, True)
             mf_ms.append(eng.kernel_stats())
-            from zra_amd import sharding
-            root, hdr, bases, totals = sharding.gather_archive(d_arc[:body_len], d_sizes, N * world, fs, getattr(step, "root", None))
-            if rank == 0:
-                step.root = root
-            arc_size = (len(hdr) + int(totals.sum())) if rank == 0 else body_len
+            arc_size = step.shard.archive_size()
+            if rank == 0 and (getattr(step, "root", None) is None or step.root.numel() < arc_size):
+                step.root = torch.empty(arc_size + (arc_size >> 4) + 64, dtype=torch.uint8, device=dev)
+            comm.gather_archive(step.shard, 0, step.root.data_ptr() if rank == 0 else 0, step.root.numel() if rank == 0 else 0)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         # RA over this rank's own shard (the archive stays sharded for serving; queries are routed to the owner)
@@ -301,18 +315,8 @@ def main():
             eng.decompress_ra_batch(d_arc.data_ptr(), arc_size, d_ra.data_ptr(), offs, sizes, oofs)
             dec_stats.append(eng.kernel_stats())
         else:
-            # local archive for serving = local header + local body (cheap host stitch of local sizes)
-            lsz = d_sizes.cpu().numpy().astype(np.uint64)
-            lh = Z.stitch_header(lsz, N, fs)
-            loc = getattr(step, "loc", None)
-            need = len(lh) + int(lsz.sum())
-            if loc is None or loc.numel() < need:
-                loc = torch.empty(need + 64, dtype=torch.uint8, device=dev)
-                step.loc = loc
-            loc[: len(lh)] = torch.frombuffer(bytearray(lh), dtype=torch.uint8).to(dev)
-            loc[len(lh): need] = d_arc[: need - len(lh)]
-            torch.cuda.synchronize()               # torch's copy stream -> the engine's streams
-            eng.decompress_ra_batch(loc.data_ptr(), need, d_ra.data_ptr(), offs, sizes, oofs)
+            # sharded serving: this rank's queries go over the WHOLE range; slices travel to the owners, answers come back
+            comm.serve(step.shard, offs, sizes, oofs, d_ra.data_ptr())
             dec_stats.append(eng.kernel_stats())
         torch.cuda.synchronize()
         t2 = time.perf_counter()
@@ -335,10 +339,21 @@ def main():
 
     # spot-check RA output of the last step against the resident input
     chk = rng.randint(0, q, size=64)
+    other = {}                                            # N>1: the corpus of the rank that owns the bytes, regenerated on the host
     for i in chk:
         o = int(offs[i])
-        if not torch.equal(d_ra[int(oofs[i]): int(oofs[i]) + qb], d_in[o: o + qb]):
-            raise SystemExit("RA result mismatch at query %d" % i)
+        got = d_ra[int(oofs[i]): int(oofs[i]) + qb]
+        for r in range(o // N, (o + qb - 1) // N + 1):
+            a, b = max(o, r * N), min(o + qb, (r + 1) * N)
+            if r == rank:
+                want = d_in[a - r * N: b - r * N]
+            else:
+                if r not in other:
+                    other[r] = synth_corpus(64 << 20, seed=1 + r)
+                idx = (np.arange(a - r * N, b - r * N) % len(other[r]))
+                want = torch.from_numpy(other[r][idx]).to(dev)
+            if not torch.equal(got[a - o: b - o], want):
+                raise SystemExit("RA result mismatch at query %d" % i)
 
     # SURVEY §8d RA size classes (outside the timed region, single rank): 64 KiB unaligned (touches 2 frames) and 1 MiB queries
     ra_classes = {}
@@ -394,7 +409,7 @@ def main():
             "config": {"workload": "%.3g GiB/GPU synthetic 'Silesia stand-in' corpus (64 MiB mixed text/binary/skew, tiled), frameSize=%d KiB, level %d, checksum on: "
                                    "CompressBuffer + %d random DecompressRA(offset,%d B) queries per GPU" % (N / GiB, fs >> 10, args.level, q, qb),
                        "frame_size": fs, "level": args.level, "bytes_per_gpu": N, "queries_per_gpu": q, "query_bytes": qb,
-                       "parallelism": "frames sharded by index, %d rank(s)" % world, "compression_ratio": round(ratio, 3),
+                       "parallelism": "frames sharded by index, %d rank(s)" % world, "transport": transport, "compression_ratio": round(ratio, 3),
                        "bit_exact_gate": gate},
             "compress_gibs": round(N * world / GiB / (np.mean(comp_ms) / 1e3), 3),
             "ra_gibs_returned": round(q * qb * world / GiB / (np.mean(ra_ms) / 1e3), 3),
@@ -404,11 +419,16 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "zra_mf_dfast_kernel" if args.level in (3, 4) else "zra_mf_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "frac_of_measured_6290": round(achieved / 6290.0, 5), "traffic": traffic,
                          "launch_ms": round(mf_launch_ms, 3), "launches_per_call": launches, "algorithmic_bytes_per_launch": int(alg_per_launch),
-                         "other_kernels_launch_ms": {"zra_entropy_kernel": round(ent_launch_ms, 3), "zra_decode_frames_kernel": round(dec_launch_ms, 3)}},
+                         "other_kernels_launch_ms": {"zra_entropy_kernel": round(ent_launch_ms, 3), "zra_dec_parse+huf+chain+exec (one decode pass)": round(dec_launch_ms, 3)}},
             "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
     if world > 1:
+        sh = getattr(step, "shard", None)
+        if sh is not None:
+            sh.close()
+        comm.close()
+        dist.barrier()
         dist.destroy_process_group()
 
 

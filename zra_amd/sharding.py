@@ -9,6 +9,7 @@ bytes back. All of that lives behind the C ABI; this module only
   * exposes the router (`route_queries`, pure host arithmetic — no GPU needed).
 """
 import ctypes
+import sys
 
 import numpy as np
 
@@ -81,7 +82,8 @@ class Shard:
 
     def __del__(self):
         try:
-            self.close()
+            if not sys.is_finalizing():          # at interpreter exit the HIP runtime may already be gone
+                self.close()
         except Exception:
             pass
 
@@ -190,6 +192,7 @@ class Comm:
 
     def __del__(self):
         try:
-            self.close()
+            if not sys.is_finalizing():          # at interpreter exit the HIP runtime may already be gone
+                self.close()
         except Exception:
             pass
