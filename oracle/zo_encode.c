@@ -19,12 +19,17 @@ static const u8 CP128[13][7] = {{17,15,16,2,5,0,2},{17,12,13,1,6,0,1},{17,13,15,
 static const u8 CP256[13][7] = {{18,16,16,1,4,0,2},{18,13,14,1,6,0,1},{18,14,14,1,5,0,2},{18,16,16,1,4,0,2},{18,16,17,2,5,2,3},{18,18,18,3,5,2,3},
   {18,18,19,3,5,4,4},{18,18,19,4,4,4,4},{18,18,19,4,4,8,5},{18,18,19,5,4,8,5},{18,18,19,6,4,8,5},{18,18,19,5,4,12,6},{18,19,19,7,4,12,6}};
 
+/* row 0 of the level tables of ZSTD_getCParams_internal: "base for negative levels" (strategy fast); the level itself becomes the
+ * acceleration: targetLength = -level */
+static const u8 CPNEG16[7] = {14,12,13,1,5,1,1}, CPNEG128[7] = {17,12,12,1,5,1,1}, CPNEG256[7] = {18,12,13,1,5,1,1};
+
 int zo_get_cparams(int level, size_t S, zo_cparams* cp) {
   if (level == 0) level = 3;
-  if (level < 1 || level > 12 || S > (256u << 10)) return -1;
-  const u8* r = S <= (16u << 10) ? CP16[level] : S <= (128u << 10) ? CP128[level] : CP256[level];
+  if (level > 12 || S > (256u << 10)) return -1;
+  const u8* r = level < 0 ? (S <= (16u << 10) ? CPNEG16 : S <= (128u << 10) ? CPNEG128 : CPNEG256)
+                          : (S <= (16u << 10) ? CP16[level] : S <= (128u << 10) ? CP128[level] : CP256[level]);
   cp->windowLog = r[0]; cp->chainLog = r[1]; cp->hashLog = r[2]; cp->searchLog = r[3];
-  cp->minMatch = r[4]; cp->targetLength = r[5]; cp->strategy = r[6];
+  cp->minMatch = r[4]; cp->targetLength = level < 0 ? (u32)(-level) : r[5]; cp->strategy = r[6];
   u32 srcLog = S < 64 ? 6 : hb32((u32)S - 1) + 1;
   if (cp->windowLog > srcLog) cp->windowLog = srcLog;
   if (cp->hashLog > cp->windowLog + 1) cp->hashLog = cp->windowLog + 1;
@@ -336,11 +341,12 @@ static size_t huf_compress(u8* dst, size_t cap, const u8* src, size_t n, int str
 
 static size_t min_gain(size_t n, unsigned strategy) { return (n >> (strategy >= 8 ? strategy - 1 : 6)) + 2; }
 
-static size_t compress_literals(const estate* prev, estate* next, unsigned strategy, u8* dst, size_t cap, const u8* lit, size_t n) {
+static size_t compress_literals(const estate* prev, estate* next, unsigned strategy, int disabled, u8* dst, size_t cap, const u8* lit, size_t n) {
   size_t minGain = min_gain(n, strategy);
   size_t lh = 3 + (n >= 1024) + (n >= 16384);
   int single = n < 256;
   next->huf = prev->huf; next->hufRepeat = prev->hufRepeat;
+  if (disabled) return raw_literals(dst, lit, n, 0);   /* ZSTD_compressLiterals: disableLiteralCompression (fast strategy with targetLength > 0) */
   if (n <= (prev->hufRepeat == 2 ? 6u : 63u)) return raw_literals(dst, lit, n, 0);
   if (cap < lh + 1) return ZO_ERR(ZO_E_DSTSIZE_TOOSMALL);
   int repeat = prev->hufRepeat, preferRepeat = strategy < 4 ? n <= 1024 : 0;
@@ -481,7 +487,7 @@ static size_t entropy_compress(cctx* c, u8* dst, size_t cap) {
   u8* op = dst; u8* oend = dst + cap;
   size_t nbSeq = c->nbSeq;
   {
-    size_t r = compress_literals(prev, next, strategy, op, cap, c->lits, c->litSize);
+    size_t r = compress_literals(prev, next, strategy, c->cp.strategy == 1 && c->cp.targetLength > 0, op, cap, c->lits, c->litSize);
     if (ZO_ISERR(r)) return r;
     op += r;
   }
@@ -581,7 +587,6 @@ static int cctx_init(cctx* c, int level, size_t n) {
   memset(c, 0, sizeof(*c));
   if (zo_get_cparams(level, n, &c->cp)) return -1;
   if (c->cp.strategy > 5) return -1; /* btlazy2 and up: not restated (SURVEY Appendix A status table) */
-  if (c->cp.strategy == 1 && c->cp.targetLength) return -1;
   size_t hsz = (size_t)1 << c->cp.hashLog, csz = (size_t)1 << c->cp.chainLog;
   size_t blockMax = n < (128u << 10) ? n : (128u << 10);
   c->hashTable = (u32*)calloc(hsz, 4);

@@ -29,7 +29,8 @@ def test_extension_is_loaded_and_gpu_visible(zra):
 
 
 @pytest.mark.parametrize("level,fs", [(3, 65536), (0, 16384), (3, 16384), (1, 65536), (2, 65536), (4, 65536), (5, 65536), (6, 65536), (7, 65536),
-                                      (9, 65536), (10, 65536), (3, 262144), (9, 262144), (5, 262144), (3, 100000), (3, 4096), (1, 200000)])
+                                      (9, 65536), (10, 65536), (3, 262144), (9, 262144), (5, 262144), (3, 100000), (3, 4096), (1, 200000),
+                                      (-1, 65536), (-5, 16384), (-20, 262144), (-128, 65536)])
 def test_compress_buffer_bit_exact(zra, gens, level, fs):
     for name, d in gens.items():
         d = d[: 5 * fs + 777] if fs >= 65536 else d[: 37 * fs + 11]
@@ -102,7 +103,7 @@ def test_randomised_differential_compress(zra, seed):
         fs = int(rng.choice([1024, 4096, 16384, 65536, 65536, 131072, 262144, 50000]))
         n = int(rng.choice([0, 1, 6, 7, 8, 100, fs - 1, fs, fs + 1, 3 * fs + 17, int(rng.randint(1, 6 * fs))]))
         n = min(n, 600000)
-        level = int(rng.choice([1, 2, 3, 3, 3, 4, 5, 6, 7, 8, 9, 10]))
+        level = int(rng.choice([1, 2, 3, 3, 3, 4, 5, 6, 7, 8, 9, 10, -1, -3, -9, -64]))
         d = _random_input(rng, n)
         st, ref = O.zra_compress(d, level, fs, bool(case & 1))
         if st != (0, 0):

@@ -77,12 +77,18 @@ const uint8_t kCP256[13][7] = {{18,16,16,1,4,0,2},{18,13,14,1,6,0,1},{18,14,14,1
 
 inline uint32_t hbit(uint32_t x) { return 31u - (uint32_t)__builtin_clz(x); }
 
-// returns false when (level, size) needs a strategy this engine does not implement (btlazy2 and up, negative levels, > 256 KiB)
+// row 0 of ZSTD_getCParams_internal's level tables, "base for negative levels": strategy fast, the level becomes the acceleration
+// (targetLength = -level), and literals are then stored raw (ZSTD_compressLiterals' disableLiteralCompression)
+const uint8_t kCPNeg16[7] = {14, 12, 13, 1, 5, 1, 1}, kCPNeg128[7] = {17, 12, 12, 1, 5, 1, 1}, kCPNeg256[7] = {18, 12, 13, 1, 5, 1, 1};
+
+// returns false when (level, size) needs a strategy this engine does not implement (btlazy2 and up, > 256 KiB)
 bool get_params(int level, size_t S, ZraEncParams* p) {
   if (level == 0) level = 3;
-  if (level < 1 || level > 12 || S > (256u << 10) || S == 0) return false;
-  const uint8_t* r = S <= (16u << 10) ? kCP16[level] : S <= (128u << 10) ? kCP128[level] : kCP256[level];
-  p->windowLog = r[0]; p->chainLog = r[1]; p->hashLog = r[2]; p->searchLog = r[3]; p->minMatch = r[4]; p->targetLength = r[5]; p->strategy = r[6];
+  if (level > 12 || S > (256u << 10) || S == 0) return false;
+  const uint8_t* r = level < 0 ? (S <= (16u << 10) ? kCPNeg16 : S <= (128u << 10) ? kCPNeg128 : kCPNeg256)
+                               : (S <= (16u << 10) ? kCP16[level] : S <= (128u << 10) ? kCP128[level] : kCP256[level]);
+  p->windowLog = r[0]; p->chainLog = r[1]; p->hashLog = r[2]; p->searchLog = r[3]; p->minMatch = r[4];
+  p->targetLength = level < 0 ? (uint32_t)(-level) : r[5]; p->strategy = r[6];
   const uint32_t srcLog = S < 64 ? 6 : hbit((uint32_t)S - 1) + 1;
   if (p->windowLog > srcLog) p->windowLog = srcLog;
   if (p->hashLog > p->windowLog + 1) p->hashLog = p->windowLog + 1;
@@ -90,7 +96,7 @@ bool get_params(int level, size_t S, ZraEncParams* p) {
   if (cycleLog > p->windowLog) p->chainLog -= cycleLog - p->windowLog;
   if (p->windowLog < 10) p->windowLog = 10;
   p->blockSize = std::min<uint32_t>(128u << 10, 1u << p->windowLog);
-  return p->strategy <= 5 && !(p->strategy == 1 && p->targetLength);
+  return p->strategy <= 5;
 }
 
 }  // namespace

@@ -599,7 +599,7 @@ zra_entropy_kernel(ZraEncArgs a, u32 block) {
       u32 mode = 0, hSize = 0, streams = 1, encSize = 0;
       u32 ssz[4] = {0, 0, 0, 0};
       const u8* nbTab = S.hNb; const u16* valTab = S.hVal;
-      if (n > 63) {
+      if (n > 63 && !(strategy == 1 && P.targetLength > 0)) {      // fast strategy with an acceleration (negative levels): literals stay raw
         const u32 cntS = S.lit.hist[0][tid] + S.lit.hist[1][tid] + S.lit.hist[2][tid] + S.lit.hist[3][tid];
         __syncthreads();
         S.lit.hist[0][tid] = cntS;
