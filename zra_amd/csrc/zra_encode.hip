@@ -267,8 +267,8 @@ Status Engine::compress_impl_body(const uint8_t* dIn, size_t inSize, uint8_t* dB
         } else {
           // frames per wave: as many as it takes to have every frame of the batch resident at once (32 waves per CU)
           static const int pwEnv = std::getenv("ZRA_MF_PERWAVE") ? std::atoi(std::getenv("ZRA_MF_PERWAVE")) : 0;
-          // (lazy2's deep chain searches diverge too much: 0.84 GiB/s with 1 frame per wave, 0.64 with 2, 0.50 with 4; fast gains 9.4 -> 14.5)
-          uint32_t perWave = pwEnv > 0 ? (uint32_t)pwEnv : full.strategy >= 5 ? 1u
+          // hash-chain strategies (greedy / lazy / lazy2): one frame per wave, the wave-cooperative finder; fast gains 9.4 -> 14.5 from 8
+          uint32_t perWave = pwEnv > 0 ? (uint32_t)pwEnv : full.strategy >= 3 ? 1u
                            : std::min<uint32_t>(8u, std::max<uint32_t>(1u, (nb + (uint32_t)numCUs_ * 32 - 1) / ((uint32_t)numCUs_ * 32)));
           hipLaunchKernelGGL(zra_mf_kernel, dim3((nb + perWave - 1) / perWave), dim3(64), dynLds, stream_, a, blk, 0xFFFFFFFFu, 0u, perWave);
           if (oddTail) hipLaunchKernelGGL(zra_mf_dfast_kernel, dim3(1), dim3(64), filterBytes, stream_, a, blk, (uint32_t)(nb - 1), (uint32_t)(nb - 1));

@@ -523,6 +523,166 @@ __device__ u32 mf_dfast_lean(const ZraEncParams& P, u32* HL, u32* HS, const u8* 
   return be - anchor;
 }
 
+
+// ================================================================================================
+// Wave-cooperative hash chain (greedy / lazy / lazy2, levels 5-10), bit-exact with mf_lazy + HC::search above.
+//
+// What makes the serial formulation slow on this machine is one dependent memory round trip after the other: every insertion, every
+// chain step, every candidate compare. Two facts about the reference remove most of them:
+//   * ZSTD_insertAndFindFirstIndex inserts EVERY position below the search position, in order, whatever the parse decided; so the
+//     tables at the moment position p is searched are a function of p alone, and the head the search starts from is exactly what
+//     p's own chain slot receives when p is inserted (chainT[(p+1) & mask] = hashT[h(p)] at that time).
+//   * ZSTD_HcFindBestMatch only reads: the answer for p does not depend on whether later positions are already in the tables.
+// So a window of 64 consecutive positions is inserted at once (one table gather + two scatters; lanes that share a bucket are linked
+// in lane order), all 64 are searched at once (each lane walks its own chain: the round trips of 64 searches overlap), and the parse
+// then consumes the answers from registers. Repcode tests and match extensions depend on the parse and stay serial, but use the
+// wave-wide counters. Only what the reference actually searched moves nextToUpdate; the positions inserted ahead of it at the end of
+// a block are remembered as a hole if the next block's "limited update after a very long match" skips them (FrameState.holeLo/Hi).
+struct HCW {
+  u32* hashT; u32* chainT; u32 hlog, mls, cmask, chainSize, searchLog;
+  u32 insEnd;            // first index (position + 1) not inserted yet
+  u32 holeLo, holeHi;    // indices the reference never inserted although they are in the tables
+  u32 ntuRef;            // the reference's nextToUpdate
+  u32 w;                 // window: answers for positions [w, w + 64) are in rml / roff of lane p - w
+  u32 rml, roff;
+  bool haveWin;
+};
+
+__device__ __forceinline__ void hcw_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// inserts indices [H.insEnd, endIdx) in order, 64 per step
+__device__ void hcw_insert(HCW& H, const u8* src, u32 endIdx, int lane) {
+  while (H.insEnd < endIdx) {
+    const u32 idx = H.insEnd + (u32)lane;
+    const bool act = idx < endIdx;
+    u32 h = 0, link = 0;
+    if (act) { h = hashN(src + idx - 1, H.hlog, H.mls); link = H.hashT[h]; }
+    // lanes with the same bucket: each links to the nearest earlier one, the last one becomes the head
+    bool head = act;
+    u64 rem = __ballot(act);
+    while (rem) {
+      const u32 l = (u32)__builtin_ctzll(rem);
+      const u32 hv = bcast(h, l);
+      const u64 same = __ballot(act && h == hv);
+      if (act && h == hv) {
+        const u64 before = same & ((1ull << lane) - 1ull), after = same >> lane >> 1;
+        if (before) link = H.insEnd + (63u - (u32)__builtin_clzll(before));
+        head = after == 0;
+      }
+      rem &= ~same;
+    }
+    if (act) {
+      H.chainT[idx & H.cmask] = link;
+      if (head) H.hashT[h] = idx;
+    }
+    H.insEnd = min(endIdx, H.insEnd + 64u);
+    hcw_sync();
+  }
+}
+
+// answers of ZSTD_HcFindBestMatch for the positions [w, w + 64) that can be searched in this block (p <= ilimit)
+__device__ void hcw_search_window(HCW& H, const u8* src, u32 w, u32 ilimit, u32 be, int lane) {
+  const u32 lastPos = min(w + 63u, ilimit);
+  hcw_insert(H, src, lastPos + 2, lane);                 // indices <= lastPos + 1: every position of the window has its chain slot
+  const u32 p = w + (u32)lane;
+  u32 ml = 3, offCode = 999999999u;
+  if (p <= lastPos) {
+    const u32 curr = p + 1, minChain = curr > H.chainSize ? curr - H.chainSize : 0;
+    int attempts = 1 << H.searchLog;
+    u32 mi = H.chainT[curr & H.cmask];
+    while (mi >= 1 && attempts > 0) {
+      if (mi >= H.holeLo && mi < H.holeHi) { mi = H.chainT[mi & H.cmask]; continue; }      // not in the reference's tables
+      const u32 m = mi - 1;
+      u32 cur = 0;
+      if (src[m + ml] == src[p + ml]) cur = count_eq(src, p, m, be);
+      if (cur > ml) { ml = cur; offCode = curr - mi + 2; if (p + cur == be) break; }
+      if (mi <= minChain) break;
+      mi = H.chainT[mi & H.cmask];
+      attempts--;
+    }
+  }
+  H.w = w; H.rml = ml; H.roff = offCode; H.haveWin = true;
+}
+
+__device__ u32 mf_lazy_wave(HCW& H, const u8* src, u32 bs, u32 be, u32* rep, u64* seqs, u32* nOut, int depth, int lane) {
+  u32 o1 = rep[0], o2 = rep[1], saved;
+  u32 anchor = bs, n = 0;
+  const u32 ilimit = be >= 8 ? be - 8 : 0;
+  u32 ip = mf_prologue(bs, o1, o2, saved);
+  H.haveWin = false;
+  // the reference's search at position q (q <= ilimit): answer from the window, which slides when q leaves it
+  auto search = [&](u32 q, u32& oc) -> u32 {
+    if (!H.haveWin || q < H.w || q >= H.w + 64u) hcw_search_window(H, src, q, ilimit, be, lane);
+    if (q + 1 > H.ntuRef) H.ntuRef = q + 1;
+    oc = bcast(H.roff, q - H.w);
+    return bcast(H.rml, q - H.w);
+  };
+  auto put = [&](u32 ll, u32 ml, u32 offVal) { if (lane == 0) seqs[n] = (u64)ll | ((u64)ml << 20) | ((u64)offVal << 40); n++; };
+  while (ip < ilimit) {
+    u32 ml = 0, start = ip + 1, off = 0; bool stored = false;
+    if (o1 > 0 && ld32(src + ip + 1 - o1) == ld32(src + ip + 1)) {
+      ml = wave_count_eq(src, ip + 5, ip + 5 - o1, be, lane) + 4;
+      if (depth == 0) stored = true;
+    }
+    if (!stored) {
+      u32 oc2; u32 m2 = search(ip, oc2);
+      if (m2 > ml) { ml = m2; start = ip; off = oc2; }
+      if (ml < 4) { ip += ((ip - anchor) >> 8) + 1; continue; }
+      if (depth >= 1) {
+        while (ip < ilimit) {
+          ip++;
+          if (off && o1 > 0 && ld32(src + ip) == ld32(src + ip - o1)) {
+            const u32 mr = wave_count_eq(src, ip + 4, ip + 4 - o1, be, lane) + 4;
+            const int g2 = (int)(mr * 3), g1 = (int)(ml * 3 - hb32(off + 1) + 1);
+            if (mr >= 4 && g2 > g1) { ml = mr; off = 0; start = ip; }
+          }
+          {
+            m2 = search(ip, oc2);
+            const int g2 = (int)(m2 * 4 - hb32(oc2 + 1)), g1 = (int)(ml * 4 - hb32(off + 1) + 4);
+            if (m2 >= 4 && g2 > g1) { ml = m2; off = oc2; start = ip; continue; }
+          }
+          if (depth == 2 && ip < ilimit) {
+            ip++;
+            if (off && o1 > 0 && ld32(src + ip) == ld32(src + ip - o1)) {
+              const u32 mr = wave_count_eq(src, ip + 4, ip + 4 - o1, be, lane) + 4;
+              const int g2 = (int)(mr * 4), g1 = (int)(ml * 4 - hb32(off + 1) + 1);
+              if (mr >= 4 && g2 > g1) { ml = mr; off = 0; start = ip; }
+            }
+            {
+              m2 = search(ip, oc2);
+              const int g2 = (int)(m2 * 4 - hb32(oc2 + 1)), g1 = (int)(ml * 4 - hb32(off + 1) + 7);
+              if (m2 >= 4 && g2 > g1) { ml = m2; off = oc2; start = ip; continue; }
+            }
+          }
+          break;
+        }
+      }
+      if (off) {
+        const u32 ro = off - 2;
+        // while (start > anchor && start > ro && src[start-1] == src[start-ro-1]) { start--; ml++; }
+        const u32 back = (start > ro) ? wave_count_back(src, start, start - ro, anchor, lane) : 0u;
+        start -= back; ml += back;
+        o2 = o1; o1 = ro;
+      }
+    }
+    put(start - anchor, ml, off ? off + 1 : 1);
+    anchor = ip = start + ml;
+    while (ip <= ilimit && o2 > 0 && ld32(src + ip) == ld32(src + ip - o2)) {
+      const u32 rl = wave_count_eq(src, ip + 4, ip + 4 - o2, be, lane) + 4;
+      const u32 t = o2; o2 = o1; o1 = t;
+      put(0, rl, 1);
+      ip += rl; anchor = ip;
+    }
+  }
+  rep[0] = o1 ? o1 : saved; rep[1] = o2 ? o2 : saved;
+  *nOut = n;
+  return be - anchor;
+}
+
 }  // namespace
 
 // ---- per-frame setup shared by the match-finder kernels: which block of which frame, cleared tables on a fresh frame
@@ -552,7 +712,7 @@ __device__ __forceinline__ bool mf_frame_setup(const ZraEncArgs& a, u32 block, i
     uint4* t4 = (uint4*)F.hashT;
     for (size_t i = lane; i < words / 4; i += 64) t4[i] = make_uint4(0, 0, 0, 0);
     for (size_t i = (words / 4) * 4 + lane; i < words; i += 64) F.hashT[i] = 0;
-    if (lane == 0) { F.st->rep[0] = 1; F.st->rep[1] = 4; F.st->rep[2] = 8; F.st->nextToUpdate = 1; }
+    if (lane == 0) { F.st->rep[0] = 1; F.st->rep[1] = 4; F.st->rep[2] = 8; F.st->nextToUpdate = 1; F.st->insEnd = 1; F.st->holeLo = F.st->holeHi = 0; }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -653,22 +813,43 @@ zra_mf_kernel(ZraEncArgs a, u32 block, u32 only, u32 onlySlot, u32 perWave) {
     if (f >= a.nFrames) break;
     MfFrame G;
     const bool go = mf_frame_setup(a, block, lane, G, f, all ? f : onlySlot);
-    if ((u32)lane == k) { F = G; mine = go && G.P->strategy != 2; }      // dfast frames belong to zra_mf_dfast_kernel
+    if ((u32)lane == k || perWave == 1) { F = G; mine = go && G.P->strategy != 2; }      // dfast frames belong to zra_mf_dfast_kernel
   }
-  if (!mine) return;
+  // one frame per wave and a hash-chain strategy: the whole wave works on it
+  const bool coop = perWave == 1 && mine && F.P->strategy >= 3;
+  if (!mine || (!coop && lane != 0 && perWave == 1)) return;
   const ZraEncParams& P = *F.P;
   const u8* src = F.src; ZraEncFrameState* st = F.st; ZraEncBlockOut* bo = F.bo;
   u32* hashT = F.hashT; u32* chainT = F.chainT; u64* seqs = F.seqs;
   const u32 bs = F.bs, be = F.be;
   u32 rep[3] = {st->rep[0], st->rep[1], st->rep[2]};
   u32 lastLL;
-  bo->skip = 0;
+  if (!coop || lane == 0) bo->skip = 0;
   Emit E; E.seqs = seqs; E.n = 0;
   // limited update after a very long match (A.4.3 hash chain prologue; harmless for the other finders)
-  u32 ntu = st->nextToUpdate;
+  const u32 ntu0 = st->nextToUpdate;
+  u32 ntu = ntu0;
   {
     const u32 cur = bs + 1;
     if (cur > ntu + 384) { const u32 d = cur - ntu - 384; ntu = cur - (d < 192 ? d : 192); }
+  }
+  if (coop) {
+    HCW H; H.hashT = hashT; H.chainT = chainT; H.hlog = P.hashLog; H.mls = P.minMatch < 4 ? 4 : P.minMatch > 6 ? 6 : P.minMatch;
+    H.chainSize = 1u << P.chainLog; H.cmask = H.chainSize - 1; H.searchLog = P.searchLog;
+    H.insEnd = st->insEnd; H.holeLo = st->holeLo; H.holeHi = st->holeHi; H.ntuRef = ntu;
+    if (ntu > ntu0) {
+      // indices [ntu0, ntu) are never inserted by the reference: those already in the tables become the hole, the rest is skipped
+      if (H.insEnd > ntu0) { H.holeLo = ntu0; H.holeHi = min(ntu, H.insEnd); }
+      if (H.insEnd < ntu) H.insEnd = ntu;
+    }
+    u32 nSeq = 0;
+    lastLL = mf_lazy_wave(H, src, bs, be, rep, seqs, &nSeq, (int)P.strategy - 3, lane);
+    if (lane == 0) {
+      st->nextToUpdate = H.ntuRef; st->insEnd = H.insEnd; st->holeLo = H.holeLo; st->holeHi = H.holeHi;
+      bo->nbSeq = nSeq; bo->lastLL = lastLL;
+      bo->rep[0] = rep[0]; bo->rep[1] = rep[1]; bo->rep[2] = rep[2];
+    }
+    return;
   }
   if (P.strategy == 1) lastLL = mf_fast(P, hashT, src, bs, be, rep, E);
   else {
@@ -677,7 +858,7 @@ zra_mf_kernel(ZraEncArgs a, u32 block, u32 only, u32 onlySlot, u32 perWave) {
     lastLL = mf_lazy(H, src, bs, be, rep, E, (int)P.strategy - 3);
     ntu = H.nextToUpdate;
   }
-  st->nextToUpdate = ntu;
+  st->nextToUpdate = ntu; st->insEnd = ntu;
   bo->nbSeq = E.n; bo->lastLL = lastLL;
   bo->rep[0] = rep[0]; bo->rep[1] = rep[1]; bo->rep[2] = rep[2];   // confirmed by stage 2 only if the block is emitted compressed
 }

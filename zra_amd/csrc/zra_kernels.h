@@ -104,6 +104,10 @@ struct ZraFseCTable {
 struct ZraEncFrameState {
   uint32_t rep[3];
   uint32_t nextToUpdate;
+  // wave-cooperative hash-chain finder: it inserts whole windows ahead of the parse. insEnd = first index not inserted yet; the
+  // indices [holeLo, holeHi) were inserted ahead of the parse at the end of a block but are skipped by the reference's "limited
+  // update after a very long match" at the start of the next one — chain walks step over them
+  uint32_t insEnd, holeLo, holeHi;
   uint32_t outPos;                 // bytes of the frame already written to its slot
   uint32_t hufRepeat;              // 0 none, 1 check, 2 valid
   uint32_t llRepeat, ofRepeat, mlRepeat;
