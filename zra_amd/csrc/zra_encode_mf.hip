@@ -538,7 +538,17 @@ __device__ u32 mf_dfast_lean(const ZraEncParams& P, u32* HL, u32* HS, const u8* 
 // then consumes the answers from registers. Repcode tests and match extensions depend on the parse and stay serial, but use the
 // wave-wide counters. Only what the reference actually searched moves nextToUpdate; the positions inserted ahead of it at the end of
 // a block are remembered as a hole if the next block's "limited update after a very long match" skips them (FrameState.holeLo/Hi).
+#ifdef ZRA_MF_PROFILE
+#define HPROF(k) { __builtin_amdgcn_s_waitcnt(0); const u64 n_ = __builtin_amdgcn_s_memtime(); H.pt[k] += n_ - H.pl; H.pl = n_; }
+#define HCNT(k, v) { H.pt[k] += (v); }
+#else
+#define HPROF(k)
+#define HCNT(k, v)
+#endif
 struct HCW {
+#ifdef ZRA_MF_PROFILE
+  u64 pt[12]; u64 pl;
+#endif
   u32* hashT; u32* chainT; u32 hlog, mls, cmask, chainSize, searchLog;
   u32 insEnd;            // first index (position + 1) not inserted yet
   u32 holeLo, holeHi;    // indices the reference never inserted although they are in the tables
@@ -557,6 +567,7 @@ __device__ __forceinline__ void hcw_sync() {
 // inserts indices [H.insEnd, endIdx) in order, 64 per step
 __device__ void hcw_insert(HCW& H, const u8* src, u32 endIdx, int lane) {
   while (H.insEnd < endIdx) {
+    HCNT(6, 1)
     const u32 idx = H.insEnd + (u32)lane;
     const bool act = idx < endIdx;
     u32 h = 0, link = 0;
@@ -574,6 +585,7 @@ __device__ void hcw_insert(HCW& H, const u8* src, u32 endIdx, int lane) {
         head = after == 0;
       }
       rem &= ~same;
+      HCNT(7, 1)
     }
     if (act) {
       H.chainT[idx & H.cmask] = link;
@@ -587,24 +599,38 @@ __device__ void hcw_insert(HCW& H, const u8* src, u32 endIdx, int lane) {
 // answers of ZSTD_HcFindBestMatch for the positions [w, w + 64) that can be searched in this block (p <= ilimit)
 __device__ void hcw_search_window(HCW& H, const u8* src, u32 w, u32 ilimit, u32 be, int lane) {
   const u32 lastPos = min(w + 63u, ilimit);
+  HPROF(2)
   hcw_insert(H, src, lastPos + 2, lane);                 // indices <= lastPos + 1: every position of the window has its chain slot
+  HPROF(0) HCNT(3, 1)
   const u32 p = w + (u32)lane;
   u32 ml = 3, offCode = 999999999u;
   if (p <= lastPos) {
     const u32 curr = p + 1, minChain = curr > H.chainSize ? curr - H.chainSize : 0;
     int attempts = 1 << H.searchLog;
     u32 mi = H.chainT[curr & H.cmask];
+    // the lane's own 16 bytes stay in registers; per candidate ONE round trip: its 16 bytes and its chain link are requested together
+    // (the reference's "byte at ml first" is only a shortcut: a candidate that differs there cannot be longer than ml).
+    // (Measured and dropped: two positions per lane in one loop, window of 128 — 101 VGPRs, 4 waves per SIMD, 1.5 instead of 2.8 GiB/s.)
+    const bool wide = p + 16 <= be;
+    const u64 own0 = wide ? ld64(src + p) : 0ull, own1 = wide ? ld64(src + p + 8) : 0ull;
     while (mi >= 1 && attempts > 0) {
-      if (mi >= H.holeLo && mi < H.holeHi) { mi = H.chainT[mi & H.cmask]; continue; }      // not in the reference's tables
+      const u32 nxt = H.chainT[mi & H.cmask];
+      if (mi >= H.holeLo && mi < H.holeHi) { mi = nxt; continue; }      // not in the reference's tables
       const u32 m = mi - 1;
       u32 cur = 0;
-      if (src[m + ml] == src[p + ml]) cur = count_eq(src, p, m, be);
+      if (wide) {
+        const u64 d0 = ld64(src + m) ^ own0, d1 = ld64(src + m + 8) ^ own1;
+        if (d0) cur = (u32)__builtin_ctzll(d0) >> 3;
+        else if (d1) cur = 8 + ((u32)__builtin_ctzll(d1) >> 3);
+        else cur = 16 + count_eq(src, p + 16, m + 16, be);
+      } else if (src[m + ml] == src[p + ml]) cur = count_eq(src, p, m, be);
       if (cur > ml) { ml = cur; offCode = curr - mi + 2; if (p + cur == be) break; }
       if (mi <= minChain) break;
-      mi = H.chainT[mi & H.cmask];
+      mi = nxt;
       attempts--;
     }
   }
+  HPROF(1)
   H.w = w; H.rml = ml; H.roff = offCode; H.haveWin = true;
 }
 
@@ -614,6 +640,10 @@ __device__ u32 mf_lazy_wave(HCW& H, const u8* src, u32 bs, u32 be, u32* rep, u64
   const u32 ilimit = be >= 8 ? be - 8 : 0;
   u32 ip = mf_prologue(bs, o1, o2, saved);
   H.haveWin = false;
+#ifdef ZRA_MF_PROFILE
+  for (int k_ = 0; k_ < 12; k_++) H.pt[k_] = 0;
+  H.pl = __builtin_amdgcn_s_memtime();
+#endif
   // the reference's search at position q (q <= ilimit): answer from the window, which slides when q leaves it
   auto search = [&](u32 q, u32& oc) -> u32 {
     if (!H.haveWin || q < H.w || q >= H.w + 64u) hcw_search_window(H, src, q, ilimit, be, lane);
@@ -680,6 +710,10 @@ __device__ u32 mf_lazy_wave(HCW& H, const u8* src, u32 bs, u32 be, u32* rep, u64
   }
   rep[0] = o1 ? o1 : saved; rep[1] = o2 ? o2 : saved;
   *nOut = n;
+#ifdef ZRA_MF_PROFILE
+  HPROF(2) HCNT(4, n) HCNT(5, 1)
+  if (lane == 0) for (int k_ = 0; k_ < 12; k_++) atomicAdd(&zra_mf_prof[k_], H.pt[k_]);
+#endif
   return be - anchor;
 }
 
