@@ -1,0 +1,44 @@
+// bring-up: known access patterns for calibrating rocprofv3's FETCH_SIZE / WRITE_SIZE on gfx950 at the widths the codec uses
+// (run under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE`, one pass each; compare with the counts printed here)
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+__device__ __forceinline__ uint64_t mix(uint64_t x) { x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33; return x; }
+// every lane reads 4 bytes at a random 4-byte-aligned place of a 4 GiB buffer
+__global__ void calib_gather4(const uint32_t* buf, uint64_t words, uint32_t* out, int rounds) {
+  uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; uint32_t acc = 0;
+  for (int r = 0; r < rounds; r++) { s = mix(s + 0x9E3779B97F4A7C15ULL); acc += buf[s % words]; }
+  out[(uint64_t)blockIdx.x * blockDim.x + threadIdx.x] = acc;
+}
+// every lane writes 4 bytes at a random place
+__global__ void calib_scatter4(uint32_t* buf, uint64_t words, int rounds) {
+  uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (int r = 0; r < rounds; r++) { s = mix(s + 0x9E3779B97F4A7C15ULL); buf[s % words] = (uint32_t)s; }
+}
+// every lane reads 8 bytes, lanes consecutive (the coalesced frame reads): 512 B per wave instruction
+__global__ void calib_stream8(const uint64_t* buf, uint64_t n, uint64_t* out) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; uint64_t acc = 0;
+  for (; i < n; i += (uint64_t)gridDim.x * blockDim.x) acc += buf[i];
+  out[(uint64_t)blockIdx.x * blockDim.x + threadIdx.x] = acc;
+}
+__global__ void calib_streamwrite8(uint64_t* buf, uint64_t n) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i < n; i += (uint64_t)gridDim.x * blockDim.x) buf[i] = i;
+}
+int main() {
+  const uint64_t bytes = 4ull << 30;
+  void* b; void* o;
+  if (hipMalloc(&b, bytes) != hipSuccess || hipMalloc(&o, 64 << 20) != hipSuccess) return 1;
+  hipMemset(b, 1, bytes);
+  const int blocks = 4096, threads = 256, rounds = 256;
+  const uint64_t nreq = (uint64_t)blocks * threads * rounds;
+  hipLaunchKernelGGL(calib_gather4, dim3(blocks), dim3(threads), 0, 0, (const uint32_t*)b, bytes / 4, (uint32_t*)o, rounds);
+  hipLaunchKernelGGL(calib_scatter4, dim3(blocks), dim3(threads), 0, 0, (uint32_t*)b, bytes / 4, rounds);
+  hipLaunchKernelGGL(calib_stream8, dim3(blocks), dim3(threads), 0, 0, (const uint64_t*)b, bytes / 8, (uint64_t*)o);
+  hipLaunchKernelGGL(calib_streamwrite8, dim3(blocks), dim3(threads), 0, 0, (uint64_t*)b, bytes / 8);
+  hipDeviceSynchronize();
+  std::printf("calib_gather4: %llu lane requests of 4 B (%.3f GB useful)\n", (unsigned long long)nreq, nreq * 4 / 1e9);
+  std::printf("calib_scatter4: %llu lane stores of 4 B (%.3f GB useful)\n", (unsigned long long)nreq, nreq * 4 / 1e9);
+  std::printf("calib_stream8 / calib_streamwrite8: %.3f GB each\n", bytes / 1e9);
+  return 0;
+}

@@ -11,6 +11,7 @@
 #include <vector>
 
 extern "C" __global__ void zra_mf_kernel(ZraEncArgs a, uint32_t block, uint32_t only, uint32_t onlySlot, uint32_t perWave);
+extern "C" __global__ void zra_mf_hc_kernel(ZraEncArgs a, uint32_t block);
 extern "C" __global__ void zra_mf_dfast_kernel(ZraEncArgs a, uint32_t block, uint32_t only, uint32_t onlySlot);
 extern "C" __global__ void zra_entropy_kernel(ZraEncArgs a, uint32_t block);
 
@@ -270,7 +271,8 @@ Status Engine::compress_impl_body(const uint8_t* dIn, size_t inSize, uint8_t* dB
           // hash-chain strategies (greedy / lazy / lazy2): one frame per wave, the wave-cooperative finder; fast gains 9.4 -> 14.5 from 8
           uint32_t perWave = pwEnv > 0 ? (uint32_t)pwEnv : full.strategy >= 3 ? 1u
                            : std::min<uint32_t>(8u, std::max<uint32_t>(1u, (nb + (uint32_t)numCUs_ * 32 - 1) / ((uint32_t)numCUs_ * 32)));
-          hipLaunchKernelGGL(zra_mf_kernel, dim3((nb + perWave - 1) / perWave), dim3(64), dynLds, stream_, a, blk, 0xFFFFFFFFu, 0u, perWave);
+          if (full.strategy >= 3 && pwEnv <= 0) hipLaunchKernelGGL(zra_mf_hc_kernel, dim3(nb), dim3(64), dynLds, stream_, a, blk);
+          else hipLaunchKernelGGL(zra_mf_kernel, dim3((nb + perWave - 1) / perWave), dim3(64), dynLds, stream_, a, blk, 0xFFFFFFFFu, 0u, perWave);
           if (oddTail) hipLaunchKernelGGL(zra_mf_dfast_kernel, dim3(1), dim3(64), filterBytes, stream_, a, blk, (uint32_t)(nb - 1), (uint32_t)(nb - 1));
         }
       }

@@ -897,6 +897,55 @@ zra_mf_kernel(ZraEncArgs a, u32 block, u32 only, u32 onlySlot, u32 perWave) {
   bo->rep[0] = rep[0]; bo->rep[1] = rep[1]; bo->rep[2] = rep[2];   // confirmed by stage 2 only if the block is emitted compressed
 }
 
+// Match finder for batches whose full-size frames use a hash-chain strategy (greedy / lazy / lazy2): one wave per frame, the
+// wave-cooperative finder. A short last frame whose cparams select "fast" is parsed here by one lane; a dfast one is left to
+// zra_mf_dfast_kernel (second launch, `only`).
+extern "C" __global__ void __launch_bounds__(64)
+zra_mf_hc_kernel(ZraEncArgs a, u32 block) {
+  const int lane = threadIdx.x;
+  const u32 f = blockIdx.x;
+  if (f >= a.nFrames) return;
+  MfFrame F;
+  if (!mf_frame_setup(a, block, lane, F, f, f)) return;
+  const ZraEncParams& P = *F.P;
+  if (P.strategy == 2) return;
+  ZraEncFrameState* st = F.st; ZraEncBlockOut* bo = F.bo;
+  const u32 bs = F.bs, be = F.be;
+  u32 rep[3] = {st->rep[0], st->rep[1], st->rep[2]};
+  // limited update after a very long match (A.4.3 hash chain prologue)
+  const u32 ntu0 = st->nextToUpdate;
+  u32 ntu = ntu0;
+  {
+    const u32 cur = bs + 1;
+    if (cur > ntu + 384) { const u32 d = cur - ntu - 384; ntu = cur - (d < 192 ? d : 192); }
+  }
+  if (P.strategy == 1) {
+    if (lane != 0) return;
+    bo->skip = 0;
+    Emit E; E.seqs = F.seqs; E.n = 0;
+    const u32 lastLL = mf_fast(P, F.hashT, F.src, bs, be, rep, E);
+    st->nextToUpdate = ntu; st->insEnd = ntu;
+    bo->nbSeq = E.n; bo->lastLL = lastLL;
+    bo->rep[0] = rep[0]; bo->rep[1] = rep[1]; bo->rep[2] = rep[2];
+    return;
+  }
+  HCW H; H.hashT = F.hashT; H.chainT = F.chainT; H.hlog = P.hashLog; H.mls = P.minMatch < 4 ? 4 : P.minMatch > 6 ? 6 : P.minMatch;
+  H.chainSize = 1u << P.chainLog; H.cmask = H.chainSize - 1; H.searchLog = P.searchLog;
+  H.insEnd = st->insEnd; H.holeLo = st->holeLo; H.holeHi = st->holeHi; H.ntuRef = ntu;
+  if (ntu > ntu0) {
+    // indices [ntu0, ntu) are never inserted by the reference: those already in the tables become the hole, the rest is skipped
+    if (H.insEnd > ntu0) { H.holeLo = ntu0; H.holeHi = min(ntu, H.insEnd); }
+    if (H.insEnd < ntu) H.insEnd = ntu;
+  }
+  u32 nSeq = 0;
+  const u32 lastLL = mf_lazy_wave(H, F.src, bs, be, rep, F.seqs, &nSeq, (int)P.strategy - 3, lane);
+  if (lane == 0) {
+    st->nextToUpdate = H.ntuRef; st->insEnd = H.insEnd; st->holeLo = H.holeLo; st->holeHi = H.holeHi;
+    bo->skip = 0; bo->nbSeq = nSeq; bo->lastLL = lastLL;
+    bo->rep[0] = rep[0]; bo->rep[1] = rep[1]; bo->rep[2] = rep[2];   // confirmed by stage 2 only if the block is emitted compressed
+  }
+}
+
 #ifdef ZRA_MF_PROFILE
 // bring-up only: copies (and optionally clears) the phase counters
 extern "C" __attribute__((visibility("default"))) void ZraHipDebugReadMfProfile(unsigned long long* out24, int reset) {
