@@ -393,12 +393,16 @@ def main():
         dec_launch_ms = float(np.mean([x["dec_ms"] / max(1, x["dec_launches"]) for x in dec_stats])) if dec_stats else 0.0
         alg_per_launch = alg_bytes / launches
         achieved = alg_per_launch / 1e9 / (mf_launch_ms / 1e3) if mf_launch_ms > 0 else 0.0
-        traffic = None
+        # HBM-side bytes of one match-finder launch: PMC passes (FETCH_SIZE, WRITE_SIZE, separate runs) of THIS workload, stored with the
+        # commit they were taken at (profiles/traffic.json, tools/pmc_bench.sh); per-frame scaling only if the size differs
+        traffic, traffic_src = None, None
         tpath = os.path.join(HERE, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                # PMC-measured HBM bytes per frame (FETCH_SIZE + WRITE_SIZE passes, profiles/) x frames of one launch
-                traffic = int(json.load(open(tpath)).get("zra_mf_kernel_hbm_bytes_per_frame") * (nframes / launches))
+                tj = json.load(open(tpath))["bench16g_r02"]
+                per_frame = tj["zra_mf_dfast_kernel"]["hbm_bytes_per_launch"] * tj["zra_mf_dfast_kernel"]["launches"] / tj["frames"]
+                traffic = int(per_frame * nframes / launches)
+                traffic_src = "rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE of bench.py --steps 1 at commit %s (profiles/r02_pmc_bench16g.txt)" % tj["measured_at_commit"]
             except Exception:
                 traffic = None
         line = {
@@ -417,7 +421,7 @@ def main():
             "ra_size_classes": ra_classes,
             "ra_latency": ra_latency,
             "roofline": {"bound": "hbm", "kernel": "zra_mf_dfast_kernel" if args.level in (3, 4) else "zra_mf_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "frac_of_measured_6290": round(achieved / 6290.0, 5), "traffic": traffic,
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "frac_of_measured_6290": round(achieved / 6290.0, 5), "traffic": traffic, "traffic_source": traffic_src,
                          "launch_ms": round(mf_launch_ms, 3), "launches_per_call": launches, "algorithmic_bytes_per_launch": int(alg_per_launch),
                          "other_kernels_launch_ms": {"zra_entropy_kernel": round(ent_launch_ms, 3), "zra_dec_parse+huf+chain+exec (one decode pass)": round(dec_launch_ms, 3)}},
             "cpu_baseline": cpu,
