@@ -165,3 +165,28 @@ def mutated_archives(seed, cases, compress):
         if len(a) < 38 or int.from_bytes(a[18:26], "little") > (1 << 24):
             continue
         yield case, a
+
+
+def random_lz_input_far(rng, n):
+    """second seeded generator of the differential tests: far offsets (up to the 256 KiB window), periodic data, long zero runs (very
+    long matches: zstd's "limited update after a very long match" at block starts), text-like alphabets"""
+    out = bytearray()
+    words = [bytes(rng.randint(97, 123, size=int(rng.randint(2, 9))).astype(np.uint8).tolist()) for _ in range(int(rng.choice([8, 60, 500])))]
+    while len(out) < n:
+        r = rng.rand()
+        if r < 0.3:
+            for _ in range(int(rng.randint(1, 40))):
+                out += words[int(rng.randint(0, len(words)))] + b" "
+        elif r < 0.6 and len(out) > 16:
+            off = int(rng.randint(1, min(len(out), 262000) + 1)); k = int(rng.choice([4, 5, 6, 7, 8, 9, 15, 33, 130, 1000, 20000]))
+            st = len(out) - off
+            for i in range(k):
+                out.append(out[st + i])
+        elif r < 0.7:
+            per = bytes(rng.randint(0, 256, size=int(rng.choice([1, 2, 3, 5, 8, 13, 64, 257]))).astype(np.uint8).tolist())
+            out += per * int(rng.randint(1, 3000 // len(per) + 2))
+        elif r < 0.8:
+            out += bytes(int(rng.choice([10, 1000, 70000, 200000])))
+        else:
+            out += bytes(rng.randint(0, 256, size=int(rng.choice([1, 10, 300, 5000]))).astype(np.uint8).tolist())
+    return bytes(out[:n])

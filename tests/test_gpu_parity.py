@@ -6,6 +6,7 @@ import ctypes
 import hashlib
 import json
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -30,7 +31,7 @@ def test_extension_is_loaded_and_gpu_visible(zra):
 
 @pytest.mark.parametrize("level,fs", [(3, 65536), (0, 16384), (3, 16384), (1, 65536), (2, 65536), (4, 65536), (5, 65536), (6, 65536), (7, 65536),
                                       (9, 65536), (10, 65536), (3, 262144), (9, 262144), (5, 262144), (3, 100000), (3, 4096), (1, 200000),
-                                      (-1, 65536), (-5, 16384), (-20, 262144), (-128, 65536)])
+                                      (-1, 65536), (-5, 16384), (-20, 262144), (-128, 65536), (5, 131072), (6, 100000)])
 def test_compress_buffer_bit_exact(zra, gens, level, fs):
     for name, d in gens.items():
         d = d[: 5 * fs + 777] if fs >= 65536 else d[: 37 * fs + 11]
@@ -95,9 +96,11 @@ def test_match_finder_sequences_equal_the_oracle(zra, gpu_engine, gens, level, f
 _random_input = C.random_lz_input
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", list(range(24)) + [386])
 def test_randomised_differential_compress(zra, seed):
-    """Differential test against the oracle on seeded synthetic LZ data: random sizes, frame sizes and levels (25 cases per seed)."""
+    """Differential test against the oracle on seeded synthetic LZ data: random sizes, frame sizes and levels (25 cases per seed).
+    Seed 386 (found by the soak, tests/gpu_soak.py): level 5 @ 128 KiB, a chain table smaller than the frame — the window-ahead
+    insertion of the hash-chain finder overwrote chain links the search still needed."""
     rng = np.random.RandomState(1000 + seed)
     for case in range(25):
         fs = int(rng.choice([1024, 4096, 16384, 65536, 65536, 131072, 262144, 50000]))
@@ -114,6 +117,15 @@ def test_randomised_differential_compress(zra, seed):
         arc = zra.CompressBuffer(d, level, fs, bool(case & 1))
         assert arc == ref, (seed, case, n, fs, level)
         assert zra.DecompressBuffer(arc) == d, (seed, case, n, fs, level)
+
+
+@pytest.mark.parametrize("seed", [1297, 1298, 100, 101])
+def test_randomised_differential_compress_far_offsets(zra, seed, monkeypatch):
+    """The same differential test on the second generator (far offsets, long zero runs, periodic data). Seed 1297 (found by the soak):
+    level 4 @ 256 KiB, two blocks, the first ending in a very long match — the positions the hash-chain finder had inserted ahead of
+    the parse had to come out of the tables again when the second block started with zstd's limited update."""
+    monkeypatch.setattr(sys.modules[__name__], "_random_input", C.random_lz_input_far)
+    test_randomised_differential_compress(zra, seed)
 
 
 @pytest.mark.parametrize("seed", range(8))

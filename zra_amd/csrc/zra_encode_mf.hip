@@ -536,8 +536,8 @@ __device__ u32 mf_dfast_lean(const ZraEncParams& P, u32* HL, u32* HS, const u8* 
 // So a window of 64 consecutive positions is inserted at once (one table gather + two scatters; lanes that share a bucket are linked
 // in lane order), all 64 are searched at once (each lane walks its own chain: the round trips of 64 searches overlap), and the parse
 // then consumes the answers from registers. Repcode tests and match extensions depend on the parse and stay serial, but use the
-// wave-wide counters. Only what the reference actually searched moves nextToUpdate; the positions inserted ahead of it at the end of
-// a block are remembered as a hole if the next block's "limited update after a very long match" skips them (FrameState.holeLo/Hi).
+// wave-wide counters. Only what the reference actually searched moves nextToUpdate; if the next block's "limited update after a
+// very long match" skips the (at most 66) positions inserted ahead of it at the end of a block, hcw_undo takes them out again.
 #ifdef ZRA_MF_PROFILE
 #define HPROF(k) { __builtin_amdgcn_s_waitcnt(0); const u64 n_ = __builtin_amdgcn_s_memtime(); H.pt[k] += n_ - H.pl; H.pl = n_; }
 #define HCNT(k, v) { H.pt[k] += (v); }
@@ -551,17 +551,34 @@ struct HCW {
 #endif
   u32* hashT; u32* chainT; u32 hlog, mls, cmask, chainSize, searchLog;
   u32 insEnd;            // first index (position + 1) not inserted yet
-  u32 holeLo, holeHi;    // indices the reference never inserted although they are in the tables
   u32 ntuRef;            // the reference's nextToUpdate
   u32 w;                 // window: answers for positions [w, w + 64) are in rml / roff of lane p - w
   u32 rml, roff;
   bool haveWin;
+  // chain tables smaller than the frame (chainLog < windowLog): inserting index i overwrites the link of index i - chainSize. The
+  // reference never follows that link once i is inserted (i - chainSize is below its minChain by then), but a window is inserted
+  // AHEAD of the positions searched in it, so the links it overwrote (at most 66, ring of 128 by index) are kept in LDS
+  u32* oldLink;
 };
 
 __device__ __forceinline__ void hcw_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// takes the indices [from, H.insEnd) out of the tables again, newest first: the head of an index's bucket goes back to what the index
+// linked to, its chain slot gets back what it held before (oldLink ring). One lane; at most 66 indices, at most once per block.
+__device__ void hcw_undo(HCW& H, const u8* src, u32 from, int lane) {
+  if (lane == 0) {
+    for (u32 idx = H.insEnd; idx-- > from;) {
+      const u32 h = hashN(src + idx - 1, H.hlog, H.mls);
+      H.hashT[h] = H.chainT[idx & H.cmask];
+      H.chainT[idx & H.cmask] = H.oldLink[idx & 127u];
+    }
+  }
+  H.insEnd = from;
+  hcw_sync();
 }
 
 // inserts indices [H.insEnd, endIdx) in order, 64 per step
@@ -588,6 +605,7 @@ __device__ void hcw_insert(HCW& H, const u8* src, u32 endIdx, int lane) {
       HCNT(7, 1)
     }
     if (act) {
+      H.oldLink[idx & 127u] = idx > H.chainSize ? H.chainT[idx & H.cmask] : 0u;
       H.chainT[idx & H.cmask] = link;
       if (head) H.hashT[h] = idx;
     }
@@ -614,8 +632,8 @@ __device__ void hcw_search_window(HCW& H, const u8* src, u32 w, u32 ilimit, u32 
     const bool wide = p + 16 <= be;
     const u64 own0 = wide ? ld64(src + p) : 0ull, own1 = wide ? ld64(src + p + 8) : 0ull;
     while (mi >= 1 && attempts > 0) {
-      const u32 nxt = H.chainT[mi & H.cmask];
-      if (mi >= H.holeLo && mi < H.holeHi) { mi = nxt; continue; }      // not in the reference's tables
+      const u32 over = mi + H.chainSize;                                  // the index that shares mi's chain slot
+      const u32 nxt = (over > curr && over < H.insEnd) ? H.oldLink[over & 127u] : H.chainT[mi & H.cmask];
       const u32 m = mi - 1;
       u32 cur = 0;
       if (wide) {
@@ -746,7 +764,7 @@ __device__ __forceinline__ bool mf_frame_setup(const ZraEncArgs& a, u32 block, i
     uint4* t4 = (uint4*)F.hashT;
     for (size_t i = lane; i < words / 4; i += 64) t4[i] = make_uint4(0, 0, 0, 0);
     for (size_t i = (words / 4) * 4 + lane; i < words; i += 64) F.hashT[i] = 0;
-    if (lane == 0) { F.st->rep[0] = 1; F.st->rep[1] = 4; F.st->rep[2] = 8; F.st->nextToUpdate = 1; F.st->insEnd = 1; F.st->holeLo = F.st->holeHi = 0; }
+    if (lane == 0) { F.st->rep[0] = 1; F.st->rep[1] = 4; F.st->rep[2] = 8; F.st->nextToUpdate = 1; F.st->insEnd = 1; }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -867,19 +885,24 @@ zra_mf_kernel(ZraEncArgs a, u32 block, u32 only, u32 onlySlot, u32 perWave) {
     const u32 cur = bs + 1;
     if (cur > ntu + 384) { const u32 d = cur - ntu - 384; ntu = cur - (d < 192 ? d : 192); }
   }
+  __shared__ u32 hcOld[128];
   if (coop) {
-    HCW H; H.hashT = hashT; H.chainT = chainT; H.hlog = P.hashLog; H.mls = P.minMatch < 4 ? 4 : P.minMatch > 6 ? 6 : P.minMatch;
+    HCW H; H.oldLink = hcOld; H.hashT = hashT; H.chainT = chainT; H.hlog = P.hashLog; H.mls = P.minMatch < 4 ? 4 : P.minMatch > 6 ? 6 : P.minMatch;
     H.chainSize = 1u << P.chainLog; H.cmask = H.chainSize - 1; H.searchLog = P.searchLog;
-    H.insEnd = st->insEnd; H.holeLo = st->holeLo; H.holeHi = st->holeHi; H.ntuRef = ntu;
+    H.insEnd = st->insEnd; H.ntuRef = ntu;
+    for (u32 i = (u32)lane; i < 128; i += 64) hcOld[i] = st->ring[i];
+    hcw_sync();
     if (ntu > ntu0) {
-      // indices [ntu0, ntu) are never inserted by the reference: those already in the tables become the hole, the rest is skipped
-      if (H.insEnd > ntu0) { H.holeLo = ntu0; H.holeHi = min(ntu, H.insEnd); }
-      if (H.insEnd < ntu) H.insEnd = ntu;
+      // indices [ntu0, ntu) are never inserted by the reference: those inserted ahead of the parse come out again, the rest is skipped
+      if (H.insEnd > ntu0) hcw_undo(H, src, ntu0, lane);
+      H.insEnd = ntu;
     }
     u32 nSeq = 0;
     lastLL = mf_lazy_wave(H, src, bs, be, rep, seqs, &nSeq, (int)P.strategy - 3, lane);
+    hcw_sync();
+    for (u32 i = (u32)lane; i < 128; i += 64) st->ring[i] = hcOld[i];
     if (lane == 0) {
-      st->nextToUpdate = H.ntuRef; st->insEnd = H.insEnd; st->holeLo = H.holeLo; st->holeHi = H.holeHi;
+      st->nextToUpdate = H.ntuRef; st->insEnd = H.insEnd;
       bo->nbSeq = nSeq; bo->lastLL = lastLL;
       bo->rep[0] = rep[0]; bo->rep[1] = rep[1]; bo->rep[2] = rep[2];
     }
@@ -929,18 +952,23 @@ zra_mf_hc_kernel(ZraEncArgs a, u32 block) {
     bo->rep[0] = rep[0]; bo->rep[1] = rep[1]; bo->rep[2] = rep[2];
     return;
   }
-  HCW H; H.hashT = F.hashT; H.chainT = F.chainT; H.hlog = P.hashLog; H.mls = P.minMatch < 4 ? 4 : P.minMatch > 6 ? 6 : P.minMatch;
+  __shared__ u32 hcOld[128];
+  HCW H; H.oldLink = hcOld; H.hashT = F.hashT; H.chainT = F.chainT; H.hlog = P.hashLog; H.mls = P.minMatch < 4 ? 4 : P.minMatch > 6 ? 6 : P.minMatch;
   H.chainSize = 1u << P.chainLog; H.cmask = H.chainSize - 1; H.searchLog = P.searchLog;
-  H.insEnd = st->insEnd; H.holeLo = st->holeLo; H.holeHi = st->holeHi; H.ntuRef = ntu;
+  H.insEnd = st->insEnd; H.ntuRef = ntu;
+  for (u32 i = (u32)lane; i < 128; i += 64) hcOld[i] = st->ring[i];
+  hcw_sync();
   if (ntu > ntu0) {
-    // indices [ntu0, ntu) are never inserted by the reference: those already in the tables become the hole, the rest is skipped
-    if (H.insEnd > ntu0) { H.holeLo = ntu0; H.holeHi = min(ntu, H.insEnd); }
-    if (H.insEnd < ntu) H.insEnd = ntu;
+    // indices [ntu0, ntu) are never inserted by the reference: those inserted ahead of the parse come out again, the rest is skipped
+    if (H.insEnd > ntu0) hcw_undo(H, F.src, ntu0, lane);
+    H.insEnd = ntu;
   }
   u32 nSeq = 0;
   const u32 lastLL = mf_lazy_wave(H, F.src, bs, be, rep, F.seqs, &nSeq, (int)P.strategy - 3, lane);
+  hcw_sync();
+  for (u32 i = (u32)lane; i < 128; i += 64) st->ring[i] = hcOld[i];
   if (lane == 0) {
-    st->nextToUpdate = H.ntuRef; st->insEnd = H.insEnd; st->holeLo = H.holeLo; st->holeHi = H.holeHi;
+    st->nextToUpdate = H.ntuRef; st->insEnd = H.insEnd;
     bo->skip = 0; bo->nbSeq = nSeq; bo->lastLL = lastLL;
     bo->rep[0] = rep[0]; bo->rep[1] = rep[1]; bo->rep[2] = rep[2];   // confirmed by stage 2 only if the block is emitted compressed
   }

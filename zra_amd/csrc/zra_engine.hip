@@ -332,7 +332,8 @@ Status Engine::decode_launch(const ZraDecodeArgs& a0, const uint32_t* dExpect, u
     a.nextActive = (active == listA) ? listB : listA;
     const uint32_t gridParse = (uint32_t)std::min<uint64_t>(nActive, (uint64_t)numCUs_ * perCUParse);
     static const uint32_t chainWaves = std::getenv("ZRA_DEC_CHAIN_WAVES") ? (uint32_t)std::atoi(std::getenv("ZRA_DEC_CHAIN_WAVES")) : 8u;   // bring-up: occupancy sweep
-    const uint32_t gridChain = (uint32_t)std::min<uint64_t>((nActive + 63) / 64, (uint64_t)numCUs_ * chainWaves);
+    static const uint32_t chainGrid = std::getenv("ZRA_DEC_CHAIN_GRID") ? (uint32_t)std::atoi(std::getenv("ZRA_DEC_CHAIN_GRID")) : 0u;        // bring-up: absolute wave count
+    const uint32_t gridChain = (uint32_t)std::min<uint64_t>((nActive + 63) / 64, chainGrid ? chainGrid : (uint64_t)numCUs_ * chainWaves);
     const uint32_t gridExec = (uint32_t)std::min<uint64_t>(nActive, (uint64_t)numCUs_ * perCUExec);
     hipLaunchKernelGGL(zra_dec_parse_kernel, dim3(gridParse), dim3(64), 0, stream_, a);
     hipLaunchKernelGGL(zra_dec_huf_kernel, dim3((uint32_t)std::min<uint64_t>((nActive + 15) / 16, (uint64_t)numCUs_ * 2)), dim3(64), 0, stream_, a);

@@ -104,10 +104,12 @@ struct ZraFseCTable {
 struct ZraEncFrameState {
   uint32_t rep[3];
   uint32_t nextToUpdate;
-  // wave-cooperative hash-chain finder: it inserts whole windows ahead of the parse. insEnd = first index not inserted yet; the
-  // indices [holeLo, holeHi) were inserted ahead of the parse at the end of a block but are skipped by the reference's "limited
-  // update after a very long match" at the start of the next one — chain walks step over them
-  uint32_t insEnd, holeLo, holeHi;
+  // wave-cooperative hash-chain finder: it inserts whole windows ahead of the parse. insEnd = first index not inserted yet (at the end
+  // of a block up to 66 indices beyond nextToUpdate); ring[i & 127] = what index i found in its chain slot when it was inserted. If
+  // the next block starts with the reference's "limited update after a very long match", the indices inserted ahead are taken out
+  // of the tables again, newest first, with these values.
+  uint32_t insEnd;
+  uint32_t ring[128];
   uint32_t outPos;                 // bytes of the frame already written to its slot
   uint32_t hufRepeat;              // 0 none, 1 check, 2 valid
   uint32_t llRepeat, ofRepeat, mlRepeat;
