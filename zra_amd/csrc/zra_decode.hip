@@ -900,6 +900,15 @@ struct Zds {
     ptr -= nbBytes; bc -= nbBytes * 8; c = ld64(base + ptr);
     return r;
   }
+  // the same transition without its status and without control flow around the load (so that the load can be in flight together with
+  // the table cells of the next sequence): all three cases above move min(bc / 8, ptr) bytes, and for streams of 8 bytes and more
+  // the container always equals the 8 bytes at ptr, so an unconditional load is exact. `pad`: 8 readable bytes for shorter streams.
+  __device__ __forceinline__ void reload_quiet(bool wide, const u8* pad) {
+    const u32 nb = bc <= 64 ? min(bc >> 3, ptr) : 0u;
+    ptr -= nb; bc -= nb * 8;
+    const u64 v = ld64(wide ? base + ptr : pad);
+    c = nb ? v : c;
+  }
 };
 
 }  // namespace
@@ -917,6 +926,12 @@ zra_dec_chain_kernel(ZraDecodeArgs a) {
   u32 sLL = 0, sOF = 0, sML = 0, rep0 = 1, rep1 = 4, rep2 = 8;
   u32 i = 0, nbSeq = 0, outPos = 0, litPos = 0, outCap = 0, regen = 0, produced0 = 0, limit = 0;
   u32 longMode = 0, err = 0, jErr = 0xFFFFFFFFu, valid = 0, validOut = 0, validLit = 0, truncated = 0;
+  // the table cells of the sequence about to be decoded: requested one step ahead, together with the container reload
+  uint2 eL = make_uint2(0, 0), eM = make_uint2(0, 0); u32 eO = 0;
+  bool wide = false; const u8* pad = nullptr;
+  auto fetch_cells = [&]() {
+    eL = *(const uint2*)(T + ZRA_DEC_TBL_LL + 2 * sLL); eM = *(const uint2*)(T + ZRA_DEC_TBL_ML + 2 * sML); eO = T[ZRA_DEC_TBL_OF + sOF];
+  };
 
   auto finish = [&]() {
     // tail literals of the block (ZSTD_decompressSequences: "last literal segment")
@@ -961,6 +976,9 @@ zra_dec_chain_kernel(ZraDecodeArgs a) {
               sLL = br.read(F->llLog); br.reload();
               sOF = br.read(F->ofLog); br.reload();
               sML = br.read(F->mlLog); br.reload();
+              wide = F->bsize - F->seqPos >= 8;
+              pad = a.body + a.frameOff[gj * a.offStride];          // the frame's first bytes: always 8 readable ones
+              fetch_cells();
             }
           }
         }
@@ -986,8 +1004,6 @@ zra_dec_chain_kernel(ZraDecodeArgs a) {
       if (go) {
         // ZSTD_decodeSequence (64-bit path): offset bits, match-length bits, [reload], literal-length bits, then the three state
         // updates — always, the last sequence included
-        const uint2 eL = *(const uint2*)(T + ZRA_DEC_TBL_LL + 2 * sLL), eM = *(const uint2*)(T + ZRA_DEC_TBL_ML + 2 * sML);
-        const u32 eO = T[ZRA_DEC_TBL_OF + sOF];
         const u32 ofBits = (eO >> 8) & 0xFF, mlBits = (eM.x >> 8) & 0xFF, llBits = (eL.x >> 8) & 0xFF;
         u32 ll = eL.y, ml = eM.y, off;
         if (ofBits > 1) {
@@ -1012,7 +1028,8 @@ zra_dec_chain_kernel(ZraDecodeArgs a) {
         sLL = (eL.x >> 20) + br.read((eL.x >> 16) & 0xF);
         sML = (eM.x >> 20) + br.read((eM.x >> 16) & 0xF);
         sOF = (eO >> 20) + br.read((eO >> 16) & 0xF);
-        if (!longMode) br.reload();
+        fetch_cells();                                      // next sequence's cells and the container: one round trip
+        if (!longMode) br.reload_quiet(wide, pad);
         // ZSTD_execSequence / ZSTD_execSequenceEnd, checks only (the execute kernel moves the bytes): destination room, literal
         // buffer, then — the literals now count as consumed — the offset
         if (jErr == 0xFFFFFFFFu) {
