@@ -23,11 +23,18 @@ static const u8 CP256[13][7] = {{18,16,16,1,4,0,2},{18,13,14,1,6,0,1},{18,14,14,
  * acceleration: targetLength = -level */
 static const u8 CPNEG16[7] = {14,12,13,1,5,1,1}, CPNEG128[7] = {17,12,12,1,5,1,1}, CPNEG256[7] = {18,12,13,1,5,1,1};
 
+/* the "default" table (srcSize > 256 KB), levels 0..12 (13 and up: btlazy2 and the optimal parsers) */
+static const u8 CPDEF[13][7] = {{21,16,17,1,5,0,2},{19,13,14,1,7,0,1},{20,15,16,1,6,0,1},{21,16,17,1,5,0,2},{21,18,18,1,5,0,2},{21,18,19,2,5,2,3},
+  {21,19,19,3,5,4,3},{21,19,19,3,5,8,4},{21,19,19,3,5,16,5},{21,19,20,4,5,16,5},{22,20,21,4,5,16,5},{22,21,22,4,5,16,5},{22,21,22,5,5,16,5}};
+static const u8 CPNEGDEF[7] = {19,12,13,1,6,1,1};
+
 int zo_get_cparams(int level, size_t S, zo_cparams* cp) {
   if (level == 0) level = 3;
-  if (level > 12 || S > (256u << 10)) return -1;
-  const u8* r = level < 0 ? (S <= (16u << 10) ? CPNEG16 : S <= (128u << 10) ? CPNEG128 : CPNEG256)
-                          : (S <= (16u << 10) ? CP16[level] : S <= (128u << 10) ? CP128[level] : CP256[level]);
+  if (level > 12) return -1;
+  const u8* r = level < 0 ? (S <= (16u << 10) ? CPNEG16 : S <= (128u << 10) ? CPNEG128 : S <= (256u << 10) ? CPNEG256 : CPNEGDEF)
+                          : (S <= (16u << 10) ? CP16[level] : S <= (128u << 10) ? CP128[level] : S <= (256u << 10) ? CP256[level] : CPDEF[level]);
+  /* a frame larger than the level's window would need the sliding-window rules (lowLimit, ZSTD_window_enforceMaxDist): not restated */
+  if (S > ((size_t)1 << r[0])) return -1;
   cp->windowLog = r[0]; cp->chainLog = r[1]; cp->hashLog = r[2]; cp->searchLog = r[3];
   cp->minMatch = r[4]; cp->targetLength = level < 0 ? (u32)(-level) : r[5]; cp->strategy = r[6];
   u32 srcLog = S < 64 ? 6 : hb32((u32)S - 1) + 1;

@@ -82,12 +82,19 @@ inline uint32_t hbit(uint32_t x) { return 31u - (uint32_t)__builtin_clz(x); }
 // (targetLength = -level), and literals are then stored raw (ZSTD_compressLiterals' disableLiteralCompression)
 const uint8_t kCPNeg16[7] = {14, 12, 13, 1, 5, 1, 1}, kCPNeg128[7] = {17, 12, 12, 1, 5, 1, 1}, kCPNeg256[7] = {18, 12, 13, 1, 5, 1, 1};
 
-// returns false when (level, size) needs a strategy this engine does not implement (btlazy2 and up, > 256 KiB)
+// the "default" table (srcSize > 256 KB), levels 0..12
+const uint8_t kCPDef[13][7] = {{21,16,17,1,5,0,2},{19,13,14,1,7,0,1},{20,15,16,1,6,0,1},{21,16,17,1,5,0,2},{21,18,18,1,5,0,2},{21,18,19,2,5,2,3},
+  {21,19,19,3,5,4,3},{21,19,19,3,5,8,4},{21,19,19,3,5,16,5},{21,19,20,4,5,16,5},{22,20,21,4,5,16,5},{22,21,22,4,5,16,5},{22,21,22,5,5,16,5}};
+const uint8_t kCPNegDef[7] = {19, 12, 13, 1, 6, 1, 1};
+
+// returns false when (level, size) needs what this engine does not implement: a strategy beyond lazy2 (btlazy2 and up), or a frame
+// larger than the level's window (the sliding-window rules are not restated; level 1: 512 KiB, level 2: 1 MiB, 3-9: 2 MiB, 10-12: 4 MiB)
 bool get_params(int level, size_t S, ZraEncParams* p) {
   if (level == 0) level = 3;
-  if (level > 12 || S > (256u << 10) || S == 0) return false;
-  const uint8_t* r = level < 0 ? (S <= (16u << 10) ? kCPNeg16 : S <= (128u << 10) ? kCPNeg128 : kCPNeg256)
-                               : (S <= (16u << 10) ? kCP16[level] : S <= (128u << 10) ? kCP128[level] : kCP256[level]);
+  if (level > 12 || S == 0) return false;
+  const uint8_t* r = level < 0 ? (S <= (16u << 10) ? kCPNeg16 : S <= (128u << 10) ? kCPNeg128 : S <= (256u << 10) ? kCPNeg256 : kCPNegDef)
+                               : (S <= (16u << 10) ? kCP16[level] : S <= (128u << 10) ? kCP128[level] : S <= (256u << 10) ? kCP256[level] : kCPDef[level]);
+  if (S > ((size_t)1 << r[0])) return false;
   p->windowLog = r[0]; p->chainLog = r[1]; p->hashLog = r[2]; p->searchLog = r[3]; p->minMatch = r[4];
   p->targetLength = level < 0 ? (uint32_t)(-level) : r[5]; p->strategy = r[6];
   const uint32_t srcLog = S < 64 ? 6 : hbit((uint32_t)S - 1) + 1;
