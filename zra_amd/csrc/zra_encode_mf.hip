@@ -670,9 +670,23 @@ __device__ u32 mf_lazy_wave(HCW& H, const u8* src, u32 bs, u32 be, u32* rep, u64
     return bcast(H.rml, q - H.w);
   };
   auto put = [&](u32 ll, u32 ml, u32 offVal) { if (lane == 0) seqs[n] = (u64)ll | ((u64)ml << 20) | ((u64)offVal << 40); n++; };
+  // repcode tests "4 bytes at t equal 4 bytes at t - o": the parse asks them at consecutive positions (ip+1, then ip+1 again from the
+  // lazy loop, ip+2, after a match ip with the second offset, ...), one dependent round trip each in the serial form. Here one round
+  // trip fetches 8 bytes at cb and at cb - o1 and cb - o2 together and answers the tests at cb .. cb+4 for both offsets.
+  u32 cb = 0xFFFFFFF0u, cbO1 = 0, cbO2 = 0; u64 cs = 0, c1 = 0, c2 = 0;
+  auto rep_test = [&](u32 t, bool first) -> bool {          // first: against o1, else against o2 (the offset is > 0 and <= t)
+    if (t < cb || t > cb + 4 || cbO1 != o1 || cbO2 != o2) {
+      cb = t; cbO1 = o1; cbO2 = o2;
+      cs = ld64(src + t);
+      c1 = (o1 > 0 && o1 <= t) ? ld64(src + t - o1) : 0ull;
+      c2 = (o2 > 0 && o2 <= t) ? ld64(src + t - o2) : 0ull;
+    }
+    const u32 sh = (t - cb) * 8;
+    return (u32)(cs >> sh) == (u32)((first ? c1 : c2) >> sh);
+  };
   while (ip < ilimit) {
     u32 ml = 0, start = ip + 1, off = 0; bool stored = false;
-    if (o1 > 0 && ld32(src + ip + 1 - o1) == ld32(src + ip + 1)) {
+    if (o1 > 0 && rep_test(ip + 1, true)) {
       ml = wave_count_eq(src, ip + 5, ip + 5 - o1, be, lane) + 4;
       if (depth == 0) stored = true;
     }
@@ -683,7 +697,7 @@ __device__ u32 mf_lazy_wave(HCW& H, const u8* src, u32 bs, u32 be, u32* rep, u64
       if (depth >= 1) {
         while (ip < ilimit) {
           ip++;
-          if (off && o1 > 0 && ld32(src + ip) == ld32(src + ip - o1)) {
+          if (off && o1 > 0 && rep_test(ip, true)) {
             const u32 mr = wave_count_eq(src, ip + 4, ip + 4 - o1, be, lane) + 4;
             const int g2 = (int)(mr * 3), g1 = (int)(ml * 3 - hb32(off + 1) + 1);
             if (mr >= 4 && g2 > g1) { ml = mr; off = 0; start = ip; }
@@ -695,7 +709,7 @@ __device__ u32 mf_lazy_wave(HCW& H, const u8* src, u32 bs, u32 be, u32* rep, u64
           }
           if (depth == 2 && ip < ilimit) {
             ip++;
-            if (off && o1 > 0 && ld32(src + ip) == ld32(src + ip - o1)) {
+            if (off && o1 > 0 && rep_test(ip, true)) {
               const u32 mr = wave_count_eq(src, ip + 4, ip + 4 - o1, be, lane) + 4;
               const int g2 = (int)(mr * 4), g1 = (int)(ml * 4 - hb32(off + 1) + 1);
               if (mr >= 4 && g2 > g1) { ml = mr; off = 0; start = ip; }
@@ -719,7 +733,7 @@ __device__ u32 mf_lazy_wave(HCW& H, const u8* src, u32 bs, u32 be, u32* rep, u64
     }
     put(start - anchor, ml, off ? off + 1 : 1);
     anchor = ip = start + ml;
-    while (ip <= ilimit && o2 > 0 && ld32(src + ip) == ld32(src + ip - o2)) {
+    while (ip <= ilimit && o2 > 0 && rep_test(ip, false)) {
       const u32 rl = wave_count_eq(src, ip + 4, ip + 4 - o2, be, lane) + 4;
       const u32 t = o2; o2 = o1; o1 = t;
       put(0, rl, 1);
