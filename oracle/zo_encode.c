@@ -23,14 +23,15 @@ static const u8 CP256[13][7] = {{18,16,16,1,4,0,2},{18,13,14,1,6,0,1},{18,14,14,
  * acceleration: targetLength = -level */
 static const u8 CPNEG16[7] = {14,12,13,1,5,1,1}, CPNEG128[7] = {17,12,12,1,5,1,1}, CPNEG256[7] = {18,12,13,1,5,1,1};
 
-/* the "default" table (srcSize > 256 KB), levels 0..12 (13 and up: btlazy2 and the optimal parsers) */
-static const u8 CPDEF[13][7] = {{21,16,17,1,5,0,2},{19,13,14,1,7,0,1},{20,15,16,1,6,0,1},{21,16,17,1,5,0,2},{21,18,18,1,5,0,2},{21,18,19,2,5,2,3},
-  {21,19,19,3,5,4,3},{21,19,19,3,5,8,4},{21,19,19,3,5,16,5},{21,19,20,4,5,16,5},{22,20,21,4,5,16,5},{22,21,22,4,5,16,5},{22,21,22,5,5,16,5}};
+/* the "default" table (srcSize > 256 KB), levels 0..15 (13-15: btlazy2; 16 and up: the optimal parsers) */
+static const u8 CPDEF[16][7] = {{21,16,17,1,5,0,2},{19,13,14,1,7,0,1},{20,15,16,1,6,0,1},{21,16,17,1,5,0,2},{21,18,18,1,5,0,2},{21,18,19,2,5,2,3},
+  {21,19,19,3,5,4,3},{21,19,19,3,5,8,4},{21,19,19,3,5,16,5},{21,19,20,4,5,16,5},{22,20,21,4,5,16,5},{22,21,22,4,5,16,5},{22,21,22,5,5,16,5},
+  {22,21,22,5,5,32,6},{22,22,23,5,5,32,6},{22,23,23,6,5,32,6}};
 static const u8 CPNEGDEF[7] = {19,12,13,1,6,1,1};
 
 int zo_get_cparams(int level, size_t S, zo_cparams* cp) {
   if (level == 0) level = 3;
-  if (level > 12) return -1;
+  if (level > 15 || (level > 12 && S <= (256u << 10))) return -1;      /* btopt and up */
   const u8* r = level < 0 ? (S <= (16u << 10) ? CPNEG16 : S <= (128u << 10) ? CPNEG128 : S <= (256u << 10) ? CPNEG256 : CPNEGDEF)
                           : (S <= (16u << 10) ? CP16[level] : S <= (128u << 10) ? CP128[level] : S <= (256u << 10) ? CP256[level] : CPDEF[level]);
   /* a frame larger than the level's window would need the sliding-window rules (lowLimit, ZSTD_window_enforceMaxDist): not restated */
@@ -213,6 +214,108 @@ static size_t hc_search(cctx* c, const u8* src, size_t ip, size_t be, u32* offCo
   return ml;
 }
 
+
+/* ---- A.4.3 binary tree with delayed updates (btlazy2): ZSTD_updateDUBT / ZSTD_insertDUBT1 / ZSTD_DUBT_findBestMatch /
+ * ZSTD_BtFindBestMatch of zstd_lazy.c (1.4.9), single-segment prefix mode. Index = position + 1 as everywhere here; the tree lives
+ * in chainTable as pairs {smaller, larger} indexed by (index & btMask), btLog = chainLog - 1; an inserted but not yet sorted
+ * position holds {previous head of its bucket, UNSORTED_MARK}. */
+#define ZO_DUBT_UNSORTED 1u
+static void bt_insert1(cctx* c, const u8* src, u32 curr, size_t iend, u32 nbCompares, u32 btLow) {
+  u32* bt = c->chainTable; u32 btMask = (1u << (c->cp.chainLog - 1)) - 1;
+  size_t commonSmaller = 0, commonLarger = 0;
+  const u8* ip = src + curr - 1;
+  u32* smallerPtr = bt + 2 * (curr & btMask);
+  u32* largerPtr = smallerPtr + 1;
+  u32 matchIndex = *smallerPtr;
+  u32 dummy32;
+  u32 windowLow = 1;                                   /* window.lowLimit; the frame never exceeds the window here */
+  while (nbCompares-- && matchIndex > windowLow) {
+    u32* nextPtr = bt + 2 * (matchIndex & btMask);
+    size_t ml = commonSmaller < commonLarger ? commonSmaller : commonLarger;
+    const u8* match = src + matchIndex - 1;
+    ml += count_eq(src, (size_t)(ip - src) + ml, (size_t)(match - src) + ml, iend);
+    if ((size_t)(ip - src) + ml == iend) break;        /* equal: no way to know if inf or sup */
+    if (match[ml] < ip[ml]) {
+      *smallerPtr = matchIndex; commonSmaller = ml;
+      if (matchIndex <= btLow) { smallerPtr = &dummy32; break; }
+      smallerPtr = nextPtr + 1; matchIndex = nextPtr[1];
+    } else {
+      *largerPtr = matchIndex; commonLarger = ml;
+      if (matchIndex <= btLow) { largerPtr = &dummy32; break; }
+      largerPtr = nextPtr; matchIndex = nextPtr[0];
+    }
+  }
+  *smallerPtr = *largerPtr = 0;
+}
+static size_t bt_search(cctx* c, const u8* src, size_t ip, size_t be, u32* offCode) {
+  u32 hlog = c->cp.hashLog, mls = c->cp.minMatch < 4 ? 4 : c->cp.minMatch > 6 ? 6 : c->cp.minMatch;
+  u32* bt = c->chainTable; u32 btMask = (1u << (c->cp.chainLog - 1)) - 1;
+  u32 curr = (u32)ip + 1;
+  *offCode = 999999999u;
+  if (curr < c->nextToUpdate) return 0;                /* skipped area */
+  for (u32 idx = c->nextToUpdate; idx < curr; idx++) { /* ZSTD_updateDUBT */
+    u32 h = hashN(src + idx - 1, hlog, mls);
+    u32* p = bt + 2 * (idx & btMask);
+    p[0] = c->hashTable[h]; p[1] = ZO_DUBT_UNSORTED;
+    c->hashTable[h] = idx;
+  }
+  c->nextToUpdate = curr;
+  u32 h = hashN(src + ip, hlog, mls);
+  u32 matchIndex = c->hashTable[h];
+  u32 windowLow = 1;
+  u32 btLow = btMask >= curr ? 0 : curr - btMask;
+  u32 unsortLimit = btLow > windowLow ? btLow : windowLow;
+  u32* nextCandidate = bt + 2 * (matchIndex & btMask);
+  u32* unsortedMark = nextCandidate + 1;
+  u32 nbCompares = 1u << c->cp.searchLog, nbCandidates = nbCompares, previousCandidate = 0;
+  while (matchIndex > unsortLimit && *unsortedMark == ZO_DUBT_UNSORTED && nbCandidates > 1) {
+    *unsortedMark = previousCandidate;                 /* the mark becomes a reversed chain */
+    previousCandidate = matchIndex;
+    matchIndex = *nextCandidate;
+    nextCandidate = bt + 2 * (matchIndex & btMask);
+    unsortedMark = nextCandidate + 1;
+    nbCandidates--;
+  }
+  if (matchIndex > unsortLimit && *unsortedMark == ZO_DUBT_UNSORTED) *nextCandidate = *unsortedMark = 0;
+  matchIndex = previousCandidate;                      /* batch sort the stacked candidates */
+  while (matchIndex) {
+    u32* nextIdxPtr = bt + 2 * (matchIndex & btMask) + 1;
+    u32 nextIdx = *nextIdxPtr;
+    bt_insert1(c, src, matchIndex, be, nbCandidates, unsortLimit);
+    matchIndex = nextIdx;
+    nbCandidates++;
+  }
+  size_t commonSmaller = 0, commonLarger = 0, bestLength = 0;
+  u32* smallerPtr = bt + 2 * (curr & btMask);
+  u32* largerPtr = smallerPtr + 1;
+  u32 matchEndIdx = curr + 8 + 1, dummy32;
+  matchIndex = c->hashTable[h];
+  c->hashTable[h] = curr;
+  while (nbCompares-- && matchIndex > windowLow) {
+    u32* nextPtr = bt + 2 * (matchIndex & btMask);
+    size_t ml = commonSmaller < commonLarger ? commonSmaller : commonLarger;
+    size_t m = matchIndex - 1;
+    ml += count_eq(src, ip + ml, m + ml, be);
+    if (ml > bestLength) {
+      if (ml > matchEndIdx - matchIndex) matchEndIdx = matchIndex + (u32)ml;
+      if (4 * (int)(ml - bestLength) > (int)(hb32(curr - matchIndex + 1) - hb32(*offCode + 1))) { bestLength = ml; *offCode = 2 + curr - matchIndex; }
+      if (ip + ml == be) break;
+    }
+    if (src[m + ml] < src[ip + ml]) {
+      *smallerPtr = matchIndex; commonSmaller = ml;
+      if (matchIndex <= btLow) { smallerPtr = &dummy32; break; }
+      smallerPtr = nextPtr + 1; matchIndex = nextPtr[1];
+    } else {
+      *largerPtr = matchIndex; commonLarger = ml;
+      if (matchIndex <= btLow) { largerPtr = &dummy32; break; }
+      largerPtr = nextPtr; matchIndex = nextPtr[0];
+    }
+  }
+  *smallerPtr = *largerPtr = 0;
+  c->nextToUpdate = matchEndIdx - 8;                   /* skip repetitive patterns */
+  return bestLength;
+}
+static size_t lazy_search(cctx* c, const u8* src, size_t ip, size_t be, u32* offCode);
 static size_t mf_lazy(cctx* c, const u8* src, size_t bs, size_t be, u32 rep[3], int depth) {
   u32 o1 = rep[0], o2 = rep[1], saved;
   size_t anchor = bs, ilimit = be >= 8 ? be - 8 : 0;   /* a 7-byte first block: iend-8 lies before the start, nothing is searched */
@@ -224,7 +327,7 @@ static size_t mf_lazy(cctx* c, const u8* src, size_t bs, size_t be, u32 rep[3], 
       if (depth == 0) stored = 1;
     }
     if (!stored) {
-      u32 oc2; size_t m2 = hc_search(c, src, ip, be, &oc2);
+      u32 oc2; size_t m2 = lazy_search(c, src, ip, be, &oc2);
       if (m2 > ml) { ml = m2; start = ip; off = oc2; }
       if (ml < 4) { ip += ((ip - anchor) >> 8) + 1; continue; }
       if (depth >= 1) {
@@ -236,7 +339,7 @@ static size_t mf_lazy(cctx* c, const u8* src, size_t bs, size_t be, u32 rep[3], 
             if (mr >= 4 && g2 > g1) { ml = mr; off = 0; start = ip; }
           }
           {
-            m2 = hc_search(c, src, ip, be, &oc2);
+            m2 = lazy_search(c, src, ip, be, &oc2);
             int g2 = (int)(m2 * 4 - hb32(oc2 + 1)), g1 = (int)(ml * 4 - hb32(off + 1) + 4);
             if (m2 >= 4 && g2 > g1) { ml = m2; off = oc2; start = ip; continue; }
           }
@@ -248,7 +351,7 @@ static size_t mf_lazy(cctx* c, const u8* src, size_t bs, size_t be, u32 rep[3], 
               if (mr >= 4 && g2 > g1) { ml = mr; off = 0; start = ip; }
             }
             {
-              m2 = hc_search(c, src, ip, be, &oc2);
+              m2 = lazy_search(c, src, ip, be, &oc2);
               int g2 = (int)(m2 * 4 - hb32(oc2 + 1)), g1 = (int)(ml * 4 - hb32(off + 1) + 7);
               if (m2 >= 4 && g2 > g1) { ml = m2; off = oc2; start = ip; continue; }
             }
@@ -273,6 +376,9 @@ static size_t mf_lazy(cctx* c, const u8* src, size_t bs, size_t be, u32 rep[3], 
   }
   rep[0] = o1 ? o1 : saved; rep[1] = o2 ? o2 : saved;
   return be - anchor;
+}
+static size_t lazy_search(cctx* c, const u8* src, size_t ip, size_t be, u32* offCode) {
+  return c->cp.strategy == 6 ? bt_search(c, src, ip, be, offCode) : hc_search(c, src, ip, be, offCode);
 }
 
 /* ------------------------------------------------------------------ A.4.5 literals */
@@ -593,7 +699,7 @@ static size_t run_match_finder(cctx* c, const u8* src, size_t bs, size_t be, u32
 static int cctx_init(cctx* c, int level, size_t n) {
   memset(c, 0, sizeof(*c));
   if (zo_get_cparams(level, n, &c->cp)) return -1;
-  if (c->cp.strategy > 5) return -1; /* btlazy2 and up: not restated (SURVEY Appendix A status table) */
+  if (c->cp.strategy > 6) return -1; /* btopt and up: not restated (SURVEY Appendix A status table) */
   size_t hsz = (size_t)1 << c->cp.hashLog, csz = (size_t)1 << c->cp.chainLog;
   size_t blockMax = n < (128u << 10) ? n : (128u << 10);
   c->hashTable = (u32*)calloc(hsz, 4);

@@ -82,16 +82,17 @@ inline uint32_t hbit(uint32_t x) { return 31u - (uint32_t)__builtin_clz(x); }
 // (targetLength = -level), and literals are then stored raw (ZSTD_compressLiterals' disableLiteralCompression)
 const uint8_t kCPNeg16[7] = {14, 12, 13, 1, 5, 1, 1}, kCPNeg128[7] = {17, 12, 12, 1, 5, 1, 1}, kCPNeg256[7] = {18, 12, 13, 1, 5, 1, 1};
 
-// the "default" table (srcSize > 256 KB), levels 0..12
-const uint8_t kCPDef[13][7] = {{21,16,17,1,5,0,2},{19,13,14,1,7,0,1},{20,15,16,1,6,0,1},{21,16,17,1,5,0,2},{21,18,18,1,5,0,2},{21,18,19,2,5,2,3},
-  {21,19,19,3,5,4,3},{21,19,19,3,5,8,4},{21,19,19,3,5,16,5},{21,19,20,4,5,16,5},{22,20,21,4,5,16,5},{22,21,22,4,5,16,5},{22,21,22,5,5,16,5}};
+// the "default" table (srcSize > 256 KB), levels 0..15 (13-15: btlazy2)
+const uint8_t kCPDef[16][7] = {{21,16,17,1,5,0,2},{19,13,14,1,7,0,1},{20,15,16,1,6,0,1},{21,16,17,1,5,0,2},{21,18,18,1,5,0,2},{21,18,19,2,5,2,3},
+  {21,19,19,3,5,4,3},{21,19,19,3,5,8,4},{21,19,19,3,5,16,5},{21,19,20,4,5,16,5},{22,20,21,4,5,16,5},{22,21,22,4,5,16,5},{22,21,22,5,5,16,5},
+  {22,21,22,5,5,32,6},{22,22,23,5,5,32,6},{22,23,23,6,5,32,6}};
 const uint8_t kCPNegDef[7] = {19, 12, 13, 1, 6, 1, 1};
 
-// returns false when (level, size) needs what this engine does not implement: a strategy beyond lazy2 (btlazy2 and up), or a frame
+// returns false when (level, size) needs what this engine does not implement: a strategy beyond btlazy2 (the optimal parsers), or a frame
 // larger than the level's window (the sliding-window rules are not restated; level 1: 512 KiB, level 2: 1 MiB, 3-9: 2 MiB, 10-12: 4 MiB)
 bool get_params(int level, size_t S, ZraEncParams* p) {
   if (level == 0) level = 3;
-  if (level > 12 || S == 0) return false;
+  if (level > 15 || (level > 12 && S <= (256u << 10)) || S == 0) return false;      // btopt and up
   const uint8_t* r = level < 0 ? (S <= (16u << 10) ? kCPNeg16 : S <= (128u << 10) ? kCPNeg128 : S <= (256u << 10) ? kCPNeg256 : kCPNegDef)
                                : (S <= (16u << 10) ? kCP16[level] : S <= (128u << 10) ? kCP128[level] : S <= (256u << 10) ? kCP256[level] : kCPDef[level]);
   if (S > ((size_t)1 << r[0])) return false;
@@ -104,7 +105,7 @@ bool get_params(int level, size_t S, ZraEncParams* p) {
   if (cycleLog > p->windowLog) p->chainLog -= cycleLog - p->windowLog;
   if (p->windowLog < 10) p->windowLog = 10;
   p->blockSize = std::min<uint32_t>(128u << 10, 1u << p->windowLog);
-  return p->strategy <= 5;
+  return p->strategy <= 6;
 }
 
 }  // namespace
@@ -276,9 +277,10 @@ Status Engine::compress_impl_body(const uint8_t* dIn, size_t inSize, uint8_t* dB
           // frames per wave: as many as it takes to have every frame of the batch resident at once (32 waves per CU)
           static const int pwEnv = std::getenv("ZRA_MF_PERWAVE") ? std::atoi(std::getenv("ZRA_MF_PERWAVE")) : 0;
           // hash-chain strategies (greedy / lazy / lazy2): one frame per wave, the wave-cooperative finder; fast gains 9.4 -> 14.5 from 8
-          uint32_t perWave = pwEnv > 0 ? (uint32_t)pwEnv : full.strategy >= 3 ? 1u
+          const bool hashChain = full.strategy >= 3 && full.strategy <= 5;
+          uint32_t perWave = pwEnv > 0 ? (uint32_t)pwEnv : hashChain ? 1u
                            : std::min<uint32_t>(8u, std::max<uint32_t>(1u, (nb + (uint32_t)numCUs_ * 32 - 1) / ((uint32_t)numCUs_ * 32)));
-          if (full.strategy >= 3 && pwEnv <= 0) hipLaunchKernelGGL(zra_mf_hc_kernel, dim3(nb), dim3(64), dynLds, stream_, a, blk);
+          if (hashChain && pwEnv <= 0) hipLaunchKernelGGL(zra_mf_hc_kernel, dim3(nb), dim3(64), dynLds, stream_, a, blk);
           else hipLaunchKernelGGL(zra_mf_kernel, dim3((nb + perWave - 1) / perWave), dim3(64), dynLds, stream_, a, blk, 0xFFFFFFFFu, 0u, perWave);
           if (oddTail) hipLaunchKernelGGL(zra_mf_dfast_kernel, dim3(1), dim3(64), filterBytes, stream_, a, blk, (uint32_t)(nb - 1), (uint32_t)(nb - 1));
         }

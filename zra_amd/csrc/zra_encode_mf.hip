@@ -108,10 +108,13 @@ __device__ u32 mf_fast(const ZraEncParams& P, u32* T, const u8* src, u32 bs, u32
   return be - anchor;
 }
 
-// ---- A.4.3 hash chain (greedy depth 0 / lazy 1 / lazy2 2)
+// ---- A.4.3 hash chain (greedy depth 0 / lazy 1 / lazy2 2) and, with `bt`, the binary tree with delayed updates of btlazy2
+// (ZSTD_updateDUBT / ZSTD_insertDUBT1 / ZSTD_DUBT_findBestMatch of zstd_lazy.c; oracle/zo_encode.c: bt_search). Serial: one lane.
 struct HC {
   u32* hashT; u32* chainT; u32 hlog, mls, cmask, chainSize, searchLog, nextToUpdate;
+  bool bt;
   __device__ u32 search(const u8* src, u32 ip, u32 be, u32& offCode) {
+    if (bt) return bt_search(src, ip, be, offCode);
     const u32 target = ip + 1;
     for (u32 idx = nextToUpdate; idx < target; idx++) {
       const u32 h = hashN(src + idx - 1, hlog, mls);
@@ -133,6 +136,99 @@ struct HC {
       mi = chainT[mi & cmask];
     }
     return ml;
+  }
+  // the tree lives in chainT as pairs {smaller, larger} at 2 * (index & btMask), btLog = chainLog - 1; an inserted but unsorted
+  // position holds {previous head of its bucket, 1}
+  __device__ void bt_insert1(const u8* src, u32 curr, u32 iend, u32 nbCompares, u32 btLow) {
+    const u32 btMask = (chainSize >> 1) - 1;
+    u32 commonSmaller = 0, commonLarger = 0;
+    const u32 ipos = curr - 1;
+    u32* smallerPtr = chainT + 2 * (curr & btMask);
+    u32* largerPtr = smallerPtr + 1;
+    u32 matchIndex = *smallerPtr;
+    u32 dummy32;
+    while (nbCompares-- && matchIndex > 1u) {
+      u32* const nextPtr = chainT + 2 * (matchIndex & btMask);
+      u32 ml = min(commonSmaller, commonLarger);
+      const u32 m = matchIndex - 1;
+      ml += count_eq(src, ipos + ml, m + ml, iend);
+      if (ipos + ml == iend) break;
+      if (src[m + ml] < src[ipos + ml]) {
+        *smallerPtr = matchIndex; commonSmaller = ml;
+        if (matchIndex <= btLow) { smallerPtr = &dummy32; break; }
+        smallerPtr = nextPtr + 1; matchIndex = nextPtr[1];
+      } else {
+        *largerPtr = matchIndex; commonLarger = ml;
+        if (matchIndex <= btLow) { largerPtr = &dummy32; break; }
+        largerPtr = nextPtr; matchIndex = nextPtr[0];
+      }
+    }
+    *smallerPtr = 0; *largerPtr = 0;
+  }
+  __device__ u32 bt_search(const u8* src, u32 ip, u32 be, u32& offCode) {
+    const u32 btMask = (chainSize >> 1) - 1;
+    const u32 curr = ip + 1;
+    offCode = 999999999u;
+    if (curr < nextToUpdate) return 0;                 // skipped area
+    for (u32 idx = nextToUpdate; idx < curr; idx++) {  // ZSTD_updateDUBT
+      const u32 h = hashN(src + idx - 1, hlog, mls);
+      u32* p = chainT + 2 * (idx & btMask);
+      p[0] = hashT[h]; p[1] = 1u;
+      hashT[h] = idx;
+    }
+    nextToUpdate = curr;
+    const u32 h = hashN(src + ip, hlog, mls);
+    u32 matchIndex = hashT[h];
+    const u32 btLow = btMask >= curr ? 0 : curr - btMask;
+    const u32 unsortLimit = max(btLow, 1u);
+    u32* nextCandidate = chainT + 2 * (matchIndex & btMask);
+    u32* unsortedMark = nextCandidate + 1;
+    u32 nbCompares = 1u << searchLog, nbCandidates = nbCompares, previousCandidate = 0;
+    while (matchIndex > unsortLimit && *unsortedMark == 1u && nbCandidates > 1) {
+      *unsortedMark = previousCandidate;               // the mark becomes a reversed chain
+      previousCandidate = matchIndex;
+      matchIndex = *nextCandidate;
+      nextCandidate = chainT + 2 * (matchIndex & btMask);
+      unsortedMark = nextCandidate + 1;
+      nbCandidates--;
+    }
+    if (matchIndex > unsortLimit && *unsortedMark == 1u) { *nextCandidate = 0; *unsortedMark = 0; }
+    matchIndex = previousCandidate;                    // batch sort the stacked candidates
+    while (matchIndex) {
+      const u32 nextIdx = chainT[2 * (matchIndex & btMask) + 1];
+      bt_insert1(src, matchIndex, be, nbCandidates, unsortLimit);
+      matchIndex = nextIdx;
+      nbCandidates++;
+    }
+    u32 commonSmaller = 0, commonLarger = 0, bestLength = 0;
+    u32* smallerPtr = chainT + 2 * (curr & btMask);
+    u32* largerPtr = smallerPtr + 1;
+    u32 matchEndIdx = curr + 8 + 1, dummy32;
+    matchIndex = hashT[h];
+    hashT[h] = curr;
+    while (nbCompares-- && matchIndex > 1u) {
+      u32* const nextPtr = chainT + 2 * (matchIndex & btMask);
+      u32 ml = min(commonSmaller, commonLarger);
+      const u32 m = matchIndex - 1;
+      ml += count_eq(src, ip + ml, m + ml, be);
+      if (ml > bestLength) {
+        if (ml > matchEndIdx - matchIndex) matchEndIdx = matchIndex + ml;
+        if (4 * (int)(ml - bestLength) > (int)(hb32(curr - matchIndex + 1) - hb32(offCode + 1))) { bestLength = ml; offCode = 2 + curr - matchIndex; }
+        if (ip + ml == be) break;
+      }
+      if (src[m + ml] < src[ip + ml]) {
+        *smallerPtr = matchIndex; commonSmaller = ml;
+        if (matchIndex <= btLow) { smallerPtr = &dummy32; break; }
+        smallerPtr = nextPtr + 1; matchIndex = nextPtr[1];
+      } else {
+        *largerPtr = matchIndex; commonLarger = ml;
+        if (matchIndex <= btLow) { largerPtr = &dummy32; break; }
+        largerPtr = nextPtr; matchIndex = nextPtr[0];
+      }
+    }
+    *smallerPtr = 0; *largerPtr = 0;
+    nextToUpdate = matchEndIdx - 8;                    // skip repetitive patterns
+    return bestLength;
   }
 };
 
@@ -882,7 +978,7 @@ zra_mf_kernel(ZraEncArgs a, u32 block, u32 only, u32 onlySlot, u32 perWave) {
     if ((u32)lane == k || perWave == 1) { F = G; mine = go && G.P->strategy != 2; }      // dfast frames belong to zra_mf_dfast_kernel
   }
   // one frame per wave and a hash-chain strategy: the whole wave works on it
-  const bool coop = perWave == 1 && mine && F.P->strategy >= 3;
+  const bool coop = perWave == 1 && mine && F.P->strategy >= 3 && F.P->strategy <= 5;
   if (!mine || (!coop && lane != 0 && perWave == 1)) return;
   const ZraEncParams& P = *F.P;
   const u8* src = F.src; ZraEncFrameState* st = F.st; ZraEncBlockOut* bo = F.bo;
@@ -926,7 +1022,8 @@ zra_mf_kernel(ZraEncArgs a, u32 block, u32 only, u32 onlySlot, u32 perWave) {
   else {
     HC H; H.hashT = hashT; H.chainT = chainT; H.hlog = P.hashLog; H.mls = P.minMatch < 4 ? 4 : P.minMatch > 6 ? 6 : P.minMatch;
     H.chainSize = 1u << P.chainLog; H.cmask = H.chainSize - 1; H.searchLog = P.searchLog; H.nextToUpdate = ntu;
-    lastLL = mf_lazy(H, src, bs, be, rep, E, (int)P.strategy - 3);
+    H.bt = P.strategy == 6;
+    lastLL = mf_lazy(H, src, bs, be, rep, E, P.strategy == 6 ? 2 : (int)P.strategy - 3);
     ntu = H.nextToUpdate;
   }
   st->nextToUpdate = ntu; st->insEnd = ntu;
@@ -956,11 +1053,18 @@ zra_mf_hc_kernel(ZraEncArgs a, u32 block) {
     const u32 cur = bs + 1;
     if (cur > ntu + 384) { const u32 d = cur - ntu - 384; ntu = cur - (d < 192 ? d : 192); }
   }
-  if (P.strategy == 1) {
+  if (P.strategy == 1 || P.strategy == 6) {            // a short last frame with "fast" or btlazy2 cparams: one lane, serial
     if (lane != 0) return;
     bo->skip = 0;
     Emit E; E.seqs = F.seqs; E.n = 0;
-    const u32 lastLL = mf_fast(P, F.hashT, F.src, bs, be, rep, E);
+    u32 lastLL;
+    if (P.strategy == 1) lastLL = mf_fast(P, F.hashT, F.src, bs, be, rep, E);
+    else {
+      HC B; B.hashT = F.hashT; B.chainT = F.chainT; B.hlog = P.hashLog; B.mls = P.minMatch < 4 ? 4 : P.minMatch > 6 ? 6 : P.minMatch;
+      B.chainSize = 1u << P.chainLog; B.cmask = B.chainSize - 1; B.searchLog = P.searchLog; B.nextToUpdate = ntu; B.bt = true;
+      lastLL = mf_lazy(B, F.src, bs, be, rep, E, 2);
+      ntu = B.nextToUpdate;
+    }
     st->nextToUpdate = ntu; st->insEnd = ntu;
     bo->nbSeq = E.n; bo->lastLL = lastLL;
     bo->rep[0] = rep[0]; bo->rep[1] = rep[1]; bo->rep[2] = rep[2];
