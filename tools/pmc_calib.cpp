@@ -32,11 +32,20 @@ int main() {
   hipMemset(b, 1, bytes);
   const int blocks = 4096, threads = 256, rounds = 256;
   const uint64_t nreq = (uint64_t)blocks * threads * rounds;
+  hipEvent_t e[5]; for (auto& x : e) hipEventCreate(&x);
+  hipEventRecord(e[0], 0);
   hipLaunchKernelGGL(calib_gather4, dim3(blocks), dim3(threads), 0, 0, (const uint32_t*)b, bytes / 4, (uint32_t*)o, rounds);
+  hipEventRecord(e[1], 0);
   hipLaunchKernelGGL(calib_scatter4, dim3(blocks), dim3(threads), 0, 0, (uint32_t*)b, bytes / 4, rounds);
+  hipEventRecord(e[2], 0);
   hipLaunchKernelGGL(calib_stream8, dim3(blocks), dim3(threads), 0, 0, (const uint64_t*)b, bytes / 8, (uint64_t*)o);
+  hipEventRecord(e[3], 0);
   hipLaunchKernelGGL(calib_streamwrite8, dim3(blocks), dim3(threads), 0, 0, (uint64_t*)b, bytes / 8);
+  hipEventRecord(e[4], 0);
   hipDeviceSynchronize();
+  float ms[4]; for (int i = 0; i < 4; i++) hipEventElapsedTime(&ms[i], e[i], e[i + 1]);
+  std::printf("rates: random 4 B reads %.1f G/s, random 4 B writes %.1f G/s, stream read %.0f GB/s, stream write %.0f GB/s\n",
+              (double)blocks * threads * rounds / ms[0] / 1e6, (double)blocks * threads * rounds / ms[1] / 1e6, bytes / ms[2] / 1e6, bytes / ms[3] / 1e6);
   std::printf("calib_gather4: %llu lane requests of 4 B (%.3f GB useful)\n", (unsigned long long)nreq, nreq * 4 / 1e9);
   std::printf("calib_scatter4: %llu lane stores of 4 B (%.3f GB useful)\n", (unsigned long long)nreq, nreq * 4 / 1e9);
   std::printf("calib_stream8 / calib_streamwrite8: %.3f GB each\n", bytes / 1e9);
