@@ -205,6 +205,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    # stdout carries exactly one line, the JSON: libraries that print banners on first use (RCCL's version block, gloo's rank lines)
+    # get stderr instead; the real stdout is kept aside for the last line
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     import zra_amd as Z
@@ -426,7 +432,8 @@ def main():
                          "other_kernels_launch_ms": {"zra_entropy_kernel": round(ent_launch_ms, 3), "zra_dec_parse+huf+chain+exec (one decode pass)": round(dec_launch_ms, 3)}},
             "cpu_baseline": cpu,
         }
-        print(json.dumps(line), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
     if world > 1:
         sh = getattr(step, "shard", None)
         if sh is not None:
