@@ -12,27 +12,31 @@
 /* ------------------------------------------------------------------ A.4.1 parameters */
 size_t zo_compress_bound(size_t n) { return n + (n >> 8) + (n < (128u << 10) ? (((128u << 10) - n) >> 11) : 0); }
 
-static const u8 CP16[13][7] = {{14,14,15,2,4,0,2},{14,14,15,1,5,0,1},{14,14,15,1,4,0,1},{14,14,15,2,4,0,2},{14,14,14,4,4,2,3},{14,14,14,3,4,4,4},
-  {14,14,14,4,4,8,5},{14,14,14,6,4,8,5},{14,14,14,8,4,8,5},{14,15,14,5,4,8,6},{14,15,14,9,4,8,6},{14,15,14,3,4,12,7},{14,15,14,4,3,24,7}};
-static const u8 CP128[13][7] = {{17,15,16,2,5,0,2},{17,12,13,1,6,0,1},{17,13,15,1,5,0,1},{17,15,16,2,5,0,2},{17,17,17,2,4,0,2},{17,16,17,3,4,2,3},
-  {17,17,17,3,4,4,4},{17,17,17,3,4,8,5},{17,17,17,4,4,8,5},{17,17,17,5,4,8,5},{17,17,17,6,4,8,5},{17,17,17,5,4,8,6},{17,18,17,7,4,12,6}};
-static const u8 CP256[13][7] = {{18,16,16,1,4,0,2},{18,13,14,1,6,0,1},{18,14,14,1,5,0,2},{18,16,16,1,4,0,2},{18,16,17,2,5,2,3},{18,18,18,3,5,2,3},
-  {18,18,19,3,5,4,4},{18,18,19,4,4,4,4},{18,18,19,4,4,8,5},{18,18,19,5,4,8,5},{18,18,19,6,4,8,5},{18,18,19,5,4,12,6},{18,19,19,7,4,12,6}};
+static const u16 CP16[23][7] = {{14,14,15,2,4,0,2},{14,14,15,1,5,0,1},{14,14,15,1,4,0,1},{14,14,15,2,4,0,2},{14,14,14,4,4,2,3},{14,14,14,3,4,4,4},
+  {14,14,14,4,4,8,5},{14,14,14,6,4,8,5},{14,14,14,8,4,8,5},{14,15,14,5,4,8,6},{14,15,14,9,4,8,6},{14,15,14,3,4,12,7},{14,15,14,4,3,24,7},
+  {14,15,14,5,3,32,8},{14,15,15,6,3,64,8},{14,15,15,7,3,256,8},{14,15,15,5,3,48,9},{14,15,15,6,3,128,9},{14,15,15,7,3,256,9},{14,15,15,8,3,256,9},{14,15,15,8,3,512,9},{14,15,15,9,3,512,9},{14,15,15,10,3,999,9}};
+static const u16 CP128[23][7] = {{17,15,16,2,5,0,2},{17,12,13,1,6,0,1},{17,13,15,1,5,0,1},{17,15,16,2,5,0,2},{17,17,17,2,4,0,2},{17,16,17,3,4,2,3},
+  {17,17,17,3,4,4,4},{17,17,17,3,4,8,5},{17,17,17,4,4,8,5},{17,17,17,5,4,8,5},{17,17,17,6,4,8,5},{17,17,17,5,4,8,6},{17,18,17,7,4,12,6},
+  {17,18,17,3,4,12,7},{17,18,17,4,3,32,7},{17,18,17,6,3,256,7},{17,18,17,6,3,128,8},{17,18,17,8,3,256,8},{17,18,17,10,3,512,8},{17,18,17,5,3,256,9},{17,18,17,7,3,512,9},{17,18,17,9,3,512,9},{17,18,17,11,3,999,9}};
+static const u16 CP256[23][7] = {{18,16,16,1,4,0,2},{18,13,14,1,6,0,1},{18,14,14,1,5,0,2},{18,16,16,1,4,0,2},{18,16,17,2,5,2,3},{18,18,18,3,5,2,3},
+  {18,18,19,3,5,4,4},{18,18,19,4,4,4,4},{18,18,19,4,4,8,5},{18,18,19,5,4,8,5},{18,18,19,6,4,8,5},{18,18,19,5,4,12,6},{18,19,19,7,4,12,6},
+  {18,18,19,4,4,16,7},{18,18,19,4,3,32,7},{18,18,19,6,3,128,7},{18,19,19,6,3,128,8},{18,19,19,8,3,256,8},{18,19,19,6,3,128,9},{18,19,19,8,3,256,9},{18,19,19,10,3,512,9},{18,19,19,12,3,512,9},{18,19,19,13,3,999,9}};
 
 /* row 0 of the level tables of ZSTD_getCParams_internal: "base for negative levels" (strategy fast); the level itself becomes the
  * acceleration: targetLength = -level */
-static const u8 CPNEG16[7] = {14,12,13,1,5,1,1}, CPNEG128[7] = {17,12,12,1,5,1,1}, CPNEG256[7] = {18,12,13,1,5,1,1};
+static const u16 CPNEG16[7] = {14,12,13,1,5,1,1}, CPNEG128[7] = {17,12,12,1,5,1,1}, CPNEG256[7] = {18,12,13,1,5,1,1};
 
-/* the "default" table (srcSize > 256 KB), levels 0..15 (13-15: btlazy2; 16 and up: the optimal parsers) */
-static const u8 CPDEF[16][7] = {{21,16,17,1,5,0,2},{19,13,14,1,7,0,1},{20,15,16,1,6,0,1},{21,16,17,1,5,0,2},{21,18,18,1,5,0,2},{21,18,19,2,5,2,3},
+/* the "default" table (srcSize > 256 KB), levels 0..22 */
+static const u16 CPDEF[23][7] = {{21,16,17,1,5,0,2},{19,13,14,1,7,0,1},{20,15,16,1,6,0,1},{21,16,17,1,5,0,2},{21,18,18,1,5,0,2},{21,18,19,2,5,2,3},
   {21,19,19,3,5,4,3},{21,19,19,3,5,8,4},{21,19,19,3,5,16,5},{21,19,20,4,5,16,5},{22,20,21,4,5,16,5},{22,21,22,4,5,16,5},{22,21,22,5,5,16,5},
-  {22,21,22,5,5,32,6},{22,22,23,5,5,32,6},{22,23,23,6,5,32,6}};
-static const u8 CPNEGDEF[7] = {19,12,13,1,6,1,1};
+  {22,21,22,5,5,32,6},{22,22,23,5,5,32,6},{22,23,23,6,5,32,6},
+  {22,22,22,5,5,48,7},{23,23,22,5,4,64,7},{23,23,22,6,3,64,8},{23,24,22,7,3,256,9},{25,25,23,7,3,256,9},{26,26,24,7,3,512,9},{27,27,25,9,3,999,9}};
+static const u16 CPNEGDEF[7] = {19,12,13,1,6,1,1};
 
 int zo_get_cparams(int level, size_t S, zo_cparams* cp) {
   if (level == 0) level = 3;
-  if (level > 15 || (level > 12 && S <= (256u << 10))) return -1;      /* btopt and up */
-  const u8* r = level < 0 ? (S <= (16u << 10) ? CPNEG16 : S <= (128u << 10) ? CPNEG128 : S <= (256u << 10) ? CPNEG256 : CPNEGDEF)
+  if (level > 22) level = 22;                                           /* ZSTD_maxCLevel */
+  const u16* r = level < 0 ? (S <= (16u << 10) ? CPNEG16 : S <= (128u << 10) ? CPNEG128 : S <= (256u << 10) ? CPNEG256 : CPNEGDEF)
                           : (S <= (16u << 10) ? CP16[level] : S <= (128u << 10) ? CP128[level] : S <= (256u << 10) ? CP256[level] : CPDEF[level]);
   /* a frame larger than the level's window would need the sliding-window rules (lowLimit, ZSTD_window_enforceMaxDist): not restated */
   if (S > ((size_t)1 << r[0])) return -1;
@@ -62,6 +66,10 @@ typedef struct {
   estate prev, next;
   zo_seq* seqs; size_t nbSeq;
   u8* lits; size_t litSize;
+  /* optimal parsers (btopt / btultra / btultra2) */
+  u32* hashTable3; u32 hashLog3;
+  u32 idxShift;                 /* index = position + 1 + idxShift (btultra2 moves the window base after its first pass) */
+  struct zo_opt_state* opt;
 } cctx;
 
 /* ------------------------------------------------------------------ A.4.3 match finders */
@@ -680,9 +688,342 @@ static size_t entropy_compress(cctx* c, u8* dst, size_t cap) {
 }
 
 /* ------------------------------------------------------------------ A.4.2 frame / block driver */
+
+/* ---- A.4.3 optimal parsers: zstd_opt.c of 1.4.9 (ZSTD_insertBt1, ZSTD_updateTree_internal, ZSTD_insertBtAndGetAllMatches, the price
+ * model and ZSTD_compressBlock_opt_generic), single-segment prefix mode, no dictionary. Index = position + 1 + c->idxShift. */
+#define ZO_OPT_NUM (1u << 12)
+#define ZO_BITCOST_ACC 8
+#define ZO_BITCOST_MUL (1u << ZO_BITCOST_ACC)
+#define ZO_MAX_PRICE (1 << 30)
+typedef struct { int price; u32 off, mlen, litlen, rep[3]; } zo_optimal;
+typedef struct { u32 off, len; } zo_match;
+struct zo_opt_state {
+  u32 litFreq[256], litLengthFreq[36], matchLengthFreq[53], offCodeFreq[32];
+  u32 litSum, litLengthSum, matchLengthSum, offCodeSum;
+  u32 litSumBasePrice, litLengthSumBasePrice, matchLengthSumBasePrice, offCodeSumBasePrice;
+  int predef;
+  zo_optimal table[ZO_OPT_NUM + 1];
+  zo_match matches[ZO_OPT_NUM + 1];
+};
+static inline u32 opt_bit_weight(u32 stat) { return hb32(stat + 1) * ZO_BITCOST_MUL; }
+static inline u32 opt_frac_weight(u32 raw) { u32 stat = raw + 1, hb = hb32(stat); return hb * ZO_BITCOST_MUL + ((stat << ZO_BITCOST_ACC) >> hb); }
+#define OPT_WEIGHT(stat, lvl) ((lvl) ? opt_frac_weight(stat) : opt_bit_weight(stat))
+static void opt_set_base_prices(struct zo_opt_state* o, int lvl) {
+  o->litSumBasePrice = OPT_WEIGHT(o->litSum, lvl);
+  o->litLengthSumBasePrice = OPT_WEIGHT(o->litLengthSum, lvl);
+  o->matchLengthSumBasePrice = OPT_WEIGHT(o->matchLengthSum, lvl);
+  o->offCodeSumBasePrice = OPT_WEIGHT(o->offCodeSum, lvl);
+}
+static u32 opt_downscale(u32* t, u32 last, int malus) {
+  u32 sum = 0;
+  for (u32 s = 0; s <= last; s++) { t[s] = 1 + (t[s] >> (4 + malus)); sum += t[s]; }
+  return sum;
+}
+static u32 opt_upscale(u32* t, u32 last, int bonus) {      /* ZSTD_upscaleStat (2-pass strategy) */
+  u32 sum = 0;
+  for (u32 s = 0; s <= last; s++) { t[s] <<= 4 + bonus; t[s]--; sum += t[s]; }
+  return sum;
+}
+static void opt_upscale_stats(struct zo_opt_state* o) {
+  o->litSum = opt_upscale(o->litFreq, 255, 0);
+  o->litLengthSum = opt_upscale(o->litLengthFreq, 35, 0);
+  o->matchLengthSum = opt_upscale(o->matchLengthFreq, 52, 0);
+  o->offCodeSum = opt_upscale(o->offCodeFreq, 31, 0);
+}
+static void opt_rescale_freqs(struct zo_opt_state* o, const u8* src, size_t n, int lvl) {
+  o->predef = 0;
+  if (o->litLengthSum == 0) {                          /* first block */
+    if (n <= 1024) o->predef = 1;
+    memset(o->litFreq, 0, sizeof(o->litFreq));
+    for (size_t i = 0; i < n; i++) o->litFreq[src[i]]++;
+    o->litSum = opt_downscale(o->litFreq, 255, 1);
+    for (u32 k = 0; k <= 35; k++) o->litLengthFreq[k] = 1;
+    o->litLengthSum = 36;
+    for (u32 k = 0; k <= 52; k++) o->matchLengthFreq[k] = 1;
+    o->matchLengthSum = 53;
+    for (u32 k = 0; k <= 31; k++) o->offCodeFreq[k] = 1;
+    o->offCodeSum = 32;
+  } else {
+    o->litSum = opt_downscale(o->litFreq, 255, 1);
+    o->litLengthSum = opt_downscale(o->litLengthFreq, 35, 0);
+    o->matchLengthSum = opt_downscale(o->matchLengthFreq, 52, 0);
+    o->offCodeSum = opt_downscale(o->offCodeFreq, 31, 0);
+  }
+  opt_set_base_prices(o, lvl);
+}
+static u32 opt_raw_literals_cost(const u8* lit, u32 n, const struct zo_opt_state* o, int lvl) {
+  if (n == 0) return 0;
+  if (o->predef) return (n * 6) * ZO_BITCOST_MUL;
+  u32 price = n * o->litSumBasePrice;
+  for (u32 u = 0; u < n; u++) price -= OPT_WEIGHT(o->litFreq[lit[u]], lvl);
+  return price;
+}
+static u32 opt_ll_price(u32 ll, const struct zo_opt_state* o, int lvl) {
+  if (o->predef) return OPT_WEIGHT(ll, lvl);
+  unsigned code = ll_code(ll);
+  return (zo_ll_bits[code] * ZO_BITCOST_MUL) + o->litLengthSumBasePrice - OPT_WEIGHT(o->litLengthFreq[code], lvl);
+}
+static u32 opt_match_price(u32 offset, u32 ml, const struct zo_opt_state* o, int lvl) {
+  u32 offCode = hb32(offset + 1), mlBase = ml - 3;
+  if (o->predef) return OPT_WEIGHT(mlBase, lvl) + ((16 + offCode) * ZO_BITCOST_MUL);
+  u32 price = (offCode * ZO_BITCOST_MUL) + (o->offCodeSumBasePrice - OPT_WEIGHT(o->offCodeFreq[offCode], lvl));
+  if (lvl < 2 && offCode >= 20) price += (offCode - 19) * 2 * ZO_BITCOST_MUL;
+  unsigned mlCode = ml_code(ml);
+  price += (zo_ml_bits[mlCode] * ZO_BITCOST_MUL) + (o->matchLengthSumBasePrice - OPT_WEIGHT(o->matchLengthFreq[mlCode], lvl));
+  price += ZO_BITCOST_MUL / 5;
+  return price;
+}
+static void opt_update_stats(struct zo_opt_state* o, u32 ll, const u8* lit, u32 offCode, u32 ml) {
+  for (u32 u = 0; u < ll; u++) o->litFreq[lit[u]] += 2;
+  o->litSum += ll * 2;
+  o->litLengthFreq[ll_code(ll)]++; o->litLengthSum++;
+  o->offCodeFreq[hb32(offCode + 1)]++; o->offCodeSum++;
+  o->matchLengthFreq[ml_code(ml)]++; o->matchLengthSum++;
+}
+static void opt_update_rep(u32 out[3], const u32 rep[3], u32 offset, u32 ll0) {
+  if (offset >= 3) { out[2] = rep[1]; out[1] = rep[0]; out[0] = offset - 2; }
+  else {
+    u32 repCode = offset + ll0;
+    if (repCode > 0) {
+      u32 cur = repCode == 3 ? rep[0] - 1 : rep[repCode];
+      u32 r2 = repCode >= 2 ? rep[1] : rep[2], r1 = rep[0];
+      out[2] = r2; out[1] = r1; out[0] = cur;
+    } else { out[0] = rep[0]; out[1] = rep[1]; out[2] = rep[2]; }
+  }
+}
+static inline u32 opt_hash3(const u8* p, u32 h) { return ((rd32(p) << 8) * 506832829u) >> (32 - h); }
+/* ZSTD_insertBt1: inserts index curr into the tree, returns how many positions may be skipped */
+static u32 opt_insert_bt1(cctx* c, const u8* src, u32 curr, size_t iend, u32 mls) {
+  u32* bt = c->chainTable; u32 btMask = (1u << (c->cp.chainLog - 1)) - 1;
+  const u8* ip = src + (curr - 1 - c->idxShift);
+  size_t ipos = (size_t)(ip - src);
+  u32 h = hashN(ip, c->cp.hashLog, mls);
+  u32 matchIndex = c->hashTable[h];
+  size_t commonSmaller = 0, commonLarger = 0;
+  u32 btLow = btMask >= curr ? 0 : curr - btMask;
+  u32* smallerPtr = bt + 2 * (curr & btMask); u32* largerPtr = smallerPtr + 1;
+  u32 dummy32, windowLow = 1 + c->idxShift, matchEndIdx = curr + 8 + 1;
+  size_t bestLength = 8;
+  u32 nbCompares = 1u << c->cp.searchLog;
+  c->hashTable[h] = curr;
+  while (nbCompares-- && matchIndex >= windowLow) {
+    u32* nextPtr = bt + 2 * (matchIndex & btMask);
+    size_t ml = commonSmaller < commonLarger ? commonSmaller : commonLarger;
+    size_t m = matchIndex - 1 - c->idxShift;
+    ml += count_eq(src, ipos + ml, m + ml, iend);
+    if (ml > bestLength) { bestLength = ml; if (ml > matchEndIdx - matchIndex) matchEndIdx = matchIndex + (u32)ml; }
+    if (ipos + ml == iend) break;
+    if (src[m + ml] < src[ipos + ml]) {
+      *smallerPtr = matchIndex; commonSmaller = ml;
+      if (matchIndex <= btLow) { smallerPtr = &dummy32; break; }
+      smallerPtr = nextPtr + 1; matchIndex = nextPtr[1];
+    } else {
+      *largerPtr = matchIndex; commonLarger = ml;
+      if (matchIndex <= btLow) { largerPtr = &dummy32; break; }
+      largerPtr = nextPtr; matchIndex = nextPtr[0];
+    }
+  }
+  *smallerPtr = *largerPtr = 0;
+  u32 positions = 0;
+  if (bestLength > 384) positions = (u32)(bestLength - 384) < 192 ? (u32)(bestLength - 384) : 192;
+  u32 fwd = matchEndIdx - (curr + 8);
+  return positions > fwd ? positions : fwd;
+}
+/* ZSTD_BtGetAllMatches: matches at position ip in increasing length */
+static u32 opt_get_all_matches(cctx* c, zo_match* matches, u32* nextToUpdate3, const u8* src, size_t ip, size_t iend, const u32 rep[3], u32 ll0, u32 lengthToBeat) {
+  u32 mls = c->cp.minMatch, curr = (u32)ip + 1 + c->idxShift;
+  if (curr < c->nextToUpdate) return 0;                /* skipped area */
+  u32 mlsH = mls < 4 ? (mls == 3 ? 3 : 4) : mls > 6 ? 6 : mls;   /* the template: 3, 4, 5, 6 (7 -> 6) */
+  for (u32 idx = c->nextToUpdate; idx < curr;) idx += opt_insert_bt1(c, src, idx, iend, mlsH);
+  c->nextToUpdate = curr;
+  u32 sufficient_len = c->cp.targetLength < ZO_OPT_NUM - 1 ? c->cp.targetLength : ZO_OPT_NUM - 1;
+  u32 minMatch = mlsH == 3 ? 3 : 4;
+  u32 h = hashN(src + ip, c->cp.hashLog, mlsH);
+  u32 matchIndex = c->hashTable[h];
+  u32* bt = c->chainTable; u32 btMask = (1u << (c->cp.chainLog - 1)) - 1;
+  size_t commonSmaller = 0, commonLarger = 0;
+  u32 dictLimit = 1 + c->idxShift;
+  u32 btLow = btMask >= curr ? 0 : curr - btMask;
+  u32 windowLow = dictLimit, matchLow = windowLow ? windowLow : 1;
+  u32* smallerPtr = bt + 2 * (curr & btMask); u32* largerPtr = smallerPtr + 1;
+  u32 matchEndIdx = curr + 8 + 1, dummy32, mnum = 0;
+  u32 nbCompares = 1u << c->cp.searchLog;
+  size_t bestLength = lengthToBeat - 1;
+  {   /* repcodes */
+    u32 lastR = 3 + ll0;
+    for (u32 repCode = ll0; repCode < lastR; repCode++) {
+      u32 repOffset = repCode == 3 ? rep[0] - 1 : rep[repCode];
+      u32 repIndex = curr - repOffset;
+      u32 repLen = 0;
+      if (repOffset - 1 < curr - dictLimit) {
+        int same = minMatch == 3 ? ((rd32(src + ip) << 8) == (rd32(src + ip - repOffset) << 8)) : (rd32(src + ip) == rd32(src + ip - repOffset));
+        if (repIndex >= windowLow && same) repLen = (u32)count_eq(src, ip + minMatch, ip + minMatch - repOffset, iend) + minMatch;
+      }
+      if (repLen > bestLength) {
+        bestLength = repLen;
+        matches[mnum].off = repCode - ll0; matches[mnum].len = repLen; mnum++;
+        if (repLen > sufficient_len || ip + repLen == iend) return mnum;
+      }
+    }
+  }
+  if (mlsH == 3 && bestLength < 3) {                   /* HC3 */
+    u32 idx = *nextToUpdate3, target = curr;
+    u32 hash3 = opt_hash3(src + ip, c->hashLog3);
+    while (idx < target) { c->hashTable3[opt_hash3(src + (idx - 1 - c->idxShift), c->hashLog3)] = idx; idx++; }
+    *nextToUpdate3 = target;
+    u32 matchIndex3 = c->hashTable3[hash3];
+    if (matchIndex3 >= matchLow && curr - matchIndex3 < (1u << 18)) {
+      size_t mlen = count_eq(src, ip, matchIndex3 - 1 - c->idxShift, iend);
+      if (mlen >= 3) {
+        bestLength = mlen;
+        matches[0].off = (curr - matchIndex3) + 2; matches[0].len = (u32)mlen; mnum = 1;
+        if (mlen > sufficient_len || ip + mlen == iend) { c->nextToUpdate = curr + 1; return 1; }
+      }
+    }
+  }
+  c->hashTable[h] = curr;
+  while (nbCompares-- && matchIndex >= matchLow) {
+    u32* nextPtr = bt + 2 * (matchIndex & btMask);
+    size_t ml = commonSmaller < commonLarger ? commonSmaller : commonLarger;
+    size_t m = matchIndex - 1 - c->idxShift;
+    ml += count_eq(src, ip + ml, m + ml, iend);
+    if (ml > bestLength) {
+      if (ml > matchEndIdx - matchIndex) matchEndIdx = matchIndex + (u32)ml;
+      bestLength = ml;
+      matches[mnum].off = (curr - matchIndex) + 2; matches[mnum].len = (u32)ml; mnum++;
+      if (ml > ZO_OPT_NUM || ip + ml == iend) break;
+    }
+    if (src[m + ml] < src[ip + ml]) {
+      *smallerPtr = matchIndex; commonSmaller = ml;
+      if (matchIndex <= btLow) { smallerPtr = &dummy32; break; }
+      smallerPtr = nextPtr + 1; matchIndex = nextPtr[1];
+    } else {
+      *largerPtr = matchIndex; commonLarger = ml;
+      if (matchIndex <= btLow) { largerPtr = &dummy32; break; }
+      largerPtr = nextPtr; matchIndex = nextPtr[0];
+    }
+  }
+  *smallerPtr = *largerPtr = 0;
+  c->nextToUpdate = matchEndIdx - 8;
+  return mnum;
+}
+/* ZSTD_compressBlock_opt_generic; emits through emit() unless dry (btultra2's statistics pass) */
+static size_t mf_opt(cctx* c, const u8* src, size_t bs, size_t be, u32 rep[3], int lvl, int dry) {
+  struct zo_opt_state* o = c->opt;
+  zo_optimal* opt = o->table; zo_match* matches = o->matches;
+  size_t anchor = bs, ilimit = be >= 8 ? be - 8 : 0, ip = bs;
+  u32 sufficient_len = c->cp.targetLength < ZO_OPT_NUM - 1 ? c->cp.targetLength : ZO_OPT_NUM - 1;
+  u32 minMatch = c->cp.minMatch == 3 ? 3 : 4;
+  u32 nextToUpdate3 = c->nextToUpdate;
+  zo_optimal lastSequence; memset(&lastSequence, 0, sizeof(lastSequence));
+  opt_rescale_freqs(o, src + bs, be - bs, lvl);
+  ip += (ip + 1 + c->idxShift == 1 + c->idxShift) && bs == 0 ? 1 : 0;      /* ip += (ip == prefixStart) */
+  while (ip < ilimit) {
+    u32 cur, last_pos = 0;
+    {
+      u32 litlen = (u32)(ip - anchor), ll0 = !litlen;
+      u32 nb = opt_get_all_matches(c, matches, &nextToUpdate3, src, ip, be, rep, ll0, minMatch);
+      if (!nb) { ip++; continue; }
+      for (int i = 0; i < 3; i++) opt[0].rep[i] = rep[i];
+      opt[0].mlen = 0; opt[0].litlen = litlen;
+      opt[0].price = (int)opt_ll_price(litlen, o, lvl);
+      {
+        u32 maxML = matches[nb - 1].len, maxOffset = matches[nb - 1].off;
+        if (maxML > sufficient_len) {
+          lastSequence.litlen = litlen; lastSequence.mlen = maxML; lastSequence.off = maxOffset;
+          cur = 0; last_pos = lastSequence.litlen + lastSequence.mlen;
+          goto shortest_path;
+        }
+      }
+      {
+        u32 literalsPrice = (u32)opt[0].price + opt_ll_price(0, o, lvl);
+        u32 pos;
+        for (pos = 1; pos < minMatch; pos++) opt[pos].price = ZO_MAX_PRICE;
+        for (u32 k = 0; k < nb; k++) {
+          u32 offset = matches[k].off, end = matches[k].len;
+          for (; pos <= end; pos++) {
+            u32 matchPrice = opt_match_price(offset, pos, o, lvl);
+            opt[pos].mlen = pos; opt[pos].off = offset; opt[pos].litlen = litlen; opt[pos].price = (int)(literalsPrice + matchPrice);
+          }
+        }
+        last_pos = pos - 1;
+      }
+    }
+    for (cur = 1; cur <= last_pos; cur++) {
+      size_t inr = ip + cur;
+      {
+        u32 litlen = opt[cur - 1].mlen == 0 ? opt[cur - 1].litlen + 1 : 1;
+        int price = opt[cur - 1].price + (int)opt_raw_literals_cost(src + ip + cur - 1, 1, o, lvl) + (int)opt_ll_price(litlen, o, lvl) - (int)opt_ll_price(litlen - 1, o, lvl);
+        if (price <= opt[cur].price) { opt[cur].mlen = 0; opt[cur].off = 0; opt[cur].litlen = litlen; opt[cur].price = price; }
+      }
+      if (opt[cur].mlen != 0) {
+        u32 prev = cur - opt[cur].mlen;
+        u32 nr[3]; opt_update_rep(nr, opt[prev].rep, opt[cur].off, opt[cur].litlen == 0);
+        memcpy(opt[cur].rep, nr, sizeof(nr));
+      } else memcpy(opt[cur].rep, opt[cur - 1].rep, sizeof(opt[cur].rep));
+      if (inr > ilimit) continue;
+      if (cur == last_pos) break;
+      if (lvl == 0 && opt[cur + 1].price <= opt[cur].price + (int)(ZO_BITCOST_MUL / 2)) continue;
+      {
+        u32 ll0 = opt[cur].mlen != 0;
+        u32 litlen = opt[cur].mlen == 0 ? opt[cur].litlen : 0;
+        u32 previousPrice = (u32)opt[cur].price;
+        u32 basePrice = previousPrice + opt_ll_price(0, o, lvl);
+        u32 nb = opt_get_all_matches(c, matches, &nextToUpdate3, src, inr, be, opt[cur].rep, ll0, minMatch);
+        if (!nb) continue;
+        {
+          u32 maxML = matches[nb - 1].len;
+          if (maxML > sufficient_len || cur + maxML >= ZO_OPT_NUM) {
+            lastSequence.mlen = maxML; lastSequence.off = matches[nb - 1].off; lastSequence.litlen = litlen;
+            cur -= opt[cur].mlen == 0 ? opt[cur].litlen : 0;
+            last_pos = cur + lastSequence.litlen + lastSequence.mlen;
+            if (cur > ZO_OPT_NUM) cur = 0;
+            goto shortest_path;
+          }
+        }
+        for (u32 k = 0; k < nb; k++) {
+          u32 offset = matches[k].off, lastML = matches[k].len, startML = k > 0 ? matches[k - 1].len + 1 : minMatch;
+          for (u32 mlen = lastML; mlen >= startML; mlen--) {
+            u32 pos = cur + mlen;
+            int price = (int)(basePrice + opt_match_price(offset, mlen, o, lvl));
+            if (pos > last_pos || price < opt[pos].price) {
+              while (last_pos < pos) { opt[last_pos + 1].price = ZO_MAX_PRICE; last_pos++; }
+              opt[pos].mlen = mlen; opt[pos].off = offset; opt[pos].litlen = litlen; opt[pos].price = price;
+            } else if (lvl == 0) break;
+          }
+        }
+      }
+    }
+    lastSequence = opt[last_pos];
+    cur = last_pos > lastSequence.litlen + lastSequence.mlen ? last_pos - (lastSequence.litlen + lastSequence.mlen) : 0;
+shortest_path:
+    if (lastSequence.mlen != 0) { u32 nr[3]; opt_update_rep(nr, opt[cur].rep, lastSequence.off, lastSequence.litlen == 0); memcpy(rep, nr, sizeof(nr)); }
+    else memcpy(rep, opt[cur].rep, 3 * sizeof(u32));
+    {
+      u32 storeEnd = cur + 1, storeStart = storeEnd, seqPos = cur;
+      opt[storeEnd] = lastSequence;
+      while (seqPos > 0) {
+        u32 backDist = opt[seqPos].litlen + opt[seqPos].mlen;
+        storeStart--;
+        opt[storeStart] = opt[seqPos];
+        seqPos = seqPos > backDist ? seqPos - backDist : 0;
+      }
+      for (u32 sp = storeStart; sp <= storeEnd; sp++) {
+        u32 llen = opt[sp].litlen, mlen = opt[sp].mlen, offCode = opt[sp].off, advance = llen + mlen;
+        if (mlen == 0) { ip = anchor + llen; continue; }
+        opt_update_stats(o, llen, src + anchor, offCode, mlen);
+        if (!dry) emit(c, src, anchor, llen, mlen, offCode + 1);
+        anchor += advance; ip = anchor;
+      }
+      opt_set_base_prices(o, lvl);
+    }
+  }
+  return be - anchor;
+}
+
 static size_t run_match_finder(cctx* c, const u8* src, size_t bs, size_t be, u32 rep[3]) {
   /* limited update after a very long match (ZSTD_buildSeqStore) */
-  u32 cur = (u32)bs + 1;
+  u32 cur = (u32)bs + 1 + c->idxShift;
   if (cur > c->nextToUpdate + 384) {
     u32 d = cur - c->nextToUpdate - 384;
     c->nextToUpdate = cur - (d < 192 ? d : 192);
@@ -692,14 +1033,32 @@ static size_t run_match_finder(cctx* c, const u8* src, size_t bs, size_t be, u32
     case 2: return mf_dfast(c, src, bs, be, rep);
     case 3: return mf_lazy(c, src, bs, be, rep, 0);
     case 4: return mf_lazy(c, src, bs, be, rep, 1);
-    default: return mf_lazy(c, src, bs, be, rep, 2);
+    case 5: case 6: return mf_lazy(c, src, bs, be, rep, 2);
+    case 7: return mf_opt(c, src, bs, be, rep, 0, 0);
+    case 8: return mf_opt(c, src, bs, be, rep, 2, 0);
+    default:
+      /* btultra2: a first pass over the first block only to collect statistics, then the window is moved past it */
+      if (c->opt->litLengthSum == 0 && bs == 0 && c->nextToUpdate == 1 && be - bs > 1024) {
+        u32 tmpRep[3] = {rep[0], rep[1], rep[2]};
+        size_t L = be - bs;
+        (void)mf_opt(c, src, bs, be, tmpRep, 2, 1);
+        c->idxShift += (u32)L;
+        c->nextToUpdate = 1 + c->idxShift;
+        opt_upscale_stats(c->opt);                     /* "re-inforce weight of collected statistics" */
+      }
+      return mf_opt(c, src, bs, be, rep, 2, 0);
   }
 }
 
 static int cctx_init(cctx* c, int level, size_t n) {
   memset(c, 0, sizeof(*c));
   if (zo_get_cparams(level, n, &c->cp)) return -1;
-  if (c->cp.strategy > 6) return -1; /* btopt and up: not restated (SURVEY Appendix A status table) */
+  if (c->cp.strategy >= 7) {
+    c->opt = (struct zo_opt_state*)calloc(1, sizeof(struct zo_opt_state));
+    c->hashLog3 = c->cp.minMatch == 3 ? (c->cp.windowLog < 17 ? c->cp.windowLog : 17) : 0;
+    c->hashTable3 = (u32*)calloc((size_t)1 << c->hashLog3, 4);
+    if (!c->opt || !c->hashTable3) return -1;
+  }
   size_t hsz = (size_t)1 << c->cp.hashLog, csz = (size_t)1 << c->cp.chainLog;
   size_t blockMax = n < (128u << 10) ? n : (128u << 10);
   c->hashTable = (u32*)calloc(hsz, 4);
@@ -710,7 +1069,7 @@ static int cctx_init(cctx* c, int level, size_t n) {
   c->prev.rep[0] = 1; c->prev.rep[1] = 4; c->prev.rep[2] = 8;
   return (c->hashTable && c->chainTable && c->seqs && c->lits) ? 0 : -1;
 }
-static void cctx_free(cctx* c) { free(c->hashTable); free(c->chainTable); free(c->seqs); free(c->lits); }
+static void cctx_free(cctx* c) { free(c->hashTable); free(c->chainTable); free(c->seqs); free(c->lits); free(c->hashTable3); free(c->opt); }
 
 size_t zo_compress_frame(void* dstv, size_t cap, const void* srcv, size_t n, int level, int checksum) {
   u8* dst = (u8*)dstv; const u8* src = (const u8*)srcv;
