@@ -33,7 +33,8 @@ def test_extension_is_loaded_and_gpu_visible(zra):
                                       (9, 65536), (10, 65536), (3, 262144), (9, 262144), (5, 262144), (3, 100000), (3, 4096), (1, 200000),
                                       (-1, 65536), (-5, 16384), (-20, 262144), (-128, 65536), (5, 131072), (6, 100000),
                                       (3, 524288), (9, 1048576), (1, 400000), (5, 2097152), (-3, 300000), (12, 524288),
-                                      (11, 65536), (12, 262144), (11, 100000), (10, 16384), (9, 8192), (14, 524288)])       # the last six: btlazy2
+                                      (11, 65536), (12, 262144), (11, 100000), (10, 16384), (9, 8192), (14, 524288),       # btlazy2
+                                      (13, 65536), (16, 65536), (19, 65536), (22, 16384), (19, 262144), (17, 524288)])   # btopt, btultra, btultra2
 def test_compress_buffer_bit_exact(zra, gens, level, fs):
     for name, d in gens.items():
         d = d[: 5 * fs + 777] if fs >= 65536 else d[: 37 * fs + 11]
@@ -109,7 +110,7 @@ def test_randomised_differential_compress(zra, seed):
         fs = int(rng.choice([1024, 4096, 16384, 65536, 65536, 131072, 262144, 50000] + ([300000, 524288] if seed >= 2000 else [])))
         n = int(rng.choice([0, 1, 6, 7, 8, 100, fs - 1, fs, fs + 1, 3 * fs + 17, int(rng.randint(1, 6 * fs))]))
         n = min(n, 600000 if seed < 2000 else 1300000)
-        level = int(rng.choice([1, 2, 3, 3, 3, 4, 5, 6, 7, 8, 9, 10, -1, -3, -9, -64] + ([11, 12] if seed >= 2000 else [])))
+        level = int(rng.choice([1, 2, 3, 3, 3, 4, 5, 6, 7, 8, 9, 10, -1, -3, -9, -64] + ([11, 12, 13, 15, 17, 19, 22] if seed >= 2000 else [])))
         d = _random_input(rng, n)
         st, ref = O.zra_compress(d, level, fs, bool(case & 1))
         if st != (0, 0):
@@ -183,9 +184,10 @@ def test_compress_edge_cases(zra):
     d = C.gen_C(100000)
     st, ref = O.zra_compress(d, 3, 16384, True, 5)
     assert zra.CompressBuffer(d, 3, 16384, True, b"12345") == ref
-    # levels the engine does not implement are refused with parameter_unsupported, never served by a CPU codec
+    # what the engine does not implement (a frame larger than the level's window) is refused with parameter_unsupported, never
+    # served by a CPU codec
     with pytest.raises(zra.ZraError) as e:
-        zra.CompressBuffer(d, 19, 16384, True)
+        zra.CompressBuffer(C.gen_C(700000), 1, 600000, True)
     assert (e.value.zra, e.value.zstd) == (1, 40)
     # output buffer too small is detected before any work (zra.cpp:196-198)
     L = zra.load()

@@ -69,31 +69,36 @@ __global__ void zra_gather_frames_kernel(const u8* slots, u64 slotStride, const 
 }
 
 // ---- zstd 1.4.9 parameter rows (dumped there from the dependency): [wlog clog hlog slog mml tlen strat]
-const uint8_t kCP16[13][7] = {{14,14,15,2,4,0,2},{14,14,15,1,5,0,1},{14,14,15,1,4,0,1},{14,14,15,2,4,0,2},{14,14,14,4,4,2,3},{14,14,14,3,4,4,4},
-  {14,14,14,4,4,8,5},{14,14,14,6,4,8,5},{14,14,14,8,4,8,5},{14,15,14,5,4,8,6},{14,15,14,9,4,8,6},{14,15,14,3,4,12,7},{14,15,14,4,3,24,7}};
-const uint8_t kCP128[13][7] = {{17,15,16,2,5,0,2},{17,12,13,1,6,0,1},{17,13,15,1,5,0,1},{17,15,16,2,5,0,2},{17,17,17,2,4,0,2},{17,16,17,3,4,2,3},
-  {17,17,17,3,4,4,4},{17,17,17,3,4,8,5},{17,17,17,4,4,8,5},{17,17,17,5,4,8,5},{17,17,17,6,4,8,5},{17,17,17,5,4,8,6},{17,18,17,7,4,12,6}};
-const uint8_t kCP256[13][7] = {{18,16,16,1,4,0,2},{18,13,14,1,6,0,1},{18,14,14,1,5,0,2},{18,16,16,1,4,0,2},{18,16,17,2,5,2,3},{18,18,18,3,5,2,3},
-  {18,18,19,3,5,4,4},{18,18,19,4,4,4,4},{18,18,19,4,4,8,5},{18,18,19,5,4,8,5},{18,18,19,6,4,8,5},{18,18,19,5,4,12,6},{18,19,19,7,4,12,6}};
+const uint16_t kCP16[23][7] = {{14,14,15,2,4,0,2},{14,14,15,1,5,0,1},{14,14,15,1,4,0,1},{14,14,15,2,4,0,2},{14,14,14,4,4,2,3},{14,14,14,3,4,4,4},
+  {14,14,14,4,4,8,5},{14,14,14,6,4,8,5},{14,14,14,8,4,8,5},{14,15,14,5,4,8,6},{14,15,14,9,4,8,6},{14,15,14,3,4,12,7},{14,15,14,4,3,24,7},
+  {14,15,14,5,3,32,8},{14,15,15,6,3,64,8},{14,15,15,7,3,256,8},{14,15,15,5,3,48,9},{14,15,15,6,3,128,9},{14,15,15,7,3,256,9},{14,15,15,8,3,256,9},{14,15,15,8,3,512,9},{14,15,15,9,3,512,9},{14,15,15,10,3,999,9}};
+const uint16_t kCP128[23][7] = {{17,15,16,2,5,0,2},{17,12,13,1,6,0,1},{17,13,15,1,5,0,1},{17,15,16,2,5,0,2},{17,17,17,2,4,0,2},{17,16,17,3,4,2,3},
+  {17,17,17,3,4,4,4},{17,17,17,3,4,8,5},{17,17,17,4,4,8,5},{17,17,17,5,4,8,5},{17,17,17,6,4,8,5},{17,17,17,5,4,8,6},{17,18,17,7,4,12,6},
+  {17,18,17,3,4,12,7},{17,18,17,4,3,32,7},{17,18,17,6,3,256,7},{17,18,17,6,3,128,8},{17,18,17,8,3,256,8},{17,18,17,10,3,512,8},{17,18,17,5,3,256,9},{17,18,17,7,3,512,9},{17,18,17,9,3,512,9},{17,18,17,11,3,999,9}};
+const uint16_t kCP256[23][7] = {{18,16,16,1,4,0,2},{18,13,14,1,6,0,1},{18,14,14,1,5,0,2},{18,16,16,1,4,0,2},{18,16,17,2,5,2,3},{18,18,18,3,5,2,3},
+  {18,18,19,3,5,4,4},{18,18,19,4,4,4,4},{18,18,19,4,4,8,5},{18,18,19,5,4,8,5},{18,18,19,6,4,8,5},{18,18,19,5,4,12,6},{18,19,19,7,4,12,6},
+  {18,18,19,4,4,16,7},{18,18,19,4,3,32,7},{18,18,19,6,3,128,7},{18,19,19,6,3,128,8},{18,19,19,8,3,256,8},{18,19,19,6,3,128,9},{18,19,19,8,3,256,9},{18,19,19,10,3,512,9},{18,19,19,12,3,512,9},{18,19,19,13,3,999,9}};
 
 inline uint32_t hbit(uint32_t x) { return 31u - (uint32_t)__builtin_clz(x); }
 
 // row 0 of ZSTD_getCParams_internal's level tables, "base for negative levels": strategy fast, the level becomes the acceleration
 // (targetLength = -level), and literals are then stored raw (ZSTD_compressLiterals' disableLiteralCompression)
-const uint8_t kCPNeg16[7] = {14, 12, 13, 1, 5, 1, 1}, kCPNeg128[7] = {17, 12, 12, 1, 5, 1, 1}, kCPNeg256[7] = {18, 12, 13, 1, 5, 1, 1};
+const uint16_t kCPNeg16[7] = {14, 12, 13, 1, 5, 1, 1}, kCPNeg128[7] = {17, 12, 12, 1, 5, 1, 1}, kCPNeg256[7] = {18, 12, 13, 1, 5, 1, 1};
 
 // the "default" table (srcSize > 256 KB), levels 0..15 (13-15: btlazy2)
-const uint8_t kCPDef[16][7] = {{21,16,17,1,5,0,2},{19,13,14,1,7,0,1},{20,15,16,1,6,0,1},{21,16,17,1,5,0,2},{21,18,18,1,5,0,2},{21,18,19,2,5,2,3},
+const uint16_t kCPDef[23][7] = {{21,16,17,1,5,0,2},{19,13,14,1,7,0,1},{20,15,16,1,6,0,1},{21,16,17,1,5,0,2},{21,18,18,1,5,0,2},{21,18,19,2,5,2,3},
   {21,19,19,3,5,4,3},{21,19,19,3,5,8,4},{21,19,19,3,5,16,5},{21,19,20,4,5,16,5},{22,20,21,4,5,16,5},{22,21,22,4,5,16,5},{22,21,22,5,5,16,5},
-  {22,21,22,5,5,32,6},{22,22,23,5,5,32,6},{22,23,23,6,5,32,6}};
-const uint8_t kCPNegDef[7] = {19, 12, 13, 1, 6, 1, 1};
+  {22,21,22,5,5,32,6},{22,22,23,5,5,32,6},{22,23,23,6,5,32,6},
+  {22,22,22,5,5,48,7},{23,23,22,5,4,64,7},{23,23,22,6,3,64,8},{23,24,22,7,3,256,9},{25,25,23,7,3,256,9},{26,26,24,7,3,512,9},{27,27,25,9,3,999,9}};
+const uint16_t kCPNegDef[7] = {19, 12, 13, 1, 6, 1, 1};
 
 // returns false when (level, size) needs what this engine does not implement: a strategy beyond btlazy2 (the optimal parsers), or a frame
 // larger than the level's window (the sliding-window rules are not restated; level 1: 512 KiB, level 2: 1 MiB, 3-9: 2 MiB, 10-12: 4 MiB)
 bool get_params(int level, size_t S, ZraEncParams* p) {
   if (level == 0) level = 3;
-  if (level > 15 || (level > 12 && S <= (256u << 10)) || S == 0) return false;      // btopt and up
-  const uint8_t* r = level < 0 ? (S <= (16u << 10) ? kCPNeg16 : S <= (128u << 10) ? kCPNeg128 : S <= (256u << 10) ? kCPNeg256 : kCPNegDef)
+  if (S == 0) return false;
+  if (level > 22) level = 22;                                                       // ZSTD_maxCLevel
+  const uint16_t* r = level < 0 ? (S <= (16u << 10) ? kCPNeg16 : S <= (128u << 10) ? kCPNeg128 : S <= (256u << 10) ? kCPNeg256 : kCPNegDef)
                                : (S <= (16u << 10) ? kCP16[level] : S <= (128u << 10) ? kCP128[level] : S <= (256u << 10) ? kCP256[level] : kCPDef[level]);
   if (S > ((size_t)1 << r[0])) return false;
   p->windowLog = r[0]; p->chainLog = r[1]; p->hashLog = r[2]; p->searchLog = r[3]; p->minMatch = r[4];
@@ -105,7 +110,7 @@ bool get_params(int level, size_t S, ZraEncParams* p) {
   if (cycleLog > p->windowLog) p->chainLog -= cycleLog - p->windowLog;
   if (p->windowLog < 10) p->windowLog = 10;
   p->blockSize = std::min<uint32_t>(128u << 10, 1u << p->windowLog);
-  return p->strategy <= 6;
+  return true;
 }
 
 }  // namespace
@@ -156,7 +161,13 @@ Status Engine::compress_impl_body(const uint8_t* dIn, size_t inSize, uint8_t* dB
   if (!(nFramesTotal > 1 || !tailSize)) full = tail;
   if (!tailSize) tail = full;
 
-  const uint64_t tableWords = std::max((1ull << full.hashLog) + (1ull << full.chainLog), (1ull << tail.hashLog) + (1ull << tail.chainLog));
+  // per-frame table slot: hash table + chain table / tree; the optimal parsers add a 3-byte hash table and their state (ZraOptState)
+  auto slotWords = [](const ZraEncParams& q) -> uint64_t {
+    uint64_t w = (1ull << q.hashLog) + (1ull << q.chainLog);
+    if (q.strategy >= 7) w += (q.minMatch == 3 ? 1ull << std::min(17u, q.windowLog) : 0) + (sizeof(ZraOptState) + 3) / 4 + 16;
+    return w;
+  };
+  const uint64_t tableWords = std::max(slotWords(full), slotWords(tail));
   const uint32_t maxBlock = std::max(full.blockSize, tail.blockSize);
   const uint64_t seqStride = maxBlock / 4 + 16;
   const uint64_t litStride = ((uint64_t)maxBlock + 64 + 15) & ~15ull;

@@ -232,6 +232,8 @@ struct HC {
   }
 };
 
+#include "zra_encode_opt.h"
+
 __device__ u32 mf_lazy(HC& H, const u8* src, u32 bs, u32 be, u32* rep, Emit& E, int depth) {
   u32 o1 = rep[0], o2 = rep[1], saved;
   u32 anchor = bs;
@@ -870,11 +872,13 @@ __device__ __forceinline__ bool mf_frame_setup(const ZraEncArgs& a, u32 block, i
   F.seqs = a.seqs + (size_t)f * a.seqStride;
   if (block == 0) {
     // fresh frame: zeroed tables, repcodes {1,4,8}, nextToUpdate 1 (A.4.8); 16-byte coalesced clears by the whole wave
-    const size_t words = ((size_t)1 << F.P->hashLog) + ((size_t)1 << F.P->chainLog);
+    size_t words = ((size_t)1 << F.P->hashLog) + ((size_t)1 << F.P->chainLog);
+    if (F.P->strategy >= 7)           // optimal parsers: the 3-byte hash table and the statistics of the price model behind the tree
+      words += (F.P->minMatch == 3 ? (size_t)1 << min(17u, F.P->windowLog) : 0) + 512;
     uint4* t4 = (uint4*)F.hashT;
     for (size_t i = lane; i < words / 4; i += 64) t4[i] = make_uint4(0, 0, 0, 0);
     for (size_t i = (words / 4) * 4 + lane; i < words; i += 64) F.hashT[i] = 0;
-    if (lane == 0) { F.st->rep[0] = 1; F.st->rep[1] = 4; F.st->rep[2] = 8; F.st->nextToUpdate = 1; F.st->insEnd = 1; }
+    if (lane == 0) { F.st->rep[0] = 1; F.st->rep[1] = 4; F.st->rep[2] = 8; F.st->nextToUpdate = 1; F.st->insEnd = 1; F.st->idxShift = 0; }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -884,6 +888,55 @@ __device__ __forceinline__ bool mf_frame_setup(const ZraEncArgs& a, u32 block, i
     return false;
   }
   return true;
+}
+
+// One block of one frame parsed by ONE lane: fast, the serial hash chain (odd tails), btlazy2 and the optimal parsers.
+__device__ void mf_serial_block(const MfFrame& F, u32 ntu0) {
+  const ZraEncParams& P = *F.P;
+  const u8* src = F.src; ZraEncFrameState* st = F.st; ZraEncBlockOut* bo = F.bo;
+  u32* hashT = F.hashT; u32* chainT = F.chainT;
+  const u32 bs = F.bs, be = F.be;
+  u32 rep[3] = {st->rep[0], st->rep[1], st->rep[2]};
+  u32 lastLL;
+  bo->skip = 0;
+  Emit E; E.seqs = F.seqs; E.n = 0;
+  // limited update after a very long match (A.4.3 hash chain prologue; harmless for the other finders)
+  u32 ntu = ntu0;
+  { const u32 cur = bs + 1; if (cur > ntu + 384) { const u32 d = cur - ntu - 384; ntu = cur - (d < 192 ? d : 192); } }
+  if (P.strategy >= 7) {
+    // btopt / btultra / btultra2 (zra_encode_opt.h); the limited update above is redone with the window shift of btultra2
+    OptCtx O;
+    O.hashT = hashT; O.bt = chainT; O.hashLog = P.hashLog; O.chainLog = P.chainLog; O.searchLog = P.searchLog;
+    O.minMatchParam = P.minMatch; O.targetLength = P.targetLength; O.lvl = P.strategy == 7 ? 0 : 2;
+    O.hashLog3 = P.minMatch == 3 ? min(17u, P.windowLog) : 0;
+    O.hash3 = chainT + ((size_t)1 << P.chainLog);
+    O.o = (ZraOptState*)(O.hash3 + (O.hashLog3 ? (size_t)1 << O.hashLog3 : 0));
+    O.idxShift = st->idxShift;
+    ntu = ntu0;
+    { const u32 cur = bs + 1 + O.idxShift; if (cur > ntu + 384) { const u32 d = cur - ntu - 384; ntu = cur - (d < 192 ? d : 192); } }
+    O.nextToUpdate = ntu;
+    if (P.strategy == 9 && O.o->litLengthSum == 0 && bs == 0 && ntu == 1 && be - bs > 1024) {
+      // btultra2: a first pass over the first block only to collect statistics, then the window is moved past it
+      u32 tmpRep[3] = {rep[0], rep[1], rep[2]};
+      (void)O.parse(src, bs, be, tmpRep, E, true);
+      O.idxShift += be - bs;
+      O.nextToUpdate = 1 + O.idxShift;
+      O.upscale_stats();
+    }
+    lastLL = O.parse(src, bs, be, rep, E, false);
+    ntu = O.nextToUpdate;
+    st->idxShift = O.idxShift;
+  } else if (P.strategy == 1) lastLL = mf_fast(P, hashT, src, bs, be, rep, E);
+  else {
+    HC H; H.hashT = hashT; H.chainT = chainT; H.hlog = P.hashLog; H.mls = P.minMatch < 4 ? 4 : P.minMatch > 6 ? 6 : P.minMatch;
+    H.chainSize = 1u << P.chainLog; H.cmask = H.chainSize - 1; H.searchLog = P.searchLog; H.nextToUpdate = ntu;
+    H.bt = P.strategy == 6;
+    lastLL = mf_lazy(H, src, bs, be, rep, E, P.strategy == 6 ? 2 : (int)P.strategy - 3);
+    ntu = H.nextToUpdate;
+  }
+  st->nextToUpdate = ntu; st->insEnd = ntu;
+  bo->nbSeq = E.n; bo->lastLL = lastLL;
+  bo->rep[0] = rep[0]; bo->rep[1] = rep[1]; bo->rep[2] = rep[2];   // confirmed by stage 2 only if the block is emitted compressed
 }
 
 // Match finder for strategy 2 (dfast, levels 3-4): one wave per frame, lean window-resolve parse. Launched when the batch's
@@ -1018,17 +1071,7 @@ zra_mf_kernel(ZraEncArgs a, u32 block, u32 only, u32 onlySlot, u32 perWave) {
     }
     return;
   }
-  if (P.strategy == 1) lastLL = mf_fast(P, hashT, src, bs, be, rep, E);
-  else {
-    HC H; H.hashT = hashT; H.chainT = chainT; H.hlog = P.hashLog; H.mls = P.minMatch < 4 ? 4 : P.minMatch > 6 ? 6 : P.minMatch;
-    H.chainSize = 1u << P.chainLog; H.cmask = H.chainSize - 1; H.searchLog = P.searchLog; H.nextToUpdate = ntu;
-    H.bt = P.strategy == 6;
-    lastLL = mf_lazy(H, src, bs, be, rep, E, P.strategy == 6 ? 2 : (int)P.strategy - 3);
-    ntu = H.nextToUpdate;
-  }
-  st->nextToUpdate = ntu; st->insEnd = ntu;
-  bo->nbSeq = E.n; bo->lastLL = lastLL;
-  bo->rep[0] = rep[0]; bo->rep[1] = rep[1]; bo->rep[2] = rep[2];   // confirmed by stage 2 only if the block is emitted compressed
+  mf_serial_block(F, ntu0);
 }
 
 // Match finder for batches whose full-size frames use a hash-chain strategy (greedy / lazy / lazy2): one wave per frame, the
@@ -1053,21 +1096,8 @@ zra_mf_hc_kernel(ZraEncArgs a, u32 block) {
     const u32 cur = bs + 1;
     if (cur > ntu + 384) { const u32 d = cur - ntu - 384; ntu = cur - (d < 192 ? d : 192); }
   }
-  if (P.strategy == 1 || P.strategy == 6) {            // a short last frame with "fast" or btlazy2 cparams: one lane, serial
-    if (lane != 0) return;
-    bo->skip = 0;
-    Emit E; E.seqs = F.seqs; E.n = 0;
-    u32 lastLL;
-    if (P.strategy == 1) lastLL = mf_fast(P, F.hashT, F.src, bs, be, rep, E);
-    else {
-      HC B; B.hashT = F.hashT; B.chainT = F.chainT; B.hlog = P.hashLog; B.mls = P.minMatch < 4 ? 4 : P.minMatch > 6 ? 6 : P.minMatch;
-      B.chainSize = 1u << P.chainLog; B.cmask = B.chainSize - 1; B.searchLog = P.searchLog; B.nextToUpdate = ntu; B.bt = true;
-      lastLL = mf_lazy(B, F.src, bs, be, rep, E, 2);
-      ntu = B.nextToUpdate;
-    }
-    st->nextToUpdate = ntu; st->insEnd = ntu;
-    bo->nbSeq = E.n; bo->lastLL = lastLL;
-    bo->rep[0] = rep[0]; bo->rep[1] = rep[1]; bo->rep[2] = rep[2];
+  if (P.strategy < 3 || P.strategy > 5) {             // a short last frame with other cparams (fast, btlazy2, an optimal parser): one lane
+    if (lane == 0) mf_serial_block(F, ntu0);
     return;
   }
   __shared__ u32 hcOld[128];

@@ -92,6 +92,20 @@ struct ZraEncParams {
   uint32_t blockSize;     // min(128 KiB, 1 << windowLog)
 };
 
+// optimal parsers (btopt / btultra / btultra2, levels 13-22): per-frame statistics of the price model (they live as long as the frame)
+// and the work arrays of the forward parse; sits in the frame's table slot behind the hash, tree and 3-byte hash tables
+#define ZRA_OPT_NUM 4096u
+struct ZraOptCell { int32_t price; uint32_t off, mlen, litlen, rep[3]; };
+struct ZraOptMatch { uint32_t off, len; };
+struct ZraOptState {
+  uint32_t litFreq[256], litLengthFreq[36], matchLengthFreq[53], offCodeFreq[32];
+  uint32_t litSum, litLengthSum, matchLengthSum, offCodeSum;
+  uint32_t litSumBasePrice, litLengthSumBasePrice, matchLengthSumBasePrice, offCodeSumBasePrice;
+  uint32_t predef, pad;
+  ZraOptCell table[ZRA_OPT_NUM + 1];
+  ZraOptMatch matches[ZRA_OPT_NUM + 1];
+};
+
 // FSE encoding table in the layout the kernels use (A.4.6)
 struct ZraFseCTable {
   uint16_t stateTable[512];
@@ -110,6 +124,7 @@ struct ZraEncFrameState {
   // of the tables again, newest first, with these values.
   uint32_t insEnd;
   uint32_t ring[128];
+  uint32_t idxShift;               // optimal parsers: table index = position + 1 + idxShift (btultra2 moves the window base after its statistics pass)
   uint32_t outPos;                 // bytes of the frame already written to its slot
   uint32_t hufRepeat;              // 0 none, 1 check, 2 valid
   uint32_t llRepeat, ofRepeat, mlRepeat;
