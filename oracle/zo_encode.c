@@ -38,8 +38,7 @@ int zo_get_cparams(int level, size_t S, zo_cparams* cp) {
   if (level > 22) level = 22;                                           /* ZSTD_maxCLevel */
   const u16* r = level < 0 ? (S <= (16u << 10) ? CPNEG16 : S <= (128u << 10) ? CPNEG128 : S <= (256u << 10) ? CPNEG256 : CPNEGDEF)
                           : (S <= (16u << 10) ? CP16[level] : S <= (128u << 10) ? CP128[level] : S <= (256u << 10) ? CP256[level] : CPDEF[level]);
-  /* a frame larger than the level's window would need the sliding-window rules (lowLimit, ZSTD_window_enforceMaxDist): not restated */
-  if (S > ((size_t)1 << r[0])) return -1;
+  /* a frame larger than the level's window: matches are limited to the last 2^windowLog bytes (lowest_at below) */
   cp->windowLog = r[0]; cp->chainLog = r[1]; cp->hashLog = r[2]; cp->searchLog = r[3];
   cp->minMatch = r[4]; cp->targetLength = level < 0 ? (u32)(-level) : r[5]; cp->strategy = r[6];
   u32 srcLog = S < 64 ? 6 : hb32((u32)S - 1) + 1;
@@ -93,9 +92,17 @@ static void emit(cctx* c, const u8* src, size_t anchor, size_t ll, size_t ml, u3
 }
 
 /* common prologue; returns start ip */
-static size_t mf_prologue(size_t bs, u32* o1, u32* o2, u32* saved) {
-  size_t ip = bs + (bs == 0);
-  u32 maxRep = (u32)ip;
+/* ZSTD_getLowestMatchIndex / ZSTD_getLowestPrefixIndex without a dictionary: the lowest index a match may have when the position
+ * with index `curr` is searched — the first index of the frame, or curr - 2^windowLog once the frame is longer than the window */
+static inline u32 lowest_at(const cctx* c, u32 curr) {
+  u32 maxDist = 1u << c->cp.windowLog, lowValid = 1 + c->idxShift;
+  return (curr - lowValid > maxDist) ? curr - maxDist : lowValid;
+}
+/* block prologue: skip the very first byte of the prefix, drop repeat offsets that reach below the window */
+static size_t mf_prologue(const cctx* c, size_t bs, size_t prefixStartPos, u32* o1, u32* o2, u32* saved) {
+  size_t ip = bs + (bs == prefixStartPos);
+  u32 curr = (u32)ip + 1;
+  u32 maxRep = curr - lowest_at(c, curr);
   *saved = 0;
   if (*o2 > maxRep) { *saved = *o2; *o2 = 0; }
   if (*o1 > maxRep) { *saved = *o1; *o1 = 0; }
@@ -107,7 +114,8 @@ static size_t mf_fast(cctx* c, const u8* src, size_t bs, size_t be, u32 rep[3]) 
   u32 tl = c->cp.targetLength; size_t step0 = tl + (tl == 0) + 1;
   u32 o1 = rep[0], o2 = rep[1], saved;
   size_t anchor = bs, ilimit = be >= 8 ? be - 8 : 0;   /* a 7-byte first block: iend-8 lies before the start, nothing is searched */
-  size_t ip0 = mf_prologue(bs, &o1, &o2, &saved), ip1 = ip0 + 1;
+  u32 psi = lowest_at(c, (u32)be + 1);                 /* prefixStartIndex, from the block's end */
+  size_t ip0 = mf_prologue(c, bs, psi - 1, &o1, &o2, &saved), ip1 = ip0 + 1;
   while (ip1 < ilimit) {
     size_t ip2 = ip0 + 2, top = ip0;
     u32 h0 = hashN(src + ip0, hlog, mls), h1 = hashN(src + ip1, hlog, mls);
@@ -118,11 +126,11 @@ static size_t mf_fast(cctx* c, const u8* src, size_t bs, size_t be, u32 rep[3]) 
       size_t back = src[ip2 - 1] == src[ip2 - o1 - 1];
       ip0 = ip2 - back; match = ip2 - o1 - back; ml = 4 + back; offVal = 1;
     } else {
-      if (m0 > 1 && rd32(src + m0 - 1) == rd32(src + ip0)) match = m0 - 1;
-      else if (m1 > 1 && rd32(src + m1 - 1) == rd32(src + ip1)) { ip0 = ip1; match = m1 - 1; }
+      if (m0 > psi && rd32(src + m0 - 1) == rd32(src + ip0)) match = m0 - 1;
+      else if (m1 > psi && rd32(src + m1 - 1) == rd32(src + ip1)) { ip0 = ip1; match = m1 - 1; }
       else { size_t st = ((ip0 - anchor) >> 7) + step0; ip0 += st; ip1 += st; continue; }
       o2 = o1; o1 = (u32)(ip0 - match); offVal = o1 + 3; ml = 4;
-      while (ip0 > anchor && match > 0 && src[ip0 - 1] == src[match - 1]) { ip0--; match--; ml++; }
+      while (ip0 > anchor && match > psi - 1 && src[ip0 - 1] == src[match - 1]) { ip0--; match--; ml++; }
     }
     ml += count_eq(src, ip0 + ml, match + ml, be);
     emit(c, src, anchor, ip0 - anchor, ml, offVal);
@@ -151,7 +159,8 @@ static size_t mf_dfast(cctx* c, const u8* src, size_t bs, size_t be, u32 rep[3])
   u32 hlog = c->cp.hashLog, clog = c->cp.chainLog, mls = c->cp.minMatch;
   u32 o1 = rep[0], o2 = rep[1], saved;
   size_t anchor = bs, ilimit = be >= 8 ? be - 8 : 0;   /* a 7-byte first block: iend-8 lies before the start, nothing is searched */
-  size_t ip = mf_prologue(bs, &o1, &o2, &saved);
+  u32 psi = lowest_at(c, (u32)be + 1);                 /* prefixLowestIndex, from the block's end */
+  size_t ip = mf_prologue(c, bs, psi - 1, &o1, &o2, &saved);
   while (ip < ilimit) {
     size_t top = ip, ml; u32 offVal;
     u32 hL = hash8(src + ip, hlog), hS = hashN(src + ip, clog, mls);
@@ -161,16 +170,16 @@ static size_t mf_dfast(cctx* c, const u8* src, size_t bs, size_t be, u32 rep[3])
       ml = count_eq(src, ip + 5, ip + 5 - o1, be) + 4; ip++; offVal = 1;
     } else {
       size_t m;
-      if (mL > 1 && rd64(src + mL - 1) == rd64(src + ip)) {
+      if (mL > psi && rd64(src + mL - 1) == rd64(src + ip)) {
         m = mL - 1; ml = count_eq(src, ip + 8, m + 8, be) + 8;
-      } else if (mS > 1 && rd32(src + mS - 1) == rd32(src + ip)) {
+      } else if (mS > psi && rd32(src + mS - 1) == rd32(src + ip)) {
         u32 h3 = hash8(src + ip + 1, hlog), m3 = HL[h3];
         HL[h3] = curr + 1;
-        if (m3 > 1 && rd64(src + m3 - 1) == rd64(src + ip + 1)) { m = m3 - 1; ip++; ml = count_eq(src, ip + 8, m + 8, be) + 8; }
+        if (m3 > psi && rd64(src + m3 - 1) == rd64(src + ip + 1)) { m = m3 - 1; ip++; ml = count_eq(src, ip + 8, m + 8, be) + 8; }
         else { m = mS - 1; ml = count_eq(src, ip + 4, m + 4, be) + 4; }
       } else { ip += ((ip - anchor) >> 8) + 1; continue; }
       u32 off = (u32)(ip - m);
-      while (ip > anchor && m > 0 && src[ip - 1] == src[m - 1]) { ip--; m--; ml++; }
+      while (ip > anchor && m > psi - 1 && src[ip - 1] == src[m - 1]) { ip--; m--; ml++; }
       o2 = o1; o1 = off; offVal = off + 3;
     }
     emit(c, src, anchor, ip - anchor, ml, offVal);
@@ -209,10 +218,11 @@ static size_t hc_search(cctx* c, const u8* src, size_t ip, size_t be, u32* offCo
   c->nextToUpdate = target;
   u32 mi = c->hashTable[hashN(src + ip, hlog, mls)];
   u32 curr = target, minChain = curr > chainSize ? curr - chainSize : 0;
+  u32 lowLimit = lowest_at(c, curr);
   int attempts = 1 << c->cp.searchLog;
   size_t ml = 3;
   *offCode = 999999999u;
-  for (; mi >= 1 && attempts > 0; attempts--) {
+  for (; mi >= lowLimit && attempts > 0; attempts--) {
     size_t m = mi - 1, cur = 0;
     if (src[m + ml] == src[ip + ml]) cur = count_eq(src, ip, m, be);
     if (cur > ml) { ml = cur; *offCode = curr - mi + 2; if (ip + cur == be) break; }
@@ -236,7 +246,7 @@ static void bt_insert1(cctx* c, const u8* src, u32 curr, size_t iend, u32 nbComp
   u32* largerPtr = smallerPtr + 1;
   u32 matchIndex = *smallerPtr;
   u32 dummy32;
-  u32 windowLow = 1;                                   /* window.lowLimit; the frame never exceeds the window here */
+  u32 windowLow = lowest_at(c, curr);
   while (nbCompares-- && matchIndex > windowLow) {
     u32* nextPtr = bt + 2 * (matchIndex & btMask);
     size_t ml = commonSmaller < commonLarger ? commonSmaller : commonLarger;
@@ -270,7 +280,7 @@ static size_t bt_search(cctx* c, const u8* src, size_t ip, size_t be, u32* offCo
   c->nextToUpdate = curr;
   u32 h = hashN(src + ip, hlog, mls);
   u32 matchIndex = c->hashTable[h];
-  u32 windowLow = 1;
+  u32 windowLow = lowest_at(c, curr);
   u32 btLow = btMask >= curr ? 0 : curr - btMask;
   u32 unsortLimit = btLow > windowLow ? btLow : windowLow;
   u32* nextCandidate = bt + 2 * (matchIndex & btMask);
@@ -327,7 +337,7 @@ static size_t lazy_search(cctx* c, const u8* src, size_t ip, size_t be, u32* off
 static size_t mf_lazy(cctx* c, const u8* src, size_t bs, size_t be, u32 rep[3], int depth) {
   u32 o1 = rep[0], o2 = rep[1], saved;
   size_t anchor = bs, ilimit = be >= 8 ? be - 8 : 0;   /* a 7-byte first block: iend-8 lies before the start, nothing is searched */
-  size_t ip = mf_prologue(bs, &o1, &o2, &saved);
+  size_t ip = mf_prologue(c, bs, 0, &o1, &o2, &saved);
   while (ip < ilimit) {
     size_t ml = 0, start = ip + 1; u32 off = 0; int stored = 0;
     if (o1 > 0 && rd32(src + ip + 1 - o1) == rd32(src + ip + 1)) {
@@ -844,7 +854,7 @@ static u32 opt_get_all_matches(cctx* c, zo_match* matches, u32* nextToUpdate3, c
   size_t commonSmaller = 0, commonLarger = 0;
   u32 dictLimit = 1 + c->idxShift;
   u32 btLow = btMask >= curr ? 0 : curr - btMask;
-  u32 windowLow = dictLimit, matchLow = windowLow ? windowLow : 1;
+  u32 windowLow = lowest_at(c, curr), matchLow = windowLow ? windowLow : 1;
   u32* smallerPtr = bt + 2 * (curr & btMask); u32* largerPtr = smallerPtr + 1;
   u32 matchEndIdx = curr + 8 + 1, dummy32, mnum = 0;
   u32 nbCompares = 1u << c->cp.searchLog;
