@@ -190,3 +190,14 @@ def random_lz_input_far(rng, n):
         else:
             out += bytes(rng.randint(0, 256, size=int(rng.choice([1, 10, 300, 5000]))).astype(np.uint8).tolist())
     return bytes(out[:n])
+
+
+def far_repeat_input(rng, total, rep_len, dist):
+    """compressible block R, `dist - rep_len` bytes of noise, R again, then more LZ data with pieces of R: repeats that lie just inside
+    or just outside a window of `dist` bytes (frames larger than the level's window)"""
+    R = random_lz_input(rng, rep_len)
+    mid = bytes(rng.randint(0, 256, size=dist - rep_len, dtype=np.uint8)) if dist > rep_len else b""
+    d = R + mid + R
+    while len(d) < total:
+        d += random_lz_input(rng, 50000) + R[:30000]
+    return d[:total]

@@ -123,6 +123,23 @@ def test_randomised_differential_compress(zra, seed):
         assert zra.DecompressBuffer(arc) == d, (seed, case, n, fs, level)
 
 
+@pytest.mark.parametrize("level,win", [(1, 19), (-2, 19), (2, 20), (3, 21), (4, 21), (5, 21), (9, 21), (11, 22), (13, 22), (16, 22)])
+def test_frames_larger_than_the_window(zra, level, win):
+    """A frame longer than 2^windowLog (level 1: 512 KiB ... level 10+: 4 MiB): the serial finders apply zstd's sliding-window rule
+    (matches only inside the last 2^windowLog bytes). Repeats just inside and just outside the window; archive == oracle, which is
+    pinned against libzstd on the same construction (tests/test_oracle.py)."""
+    rng = np.random.RandomState(500 + level)
+    W = 1 << win
+    for dist in ((W - 1000, W + 1) if level < 16 else (W + 1,)):
+        n = dist + 400000
+        d = C.far_repeat_input(rng, n + 70000, 200000, dist)
+        st, ref = O.zra_compress(d, level, n, True)           # one oversized frame + a short one
+        assert st == (0, 0)
+        arc = zra.CompressBuffer(d, level, n, True)
+        assert arc == ref, (level, dist - W)
+        assert zra.DecompressBuffer(arc) == d
+
+
 @pytest.mark.parametrize("seed", [1297, 1298, 100, 101])
 def test_randomised_differential_compress_far_offsets(zra, seed, monkeypatch):
     """The same differential test on the second generator (far offsets, long zero runs, periodic data). Seed 1297 (found by the soak):
@@ -184,11 +201,7 @@ def test_compress_edge_cases(zra):
     d = C.gen_C(100000)
     st, ref = O.zra_compress(d, 3, 16384, True, 5)
     assert zra.CompressBuffer(d, 3, 16384, True, b"12345") == ref
-    # what the engine does not implement (a frame larger than the level's window) is refused with parameter_unsupported, never
-    # served by a CPU codec
-    with pytest.raises(zra.ZraError) as e:
-        zra.CompressBuffer(C.gen_C(700000), 1, 600000, True)
-    assert (e.value.zra, e.value.zstd) == (1, 40)
+    # (every level and frame size is implemented on the device; there is nothing left to refuse with parameter_unsupported)
     # output buffer too small is detected before any work (zra.cpp:196-198)
     L = zra.load()
     osz = ctypes.c_size_t(0)

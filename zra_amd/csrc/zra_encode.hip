@@ -92,15 +92,14 @@ const uint16_t kCPDef[23][7] = {{21,16,17,1,5,0,2},{19,13,14,1,7,0,1},{20,15,16,
   {22,22,22,5,5,48,7},{23,23,22,5,4,64,7},{23,23,22,6,3,64,8},{23,24,22,7,3,256,9},{25,25,23,7,3,256,9},{26,26,24,7,3,512,9},{27,27,25,9,3,999,9}};
 const uint16_t kCPNegDef[7] = {19, 12, 13, 1, 6, 1, 1};
 
-// returns false when (level, size) needs what this engine does not implement: a strategy beyond btlazy2 (the optimal parsers), or a frame
-// larger than the level's window (the sliding-window rules are not restated; level 1: 512 KiB, level 2: 1 MiB, 3-9: 2 MiB, 10-12: 4 MiB)
+// parameters of ZSTD_getCParams(level, S) for every level (-128..22); false only for S == 0
 bool get_params(int level, size_t S, ZraEncParams* p) {
   if (level == 0) level = 3;
   if (S == 0) return false;
   if (level > 22) level = 22;                                                       // ZSTD_maxCLevel
   const uint16_t* r = level < 0 ? (S <= (16u << 10) ? kCPNeg16 : S <= (128u << 10) ? kCPNeg128 : S <= (256u << 10) ? kCPNeg256 : kCPNegDef)
                                : (S <= (16u << 10) ? kCP16[level] : S <= (128u << 10) ? kCP128[level] : S <= (256u << 10) ? kCP256[level] : kCPDef[level]);
-  if (S > ((size_t)1 << r[0])) return false;
+  // (a frame larger than 2^windowLog is parsed by the serial finders with the sliding-window rules: compress_impl_body, serialAll)
   p->windowLog = r[0]; p->chainLog = r[1]; p->hashLog = r[2]; p->searchLog = r[3]; p->minMatch = r[4];
   p->targetLength = level < 0 ? (uint32_t)(-level) : r[5]; p->strategy = r[6];
   const uint32_t srcLog = S < 64 ? 6 : hbit((uint32_t)S - 1) + 1;
@@ -185,7 +184,7 @@ Status Engine::compress_impl_body(const uint8_t* dIn, size_t inSize, uint8_t* dB
   // gather of a sub-batch are released on stream B by hipStreamWaitValue32 on that counter — no per-batch launch tails in the
   // DRAM-bound match finder, and the entropy stage runs under it in small pieces.
   {
-    bool persist = maxBlocksPerFrame == 1 && full.strategy == 2 && !std::getenv("ZRA_MF_NOPERSIST");
+    bool persist = maxBlocksPerFrame == 1 && full.strategy == 2 && !std::getenv("ZRA_MF_NOPERSIST");   // (one block: the frame fits any window)
     if (persist && waitValueOk_ == 0) {
       // the pipeline needs stream memory operations on plain device memory; probe once (a wait that is already satisfied), and
       // use the batch path below on runtimes without them
@@ -280,15 +279,18 @@ Status Engine::compress_impl_body(const uint8_t* dIn, size_t inSize, uint8_t* dB
         a.mfFilter = shL | (shS << 4) | (dupLog << 8);
         const uint32_t hl = std::max(full.hashLog, tail.hashLog), cl = std::max(full.chainLog, tail.chainLog);
         const size_t filterBytes = (2u << dupLog) + (((size_t)1 << hl) >> shL) / 8 + (((size_t)1 << cl) >> shS) / 8 + 64;
-        const bool oddTail = hasTail && (tail.strategy == 2) != (full.strategy == 2);
-        if (full.strategy == 2) {
+        // frames larger than the level's window (0.5 - 4 MiB and more): the sliding-window rules live in the serial finders only
+        const bool serialAll = std::min<uint64_t>(frameSize, inSize) > (1ull << full.windowLog);
+        a.serialAll = serialAll ? 1u : 0u;
+        const bool oddTail = !serialAll && hasTail && (tail.strategy == 2) != (full.strategy == 2);
+        if (full.strategy == 2 && !serialAll) {
           hipLaunchKernelGGL(zra_mf_dfast_kernel, dim3(nb), dim3(64), filterBytes + dynLds, stream_, a, blk, 0xFFFFFFFFu, 0u);
           if (oddTail) hipLaunchKernelGGL(zra_mf_kernel, dim3(1), dim3(64), 0, stream_, a, blk, (uint32_t)(nb - 1), (uint32_t)(nb - 1), 1u);
         } else {
           // frames per wave: as many as it takes to have every frame of the batch resident at once (32 waves per CU)
           static const int pwEnv = std::getenv("ZRA_MF_PERWAVE") ? std::atoi(std::getenv("ZRA_MF_PERWAVE")) : 0;
           // hash-chain strategies (greedy / lazy / lazy2): one frame per wave, the wave-cooperative finder; fast gains 9.4 -> 14.5 from 8
-          const bool hashChain = full.strategy >= 3 && full.strategy <= 5;
+          const bool hashChain = full.strategy >= 3 && full.strategy <= 5 && !serialAll;
           uint32_t perWave = pwEnv > 0 ? (uint32_t)pwEnv : hashChain ? 1u
                            : std::min<uint32_t>(8u, std::max<uint32_t>(1u, (nb + (uint32_t)numCUs_ * 32 - 1) / ((uint32_t)numCUs_ * 32)));
           if (hashChain && pwEnv <= 0) hipLaunchKernelGGL(zra_mf_hc_kernel, dim3(nb), dim3(64), dynLds, stream_, a, blk);

@@ -54,8 +54,16 @@ struct Emit {
   __device__ __forceinline__ void put(u32 ll, u32 ml, u32 offVal) { seqs[n++] = (u64)ll | ((u64)ml << 20) | ((u64)offVal << 40); }
 };
 
-__device__ __forceinline__ u32 mf_prologue(u32 bs, u32& o1, u32& o2, u32& saved) {
-  u32 ip = bs + (bs == 0), maxRep = ip;
+// ZSTD_getLowestMatchIndex / ZSTD_getLowestPrefixIndex without a dictionary: the lowest index a match may have when the position with
+// index `curr` is searched — the frame's first index, or curr - 2^windowLog once the frame is longer than the window (serial finders
+// only: the wave-cooperative kernels are given frames that fit their window)
+__device__ __forceinline__ u32 lowest_at(u32 curr, u32 windowLog, u32 idxShift = 0) {
+  const u32 maxDist = 1u << windowLog, lowValid = 1 + idxShift;
+  return (curr - lowValid > maxDist) ? curr - maxDist : lowValid;
+}
+__device__ __forceinline__ u32 mf_prologue(u32 bs, u32& o1, u32& o2, u32& saved, u32 windowLog = 31, u32 prefixStartPos = 0) {
+  u32 ip = bs + (bs == prefixStartPos);
+  const u32 maxRep = (ip + 1) - lowest_at(ip + 1, windowLog);
   saved = 0;
   if (o2 > maxRep) { saved = o2; o2 = 0; }
   if (o1 > maxRep) { saved = o1; o1 = 0; }
@@ -69,7 +77,8 @@ __device__ u32 mf_fast(const ZraEncParams& P, u32* T, const u8* src, u32 bs, u32
   u32 o1 = rep[0], o2 = rep[1], saved;
   u32 anchor = bs;
   const u32 ilimit = be >= 8 ? be - 8 : 0;            // a 7-byte first block: iend-8 lies before the start, nothing is searched
-  u32 ip0 = mf_prologue(bs, o1, o2, saved), ip1 = ip0 + 1;
+  const u32 psi = lowest_at(be + 1, P.windowLog);    // prefixStartIndex, from the block's end
+  u32 ip0 = mf_prologue(bs, o1, o2, saved, P.windowLog, psi - 1), ip1 = ip0 + 1;
   while (ip1 < ilimit) {
     const u32 ip2 = ip0 + 2, top = ip0;
     const u32 h0 = hashN(src + ip0, hlog, mls), h1 = hashN(src + ip1, hlog, mls);
@@ -80,11 +89,11 @@ __device__ u32 mf_fast(const ZraEncParams& P, u32* T, const u8* src, u32 bs, u32
       const u32 back = src[ip2 - 1] == src[ip2 - o1 - 1];
       ip0 = ip2 - back; match = ip2 - o1 - back; ml = 4 + back; offVal = 1;
     } else {
-      if (m0 > 1 && ld32(src + m0 - 1) == ld32(src + ip0)) match = m0 - 1;
-      else if (m1 > 1 && ld32(src + m1 - 1) == ld32(src + ip1)) { ip0 = ip1; match = m1 - 1; }
+      if (m0 > psi && ld32(src + m0 - 1) == ld32(src + ip0)) match = m0 - 1;
+      else if (m1 > psi && ld32(src + m1 - 1) == ld32(src + ip1)) { ip0 = ip1; match = m1 - 1; }
       else { const u32 st = ((ip0 - anchor) >> 7) + step0; ip0 += st; ip1 += st; continue; }
       o2 = o1; o1 = ip0 - match; offVal = o1 + 3; ml = 4;
-      while (ip0 > anchor && match > 0 && src[ip0 - 1] == src[match - 1]) { ip0--; match--; ml++; }
+      while (ip0 > anchor && match > psi - 1 && src[ip0 - 1] == src[match - 1]) { ip0--; match--; ml++; }
     }
     ml += count_eq(src, ip0 + ml, match + ml, be);
     E.put(ip0 - anchor, ml, offVal);
@@ -108,10 +117,64 @@ __device__ u32 mf_fast(const ZraEncParams& P, u32* T, const u8* src, u32 bs, u32
   return be - anchor;
 }
 
+
+// ---- A.4.3 "dfast", serial (oracle/zo_encode.c: mf_dfast). The window-resolve kernel below is the fast path; this one serves frames
+// larger than the level's window, which that kernel is never given.
+__device__ u32 mf_dfast_serial(const ZraEncParams& P, u32* HL, u32* HS, const u8* src, u32 bs, u32 be, u32* rep, Emit& E) {
+  const u32 hlog = P.hashLog, clog = P.chainLog, mls = P.minMatch;
+  u32 o1 = rep[0], o2 = rep[1], saved;
+  u32 anchor = bs;
+  const u32 ilimit = be >= 8 ? be - 8 : 0;
+  const u32 psi = lowest_at(be + 1, P.windowLog);    // prefixLowestIndex, from the block's end
+  u32 ip = mf_prologue(bs, o1, o2, saved, P.windowLog, psi - 1);
+  while (ip < ilimit) {
+    const u32 top = ip; u32 ml, offVal;
+    const u32 hL = hash8(src + ip, hlog), hS = hashN(src + ip, clog, mls);
+    const u32 curr = ip + 1, mL = HL[hL], mS = HS[hS];
+    HL[hL] = curr; HS[hS] = curr;
+    if (o1 > 0 && ld32(src + ip + 1 - o1) == ld32(src + ip + 1)) {
+      ml = count_eq(src, ip + 5, ip + 5 - o1, be) + 4; ip++; offVal = 1;
+    } else {
+      u32 m;
+      if (mL > psi && ld64(src + mL - 1) == ld64(src + ip)) {
+        m = mL - 1; ml = count_eq(src, ip + 8, m + 8, be) + 8;
+      } else if (mS > psi && ld32(src + mS - 1) == ld32(src + ip)) {
+        const u32 h3 = hash8(src + ip + 1, hlog), m3 = HL[h3];
+        HL[h3] = curr + 1;
+        if (m3 > psi && ld64(src + m3 - 1) == ld64(src + ip + 1)) { m = m3 - 1; ip++; ml = count_eq(src, ip + 8, m + 8, be) + 8; }
+        else { m = mS - 1; ml = count_eq(src, ip + 4, m + 4, be) + 4; }
+      } else { ip += ((ip - anchor) >> 8) + 1; continue; }
+      const u32 off = ip - m;
+      while (ip > anchor && m > psi - 1 && src[ip - 1] == src[m - 1]) { ip--; m--; ml++; }
+      o2 = o1; o1 = off; offVal = off + 3;
+    }
+    E.put(ip - anchor, ml, offVal);
+    ip += ml; anchor = ip;
+    if (ip <= ilimit) {
+      const u32 q = top + 2;
+      HL[hash8(src + q, hlog)] = q + 1;
+      HL[hash8(src + ip - 2, hlog)] = ip - 1;
+      HS[hashN(src + q, clog, mls)] = q + 1;
+      HS[hashN(src + ip - 1, clog, mls)] = ip;
+      while (ip <= ilimit && o2 > 0 && ld32(src + ip) == ld32(src + ip - o2)) {
+        const u32 rl = count_eq(src, ip + 4, ip + 4 - o2, be) + 4;
+        const u32 t = o2; o2 = o1; o1 = t;
+        HS[hashN(src + ip, clog, mls)] = ip + 1;
+        HL[hash8(src + ip, hlog)] = ip + 1;
+        E.put(0, rl, 1);
+        ip += rl; anchor = ip;
+      }
+    }
+  }
+  rep[0] = o1 ? o1 : saved; rep[1] = o2 ? o2 : saved;
+  return be - anchor;
+}
+
 // ---- A.4.3 hash chain (greedy depth 0 / lazy 1 / lazy2 2) and, with `bt`, the binary tree with delayed updates of btlazy2
 // (ZSTD_updateDUBT / ZSTD_insertDUBT1 / ZSTD_DUBT_findBestMatch of zstd_lazy.c; oracle/zo_encode.c: bt_search). Serial: one lane.
 struct HC {
   u32* hashT; u32* chainT; u32 hlog, mls, cmask, chainSize, searchLog, nextToUpdate;
+  u32 windowLog;
   bool bt;
   __device__ u32 search(const u8* src, u32 ip, u32 be, u32& offCode) {
     if (bt) return bt_search(src, ip, be, offCode);
@@ -124,10 +187,11 @@ struct HC {
     nextToUpdate = target;
     u32 mi = hashT[hashN(src + ip, hlog, mls)];
     const u32 curr = target, minChain = curr > chainSize ? curr - chainSize : 0;
+    const u32 lowLimit = lowest_at(curr, windowLog);
     int attempts = 1 << searchLog;
     u32 ml = 3;
     offCode = 999999999u;
-    for (; mi >= 1 && attempts > 0; attempts--) {
+    for (; mi >= lowLimit && attempts > 0; attempts--) {
       const u32 m = mi - 1;
       u32 cur = 0;
       if (src[m + ml] == src[ip + ml]) cur = count_eq(src, ip, m, be);
@@ -147,7 +211,8 @@ struct HC {
     u32* largerPtr = smallerPtr + 1;
     u32 matchIndex = *smallerPtr;
     u32 dummy32;
-    while (nbCompares-- && matchIndex > 1u) {
+    const u32 windowLow = lowest_at(curr, windowLog);
+    while (nbCompares-- && matchIndex > windowLow) {
       u32* const nextPtr = chainT + 2 * (matchIndex & btMask);
       u32 ml = min(commonSmaller, commonLarger);
       const u32 m = matchIndex - 1;
@@ -180,7 +245,8 @@ struct HC {
     const u32 h = hashN(src + ip, hlog, mls);
     u32 matchIndex = hashT[h];
     const u32 btLow = btMask >= curr ? 0 : curr - btMask;
-    const u32 unsortLimit = max(btLow, 1u);
+    const u32 windowLow = lowest_at(curr, windowLog);
+    const u32 unsortLimit = max(btLow, windowLow);
     u32* nextCandidate = chainT + 2 * (matchIndex & btMask);
     u32* unsortedMark = nextCandidate + 1;
     u32 nbCompares = 1u << searchLog, nbCandidates = nbCompares, previousCandidate = 0;
@@ -206,7 +272,7 @@ struct HC {
     u32 matchEndIdx = curr + 8 + 1, dummy32;
     matchIndex = hashT[h];
     hashT[h] = curr;
-    while (nbCompares-- && matchIndex > 1u) {
+    while (nbCompares-- && matchIndex > windowLow) {
       u32* const nextPtr = chainT + 2 * (matchIndex & btMask);
       u32 ml = min(commonSmaller, commonLarger);
       const u32 m = matchIndex - 1;
@@ -238,7 +304,7 @@ __device__ u32 mf_lazy(HC& H, const u8* src, u32 bs, u32 be, u32* rep, Emit& E, 
   u32 o1 = rep[0], o2 = rep[1], saved;
   u32 anchor = bs;
   const u32 ilimit = be >= 8 ? be - 8 : 0;            // a 7-byte first block: iend-8 lies before the start, nothing is searched
-  u32 ip = mf_prologue(bs, o1, o2, saved);
+  u32 ip = mf_prologue(bs, o1, o2, saved, H.windowLog, 0);
   while (ip < ilimit) {
     u32 ml = 0, start = ip + 1, off = 0; bool stored = false;
     if (o1 > 0 && ld32(src + ip + 1 - o1) == ld32(src + ip + 1)) {
@@ -907,7 +973,7 @@ __device__ void mf_serial_block(const MfFrame& F, u32 ntu0) {
     // btopt / btultra / btultra2 (zra_encode_opt.h); the limited update above is redone with the window shift of btultra2
     OptCtx O;
     O.hashT = hashT; O.bt = chainT; O.hashLog = P.hashLog; O.chainLog = P.chainLog; O.searchLog = P.searchLog;
-    O.minMatchParam = P.minMatch; O.targetLength = P.targetLength; O.lvl = P.strategy == 7 ? 0 : 2;
+    O.minMatchParam = P.minMatch; O.targetLength = P.targetLength; O.lvl = P.strategy == 7 ? 0 : 2; O.windowLog = P.windowLog;
     O.hashLog3 = P.minMatch == 3 ? min(17u, P.windowLog) : 0;
     O.hash3 = chainT + ((size_t)1 << P.chainLog);
     O.o = (ZraOptState*)(O.hash3 + (O.hashLog3 ? (size_t)1 << O.hashLog3 : 0));
@@ -927,9 +993,11 @@ __device__ void mf_serial_block(const MfFrame& F, u32 ntu0) {
     ntu = O.nextToUpdate;
     st->idxShift = O.idxShift;
   } else if (P.strategy == 1) lastLL = mf_fast(P, hashT, src, bs, be, rep, E);
+  else if (P.strategy == 2) lastLL = mf_dfast_serial(P, hashT, chainT, src, bs, be, rep, E);
   else {
     HC H; H.hashT = hashT; H.chainT = chainT; H.hlog = P.hashLog; H.mls = P.minMatch < 4 ? 4 : P.minMatch > 6 ? 6 : P.minMatch;
     H.chainSize = 1u << P.chainLog; H.cmask = H.chainSize - 1; H.searchLog = P.searchLog; H.nextToUpdate = ntu;
+    H.windowLog = P.windowLog;
     H.bt = P.strategy == 6;
     lastLL = mf_lazy(H, src, bs, be, rep, E, P.strategy == 6 ? 2 : (int)P.strategy - 3);
     ntu = H.nextToUpdate;
@@ -1028,10 +1096,10 @@ zra_mf_kernel(ZraEncArgs a, u32 block, u32 only, u32 onlySlot, u32 perWave) {
     if (f >= a.nFrames) break;
     MfFrame G;
     const bool go = mf_frame_setup(a, block, lane, G, f, all ? f : onlySlot);
-    if ((u32)lane == k || perWave == 1) { F = G; mine = go && G.P->strategy != 2; }      // dfast frames belong to zra_mf_dfast_kernel
+    if ((u32)lane == k || perWave == 1) { F = G; mine = go && (G.P->strategy != 2 || a.serialAll); }   // dfast frames belong to zra_mf_dfast_kernel
   }
   // one frame per wave and a hash-chain strategy: the whole wave works on it
-  const bool coop = perWave == 1 && mine && F.P->strategy >= 3 && F.P->strategy <= 5;
+  const bool coop = perWave == 1 && mine && F.P->strategy >= 3 && F.P->strategy <= 5 && !a.serialAll;
   if (!mine || (!coop && lane != 0 && perWave == 1)) return;
   const ZraEncParams& P = *F.P;
   const u8* src = F.src; ZraEncFrameState* st = F.st; ZraEncBlockOut* bo = F.bo;

@@ -18,7 +18,7 @@ struct OptCtx {
   ZraOptState* o;
   u32* hashT; u32* bt; u32* hash3;
   u32 hashLog, chainLog, searchLog, minMatchParam, targetLength, hashLog3;
-  u32 idxShift, nextToUpdate;
+  u32 idxShift, nextToUpdate, windowLog;
   int lvl;
 
   __device__ static u32 ll_code(u32 v) { return v > 63 ? hb32(v) + 19 : o_LLcode[v]; }
@@ -158,7 +158,7 @@ struct OptCtx {
     u32 commonSmaller = 0, commonLarger = 0;
     const u32 dictLimit = 1 + idxShift;
     const u32 btLow = btMask >= curr ? 0 : curr - btMask;
-    const u32 windowLow = dictLimit, matchLow = windowLow ? windowLow : 1;
+    const u32 windowLow = lowest_at(curr, windowLog, idxShift), matchLow = windowLow ? windowLow : 1;
     u32* smallerPtr = bt + 2 * (curr & btMask); u32* largerPtr = smallerPtr + 1;
     u32 matchEndIdx = curr + 8 + 1, dummy32, mnum = 0;
     u32 nbCompares = 1u << searchLog;

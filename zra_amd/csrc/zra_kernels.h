@@ -148,6 +148,7 @@ struct ZraEncArgs {
   uint32_t nFrames;        // frames in the batch
   uint32_t checksum;
   uint32_t mfFilter;       // dfast kernel LDS geometry: filterShiftLong | filterShiftShort<<4 | log2(dupSlots)<<8
+  uint32_t serialAll;      // frames larger than the level's window: every frame of the batch goes through the serial finders (zra_mf_kernel)
   ZraEncParams full, tail; // parameters of full-size frames / of the short last frame
   uint32_t* tables;        // nFrames * tableStride u32
   uint64_t tableStride;    // words per frame
