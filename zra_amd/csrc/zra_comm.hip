@@ -146,7 +146,6 @@ struct ZraHipShard {
 
 namespace {
 ZraStatus mk(int z, int zstd = 0) { return ZraStatus{(ZraStatusCode)z, (int)(int8_t)zstd}; }
-ZraStatus mk(Status s) { return ZraStatus{(ZraStatusCode)s.zra, s.zstd}; }
 uint64_t range_lo(uint64_t nFrames, int r, int world) { return (uint64_t)((unsigned __int128)nFrames * (unsigned)r / (unsigned)world); }
 }  // namespace
 
