@@ -624,8 +624,10 @@ zra_dec_parse_kernel(ZraDecodeArgs a) {
         parse_seq_header(S, sw + S.seqPos, bsize - S.seqPos);
         if (S.err) { S.lateErr = S.err; S.err = 0; S.nbSeq = 0; }
         if (S.alloc && S.nbSeq) {
-          const u64 at = atomicAdd((unsigned long long*)&a.counters[ZRA_DC_SEQCUR], (unsigned long long)S.nbSeq);
-          if (at + S.nbSeq > a.seqCap) S.alloc = 0;
+          // whole 32-byte sectors per frame: the chain kernel writes its sequences four at a time
+          const u64 take = ((u64)S.nbSeq + 3) & ~3ull;
+          const u64 at = atomicAdd((unsigned long long*)&a.counters[ZRA_DC_SEQCUR], (unsigned long long)take);
+          if (at + take > a.seqCap) S.alloc = 0;
           S.seqBase = at;
         }
       }
@@ -926,6 +928,8 @@ zra_dec_chain_kernel(ZraDecodeArgs a) {
   u32 sLL = 0, sOF = 0, sML = 0, rep0 = 1, rep1 = 4, rep2 = 8;
   u32 i = 0, nbSeq = 0, outPos = 0, litPos = 0, outCap = 0, regen = 0, produced0 = 0, limit = 0;
   u32 longMode = 0, err = 0, jErr = 0xFFFFFFFFu, valid = 0, validOut = 0, validLit = 0, truncated = 0;
+  // decoded sequences leave four at a time (one full 32-byte sector: a lone 8-byte store is a read-modify-write at the memory side)
+  u64 q0 = 0, q1 = 0, q2 = 0;
   // the table cells of the sequence about to be decoded: requested one step ahead, together with the container reload
   uint2 eL = make_uint2(0, 0), eM = make_uint2(0, 0); u32 eO = 0;
   bool wide = false; const u8* pad = nullptr;
@@ -934,6 +938,11 @@ zra_dec_chain_kernel(ZraDecodeArgs a) {
   };
 
   auto finish = [&]() {
+    // the last one to three sequences still sit in registers
+    { const u32 r = valid & 3u, b = valid - r;
+      if (r >= 1) sq[b] = q0;
+      if (r >= 2) sq[b + 1] = q1;
+      if (r >= 3) sq[b + 2] = q2; }
     // tail literals of the block (ZSTD_decompressSequences: "last literal segment")
     if (!err && !truncated) {
       if (regen - litPos > outCap - outPos) err = ZE_DSTSIZE_TOOSMALL;
@@ -1039,7 +1048,10 @@ zra_dec_chain_kernel(ZraDecodeArgs a) {
           else if (off > produced0 + outPos + ll) e = ZE_CORRUPTION;
           if (e) { jErr = i; err = e; if (!longMode) finish(); }
           else {
-            sq[i] = (u64)ll | ((u64)ml << 18) | ((u64)min(off, 0x0FFFFFFFu) << 36);
+            const u64 qv = (u64)ll | ((u64)ml << 18) | ((u64)min(off, 0x0FFFFFFFu) << 36);
+            const u32 slot = i & 3u;
+            if (slot == 0) q0 = qv; else if (slot == 1) q1 = qv; else if (slot == 2) q2 = qv;
+            else { uint4* d4 = (uint4*)(sq + (i - 3)); d4[0] = make_uint4((u32)q0, (u32)(q0 >> 32), (u32)q1, (u32)(q1 >> 32)); d4[1] = make_uint4((u32)q2, (u32)(q2 >> 32), (u32)qv, (u32)(qv >> 32)); }
             outPos += ll + ml; litPos += ll;
             valid = i + 1; validOut = outPos; validLit = litPos;
             if (produced0 + outPos >= limit) { truncated = 1; finish(); }     // random access: stop at the sequence that covers the last needed byte
