@@ -837,7 +837,25 @@ zra_dec_huf_kernel(ZraDecodeArgs a) {
         if (!bad) {
           u32 i = 0;
           if (mb < 12) {
-            for (; i + 4 <= myLen; i += 4) {        // 4 symbols per window reload (4*11 = 44 <= 56 guaranteed bits)
+            // 16 symbols per store (a 4-byte store into a fresh sector is a read-modify-write at the memory side), 4 symbols per
+            // window reload (4*11 = 44 <= 56 guaranteed bits)
+            for (; i + 16 <= myLen; i += 16) {
+              u32 pk[4];
+#pragma unroll
+              for (int g = 0; g < 4; g++) {
+                hb.ensure(4 * mb);
+                u32 packed = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                  u32 e = tab[hb.peek(mb)];
+                  packed |= (e & 0xFF) << (8 * k);
+                  hb.skip((int)(e >> 8));
+                }
+                pk[g] = packed;
+              }
+              st128(o + i, pk[0], pk[1], pk[2], pk[3]);
+            }
+            for (; i + 4 <= myLen; i += 4) {
               hb.ensure(4 * mb);
               u32 packed = 0;
 #pragma unroll

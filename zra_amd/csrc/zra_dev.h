@@ -41,6 +41,8 @@ __device__ __forceinline__ u64 ld64_safe(const u8* p, const u8* end) {
 }
 __device__ __forceinline__ void st32(u8* p, u32 v) { *(u32_u*)p = v; }
 __device__ __forceinline__ void st64(u8* p, u64 v) { *(u64_u*)p = v; }
+struct __attribute__((packed, aligned(1))) u128_u { u32 a, b, c, d; };
+__device__ __forceinline__ void st128(u8* p, u32 a, u32 b, u32 c, u32 d) { u128_u v; v.a = a; v.b = b; v.c = c; v.d = d; *(u128_u*)p = v; }
 
 // wave-level inclusive prefix sum of a u32 (64 lanes), DPP-free portable shuffle form
 __device__ __forceinline__ u32 wave_incl_scan(u32 v) {
