@@ -46,6 +46,18 @@ int main() {
   float ms[4]; for (int i = 0; i < 4; i++) hipEventElapsedTime(&ms[i], e[i], e[i + 1]);
   std::printf("rates: random 4 B reads %.1f G/s, random 4 B writes %.1f G/s, stream read %.0f GB/s, stream write %.0f GB/s\n",
               (double)blocks * threads * rounds / ms[0] / 1e6, (double)blocks * threads * rounds / ms[1] / 1e6, bytes / ms[2] / 1e6, bytes / ms[3] / 1e6);
+  // the same random patterns inside regions that fit the 256 MiB Infinity Cache / one XCD's 4 MiB L2
+  for (uint64_t region : {128ull << 20, 2ull << 20}) {
+    hipEventRecord(e[0], 0);
+    hipLaunchKernelGGL(calib_gather4, dim3(blocks), dim3(threads), 0, 0, (const uint32_t*)b, region / 4, (uint32_t*)o, rounds);
+    hipEventRecord(e[1], 0);
+    hipLaunchKernelGGL(calib_scatter4, dim3(blocks), dim3(threads), 0, 0, (uint32_t*)b, region / 4, rounds);
+    hipEventRecord(e[2], 0);
+    hipDeviceSynchronize();
+    float m0, m1; hipEventElapsedTime(&m0, e[0], e[1]); hipEventElapsedTime(&m1, e[1], e[2]);
+    std::printf("region %4llu MiB: random 4 B reads %.1f G/s, random 4 B writes %.1f G/s\n", (unsigned long long)(region >> 20),
+                (double)blocks * threads * rounds / m0 / 1e6, (double)blocks * threads * rounds / m1 / 1e6);
+  }
   std::printf("calib_gather4: %llu lane requests of 4 B (%.3f GB useful)\n", (unsigned long long)nreq, nreq * 4 / 1e9);
   std::printf("calib_scatter4: %llu lane stores of 4 B (%.3f GB useful)\n", (unsigned long long)nreq, nreq * 4 / 1e9);
   std::printf("calib_stream8 / calib_streamwrite8: %.3f GB each\n", bytes / 1e9);
