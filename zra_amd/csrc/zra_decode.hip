@@ -624,7 +624,7 @@ zra_dec_parse_kernel(ZraDecodeArgs a) {
         parse_seq_header(S, sw + S.seqPos, bsize - S.seqPos);
         if (S.err) { S.lateErr = S.err; S.err = 0; S.nbSeq = 0; }
         if (S.alloc && S.nbSeq) {
-          // whole 32-byte sectors per frame: the chain kernel writes its sequences four at a time
+          // multiples of four entries per frame: the chain kernel writes its sequences four at a time (aligned 32 bytes)
           const u64 take = ((u64)S.nbSeq + 3) & ~3ull;
           const u64 at = atomicAdd((unsigned long long*)&a.counters[ZRA_DC_SEQCUR], (unsigned long long)take);
           if (at + take > a.seqCap) S.alloc = 0;
@@ -837,8 +837,7 @@ zra_dec_huf_kernel(ZraDecodeArgs a) {
         if (!bad) {
           u32 i = 0;
           if (mb < 12) {
-            // 16 symbols per store (a 4-byte store into a fresh sector is a read-modify-write at the memory side), 4 symbols per
-            // window reload (4*11 = 44 <= 56 guaranteed bits)
+            // 16 symbols per store (write requests are the expensive ones), 4 symbols per window reload (4*11 = 44 <= 56 guaranteed bits)
             for (; i + 16 <= myLen; i += 16) {
               u32 pk[4];
 #pragma unroll
@@ -946,7 +945,8 @@ zra_dec_chain_kernel(ZraDecodeArgs a) {
   u32 sLL = 0, sOF = 0, sML = 0, rep0 = 1, rep1 = 4, rep2 = 8;
   u32 i = 0, nbSeq = 0, outPos = 0, litPos = 0, outCap = 0, regen = 0, produced0 = 0, limit = 0;
   u32 longMode = 0, err = 0, jErr = 0xFFFFFFFFu, valid = 0, validOut = 0, validLit = 0, truncated = 0;
-  // decoded sequences leave four at a time (one full 32-byte sector: a lone 8-byte store is a read-modify-write at the memory side)
+  // decoded sequences leave four at a time: a random write costs the memory system about two random reads whatever its width, so 32 bytes
+  // per request instead of 8
   u64 q0 = 0, q1 = 0, q2 = 0;
   // the table cells of the sequence about to be decoded: requested one step ahead, together with the container reload
   uint2 eL = make_uint2(0, 0), eM = make_uint2(0, 0); u32 eO = 0;
