@@ -293,6 +293,15 @@ ZraStatus ZraHipCommCompress(ZraHipComm* c, const void* dLocal, size_t localByte
   if (zs.zra) { delete sh; return zs; }
   sh->bodyBase = sh->bodyBaseOf[c->rank]; sh->bodyBytes = bodyBytes; sh->bodyTotal = run;
   if (hipMemcpy(sh->dev.p, sh->header.data(), headerSize, hipMemcpyHostToDevice) != hipSuccess) { delete sh; return mk(ZStdError, 1); }
+  // the shard keeps what it holds, not the compress-bound sized work buffer (a third of it at ratio 3)
+  if (headerSize + bodyBytes + (64u << 20) < sh->dev.cap) {
+    DevBuf exact;
+    if (exact.reserve(headerSize + bodyBytes + 64) &&
+        hipMemcpy(exact.p, sh->dev.p, headerSize + bodyBytes, hipMemcpyDeviceToDevice) == hipSuccess) {
+      sh->dev.release();
+      sh->dev = exact;
+    } else exact.release();
+  }
   *shardOut = sh;
   return mk(Success);
 }
