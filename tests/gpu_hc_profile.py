@@ -21,3 +21,4 @@ print("L%d fs %d: %.2f GiB/s  ratio %.2f  stats %s" % (lvl, fs, gib / dt, n / as
 tot = v[0] + v[1] + v[2]
 print("blocks %d  ticks/block %.0f (100 MHz: %.2f ms)  insert %.1f %%  search %.1f %%  parse %.1f %%" % (nb, tot / nb, tot / nb / 1e5, 100 * v[0] / tot, 100 * v[1] / tot, 100 * v[2] / tot))
 print("windows/block %.0f  insert steps/block %.0f  bucket groups/insert step %.1f  seqs/block %.0f  positions/window %.1f" % (v[3] / nb, v[6] / nb, v[7] / max(v[6], 1), v[4] / nb, (n / nb) / max(v[3] / nb, 1)))
+print("chain steps/block: all lanes %.0f, lanes the parse asked %.0f (%.1f %%), searches asked/block %.0f, steps per asked search %.1f" % (v[8] / nb, v[9] / nb, 100.0 * v[9] / max(v[8], 1), v[10] / nb, v[9] / max(v[10], 1)))

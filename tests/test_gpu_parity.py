@@ -65,10 +65,13 @@ def test_persistent_pipeline_sub_batch_boundaries(zra, nframes, tail):
     assert zra.DecompressBuffer(arc) == d
 
 
-@pytest.mark.parametrize("level,fs,tail", [(4, 65536, 5000), (4, 65536, 16384), (4, 131072, 777), (3, 131072, 20000)])
+@pytest.mark.parametrize("level,fs,tail", [(4, 65536, 5000), (4, 65536, 16384), (4, 131072, 777), (3, 131072, 20000),
+                                           (9, 65536, 3000), (10, 65536, 17), (9, 262144, 16384), (6, 65536, 10000), (2, 262144, 10000), (12, 65536, 3000)])
 def test_short_last_frame_with_other_cparams(zra, gens, level, fs, tail):
     """The short last frame gets its own cparams (A.4.1) — at level 4 even another strategy (greedy below 16 KiB): the persistent
-    dfast launch leaves that frame to the generic kernel and the entropy stage waits for both."""
+    dfast launch leaves that frame to the generic kernel and the entropy stage waits for both. Levels 9-10: btlazy2 tail behind lazy2
+    frames (the hash-chain kernel holds its own finder only, the tail is a second launch); level 6: lazy2 tail behind lazy frames (same
+    kernel); level 2 @ 256 KiB: fast tail behind dfast frames; level 12: btopt tail behind btlazy2 frames (generic kernel, both)."""
     for name in ("C", "E", "L"):
         d = gens[name][: 3 * fs + tail]
         st, ref = O.zra_compress(d, level, fs, True)

@@ -718,6 +718,9 @@ struct HCW {
   u32 ntuRef;            // the reference's nextToUpdate
   u32 w;                 // window: answers for positions [w, w + 64) are in rml / roff of lane p - w
   u32 rml, roff;
+#ifdef ZRA_MF_PROFILE
+  u32 rsteps;            // chain steps this lane walked for the window
+#endif
   bool haveWin;
   // chain tables smaller than the frame (chainLog < windowLog): inserting index i overwrites the link of index i - chainSize. The
   // reference never follows that link once i is inserted (i - chainSize is below its minChain by then), but a window is inserted
@@ -786,6 +789,9 @@ __device__ void hcw_search_window(HCW& H, const u8* src, u32 w, u32 ilimit, u32 
   HPROF(0) HCNT(3, 1)
   const u32 p = w + (u32)lane;
   u32 ml = 3, offCode = 999999999u;
+#ifdef ZRA_MF_PROFILE
+  u32 steps_ = 0;
+#endif
   if (p <= lastPos) {
     const u32 curr = p + 1, minChain = curr > H.chainSize ? curr - H.chainSize : 0;
     int attempts = 1 << H.searchLog;
@@ -800,6 +806,9 @@ __device__ void hcw_search_window(HCW& H, const u8* src, u32 w, u32 ilimit, u32 
       const u32 nxt = (over > curr && over < H.insEnd) ? H.oldLink[over & 127u] : H.chainT[mi & H.cmask];
       const u32 m = mi - 1;
       u32 cur = 0;
+#ifdef ZRA_MF_PROFILE
+      steps_++;
+#endif
       if (wide) {
         const u64 d0 = ld64(src + m) ^ own0, d1 = ld64(src + m + 8) ^ own1;
         if (d0) cur = (u32)__builtin_ctzll(d0) >> 3;
@@ -813,6 +822,10 @@ __device__ void hcw_search_window(HCW& H, const u8* src, u32 w, u32 ilimit, u32 
     }
   }
   HPROF(1)
+#ifdef ZRA_MF_PROFILE
+  H.rsteps = steps_;
+  for (u32 l_ = 0; l_ < 64; l_++) H.pt[8] += bcast(steps_, l_);
+#endif
   H.w = w; H.rml = ml; H.roff = offCode; H.haveWin = true;
 }
 
@@ -830,6 +843,9 @@ __device__ u32 mf_lazy_wave(HCW& H, const u8* src, u32 bs, u32 be, u32* rep, u64
   auto search = [&](u32 q, u32& oc) -> u32 {
     if (!H.haveWin || q < H.w || q >= H.w + 64u) hcw_search_window(H, src, q, ilimit, be, lane);
     if (q + 1 > H.ntuRef) H.ntuRef = q + 1;
+#ifdef ZRA_MF_PROFILE
+    H.pt[9] += bcast(H.rsteps, q - H.w); H.pt[10] += 1;
+#endif
     oc = bcast(H.roff, q - H.w);
     return bcast(H.rml, q - H.w);
   };
@@ -957,7 +973,9 @@ __device__ __forceinline__ bool mf_frame_setup(const ZraEncArgs& a, u32 block, i
 }
 
 // One block of one frame parsed by ONE lane: fast, the serial hash chain (odd tails), btlazy2 and the optimal parsers.
-__device__ void mf_serial_block(const MfFrame& F, u32 ntu0) {
+// FAST_ONLY: the caller has checked strategy == 1; the other finders stay out of its kernel (and out of its register budget).
+template <bool FAST_ONLY>
+__device__ __forceinline__ void mf_serial_block_t(const MfFrame& F, u32 ntu0) {
   const ZraEncParams& P = *F.P;
   const u8* src = F.src; ZraEncFrameState* st = F.st; ZraEncBlockOut* bo = F.bo;
   u32* hashT = F.hashT; u32* chainT = F.chainT;
@@ -969,7 +987,8 @@ __device__ void mf_serial_block(const MfFrame& F, u32 ntu0) {
   // limited update after a very long match (A.4.3 hash chain prologue; harmless for the other finders)
   u32 ntu = ntu0;
   { const u32 cur = bs + 1; if (cur > ntu + 384) { const u32 d = cur - ntu - 384; ntu = cur - (d < 192 ? d : 192); } }
-  if (P.strategy >= 7) {
+  if constexpr (FAST_ONLY) lastLL = mf_fast(P, hashT, src, bs, be, rep, E);
+  else if (P.strategy >= 7) {
     // btopt / btultra / btultra2 (zra_encode_opt.h); the limited update above is redone with the window shift of btultra2
     OptCtx O;
     O.hashT = hashT; O.bt = chainT; O.hashLog = P.hashLog; O.chainLog = P.chainLog; O.searchLog = P.searchLog;
@@ -1006,6 +1025,7 @@ __device__ void mf_serial_block(const MfFrame& F, u32 ntu0) {
   bo->nbSeq = E.n; bo->lastLL = lastLL;
   bo->rep[0] = rep[0]; bo->rep[1] = rep[1]; bo->rep[2] = rep[2];   // confirmed by stage 2 only if the block is emitted compressed
 }
+__device__ void mf_serial_block(const MfFrame& F, u32 ntu0) { mf_serial_block_t<false>(F, ntu0); }
 
 // Match finder for strategy 2 (dfast, levels 3-4): one wave per frame, lean window-resolve parse. Launched when the batch's
 // full-size frames use dfast; a short last frame with another strategy is left to zra_mf_kernel (second launch, `only`).
@@ -1142,18 +1162,47 @@ zra_mf_kernel(ZraEncArgs a, u32 block, u32 only, u32 onlySlot, u32 perWave) {
   mf_serial_block(F, ntu0);
 }
 
+// Match finder for batches whose full-size frames use "fast" (levels 1-2 and all negative levels): lane = frame, `perWave` frames in
+// the first lanes of a wave (SIMT across frames: divergent, but the lanes' memory round trips overlap), the whole wave clears their
+// tables. Nothing but mf_fast lives here: in one kernel with the tree and optimal-parser code the register budget was 215 VGPRs and
+// 412 B of scratch, and level 1 ran at 9.2 instead of 14 GiB/s. A short last frame with other cparams: second launch by the host.
+extern "C" __global__ void __launch_bounds__(64)
+zra_mf_fast_kernel(ZraEncArgs a, u32 block, u32 perWave) {
+  const int lane = threadIdx.x;
+  MfFrame F; bool mine = false;
+  for (u32 k = 0; k < perWave; k++) {
+    const u32 f = blockIdx.x * perWave + k;
+    if (f >= a.nFrames) break;
+    {
+      const u64 fstart = (u64)(a.firstFrame + f) * a.frameSize;
+      const ZraEncParams& Pf = (a.inSize - fstart < a.frameSize) ? a.tail : a.full;
+      if (Pf.strategy != 1) continue;
+    }
+    MfFrame G;
+    const bool go = mf_frame_setup(a, block, lane, G, f, f);
+    if ((u32)lane == k) { F = G; mine = go; }
+  }
+  if (!mine) return;
+  mf_serial_block_t<true>(F, F.st->nextToUpdate);
+}
+
 // Match finder for batches whose full-size frames use a hash-chain strategy (greedy / lazy / lazy2): one wave per frame, the
-// wave-cooperative finder. A short last frame whose cparams select "fast" is parsed here by one lane; a dfast one is left to
-// zra_mf_dfast_kernel (second launch, `only`).
+// wave-cooperative finder and nothing else (37 VGPRs; with the serial finders in the same kernel it was 119 and half the waves).
+// A short last frame whose cparams select another strategy is left to a second single-frame launch by the host
+// (zra_mf_dfast_kernel or zra_mf_kernel with `only`).
 extern "C" __global__ void __launch_bounds__(64)
 zra_mf_hc_kernel(ZraEncArgs a, u32 block) {
   const int lane = threadIdx.x;
   const u32 f = blockIdx.x;
   if (f >= a.nFrames) return;
+  {
+    const u64 fstart = (u64)(a.firstFrame + f) * a.frameSize;
+    const ZraEncParams& Pf = (a.inSize - fstart < a.frameSize) ? a.tail : a.full;
+    if (Pf.strategy < 3 || Pf.strategy > 5) return;
+  }
   MfFrame F;
   if (!mf_frame_setup(a, block, lane, F, f, f)) return;
   const ZraEncParams& P = *F.P;
-  if (P.strategy == 2) return;
   ZraEncFrameState* st = F.st; ZraEncBlockOut* bo = F.bo;
   const u32 bs = F.bs, be = F.be;
   u32 rep[3] = {st->rep[0], st->rep[1], st->rep[2]};
@@ -1163,10 +1212,6 @@ zra_mf_hc_kernel(ZraEncArgs a, u32 block) {
   {
     const u32 cur = bs + 1;
     if (cur > ntu + 384) { const u32 d = cur - ntu - 384; ntu = cur - (d < 192 ? d : 192); }
-  }
-  if (P.strategy < 3 || P.strategy > 5) {             // a short last frame with other cparams (fast, btlazy2, an optimal parser): one lane
-    if (lane == 0) mf_serial_block(F, ntu0);
-    return;
   }
   __shared__ u32 hcOld[128];
   HCW H; H.oldLink = hcOld; H.hashT = F.hashT; H.chainT = F.chainT; H.hlog = P.hashLog; H.mls = P.minMatch < 4 ? 4 : P.minMatch > 6 ? 6 : P.minMatch;
