@@ -256,7 +256,7 @@ def main():
     del tbase
     nframes = N // fs
     bound = Z.GetOutputBufferSize(N, fs)
-    d_arc = torch.empty(bound + 64, dtype=torch.uint8, device=dev)
+    d_arc = torch.empty(bound + 64, dtype=torch.uint8, device=dev) if world == 1 else None    # N>1: the shard object holds the frames
     # RA workload: offsets uniform over the whole (all ranks') uncompressed range from a fixed seed; N>1: routed to the owners
     q = args.queries
     qb = args.query_bytes
