@@ -11,6 +11,7 @@
 #include <vector>
 
 extern "C" __global__ void zra_mf_kernel(ZraEncArgs a, uint32_t block, uint32_t only, uint32_t onlySlot, uint32_t perWave);
+extern "C" __global__ void zra_mf_opt_kernel(ZraEncArgs a, uint32_t block, uint32_t only, uint32_t onlySlot, uint32_t perWave);
 extern "C" __global__ void zra_mf_hc_kernel(ZraEncArgs a, uint32_t block);
 extern "C" __global__ void zra_mf_fast_kernel(ZraEncArgs a, uint32_t block, uint32_t perWave);
 extern "C" __global__ void zra_mf_dfast_kernel(ZraEncArgs a, uint32_t block, uint32_t only, uint32_t onlySlot);
@@ -160,6 +161,8 @@ Status Engine::compress_impl_body(const uint8_t* dIn, size_t inSize, uint8_t* dB
   if (tailSize) { if (!get_params(level, tailSize, &tail)) return zerr(40); }
   if (!(nFramesTotal > 1 || !tailSize)) full = tail;
   if (!tailSize) tail = full;
+  // the generic (one lane per frame) finder exists with and without the optimal parsers: only levels 13-22 pay for their registers
+  const auto mfGeneric = (full.strategy >= 7 || tail.strategy >= 7) ? zra_mf_opt_kernel : zra_mf_kernel;
 
   // per-frame table slot: hash table + chain table / tree; the optimal parsers add a 3-byte hash table and their state (ZraOptState)
   auto slotWords = [](const ZraEncParams& q) -> uint64_t {
@@ -286,7 +289,7 @@ Status Engine::compress_impl_body(const uint8_t* dIn, size_t inSize, uint8_t* dB
         const bool oddTail = !serialAll && hasTail && (tail.strategy == 2) != (full.strategy == 2);
         if (full.strategy == 2 && !serialAll) {
           hipLaunchKernelGGL(zra_mf_dfast_kernel, dim3(nb), dim3(64), filterBytes + dynLds, stream_, a, blk, 0xFFFFFFFFu, 0u);
-          if (oddTail) hipLaunchKernelGGL(zra_mf_kernel, dim3(1), dim3(64), 0, stream_, a, blk, (uint32_t)(nb - 1), (uint32_t)(nb - 1), 1u);
+          if (oddTail) hipLaunchKernelGGL(mfGeneric, dim3(1), dim3(64), 0, stream_, a, blk, (uint32_t)(nb - 1), (uint32_t)(nb - 1), 1u);
         } else {
           // frames per wave: as many as it takes to have every frame of the batch resident at once (32 waves per CU)
           static const int pwEnv = std::getenv("ZRA_MF_PERWAVE") ? std::atoi(std::getenv("ZRA_MF_PERWAVE")) : 0;
@@ -299,10 +302,10 @@ Status Engine::compress_impl_body(const uint8_t* dIn, size_t inSize, uint8_t* dB
           const bool lean = pwEnv <= 0 && (hashChain || full.strategy == 1);
           if (hashChain && pwEnv <= 0) hipLaunchKernelGGL(zra_mf_hc_kernel, dim3(nb), dim3(64), dynLds, stream_, a, blk);
           else if (lean) hipLaunchKernelGGL(zra_mf_fast_kernel, dim3((nb + perWave - 1) / perWave), dim3(64), dynLds, stream_, a, blk, perWave);
-          else hipLaunchKernelGGL(zra_mf_kernel, dim3((nb + perWave - 1) / perWave), dim3(64), dynLds, stream_, a, blk, 0xFFFFFFFFu, 0u, perWave);
+          else hipLaunchKernelGGL(mfGeneric, dim3((nb + perWave - 1) / perWave), dim3(64), dynLds, stream_, a, blk, 0xFFFFFFFFu, 0u, perWave);
           if (oddTail) hipLaunchKernelGGL(zra_mf_dfast_kernel, dim3(1), dim3(64), filterBytes, stream_, a, blk, (uint32_t)(nb - 1), (uint32_t)(nb - 1));
           else if (lean && hasTail && (hashChain ? (tail.strategy < 3 || tail.strategy > 5) : tail.strategy != 1))
-            hipLaunchKernelGGL(zra_mf_kernel, dim3(1), dim3(64), 0, stream_, a, blk, (uint32_t)(nb - 1), (uint32_t)(nb - 1), 1u);
+            hipLaunchKernelGGL(mfGeneric, dim3(1), dim3(64), 0, stream_, a, blk, (uint32_t)(nb - 1), (uint32_t)(nb - 1), 1u);
         }
       }
       HIPCHK(hipEventRecord(m1, stream_));
@@ -343,6 +346,7 @@ Status Engine::compress_persistent(const uint8_t* dIn, size_t inSize, uint8_t* d
                                    uint64_t tableWords, uint64_t seqStride, uint64_t litStride, uint64_t slotStride) {
   const uint64_t nFramesTotal = (inSize + frameSize - 1) / frameSize;
   const size_t tailSize = inSize % frameSize;
+  const auto mfGeneric = (full.strategy >= 7 || tail.strategy >= 7) ? zra_mf_opt_kernel : zra_mf_kernel;
   static const uint32_t wavesPerCU = std::getenv("ZRA_MF_WAVES") ? (uint32_t)std::atoi(std::getenv("ZRA_MF_WAVES")) : 16u;
   static const uint32_t SB = std::getenv("ZRA_ENC_SUB") ? (uint32_t)std::atoi(std::getenv("ZRA_ENC_SUB")) : 8192u;   // frames per sub-batch
   const uint32_t nSlots = (uint32_t)std::min<uint64_t>((uint64_t)numCUs_ * wavesPerCU, nFramesTotal);
@@ -425,7 +429,7 @@ Status Engine::compress_persistent(const uint8_t* dIn, size_t inSize, uint8_t* d
     hipEvent_t tailEv = nullptr;
     if (oddTail) {
       ZraEncArgs at = a; at.mfQueue = nullptr;
-      hipLaunchKernelGGL(zra_mf_kernel, dim3(1), dim3(64), 0, stream_, at, 0u, (uint32_t)(n - 1), 0u, 1u);
+      hipLaunchKernelGGL(mfGeneric, dim3(1), dim3(64), 0, stream_, at, 0u, (uint32_t)(n - 1), 0u, 1u);
       tailEv = ev(); if (!tailEv) return zerr(1);
       HIPCHK(hipEventRecord(tailEv, stream_));
     }

@@ -973,8 +973,9 @@ __device__ __forceinline__ bool mf_frame_setup(const ZraEncArgs& a, u32 block, i
 }
 
 // One block of one frame parsed by ONE lane: fast, the serial hash chain (odd tails), btlazy2 and the optimal parsers.
-// FAST_ONLY: the caller has checked strategy == 1; the other finders stay out of its kernel (and out of its register budget).
-template <bool FAST_ONLY>
+// MODE 1: the caller has checked strategy == 1; MODE 2: no frame with an optimal parser (strategy >= 7) comes here — the finders left
+// out stay out of the caller's kernel and out of its register budget (a kernel pays for everything it can call). MODE 0: all of them.
+template <int MODE>
 __device__ __forceinline__ void mf_serial_block_t(const MfFrame& F, u32 ntu0) {
   const ZraEncParams& P = *F.P;
   const u8* src = F.src; ZraEncFrameState* st = F.st; ZraEncBlockOut* bo = F.bo;
@@ -987,8 +988,8 @@ __device__ __forceinline__ void mf_serial_block_t(const MfFrame& F, u32 ntu0) {
   // limited update after a very long match (A.4.3 hash chain prologue; harmless for the other finders)
   u32 ntu = ntu0;
   { const u32 cur = bs + 1; if (cur > ntu + 384) { const u32 d = cur - ntu - 384; ntu = cur - (d < 192 ? d : 192); } }
-  if constexpr (FAST_ONLY) lastLL = mf_fast(P, hashT, src, bs, be, rep, E);
-  else if (P.strategy >= 7) {
+  if constexpr (MODE == 1) lastLL = mf_fast(P, hashT, src, bs, be, rep, E);
+  else if (MODE == 0 && P.strategy >= 7) {
     // btopt / btultra / btultra2 (zra_encode_opt.h); the limited update above is redone with the window shift of btultra2
     OptCtx O;
     O.hashT = hashT; O.bt = chainT; O.hashLog = P.hashLog; O.chainLog = P.chainLog; O.searchLog = P.searchLog;
@@ -1025,7 +1026,6 @@ __device__ __forceinline__ void mf_serial_block_t(const MfFrame& F, u32 ntu0) {
   bo->nbSeq = E.n; bo->lastLL = lastLL;
   bo->rep[0] = rep[0]; bo->rep[1] = rep[1]; bo->rep[2] = rep[2];   // confirmed by stage 2 only if the block is emitted compressed
 }
-__device__ void mf_serial_block(const MfFrame& F, u32 ntu0) { mf_serial_block_t<false>(F, ntu0); }
 
 // Match finder for strategy 2 (dfast, levels 3-4): one wave per frame, lean window-resolve parse. Launched when the batch's
 // full-size frames use dfast; a short last frame with another strategy is left to zra_mf_kernel (second launch, `only`).
@@ -1099,13 +1099,14 @@ zra_mf_dfast_kernel(ZraEncArgs a, u32 block, u32 only, u32 onlySlot) {
   }
 }
 
-// Match finder for the other strategies (fast, greedy, lazy, lazy2). The parse of a frame is one dependent pointer chase (hash head
+// Match finder for everything the lean kernels do not take (btlazy2, the optimal parsers, frames larger than the level's window, single
+// odd tails of any strategy). The parse of a frame is one dependent pointer chase (hash head
 // -> chain -> candidate bytes), so a frame gets ONE lane and throughput is frames in flight / frame latency: a wave carries `perWave`
 // frames in its first lanes (SIMT across frames: divergent, but the lanes' memory round trips overlap), and the whole wave clears
 // their tables. `only` = 0xFFFFFFFF: every frame of the batch; otherwise just that frame (the short last frame whose strategy differs
 // from the batch's), launched as one workgroup on table slot `onlySlot`.
-extern "C" __global__ void __launch_bounds__(64)
-zra_mf_kernel(ZraEncArgs a, u32 block, u32 only, u32 onlySlot, u32 perWave) {
+template <bool OPT>
+__device__ __forceinline__ void mf_generic(const ZraEncArgs& a, u32 block, u32 only, u32 onlySlot, u32 perWave, u32* hcOld) {
   const int lane = threadIdx.x;
   const bool all = only == 0xFFFFFFFFu;
   if (!all) perWave = 1;
@@ -1136,7 +1137,6 @@ zra_mf_kernel(ZraEncArgs a, u32 block, u32 only, u32 onlySlot, u32 perWave) {
     const u32 cur = bs + 1;
     if (cur > ntu + 384) { const u32 d = cur - ntu - 384; ntu = cur - (d < 192 ? d : 192); }
   }
-  __shared__ u32 hcOld[128];
   if (coop) {
     HCW H; H.oldLink = hcOld; H.hashT = hashT; H.chainT = chainT; H.hlog = P.hashLog; H.mls = P.minMatch < 4 ? 4 : P.minMatch > 6 ? 6 : P.minMatch;
     H.chainSize = 1u << P.chainLog; H.cmask = H.chainSize - 1; H.searchLog = P.searchLog;
@@ -1159,7 +1159,18 @@ zra_mf_kernel(ZraEncArgs a, u32 block, u32 only, u32 onlySlot, u32 perWave) {
     }
     return;
   }
-  mf_serial_block(F, ntu0);
+  mf_serial_block_t<OPT ? 0 : 2>(F, ntu0);
+}
+// the generic finder without / with the optimal parsers (215 VGPRs with them: batches and tails of levels 13-22 only)
+extern "C" __global__ void __launch_bounds__(64)
+zra_mf_kernel(ZraEncArgs a, u32 block, u32 only, u32 onlySlot, u32 perWave) {
+  __shared__ u32 hcOld[128];
+  mf_generic<false>(a, block, only, onlySlot, perWave, hcOld);
+}
+extern "C" __global__ void __launch_bounds__(64)
+zra_mf_opt_kernel(ZraEncArgs a, u32 block, u32 only, u32 onlySlot, u32 perWave) {
+  __shared__ u32 hcOld[128];
+  mf_generic<true>(a, block, only, onlySlot, perWave, hcOld);
 }
 
 // Match finder for batches whose full-size frames use "fast" (levels 1-2 and all negative levels): lane = frame, `perWave` frames in
@@ -1183,7 +1194,7 @@ zra_mf_fast_kernel(ZraEncArgs a, u32 block, u32 perWave) {
     if ((u32)lane == k) { F = G; mine = go; }
   }
   if (!mine) return;
-  mf_serial_block_t<true>(F, F.st->nextToUpdate);
+  mf_serial_block_t<1>(F, F.st->nextToUpdate);
 }
 
 // Match finder for batches whose full-size frames use a hash-chain strategy (greedy / lazy / lazy2): one wave per frame, the
