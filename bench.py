@@ -244,6 +244,12 @@ def main():
                 comm, transport = sharding.Comm.rccl(eng, rank, world), "rccl (direct)"
             except Exception as e:
                 sys.stderr.write("bench: direct RCCL communicator failed (%r); falling back to torch.distributed\n" % (e,))
+            # every rank takes the same transport: one rank without a communicator sends everybody to the fallback
+            flag = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device="cpu" if one_gpu else dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0 and comm is not None:
+                comm.close()
+                comm = None
         if comm is None:
             comm, transport = sharding.Comm.torch_dist(eng), "torch.distributed/" + dist.get_backend()
 
