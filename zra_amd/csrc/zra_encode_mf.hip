@@ -1,12 +1,17 @@
-// zra_amd — ENCODE stage 1 for gfx950: the match finder (sequence producer) of zstd 1.4.9, bit-exact.
+// zra_amd — ENCODE stage 1 for gfx950: the match finders (sequence producers) of zstd 1.4.9, bit-exact.
 //
-// Replaces the match-finding ~78-97 % of the reference's per-frame ZSTD_compress2 work (zra.cpp:219,331).
-// One independent frame per workgroup; the workgroup is a single 64-lane wave. The greedy/lazy parse is a
-// strict dependency chain (every table insertion depends on where the previous match ended), so one lane walks
-// it while the whole wave clears the hash tables with coalesced 16-byte stores; throughput comes from thousands
-// of frames in flight (up to 32 waves per CU), not from SIMD inside a frame. Hash tables live in HBM/L2 scratch
-// (64 KiB frames at level 3 need 384 KiB: more than the 160 KiB LDS).
-// Rules restated from SURVEY.md Appendix A.4.3 (validated there against libzstd 1.4.9).
+// Replaces the match-finding 78-97 % of the reference's per-frame ZSTD_compress2 work (zra.cpp:219,331). Frames are independent; a
+// frame's hash tables (384 KiB at level 3 @ 64 KiB, 3.3 MiB at level 9 @ 256 KiB) live in an HBM table slot, not in the 160 KiB LDS.
+// Five kernels, one per way a strategy can be spread over a wave — each holds its own finder only, because a kernel pays the register
+// budget of everything it can call (tests/test_kernel_budgets.py):
+//   zra_mf_dfast_kernel  dfast (levels 3-4): one wave per frame, window-resolve parse (64 positions looked up at once, resolved in
+//                        registers), persistent waves pulling frames from a queue
+//   zra_mf_hc_kernel     greedy / lazy / lazy2 (levels 5-10): one wave per frame, a window of 64 positions inserted and searched at
+//                        once (one lane per chain), the parse consumes the answers
+//   zra_mf_fast_kernel   fast (levels 1-2, negative levels): lane = frame, up to 8 frames per wave
+//   zra_mf_kernel        btlazy2, frames larger than the level's window (sliding-window rules), single odd tails: lane = frame
+//   zra_mf_opt_kernel    the same plus btopt / btultra / btultra2 (zra_encode_opt.h)
+// Rules restated from SURVEY.md Appendix A.4.3 (validated there against libzstd 1.4.9) and checked against oracle/zo_encode.c.
 #include "zra_dev.h"
 #include "zra_kernels.h"
 
