@@ -3,13 +3,14 @@
 // Replaces the reference's per-frame ZSTD_decompressDCtx work (zra.cpp:249,280,289,293,397,406,410,435).
 // A zstd frame is a chain of serial sections (header parses, the FSE sequence bit chain) around data-parallel ones (table fills,
 // literal and match copies). One wave per frame left 63 lanes idle in the serial sections, and the sequence chain alone was more
-// than half of all instructions. So the work of a frame is split by its SHAPE into three kernels that run once per round
+// than half of all instructions. So the work of a frame is split by its SHAPE into four kernels that run once per round
 // (a round = one compressed block of every unfinished frame; 64 KiB ZRA frames take exactly one):
 //
-//   zra_dec_parse_kernel   wave per frame. Frame / block / literal / sequence headers (lane 0), Huffman table fill (wave), the
-//                          Huffman literal streams (one lane per stream) into a bump-allocated literal scratch, the three FSE
+//   zra_dec_parse_kernel   wave per frame. Frame / block / literal / sequence headers (lane 0), the Huffman weights, the three FSE
 //                          decode tables (built in LDS, stored to the frame's table scratch in HBM). Raw and RLE blocks and
 //                          the frame end are handled on the way; a compressed block is handed on.
+//   zra_dec_huf_kernel     16 frames per wave, four lanes per frame (one per Huffman stream): decode tables of the batch in LDS,
+//                          literals to a bump-allocated scratch, sixteen at a time.
 //   zra_dec_chain_kernel   LANE per frame: the FSE sequence chains of 64 frames advance together in the 64 lanes of a wave
 //                          (tables and bitstreams read from L2/HBM, one dependent round trip per sequence, thousands of frames
 //                          in flight per CU). Every check of the reference's sequence loop lives here, in its order, so the
