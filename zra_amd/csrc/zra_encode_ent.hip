@@ -7,7 +7,7 @@
 //   * sequence bitstream: the three FSE state chains (inherently serial) run on 3 lanes, then the
 //     state/extra bits of 1024 sequences at a time are prefix-scanned and packed the same way
 // The small serial pieces (Huffman tree, depth limiter, FSE normalisation, table descriptions) run on one
-// lane per table, three tables concurrently on three waves. Tables and staging live in LDS (~45 KiB).
+// lane per table, three tables concurrently on three waves. Tables, work arrays and staging live in LDS (20 KiB per workgroup).
 // Rules restated from SURVEY.md Appendix A.4.2, A.4.4-A.4.8 (validated there against libzstd 1.4.9).
 #include "zra_dev.h"
 #include "zra_kernels.h"
