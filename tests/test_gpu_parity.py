@@ -177,7 +177,24 @@ def test_randomised_differential_decode(zra, seed):
                     assert zra.DecompressRA(arc, off, sz) == d[off:off + sz], (seed, case, off, sz)
 
 
-@pytest.mark.parametrize("seed", range(6))
+def test_damaged_frame_size_field_host_and_device_calls(zra, gpu_engine):
+    """Found by the corruption soak (seed 13141, case 9): the header's frameSize overwritten from 4096 to 1792, everything else
+    intact. The reference ignores that field in DecompressBuffer (one multi-frame zstd call over the body, zra.cpp:249) and
+    regenerates all 20,187 bytes; here the frames first land in 1,792-byte slots, fail, and the sequential tail packs them back to
+    back — the host-pointer call then copied only frames x frameSize = 8,960 bytes back to the caller."""
+    import torch
+    a = open(os.path.join(GOLD, "corrupt_seed13141_case9.zra"), "rb").read()
+    U = int.from_bytes(a[18:26], "little")
+    want, wbytes = O.zra_decompress(a, U, "zl" if O.have_libzstd() else "zo", defined_only=True)
+    assert want == (0, 0) and len(wbytes) == U == 20187
+    assert zra.DecompressBuffer(a) == wbytes
+    d_arc = torch.from_numpy(np.frombuffer(a, dtype=np.uint8).copy()).cuda()
+    d_out = torch.zeros(U + 64, dtype=torch.uint8, device="cuda")
+    gpu_engine.decompress(d_arc.data_ptr(), len(a), d_out.data_ptr(), U)
+    assert d_out[:U].cpu().numpy().tobytes() == wbytes and int(d_out[U:].max()) == 0
+
+
+@pytest.mark.parametrize("seed", list(range(6)) + [13141])
 def test_randomised_corruption_statuses(zra, seed):
     """Mutated archives (bit flips, byte overwrites, truncation): DecompressBuffer must report the (zra, zstd) status of the REAL
     dependency (libzstd 1.4.9 behind the oracle's container code, backend "zl") — and the same bytes wherever the decode is defined —

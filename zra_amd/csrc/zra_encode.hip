@@ -566,9 +566,13 @@ Status Engine::decode_host(const uint8_t* hSpan, size_t spanSize, const std::vec
   Status s = decode_jobs(hostIn_.as<uint8_t>(), spanSize, frameOff_.as<uint64_t>(), hostOut_.as<uint8_t>(), outOff_.as<uint64_t>(),
                          expect_.as<uint32_t>(), nFrames, frameSize, 2, wholeArchive ? total : 0);
   if (s.zra) return s;
-  if (skip + size > (uint64_t)nFrames * frameSize) return {kOutOfBounds, 0};
-  // frames that regenerated less than their slots (corrupted archive, sequential tail): only what was written reaches the caller
-  if (wholeArchive && lastProducedTotal_ != ~0ull) size = lastProducedTotal_ > skip ? (size_t)std::min<uint64_t>(size, lastProducedTotal_ - skip) : 0;
+  if (wholeArchive && lastProducedTotal_ != ~0ull) {
+    // frames that regenerated another size than the header's frameSize (corrupted or foreign archive): the sequential tail has packed
+    // them back to back like the reference's one multi-frame call (zra.cpp:249) — what it wrote, less or MORE than the nominal slots
+    // add up to (a frameSize field damaged downwards), is what reaches the caller; never more than the declared size
+    const uint64_t have = std::min<uint64_t>(total, lastProducedTotal_);
+    size = have > skip ? (size_t)(have - skip) : 0;
+  } else if (skip + size > (uint64_t)nFrames * frameSize) return {kOutOfBounds, 0};
   if (size) HIPCHK(hipMemcpyAsync(hOut, hostOut_.as<uint8_t>() + skip, size, hipMemcpyDeviceToHost, stream_));
   HIPCHK(hipStreamSynchronize(stream_));
   return ok();

@@ -496,7 +496,12 @@ __device__ unsigned long long zra_ent_prof[16];
 #define EPROF(k)
 #endif
 
-extern "C" __global__ void __launch_bounds__(ENT_THREADS, 7)
+// Register budget: beside the persistent match finder (112 KiB of a CU's LDS) two workgroups of this kernel fit on a CU, so nothing is
+// gained by squeezing it under 72 VGPRs for 7 waves per SIMD (that cost 8 spilled VGPRs and 72 B of scratch in the one-lane sections).
+#ifndef ZRA_ENT_WAVES
+#define ZRA_ENT_WAVES 5
+#endif
+extern "C" __global__ void __launch_bounds__(ENT_THREADS, ZRA_ENT_WAVES)
 zra_entropy_kernel(ZraEncArgs a, u32 block) {
   __shared__ EncShared S;
   // This stage runs beside the persistent match finder, which is DRAM-bound but fills most issue slots; the one-lane serial
