@@ -201,3 +201,55 @@ def far_repeat_input(rng, total, rep_len, dist):
     while len(d) < total:
         d += random_lz_input(rng, 50000) + R[:30000]
     return d[:total]
+
+
+def mutated_headers(seed, cases, compress):
+    """Yields (case, archive, ra_defined, ra_bytes_defined, what): a valid archive with 1-2 HEADER fields overwritten — frameSize, uncompressedSize,
+    tableSize, headerSize, version, single seek-table entries — restricted to values for which the reference's behaviour is defined
+    (it trusts the seek table: entries beyond the body, an inflated tableSize or a shifted table are out-of-bounds reads in
+    DecompressRA, zra.cpp:265-296, and crash it). ra_defined: DecompressRA may be compared too (only frameSize, a smaller
+    uncompressedSize, the version and in-range entry values were touched). ra_bytes_defined: its bytes too — with a damaged frameSize
+    the reference copies out of a frameSize-sized buffer that the frames fill only partly, and what libzstd leaves behind the
+    regenerated bytes (wildcopy overrun inside the capacity) is not specified; the status is."""
+    rng = np.random.RandomState(70000 + seed)
+
+    def put(a, off, n, v):
+        a[off:off + n] = int(v).to_bytes(n, "little")
+
+    for case in range(cases):
+        fs = int(rng.choice([1024, 4096, 16384, 65536]))
+        n = int(rng.randint(1, 5 * fs))
+        d = random_lz_input(rng, n)
+        st, arc = compress(d, int(rng.choice([1, 3, 3, 5])), fs, bool(case & 1))
+        if st != (0, 0):
+            continue
+        a = bytearray(arc)
+        ts = int.from_bytes(a[26:30], "little"); hs = int.from_bytes(a[4:8], "little")
+        body = len(arc) - (hs + 8)
+        what = []; ra_ok = True; ra_bytes = True
+        for _ in range(int(rng.choice([1, 1, 2]))):
+            m = int(rng.randint(0, 6))
+            if m == 0:
+                v = int(rng.choice([1, 2, 3, max(1, fs // 2), fs - 1, fs + 1, 2 * fs, 1792, 3 * fs + 5, 65535])); put(a, 30, 4, v); what.append(("frameSize", v)); ra_bytes = False
+            elif m == 1:
+                v = int(rng.choice([1, max(1, n - 1), n + 1, max(1, n // 2), n + fs, 2 * n])); put(a, 18, 8, v); what.append(("uncompressedSize", v)); ra_ok &= v <= n
+            elif m == 2:
+                v = int(rng.choice([1, max(1, ts - 1), ts + 1, ts + 7, 2 * ts])); put(a, 26, 4, v); what.append(("tableSize", v)); ra_ok = False
+            elif m == 3:
+                v = int(rng.choice([hs - 1, hs + 1, hs + 5, max(0, hs - 5)])); put(a, 4, 4, v); what.append(("headerSize", v)); ra_ok = False
+            elif m == 4:
+                v = int(rng.choice([0, 2, 3, 255])); put(a, 12, 2, v); what.append(("version", v))
+            elif ts >= 2:
+                k = int(rng.randint(0, ts)); e = int.from_bytes(a[38 + 5 * k:43 + 5 * k], "little")
+                v = int(rng.choice([max(0, e - 1), min(body, e + 1), int(rng.randint(0, body + 1)), 0])); put(a, 38 + 5 * k, 5, v); what.append(("entry", k, v))
+        # the reference's RA also needs every frame it touches to exist in the table: a frameSize that makes offset / frameSize run past
+        # the table is an out-of-bounds vector read there
+        fs2 = int.from_bytes(a[30:34], "little"); u2 = int.from_bytes(a[18:26], "little")
+        if fs2 == 0 or u2 > (1 << 24):
+            continue
+        if (u2 + fs2 - 1) // fs2 + 1 > ts:
+            ra_ok = False
+        ents = [int.from_bytes(a[38 + 5 * k:43 + 5 * k], "little") for k in range(ts)]
+        if any(y < x for x, y in zip(ents, ents[1:])) or (ents and ents[-1] > body):
+            ra_ok = False                             # a span that runs backwards is a wrapped size_t there
+        yield case, bytes(a), ra_ok, ra_bytes, what

@@ -210,6 +210,35 @@ def test_randomised_corruption_statuses(zra, seed):
             assert (e.zra, e.zstd) == want, (seed, case, want, (e.zra, e.zstd))
 
 
+@pytest.mark.parametrize("seed", range(4))
+def test_randomised_header_damage(zra, seed):
+    """Overwritten HEADER fields (frameSize, uncompressedSize, tableSize, headerSize, version, single seek-table entries), limited to
+    values the reference handles without reading out of bounds (tests/corpus.py mutated_headers): DecompressBuffer status and bytes,
+    DecompressRA status (bytes too unless frameSize was touched) against the oracle's container code over the real libzstd
+    (20 archives x up to 4 queries per seed; the restatement itself is pinned against libzstd on the same archives by tests/test_oracle.py)."""
+    backend = "zl" if O.have_libzstd() else "zo"
+    for case, a, ra_ok, ra_bytes, what in C.mutated_headers(seed, 20, O.zra_compress):
+        cap = int.from_bytes(a[18:26], "little"); fs = int.from_bytes(a[30:34], "little")
+        want, wbytes = O.zra_decompress(a, cap, backend, defined_only=True)
+        try:
+            got = zra.DecompressBuffer(a)
+            assert want == (0, 0) and got[:len(wbytes)] == wbytes, (seed, case, what, want)
+        except zra.ZraError as e:
+            assert (e.zra, e.zstd) == want, (seed, case, what, want, (e.zra, e.zstd))
+        if not ra_ok or cap < 2:
+            continue
+        rng = np.random.RandomState(seed * 100 + case)
+        for _ in range(4):
+            off = int(rng.randint(0, cap))
+            size = max(1, min(int(rng.choice([1, 100, fs, 2 * fs + 3, max(1, cap - off - 1), max(1, cap - off)])), 1 << 24))
+            wq, qbytes = O.zra_ra(a, off, size, backend)
+            try:
+                g = zra.DecompressRA(a, off, size)
+                assert wq == (0, 0) and (g == qbytes or not ra_bytes), (seed, case, what, (off, size), wq)
+            except zra.ZraError as e:
+                assert (e.zra, e.zstd) == wq, (seed, case, what, (off, size), wq, (e.zra, e.zstd))
+
+
 def test_compress_edge_cases(zra):
     assert zra.CompressBuffer(b"abcdefghij", 3, 4, True) == open(os.path.join(GOLD, "g1_abcdefghij_fs4.zra"), "rb").read()
     assert zra.CompressBuffer(b"", 3, 65536, True) == open(os.path.join(GOLD, "g1_empty_fs65536.zra"), "rb").read()

@@ -309,6 +309,71 @@ namespace zra {
     }
   }
 
+  namespace {
+    // One ZSTD_decompressDCtx call of the reference over `n` source bytes into `cap` bytes of destination, with libzstd's multi-frame
+    // semantics (zero, one or several concatenated frames packed back to back, skippable frames skipped, errors in frame order,
+    // dstSize_tooSmall against the whole destination) — the machinery of DecompressBuffer on a piece of the body. Returns the bytes
+    // regenerated.
+    size_t multiframe_call(const u8* src, size_t n, u8* dst, size_t cap, u32 slotSize) {
+      std::vector<uint64_t> starts, ends;
+      uint64_t brokenAt = ~0ull;
+      const int walkErr = walk_frames(src, n, starts, ends, &brokenAt);
+      if (walkErr && brokenAt != ~0ull) { starts.push_back(brokenAt); ends.push_back(n); }
+      size_t produced = 0;
+      if (!starts.empty()) {
+        LEASE_ENGINE(eng);
+        const u64 avail = std::min<u64>(cap, (u64)starts.size() * slotSize);
+        check(eng->decode_host(src, n, starts, ends, slotSize, cap, dst, 0, (size_t)avail, true));
+        const uint64_t packed = eng->last_produced_total();
+        produced = packed == ~0ull ? (size_t)avail : (size_t)std::min<u64>(cap, packed);
+      }
+      if (walkErr) throw Exception(StatusCode::ZStdError, walkErr);
+      return produced;
+    }
+
+    // The three zstd calls of the reference's random access, literally (zra.cpp:279-295 and :400-414): taken when the one-pass device
+    // decode of the touched frames reports anything but success — a seek table, frameSize or uncompressedSize that does not describe
+    // the frames (damaged or foreign archive). What the reference then returns depends on what each of ITS calls sees: a span with two
+    // frames in it overflows the frameSize buffer (dstSize_tooSmall), one that starts inside a frame has no magic number
+    // (prefix_unknown), a frame shorter than frameSize is simply copied from a zero-filled buffer. `span` = the body bytes from
+    // the caller holds (the whole body for the in-memory call, the bytes read from entry[q] on for the streaming class); entries
+    // that run backwards or leave those bytes are srcSize_wrong here (the reference reads out of bounds).
+    void ra_exact(const u8* table, u64 q, u64 rem, u64 quot2, u64 rem2, const u8* span, u64 spanAvail, u64 spanBase, const Header& header, u8* out, size_t outSize, size_t size) {
+      const u64 last = quot2 + (rem2 ? 1 : 0);
+      auto rel = [&](u64 i) -> u64 {                      // entry -> position inside `span` (whose first byte is body offset spanBase)
+        const u64 e = fmt::entry_get(table + (q + i) * 5);
+        if (e < spanBase || e - spanBase > spanAvail) throw Exception(StatusCode::ZStdError, 72);
+        return e - spanBase;
+      };
+      auto piece = [&](u64 a, u64 b) -> std::pair<const u8*, size_t> {
+        const u64 ra = rel(a), rb = rel(b);
+        if (rb < ra) throw Exception(StatusCode::ZStdError, 72);
+        return {span + ra, (size_t)(rb - ra)};
+      };
+      std::vector<u8> frameBuffer;
+      if (rem || rem2) frameBuffer.assign(header.frameSize, 0);
+      size_t done = 0; u64 first = 0;
+      if (rem) {
+        auto p = piece(0, 1);
+        multiframe_call(p.first, p.second, frameBuffer.data(), frameBuffer.size(), header.frameSize);
+        const size_t minSize = std::min<size_t>(size, (size_t)(header.frameSize - rem));
+        std::memcpy(out, frameBuffer.data() + rem, minSize);
+        done += minSize; first = 1;
+      }
+      if (done < size) {
+        auto p = piece(first, rem2 ? last - 1 : last);
+        done += multiframe_call(p.first, p.second, out + done, outSize - done, header.frameSize);
+      }
+      if (done < size && rem2) {
+        auto p = piece(last - 1, last);
+        multiframe_call(p.first, p.second, frameBuffer.data(), frameBuffer.size(), header.frameSize);
+        std::memcpy(out + done, frameBuffer.data(), size - done);
+      }
+    }
+    // infrastructure failures (allocation, launch) are not statuses of the archive: they are not retried
+    bool archive_status(const Exception& e) { return e.code == StatusCode::ZStdError && e.zstdCode != 1 && e.zstdCode != 64; }
+  }
+
   void DecompressRA(const BufferView& input, const BufferView& output, size_t offset, size_t size) {
     Header header(input);
     const bool inclusive = g_options.load() & kOptInclusiveRaBound;      // opt-in: the last byte becomes reachable, as in Decompressor
@@ -325,7 +390,12 @@ namespace zra {
     const u64 base = fmt::entry_get(table + q * 5);
     const u64 bodyAvail = input.size - header.size;
     if (base > bodyAvail) throw Exception(StatusCode::ZStdError, 72);
-    ra_decode(table, header.seekTableSize, input.data + header.size + base, bodyAvail - base, base, q, count, header, output.data, r, size);
+    try {
+      ra_decode(table, header.seekTableSize, input.data + header.size + base, bodyAvail - base, base, q, count, header, output.data, r, size);
+    } catch (const Exception& e) {
+      if (!archive_status(e)) throw;
+      ra_exact(table, q, r, n, t, input.data + header.size, bodyAvail, 0, header, output.data, output.size, size);
+    }
   }
 
   Buffer DecompressRA(const BufferView& buffer, size_t offset, size_t size) {
@@ -413,7 +483,12 @@ namespace zra {
     in.resize(compressedSize);
     readFunction(header.size + base, compressedSize, in.data());
     if (size == 0 || count == 0) return;
-    ra_decode(table, seekTable.size(), in.data(), in.size(), base, q, count, header, output.data, r, size);
+    try {
+      ra_decode(table, seekTable.size(), in.data(), in.size(), base, q, count, header, output.data, r, size);
+    } catch (const Exception& e) {
+      if (!archive_status(e)) throw;
+      ra_exact(table, q, r, n, t, in.data(), in.size(), base, header, output.data, output.size, size);
+    }
   }
   void Decompressor::Decompress(size_t offset, size_t size, Buffer& output) { output.resize(size); Decompress(offset, size, BufferView(output)); }
   Buffer Decompressor::Decompress(size_t offset, size_t size) { Buffer b; Decompress(offset, size, b); return b; }

@@ -47,6 +47,9 @@ class Engine {
   // large level-9 compression); the next call allocates again what it needs
   Status release_scratch();
   double last_kernel_ms() const { return lastKernelMs_; }
+  // after a whole-archive decode_host(): bytes regenerated when frames had to be packed one after the other (a frame regenerated
+  // another size than its slot), ~0 when every frame filled exactly its slot
+  uint64_t last_produced_total() const { return lastProducedTotal_; }
   // HIP-event timings of the last call on the engine's stream: {mf ms, mf launches, entropy ms, entropy launches, decode ms, decode launches}
   void kernel_stats(double out[6]) const { for (int i = 0; i < 6; i++) out[i] = kstats_[i]; }
   // bring-up: sequences {ll | ml<<20 | offVal<<40} the match finder left in scratch context 0 for frame `frame` of the LAST batch
