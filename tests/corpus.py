@@ -230,7 +230,7 @@ def mutated_headers(seed, cases, compress):
         for _ in range(int(rng.choice([1, 1, 2]))):
             m = int(rng.randint(0, 6))
             if m == 0:
-                v = int(rng.choice([1, 2, 3, max(1, fs // 2), fs - 1, fs + 1, 2 * fs, 1792, 3 * fs + 5, 65535])); put(a, 30, 4, v); what.append(("frameSize", v)); ra_bytes = False
+                v = int(rng.choice([1, 2, 3, max(1, fs // 2), fs - 1, fs + 1, 2 * fs, 1792, 3 * fs + 5, 65535, 1 << 24, (1 << 31) + 5])); put(a, 30, 4, v); what.append(("frameSize", v)); ra_bytes = False
             elif m == 1:
                 v = int(rng.choice([1, max(1, n - 1), n + 1, max(1, n // 2), n + fs, 2 * n])); put(a, 18, 8, v); what.append(("uncompressedSize", v)); ra_ok &= v <= n
             elif m == 2:
@@ -247,8 +247,8 @@ def mutated_headers(seed, cases, compress):
         fs2 = int.from_bytes(a[30:34], "little"); u2 = int.from_bytes(a[18:26], "little")
         if fs2 == 0 or u2 > (1 << 24):
             continue
-        if (u2 + fs2 - 1) // fs2 + 1 > ts:
-            ra_ok = False
+        if (u2 + fs2 - 1) // fs2 + 1 > ts or fs2 > (1 << 22):
+            ra_ok = False                             # (a huge frameSize: the reference's random access zero-fills a buffer of that size per call)
         ents = [int.from_bytes(a[38 + 5 * k:43 + 5 * k], "little") for k in range(ts)]
         if any(y < x for x, y in zip(ents, ents[1:])) or (ents and ents[-1] > body):
             ra_ok = False                             # a span that runs backwards is a wrapped size_t there

@@ -547,7 +547,7 @@ Status Engine::decode_host(const uint8_t* hSpan, size_t spanSize, const std::vec
   for (uint32_t i = 0; i < nFrames; i++) {
     se[2 * (size_t)i] = starts[i]; se[2 * (size_t)i + 1] = ends[i];
     const uint64_t o = (uint64_t)i * frameSize;
-    oo[i] = o;
+    oo[i] = wholeArchive ? std::min<uint64_t>(o, total) : o;        // a slot past the declared size has no room and no address of its own
     ex[i] = o >= total ? 0 : (uint32_t)std::min<uint64_t>(frameSize, total - o);
   }
   if (wholeArchive && skip == 0 && frameSize && (size_t)nFrames >= 2 * std::max<size_t>(1, host_chunk_bytes() / frameSize) && size == std::min<uint64_t>(total, (uint64_t)nFrames * frameSize)) {
@@ -555,7 +555,8 @@ Status Engine::decode_host(const uint8_t* hSpan, size_t spanSize, const std::vec
     Status s = decode_host_pipelined(hSpan, starts, ends, frameSize, total, hOut, &fallBack);
     if (!fallBack) return s;
   }
-  if (!hostIn_.reserve(spanSize + 64) || !hostOut_.reserve(std::max<size_t>((size_t)nFrames * frameSize, wholeArchive ? (size_t)total : 0) + 64) || !frameOff_.reserve(se.size() * 8) ||
+  // whole-archive mode never writes at or beyond `total` (slots past it have no room), whatever the header's frameSize claims
+  if (!hostIn_.reserve(spanSize + 64) || !hostOut_.reserve((wholeArchive ? (size_t)total : (size_t)nFrames * frameSize) + 64) || !frameOff_.reserve(se.size() * 8) ||
       !outOff_.reserve((size_t)nFrames * 8) || !expect_.reserve((size_t)nFrames * 4))
     return zerr(64);
   HIPCHK(hipMemcpyAsync(hostIn_.p, hSpan, spanSize, hipMemcpyHostToDevice, stream_));
