@@ -194,6 +194,36 @@ def test_damaged_frame_size_field_host_and_device_calls(zra, gpu_engine):
     assert d_out[:U].cpu().numpy().tobytes() == wbytes and int(d_out[U:].max()) == 0
 
 
+def test_damaged_frame_size_field_streaming_full_decompressor(zra):
+    """The same archive through FullDecompressor (zra.cpp:428-436): one zstd call per Decompress() over floor(capacity / frameSize)
+    table entries, the frames packed into the caller's buffer whatever they regenerate. With the damaged frameSize (1792 instead of
+    4096) a 64 KiB buffer takes all five frames at once (20,187 bytes); a 7,168-byte one takes four and overflows (dstSize_tooSmall)."""
+    L = zra.load()
+    a = open(os.path.join(GOLD, "corrupt_seed13141_case9.zra"), "rb").read()
+    U = int.from_bytes(a[18:26], "little")
+    want, wbytes = O.zra_decompress(a, U, "zl" if O.have_libzstd() else "zo", defined_only=True)
+    def rd(off, size, buf):
+        ctypes.memmove(buf, a[off: off + size], size)
+    cb = zra.READ_FN(rd)
+    for ahead in ("0", "256"):
+        os.environ["ZRA_STREAM_AHEAD_MIB"] = ahead
+        try:
+            fd = ctypes.c_void_p()
+            assert L.ZraCreateFullDecompressor(ctypes.byref(fd), cb, 0).tup() == (0, 0)
+            out = ctypes.create_string_buffer(65536); osz = ctypes.c_size_t(0)
+            assert L.ZraDecompressWithFullDecompressor(fd, out, 65536, ctypes.byref(osz)).tup() == (0, 0)
+            assert out.raw[: osz.value] == wbytes
+            assert L.ZraDecompressWithFullDecompressor(fd, out, 65536, ctypes.byref(osz)).tup() == (0, 0) and osz.value == 0
+            L.ZraDeleteFullDecompressor(fd)
+            fd = ctypes.c_void_p()
+            assert L.ZraCreateFullDecompressor(ctypes.byref(fd), cb, 0).tup() == (0, 0)
+            small = ctypes.create_string_buffer(7168)
+            assert L.ZraDecompressWithFullDecompressor(fd, small, 7168, ctypes.byref(osz)).tup() == (1, 70)
+            L.ZraDeleteFullDecompressor(fd)
+        finally:
+            os.environ.pop("ZRA_STREAM_AHEAD_MIB", None)
+
+
 @pytest.mark.parametrize("seed", list(range(6)) + [13141])
 def test_randomised_corruption_statuses(zra, seed):
     """Mutated archives (bit flips, byte overwrites, truncation): DecompressBuffer must report the (zra, zstd) status of the REAL

@@ -553,7 +553,14 @@ namespace zra {
     readFunction(header.size + base, cache.size(), cache.data());
     entryIndex = stop;
     if (!count) return 0;
-    ra_decode(table, seekTable.size(), cache.data(), cache.size(), base, first, count, header, output.data, 0, produced);
+    try {
+      ra_decode(table, seekTable.size(), cache.data(), cache.size(), base, first, count, header, output.data, 0, produced);
+    } catch (const Exception& e) {
+      // frames that do not fill frameSize-sized slots (damaged or foreign header): the reference's single zstd call over the span
+      // packs whatever the frames regenerate into the caller's buffer and returns that size (zra.cpp:435)
+      if (!archive_status(e)) throw;
+      return multiframe_call(cache.data(), cache.size(), output.data, output.size, header.frameSize);
+    }
     return produced;
   }
 }  // namespace zra
