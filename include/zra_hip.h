@@ -47,7 +47,12 @@ ZRA_EXPORT void* ZraHipGetStream(ZraHipEngine* engine);
 ZRA_EXPORT ZraStatus ZraHipCompressBuffer(ZraHipEngine* engine, const void* dIn, size_t inSize, void* dOut, size_t* outSize,
                                           int8_t compressionLevel, uint32_t frameSize, bool checksum);
 
-/** DecompressBuffer with a device-resident archive; dOut must hold the archive's uncompressedSize bytes. Synchronous. */
+/** DecompressBuffer with a device-resident archive; dOut must hold the archive's uncompressedSize bytes. Synchronous.
+ *  Frame boundaries come from the archive's own seek table (the body stays on the device, nothing walks it on the host): on a valid
+ *  archive the result is the reference's; on a damaged one the frames' own errors are reported like libzstd's, but a seek table
+ *  that does not match the frames is an error here (srcSize_wrong / corruption_detected) where zra::DecompressBuffer — one
+ *  multi-frame zstd call that never looks at the table, zra.cpp:249 — may still succeed. The host-pointer ZraDecompressBuffer /
+ *  ZraDecompressRA of include/zra.h reproduce the reference on such archives too. The same holds for ZraHipDecompressRABatch. */
 ZRA_EXPORT ZraStatus ZraHipDecompressBuffer(ZraHipEngine* engine, const void* dIn, size_t inSize, void* dOut, size_t outCapacity);
 
 /** Batched DecompressRA: query i returns bytes [hOffsets[i], hOffsets[i]+hSizes[i]) of the original data at dOut + hOutOffsets[i].
