@@ -253,3 +253,19 @@ def mutated_headers(seed, cases, compress):
         if any(y < x for x, y in zip(ents, ents[1:])) or (ents and ents[-1] > body):
             ra_ok = False                             # a span that runs backwards is a wrapped size_t there
         yield case, bytes(a), ra_ok, ra_bytes, what
+
+
+def seek_table_consistent(a):
+    """True when the header of archive `a` still describes a table the reference's random access can follow without reading out of
+    bounds: magic / version intact, tableSize and headerSize matching uncompressedSize and frameSize, entries non-decreasing and inside
+    the bytes present (zra.cpp:265-296 trusts all of that)."""
+    if len(a) < 43:
+        return False
+    hs = int.from_bytes(a[4:8], "little"); U = int.from_bytes(a[18:26], "little"); ts = int.from_bytes(a[26:30], "little")
+    fs = int.from_bytes(a[30:34], "little"); ms = int.from_bytes(a[34:38], "little")
+    if fs == 0 or ms != 0 or int.from_bytes(a[0:4], "little") != 0x184D2A50 or int.from_bytes(a[8:12], "little") != 0x3041525A or int.from_bytes(a[12:14], "little") != 1:
+        return False
+    if ts != (U + fs - 1) // fs + 1 or hs != 30 + 5 * ts or len(a) < hs + 8:
+        return False
+    ents = [int.from_bytes(a[38 + 5 * k:43 + 5 * k], "little") for k in range(ts)]
+    return not any(y < x for x, y in zip(ents, ents[1:])) and ents[-1] <= len(a) - (hs + 8)

@@ -269,6 +269,32 @@ def test_randomised_header_damage(zra, seed):
                 assert (e.zra, e.zstd) == wq, (seed, case, what, (off, size), wq, (e.zra, e.zstd))
 
 
+@pytest.mark.parametrize("seed", range(4))
+def test_randomised_random_access_on_damaged_frames(zra, seed):
+    """DecompressRA on archives whose FRAMES are damaged (bit flips, overwrites, truncation; the header must still describe a table the
+    reference can follow, tests/corpus.py seek_table_consistent): status of every query against libzstd behind the container code,
+    bytes wherever restatement and libzstd agree on them (a damaged frame may regenerate fewer bytes than frameSize without an error;
+    the reference then copies what its buffer held behind them, which is not specified)."""
+    backend = "zl" if O.have_libzstd() else "zo"
+    for case, a in C.mutated_archives(20000 + seed, 50, O.zra_compress):
+        if not C.seek_table_consistent(a):
+            continue
+        U = int.from_bytes(a[18:26], "little"); fs = int.from_bytes(a[30:34], "little")
+        rng = np.random.RandomState(seed * 1000 + case)
+        for _ in range(4):
+            if U < 2:
+                break
+            off = int(rng.randint(0, U))
+            size = max(1, min(int(rng.choice([1, 100, fs, 2 * fs + 3, max(1, U - off - 1), max(1, U - off)])), 1 << 24))
+            wq, qbytes = O.zra_ra(a, off, size, backend)
+            other = O.zra_ra(a, off, size, "zo")[1] if backend == "zl" else qbytes
+            try:
+                g = zra.DecompressRA(a, off, size)
+                assert wq == (0, 0) and (g == qbytes or other != qbytes), (seed, case, (off, size), wq)
+            except zra.ZraError as e:
+                assert (e.zra, e.zstd) == wq, (seed, case, (off, size), wq, (e.zra, e.zstd))
+
+
 def test_compress_edge_cases(zra):
     assert zra.CompressBuffer(b"abcdefghij", 3, 4, True) == open(os.path.join(GOLD, "g1_abcdefghij_fs4.zra"), "rb").read()
     assert zra.CompressBuffer(b"", 3, 65536, True) == open(os.path.join(GOLD, "g1_empty_fs65536.zra"), "rb").read()
