@@ -21,7 +21,7 @@ BUDGET = {
     "zra_dec_huf_kernel": (72, 0),
     "zra_dec_parse_kernel": (168, 0),
     "zra_dec_exec_kernel": (128, 0),
-    "zra_entropy_kernel": (72, 72),
+    "zra_entropy_kernel": (88, 8),       # 5 waves per SIMD asked for: no spills (7 cost 8 spilled VGPRs + 72 B scratch and 2 % of the bench)
 }
 
 
@@ -35,4 +35,4 @@ def test_hot_kernels_stay_inside_their_register_and_scratch_budgets():
         r = res[name]
         assert r["vgprs"] <= vg, (name, r)
         assert r["scratch_bytes"] <= scratch, (name, r)
-        assert r["vgpr_spill"] <= (8 if name == "zra_entropy_kernel" else 0), (name, r)
+        assert r["vgpr_spill"] == 0, (name, r)
