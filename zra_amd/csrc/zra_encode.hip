@@ -278,7 +278,7 @@ Status Engine::compress_impl_body(const uint8_t* dIn, size_t inSize, uint8_t* dB
         // strategy is parsed by the generic kernel in a second single-frame launch
         const bool hasTail = tailSize && f0 + nb == nFramesTotal;
         // LDS geometry of the dfast kernel's bucket filter (see compress_persistent)
-        uint32_t shL = 1, shS = 1, dupLog = 9;
+        uint32_t shL = 1, shS = 2, dupLog = 9;
         if (const char* f = std::getenv("ZRA_MF_FILTER")) { unsigned x = 1, y = 1, z = 9; if (std::sscanf(f, "%u,%u,%u", &x, &y, &z) >= 1) { shL = x & 15; shS = y & 15; dupLog = z & 15; } }
         a.mfFilter = shL | (shS << 4) | (dupLog << 8);
         const uint32_t hl = std::max(full.hashLog, tail.hashLog), cl = std::max(full.chainLog, tail.chainLog);
@@ -347,7 +347,9 @@ Status Engine::compress_persistent(const uint8_t* dIn, size_t inSize, uint8_t* d
   const uint64_t nFramesTotal = (inSize + frameSize - 1) / frameSize;
   const size_t tailSize = inSize % frameSize;
   const auto mfGeneric = (full.strategy >= 7 || tail.strategy >= 7) ? zra_mf_opt_kernel : zra_mf_kernel;
-  static const uint32_t wavesPerCU = std::getenv("ZRA_MF_WAVES") ? (uint32_t)std::atoi(std::getenv("ZRA_MF_WAVES")) : 16u;
+  // 18 resident waves per CU with the 6 KiB filter below: A/B on one box (tools/bench_ab_env.sh, profiles/r02_experiments.md): +2.5-4 % over
+  // 16 waves with the 7 KiB filter; 20 and more lose it again to the entropy stage
+  static const uint32_t wavesPerCU = std::getenv("ZRA_MF_WAVES") ? (uint32_t)std::atoi(std::getenv("ZRA_MF_WAVES")) : 18u;
   static const uint32_t SB = std::getenv("ZRA_ENC_SUB") ? (uint32_t)std::atoi(std::getenv("ZRA_ENC_SUB")) : 8192u;   // frames per sub-batch
   const uint32_t nSlots = (uint32_t)std::min<uint64_t>((uint64_t)numCUs_ * wavesPerCU, nFramesTotal);
   // per-frame scratch that lives from the match finder to the entropy stage: sequences + block record + checksum + size/offset
@@ -383,10 +385,10 @@ Status Engine::compress_persistent(const uint8_t* dIn, size_t inSize, uint8_t* d
   dbgSeqStride_ = seqStride; dbgB_ = (uint32_t)SBIG;
   base.tableStride = tableWords; base.seqStride = seqStride; base.litStride = litStride; base.slotStride = slotStride;
   // LDS geometry of the bucket filter: 1 bit per 2^shL long-table buckets, 1 bit per 2^shS short-table buckets, and the
-  // duplicate-detection slots (1 KiB + 4 KiB + 2 KiB at hashLog 16 / chainLog 15). 16 resident waves per CU x 7 KiB leave LDS and
-  // wave slots for two entropy-stage workgroups per CU, which is what lets stream B run under the match finder (sweeps in
-  // profiles/r01_mf_occupancy_sweep.log)
-  uint32_t shL = 1, shS = 1, dupLog = 9;
+  // duplicate-detection slots (1 KiB + 4 KiB + 1 KiB at hashLog 16 / chainLog 15: one bit per 2 long buckets, per 4 short buckets).
+  // 18 resident waves per CU x 6 KiB leave LDS and wave slots for two entropy-stage workgroups per CU, which is what lets stream B
+  // run under the match finder (round 1: profiles/r01_mf_occupancy_sweep.log; round 2 A/B on one box: profiles/r02_experiments.md)
+  uint32_t shL = 1, shS = 2, dupLog = 9;
   if (const char* f = std::getenv("ZRA_MF_FILTER")) { unsigned x = 1, y = 1, z = 9; if (std::sscanf(f, "%u,%u,%u", &x, &y, &z) >= 1) { shL = x & 15; shS = y & 15; dupLog = z & 15; } }
   base.mfFilter = shL | (shS << 4) | (dupLog << 8);
   const uint32_t hl = std::max(full.hashLog, tail.hashLog), cl = std::max(full.chainLog, tail.chainLog);
