@@ -354,7 +354,9 @@ Status Engine::compress_persistent(const uint8_t* dIn, size_t inSize, uint8_t* d
   const uint32_t nSlots = (uint32_t)std::min<uint64_t>((uint64_t)numCUs_ * wavesPerCU, nFramesTotal);
   // per-frame scratch that lives from the match finder to the entropy stage: sequences + block record + checksum + size/offset
   const uint64_t perFrame = seqStride * 8 + sizeof(ZraEncFrameState) + sizeof(ZraEncBlockOut) + 4 + 16 + 8;
-  const uint64_t budget = 8ull << 30;              // per context; launch length is not critical (sweep in the log: 16 K ... 128 K frames within noise)
+  // per context (two of them); every launch boundary costs the pipeline about 7 ms (A/B on one box: 8 launches instead of 5 per 16 GiB
+  // = -2 %), so the launches are as long as a scratch budget allows; bring-up knob ZRA_ENC_PBUDGET_GIB
+  static const uint64_t budget = (std::getenv("ZRA_ENC_PBUDGET_GIB") ? (uint64_t)std::max(1, std::atoi(std::getenv("ZRA_ENC_PBUDGET_GIB"))) : 8ull) << 30;
   uint64_t SBIG = std::max<uint64_t>(1, std::min<uint64_t>(nFramesTotal, budget / perFrame));
   if (const char* e = std::getenv("ZRA_ENC_SUPER")) SBIG = std::max<uint64_t>(1, std::min<uint64_t>(SBIG, (uint64_t)std::atoll(e)));   // bring-up knob
   if (SBIG > SB) SBIG -= SBIG % SB;
