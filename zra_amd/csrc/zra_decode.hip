@@ -833,7 +833,14 @@ zra_dec_huf_kernel(ZraDecodeArgs a) {
         const u8* const sb = blk + F->streamOff[strm]; const u32 sl = F->streamLen[strm];
         const u16* const tab = S.tab[slot];
         const int mb = (int)F->hufMaxBits;
+#ifndef ZRA_HUF_READER_AHEAD
+#define ZRA_HUF_READER_AHEAD 1
+#endif
+#if ZRA_HUF_READER_AHEAD
+        BitRS hb;
+#else
         BitR hb;
+#endif
         bool bad = hb.init(sb, sl, lim) != 0;
         if (!bad) {
           u32 i = 0;

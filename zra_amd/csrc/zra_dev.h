@@ -107,6 +107,45 @@ struct BitR {
   }
 };
 
+// BitR for long streams that are read from end to start in one go (the Huffman literal streams): the same window at the same
+// positions, but assembled from an 8-byte grid that is loaded one word AHEAD of the window. Which bytes a backward stream needs next
+// does not depend on what is decoded — only the bit position inside them does — so the load latency (a DRAM round trip per four
+// symbols with BitR, the whole cost of the Huffman stage) stays out of the decode chain.
+struct BitRS {
+  const u8* base; const u8* lim;
+  i32 pos, wlo; u64 w;
+  i32 gtop;                      // byte index of grid word g0; g1 = the 8 bytes below it, g2 the 8 below those (in flight)
+  u64 g0, g1, g2;
+  // 8 stream bytes at byte index idx; bytes below the stream's start read as zero (BitR::reload does the same with one shifted load)
+  __device__ __forceinline__ u64 grid(i32 idx) const {
+    if (idx >= 0) return ld64_safe(base + idx, lim);
+    if (idx <= -8) return 0;
+    return ld64_safe(base, lim) << (u32)(-idx * 8);
+  }
+  __device__ __forceinline__ void reload() {
+    const i32 byteIdx = ((pos + 7) >> 3) - 8;
+    while (byteIdx <= gtop - 8) { g0 = g1; g1 = g2; gtop -= 8; g2 = grid(gtop - 16); }
+    const u32 d = (u32)(gtop - byteIdx);               // 0..7 bytes of g1 under the window
+    w = d ? ((g0 << (8 * d)) | (g1 >> (64 - 8 * d))) : g0;
+    wlo = byteIdx * 8;
+  }
+  __device__ __forceinline__ int init(const u8* b, u32 n, const u8* bufLim) {
+    base = b; lim = bufLim;
+    if (n == 0) return 1;
+    u32 last = b[n - 1];
+    if (last == 0) return 1;
+    pos = (i32)(n - 1) * 8 + (i32)hb32(last);
+    gtop = ((pos + 7) >> 3) - 8;
+    g0 = grid(gtop); g1 = grid(gtop - 8); g2 = grid(gtop - 16);
+    w = g0; wlo = gtop * 8;
+    return 0;
+  }
+  __device__ __forceinline__ void ensure(int nb) { if (pos - wlo < nb) reload(); }
+  __device__ __forceinline__ u32 peek(int nb) const { return (u32)((w >> (pos - nb - wlo)) & ((1ull << nb) - 1)); }
+  __device__ __forceinline__ void skip(int nb) { pos -= nb; }
+};
+
+
 // ---- XXH64 (seed 0), zstd content checksum
 constexpr u64 XP1 = 11400714785074694791ULL, XP2 = 14029467366897019727ULL, XP3 = 1609587929392839161ULL,
               XP4 = 9650029242287828579ULL, XP5 = 2870177450012600261ULL;
