@@ -731,6 +731,7 @@ struct HCW {
   // reference never follows that link once i is inserted (i - chainSize is below its minChain by then), but a window is inserted
   // AHEAD of the positions searched in it, so the links it overwrote (at most 66, ring of 128 by index) are kept in LDS
   u32* oldLink;
+  volatile u8* dup;      // 1024 byte slots: which lanes of an insert step may share a bucket (hcw_insert)
 };
 
 __device__ __forceinline__ void hcw_sync() {
@@ -761,9 +762,21 @@ __device__ void hcw_insert(HCW& H, const u8* src, u32 endIdx, int lane) {
     const bool act = idx < endIdx;
     u32 h = 0, link = 0;
     if (act) { h = hashN(src + idx - 1, H.hlog, H.mls); link = H.hashT[h]; }
-    // lanes with the same bucket: each links to the nearest earlier one, the last one becomes the head
+    // lanes with the same bucket: each links to the nearest earlier one, the last one becomes the head. Most lanes share their bucket
+    // with nobody (43 distinct buckets per step on average): two rounds through 1024 byte slots in LDS (slot = low hash bits, value =
+    // lane) find every lane of a shared bucket — the lanes that lose a slot in round one, and in round two the winner they lost to —
+    // plus a few that only share a slot; the exact grouping below runs over those only. (A wave's LDS accesses execute in issue
+    // order: volatile accesses and a scheduling barrier are all the ordering it takes.)
     bool head = act;
-    u64 rem = __ballot(act);
+    const u32 slot = h & 1023u;
+    if (act) H.dup[slot] = (u8)lane;
+    __builtin_amdgcn_wave_barrier();
+    const bool lost = act && H.dup[slot] != (u8)lane;
+    __builtin_amdgcn_wave_barrier();
+    if (lost) H.dup[slot] = (u8)lane;
+    __builtin_amdgcn_wave_barrier();
+    const bool shared = act && (lost || H.dup[slot] != (u8)lane);
+    u64 rem = __ballot(shared);
     while (rem) {
       const u32 l = (u32)__builtin_ctzll(rem);
       const u32 hv = bcast(h, l);
@@ -1111,7 +1124,7 @@ zra_mf_dfast_kernel(ZraEncArgs a, u32 block, u32 only, u32 onlySlot) {
 // their tables. `only` = 0xFFFFFFFF: every frame of the batch; otherwise just that frame (the short last frame whose strategy differs
 // from the batch's), launched as one workgroup on table slot `onlySlot`.
 template <bool OPT>
-__device__ __forceinline__ void mf_generic(const ZraEncArgs& a, u32 block, u32 only, u32 onlySlot, u32 perWave, u32* hcOld) {
+__device__ __forceinline__ void mf_generic(const ZraEncArgs& a, u32 block, u32 only, u32 onlySlot, u32 perWave, u32* hcOld, u8* hcDup) {
   const int lane = threadIdx.x;
   const bool all = only == 0xFFFFFFFFu;
   if (!all) perWave = 1;
@@ -1143,7 +1156,7 @@ __device__ __forceinline__ void mf_generic(const ZraEncArgs& a, u32 block, u32 o
     if (cur > ntu + 384) { const u32 d = cur - ntu - 384; ntu = cur - (d < 192 ? d : 192); }
   }
   if (coop) {
-    HCW H; H.oldLink = hcOld; H.hashT = hashT; H.chainT = chainT; H.hlog = P.hashLog; H.mls = P.minMatch < 4 ? 4 : P.minMatch > 6 ? 6 : P.minMatch;
+    HCW H; H.oldLink = hcOld; H.dup = hcDup; H.hashT = hashT; H.chainT = chainT; H.hlog = P.hashLog; H.mls = P.minMatch < 4 ? 4 : P.minMatch > 6 ? 6 : P.minMatch;
     H.chainSize = 1u << P.chainLog; H.cmask = H.chainSize - 1; H.searchLog = P.searchLog;
     H.insEnd = st->insEnd; H.ntuRef = ntu;
     for (u32 i = (u32)lane; i < 128; i += 64) hcOld[i] = st->ring[i];
@@ -1170,12 +1183,14 @@ __device__ __forceinline__ void mf_generic(const ZraEncArgs& a, u32 block, u32 o
 extern "C" __global__ void __launch_bounds__(64)
 zra_mf_kernel(ZraEncArgs a, u32 block, u32 only, u32 onlySlot, u32 perWave) {
   __shared__ u32 hcOld[128];
-  mf_generic<false>(a, block, only, onlySlot, perWave, hcOld);
+  __shared__ u8 hcDup[1024];
+  mf_generic<false>(a, block, only, onlySlot, perWave, hcOld, hcDup);
 }
 extern "C" __global__ void __launch_bounds__(64)
 zra_mf_opt_kernel(ZraEncArgs a, u32 block, u32 only, u32 onlySlot, u32 perWave) {
   __shared__ u32 hcOld[128];
-  mf_generic<true>(a, block, only, onlySlot, perWave, hcOld);
+  __shared__ u8 hcDup[1024];
+  mf_generic<true>(a, block, only, onlySlot, perWave, hcOld, hcDup);
 }
 
 // Match finder for batches whose full-size frames use "fast" (levels 1-2 and all negative levels): lane = frame, `perWave` frames in
@@ -1230,7 +1245,8 @@ zra_mf_hc_kernel(ZraEncArgs a, u32 block) {
     if (cur > ntu + 384) { const u32 d = cur - ntu - 384; ntu = cur - (d < 192 ? d : 192); }
   }
   __shared__ u32 hcOld[128];
-  HCW H; H.oldLink = hcOld; H.hashT = F.hashT; H.chainT = F.chainT; H.hlog = P.hashLog; H.mls = P.minMatch < 4 ? 4 : P.minMatch > 6 ? 6 : P.minMatch;
+  __shared__ u8 hcDup[1024];
+  HCW H; H.oldLink = hcOld; H.dup = hcDup; H.hashT = F.hashT; H.chainT = F.chainT; H.hlog = P.hashLog; H.mls = P.minMatch < 4 ? 4 : P.minMatch > 6 ? 6 : P.minMatch;
   H.chainSize = 1u << P.chainLog; H.cmask = H.chainSize - 1; H.searchLog = P.searchLog;
   H.insEnd = st->insEnd; H.ntuRef = ntu;
   for (u32 i = (u32)lane; i < 128; i += 64) hcOld[i] = st->ring[i];
