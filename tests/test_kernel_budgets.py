@@ -16,7 +16,7 @@ BUDGET = {
     "zra_mf_hc_kernel": (64, 0),         # one wave per frame, as many waves per CU as the hardware holds
     "zra_mf_fast_kernel": (64, 232),     # lane = frame; the scratch is the per-lane frame descriptor
     "zra_mf_kernel": (96, 240),          # generic one-lane finder without the optimal parsers (btlazy2, frames beyond the window, odd tails)
-    "zra_mf_opt_kernel": (136, 364),     # ... with them (levels 13-22)
+    "zra_mf_opt_kernel": (136, 400),     # ... with them (levels 13-22; its scratch holds the parser's small arrays)
     "zra_dec_chain_kernel": (72, 0),     # lane = frame FSE chains
     "zra_dec_huf_kernel": (72, 0),
     "zra_dec_parse_kernel": (168, 0),
