@@ -106,7 +106,7 @@ _random_input = C.random_lz_input
 def test_randomised_differential_compress(zra, seed):
     """Differential test against the oracle on seeded synthetic LZ data: random sizes, frame sizes and levels (25 cases per seed).
     Seeds from 2000 on add frames beyond 256 KiB (the "default" parameter table, up to ten 128 KiB blocks per frame).
-    Seed 386 (found by the soak, tests/gpu_soak.py): level 5 @ 128 KiB, a chain table smaller than the frame — the window-ahead
+    Seed 386 (found by the soak, tools/bringup/gpu_soak.py): level 5 @ 128 KiB, a chain table smaller than the frame — the window-ahead
     insertion of the hash-chain finder overwrote chain links the search still needed."""
     rng = np.random.RandomState(1000 + seed)
     for case in range(25):

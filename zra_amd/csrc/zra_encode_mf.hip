@@ -463,6 +463,15 @@ struct LeanLds {
   __device__ __forceinline__ void markS(u32 b) const { const u32 g = b >> shS; atomicOr(&bmS[g >> 5], 1u << (g & 31)); }
 };
 
+// table accesses of the lean dfast parse: with -DZRA_MF_NT they carry the non-temporal hint (bring-up A/B: do the random table lines
+// leave the L2 to the frame's source bytes?)
+#ifdef ZRA_MF_NT
+#define TLD(p) __builtin_nontemporal_load(p)
+#define TST(p, v) __builtin_nontemporal_store((u32)(v), p)
+#else
+#define TLD(p) (*(p))
+#define TST(p, v) (*(p) = (v))
+#endif
 template <u32 MLS>
 __device__ u32 mf_dfast_lean(const ZraEncParams& P, u32* HL, u32* HS, const u8* src, u32 bs, u32 be, u32* rep, u64* seqs, u32* nOut,
                              const LeanLds& W, int lane, u32 ib) {
@@ -490,8 +499,8 @@ __device__ u32 mf_dfast_lean(const ZraEncParams& P, u32* HL, u32* HS, const u8* 
   auto insert_slow = [&](u32 pos, bool doL, bool doS) {
     if (lane == 0) {
       u32 bl, bs_, tl, ts; H.both(ld64(src + pos), bl, bs_, tl, ts);
-      if (doL) { HL[bl] = (pos + 1) | tl; W.markL(bl); }
-      if (doS) { HS[bs_] = (pos + 1) | ts; W.markS(bs_); }
+      if (doL) { TST(HL + bl, (pos + 1) | tl); W.markL(bl); }
+      if (doS) { TST(HS + bs_, (pos + 1) | ts); W.markS(bs_); }
     }
   };
   while (ip < ilimit) {
@@ -532,7 +541,7 @@ __device__ u32 mf_dfast_lean(const ZraEncParams& P, u32* HL, u32* HS, const u8* 
     u32 mL = 0, mS = 0;
     if (active) {
       const bool needL = (bmL[wL] & qL) != 0, needS = (bmS[wS] & qS) != 0;
-      const u32 rL = needL ? HL[bL] : 0u, rS = needS ? HS[bS] : 0u;
+      const u32 rL = needL ? TLD(HL + bL) : 0u, rS = needS ? TLD(HS + bS) : 0u;
       mL = ((rL & H.tagMask) == tL) ? (rL & idxMask) : 0u;
       mS = ((rS & H.tagMask) == tS) ? (rS & idxMask) : 0u;
     }
@@ -557,7 +566,7 @@ __device__ u32 mf_dfast_lean(const ZraEncParams& P, u32* HL, u32* HS, const u8* 
       const u64 live = AM & (~0ull << cur);
       const u64 hm = (RH | LH | SH) & live;
       if (!hm) {
-        if (lane_in(live)) { HL[bL] = valL; HS[bS] = valS; atomicOr(&bmL[wL], qL); atomicOr(&bmS[wS], qS); }
+        if (lane_in(live)) { TST(HL + bL, valL); TST(HS + bS, valS); atomicOr(&bmL[wL], qL); atomicOr(&bmS[wS], qS); }
         ip = wip + nAct * s; PROF(4)
         break;
       }
@@ -576,16 +585,16 @@ __device__ u32 mf_dfast_lean(const ZraEncParams& P, u32* HL, u32* HS, const u8* 
         else {
           PROF_CNT(15)
           // the probed bucket is not covered by the window's no-duplicate guarantee: commit the visited positions first
-          if (lane_in(mkL)) { HL[bL] = valL; atomicOr(&bmL[wL], qL); }
-          if (lane_in(mkS)) { HS[bS] = valS; atomicOr(&bmS[wS], qS); }
+          if (lane_in(mkL)) { TST(HL + bL, valL); atomicOr(&bmL[wL], qL); }
+          if (lane_in(mkS)) { TST(HS + bS, valS); atomicOr(&bmS[wS], qS); }
           mkL = 0; mkS = 0;
           u32 m3v = 0; bool h3v = false;                // rare: done on lane 0's vector path (keeps the parse state scalar)
           if (lane == 0) {
             const u64 v9 = ld64(src + top + 1);
             u32 b3, bx, t3, tx; H.both(v9, b3, bx, t3, tx);
-            const u32 r3 = HL[b3];
+            const u32 r3 = TLD(HL + b3);
             m3v = ((r3 & H.tagMask) == t3) ? (r3 & idxMask) : 0u;
-            HL[b3] = (top + 2) | t3; W.markL(b3);
+            TST(HL + b3, (top + 2) | t3); W.markL(b3);
             h3v = m3v > 1 && ld64(src + m3v - 1) == v9;
           }
           hit3 = __ballot(h3v) & 1; m3 = bcast(m3v, 0);
@@ -632,8 +641,8 @@ __device__ u32 mf_dfast_lean(const ZraEncParams& P, u32* HL, u32* HS, const u8* 
       ip += ml; anchor = ip;
       PROF(7) PROF_CNT(13)
       if (ip > ilimit) {
-        if (lane_in(mkL)) { HL[bL] = valL; atomicOr(&bmL[wL], qL); }
-        if (lane_in(mkS)) { HS[bS] = valS; atomicOr(&bmS[wS], qS); }
+        if (lane_in(mkL)) { TST(HL + bL, valL); atomicOr(&bmL[wL], qL); }
+        if (lane_in(mkS)) { TST(HS + bS, valS); atomicOr(&bmS[wS], qS); }
         break;
       }
       // ---- complementary insertions (top+2 into both tables, then ip-2 long / ip-1 short) and the immediate repcode test
@@ -644,8 +653,8 @@ __device__ u32 mf_dfast_lean(const ZraEncParams& P, u32* HL, u32* HS, const u8* 
       if (in2) { mkL |= bit64(f + 2); mkS |= bit64(f + 2); }
       if (s == 1 && relE - 2 < nAct) mkL |= bit64(relE - 2);
       if (inE) mkS |= bit64(relE - 1);
-      if (lane_in(mkL)) { HL[bL] = valL; atomicOr(&bmL[wL], qL); }
-      if (lane_in(mkS)) { HS[bS] = valS; atomicOr(&bmS[wS], qS); }
+      if (lane_in(mkL)) { TST(HL + bL, valL); atomicOr(&bmL[wL], qL); }
+      if (lane_in(mkS)) { TST(HS + bS, valS); atomicOr(&bmS[wS], qS); }
       u32 here = 0, there = 1;
       const bool thereIn = inI && repOldFor == o2 && ((ROV >> (relE - 1)) & 1);   // src[ip - o2] == old rep gather of lane ip-1-wip
       if (in2 && inE && (o2 == 0 || thereIn)) {
@@ -659,10 +668,10 @@ __device__ u32 mf_dfast_lean(const ZraEncParams& P, u32* HL, u32* HS, const u8* 
         u32* const tp = (lane & 1) ? HS + xbS : HL + xbL;
         const u32 tv = (ipos + 1) | ((lane & 1) ? xtS : xtL);
         if (lane < 4) { if (lane & 1) W.markS(xbS); else W.markL(xbL); }     // (a superset of the stores below: harmless)
-        if (!in2 && lane < 2) *tp = tv;                                    // top+2 first ...
+        if (!in2 && lane < 2) TST(tp, tv);                                    // top+2 first ...
         asm volatile("" ::: "memory");                                     // two instructions: lanes 0/2 (1/3) may hit the same bucket
         const u64 later = (s == 1 && relE - 2 < nAct ? 0ull : 4ull) | (inE ? 0ull : 8ull);
-        if (lane_in(later)) *tp = tv;                                      // ... then ip-2 / ip-1 (same-bucket order per table)
+        if (lane_in(later)) TST(tp, tv);                                      // ... then ip-2 / ip-1 (same-bucket order per table)
         here = bcast((u32)x, 4); there = o2 ? bcast((u32)x, 5) : here + 1;
         if (o2 == 0) { here = 0; there = 1; }
       }
