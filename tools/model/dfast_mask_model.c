@@ -24,7 +24,7 @@ static inline void sset(s128* s, u32 x) { if (x < 64) s->lo |= 1ull << x; else i
 static inline u32 srun(s128 s, u32 x0) { u32 r = 0; while (x0 + r < 128 && sbit(s, x0 + r)) r++; return r; }
 static inline int s4(s128 s, u32 x) { return sbit(s, x) && sbit(s, x + 1) && sbit(s, x + 2) && sbit(s, x + 3); }
 
-static struct { u64 windows, seqs, slowFwd, slowBack, slowRep, refresh, oow, probeSlow, pass2, cuts, repSeq, immRep, lanesE, strideWin; } ST;
+static struct { u64 windows, seqs, slowFwd, slowBack, slowRep, refresh, oow, probeSlow, pass2, cuts, repSeq, immRep, lanesE, strideWin, barrier, patched, laterSlow; } ST;
 
 typedef struct {
   u32 hlog, clog, mls, ib, tagMask, idxMask;
@@ -71,6 +71,7 @@ static size_t model_dfast(cctx* c, MD* M, const u8* src, u32 fsize, u32 bs, u32 
   u32 anchor = bs;
   const u32 ilimit = be >= 8 ? be - 8 : 0;
   u32 ip = (u32)mf_prologue(c, bs, 0, &o1, &o2, &saved);
+  u64 pendL = 0, pendS = 0; u32 pendG = 0xFFFFFFFFu;        /* insertions handed to the next window: lanes of chunk pendG */
   while (ip < ilimit) {
     /* ------------------------------------------------ window build */
     ST.windows++;
@@ -82,17 +83,29 @@ static size_t model_dfast(cctx* c, MD* M, const u8* src, u32 fsize, u32 bs, u32 
       s = (run >> 8) + 1; g = ip; l0 = 0; l1 = (256 * s - run + s - 1) / s; u32 t = (ilimit - ip + s - 1) / s; if (t < l1) l1 = t; if (l1 > 64) l1 = 64;
       ST.strideWin++;
     }
+    if (pendG != g || s != 1) { if (pendL | pendS) { fprintf(stderr, "model: pending insertions for another window\n"); abort(); } }
     u32 p[64], bL[64], bS[64], tL[64], tS[64], mL[64], mS[64], cand[64], E1[64], kn[64], bk[64], bkK[64];
     u64 v8[64], E0[64];
-    for (u32 l = l0; l < l1; l++) { p[l] = g + l * s; v8[l] = rd64(src + p[l]); md_hash(M, v8[l], &bL[l], &bS[l], &tL[l], &tS[l]); }
-    /* duplicate buckets: cut at the first lane with an earlier bucket-mate */
-    for (u32 j = l0 + 1; j < l1; j++) {
-      int dup = 0;
-      for (u32 i = l0; i < j; i++) if (bL[i] == bL[j] || bS[i] == bS[j]) { dup = 1; break; }
-      if (dup) { l1 = j; ST.cuts++; break; }
+    /* every lane of the chunk whose 8 bytes lie inside the block is hashed (pending lanes sit below l0) */
+    u64 HM = 0;
+    for (u32 l = 0; l < 64; l++) {
+      p[l] = g + l * s;
+      if (p[l] + 8 > be || (l < l0 && !(((pendL | pendS) >> l) & 1)) || l >= l1) { bL[l] = bS[l] = 0xFFFFFFFFu; continue; }
+      v8[l] = rd64(src + p[l]); md_hash(M, v8[l], &bL[l], &bS[l], &tL[l], &tS[l]); HM |= 1ull << l;
     }
     u64 AM = 0; for (u32 l = l0; l < l1; l++) AM |= 1ull << l;
-    /* filter + table gather */
+    /* D: lanes that share a bucket with another hashed lane of the window (the kernel: LDS slot collisions, a superset) */
+    u64 D = 0;
+    for (u32 j = 0; j < 64; j++) if ((HM >> j) & 1) for (u32 i = 0; i < 64; i++) if (i != j && ((HM >> i) & 1) && (bL[i] == bL[j] || bS[i] == bS[j])) { D |= 1ull << j; break; }
+    if (D) ST.cuts++;
+    /* pending insertions first (the latest position of a bucket wins), then the gather */
+#define STORE_MASKED(mkL_, mkS_) do { u64 a_ = (mkL_), b_ = (mkS_); \
+      for (u32 l_ = 0; l_ < 64; l_++) if (((a_ & D) >> l_) & 1) for (u32 k_ = l_ + 1; k_ < 64; k_++) if (((a_ >> k_) & 1) && bL[k_] == bL[l_]) { a_ &= ~(1ull << l_); break; } \
+      for (u32 l_ = 0; l_ < 64; l_++) if (((b_ & D) >> l_) & 1) for (u32 k_ = l_ + 1; k_ < 64; k_++) if (((b_ >> k_) & 1) && bS[k_] == bS[l_]) { b_ &= ~(1ull << l_); break; } \
+      for (int l_ = 63; l_ >= 0; l_--) { \
+        if ((a_ >> l_) & 1) { M->HL[bL[l_]] = (p[l_] + 1) | tL[l_]; md_markL(M, bL[l_]); } \
+        if ((b_ >> l_) & 1) { M->HS[bS[l_]] = (p[l_] + 1) | tS[l_]; md_markS(M, bS[l_]); } } } while (0)
+    STORE_MASKED(pendL, pendS); pendL = pendS = 0; pendG = 0xFFFFFFFFu;
     for (u32 l = l0; l < l1; l++) {
       u32 gL = bL[l] >> M->shL, gS = bS[l] >> M->shS;
       int needL = (M->bmL[gL >> 5] >> (gL & 31)) & 1, needS = (M->bmS[gS >> 5] >> (gS & 31)) & 1;
@@ -100,23 +113,21 @@ static size_t model_dfast(cctx* c, MD* M, const u8* src, u32 fsize, u32 bs, u32 
       mL[l] = ((rL & M->tagMask) == tL[l]) ? (rL & M->idxMask) : 0;
       mS[l] = ((rS & M->tagMask) == tS[l]) ? (rS & M->idxMask) : 0;
     }
-    /* candidate masks: primary = long if it has one, else short; a long candidate that fails its 8 bytes retries with the short one */
-    u64 LH = 0, SH = 0, HASE = 0;
+    u64 LH = 0, SH = 0;
     for (u32 l = l0; l < l1; l++) {
       int prim = mL[l] > 1 ? 2 : mS[l] > 1 ? 1 : 0;
       if (!prim) continue;
       cand[l] = (prim == 2 ? mL[l] : mS[l]) - 1;
       lane_E(src, fsize, be, p[l], cand[l], &E0[l], &E1[l], &kn[l], &bk[l], &bkK[l]); ST.lanesE++;
       if (prim == 2) {
-        if ((E0[l] & 0xFF) == 0xFF) { LH |= 1ull << l; HASE |= 1ull << l; continue; }
+        if ((E0[l] & 0xFF) == 0xFF) { LH |= 1ull << l; continue; }
         if (mS[l] <= 1) continue;
         ST.pass2++;
         cand[l] = mS[l] - 1;
         lane_E(src, fsize, be, p[l], cand[l], &E0[l], &E1[l], &kn[l], &bk[l], &bkK[l]);
       }
-      if ((E0[l] & 0xF) == 0xF) { SH |= 1ull << l; HASE |= 1ull << l; }
+      if ((E0[l] & 0xF) == 0xF) SH |= 1ull << l;
     }
-    /* equality streams of the two repeat offsets over positions g + [0,128) (stride-1 windows) */
     s128 EQA = {0, 0}, EQB = {0, 0}; u32 hiA = 0, hiB = 0;
     u64 RHa = 0, RHb = 0;
     if (s == 1) {
@@ -130,16 +141,43 @@ static size_t model_dfast(cctx* c, MD* M, const u8* src, u32 fsize, u32 bs, u32 
     } else {
       for (u32 l = l0; l < l1; l++) if (o1 > 0 && p[l] + 1 >= o1 && rd32(src + p[l] + 1 - o1) == rd32(src + p[l] + 1)) RHa |= 1ull << l;
     }
-    const u32 valLtag = 0; (void)valLtag;
     /* ------------------------------------------------ resolve */
-    u64 insL = 0, insS = 0;
+    u64 insL = 0, insS = 0, Dres = 0;                            /* Dres: shared-bucket lanes whose candidates are settled */
+    u32 patLane = 64, patCand = 0; int patLong = 0;              /* the one lane whose candidate came from an in-window insertion */
     u32 cur = l0;
-#define FLUSH() do { for (u32 l_ = 0; l_ < 64; l_++) { \
-      if ((insL >> l_) & 1) { M->HL[bL[l_]] = (p[l_] + 1) | tL[l_]; md_markL(M, bL[l_]); } \
-      if ((insS >> l_) & 1) { M->HS[bS[l_]] = (p[l_] + 1) | tS[l_]; md_markS(M, bS[l_]); } } insL = insS = 0; } while (0)
+    /* positions beyond this window that the parse inserts: lanes of the next chunk when that is the next window, else stored now */
+    u32 laterPos[8]; int laterL[8], laterS[8]; int nLater = 0;
+#define FLUSH() do { STORE_MASKED(insL, insS); insL = insS = 0; } while (0)
+    /* settle lane d's table candidates against the insertions this window has made so far (lanes below `lim`) */
+#define SETTLE(d, lim, doS_) do { \
+      u64 cmL_ = 0, cmS_ = 0; const u64 bel_ = (lim) == 0 ? 0 : (~0ull >> (64 - (lim))); ST.slowBack += 0; \
+      for (u32 i_ = 0; i_ < 64; i_++) { if (((insL & bel_) >> i_) & 1 && bL[i_] == bL[d]) cmL_ |= 1ull << i_; if ((doS_) && ((insS & bel_) >> i_) & 1 && bS[i_] == bS[d]) cmS_ |= 1ull << i_; } \
+      ST.barrier++; \
+      if (cmL_ | cmS_) { ST.patched++; \
+        u32 nL_ = mL[d], nS_ = mS[d]; \
+        if (cmL_) { u32 i_ = 63 - (u32)__builtin_clzll(cmL_); nL_ = tL[i_] == tL[d] ? p[i_] + 1 : 0; } \
+        if (cmS_) { u32 i_ = 63 - (u32)__builtin_clzll(cmS_); nS_ = tS[i_] == tS[d] ? p[i_] + 1 : 0; } \
+        /* re-evaluate the lane with the candidates the tables hold now (the kernel: one small round trip) */ \
+        const int wasL_ = (LH >> d) & 1; \
+        if (cmL_) { LH &= ~(1ull << d); if (nL_ > 1 && rd64(src + nL_ - 1) == v8[d]) { LH |= 1ull << d; patLane = d; patCand = nL_ - 1; patLong = 1; } } \
+        if (!((LH >> d) & 1) && (doS_) && (cmS_ || (cmL_ && wasL_))) { SH &= ~(1ull << d); \
+          if (nS_ > 1 && rd32(src + nS_ - 1) == (u32)v8[d]) { SH |= 1ull << d; patLane = d; patCand = nS_ - 1; patLong = 0; } } \
+      } } while (0)
     for (;;) {
       const u64 live = AM & (~0ull << cur);
-      const u64 hm = (RHa | LH | SH) & live;
+      const u64 Dl = D & live & ~Dres;
+      const u32 h = Dl ? (u32)__builtin_ctzll(Dl) : 64;
+      const u64 below = h >= 64 ? live : live & ((1ull << h) - 1);
+      u64 hm = (RHa | LH | SH) & below;
+      if (!hm && h < 64) {
+        if ((RHa >> h) & 1) hm = 1ull << h;                     /* a repcode hit needs no table */
+        else {
+          const u64 upto_ = live & ((1ull << h) - 1);          /* the lanes before h are visited without a hit */
+          insL |= upto_; insS |= upto_;
+          SETTLE(h, h, 1); Dres |= 1ull << h; cur = h;
+          continue;
+        }
+      }
       if (!hm) { insL |= live; insS |= live; FLUSH(); ip = g + l1 * s; break; }
       const u32 f = (u32)__builtin_ctzll(hm);
       const u64 upto = live & ((2ull << f) - 1);                 /* visited lanes cur..f */
@@ -156,13 +194,14 @@ static size_t model_dfast(cctx* c, MD* M, const u8* src, u32 fsize, u32 bs, u32 
         if (slow) { ST.slowRep++; ml = (u32)count_eq(src, ip + 4, ip + 4 - o1, be) + 4; }
         else ml = r;
       } else {
-        u32 fE = f; int haveE = 1; u32 m = 0;
+        u32 fE = f; int haveE = !(patLane == f); u32 m = haveE ? 0 : patCand;
         if (!isLong) {
           if (s == 1 && f + 1 < l1) {
+            if (((D & ~Dres) >> (f + 1)) & 1) { SETTLE(f + 1, f + 1, 0); Dres |= 1ull << (f + 1); }   /* the probe reads the long table only */
             insL |= 1ull << (f + 1);
-            if ((LH >> (f + 1)) & 1) { fE = f + 1; ip = top + 1; }
+            if ((LH >> (f + 1)) & 1) { fE = f + 1; ip = top + 1; haveE = !(patLane == f + 1); if (!haveE) m = patCand; }
           } else {
-            /* the probed bucket is outside the window's no-duplicate guarantee: commit first, then probe on one lane */
+            /* the probed position is outside the window: commit first, then probe on one lane */
             ST.probeSlow++;
             FLUSH();
             u64 v9 = rd64(src + top + 1); u32 b3, bx, t3, tx; md_hash(M, v9, &b3, &bx, &t3, &tx);
@@ -172,6 +211,7 @@ static size_t model_dfast(cctx* c, MD* M, const u8* src, u32 fsize, u32 bs, u32 
           }
         }
         u32 back;
+        const u32 known = (isLong || ip != top) ? 8 : 4;
         if (haveE) {
           m = cand[fE];
           u32 r = E0[fE] == ~0ull ? 64 + (u32)__builtin_ctz(~E1[fE]) : (u32)__builtin_ctzll(~E0[fE]);
@@ -183,16 +223,15 @@ static size_t model_dfast(cctx* c, MD* M, const u8* src, u32 fsize, u32 bs, u32 
           else back = bk[fE] < blim ? bk[fE] : blim;
         } else {
           ST.slowFwd++;
-          ml = 8 + (u32)count_eq(src, ip + 8, m + 8, be);
+          ml = known + (u32)count_eq(src, ip + known, m + known, be);
           const u32 blim = ip - anchor < m ? ip - anchor : m;
           back = 0; while (back < blim && src[ip - 1 - back] == src[m - 1 - back]) back++;
         }
         const u32 off = ip - m;
-        /* streams: offset_2 takes offset_1's, offset_1's comes from E */
         EQB = EQA; hiB = hiA; RHb = RHa;
         EQA.lo = EQA.hi = 0; hiA = 0; RHa = 0;
         if (s == 1 && haveE) {
-          const u32 xE = ip - g;                                  /* position E is relative to (before the backward extension) */
+          const u32 xE = ip - g;
           const u32 lim = kn[fE] < be - ip ? kn[fE] : be - ip;
           for (u32 j = 0; j < lim; j++) { int b = j < 64 ? (int)((E0[fE] >> j) & 1) : (int)((E1[fE] >> (j - 64)) & 1); if (b) sset(&EQA, xE + j); }
           hiA = (ip + kn[fE] >= be) ? 128 : (xE + kn[fE] < 128 ? xE + kn[fE] : 128);
@@ -207,39 +246,34 @@ static size_t model_dfast(cctx* c, MD* M, const u8* src, u32 fsize, u32 bs, u32 
       /* complementary insertions (top+2 both tables, ip-2 long, ip-1 short) and the immediate repcode test */
       const u32 x = ip - g;
       const int in2 = s == 1 && f + 2 < l1, inE2 = s == 1 && x - 2 < l1, inE1 = s == 1 && x - 1 < l1;
-      if (in2) { insL |= 1ull << (f + 2); insS |= 1ull << (f + 2); }
-      if (inE2) insL |= 1ull << (x - 2);
-      if (inE1) insS |= 1ull << (x - 1);
-      int repKnown = s == 1 && (o2 == 0 || x + 4 <= hiB);
+      if (in2) { insL |= 1ull << (f + 2); insS |= 1ull << (f + 2); } else { laterPos[nLater] = top + 2; laterL[nLater] = 1; laterS[nLater] = 1; nLater++; }
+      if (inE2) insL |= 1ull << (x - 2); else { laterPos[nLater] = ip - 2; laterL[nLater] = 1; laterS[nLater] = 0; nLater++; }
+      if (inE1) insS |= 1ull << (x - 1); else { laterPos[nLater] = ip - 1; laterL[nLater] = 0; laterS[nLater] = 1; nLater++; }
       int here_eq_there;
-      if (in2 && inE2 && inE1 && repKnown) here_eq_there = o2 > 0 && s4(EQB, x);
-      else {
-        ST.oow++;
-        FLUSH();
-        if (!in2) md_insert(M, src, top + 2, 1, 1);
-        if (!inE2) md_insert(M, src, ip - 2, 1, 0);
-        if (!inE1) md_insert(M, src, ip - 1, 0, 1);
-        here_eq_there = o2 > 0 && rd32(src + ip) == rd32(src + ip - o2);
-      }
+      if (s == 1 && (o2 == 0 || x + 4 <= hiB)) here_eq_there = o2 > 0 && s4(EQB, x);
+      else { ST.oow++; here_eq_there = o2 > 0 && rd32(src + ip) == rd32(src + ip - o2); }
       while (here_eq_there) {
         ST.immRep++;
         const u32 xx = ip - g;
-        u32 rl; int slow = 1;
+        u32 rl = 0; int slow = 1;
         if (s == 1 && xx + 4 <= hiB) { u32 r = srun(EQB, xx); slow = (xx + r >= hiB) && (g + hiB < be); rl = r; }
         if (slow) { ST.slowRep++; rl = (u32)count_eq(src, ip + 4, ip + 4 - o2, be) + 4; }
         { u32 t = o2; o2 = o1; o1 = t; s128 ts = EQA; EQA = EQB; EQB = ts; u32 th = hiA; hiA = hiB; hiB = th; u64 tr = RHa; RHa = RHb; RHb = tr; }
         if (s == 1 && xx < l1) { insL |= 1ull << xx; insS |= 1ull << xx; }
-        else { FLUSH(); md_insert(M, src, ip, 1, 1); }
+        else { laterPos[nLater] = ip; laterL[nLater] = 1; laterS[nLater] = 1; nLater++; }
         emit(c, src, anchor, 0, rl, 1); ST.seqs++;
         ip += rl; anchor = ip;
         if (!(ip <= ilimit && o2 > 0)) break;
         const u32 xn = ip - g;
         if (s == 1 && xn + 4 <= hiB) here_eq_there = s4(EQB, xn);
-        else here_eq_there = rd32(src + ip) == rd32(src + ip - o2);
+        else { ST.oow++; here_eq_there = rd32(src + ip) == rd32(src + ip - o2); }
+        if (nLater > 4 && here_eq_there) {                     /* keep the list short: store what has piled up */
+          FLUSH(); for (int k = 0; k < nLater; k++) md_insert(M, src, laterPos[k], laterL[k], laterS[k]); nLater = 0;
+        }
       }
       if (s != 1 || ip >= g + l1 || ip >= ilimit) { FLUSH(); break; }
       cur = ip - g;
-      /* the rep-hit mask of the remaining lanes needs stream bits up to l1 + 3 */
+      if (nLater) { fprintf(stderr, "model: later insertions although the window goes on\n"); abort(); }
       if (hiA < l1 + 4 && o1 > 0) {
         ST.refresh++;
         EQA.lo = EQA.hi = 0; RHa = 0;
@@ -248,7 +282,18 @@ static size_t model_dfast(cctx* c, MD* M, const u8* src, u32 fsize, u32 bs, u32 
         for (u32 l = 0; l < 64; l++) if (s4(EQA, l + 1)) RHa |= 1ull << l;
       }
     }
+    /* hand the insertions behind the window to the next one, or store them now */
+    if (nLater) {
+      const int nextS1 = ip < ilimit && ip - anchor < 256;
+      const u32 gN = ip & ~63u;
+      for (int k = 0; k < nLater; k++) {
+        const u32 q = laterPos[k];
+        if (nextS1 && q >= gN && q < gN + 64 && q + 8 <= be) { if (laterL[k]) pendL |= 1ull << (q - gN); if (laterS[k]) pendS |= 1ull << (q - gN); pendG = gN; }
+        else { ST.laterSlow++; md_insert(M, src, q, laterL[k], laterS[k]); }
+      }
+    }
   }
+  if (pendL | pendS) { fprintf(stderr, "model: pending insertions at the block end\n"); abort(); }
   rep[0] = o1 ? o1 : saved; rep[1] = o2 ? o2 : saved;
   return be - anchor;
 }
@@ -317,9 +362,9 @@ int main(int argc, char** argv) {
       if (na != nm || memcmp(a, m, na * sizeof(zo_seq))) bad++;
       frames++;
     }
-    printf("frames %zu bad %zu | per frame: windows %.0f seqs %.0f repSeq %.0f immRep %.0f lanesE %.0f cuts %.0f | slowFwd %.1f slowBack %.1f slowRep %.1f refresh %.1f oow %.1f probeSlow %.1f pass2 %.2f strideWin %.1f\n",
+    printf("frames %zu bad %zu | per frame: windows %.0f seqs %.0f repSeq %.0f immRep %.0f lanesE %.0f cuts %.0f | slowFwd %.1f slowBack %.1f slowRep %.1f refresh %.1f oow %.1f probeSlow %.1f pass2 %.2f strideWin %.1f barrier %.1f patched %.1f laterSlow %.1f\n",
            frames, bad, (double)ST.windows / frames, (double)ST.seqs / frames, (double)ST.repSeq / frames, (double)ST.immRep / frames, (double)ST.lanesE / frames, (double)ST.cuts / frames,
-           (double)ST.slowFwd / frames, (double)ST.slowBack / frames, (double)ST.slowRep / frames, (double)ST.refresh / frames, (double)ST.oow / frames, (double)ST.probeSlow / frames, (double)ST.pass2 / frames, (double)ST.strideWin / frames);
+           (double)ST.slowFwd / frames, (double)ST.slowBack / frames, (double)ST.slowRep / frames, (double)ST.refresh / frames, (double)ST.oow / frames, (double)ST.probeSlow / frames, (double)ST.pass2 / frames, (double)ST.strideWin / frames, (double)ST.barrier / frames, (double)ST.patched / frames, (double)ST.laterSlow / frames);
     return bad != 0;
   }
   u32 seed0 = argc > 1 ? (u32)atol(argv[1]) : 1, nseed = argc > 2 ? (u32)atol(argv[2]) : 200;

@@ -15,6 +15,10 @@ extern "C" __global__ void zra_mf_opt_kernel(ZraEncArgs a, uint32_t block, uint3
 extern "C" __global__ void zra_mf_hc_kernel(ZraEncArgs a, uint32_t block);
 extern "C" __global__ void zra_mf_fast_kernel(ZraEncArgs a, uint32_t block, uint32_t perWave);
 extern "C" __global__ void zra_mf_dfast_kernel(ZraEncArgs a, uint32_t block, uint32_t only, uint32_t onlySlot);
+extern "C" __global__ void zra_mf_dfast2_kernel(ZraEncArgs a, uint32_t block, uint32_t only, uint32_t onlySlot);
+// which dfast parse runs: the mask-resolve kernel (round 3) or, with ZRA_MF_V2=0, the window-resolve kernel of round 2
+static bool mf_v2() { static const bool v = !(std::getenv("ZRA_MF_V2") && std::atoi(std::getenv("ZRA_MF_V2")) == 0); return v; }
+#define ZRA_DFAST_KERNEL (mf_v2() ? zra_mf_dfast2_kernel : zra_mf_dfast_kernel)
 extern "C" __global__ void zra_entropy_kernel(ZraEncArgs a, uint32_t block);
 
 using namespace zra_dev;
@@ -288,7 +292,7 @@ Status Engine::compress_impl_body(const uint8_t* dIn, size_t inSize, uint8_t* dB
         a.serialAll = serialAll ? 1u : 0u;
         const bool oddTail = !serialAll && hasTail && (tail.strategy == 2) != (full.strategy == 2);
         if (full.strategy == 2 && !serialAll) {
-          hipLaunchKernelGGL(zra_mf_dfast_kernel, dim3(nb), dim3(64), filterBytes + dynLds, stream_, a, blk, 0xFFFFFFFFu, 0u);
+          hipLaunchKernelGGL(ZRA_DFAST_KERNEL, dim3(nb), dim3(64), filterBytes + dynLds, stream_, a, blk, 0xFFFFFFFFu, 0u);
           if (oddTail) hipLaunchKernelGGL(mfGeneric, dim3(1), dim3(64), 0, stream_, a, blk, (uint32_t)(nb - 1), (uint32_t)(nb - 1), 1u);
         } else {
           // frames per wave: as many as it takes to have every frame of the batch resident at once (32 waves per CU)
@@ -303,7 +307,7 @@ Status Engine::compress_impl_body(const uint8_t* dIn, size_t inSize, uint8_t* dB
           if (hashChain && pwEnv <= 0) hipLaunchKernelGGL(zra_mf_hc_kernel, dim3(nb), dim3(64), dynLds, stream_, a, blk);
           else if (lean) hipLaunchKernelGGL(zra_mf_fast_kernel, dim3((nb + perWave - 1) / perWave), dim3(64), dynLds, stream_, a, blk, perWave);
           else hipLaunchKernelGGL(mfGeneric, dim3((nb + perWave - 1) / perWave), dim3(64), dynLds, stream_, a, blk, 0xFFFFFFFFu, 0u, perWave);
-          if (oddTail) hipLaunchKernelGGL(zra_mf_dfast_kernel, dim3(1), dim3(64), filterBytes, stream_, a, blk, (uint32_t)(nb - 1), (uint32_t)(nb - 1));
+          if (oddTail) hipLaunchKernelGGL(ZRA_DFAST_KERNEL, dim3(1), dim3(64), filterBytes, stream_, a, blk, (uint32_t)(nb - 1), (uint32_t)(nb - 1));
           else if (lean && hasTail && (hashChain ? (tail.strategy < 3 || tail.strategy > 5) : tail.strategy != 1))
             hipLaunchKernelGGL(mfGeneric, dim3(1), dim3(64), 0, stream_, a, blk, (uint32_t)(nb - 1), (uint32_t)(nb - 1), 1u);
         }
@@ -425,7 +429,7 @@ Status Engine::compress_persistent(const uint8_t* dIn, size_t inSize, uint8_t* d
     hipEvent_t m0 = ev(), m1 = ev();
     if (!m0 || !m1) return zerr(1);
     HIPCHK(hipEventRecord(m0, stream_));
-    hipLaunchKernelGGL(zra_mf_dfast_kernel, dim3(std::min<uint32_t>(n, nSlots)), dim3(64), filterBytes, stream_, a, 0u, 0xFFFFFFFFu, 0u);
+    hipLaunchKernelGGL(ZRA_DFAST_KERNEL, dim3(std::min<uint32_t>(n, nSlots)), dim3(64), filterBytes, stream_, a, 0u, 0xFFFFFFFFu, 0u);
     HIPCHK(hipEventRecord(m1, stream_));
     mfSpans.push_back({m0, m1});
     // a short last frame whose cparams select another strategy: parsed by the generic kernel (table slot 0 is free by then)
