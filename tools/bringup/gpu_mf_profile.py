@@ -3,7 +3,7 @@ import sys, os, ctypes
 here = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"); sys.path.insert(0, here); sys.path.insert(0, os.path.dirname(here))
 import numpy as np, torch, zra_amd as Z, bench
 gib = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
-lib = ctypes.CDLL(os.path.join(os.path.dirname(here), "zra_amd", "libzra_amd.so"))
+lib = ctypes.CDLL(Z.LIB_PATH)
 dev = torch.device("cuda", 0); eng = Z.Engine(0)
 base = bench.synth_corpus(64 << 20, 1); fs = 65536; n = int(gib * (1 << 30))
 d_in = torch.from_numpy(np.resize(base, n)).to(dev)
@@ -20,7 +20,7 @@ names = ["0 src load", "1 dup detect (LDS)", "2 table gather", "3 candidate load
 tot = v[21] / nf
 print("frames %d  total/frame %.0f memtime ticks; clear %.0f" % (nf, tot, v[20] / nf))
 for i, nm in enumerate(names): print("  %-40s %10.0f  %5.1f %%" % (nm, v[i] / nf, 100.0 * v[i] / max(v[21], 1)))
-print("  windows/frame %.0f  seqs/frame %.0f  out-of-window insert loads %.0f  probe loads %.0f  rep-loop seqs %.0f" % (v[12] / nf, v[13] / nf, v[14] / nf, v[15] / nf, v[16] / nf))
+print("  windows/frame %.0f  cnt13 %.0f  cnt14 %.0f  cnt15 %.0f  cnt16 %.0f  cnt17 %.0f  cnt18 %.0f  (window-resolve kernel: seqs, out-of-window loads, probe loads, rep-loop seqs; mask-resolve kernel: slow forward counts, slow backward counts, slow probes, slow repcode counts, settled lanes with an insertion, stored hand-over batches)" % (v[12] / nf, v[13] / nf, v[14] / nf, v[15] / nf, v[16] / nf, v[17] / nf, v[18] / nf))
 
 if hasattr(lib, "ZraHipDebugReadEntProfile"):
     eb = (ctypes.c_ulonglong * 16)(); lib.ZraHipDebugReadEntProfile(eb, 0); e = list(eb); ne = max(e[15], 1)

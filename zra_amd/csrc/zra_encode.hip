@@ -16,8 +16,9 @@ extern "C" __global__ void zra_mf_hc_kernel(ZraEncArgs a, uint32_t block);
 extern "C" __global__ void zra_mf_fast_kernel(ZraEncArgs a, uint32_t block, uint32_t perWave);
 extern "C" __global__ void zra_mf_dfast_kernel(ZraEncArgs a, uint32_t block, uint32_t only, uint32_t onlySlot);
 extern "C" __global__ void zra_mf_dfast2_kernel(ZraEncArgs a, uint32_t block, uint32_t only, uint32_t onlySlot);
-// which dfast parse runs: the mask-resolve kernel (round 3) or, with ZRA_MF_V2=0, the window-resolve kernel of round 2
-static bool mf_v2() { static const bool v = !(std::getenv("ZRA_MF_V2") && std::atoi(std::getenv("ZRA_MF_V2")) == 0); return v; }
+// which dfast parse runs: the window-resolve kernel, or with ZRA_MF_V2=1 the mask-resolve kernel of round 3 (bit-exact, fewer memory
+// round trips per sequence, but 45 % more instructions as compiled: slower today — profiles/r03_experiments.md)
+static bool mf_v2() { static const bool v = std::getenv("ZRA_MF_V2") && std::atoi(std::getenv("ZRA_MF_V2")) != 0; return v; }
 #define ZRA_DFAST_KERNEL (mf_v2() ? zra_mf_dfast2_kernel : zra_mf_dfast_kernel)
 extern "C" __global__ void zra_entropy_kernel(ZraEncArgs a, uint32_t block);
 

@@ -739,8 +739,8 @@ __device__ __forceinline__ u32 s_run(const S128& s, u32 x) {
 __device__ __forceinline__ u64 s_rephits(const S128& s) { return s_from(s, 1) & s_from(s, 2) & s_from(s, 3) & s_from(s, 4); }
 __device__ __forceinline__ bool s_four(const S128& s, u32 x) { return (s_from(s, x) & 0xF) == 0xF; }
 
-typedef uint4 __attribute__((aligned(1))) uint4_u;
-__device__ __forceinline__ uint4 ld128(const u8* p) { return *(const uint4_u*)p; }
+struct __attribute__((packed, aligned(1))) quad_u { u32 x, y, z, w; };
+__device__ __forceinline__ uint4 ld128(const u8* p) { const quad_u q = *(const quad_u*)p; return make_uint4(q.x, q.y, q.z, q.w); }
 // 4 bits: bytes of a and b equal
 __device__ __forceinline__ u32 eq_nib(u32 a, u32 b) {
   const u32 t = a ^ b;
@@ -750,12 +750,15 @@ __device__ __forceinline__ u32 eq_nib(u32 a, u32 b) {
 }
 __device__ __forceinline__ u32 eq_nib4(uint4 a, uint4 b) { return eq_nib(a.x, b.x) | (eq_nib(a.y, b.y) << 4) | (eq_nib(a.z, b.z) << 8) | (eq_nib(a.w, b.w) << 12); }
 
-// bucket indices and tags with the short hash's width as a run-time value (one copy of the parse for minMatch 4..7)
+// bucket indices and tags with the short hash's width as a run-time value (one copy of the parse for minMatch 4..7); built from one
+// packed word (hashLog | chainLog << 8 | index bits << 16 | minMatch << 24) where it is used, so that nothing of it stays in scalar
+// registers while a window is resolved
 struct DfHashR {
   u32 shL, shS, shT, ib, tagMask, mls, shV; u64 primeS;
-  __device__ __forceinline__ void init(u32 hlog, u32 clog, u32 ibits, u32 m) {
-    mls = m < 4 ? 4 : m > 7 ? 7 : m;
-    ib = ibits; tagMask = ~((1u << ib) - 1u); shL = 64 - hlog; shS = (mls == 4 ? 32 : 64) - clog; shT = shL - (32 - ib);
+  __device__ __forceinline__ void init(u32 packed) {
+    const u32 hlog = packed & 255, clog = (packed >> 8) & 255;
+    ib = (packed >> 16) & 255; mls = packed >> 24;
+    tagMask = ~((1u << ib) - 1u); shL = 64 - hlog; shS = (mls == 4 ? 32 : 64) - clog; shT = shL - (32 - ib);
     shV = 64 - 8 * mls;
     primeS = mls == 5 ? 889523592379ULL : mls == 6 ? 227718039650203ULL : 58295818150454627ULL;
   }
@@ -768,68 +771,51 @@ struct DfHashR {
     else bS = (u32)(((v << shV) * primeS) >> shS);
   }
 };
+// lane l of `old` := val (val and l wave-uniform): v_writelane_b32 with the lane select in M0 (gfx9 reads one SGPR per VALU
+// instruction, and the compiler offers no builtin)
+__device__ __forceinline__ u32 wrlane(u32 old, u32 val, u32 l) {
+  asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(old) : "s"(val), "s"(l) : "m0");
+  return old;
+}
 
 __device__ u32 mf_dfast_mask(const ZraEncParams& P, u32* HL, u32* HS, const u8* src, u32 fsize, u32 bs, u32 be, u32* rep, u64* seqs, u32* nOut,
                              const LeanLds& W, int lane, u32 ib) {
-  DfHashR H; H.init(rfl(P.hashLog), rfl(P.chainLog), rfl(ib), rfl(P.minMatch));
-  const u32 idxMask = ~H.tagMask;
+  const u32 mlsc = P.minMatch < 4 ? 4u : P.minMatch > 7 ? 7u : P.minMatch;
+  const u32 hpack = rfl(P.hashLog | (P.chainLog << 8) | (ib << 16) | (mlsc << 24));
   bs = rfl(bs); be = rfl(be); fsize = rfl(fsize);
   u32 o1 = rfl(rep[0]), o2 = rfl(rep[1]), saved;
   u32 anchor = bs, nseq = 0;
   const u32 ilimit = be >= 8 ? be - 8 : 0;
   u32 ip = mf_prologue(bs, o1, o2, saved);
   u32 sqLo = 0, sqHi = 0;
-  u8* const dL = W.dup; u8* const dS = W.dup + W.dupSlots;
-  const u32 dmask = W.dupSlots - 1;
-  u32* const bmL = W.bmL; u32* const bmS = W.bmS;
   u64 pendL = 0, pendS = 0;                           // insertions handed over by the previous window: lanes of this window's chunk
   u32 nxtG = 0xFFFFFFFFu; u64 v8n = 0;                 // source bytes of chunk nxtG, loaded one window ahead
-  bool repCont = false;                               // a run of immediate repcode sequences outgrew the hand-over list: continue it first
   PROF_DECL
   auto emit = [&](u32 ll, u32 ml, u32 offVal) {
     const u64 q = (u64)ll | ((u64)ml << 20) | ((u64)offVal << 40);
-    sqLo = wlane(sqLo, (u32)q, nseq & 63); sqHi = wlane(sqHi, (u32)(q >> 32), nseq & 63);
+    sqLo = wrlane(sqLo, (u32)q, nseq & 63); sqHi = wrlane(sqHi, (u32)(q >> 32), nseq & 63);
     nseq++;
     if ((nseq & 63) == 0) seqs[nseq - 64 + (u32)lane] = (u64)sqLo | ((u64)sqHi << 32);
   };
-  auto insert_slow = [&](u32 pos, bool doL, bool doS) {
-    if (lane == 0) {
-      u32 bl, bs_, tl, ts; H.both(ld64(src + pos), bl, bs_, tl, ts);
-      if (doL) { TST(HL + bl, (pos + 1) | tl); W.markL(bl); }
-      if (doS) { TST(HS + bs_, (pos + 1) | ts); W.markS(bs_); }
-    }
-  };
   while (ip < ilimit) {
-    if (repCont) {
-      // (rare) the rest of a run of immediate repcode sequences, from memory
-      repCont = false;
-      while (ip <= ilimit && o2 > 0 && rfl(ld32(src + ip)) == rfl(ld32(src + ip - o2))) {
-        const u32 rl = wave_count_eq(src, ip + 4, ip + 4 - o2, be, lane) + 4;
-        const u32 t = o2; o2 = o1; o1 = t;
-        insert_slow(ip, true, true);
-        emit(0, rl, 1);
-        ip += rl; anchor = ip;
-      }
-      continue;
-    }
     // ---------------------------------------------------------------- window build
     const u32 run = ip - anchor;
     u32 s = 1, g, l0, l1;
     if (run < 256) { g = ip & ~63u; l0 = ip - g; l1 = min(min(64u, l0 + 256u - run), ilimit - g); }
     else { s = (run >> 8) + 1; g = ip; l0 = 0; l1 = min(64u, min((256 * s - run + s - 1) / s, (ilimit - ip + s - 1) / s)); }
+    const u32 l1w = s == 1 ? l1 : 0u;                  // lanes that ARE consecutive positions (none in a stride window)
     const u64 AM = (l1 >= 64 ? ~0ull : (bit64(l1) - 1)) & ~(bit64(l0) - 1);
     const u32 p = g + (u32)lane * s;
     const bool hashed = p + 8 <= be;
     u64 v8;
     if (s == 1 && g == nxtG) v8 = v8n; else v8 = hashed ? ld64(src + p) : 0;
     S128 EQA, EQB; EQA.lo = EQA.hi = EQB.lo = EQB.hi = 0;
-    u32 hiA = 0, hiB = 0;
+    u32 hiA = 0, hiB = 0;                               // stream bits known (0 in a stride window: everything from memory)
     u64 RHa = 0;
     if (s == 1) {
-      const u32 pn = p + 64;
-      v8n = pn + 8 <= be ? ld64(src + pn) : 0; nxtG = g + 64;
-      // equality streams of the two repeat offsets over the positions g + [0, 128) (bits at and beyond the block end are 0)
       const u32 q1 = p + 64;
+      v8n = q1 + 8 <= be ? ld64(src + q1) : 0; nxtG = g + 64;
+      // equality streams of the two repeat offsets over the positions g + [0, 128) (bits at and beyond the block end are 0)
       const bool v0 = p < be, v1 = q1 < be;
       const u32 c0 = v0 ? src[p] : 0x100u, c1 = v1 ? src[q1] : 0x100u;
       const u32 a0 = (v0 && o1 > 0 && p >= o1) ? src[p - o1] : 0x200u, a1 = (v1 && o1 > 0 && q1 >= o1) ? src[q1 - o1] : 0x200u;
@@ -844,13 +830,18 @@ __device__ u32 mf_dfast_mask(const ZraEncParams& P, u32* HL, u32* HS, const u8* 
       RHa = __ballot(rv && repVal == (u32)(v8 >> 8));
     }
     PROF(0) PROF_CNT(12)
-    u32 bL, bS, valL, valS;
-    { u32 tL, tS; H.both(v8, bL, bS, tL, tS); valL = (p + 1) | tL; valS = (p + 1) | tS; }
+    u32 bL, bS, valL, valS, tagMask;
+    {
+      DfHashR H; H.init(hpack); tagMask = H.tagMask;
+      u32 tL, tS; H.both(v8, bL, bS, tL, tS); valL = (p + 1) | tL; valS = (p + 1) | tS;
+    }
     if (!hashed) { bL = 0xFFFFFFFFu; bS = 0xFFFFFFFFu; }
     // D: lanes whose LDS slot is shared with another lane of the window (a superset of the lanes that share a bucket): winners
     // learn of the collision from the marker the losers leave
-    u64 D;
+    u32 dflag;
     {
+      u8* const dL = W.dup; u8* const dS = W.dup + W.dupSlots;
+      const u32 dmask = W.dupSlots - 1;
       const bool part = lane_in(AM | pendL | pendS);
       if (part) { dL[bL & dmask] = (u8)lane; dS[bS & dmask] = (u8)lane; }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
@@ -859,12 +850,12 @@ __device__ u32 mf_dfast_mask(const ZraEncParams& P, u32* HL, u32* HS, const u8* 
       if (loseL) dL[bL & dmask] = 0xFF;
       if (loseS) dS[bS & dmask] = 0xFF;
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-      const bool fl = part && (loseL || loseS || dL[bL & dmask] == 0xFF || dS[bS & dmask] == 0xFF);
+      dflag = (part && (loseL || loseS || dL[bL & dmask] == 0xFF || dS[bS & dmask] == 0xFF)) ? 1u : 0u;
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-      D = __ballot(fl);
     }
     // masked table stores: of the lanes of a mask that share a bucket only the latest position stores
     auto store_masked = [&](u64 mkL, u64 mkS) {
+      const u64 D = __ballot(dflag != 0);
       u64 cl = mkL & D;
       while (cl) {
         const u32 l = (u32)__builtin_ctzll(cl); cl &= cl - 1;
@@ -876,8 +867,8 @@ __device__ u32 mf_dfast_mask(const ZraEncParams& P, u32* HL, u32* HS, const u8* 
         if (__ballot(bS == bcast(bS, l)) & mkS & ~((bit64(l) << 1) - 1)) mkS &= ~bit64(l);
       }
       const u32 gL = bL >> W.shL, gS = bS >> W.shS;
-      if (lane_in(mkL)) { TST(HL + bL, valL); atomicOr(&bmL[gL >> 5], 1u << (gL & 31)); }
-      if (lane_in(mkS)) { TST(HS + bS, valS); atomicOr(&bmS[gS >> 5], 1u << (gS & 31)); }
+      if (lane_in(mkL)) { TST(HL + bL, valL); atomicOr(&W.bmL[gL >> 5], 1u << (gL & 31)); }
+      if (lane_in(mkS)) { TST(HS + bS, valS); atomicOr(&W.bmS[gS >> 5], 1u << (gS & 31)); }
     };
     if (pendL | pendS) { store_masked(pendL, pendS); pendL = 0; pendS = 0; __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); }
     PROF(1)
@@ -885,10 +876,10 @@ __device__ u32 mf_dfast_mask(const ZraEncParams& P, u32* HL, u32* HS, const u8* 
     u32 mL = 0, mS = 0;
     if (active) {
       const u32 gL = bL >> W.shL, gS = bS >> W.shS;
-      const bool needL = (bmL[gL >> 5] >> (gL & 31)) & 1, needS = (bmS[gS >> 5] >> (gS & 31)) & 1;
+      const bool needL = (W.bmL[gL >> 5] >> (gL & 31)) & 1, needS = (W.bmS[gS >> 5] >> (gS & 31)) & 1;
       const u32 rL = needL ? TLD(HL + bL) : 0u, rS = needS ? TLD(HS + bS) : 0u;
-      mL = (((rL ^ valL) & H.tagMask) == 0) ? (rL & idxMask) : 0u;
-      mS = (((rS ^ valS) & H.tagMask) == 0) ? (rS & idxMask) : 0u;
+      mL = (((rL ^ valL) & tagMask) == 0) ? (rL & ~tagMask) : 0u;
+      mS = (((rS ^ valS) & tagMask) == 0) ? (rS & ~tagMask) : 0u;
     }
     PROF(2)
     // candidate masks: long candidate first, the short one when there is no long one (or, second pass, when the long one fails its 8 bytes)
@@ -946,11 +937,25 @@ __device__ u32 mf_dfast_mask(const ZraEncParams& P, u32* HL, u32* HS, const u8* 
     u64 LH = __ballot(active && lhit), SH = __ballot(active && shit);
     PROF(3)
     // ---------------------------------------------------------------- resolve the window
-    u64 insL = 0, insS = 0, Dun = D;                    // Dun: shared-slot lanes whose candidates are not settled yet
-    u32 patLane = 64, patCand = 0;                      // the lane whose candidate came from an insertion of this window
+    u64 insL = 0, insS = 0, Dun = __ballot(dflag != 0) & AM;   // Dun: shared-slot lanes whose candidates are not settled yet
     u32 laterV = 0, nLater = 0;                         // insertions behind the window: lane k = position | long << 30 | short << 31
     u32 cur = l0;
     const u32 v8lo = (u32)v8, v8hi = (u32)(v8 >> 32);
+    // the candidate of position q (origin of the mask) becomes c: equality mask and backward count by the whole wave, written into
+    // lane d's registers (one small round trip; c lies inside or just before the window, so the lines are in the vector cache)
+    auto rewrite_lane = [&](u32 d, u32 q, u32 c) {
+      const u32 qa = q + (u32)lane;
+      const bool fv = qa < be;
+      const u32 x0 = fv ? src[qa] : 0x100u, y0 = fv ? src[c + (u32)lane] : 0x200u;
+      const bool bv = (u32)lane < 8 && (u32)lane < c;
+      const u32 x1 = bv ? src[q - 1 - (u32)lane] : 0x100u, y1 = bv ? src[c - 1 - (u32)lane] : 0x200u;
+      const u64 e = __ballot(x0 == y0);
+      const u64 nb = ~__ballot(x1 == y1);
+      const u32 bk = min(8u, (u32)__builtin_ctzll(nb | 0x100ull)), bkK = min(8u, c);
+      cand = wrlane(cand, c, d); e0lo = wrlane(e0lo, (u32)e, d); e0hi = wrlane(e0hi, (u32)(e >> 32), d);
+      ex = wrlane(ex, (bk << 8) | (bkK << 12) | (64u << 16), d);
+      return e;
+    };
     // settle lane d's table candidates against the insertions this window has made below lane `lim`
     auto settle = [&](u32 d, u32 lim, bool doS) {
       const u64 bel = lim ? (~0ull >> (64 - lim)) : 0ull;
@@ -959,156 +964,23 @@ __device__ u32 mf_dfast_mask(const ZraEncParams& P, u32* HL, u32* HS, const u8* 
       if (!(cmL | cmS)) return;
       PROF_CNT(17)
       u32 nL = bcast(mL, d), nS = bcast(mS, d);
-      if (cmL) { const u32 i = 63u - (u32)__builtin_clzll(cmL); nL = ((bcast(valL, i) ^ bcast(valL, d)) & H.tagMask) == 0 ? g + i * s + 1 : 0u; }
-      if (cmS) { const u32 i = 63u - (u32)__builtin_clzll(cmS); nS = ((bcast(valS, i) ^ bcast(valS, d)) & H.tagMask) == 0 ? g + i * s + 1 : 0u; }
-      const u32 dlo = bcast(v8lo, d), dhi = bcast(v8hi, d);
+      if (cmL) { const u32 i = 63u - (u32)__builtin_clzll(cmL); nL = ((bcast(valL, i) ^ bcast(valL, d)) & tagMask) == 0 ? g + i * s + 1 : 0u; }
+      if (cmS) { const u32 i = 63u - (u32)__builtin_clzll(cmS); nS = ((bcast(valS, i) ^ bcast(valS, d)) & tagMask) == 0 ? g + i * s + 1 : 0u; }
       const bool wasL = (LH >> d) & 1;
+      const u32 pd = g + d * s;
       if (cmL) {
         LH &= ~bit64(d);
-        if (nL > 1) {
-          const u64 cv = ld64(src + nL - 1);
-          if (rfl((u32)cv) == dlo && rfl((u32)(cv >> 32)) == dhi) { LH |= bit64(d); patLane = d; patCand = nL - 1; }
-        }
+        if (nL > 1 && (rewrite_lane(d, pd, nL - 1) & 0xFF) == 0xFF) LH |= bit64(d);
       }
       if (!((LH >> d) & 1) && doS && (cmS || (cmL && wasL))) {
         SH &= ~bit64(d);
-        if (nS > 1 && rfl(ld32(src + nS - 1)) == dlo) { SH |= bit64(d); patLane = d; patCand = nS - 1; }
+        if (nS > 1 && (rewrite_lane(d, pd, nS - 1) & 0xF) == 0xF) SH |= bit64(d);
       }
     };
-    auto later = [&](u32 pos, u32 flags) { laterV = wlane(laterV, pos | flags, nLater); nLater++; };
-    for (;;) {
-      const u64 live = AM & (~0ull << cur);
-      const u64 Dl = Dun & live;
-      const u32 h = Dl ? (u32)__builtin_ctzll(Dl) : 64u;
-      const u64 below = h >= 64 ? live : (live & (bit64(h) - 1));
-      u64 hm = (RHa | LH | SH) & below;
-      if (!hm && h < 64) {
-        if ((RHa >> h) & 1) hm = bit64(h);              // a repcode hit needs no table
-        else {
-          insL |= below; insS |= below;                 // the lanes before h are visited without a hit
-          settle(h, h, true); Dun &= ~bit64(h); cur = h;
-          continue;
-        }
-      }
-      if (!hm) { insL |= live; insS |= live; ip = g + l1 * s; PROF(4) break; }
-      const u32 f = (u32)__builtin_ctzll(hm);
-      { const u64 upto = live & ((bit64(f) << 1) - 1); insL |= upto; insS |= upto; }
-      const u32 top = g + f * s;
-      const bool isRep = (RHa >> f) & 1, isLong = (LH >> f) & 1;
-      u32 ml, offVal = 1, m = 0;
-      bool slowF = false, slowB = false; u32 baseF = 4;
-      u64 e0 = 0; u32 e1 = 0, kn = 0;
-      bool haveE = false;
-      ip = top;
-      if (isRep) {
-        ip = top + 1;
-        m = ip - o1;
-        const u32 x0 = ip - g;
-        slowF = true; ml = 0;
-        if (s == 1) { ml = s_run(EQA, x0); slowF = (x0 + ml >= hiA) && (g + hiA < be); }
-      } else {
-        u32 fE = f; haveE = patLane != f; m = patCand;
-        if (!isLong) {
-          if (s == 1 && f + 1 < l1) {
-            if ((Dun >> (f + 1)) & 1) { settle(f + 1, f + 1, false); Dun &= ~bit64(f + 1); }   // the probe reads the long table only
-            insL |= bit64(f + 1);
-            if ((LH >> (f + 1)) & 1) { fE = f + 1; ip = top + 1; haveE = patLane != f + 1; m = patCand; }
-          } else {
-            PROF_CNT(15)
-            // the probed position top+1 is not a lane of the window: its bucket comes from memory; what the long table holds there
-            // is the latest insertion of this window into that bucket, else the table itself
-            const u64 v9 = (u64)rfl(ld32(src + top + 1)) | ((u64)rfl(ld32(src + top + 5)) << 32);
-            u32 b3, bx, t3, tx; H.both(v9, b3, bx, t3, tx);
-            const u64 cm = __ballot(bL == b3) & insL;
-            u32 m3;
-            if (cm) { const u32 i = 63u - (u32)__builtin_clzll(cm); m3 = ((bcast(valL, i) & H.tagMask) == t3) ? g + i * s + 1 : 0u; }
-            else { const u32 r3 = rfl(TLD(HL + b3)); m3 = ((r3 & H.tagMask) == t3) ? (r3 & idxMask) : 0u; }
-            later(top + 1, 1u << 30);
-            if (m3 > 1) {
-              const u64 cv = ld64(src + m3 - 1);
-              if (rfl((u32)cv) == (u32)v9 && rfl((u32)(cv >> 32)) == (u32)(v9 >> 32)) { haveE = false; m = m3 - 1; ip = top + 1; }
-            }
-          }
-        }
-        PROF(5)
-        baseF = (isLong || ip != top) ? 8u : 4u;
-        u32 back;
-        if (haveE) {
-          m = bcast(cand, fE);
-          e0 = (u64)bcast(e0lo, fE) | ((u64)bcast(e0hi, fE) << 32);
-          const u32 x = bcast(ex, fE);
-          e1 = x & 0xFF; kn = x >> 16;
-          const u32 bk = (x >> 8) & 15, bkK = (x >> 12) & 15;
-          ml = e0 != ~0ull ? (u32)__builtin_ctzll(~e0) : 64u + (u32)__builtin_ctz(~e1);
-          const u32 lim = min(kn, be - ip);
-          if (ml >= lim && ip + lim < be) { slowF = true; baseF = lim; }
-          const u32 blim = min(ip - anchor, m);
-          back = min(bk, blim);
-          slowB = bk == bkK && blim > bkK;
-        } else { slowF = true; slowB = true; back = 0; ml = 0; }
-        if (slowB) { PROF_CNT(14) back = wave_count_back(src, ip, m, anchor, lane); }
-        offVal = back;                                   // (carried to the common tail below)
-      }
-      if (slowF) { PROF_CNT(13) ml = baseF + wave_count_eq(src, ip + baseF, m + baseF, be, lane); }
-      PROF(6)
-      if (!isRep) {
-        const u32 back = offVal;
-        const u32 off = ip - m;
-        // streams: offset_2 takes over offset_1's, offset_1's comes from E
-        EQB = EQA; hiB = hiA;
-        EQA.lo = 0; EQA.hi = 0; hiA = 0; RHa = 0;
-        if (s == 1 && haveE) {
-          const u32 xE = ip - g;
-          EQA = s_shl72(e0, e1, xE);
-          hiA = (ip + kn >= be) ? 128u : min(128u, xE + kn);
-          RHa = s_rephits(EQA);
-        }
-        ip -= back; ml += back;
-        o2 = o1; o1 = off; offVal = off + 3;
-      }
-      emit(ip - anchor, ml, offVal);
-      ip += ml; anchor = ip;
-      PROF(7)
-      if (ip > ilimit) break;
-      // ---- complementary insertions (top+2 into both tables, ip-2 long, ip-1 short) and the immediate repcode test
-      const u32 x = ip - g;
-      if (s == 1 && f + 2 < l1) { insL |= bit64(f + 2); insS |= bit64(f + 2); } else later(top + 2, 3u << 30);
-      if (s == 1 && x - 2 < l1) insL |= bit64(x - 2); else later(ip - 2, 1u << 30);
-      if (s == 1 && x - 1 < l1) insS |= bit64(x - 1); else later(ip - 1, 2u << 30);
-      bool rephit;
-      if (s == 1 && (o2 == 0 || x + 4 <= hiB)) rephit = o2 > 0 && s_four(EQB, x);
-      else rephit = o2 > 0 && rfl(ld32(src + ip)) == rfl(ld32(src + ip - o2));
-      while (rephit) {
-        if (nLater > 56) { repCont = true; break; }      // (the hand-over list is full: the run goes on from memory after the flush)
-        const u32 xx = ip - g;
-        bool slow = true; u32 rl = 0;
-        if (s == 1 && xx + 4 <= hiB) { rl = s_run(EQB, xx); slow = (xx + rl >= hiB) && (g + hiB < be); }
-        if (slow) { PROF_CNT(16) rl = wave_count_eq(src, ip + 4, ip + 4 - o2, be, lane) + 4; }
-        { const u32 t = o2; o2 = o1; o1 = t; const S128 ts = EQA; EQA = EQB; EQB = ts; const u32 th = hiA; hiA = hiB; hiB = th; RHa = s_rephits(EQA); }
-        if (s == 1 && xx < l1) { insL |= bit64(xx); insS |= bit64(xx); } else later(ip, 3u << 30);
-        emit(0, rl, 1);
-        ip += rl; anchor = ip;
-        if (!(ip <= ilimit && o2 > 0)) break;
-        const u32 xn = ip - g;
-        if (s == 1 && xn + 4 <= hiB) rephit = s_four(EQB, xn);
-        else rephit = rfl(ld32(src + ip)) == rfl(ld32(src + ip - o2));
-      }
-      PROF(8)
-      if (s != 1 || ip >= g + l1 || ip >= ilimit || nLater) break;
-      cur = ip - g;
-      if (hiA < l1 + 4 && o1 > 0) {                     // the rest of the window needs stream bits up to l1 + 3: from memory
-        const u32 q1 = p + 64;
-        const bool v0 = p < be && p >= o1, v1 = q1 < be && q1 >= o1;
-        const u32 c0 = v0 ? src[p] : 0x100u, a0 = v0 ? src[p - o1] : 0x200u;
-        const u32 c1 = v1 ? src[q1] : 0x100u, a1 = v1 ? src[q1 - o1] : 0x200u;
-        EQA.lo = __ballot(c0 == a0); EQA.hi = __ballot(c1 == a1);
-        hiA = 128; RHa = s_rephits(EQA);
-      }
-    }
-    // ---- the window's insertions, then those behind its end: lanes of the next window's chunk, or stored now (position order per table)
-    store_masked(insL, insS);
-    if (nLater) {
-      const bool nextS1 = !repCont && ip < ilimit && ip - anchor < 256;
+    auto later = [&](u32 pos, u32 flags) { laterV = wrlane(laterV, pos | flags, nLater); nLater++; };
+    // insertions behind the window's end: lanes of the next window's chunk (toNext), or stored now — in position order per table
+    auto flush_later = [&](bool toNext) {
+      const bool nextS1 = toNext && ip < ilimit && ip - anchor < 256;
       const u32 gN = ip & ~63u;
       const bool mine = (u32)lane < nLater;
       const u32 e = mine ? laterV : 0u;
@@ -1124,6 +996,7 @@ __device__ u32 mf_dfast_mask(const ZraEncParams& P, u32* HL, u32* HS, const u8* 
       }
       if (slowM) {
         PROF_CNT(18)
+        DfHashR H; H.init(hpack);
         const u64 xv = lane_in(slowM) ? ld64(src + q) : 0;
         u32 xbL, xbS, xtL, xtS; H.both(xv, xbL, xbS, xtL, xtS);
         while (slowM) {                                   // one store instruction per entry: entries may share a bucket, the later one wins
@@ -1135,7 +1008,128 @@ __device__ u32 mf_dfast_mask(const ZraEncParams& P, u32* HL, u32* HS, const u8* 
           asm volatile("" ::: "memory");
         }
       }
+      nLater = 0;
+    };
+    for (;;) {
+      const u64 live = AM & (~0ull << cur);
+      const u64 ev = ((RHa | LH | SH) | Dun) & live;     // first event: a hit lane or a lane that is not settled yet
+      if (!ev) { insL |= live; insS |= live; ip = g + l1 * s; PROF(4) break; }
+      const u32 f = (u32)__builtin_ctzll(ev);
+      const u64 fb = bit64(f);
+      const bool isRep = (RHa & fb) != 0;                // (a repcode hit needs no table: it wins on an unsettled lane too)
+      if (__builtin_expect((Dun & fb) != 0 && !isRep, 0)) {
+        const u64 vis = live & (fb - 1);                 // the lanes before f are visited without a hit
+        insL |= vis; insS |= vis;
+        settle(f, f, true); Dun &= ~fb; cur = f;
+        continue;
+      }
+      { const u64 upto = live & ((fb << 1) - 1); insL |= upto; insS |= upto; }
+      const u32 top = g + f * s;
+      u32 ml, offVal = 1;
+      ip = top;
+      if (isRep) {
+        ip = top + 1;
+        const u32 x0 = ip - g;
+        ml = s_run(EQA, x0);
+        if (__builtin_expect(x0 + ml >= hiA && g + hiA < be, 0)) { PROF_CNT(16) ml = wave_count_eq(src, ip + 4, ip + 4 - o1, be, lane) + 4; }
+      } else {
+        u32 fE = f;
+        if (!(LH & fb)) {
+          // short hit: the long table is probed at top + 1
+          if (f + 1 < l1w) {
+            if (__builtin_expect((Dun >> (f + 1)) & 1, 0)) { settle(f + 1, f + 1, false); Dun &= ~(fb << 1); }   // the probe reads the long table only
+            insL |= fb << 1;
+            if (LH & (fb << 1)) { fE = f + 1; ip = top + 1; }
+          } else {
+            PROF_CNT(15)
+            // top + 1 is not a lane of the window: its bucket comes from memory; what the long table holds there is the latest
+            // insertion of this window into that bucket, else the table itself
+            DfHashR H; H.init(hpack);
+            const u64 v9 = (u64)rfl(ld32(src + top + 1)) | ((u64)rfl(ld32(src + top + 5)) << 32);
+            u32 b3, bx, t3, tx; H.both(v9, b3, bx, t3, tx);
+            const u64 cm = __ballot(bL == b3) & insL;
+            u32 m3;
+            if (cm) { const u32 i = 63u - (u32)__builtin_clzll(cm); m3 = ((bcast(valL, i) & tagMask) == t3) ? g + i * s + 1 : 0u; }
+            else { const u32 r3 = rfl(TLD(HL + b3)); m3 = ((r3 & tagMask) == t3) ? (r3 & ~tagMask) : 0u; }
+            later(top + 1, 1u << 30);
+            if (m3 > 1 && (rewrite_lane(f, top + 1, m3 - 1) & 0xFF) == 0xFF) ip = top + 1;   // lane f now holds the mask of top + 1
+            else if (m3 > 1) {                           // no long match at top + 1: lane f gets the mask of its own short candidate back
+              const u32 cS = bcast(mS, f) - 1;
+              (void)rewrite_lane(f, top, cS);
+            }
+          }
+        }
+        PROF(5)
+        const u32 m = bcast(cand, fE);
+        const u64 e0 = (u64)bcast(e0lo, fE) | ((u64)bcast(e0hi, fE) << 32);
+        const u32 x = bcast(ex, fE);
+        const u32 e1 = x & 0xFF, kn = x >> 16;
+        const u32 bk = (x >> 8) & 15, bkK = (x >> 12) & 15;
+        ml = e0 != ~0ull ? (u32)__builtin_ctzll(~e0) : 64u + (u32)__builtin_ctz(~e1);
+        const u32 lim = min(kn, be - ip);
+        if (__builtin_expect(ml >= lim && ip + lim < be, 0)) { PROF_CNT(13) ml = lim + wave_count_eq(src, ip + lim, m + lim, be, lane); }
+        const u32 blim = min(ip - anchor, m);
+        u32 back = min(bk, blim);
+        if (__builtin_expect(bk == bkK && blim > bkK, 0)) { PROF_CNT(14) back = wave_count_back(src, ip, m, anchor, lane); }
+        PROF(6)
+        const u32 off = ip - m;
+        // streams: offset_2 takes over offset_1's, offset_1's comes from the mask (known for kn bytes from ip on)
+        EQB = EQA; hiB = hiA;
+        {
+          const u32 xE = ip - g;
+          EQA = s_shl72(e0, e1, xE);
+          hiA = l1w ? ((ip + kn >= be) ? 128u : min(128u, xE + kn)) : 0u;
+          RHa = l1w ? s_rephits(EQA) : 0ull;
+        }
+        ip -= back; ml += back;
+        o2 = o1; o1 = off; offVal = off + 3;
+      }
+      emit(ip - anchor, ml, offVal);
+      ip += ml; anchor = ip;
+      PROF(7)
+      if (ip > ilimit) break;
+      // ---- complementary insertions (top+2 into both tables, ip-2 long, ip-1 short) and the immediate repcode test
+      const u32 x = ip - g;
+      if (f + 2 < l1w) { insL |= fb << 2; insS |= fb << 2; } else later(top + 2, 3u << 30);
+      if (x - 2 < l1w) insL |= bit64(x - 2); else later(ip - 2, 1u << 30);
+      if (x - 1 < l1w) insS |= bit64(x - 1); else later(ip - 1, 2u << 30);
+      bool rephit;
+      if (o2 == 0) rephit = false;
+      else if (x + 4 <= hiB) rephit = s_four(EQB, x);
+      else rephit = rfl(ld32(src + ip)) == rfl(ld32(src + ip - o2));
+      while (__builtin_expect(rephit, 0)) {
+        const u32 xx = ip - g;
+        u32 rl = 0; bool slow = true;
+        if (xx + 4 <= hiB) { rl = s_run(EQB, xx); slow = (xx + rl >= hiB) && (g + hiB < be); }
+        if (slow) { PROF_CNT(16) rl = wave_count_eq(src, ip + 4, ip + 4 - o2, be, lane) + 4; }
+        { const u32 t = o2; o2 = o1; o1 = t; const S128 ts = EQA; EQA = EQB; EQB = ts; const u32 th = hiA; hiA = hiB; hiB = th; RHa = l1w ? s_rephits(EQA) : 0ull; }
+        if (xx < l1w) { insL |= bit64(xx); insS |= bit64(xx); }
+        else {
+          if (nLater >= 60) { store_masked(insL, insS); insL = 0; insS = 0; flush_later(false); }   // (a very long run of repcode sequences behind the window)
+          later(ip, 3u << 30);
+        }
+        emit(0, rl, 1);
+        ip += rl; anchor = ip;
+        if (!(ip <= ilimit && o2 > 0)) break;
+        const u32 xn = ip - g;
+        if (xn + 4 <= hiB) rephit = s_four(EQB, xn);
+        else rephit = rfl(ld32(src + ip)) == rfl(ld32(src + ip - o2));
+      }
+      PROF(8)
+      if (ip >= g + l1w || ip >= ilimit) break;
+      cur = ip - g;
+      if (__builtin_expect(hiA < l1 + 4 && o1 > 0, 0)) { // the rest of the window needs stream bits up to l1 + 3: from memory
+        const u32 q1 = p + 64;
+        const bool v0 = p < be && p >= o1, v1 = q1 < be && q1 >= o1;
+        const u32 c0 = v0 ? src[p] : 0x100u, a0 = v0 ? src[p - o1] : 0x200u;
+        const u32 c1 = v1 ? src[q1] : 0x100u, a1 = v1 ? src[q1 - o1] : 0x200u;
+        EQA.lo = __ballot(c0 == a0); EQA.hi = __ballot(c1 == a1);
+        hiA = 128; RHa = s_rephits(EQA);
+      }
     }
+    // ---- the window's insertions, then those behind its end: lanes of the next window's chunk, or stored now
+    store_masked(insL, insS);
+    if (nLater) flush_later(true);
     PROF(9)
   }
   if (nseq & 63) { if ((u32)lane < (nseq & 63)) seqs[(nseq & ~63u) + (u32)lane] = (u64)sqLo | ((u64)sqHi << 32); }
