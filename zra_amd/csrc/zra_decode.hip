@@ -97,7 +97,7 @@ __device__ __forceinline__ u32 bcast_u32(u32 v, u32 l) { return (u32)__builtin_a
 
 // ---------------------------------------------------------------------------------------------
 // FSE table description (A.3) -> norm[] ; single thread. returns bytes consumed, 0 on corruption
-__device__ u32 read_ncount(short* norm, u32* maxSymIO, u32* tableLogOut, const u8* src, u32 n, u32 maxAL, const u8* lim) {
+__device__ __forceinline__ u32 read_ncount(short* norm, u32* maxSymIO, u32* tableLogOut, const u8* src, u32 n, u32 maxAL, const u8* lim) {
   if (n < 1) return 0;
   u32 bitpos = 0, nbits = n * 8;
   auto peekf = [&](u32 k) -> u32 {
@@ -141,7 +141,7 @@ __device__ u32 read_ncount(short* norm, u32* maxSymIO, u32* tableLogOut, const u
 
 // Build an FSE decode table from norm[] into the LDS staging area (single wave; lanes cooperate on the final fill).
 // kind: 0 = LL, 1 = ML (two words per cell: packed fields, base value), 2 = OF (one word per cell)
-__device__ void build_fse_dtable(u32* stage, const short* norm, u32 maxSym, u32 tableLog, int kind, u8* spread, int lane) {
+__device__ __forceinline__ void build_fse_dtable(u32* stage, const short* norm, u32 maxSym, u32 tableLog, int kind, u8* spread, int lane) {
   u32 size = 1u << tableLog, mask = size - 1;
   if (lane == 0) {
     u32 high = size - 1, step = (size >> 1) + (size >> 3) + 3, pos = 0;
@@ -239,8 +239,10 @@ __device__ __forceinline__ void copy_periodic_le64(u8* dp, const u8* sp, u32 n, 
 
 // ---------------------------------------------------------------------------------------------
 // literals section header + Huffman tree description; thread 0 only. Sets S.lit* / S.huf* / S.err.
+// (Forced inline like every helper that is handed `win + x` pointers: those are LDS window addresses minus the window's frame position,
+// 32-bit arithmetic that only comes out right while it stays in the LDS address space — a real call takes them as flat pointers.)
 // Check order of ZSTD_decodeLiteralsBlock (zstd_decompress_block.c of 1.4.9).
-__device__ void parse_literals_header(ParseShared& S, const u8* src, u32 n, const u8* lim) {
+__device__ __forceinline__ void parse_literals_header(ParseShared& S, const u8* src, u32 n, const u8* lim) {
   if (n < 3) { S.err = ZE_CORRUPTION; return; }                       // MIN_CBLOCK_SIZE
   u32 b0 = src[0], type = b0 & 3, sf = (b0 >> 2) & 3;
   S.litType = type;
@@ -359,7 +361,7 @@ __device__ void parse_literals_header(ParseShared& S, const u8* src, u32 n, cons
 }
 
 // sequences section header (nbSeq + modes byte; ZSTD_decodeSeqHeaders). thread 0.
-__device__ void parse_seq_header(ParseShared& S, const u8* p, u32 rem) {
+__device__ __forceinline__ void parse_seq_header(ParseShared& S, const u8* p, u32 rem) {
   if (rem < 1) { S.err = ZE_SRCSIZE_WRONG; return; }
   u32 nb = p[0], used;
   if (nb == 0) { used = 1; if (rem != 1) { S.err = ZE_SRCSIZE_WRONG; return; } }
@@ -375,7 +377,7 @@ __device__ void parse_seq_header(ParseShared& S, const u8* p, u32 rem) {
 }
 
 // one LL/ML/OF table: thread 0 parses (fills S.norm + logs), then the wave builds.  kind 0 LL, 1 ML, 2 OF
-__device__ void seq_table_parse(ParseShared& S, int kind, u32 mode, const u8* p, u32 rem, u32* tlOut, u32* msOut, u32* usedOut, const u8* lim) {
+__device__ __forceinline__ void seq_table_parse(ParseShared& S, int kind, u32 mode, const u8* p, u32 rem, u32* tlOut, u32* msOut, u32* usedOut, const u8* lim) {
   const u32 maxSymK = kind == 0 ? 35 : kind == 1 ? 52 : 31;
   const u32 maxALK = kind == 2 ? 8 : 9;
   *usedOut = 0;
@@ -398,7 +400,7 @@ __device__ void seq_table_parse(ParseShared& S, int kind, u32 mode, const u8* p,
 // frame end (shared by the parse and execute kernels): frame-level checks in the order of ZSTD_decompressFrame, the per-frame
 // result words, and — random access — the query slices of this frame
 // (lane / nthreads: rank and size of the calling group)
-__device__ void frame_finish(const ZraDecodeArgs& a, u32 j, const u8* src, u32 srcSize, u32 err, u32 produced, u32 endPos, bool truncated,
+__device__ __forceinline__ void frame_finish(const ZraDecodeArgs& a, u32 j, const u8* src, u32 srcSize, u32 err, u32 produced, u32 endPos, bool truncated,
                              u32 fcsHave, u32 fcsLo, u32 fcsHi, u32 hasChecksum, int lane, int nthreads = DEC_THREADS) {
   if (lane == 0) {
     u32 ck = 0;
@@ -439,20 +441,15 @@ __device__ void frame_finish(const ZraDecodeArgs& a, u32 j, const u8* src, u32 s
 }  // namespace
 
 // =================================================================================================
-// stage 1: parse
-extern "C" __global__ void __launch_bounds__(DEC_THREADS)
-zra_dec_parse_kernel(ZraDecodeArgs a) {
-  __shared__ ParseShared S;
-  const int lane = threadIdx.x;
-
-  for (;;) {
-    if (lane == 0) S.job = atomicAdd(&a.counters[ZRA_DC_QPARSE], 1u);
-    wsync();
-    const u32 qi = S.job;
-    wsync();
-    if (qi >= a.nActive) return;
-    const u32 j = a.active ? a.active[qi] : qi;
-
+// stage 1: parse — one job (frame j, its next block) by one wave. FUSED (the one-launch path for small random-access batches,
+// zra_ra_small_kernel below): nothing is appended to the stage lists, the sequence tables are also left in LDS (ldsT), and the
+// outcome comes back as a code: 0 = the frame is finished (frame_finish has run), 1 = a compressed block was handed on,
+// 2 = no scratch for it in this round.
+namespace {
+template <bool FUSED>
+__device__ __forceinline__ u32 parse_job(const ZraDecodeArgs& a, const u32 j, ParseShared& S, const int lane, u32* ldsT) {
+  u32 outcome = 0;
+  {
     const u64 so = a.frameOff[(size_t)j * a.offStride], se = a.frameOff[(size_t)j * a.offStride + 1];
     const u8* const src = a.body + so;
     const bool spanOk = se >= so && se <= a.bodySize;
@@ -637,9 +634,9 @@ zra_dec_parse_kernel(ZraDecodeArgs a) {
         // this round's scratch is full: the frame keeps its state as of this block's header and takes the next round
         if (lane == 0) {
           save_persistent(S.hdrPos, produced0, hv0, hmb0, hns0, hx20);
-          a.nextActive[atomicAdd(&a.counters[ZRA_DC_NNEXT], 1u)] = j;
+          if (!FUSED) a.nextActive[atomicAdd(&a.counters[ZRA_DC_NNEXT], 1u)] = j;
         }
-        handed = true;          // (nothing pending, but the frame is not finished either)
+        handed = true; outcome = 2;          // (nothing pending, but the frame is not finished either)
         wsync();
         break;
       }
@@ -666,12 +663,14 @@ zra_dec_parse_kernel(ZraDecodeArgs a) {
             if (lane == 0) {
               if (k == 2) { G[0] = mk_cell(ms, ms, 0, 0); S.ofShare = (ms > 22) ? 256u : 0u; }
               else { G[0] = mk_cell(ms, k == 0 ? c_ll_bits[ms] : c_ml_bits[ms], 0, 0); G[1] = k == 0 ? c_ll_base[ms] : c_ml_base[ms]; }
+              if (FUSED) { u32* const GL = ldsT + (k == 0 ? ZRA_DEC_TBL_LL : k == 1 ? ZRA_DEC_TBL_ML : ZRA_DEC_TBL_OF); GL[0] = G[0]; if (k != 2) GL[1] = G[1]; }
             }
           } else if (mode != 3) {
             build_fse_dtable(S.stage, S.norm, ms, tl, k, S.spread, lane);
             wsync();
             const u32 words = (k == 2 ? 1u : 2u) << tl;
             for (u32 i = lane; i < words; i += DEC_THREADS) G[i] = S.stage[i];
+            if (FUSED) { u32* const GL = ldsT + (k == 0 ? ZRA_DEC_TBL_LL : k == 1 ? ZRA_DEC_TBL_ML : ZRA_DEC_TBL_OF); for (u32 i = lane; i < words; i += DEC_THREADS) GL[i] = S.stage[i]; }
             if (k == 2) {
               // share of long offset codes (ZSTD_getLongOffsetsShare): cells whose code needs more than 22 extra bits, scaled to 8 bits
               u32 cnt = 0;
@@ -698,13 +697,15 @@ zra_dec_parse_kernel(ZraDecodeArgs a) {
         F->hufErr = 0; F->lateErr = S.lateErr;
         F->nbSeq = S.lateErr ? 0u : nbSeq; F->seqPos = S.seqPos; F->seqBase = S.seqBase;
         F->longMode = (S.bigWindow && nbSeq > 4 && S.ofShare >= 7) ? 1u : 0u;
-        a.pending[atomicAdd(&a.counters[ZRA_DC_NPENDING], 1u)] = j;
-        if (S.litKind == 2) a.hufJobs[atomicAdd(&a.counters[ZRA_DC_NHUF], 1u)] = j;
+        if (!FUSED) {
+          a.pending[atomicAdd(&a.counters[ZRA_DC_NPENDING], 1u)] = j;
+          if (S.litKind == 2) a.hufJobs[atomicAdd(&a.counters[ZRA_DC_NHUF], 1u)] = j;
+        }
       }
       if (S.litType == 2) {                               // a new tree: its description stays with the frame (treeless blocks reuse it)
         for (u32 i = lane; i < 256; i += DEC_THREADS) { F->weights[i] = S.weights[i]; F->hufStart[i] = S.hufStart[i]; }
       }
-      handed = true;
+      handed = true; outcome = 1;
       wsync();
       break;
     }
@@ -712,6 +713,22 @@ zra_dec_parse_kernel(ZraDecodeArgs a) {
       frame_finish(a, j, src, srcSize, S.err, S.produced, S.blkPos, truncated, S.fcsHave, S.fcsLo, S.fcsHi, S.hasChecksum, lane);
     }
     wsync();
+  }
+  return outcome;
+}
+}  // namespace
+
+extern "C" __global__ void __launch_bounds__(DEC_THREADS)
+zra_dec_parse_kernel(ZraDecodeArgs a) {
+  __shared__ ParseShared S;
+  const int lane = threadIdx.x;
+  for (;;) {
+    if (lane == 0) S.job = atomicAdd(&a.counters[ZRA_DC_QPARSE], 1u);
+    wsync();
+    const u32 qi = S.job;
+    wsync();
+    if (qi >= a.nActive) return;
+    (void)parse_job<false>(a, a.active ? a.active[qi] : qi, S, lane, nullptr);
   }
 }
 
@@ -745,7 +762,7 @@ __device__ __forceinline__ u32 peek12(const u8* base, const u8* lim, i32 pos) {
 // one symbol or a PAIR (when both codes fit in 12 bits); if the walk ends one output position short, HUF_decodeLastSymbolX2 takes
 // the first symbol of the entry under the cursor and, for a pair entry, skips the bits of both codes clamped to the end of the
 // stream (nothing when no bit is left). Returns true when that decoder accepts the stream; `o` gets the symbols it writes.
-__device__ bool huf_stream_x2(const u16* tab, const u8* w1, u32 mb, const u8* base, u32 n, const u8* lim, u8* o, u32 regen) {
+__device__ __forceinline__ bool huf_stream_x2(const u16* tab, const u8* w1, u32 mb, const u8* base, u32 n, const u8* lim, u8* o, u32 regen) {
   if (n == 0) return false;
   const u32 last = base[n - 1];
   if (last == 0) return false;
@@ -778,6 +795,95 @@ __device__ bool huf_stream_x2(const u16* tab, const u8* w1, u32 mb, const u8* ba
 }
 }  // namespace
 
+namespace {
+// decode table of one frame's kept Huffman description, by the whole wave: lane l owns symbols 4l .. 4l+3
+__device__ __forceinline__ void huf_build_table(const ZraDecFrame* const F, u16* const tab, u8* const w1, const int lane) {
+  const u32 maxBits = F->hufMaxBits, nSym = F->hufNSym;
+  const u32 sh = maxBits == 12 ? 1u : 0u;          // depth 12: cells are indexed by the top 11 bits, the 12-bit codes come in pairs
+  const u32 w4 = *(const u32*)(F->weights + 4 * lane);
+  const u64 st4 = *(const u64*)(F->hufStart + 4 * lane);
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const u32 sy = 4 * (u32)lane + k;
+    const u32 w = sy < nSym ? (w4 >> (8 * k)) & 0xFF : 0u;
+    u32 start = (u32)(st4 >> (16 * k)) & 0xFFFFu, len = w ? 1u << (w - 1) : 0u;
+    const u16 e = (u16)(sy | ((maxBits + 1 - w) << 8));
+    if (sh && w == 1) { w1[start] = (u8)sy; if (!(start & 1)) tab[start >> 1] = (u16)(0x8000u | (12u << 8)); len = 0; }
+    len >>= sh; start >>= sh;
+    // short runs by their own lane, long ones by the whole wave
+    const bool big = len >= 32;
+    if (!big) for (u32 c = 0; c < len; c++) tab[start + c] = e;
+    u64 bm = __ballot(big);
+    while (bm) {
+      const u32 l2 = (u32)__builtin_ctzll(bm); bm &= bm - 1;
+      const u32 bs = bcast_u32(start, l2), bl = bcast_u32(len, l2), be = bcast_u32((u32)e, l2);
+      for (u32 c = lane; c < bl; c += DEC_THREADS) tab[bs + c] = (u16)be;
+    }
+  }
+}
+// one literal stream of frame job j by ONE lane (strm < F->litStreams); returns false when libzstd would reject the stream.
+// stopAt: symbols of this stream that are needed (random access that stops early: the rest is not decoded; only without X2 fall-back)
+__device__ __forceinline__ bool huf_decode_stream(const ZraDecodeArgs& a, ZraDecFrame* const F, const u32 j, const u16* const tab, const u8* const w1,
+                                                  const u32 strm, const u8* const lim) {
+  const u32 nStreams = F->litStreams, regen = F->litRegen;
+  const u32 seg = nStreams == 1 ? regen : (regen + 3) / 4;
+  const u32 myLen = nStreams == 1 ? regen : (strm < 3 ? seg : regen - 3 * seg);
+  u8* o = a.lits + F->litBase + (size_t)strm * seg;
+  const u8* const blk = a.body + a.frameOff[(size_t)j * a.offStride] + F->bpos;
+  const u8* const sb = blk + F->streamOff[strm]; const u32 sl = F->streamLen[strm];
+  const int mb = (int)F->hufMaxBits;
+#ifndef ZRA_HUF_READER_AHEAD
+#define ZRA_HUF_READER_AHEAD 1
+#endif
+#if ZRA_HUF_READER_AHEAD
+  BitRS hb;
+#else
+  BitR hb;
+#endif
+  bool bad = hb.init(sb, sl, lim) != 0;
+  if (!bad) {
+    u32 i = 0;
+    if (mb < 12) {
+      // 16 symbols per store (write requests are the expensive ones), 4 symbols per window reload (4*11 = 44 <= 56 guaranteed bits)
+      for (; i + 16 <= myLen; i += 16) {
+        u32 pk[4];
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+          hb.ensure(4 * mb);
+          u32 packed = 0;
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            u32 e = tab[hb.peek(mb)];
+            packed |= (e & 0xFF) << (8 * k);
+            hb.skip((int)(e >> 8));
+          }
+          pk[g] = packed;
+        }
+        st128(o + i, pk[0], pk[1], pk[2], pk[3]);
+      }
+      for (; i + 4 <= myLen; i += 4) {
+        hb.ensure(4 * mb);
+        u32 packed = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          u32 e = tab[hb.peek(mb)];
+          packed |= (e & 0xFF) << (8 * k);
+          hb.skip((int)(e >> 8));
+        }
+        st32(o + i, packed);
+      }
+      for (; i < myLen; i++) { hb.ensure(mb); u32 e = tab[hb.peek(mb)]; o[i] = (u8)e; hb.skip((int)(e >> 8)); }
+    } else {
+      for (; i < myLen; i++) { hb.ensure(12); const u32 e = huf_lookup12(tab, w1, hb.peek(12), 12); o[i] = (u8)e; hb.skip((int)(e >> 8)); }
+    }
+    if (hb.pos != 0) bad = true;
+  }
+  // a stream the single-symbol rules reject may still pass libzstd's double-symbol decoder, if that is the one it would use
+  if (bad && F->hufX2) bad = !huf_stream_x2(tab, w1, (u32)mb, sb, sl, lim, o, myLen);
+  return !bad;
+}
+}  // namespace
+
 extern "C" __global__ void __launch_bounds__(DEC_THREADS)
 zra_dec_huf_kernel(ZraDecodeArgs a) {
   __shared__ HufShared S;
@@ -791,98 +897,15 @@ zra_dec_huf_kernel(ZraDecodeArgs a) {
     const u32 base = S.base;
     if (base >= nJobs) return;
     const u32 nHere = min((u32)HUF_FRAMES, nJobs - base);
-    // ---- the tables of this batch, one frame after the other, all lanes on each: lane l owns symbols 4l .. 4l+3
-    for (u32 s = 0; s < nHere; s++) {
-      const ZraDecFrame* const F = &a.frames[a.hufJobs[base + s]];
-      const u32 maxBits = F->hufMaxBits, nSym = F->hufNSym;
-      const u32 sh = maxBits == 12 ? 1u : 0u;          // depth 12: cells are indexed by the top 11 bits, the 12-bit codes come in pairs
-      const u32 w4 = *(const u32*)(F->weights + 4 * lane);
-      const u64 st4 = *(const u64*)(F->hufStart + 4 * lane);
-      u16* const tab = S.tab[s]; u8* const w1 = S.w1[s];
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const u32 sy = 4 * (u32)lane + k;
-        const u32 w = sy < nSym ? (w4 >> (8 * k)) & 0xFF : 0u;
-        u32 start = (u32)(st4 >> (16 * k)) & 0xFFFFu, len = w ? 1u << (w - 1) : 0u;
-        const u16 e = (u16)(sy | ((maxBits + 1 - w) << 8));
-        if (sh && w == 1) { w1[start] = (u8)sy; if (!(start & 1)) tab[start >> 1] = (u16)(0x8000u | (12u << 8)); len = 0; }
-        len >>= sh; start >>= sh;
-        // short runs by their own lane, long ones by the whole wave
-        const bool big = len >= 32;
-        if (!big) for (u32 c = 0; c < len; c++) tab[start + c] = e;
-        u64 bm = __ballot(big);
-        while (bm) {
-          const u32 l2 = (u32)__builtin_ctzll(bm); bm &= bm - 1;
-          const u32 bs = bcast_u32(start, l2), bl = bcast_u32(len, l2), be = bcast_u32((u32)e, l2);
-          for (u32 c = lane; c < bl; c += DEC_THREADS) tab[bs + c] = (u16)be;
-        }
-      }
-    }
+    // ---- the tables of this batch, one frame after the other, all lanes on each
+    for (u32 s = 0; s < nHere; s++) huf_build_table(&a.frames[a.hufJobs[base + s]], S.tab[s], S.w1[s], lane);
     wsync();
     // ---- the streams: lane -> (frame slot, stream)
     const u32 slot = (u32)lane >> 2, strm = (u32)lane & 3;
     if (slot < nHere) {
-      ZraDecFrame* const F = &a.frames[a.hufJobs[base + slot]];
-      const u32 nStreams = F->litStreams, regen = F->litRegen;
-      if (strm < nStreams) {
-        const u32 seg = nStreams == 1 ? regen : (regen + 3) / 4;
-        const u32 myLen = nStreams == 1 ? regen : (strm < 3 ? seg : regen - 3 * seg);
-        u8* o = a.lits + F->litBase + (size_t)strm * seg;
-        const u32 j = a.hufJobs[base + slot];
-        const u8* const blk = a.body + a.frameOff[(size_t)j * a.offStride] + F->bpos;
-        const u8* const sb = blk + F->streamOff[strm]; const u32 sl = F->streamLen[strm];
-        const u16* const tab = S.tab[slot];
-        const int mb = (int)F->hufMaxBits;
-#ifndef ZRA_HUF_READER_AHEAD
-#define ZRA_HUF_READER_AHEAD 1
-#endif
-#if ZRA_HUF_READER_AHEAD
-        BitRS hb;
-#else
-        BitR hb;
-#endif
-        bool bad = hb.init(sb, sl, lim) != 0;
-        if (!bad) {
-          u32 i = 0;
-          if (mb < 12) {
-            // 16 symbols per store (write requests are the expensive ones), 4 symbols per window reload (4*11 = 44 <= 56 guaranteed bits)
-            for (; i + 16 <= myLen; i += 16) {
-              u32 pk[4];
-#pragma unroll
-              for (int g = 0; g < 4; g++) {
-                hb.ensure(4 * mb);
-                u32 packed = 0;
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                  u32 e = tab[hb.peek(mb)];
-                  packed |= (e & 0xFF) << (8 * k);
-                  hb.skip((int)(e >> 8));
-                }
-                pk[g] = packed;
-              }
-              st128(o + i, pk[0], pk[1], pk[2], pk[3]);
-            }
-            for (; i + 4 <= myLen; i += 4) {
-              hb.ensure(4 * mb);
-              u32 packed = 0;
-#pragma unroll
-              for (int k = 0; k < 4; k++) {
-                u32 e = tab[hb.peek(mb)];
-                packed |= (e & 0xFF) << (8 * k);
-                hb.skip((int)(e >> 8));
-              }
-              st32(o + i, packed);
-            }
-            for (; i < myLen; i++) { hb.ensure(mb); u32 e = tab[hb.peek(mb)]; o[i] = (u8)e; hb.skip((int)(e >> 8)); }
-          } else {
-            for (; i < myLen; i++) { hb.ensure(12); const u32 e = huf_lookup12(tab, S.w1[slot], hb.peek(12), 12); o[i] = (u8)e; hb.skip((int)(e >> 8)); }
-          }
-          if (hb.pos != 0) bad = true;
-        }
-        // a stream the single-symbol rules reject may still pass libzstd's double-symbol decoder, if that is the one it would use
-        if (bad && F->hufX2) bad = !huf_stream_x2(tab, S.w1[slot], (u32)mb, sb, sl, lim, o, myLen);
-        if (bad) F->hufErr = 1;
-      }
+      const u32 j = a.hufJobs[base + slot];
+      ZraDecFrame* const F = &a.frames[j];
+      if (strm < F->litStreams && !huf_decode_stream(a, F, j, S.tab[slot], S.w1[slot], strm, lim)) F->hufErr = 1;
     }
   }
 }
@@ -1115,18 +1138,13 @@ extern "C" __attribute__((visibility("default"))) void ZraHipDebugReadDecProfile
 #define XTIME(k)
 #endif
 
-extern "C" __global__ void __launch_bounds__(DEC_THREADS)
-zra_dec_exec_kernel(ZraDecodeArgs a) {
-  __shared__ ExecShared S;
-  const int lane = threadIdx.x;
-  const u32 nPend = a.counters[ZRA_DC_NPENDING];
-  for (;;) {
-    if (lane == 0) S.job = atomicAdd(&a.counters[ZRA_DC_QEXEC], 1u);
-    wsync();
-    const u32 qi = S.job;
-    wsync();
-    if (qi >= nPend) return;
-    const u32 j = a.pending[qi];
+namespace {
+// one job (frame j, the block the chain stage left sequences for) by one wave. FUSED: a frame that goes on is not appended to the
+// next round's list; returns 1 when the frame has another block to go.
+template <bool FUSED>
+__device__ __forceinline__ u32 exec_job(const ZraDecodeArgs& a, const u32 j, ExecShared& S, const int lane) {
+  u32 more = 0;
+  {
     const size_t gj = j;
     ZraDecFrame* const F = &a.frames[j];
     const u64 so = a.frameOff[gj * a.offStride], se = a.frameOff[gj * a.offStride + 1];
@@ -1221,11 +1239,163 @@ zra_dec_exec_kernel(ZraDecodeArgs a) {
     const u32 produced = produced0 + blockOut, endPos = F->bpos + F->bsize;
     if (chainErr || truncated || F->blast) {
       frame_finish(a, j, src, srcSize, chainErr, produced, endPos, truncated != 0, F->fcsHave, F->fcsLo, F->fcsHi, F->hasChecksum, lane);
-    } else if (lane == 0) {
-      F->produced = produced; F->blkPos = endPos;
-      F->rep[0] = F->repOut[0]; F->rep[1] = F->repOut[1]; F->rep[2] = F->repOut[2];
-      a.nextActive[atomicAdd(&a.counters[ZRA_DC_NNEXT], 1u)] = j;
+    } else {
+      more = 1;
+      if (lane == 0) {
+        F->produced = produced; F->blkPos = endPos;
+        F->rep[0] = F->repOut[0]; F->rep[1] = F->repOut[1]; F->rep[2] = F->repOut[2];
+        if (!FUSED) a.nextActive[atomicAdd(&a.counters[ZRA_DC_NNEXT], 1u)] = j;
+      }
     }
     wsync();
+  }
+  return more;
+}
+}  // namespace
+
+extern "C" __global__ void __launch_bounds__(DEC_THREADS)
+zra_dec_exec_kernel(ZraDecodeArgs a) {
+  __shared__ ExecShared S;
+  const int lane = threadIdx.x;
+  const u32 nPend = a.counters[ZRA_DC_NPENDING];
+  for (;;) {
+    if (lane == 0) S.job = atomicAdd(&a.counters[ZRA_DC_QEXEC], 1u);
+    wsync();
+    const u32 qi = S.job;
+    wsync();
+    if (qi >= nPend) return;
+    (void)exec_job<false>(a, a.pending[qi], S, lane);
+  }
+}
+
+// =================================================================================================
+// One-launch decode for SMALL random-access batches (the latency path; reference call: DecompressRA, zra.cpp:258-296, one core
+// answers a 4 KiB query in ~37 us). The four-kernel pipeline above is built for throughput: a lone frame pays four launches, a host
+// synchronisation per round and a sequence chain that runs one lane at the pace of global-memory round trips. Here ONE workgroup of
+// two waves takes a frame through all stages without leaving the kernel: wave 0 parses (the same parse_job), then wave 1 decodes the
+// Huffman literals while wave 0 runs the FSE sequence chain out of LDS (tables and bitstream copied there: a table cell costs an LDS
+// read instead of an L2 round trip), then wave 0 executes (the same exec_job). The chain here is the straight-line case of
+// zra_dec_chain_kernel's step — the 64-bit sequence loop on a well-formed stream; whatever that loop would have to look at twice (a
+// sequence that fails a check, the long-offset loop, a literal stream the decoder rejects, a stream that is not consumed exactly) makes
+// the job BAIL: the host then takes the whole batch through the four-kernel pipeline, which is where every status of the reference is
+// reproduced. Valid archives never bail.
+namespace {
+constexpr u32 SMALL_SEQ_BYTES = 40u << 10;      // sequence bitstreams up to this size are copied to LDS (a 64 KiB frame's is ~10 KiB)
+struct __attribute__((aligned(16))) SmallShared {
+  ParseShared P;
+  ExecShared X;
+  u32 tabs[ZRA_DEC_TBL_WORDS];
+  u16 hufTab[2048]; u8 hufW1[256];
+  u8 bits[SMALL_SEQ_BYTES + 16];
+  u32 ctl[4];                                   // [0] parse outcome, [1] bail, [2] frame goes on
+};
+
+// returns 0: sequences of the block validated and stored (F->chainErr = 0 ...); 1: bail
+__device__ __forceinline__ u32 chain_job_lean(const ZraDecodeArgs& a, const u32 j, ZraDecFrame* const F, const u32* const T, u8* const bits, const int lane) {
+  const u32 nbSeq = F->nbSeq;
+  if (F->lateErr || F->longMode) return 1;
+  const u32 regen = F->litRegen, produced0 = F->produced;
+  const u32 outCap = a.outCap[j] - produced0;
+  const u32 limit = a.limit ? a.limit[j] : 0xFFFFFFFFu;
+  u64* const sq = a.seqs + F->seqBase;
+  u32 rep0 = F->rep[0], rep1 = F->rep[1], rep2 = F->rep[2];
+  u32 outPos = 0, litPos = 0, valid = 0, truncated = 0;
+  if (nbSeq) {
+    const u32 n = F->bsize - F->seqPos;
+    if (n < 8 || n > SMALL_SEQ_BYTES) return 1;
+    {
+      const u8* const g = a.body + a.frameOff[(size_t)j * a.offStride] + F->bpos + F->seqPos;
+      for (u32 o = 8u * (u32)lane; o < n; o += 8u * DEC_THREADS) {
+        if (o + 8 <= n) *(u64*)(bits + o) = ld64(g + o);
+        else for (u32 k = o; k < n; k++) bits[k] = g[k];
+      }
+      wsync();
+    }
+    Zds br;
+    if (!br.init(bits, n)) return 1;
+    u32 sLL = br.read(F->llLog); br.reload();
+    u32 sOF = br.read(F->ofLog); br.reload();
+    u32 sML = br.read(F->mlLog); br.reload();
+    u32 qlo = 0, qhi = 0;                        // sequences leave 64 at a time: lane (i & 63) keeps sequence i
+    u32 i = 0;
+    for (; i < nbSeq; i++) {
+      const uint2 eL = *(const uint2*)(T + ZRA_DEC_TBL_LL + 2 * sLL), eM = *(const uint2*)(T + ZRA_DEC_TBL_ML + 2 * sML);
+      const u32 eO = T[ZRA_DEC_TBL_OF + sOF];
+      const u32 ofBits = (eO >> 8) & 0xFF, mlBits = (eM.x >> 8) & 0xFF, llBits = (eL.x >> 8) & 0xFF;
+      u32 ll = eL.y, ml = eM.y, off;
+      if (ofBits > 1) {
+        off = ((1u << ofBits) - 3u) + br.read_fast(ofBits);
+        rep2 = rep1; rep1 = rep0; rep0 = off;
+      } else {
+        const u32 ll0 = (ll == 0);
+        if (ofBits == 0) {
+          if (!ll0) off = rep0;
+          else { off = rep1; rep1 = rep0; rep0 = off; }
+        } else {
+          const u32 idx = 1 + ll0 + br.read_fast(1);
+          u32 t = idx == 3 ? rep0 - 1 : idx == 1 ? rep1 : rep2;
+          t += !t;
+          if (idx != 1) rep2 = rep1;
+          rep1 = rep0; rep0 = off = t;
+        }
+      }
+      if (mlBits) ml += br.read_fast(mlBits);
+      if (llBits + mlBits + ofBits >= 57 - (9 + 9 + 8)) br.reload();
+      if (llBits) ll += br.read_fast(llBits);
+      sLL = (eL.x >> 20) + br.read((eL.x >> 16) & 0xF);
+      sML = (eM.x >> 20) + br.read((eM.x >> 16) & 0xF);
+      sOF = (eO >> 20) + br.read((eO >> 16) & 0xF);
+      br.reload_quiet(true, bits);
+      if (ll + ml > outCap - outPos || ll > regen - litPos || off > produced0 + outPos + ll) return 1;
+      const u64 qv = (u64)ll | ((u64)ml << 18) | ((u64)min(off, 0x0FFFFFFFu) << 36);
+      if (((u32)lane) == (i & 63u)) { qlo = (u32)qv; qhi = (u32)(qv >> 32); }
+      if ((i & 63u) == 63u) sq[i - 63 + (u32)lane] = (u64)qlo | ((u64)qhi << 32);
+      outPos += ll + ml; litPos += ll;
+      valid = i + 1;
+      if (produced0 + outPos >= limit) { truncated = 1; break; }       // random access: stop at the sequence that covers the last needed byte
+    }
+    if ((valid & 63u) && (u32)lane < (valid & 63u)) sq[(valid & ~63u) + (u32)lane] = (u64)qlo | ((u64)qhi << 32);
+    if (!truncated && br.reload() < Zds::COMPLETED) return 1;            // the stream must be consumed exactly
+  }
+  if (!truncated && regen - litPos > outCap - outPos) return 1;          // the tail literals need room
+  if (lane == 0) {
+    F->chainErr = 0; F->nSeqValid = valid; F->seqOut = outPos; F->seqLit = litPos; F->truncated = truncated;
+    F->repOut[0] = rep0; F->repOut[1] = rep1; F->repOut[2] = rep2;
+  }
+  return 0;
+}
+}  // namespace
+
+// grid = jobs (one workgroup each), 128 threads. *bail counts the jobs that have to go through the four-kernel pipeline.
+extern "C" __global__ void __launch_bounds__(2 * DEC_THREADS)
+zra_ra_small_kernel(ZraDecodeArgs a0, u32* bail) {
+  __shared__ SmallShared S;
+  const int wave = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
+  const u32 j = blockIdx.x;
+  ZraDecodeArgs a = a0;
+  ZraDecFrame* const F = &a.frames[j];
+  const u8* const lim = a.body + a.bodySize;
+  for (u32 round = 0;; round++) {
+    a.round = round;
+    if (wave == 0) { const u32 oc = parse_job<true>(a, j, S.P, lane, S.tabs); if (lane == 0) { S.ctl[0] = oc; S.ctl[1] = 0; } }
+    __syncthreads();
+    const u32 oc = S.ctl[0];
+    if (oc == 0) return;                                   // the frame is finished (status and slices written by frame_finish)
+    if (oc == 2) { if (threadIdx.x == 0) atomicAdd(bail, 1u); return; }
+    if (wave == 1) {
+      if (F->litKind == 2) {
+        huf_build_table(F, S.hufTab, S.hufW1, lane);
+        wsync();
+        if ((u32)lane < F->litStreams && !huf_decode_stream(a, F, j, S.hufTab, S.hufW1, (u32)lane, lim)) S.ctl[1] = 1;
+      }
+    } else {
+      if (chain_job_lean(a, j, F, S.tabs, S.bits, lane) && lane == 0) S.ctl[1] = 1;
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (S.ctl[1]) { if (threadIdx.x == 0) atomicAdd(bail, 1u); return; }
+    if (wave == 0) { const u32 more = exec_job<true>(a, j, S.X, lane); if (lane == 0) S.ctl[2] = more; }
+    __syncthreads();
+    if (!S.ctl[2]) return;
   }
 }

@@ -66,6 +66,9 @@ class Engine {
   // one pass: jobs [0, a.nFrames) of the arrays in `a` through the parse / chain / execute rounds + frame-end checks;
   // *res = min over failing jobs of ((jobBase + job) << 8 | code), untouched when none fails
   Status decode_launch(const struct ZraDecodeArgs& a, const uint32_t* dExpect, uint32_t maxFrameBytes, uint32_t jobBase, unsigned long long* hResult);
+  // the same for few jobs: one launch (zra_ra_small_kernel), one synchronisation; *bailed = jobs that need decode_launch after all
+  Status decode_small(const struct ZraDecodeArgs& a, const uint32_t* dExpect, uint32_t maxFrameBytes, uint32_t jobBase, unsigned long long* hResult, uint32_t* bailed);
+  Status decode_scratch(struct ZraDecodeArgs& a, uint32_t maxFrameBytes);
   // Whole archive resident on the device (header + body), output on the device.
   Status decompress_device(const uint8_t* dArc, size_t arcSize, uint8_t* dOut, size_t outCap);
   // Batched random access, archive + output on the device, query arrays on the host.

@@ -13,6 +13,7 @@ extern "C" __global__ void zra_dec_parse_kernel(ZraDecodeArgs a);
 extern "C" __global__ void zra_dec_huf_kernel(ZraDecodeArgs a);
 extern "C" __global__ void zra_dec_chain_kernel(ZraDecodeArgs a);
 extern "C" __global__ void zra_dec_exec_kernel(ZraDecodeArgs a);
+extern "C" __global__ void zra_ra_small_kernel(ZraDecodeArgs a, uint32_t* bail);
 
 using namespace zra_dev;
 
@@ -294,8 +295,8 @@ Status Engine::wait_stream(hipStream_t producer) {
 
 // One pass of the decoder over the jobs of `a0`: rounds of parse -> chain -> execute (a round = one compressed block of every
 // unfinished frame) until no frame is left, then the content checksums and the first-error reduction.
-Status Engine::decode_launch(const ZraDecodeArgs& a0, const uint32_t* dExpect, uint32_t maxFrameBytes, uint32_t jobBase, unsigned long long* hResult) {
-  ZraDecodeArgs a = a0;
+// scratch of one decode pass over a.nFrames jobs (decode records, table slots, stage lists, literal / sequence scratch, result words)
+Status Engine::decode_scratch(ZraDecodeArgs& a, uint32_t maxFrameBytes) {
   const uint32_t n = a.nFrames;
   // scratch of a round: Huffman-decoded literals and decoded sequences of one block per frame, bump-allocated on the device
   const uint64_t perFrame = std::min<uint64_t>((uint64_t)maxFrameBytes + 16, (128u << 10) + 16);
@@ -304,16 +305,56 @@ Status Engine::decode_launch(const ZraDecodeArgs& a0, const uint32_t* dExpect, u
   const uint64_t litCap = std::max<uint64_t>((uint64_t)n * perFrame / 2, 1u << 20);
   const uint64_t seqCap = std::max<uint64_t>((uint64_t)n * perFrame * 3 / 32, 1u << 20);               // entries of 8 bytes
   if (!decFrames_.reserve((size_t)n * sizeof(ZraDecFrame)) || !decTables_.reserve((size_t)n * ZRA_DEC_TBL_WORDS * 4) ||
-      !decLists_.reserve((size_t)n * 16 + 64) || !decCounters_.reserve(ZRA_DC_WORDS * 4) || !decLits_.reserve(litCap + 64) ||
+      !decLists_.reserve((size_t)n * 16 + 64) || !decCounters_.reserve(ZRA_DC_WORDS * 4 + 64) || !decLits_.reserve(litCap + 64) ||
       !decSeqs_.reserve(seqCap * 8 + 64) || !status_.reserve((size_t)n * 4) || !produced_.reserve((size_t)n * 4) ||
       !frameMeta_.reserve((size_t)n * 8) || !result_.reserve(64))
     return zerr(64 /* memory_allocation */);
-  uint32_t* listA = decLists_.as<uint32_t>(); uint32_t* listB = listA + n;
+  uint32_t* listA = decLists_.as<uint32_t>();
   a.pending = listA + 2 * (size_t)n; a.hufJobs = listA + 3 * (size_t)n;
   a.counters = decCounters_.as<uint32_t>();
   a.frames = decFrames_.as<ZraDecFrame>(); a.tables = decTables_.as<uint32_t>();
   a.lits = decLits_.as<uint8_t>(); a.litCap = litCap; a.seqs = decSeqs_.as<uint64_t>(); a.seqCap = seqCap;
   a.status = status_.as<uint32_t>(); a.produced = produced_.as<uint32_t>(); a.frameMeta = frameMeta_.as<uint32_t>();
+  return ok();
+}
+
+// Small batches (random access): every job in ONE launch of zra_ra_small_kernel, frame-end checks behind it, one synchronisation.
+// *bailed: jobs the kernel handed back (damaged or unusual frames): the caller takes the batch through decode_launch.
+Status Engine::decode_small(const ZraDecodeArgs& a0, const uint32_t* dExpect, uint32_t maxFrameBytes, uint32_t jobBase, unsigned long long* hResult, uint32_t* bailed) {
+  ZraDecodeArgs a = a0;
+  const uint32_t n = a.nFrames;
+  { Status st = decode_scratch(a, maxFrameBytes); if (st.zra) return st; }
+  a.active = nullptr; a.nActive = n; a.round = 0; a.nextActive = decLists_.as<uint32_t>(); a.debugSkip = 0;
+  uint32_t* dBail = a.counters + ZRA_DC_WORDS;
+  HIPCHK(hipMemsetAsync(a.counters, 0, ZRA_DC_WORDS * 4 + 8, stream_));
+  HIPCHK(hipEventRecord(ev0_, stream_));
+  hipLaunchKernelGGL(zra_ra_small_kernel, dim3(n), dim3(128), 0, stream_, a, dBail);
+  HIPCHK(hipEventRecord(ev1_, stream_));
+  const uint32_t tb = 256;
+  hipLaunchKernelGGL(zra_xxh64_verify_kernel, dim3((n * 4 + tb - 1) / tb), dim3(tb), 0, stream_, a.out, a.outOff, dExpect,
+                     produced_.as<uint32_t>(), frameMeta_.as<uint32_t>(), status_.as<uint32_t>(), n);
+  hipLaunchKernelGGL(zra_first_error_kernel, dim3((n + tb - 1) / tb), dim3(tb), 0, stream_, status_.as<uint32_t>(), n, jobBase,
+                     result_.as<unsigned long long>());
+  // result word and bail counter come back together
+  HIPCHK(hipMemcpyAsync(result_.as<uint8_t>() + 8, dBail, 4, hipMemcpyDeviceToDevice, stream_));
+  unsigned long long two[2] = {~0ull, 0};
+  HIPCHK(hipMemcpyAsync(two, result_.p, 16, hipMemcpyDeviceToHost, stream_));
+  HIPCHK(hipStreamSynchronize(stream_));
+  HIPCHK(hipGetLastError());
+  *bailed = (uint32_t)two[1];
+  if (!*bailed) *hResult = two[0];
+  float ms = 0;
+  if (hipEventElapsedTime(&ms, ev0_, ev1_) == hipSuccess) { lastKernelMs_ = ms; kstats_[4] += ms; kstats_[5] += 1; }
+  return ok();
+}
+
+// One pass of the decoder over the jobs of `a0`: rounds of parse -> chain -> execute (a round = one compressed block of every
+// unfinished frame) until no frame is left, then the content checksums and the first-error reduction.
+Status Engine::decode_launch(const ZraDecodeArgs& a0, const uint32_t* dExpect, uint32_t maxFrameBytes, uint32_t jobBase, unsigned long long* hResult) {
+  ZraDecodeArgs a = a0;
+  const uint32_t n = a.nFrames;
+  { Status st = decode_scratch(a, maxFrameBytes); if (st.zra) return st; }
+  uint32_t* listA = decLists_.as<uint32_t>(); uint32_t* listB = listA + n;
   static const int wavesCap = std::getenv("ZRA_DEC_WAVES") ? std::atoi(std::getenv("ZRA_DEC_WAVES")) : 0;   // bring-up: occupancy sweep
   if (!decOccParse_) {
     HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&decOccParse_, zra_dec_parse_kernel, 64, 0));
@@ -392,8 +433,23 @@ Status Engine::decode_jobs(const uint8_t* dBody, uint64_t bodySize, const uint64
     b.nFrames = std::min(passFrames, nFrames - p0);
     b.frameOff = dFrameOff + (size_t)p0 * offStride; b.outOff = dOutOff + p0; b.outCap = dExpect + p0;
     if (ra) { if (ra->limit) b.limit = ra->limit + p0; if (ra->pieceBase) b.pieceBase = ra->pieceBase + p0; }
-    Status st = decode_launch(b, dExpect + p0, maxFrameBytes, p0, &res);
-    if (st.zra) return st;
+    // few jobs: the one-launch kernel (latency path); a job it hands back (damaged / unusual frame) sends the pass through the
+    // four-kernel pipeline, where every status of the reference is reproduced
+    static const uint32_t smallMax = std::getenv("ZRA_DEC_SMALL_MAX") ? (uint32_t)std::atoi(std::getenv("ZRA_DEC_SMALL_MAX")) : 1024u;
+    bool done = false;
+    if (b.nFrames <= smallMax) {
+      uint32_t bailed = 0;
+      unsigned long long r2 = res;
+      Status st = decode_small(b, dExpect + p0, maxFrameBytes, p0, &r2, &bailed);
+      if (st.zra) return st;
+      if (!bailed) { res = r2; done = true; }
+      else if (res == ~0ull) HIPCHK(hipMemsetAsync(result_.p, 0xFF, 64, stream_));   // (what the handed-back pass left in the result word)
+      else { unsigned long long keep = res; HIPCHK(hipMemsetAsync(result_.p, 0xFF, 64, stream_)); HIPCHK(hipMemcpyAsync(result_.p, &keep, 8, hipMemcpyHostToDevice, stream_)); HIPCHK(hipStreamSynchronize(stream_)); }
+    }
+    if (!done) {
+      Status st = decode_launch(b, dExpect + p0, maxFrameBytes, p0, &res);
+      if (st.zra) return st;
+    }
   }
   if (res == ~0ull) return ok();
   const uint32_t code = (uint32_t)(res & 0xFF), first = (uint32_t)(res >> 8);
