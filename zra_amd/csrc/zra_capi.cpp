@@ -367,6 +367,9 @@ namespace zra {
       if (done < size && rem2) {
         auto p = piece(last - 1, last);
         multiframe_call(p.first, p.second, frameBuffer.data(), frameBuffer.size(), header.frameSize);
+        // frames that regenerate less than the header's frameSize (an inflated frameSize / uncompressedSize) leave more than one frame
+        // buffer to fill here: the reference copies past its buffer (undefined); here that is a corrupted archive
+        if (size - done > frameBuffer.size()) throw Exception(StatusCode::ZStdError, 20);
         std::memcpy(out + done, frameBuffer.data(), size - done);
       }
     }

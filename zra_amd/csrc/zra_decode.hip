@@ -94,6 +94,12 @@ __device__ __forceinline__ void wsync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 __device__ __forceinline__ u32 bcast_u32(u32 v, u32 l) { return (u32)__builtin_amdgcn_readlane((int)v, (int)l); }
+__device__ __forceinline__ u32 rfl(u32 v) { return (u32)__builtin_amdgcn_readfirstlane((int)v); }
+// lane l of `old` := val (val and l wave-uniform): v_writelane_b32 with the lane select in M0
+__device__ __forceinline__ u32 wrlane_d(u32 old, u32 val, u32 l) {
+  asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(old) : "s"(val), "s"(l) : "m0");
+  return old;
+}
 
 // ---------------------------------------------------------------------------------------------
 // FSE table description (A.3) -> norm[] ; single thread. returns bytes consumed, 0 on corruption
@@ -1318,7 +1324,63 @@ __device__ __forceinline__ u32 chain_job_lean(const ZraDecodeArgs& a, const u32 
     u32 sML = br.read(F->mlLog); br.reload();
     u32 qlo = 0, qhi = 0;                        // sequences leave 64 at a time: lane (i & 63) keeps sequence i
     u32 i = 0;
-    for (; i < nbSeq; i++) {
+    bool stop = false;
+    // ---- far from the stream's start (8 and more bytes below the container) every reload is BIT_reloadDStream's first case and no
+    // read can leave the container: the step below is the same arithmetic as the careful one further down, on wave-uniform values
+    // (scalar unit), without the cases that cannot occur here
+    {
+      u64 c = (u64)rfl((u32)br.c) | ((u64)rfl((u32)(br.c >> 32)) << 32);
+      u32 bc = rfl(br.bc), ptr = rfl(br.ptr);
+      sLL = rfl(sLL); sML = rfl(sML); sOF = rfl(sOF);
+      rep0 = rfl(rep0); rep1 = rfl(rep1); rep2 = rfl(rep2);
+      for (; i < nbSeq && ptr >= 8 && bc <= 64; i++) {
+        const uint2 vL = *(const uint2*)(T + ZRA_DEC_TBL_LL + 2 * sLL), vM = *(const uint2*)(T + ZRA_DEC_TBL_ML + 2 * sML);
+        const u32 eLx = rfl(vL.x), eLy = rfl(vL.y), eMx = rfl(vM.x), eMy = rfl(vM.y), eO = rfl(T[ZRA_DEC_TBL_OF + sOF]);
+        const u32 ofBits = (eO >> 8) & 0xFF, mlBits = (eMx >> 8) & 0xFF, llBits = (eLx >> 8) & 0xFF;
+        u32 ll = eLy, ml = eMy, off;
+        if (ofBits > 1) {
+          off = ((1u << ofBits) - 3u) + (u32)((c << (bc & 63)) >> ((64 - ofBits) & 63)); bc += ofBits;
+          rep2 = rep1; rep1 = rep0; rep0 = off;
+        } else {
+          const u32 ll0 = (ll == 0);
+          if (ofBits == 0) {
+            if (!ll0) off = rep0;
+            else { off = rep1; rep1 = rep0; rep0 = off; }
+          } else {
+            const u32 idx = 1 + ll0 + (u32)((c << (bc & 63)) >> 63); bc += 1;
+            u32 t = idx == 3 ? rep0 - 1 : idx == 1 ? rep1 : rep2;
+            t += !t;
+            if (idx != 1) rep2 = rep1;
+            rep1 = rep0; rep0 = off = t;
+          }
+        }
+        if (mlBits) { ml += (u32)((c << (bc & 63)) >> ((64 - mlBits) & 63)); bc += mlBits; }
+        if (llBits + mlBits + ofBits >= 57 - (9 + 9 + 8)) {           // BIT_reloadDStream in the middle of a long sequence
+          if (bc > 64 || ptr < 8) return 1;                             // (cannot happen: bc <= 7 + 31 + 16 here, and ptr >= 8 is the loop condition)
+          ptr -= bc >> 3; bc &= 7;
+          const u64 v = ld64(bits + ptr); c = (u64)rfl((u32)v) | ((u64)rfl((u32)(v >> 32)) << 32);
+        }
+        if (llBits) { ll += (u32)((c << (bc & 63)) >> ((64 - llBits) & 63)); bc += llBits; }
+        { const u32 nb = (eLx >> 16) & 0xF; sLL = (eLx >> 20) + ((u32)(c >> ((64u - bc - nb) & 63)) & ((1u << nb) - 1u)); bc += nb; }
+        { const u32 nb = (eMx >> 16) & 0xF; sML = (eMx >> 20) + ((u32)(c >> ((64u - bc - nb) & 63)) & ((1u << nb) - 1u)); bc += nb; }
+        { const u32 nb = (eO >> 16) & 0xF; sOF = (eO >> 20) + ((u32)(c >> ((64u - bc - nb) & 63)) & ((1u << nb) - 1u)); bc += nb; }
+        if (bc <= 64) {                                                   // (an over-read container stays as it is: reload_quiet's rule)
+          const u32 nbB = min(bc >> 3, ptr);
+          ptr -= nbB; bc -= nbB * 8;
+          if (nbB) { const u64 v = ld64(bits + ptr); c = (u64)rfl((u32)v) | ((u64)rfl((u32)(v >> 32)) << 32); }
+        }
+        if (ll + ml > outCap - outPos || ll > regen - litPos || off > produced0 + outPos + ll) return 1;
+        const u64 qv = (u64)ll | ((u64)ml << 18) | ((u64)min(off, 0x0FFFFFFFu) << 36);
+        qlo = wrlane_d(qlo, (u32)qv, i & 63u); qhi = wrlane_d(qhi, (u32)(qv >> 32), i & 63u);
+        if ((i & 63u) == 63u) sq[i - 63 + (u32)lane] = (u64)qlo | ((u64)qhi << 32);
+        outPos += ll + ml; litPos += ll;
+        valid = i + 1;
+        if (produced0 + outPos >= limit) { truncated = 1; stop = true; i++; break; }
+      }
+      br.c = c; br.bc = bc; br.ptr = ptr;
+    }
+    // ---- the stream's last bytes (and whatever the loop above did not want): the careful step
+    for (; !stop && i < nbSeq; i++) {
       const uint2 eL = *(const uint2*)(T + ZRA_DEC_TBL_LL + 2 * sLL), eM = *(const uint2*)(T + ZRA_DEC_TBL_ML + 2 * sML);
       const u32 eO = T[ZRA_DEC_TBL_OF + sOF];
       const u32 ofBits = (eO >> 8) & 0xFF, mlBits = (eM.x >> 8) & 0xFF, llBits = (eL.x >> 8) & 0xFF;
@@ -1366,6 +1428,22 @@ __device__ __forceinline__ u32 chain_job_lean(const ZraDecodeArgs& a, const u32 
 }
 }  // namespace
 
+#ifdef ZRA_SMALL_PROFILE
+// bring-up (never in the shipped library): s_memtime sums per stage of zra_ra_small_kernel: parse, Huffman (wave 1), chain (wave 0), execute, jobs
+__device__ unsigned long long zra_small_prof[8];
+extern "C" __attribute__((visibility("default"))) void ZraHipDebugReadSmallProfile(unsigned long long* out8, int reset) {
+  (void)hipMemcpyFromSymbol(out8, HIP_SYMBOL(zra_small_prof), sizeof(unsigned long long) * 8);
+  if (reset) { unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(zra_small_prof), z, sizeof(z)); }
+}
+#define SPROF(k) { __builtin_amdgcn_s_waitcnt(0); const u64 n_ = __builtin_amdgcn_s_memtime(); if (lane == 0) atomicAdd(&zra_small_prof[k], n_ - spt_); spt_ = n_; }
+#define SPROF_T0 u64 spt_ = __builtin_amdgcn_s_memtime();
+#define SPROF_RESET spt_ = __builtin_amdgcn_s_memtime();
+#else
+#define SPROF(k)
+#define SPROF_T0
+#define SPROF_RESET
+#endif
+
 // grid = jobs (one workgroup each), 128 threads. *bail counts the jobs that have to go through the four-kernel pipeline.
 extern "C" __global__ void __launch_bounds__(2 * DEC_THREADS)
 zra_ra_small_kernel(ZraDecodeArgs a0, u32* bail) {
@@ -1375,10 +1453,15 @@ zra_ra_small_kernel(ZraDecodeArgs a0, u32* bail) {
   ZraDecodeArgs a = a0;
   ZraDecFrame* const F = &a.frames[j];
   const u8* const lim = a.body + a.bodySize;
+  SPROF_T0
+#ifdef ZRA_SMALL_PROFILE
+  if (threadIdx.x == 0) atomicAdd(&zra_small_prof[4], 1ull);
+#endif
   for (u32 round = 0;; round++) {
     a.round = round;
-    if (wave == 0) { const u32 oc = parse_job<true>(a, j, S.P, lane, S.tabs); if (lane == 0) { S.ctl[0] = oc; S.ctl[1] = 0; } }
+    if (wave == 0) { const u32 oc = parse_job<true>(a, j, S.P, lane, S.tabs); if (lane == 0) { S.ctl[0] = oc; S.ctl[1] = 0; } SPROF(0) }
     __syncthreads();
+    SPROF_RESET
     const u32 oc = S.ctl[0];
     if (oc == 0) return;                                   // the frame is finished (status and slices written by frame_finish)
     if (oc == 2) { if (threadIdx.x == 0) atomicAdd(bail, 1u); return; }
@@ -1388,13 +1471,16 @@ zra_ra_small_kernel(ZraDecodeArgs a0, u32* bail) {
         wsync();
         if ((u32)lane < F->litStreams && !huf_decode_stream(a, F, j, S.hufTab, S.hufW1, (u32)lane, lim)) S.ctl[1] = 1;
       }
+      SPROF(1)
     } else {
       if (chain_job_lean(a, j, F, S.tabs, S.bits, lane) && lane == 0) S.ctl[1] = 1;
+      SPROF(2)
     }
     __threadfence_block();
     __syncthreads();
     if (S.ctl[1]) { if (threadIdx.x == 0) atomicAdd(bail, 1u); return; }
-    if (wave == 0) { const u32 more = exec_job<true>(a, j, S.X, lane); if (lane == 0) S.ctl[2] = more; }
+    SPROF_RESET
+    if (wave == 0) { const u32 more = exec_job<true>(a, j, S.X, lane); if (lane == 0) S.ctl[2] = more; SPROF(3) }
     __syncthreads();
     if (!S.ctl[2]) return;
   }

@@ -533,12 +533,22 @@ Status Engine::decompress_ra_batch(const uint8_t* dArc, size_t arcSize, uint8_t*
 // [bodyBase, bodyBase + bodyBytes) of the archive's body — the frames one rank of a distributed archive owns (zra_comm.hip).
 Status Engine::decompress_ra_batch_shard(const uint8_t* dArc, size_t arcSize, const uint8_t* dBody, uint64_t bodyBytes, uint64_t bodyBase, uint8_t* dOut,
                                          const uint64_t* hOff, const uint64_t* hSize, const uint64_t* hOutOff, size_t nq) {
+  // bring-up: ZRA_RA_TRACE=1 prints the host microseconds between the marks of a call
+  static const bool trace = std::getenv("ZRA_RA_TRACE") != nullptr;
+  auto t_last = std::chrono::steady_clock::now();
+  auto mark = [&](const char* what) {
+    if (!trace) return;
+    const auto t = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "  ra %-14s %7.1f us\n", what, std::chrono::duration<double, std::micro>(t - t_last).count());
+    t_last = t;
+  };
   HIPCHK(hipSetDevice(device_));
   kstats_[4] = kstats_[5] = 0;
   if (arcSize <= zra_fmt::kFixedSize) return {kOutOfBounds, 0};
   uint8_t fixed[zra_fmt::kFixedSize];
   HIPCHK(hipMemcpyAsync(fixed, dArc, sizeof(fixed), hipMemcpyDeviceToHost, stream_));
   HIPCHK(hipStreamSynchronize(stream_));
+  mark("header read");
   HeaderInfo h;
   if (int e = parse_fixed_header(fixed, &h)) return {e, 0};
   if (arcSize < h.size) return {kOutOfBounds, 0};
@@ -581,6 +591,7 @@ Status Engine::decompress_ra_batch_shard(const uint8_t* dArc, size_t arcSize, co
                        (u64)U, dArc + h.seekTableOffset, (u64)bodyBase, raVerifyWholeFrames_ ? 1u : 0u, frameOff_.as<uint64_t>(), outOff_.as<uint64_t>(),
                        expect_.as<uint32_t>(), raLimit_.as<uint32_t>(), raPieceBase_.as<uint32_t>(), raPieces_.as<ZraRaPiece>());
     touched = (uint32_t)maxPieces;
+    mark("jobs queued");
   } else {
     // queries -> device (offset, size, destination) triples
     std::vector<uint64_t> hq(3 * nq);
@@ -617,6 +628,7 @@ Status Engine::decompress_ra_batch_shard(const uint8_t* dArc, size_t arcSize, co
                             expect_.as<uint32_t>() + s0, n, (uint32_t)std::min<uint64_t>(fs, 0xFFFFFFFFu), 2, 0, &ra);
     if (st.zra) return st;
   }
+  mark("decode");
   return ok();
 }
 
