@@ -155,6 +155,76 @@ def cpu_baseline(sample, frame_size, level, nq, qsize, seed=42):
                                       "note": "not the reference (single-threaded): %d threads x %d MiB, one libzstd context each" % (T, sl >> 20)}}, arc
 
 
+def kernel_source_sha():
+    """sha256 over the kernel sources (zra_amd/csrc, sorted by name): ties a PMC measurement in profiles/traffic.json to a build."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(HERE, "zra_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h", ".cpp")):
+            h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def gpu_clocks():
+    """Current shader / memory clocks, power and performance level of GPU 0 as rocm-smi reports them (None when it cannot be asked):
+    recorded before and after the timed region, because the same build reads two different match-finder times on different boxes."""
+    import subprocess
+    try:
+        r = subprocess.run(["rocm-smi", "-d", "0", "--showclocks", "--showpower", "--showperflevel", "--showtemp", "--json"], capture_output=True, text=True, timeout=20)
+        j = json.loads(r.stdout)
+        c = j.get("card0", next(iter(j.values())))
+        keep = {}
+        for k, v in c.items():
+            kl = k.lower()
+            if "sclk" in kl or "mclk" in kl or "fclk" in kl or "power" in kl or "performance level" in kl or ("temperature" in kl and ("junction" in kl or "edge" in kl)):
+                keep[k] = v
+        return keep or None
+    except Exception:
+        return None
+
+
+def host_pointer_calls(level, fs, gib=4):
+    """The reference's own calling convention (host pointers, zra.h) measured OUTSIDE the timed region through the CLI counterpart's
+    benchmark mode (zra_amd/tools/zratool_amd b): in-memory CompressBuffer / DecompressBuffer on `gib` GiB of the bench corpus (steady
+    state of the C ABI, third repetition) and the streaming Compressor / FullDecompressor with the reference tool's 10 MB buffers."""
+    import subprocess, re
+    tool = os.path.join(HERE, "zra_amd", "tools", "zratool_amd")
+    if not os.path.exists(tool):
+        return None
+    path = "/tmp/zra_bench_host_%d.bin" % os.getpid()
+    try:
+        base = synth_corpus(64 << 20, seed=1).tobytes()
+        with open(path, "wb") as f:
+            for _ in range(int(gib * 16)):
+                f.write(base)
+        r = subprocess.run([tool, "b", path, str(level), str(fs), "10"], capture_output=True, text=True, timeout=600)
+        out = {"bytes": int(gib * 16) * len(base), "tool": "zratool_amd b (level %d, frameSize %d, 10 MB streaming buffers)" % (level, fs)}
+        for line in r.stdout.splitlines():
+            m = re.match(r"(in-memory compress|in-memory decompress|streaming compress|streaming decompress)\s*:\s*([\d.]+) ms\s+([\d.]+) MB/s", line)
+            if m:
+                out[m.group(1).replace(" ", "_").replace("-", "_") + "_first_call"] = {"ms": float(m.group(2)), "gbs": round(float(m.group(3)) / 1e3, 3)}
+            m = re.match(r"C ABI rep 2: compress\s+([\d.]+) ms\s+([\d.]+) MB/s \(status (\d+)\)\s+decompress\s+([\d.]+) ms\s+([\d.]+) MB/s \(status (\d+), (\w+)\)", line)
+            if m:
+                out["ZraCompressBuffer"] = {"ms": float(m.group(1)), "gbs": round(float(m.group(2)) / 1e3, 3), "status": int(m.group(3))}
+                out["ZraDecompressBuffer"] = {"ms": float(m.group(4)), "gbs": round(float(m.group(5)) / 1e3, 3), "status": int(m.group(6)), "roundtrip": m.group(7)}
+            m = re.match(r"random access (\d+) B @ (\d+) \((in-memory|streaming)\) :\s+([\d.]+) ms\s+(\w+)", line)
+            if m:
+                out["random_access_%s" % m.group(3).replace("-", "_")] = {"bytes": int(m.group(1)), "ms": float(m.group(4)), "check": m.group(5)}
+        # the streaming classes are named as in zra.hpp
+        if "streaming_compress_first_call" in out: out["Compressor_10MB_buffers"] = out.pop("streaming_compress_first_call")
+        if "streaming_decompress_first_call" in out: out["FullDecompressor_10MB_buffers"] = out.pop("streaming_decompress_first_call")
+        return out
+    except Exception as e:
+        return {"error": repr(e)}
+    finally:
+        for suffix in ("", ".bench.zra", ".bench.out"):
+            try:
+                os.remove(path + suffix)
+            except OSError:
+                pass
+
+
 def ra_latency_probe(Z, eng, d_arc, arc_size, d_in, N, qb, torch):
     """Latency of small random-access batches (outside the timed region): batch sizes 1 / 64 / 4096 through the device-pointer call
     (ZraHipDecompressRABatch) and, per query, through the reference's host-pointer call (ZraDecompressRA on a host copy of the archive)."""
@@ -203,6 +273,8 @@ def main():
     ap.add_argument("--queries", type=int, default=1_000_000)
     ap.add_argument("--query-bytes", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--timed-only", action="store_true", help="nothing but the timed steps (PMC passes: tools/pmc_bench.sh)")
+    ap.add_argument("--no-host-calls", action="store_true", help="skip the host-pointer extras (4 GiB through zratool_amd b, outside the timed region)")
     args = ap.parse_args()
 
     # stdout carries exactly one line, the JSON: libraries that print banners on first use (RCCL's version block, gloo's rank lines)
@@ -300,6 +372,7 @@ def main():
     ra_ms = []
     mf_ms = []
     dec_stats = []
+    dec_stage = []
     arc_size = 0
 
     def step():
@@ -325,11 +398,11 @@ def main():
         # RA over this rank's own shard (the archive stays sharded for serving; queries are routed to the owner)
         if world == 1:
             eng.decompress_ra_batch(d_arc.data_ptr(), arc_size, d_ra.data_ptr(), offs, sizes, oofs)
-            dec_stats.append(eng.kernel_stats())
+            dec_stats.append(eng.kernel_stats()); dec_stage.append(eng.decode_stage_stats())
         else:
             # sharded serving: this rank's queries go over the WHOLE range; slices travel to the owners, answers come back
             comm.serve(step.shard, offs, sizes, oofs, d_ra.data_ptr())
-            dec_stats.append(eng.kernel_stats())
+            dec_stats.append(eng.kernel_stats()); dec_stage.append(eng.decode_stage_stats())
         torch.cuda.synchronize()
         t2 = time.perf_counter()
         comp_ms.append((t1 - t0) * 1e3)
@@ -337,13 +410,15 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    comp_ms.clear(); ra_ms.clear(); mf_ms.clear(); dec_stats.clear()
+    comp_ms.clear(); ra_ms.clear(); mf_ms.clear(); dec_stats.clear(); dec_stage.clear()
+    clocks_before = gpu_clocks() if rank == 0 else None
     sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     sync_all()
     elapsed = time.perf_counter() - t0
+    clocks_after = gpu_clocks() if rank == 0 else None
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if one_gpu else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -369,7 +444,7 @@ def main():
 
     # SURVEY §8d RA size classes (outside the timed region, single rank): 64 KiB unaligned (touches 2 frames) and 1 MiB queries
     ra_classes = {}
-    if world == 1:
+    if world == 1 and not args.timed_only:
         for qsz, nq2 in ((65536, 100000), (1 << 20, 8000)):
             o2 = rng.randint(0, N - qsz - 1, size=nq2).astype(np.uint64)
             s2 = np.full(nq2, qsz, dtype=np.uint64); oo2 = (np.arange(nq2, dtype=np.uint64) * qsz)
@@ -387,6 +462,24 @@ def main():
     ra_latency = None
     if world == 1 and not args.no_cpu_baseline:
         ra_latency = ra_latency_probe(Z, eng, d_arc, arc_size, d_in, N, qb, torch)
+
+    host_calls = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.no_host_calls:
+        host_calls = host_pointer_calls(args.level, fs)
+
+    # compressed bytes of the frames the timed queries touch (for the random-access leg's roofline): the archive's own seek table
+    ra_touched = None
+    if rank == 0 and world == 1:
+        try:
+            hdr = d_arc[:38].cpu().numpy().tobytes()
+            tsz = int.from_bytes(hdr[26:30], "little")
+            tab = d_arc[38:38 + 5 * tsz].cpu().numpy().reshape(tsz, 5).astype(np.uint64)
+            ent = tab[:, 0] | (tab[:, 1] << np.uint64(8)) | (tab[:, 2] << np.uint64(16)) | (tab[:, 3] << np.uint64(24)) | (tab[:, 4] << np.uint64(32))
+            f0 = (offs // np.uint64(fs)).astype(np.int64); f1 = ((offs + np.uint64(qb - 1)) // np.uint64(fs)).astype(np.int64)
+            hit = np.zeros(tsz - 1, dtype=bool); hit[f0] = True; hit[f1] = True
+            ra_touched = {"frames": int(hit.sum()), "compressed_bytes": int((ent[1:][hit] - ent[:-1][hit]).sum())}
+        except Exception:
+            ra_touched = None
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -407,16 +500,37 @@ def main():
         achieved = alg_per_launch / 1e9 / (mf_launch_ms / 1e3) if mf_launch_ms > 0 else 0.0
         # HBM-side bytes of one match-finder launch: PMC passes (FETCH_SIZE, WRITE_SIZE, separate runs) of THIS workload, stored with the
         # commit they were taken at (profiles/traffic.json, tools/pmc_bench.sh); per-frame scaling only if the size differs
-        traffic, traffic_src = None, None
+        # which match finder the level runs (frame sizes of the 128 KiB class; the kernel-per-strategy table of zra_encode.hip)
+        lv = 3 if args.level == 0 else args.level
+        mf_kernel = ("zra_mf_fast_kernel" if lv <= 2 else "zra_mf_dfast_kernel" if lv <= 4 else "zra_mf_hc_kernel" if lv <= 10 else
+                     "zra_mf_kernel" if lv <= 12 or lv == 15 else "zra_mf_opt_kernel")
+        if os.environ.get("ZRA_MF_V2", "0") not in ("", "0") and mf_kernel == "zra_mf_dfast_kernel":
+            mf_kernel = "zra_mf_dfast2_kernel"
+        traffic, traffic_src, traffic_stale, ra_traffic = None, None, None, None
         tpath = os.path.join(HERE, "profiles", "traffic.json")
+        wkey = "L%d_fs%d" % (args.level, fs)
         if os.path.exists(tpath):
             try:
-                tj = json.load(open(tpath))["bench16g_r02"]
-                per_frame = tj["zra_mf_dfast_kernel"]["hbm_bytes_per_launch"] * tj["zra_mf_dfast_kernel"]["launches"] / tj["frames"]
-                traffic = int(per_frame * nframes / launches)
-                traffic_src = "rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE of bench.py --steps 1 at commit %s (profiles/r02_pmc_bench16g.txt)" % tj["measured_at_commit"]
+                tall = json.load(open(tpath))
+                cands = [v for k, v in tall.items() if isinstance(v, dict) and v.get("workload_key", "L3_fs65536" if k.startswith("bench16g") else None) == wkey and mf_kernel in v]
+                if cands:
+                    tj = cands[-1]
+                    per_frame = tj[mf_kernel]["hbm_bytes_per_launch"] * tj[mf_kernel]["launches"] / tj["frames"]
+                    traffic = int(per_frame * nframes / launches)
+                    traffic_stale = tj.get("kernel_source_sha") != kernel_source_sha()
+                    traffic_src = "rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE (separate passes) of bench.py --steps 1 (%s); kernel sources %s at measurement, %s now" % (
+                        tj.get("raw", "profiles/"), tj.get("kernel_source_sha", "unrecorded (commit %s)" % tj.get("measured_at_commit")), kernel_source_sha())
+                    d1 = tj.get("decode_one_pass_of_16GiB", {}).get("zra_dec_chain_kernel")
+                    if d1:
+                        ra_traffic = int((d1["fetch_kib"] + d1["write_kib"]) * 1024 * nframes / tj["frames"])
             except Exception:
                 traffic = None
+        # second roofline object: the random-access leg's dominant kernel (the sequence chains). Algorithmic bytes = compressed bytes
+        # of the frames the queries touch + the bytes returned; duration = its HIP-event span per decode pass
+        chain_ms = float(np.mean([x["chain_ms"] for x in dec_stage])) if dec_stage else 0.0
+        ra_alg = (ra_touched["compressed_bytes"] + q * qb) if ra_touched else None
+        ra_ach = (ra_alg / 1e9 / (chain_ms / 1e3)) if (ra_alg and chain_ms > 0) else 0.0
+        stage_ms = {k: round(float(np.mean([x[k] for x in dec_stage])), 3) for k in ("parse_ms", "huf_ms", "chain_ms", "exec_ms", "small_ms")} if dec_stage else None
         line = {
             "metric": "compress + RA-decompress GiB/s, 16 GiB @ 64 KiB frames, 1/2/4/8 MI355X",
             "value": round(value, 3), "unit": "GiB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -432,10 +546,17 @@ def main():
             "ra_us_per_query": round(np.mean(ra_ms) * 1e3 / q, 3),
             "ra_size_classes": ra_classes,
             "ra_latency": ra_latency,
-            "roofline": {"bound": "hbm", "kernel": "zra_mf_dfast_kernel" if args.level in (3, 4) else "zra_mf_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": mf_kernel, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "frac_of_measured_6290": round(achieved / 6290.0, 5), "traffic": traffic, "traffic_source": traffic_src,
+                         "traffic_stale": traffic_stale,
                          "launch_ms": round(mf_launch_ms, 3), "launches_per_call": launches, "algorithmic_bytes_per_launch": int(alg_per_launch),
                          "other_kernels_launch_ms": {"zra_entropy_kernel": round(ent_launch_ms, 3), "zra_dec_parse+huf+chain+exec (one decode pass)": round(dec_launch_ms, 3)}},
+            "roofline_ra": {"bound": "hbm", "kernel": "zra_dec_chain_kernel", "achieved": round(ra_ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": round(ra_ach / HBM_PEAK_GBS, 5), "traffic": ra_traffic, "traffic_stale": traffic_stale, "launch_ms": round(chain_ms, 3),
+                            "algorithmic_bytes_per_launch": ra_alg, "touched": ra_touched, "stage_ms_per_pass": stage_ms,
+                            "note": "one decode pass of the touched frames per step; algorithmic = compressed bytes of the touched frames + bytes returned"},
+            "clocks": {"before_timed_region": clocks_before, "after_timed_region": clocks_after},
+            "host_pointer_calls": host_calls,
             "cpu_baseline": cpu,
         }
         sys.stdout.flush()

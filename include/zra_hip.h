@@ -150,6 +150,9 @@ ZRA_EXPORT double ZraHipLastKernelMs(ZraHipEngine* engine);
 /** HIP-event timings (ms) and launch counts of the kernels of the LAST call on this engine, measured on the engine's stream:
  *  out6 = {match-finder ms, launches, entropy-stage ms, launches, decode ms, launches}. */
 ZRA_EXPORT void ZraHipGetKernelStats(ZraHipEngine* engine, double* out6);
+/** Decode stages of the LAST decode / random-access call on this engine (HIP events on the engine's stream, summed over its rounds):
+ *  out8 = {parse ms, Huffman ms, sequence-chain ms, execute ms, rounds, one-launch small-batch kernel ms, its launches, 0}. */
+ZRA_EXPORT void ZraHipGetDecodeStageStats(ZraHipEngine* engine, double* out8);
 
 /* ---- opt-in integrity options (default 0: bit- and error-compatible with the reference, quirks included) ---- */
 #define ZRA_HIP_OPT_VERIFY_HEADER_CRC 1u     /* Header constructors check the CRC-32 the reference writes but never reads (zra.cpp:128-133) */

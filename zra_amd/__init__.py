@@ -111,6 +111,7 @@ def load():
         "ZraHipReleaseScratch": (S, [vp]),
         "ZraHipLastKernelMs": (ctypes.c_double, [vp]),
         "ZraHipGetKernelStats": (None, [vp, ctypes.POINTER(ctypes.c_double)]),
+        "ZraHipGetDecodeStageStats": (None, [vp, ctypes.POINTER(ctypes.c_double)]),
         "ZraHipCompressBuffer": (S, [vp, vp, sz, vp, szp, ctypes.c_int8, u32, ctypes.c_bool]),
         "ZraHipDecompressBuffer": (S, [vp, vp, sz, vp, sz]),
         "ZraHipDecompressRABatch": (S, [vp, vp, sz, vp, u64p, u64p, u64p, sz]),
@@ -150,7 +151,7 @@ C_ABI_SYMBOLS = [
     "ZraDecompressWithDecompressor", "ZraCreateFullDecompressor", "ZraDeleteFullDecompressor", "ZraGetHeaderWithFullDecompressor",
     "ZraDecompressWithFullDecompressor",
 ]
-HIP_ABI_SYMBOLS = ["ZraHipDeviceCount", "ZraHipCreateEngine", "ZraHipDestroyEngine", "ZraHipSynchronize", "ZraHipGetStream", "ZraHipWaitStream", "ZraHipReleaseScratch", "ZraHipLastKernelMs", "ZraHipGetKernelStats",
+HIP_ABI_SYMBOLS = ["ZraHipDeviceCount", "ZraHipCreateEngine", "ZraHipDestroyEngine", "ZraHipSynchronize", "ZraHipGetStream", "ZraHipWaitStream", "ZraHipReleaseScratch", "ZraHipLastKernelMs", "ZraHipGetKernelStats", "ZraHipGetDecodeStageStats",
                    "ZraHipCompressBuffer", "ZraHipDecompressBuffer", "ZraHipDecompressRABatch", "ZraHipCompressFrames", "ZraHipStitchHeader", "ZraHipDebugReadSeqs", "ZraHipSetOptions", "ZraHipGetOptions",
                    "ZraHipShardRange", "ZraHipOwnerOfFrame", "ZraHipRouteQueries", "ZraHipCommGetUniqueId", "ZraHipCommCreateRccl", "ZraHipCommCreateHost", "ZraHipCommDestroy",
                    "ZraHipCommCompress", "ZraHipShardDestroy", "ZraHipShardHeaderSize", "ZraHipShardGetHeader", "ZraHipShardArchiveSize", "ZraHipShardGetBody",
@@ -206,6 +207,7 @@ class Engine:
         h = ctypes.c_void_p()
         _chk(self.L.ZraHipCreateEngine(ctypes.byref(h), device), "ZraHipCreateEngine")
         self.h = h
+        self.device = device
 
     def close(self):
         if self.h:
@@ -234,7 +236,7 @@ class Engine:
         # (event wait, no host sync). Plumbing only; C callers use ZraHipWaitStream / their own synchronisation (zra_hip.h).
         t = sys.modules.get("torch")
         if t is not None and t.cuda.is_available():
-            self.wait_stream(t.cuda.current_stream().cuda_stream)
+            self.wait_stream(t.cuda.current_stream(device=self.device).cuda_stream)      # the ENGINE's device, whatever torch's current one is
 
     def last_kernel_ms(self):
         return self.L.ZraHipLastKernelMs(self.h)
@@ -244,6 +246,12 @@ class Engine:
         a = (ctypes.c_double * 6)()
         self.L.ZraHipGetKernelStats(self.h, a)
         return dict(mf_ms=a[0], mf_launches=int(a[1]), ent_ms=a[2], ent_launches=int(a[3]), dec_ms=a[4], dec_launches=int(a[5]))
+
+    def decode_stage_stats(self):
+        """{parse_ms, huf_ms, chain_ms, exec_ms, rounds, small_ms, small_launches} of the last decode / random-access call."""
+        a = (ctypes.c_double * 8)()
+        self.L.ZraHipGetDecodeStageStats(self.h, a)
+        return dict(parse_ms=a[0], huf_ms=a[1], chain_ms=a[2], exec_ms=a[3], rounds=int(a[4]), small_ms=a[5], small_launches=int(a[6]))
 
     def debug_read_seqs(self, frame, cap=65536):
         """bring-up: [(litLength, matchLength, offsetValue)] of `frame` in the last batch + (nbSeq, lastLL, skip)."""

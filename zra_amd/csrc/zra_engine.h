@@ -52,6 +52,8 @@ class Engine {
   uint64_t last_produced_total() const { return lastProducedTotal_; }
   // HIP-event timings of the last call on the engine's stream: {mf ms, mf launches, entropy ms, entropy launches, decode ms, decode launches}
   void kernel_stats(double out[6]) const { for (int i = 0; i < 6; i++) out[i] = kstats_[i]; }
+  // decode stages of the last call: {parse ms, Huffman ms, sequence-chain ms, execute ms, rounds, one-launch kernel ms, its launches, 0}
+  void decode_stage_stats(double out[8]) const { for (int i = 0; i < 8; i++) out[i] = dstats_[i]; }
   // bring-up: sequences {ll | ml<<20 | offVal<<40} the match finder left in scratch context 0 for frame `frame` of the LAST batch
   // (last block of the frame); returns the count, meta = {nbSeq, lastLL, skip}
   uint32_t debug_read_seqs(uint32_t frame, uint64_t* out, uint32_t cap, uint32_t meta[3]);
@@ -121,6 +123,9 @@ class Engine {
   hipEvent_t ev0_ = nullptr, ev1_ = nullptr, evWait_ = nullptr;
   double lastKernelMs_ = 0;
   double kstats_[6] = {0, 0, 0, 0, 0, 0};
+  double dstats_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  std::vector<hipEvent_t> stageEv_; size_t stageEvNext_ = 0;
+  hipEvent_t stage_event();
   hipEvent_t evR_[17] = {nullptr};   // per-round events of one encode batch: e[2r] before mf, e[2r+1] between, e[2r+2] after entropy
   // decode scratch
   DevBuf decFrames_, decTables_, decLists_, decCounters_, decLits_, decSeqs_;

@@ -275,6 +275,7 @@ Engine::~Engine() {
     b->release();
   for (auto& x : encCtx_) for (DevBuf* b : {&x.tables, &x.seqs, &x.lits, &x.slots, &x.misc, &x.ck, &x.sizes}) b->release();
   for (auto ev : evPool_) (void)hipEventDestroy(ev);
+  for (auto ev : stageEv_) (void)hipEventDestroy(ev);
   if (stream2_) { (void)hipStreamSynchronize(stream2_); (void)hipStreamDestroy(stream2_); }
   for (auto& ev : evR_) if (ev) (void)hipEventDestroy(ev);
   if (ev0_) (void)hipEventDestroy(ev0_);
@@ -344,8 +345,13 @@ Status Engine::decode_small(const ZraDecodeArgs& a0, const uint32_t* dExpect, ui
   *bailed = (uint32_t)two[1];
   if (!*bailed) *hResult = two[0];
   float ms = 0;
-  if (hipEventElapsedTime(&ms, ev0_, ev1_) == hipSuccess) { lastKernelMs_ = ms; kstats_[4] += ms; kstats_[5] += 1; }
+  if (hipEventElapsedTime(&ms, ev0_, ev1_) == hipSuccess) { lastKernelMs_ = ms; kstats_[4] += ms; kstats_[5] += 1; dstats_[5] += ms; dstats_[6] += 1; }
   return ok();
+}
+
+hipEvent_t Engine::stage_event() {
+  if (stageEvNext_ == stageEv_.size()) { hipEvent_t e = nullptr; if (hipEventCreate(&e) != hipSuccess) return nullptr; stageEv_.push_back(e); }
+  return stageEv_[stageEvNext_++];
 }
 
 // One pass of the decoder over the jobs of `a0`: rounds of parse -> chain -> execute (a round = one compressed block of every
@@ -376,14 +382,25 @@ Status Engine::decode_launch(const ZraDecodeArgs& a0, const uint32_t* dExpect, u
     static const uint32_t chainGrid = std::getenv("ZRA_DEC_CHAIN_GRID") ? (uint32_t)std::atoi(std::getenv("ZRA_DEC_CHAIN_GRID")) : 0u;        // bring-up: absolute wave count
     const uint32_t gridChain = (uint32_t)std::min<uint64_t>((nActive + 63) / 64, chainGrid ? chainGrid : (uint64_t)numCUs_ * chainWaves);
     const uint32_t gridExec = (uint32_t)std::min<uint64_t>(nActive, (uint64_t)numCUs_ * perCUExec);
+    // per-stage spans (HIP events on the engine's stream; summed into dstats_ once the round has synchronised)
+    hipEvent_t se[5];
+    for (auto& e : se) { e = stage_event(); if (!e) return zerr(1); }
+    HIPCHK(hipEventRecord(se[0], stream_));
     hipLaunchKernelGGL(zra_dec_parse_kernel, dim3(gridParse), dim3(64), 0, stream_, a);
+    HIPCHK(hipEventRecord(se[1], stream_));
     hipLaunchKernelGGL(zra_dec_huf_kernel, dim3((uint32_t)std::min<uint64_t>((nActive + 15) / 16, (uint64_t)numCUs_ * 2)), dim3(64), 0, stream_, a);
+    HIPCHK(hipEventRecord(se[2], stream_));
     hipLaunchKernelGGL(zra_dec_chain_kernel, dim3(gridChain), dim3(64), 0, stream_, a);
+    HIPCHK(hipEventRecord(se[3], stream_));
     hipLaunchKernelGGL(zra_dec_exec_kernel, dim3(gridExec), dim3(64), 0, stream_, a);
+    HIPCHK(hipEventRecord(se[4], stream_));
     uint32_t next = 0;
     HIPCHK(hipMemcpyAsync(&next, a.counters + ZRA_DC_NNEXT, 4, hipMemcpyDeviceToHost, stream_));
     HIPCHK(hipStreamSynchronize(stream_));
     HIPCHK(hipGetLastError());
+    for (int k = 0; k < 4; k++) { float m = 0; if (hipEventElapsedTime(&m, se[k], se[k + 1]) == hipSuccess) dstats_[k] += m; }
+    dstats_[4] += 1;
+    stageEvNext_ = 0;
     active = a.nextActive; nActive = next; round++;
     if (round > (1u << 20)) return zerr(1);          // cannot happen: every round finishes at least one block of some frame
   }
@@ -483,7 +500,7 @@ Status Engine::decode_jobs(const uint8_t* dBody, uint64_t bodySize, const uint64
 
 Status Engine::decompress_device(const uint8_t* dArc, size_t arcSize, uint8_t* dOut, size_t outCap) {
   HIPCHK(hipSetDevice(device_));
-  kstats_[4] = kstats_[5] = 0;
+  kstats_[4] = kstats_[5] = 0; for (auto& d : dstats_) d = 0;
   if (arcSize <= zra_fmt::kFixedSize) return {kOutOfBounds, 0};          // BufferView reader quirk, zra.cpp:166
   uint8_t fixed[zra_fmt::kFixedSize];
   HIPCHK(hipMemcpyAsync(fixed, dArc, sizeof(fixed), hipMemcpyDeviceToHost, stream_));
@@ -543,7 +560,7 @@ Status Engine::decompress_ra_batch_shard(const uint8_t* dArc, size_t arcSize, co
     t_last = t;
   };
   HIPCHK(hipSetDevice(device_));
-  kstats_[4] = kstats_[5] = 0;
+  kstats_[4] = kstats_[5] = 0; for (auto& d : dstats_) d = 0;
   if (arcSize <= zra_fmt::kFixedSize) return {kOutOfBounds, 0};
   uint8_t fixed[zra_fmt::kFixedSize];
   HIPCHK(hipMemcpyAsync(fixed, dArc, sizeof(fixed), hipMemcpyDeviceToHost, stream_));
