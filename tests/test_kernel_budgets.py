@@ -19,8 +19,10 @@ BUDGET = {
     "zra_mf_opt_kernel": (136, 400),     # ... with them (levels 13-22; its scratch holds the parser's small arrays)
     "zra_dec_chain_kernel": (72, 0),     # lane = frame FSE chains
     "zra_dec_huf_kernel": (72, 0),
-    "zra_dec_parse_kernel": (168, 0),
-    "zra_dec_exec_kernel": (128, 0),
+    "zra_dec_parse_kernel": (96, 176),   # 5 waves per SIMD asked for: 40 spilled VGPRs bought 2.1x on the stage (frames in flight are what it needs)
+    "zra_dec_exec_kernel": (96, 64),     # 5 waves per SIMD: 14 spilled VGPRs, -13 % on the stage
+    "zra_mf_dfast2_kernel": (104, 0),    # the mask-resolve parse (opt-in): meant for few resident waves
+    "zra_ra_small_kernel": (256, 0),     # one-launch path for small batches: all stages of a frame in one workgroup, occupancy is not its point
     "zra_entropy_kernel": (88, 8),       # 5 waves per SIMD asked for: no spills (7 cost 8 spilled VGPRs + 72 B scratch and 2 % of the bench)
 }
 
@@ -35,4 +37,4 @@ def test_hot_kernels_stay_inside_their_register_and_scratch_budgets():
         r = res[name]
         assert r["vgprs"] <= vg, (name, r)
         assert r["scratch_bytes"] <= scratch, (name, r)
-        assert r["vgpr_spill"] == 0, (name, r)
+        assert r["vgpr_spill"] == 0 or scratch >= 64, (name, r)        # spills only where the budget line above says they were bought

@@ -12,7 +12,8 @@ d_out = torch.empty(n, dtype=torch.uint8, device=dev)
 for i in range(3):
     torch.cuda.synchronize(); t = time.time(); eng.decompress(d_arc.data_ptr(), asz, d_out.data_ptr(), n); torch.cuda.synchronize(); dt = time.time() - t
     st = eng.kernel_stats()
-    print("decode %.2f GiB: %.1f ms wall (%.1f GiB/s), kernels %.1f ms in %d passes" % (gib, dt * 1e3, gib / dt, st["dec_ms"], st["dec_launches"]), flush=True)
+    sg = eng.decode_stage_stats()
+    print("decode %.2f GiB: %.1f ms wall (%.1f GiB/s), kernels %.1f ms in %d passes | parse %.1f huf %.1f chain %.1f exec %.1f" % (gib, dt * 1e3, gib / dt, st["dec_ms"], st["dec_launches"], sg["parse_ms"], sg["huf_ms"], sg["chain_ms"], sg["exec_ms"]), flush=True)
 assert torch.equal(d_out, d_in)
 rng = np.random.RandomState(42)
 for qb, q in ((4096, 1000000), (65536, 100000), (1 << 20, 4000)):
@@ -24,4 +25,5 @@ for qb, q in ((4096, 1000000), (65536, 100000), (1 << 20, 4000)):
     st = eng.kernel_stats()
     k = int(rng.randint(0, q))
     assert torch.equal(d_ra[k * qb:(k + 1) * qb], d_in[int(offs[k]):int(offs[k]) + qb])
-    print("RA %7d B x %7d: %.1f ms (%.3f us/query, %.1f GiB/s returned), decode kernels %.1f ms" % (qb, q, dt * 1e3, dt / q * 1e6, q * qb / dt / (1 << 30), st["dec_ms"]), flush=True)
+    sg = eng.decode_stage_stats()
+    print("RA %7d B x %7d: %.1f ms (%.3f us/query, %.1f GiB/s returned), decode kernels %.1f ms | parse %.1f huf %.1f chain %.1f exec %.1f" % (qb, q, dt * 1e3, dt / q * 1e6, q * qb / dt / (1 << 30), st["dec_ms"], sg["parse_ms"], sg["huf_ms"], sg["chain_ms"], sg["exec_ms"]), flush=True)

@@ -724,7 +724,13 @@ __device__ __forceinline__ u32 parse_job(const ZraDecodeArgs& a, const u32 j, Pa
 }
 }  // namespace
 
-extern "C" __global__ void __launch_bounds__(DEC_THREADS)
+// waves per SIMD the parse kernel is compiled for. The stage is one lane's serial work per frame (header fields, weight decode, table
+// spreads): what it needs is frames in flight. A/B on one box, 8 GiB decode, parse stage: 2 waves per SIMD (170 VGPRs, the compiler's
+// own choice) 22.5 ms, 3 (162) 15.2, 4 (128, 9 spilled) 11.9, 5 (96, 40 spilled, 164 B scratch) 10.7, 6 (80, 55 spilled) 10.9
+#ifndef ZRA_PARSE_WAVES
+#define ZRA_PARSE_WAVES 5
+#endif
+extern "C" __global__ void __launch_bounds__(DEC_THREADS, ZRA_PARSE_WAVES)
 zra_dec_parse_kernel(ZraDecodeArgs a) {
   __shared__ ParseShared S;
   const int lane = threadIdx.x;
@@ -743,7 +749,7 @@ zra_dec_parse_kernel(ZraDecodeArgs a) {
 // A stream is a serial chain (table lookup -> code length -> next bit position); the four streams of a frame gave a wave four busy
 // lanes. Here a wave takes 16 frames: their 16 decode tables are built in LDS (64 KiB) and the 64 streams advance together.
 namespace {
-constexpr int HUF_FRAMES = 16;
+constexpr int HUF_FRAMES = ZRA_HUF_FRAMES;
 struct __attribute__((aligned(16))) HufShared {
   u16 tab[HUF_FRAMES][2048];   // sym | nbBits<<8 (bit 15: a pair of 12-bit codes, resolved through w1[])
   u8 w1[HUF_FRAMES][256];      // weight-1 symbols in order (only tables of depth 12 need them)
@@ -1259,7 +1265,11 @@ __device__ __forceinline__ u32 exec_job(const ZraDecodeArgs& a, const u32 j, Exe
 }
 }  // namespace
 
-extern "C" __global__ void __launch_bounds__(DEC_THREADS)
+// the same for the execute kernel (per-lane copies, waits on memory): 4 waves per SIMD (114 VGPRs) 26.4 ms, 5 (96, 14 spilled) 22.9, 6 (80) 23.4
+#ifndef ZRA_EXEC_WAVES
+#define ZRA_EXEC_WAVES 5
+#endif
+extern "C" __global__ void __launch_bounds__(DEC_THREADS, ZRA_EXEC_WAVES)
 zra_dec_exec_kernel(ZraDecodeArgs a) {
   __shared__ ExecShared S;
   const int lane = threadIdx.x;

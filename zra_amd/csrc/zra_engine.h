@@ -131,7 +131,7 @@ class Engine {
   DevBuf decFrames_, decTables_, decLists_, decCounters_, decLits_, decSeqs_;
   DevBuf raPlan_, raLimit_, raPieceBase_, raPieces_;
   std::vector<uint64_t> raHostQ_;        // query tuples of the running batch (host side of an asynchronous copy)
-  int decOccParse_ = 0, decOccExec_ = 0; // resident workgroups per CU of the parse / execute kernels
+  int decOccParse_ = 0, decOccExec_ = 0, decOccHuf_ = 0; // resident workgroups per CU of the parse / execute kernels
   bool raVerifyWholeFrames_ = false;     // batched random access decodes every touched frame in full and checks its checksum
   DevBuf status_, produced_, frameMeta_, frameOff_, outOff_, expect_, result_, temp_, qmeta_;
   // encode scratch (see zra_encode.hip)

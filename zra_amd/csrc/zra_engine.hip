@@ -365,7 +365,8 @@ Status Engine::decode_launch(const ZraDecodeArgs& a0, const uint32_t* dExpect, u
   if (!decOccParse_) {
     HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&decOccParse_, zra_dec_parse_kernel, 64, 0));
     HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&decOccExec_, zra_dec_exec_kernel, 64, 0));
-    decOccParse_ = std::max(1, decOccParse_); decOccExec_ = std::max(1, decOccExec_);
+    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&decOccHuf_, zra_dec_huf_kernel, 64, 0));
+    decOccParse_ = std::max(1, decOccParse_); decOccExec_ = std::max(1, decOccExec_); decOccHuf_ = std::max(1, decOccHuf_);
   }
   int perCUParse = decOccParse_, perCUExec = decOccExec_;
   if (wavesCap > 0) { perCUParse = std::min(perCUParse, wavesCap); perCUExec = std::min(perCUExec, wavesCap); }
@@ -388,7 +389,7 @@ Status Engine::decode_launch(const ZraDecodeArgs& a0, const uint32_t* dExpect, u
     HIPCHK(hipEventRecord(se[0], stream_));
     hipLaunchKernelGGL(zra_dec_parse_kernel, dim3(gridParse), dim3(64), 0, stream_, a);
     HIPCHK(hipEventRecord(se[1], stream_));
-    hipLaunchKernelGGL(zra_dec_huf_kernel, dim3((uint32_t)std::min<uint64_t>((nActive + 15) / 16, (uint64_t)numCUs_ * 2)), dim3(64), 0, stream_, a);
+    hipLaunchKernelGGL(zra_dec_huf_kernel, dim3((uint32_t)std::min<uint64_t>((nActive + ZRA_HUF_FRAMES - 1) / ZRA_HUF_FRAMES, (uint64_t)numCUs_ * decOccHuf_)), dim3(64), 0, stream_, a);
     HIPCHK(hipEventRecord(se[2], stream_));
     hipLaunchKernelGGL(zra_dec_chain_kernel, dim3(gridChain), dim3(64), 0, stream_, a);
     HIPCHK(hipEventRecord(se[3], stream_));

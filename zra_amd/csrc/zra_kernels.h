@@ -13,6 +13,10 @@
 //                                          the reference's sequence loop (its statuses, in its order) -> sequence scratch
 //   zra_dec_exec_kernel   wave per frame   pure data movement: literal + match copies of the validated sequences, frame end,
 //                                          random-access slices
+// frames whose Huffman literal streams one wave of zra_dec_huf_kernel decodes side by side (4 lanes each); its LDS = this many 4.25 KiB tables
+#ifndef ZRA_HUF_FRAMES
+#define ZRA_HUF_FRAMES 2        /* A/B on one box, 8 GiB decode: 16 / 8 / 4 / 2 / 1 frames per wave -> Huffman stage 20.0 / 18.4 / 14.7 / 13.3 / 15.4 ms */
+#endif
 #define ZRA_DEC_TBL_LL 0u       // 512 cells x 8 B  {sym | extraBits<<8 | stateBits<<16 | nextBase<<20, baseValue}
 #define ZRA_DEC_TBL_ML 1024u    // 512 cells x 8 B
 #define ZRA_DEC_TBL_OF 2048u    // 256 cells x 4 B  (base value = 1 << code)
