@@ -15,7 +15,8 @@ import corpus as C
 import oracle_lib as O
 
 pytestmark = pytest.mark.gpu
-GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = os.path.join(HERE, "golden")
 
 
 @pytest.fixture(scope="module")
@@ -823,3 +824,37 @@ def test_host_pointer_calls_chunked_pipeline(zra, monkeypatch):
         L.ZraDeleteFullDecompressor(fd)
         results[ahead] = (stt, good)
     assert results["0"] == results["256"] and results["0"][0][0] == 1
+
+
+def test_allocation_failure_is_a_status_and_leaves_the_library_usable():
+    """memory_allocation (zstd code 64) instead of a crash or a hang when device scratch cannot be reserved, and the next call works
+    (nothing of the failed one is left in flight). Forced with the bring-up knob ZRA_ALLOC_LIMIT_MIB in a fresh process; the pool's
+    scratch cap (ZRA_SCRATCH_CAP_GIB) is exercised on the way: with a 1 GiB cap the engine hands its scratch back after every call."""
+    import subprocess
+    code = r'''
+import sys, os
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import corpus as C, zra_amd as Z
+big = C.gen_E(1 << 20) * 64
+try:
+    Z.CompressBuffer(big, 3, 65536, True)
+    print("NOFAIL")
+except Z.ZraError as e:
+    print("ERR", e.zra, e.zstd)
+small = C.gen_E(1 << 20)[:300000]
+arc = Z.CompressBuffer(small, 3, 65536, True)
+assert Z.DecompressBuffer(arc) == small
+try:
+    Z.DecompressBuffer(Z.CompressBuffer(big[: 32 << 20], 1, 65536, True))
+    print("NOFAIL2")
+except Z.ZraError as e:
+    print("ERR2", e.zra, e.zstd)
+assert Z.DecompressRA(arc, 1000, 5000) == small[1000:6000]
+print("OK")
+''' % (HERE, os.path.dirname(HERE))
+    env = dict(os.environ, ZRA_ALLOC_LIMIT_MIB="24", ZRA_SCRATCH_CAP_GIB="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    out = r.stdout.split("\n")
+    assert r.returncode == 0, (r.stdout[-500:], r.stderr[-1500:])
+    assert out[0] == "ERR 1 64", out
+    assert "OK" in out, out

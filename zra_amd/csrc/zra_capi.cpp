@@ -53,11 +53,28 @@ class EnginePool {
       cv_.wait(lk);
     }
   }
-  void give_back(Engine* e) { { std::lock_guard<std::mutex> lk(mu_); idle_.push_back(e); } cv_.notify_one(); }
+  // Scratch is grow-only per engine (a level-9 compression can leave tens of GiB behind); the pool as a whole keeps at most
+  // ZRA_SCRATCH_CAP_GIB (default 48) of it between calls: an engine that comes back while the process is above the cap hands its
+  // scratch to the device again, and so do the idle ones until the total fits.
+  void give_back(Engine* e) {
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      if (zra_eng::scratch_bytes_in_use() > cap()) {
+        (void)e->release_scratch();
+        for (Engine* i : idle_) { if (zra_eng::scratch_bytes_in_use() <= cap()) break; (void)i->release_scratch(); }
+      }
+      idle_.push_back(e);
+    }
+    cv_.notify_one();
+  }
  private:
   static int limit() {
     static const int n = [] { const char* s = std::getenv("ZRA_ENGINES"); int v = s ? std::atoi(s) : 4; return v < 1 ? 1 : v > 64 ? 64 : v; }();
     return n;
+  }
+  static uint64_t cap() {
+    static const uint64_t c = [] { const char* s = std::getenv("ZRA_SCRATCH_CAP_GIB"); long long v = s ? std::atoll(s) : 48; return (uint64_t)(v < 1 ? 1 : v) << 30; }();
+    return c;
   }
   std::mutex mu_; std::condition_variable cv_;
   std::vector<Engine*> idle_; int created_ = 0;

@@ -437,6 +437,7 @@ ZraStatus ZraHipCommServe(ZraHipComm* c, const ZraHipShard* s, const uint64_t* o
       if (hipStreamSynchronize(stream) != hipSuccess) st = zra_eng::zerr(1);
     }
   }
+  if (st.zra && std::getenv("ZRA_COMM_TRACE")) std::fprintf(stderr, "ZraHipCommServe: rank %d local status {%d, %d}\n", me, st.zra, st.zstd);
   return c->agree(st);
 }
 

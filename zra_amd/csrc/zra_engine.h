@@ -23,6 +23,9 @@ struct DevBuf {
   template <typename T> T* as() const { return (T*)p; }
 };
 
+// device scratch held by all engines of the process (DevBuf reservations), in bytes
+uint64_t scratch_bytes_in_use();
+
 // parsed fixed header (host side; zra.cpp:141-163 semantics)
 struct HeaderInfo {
   uint16_t version; uint32_t size; uint64_t uncompressedSize; uint32_t frameSize, metaOffset, metaSize, seekTableOffset, seekTableSize;

@@ -3,6 +3,7 @@
 #include "zra_dev.h"
 #include "zra_format.h"
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <chrono>
 #include <cstdio>
@@ -213,15 +214,21 @@ namespace zra_eng {
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { last_hip_error = e_; return zerr(1); } } while (0)
 static thread_local hipError_t last_hip_error = hipSuccess;
 
+// bytes of device scratch all engines of the process hold (what the engine pool's cap looks at)
+static std::atomic<uint64_t> g_scratchBytes{0};
+uint64_t scratch_bytes_in_use() { return g_scratchBytes.load(); }
+
 bool DevBuf::reserve(size_t n) {
   if (n <= cap) return true;
-  if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+  if (p) { (void)hipFree(p); g_scratchBytes -= cap; p = nullptr; cap = 0; }
   size_t want = n + n / 8 + 256;
-  if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; cap = 0; return false; }
-  cap = want;
+  // bring-up / test knob: ZRA_ALLOC_LIMIT_MIB makes any single reservation above the limit fail (memory_allocation paths without a full device)
+  static const uint64_t limit = std::getenv("ZRA_ALLOC_LIMIT_MIB") ? (uint64_t)std::atoll(std::getenv("ZRA_ALLOC_LIMIT_MIB")) << 20 : ~0ull;
+  if (want > limit || hipMalloc(&p, want) != hipSuccess) { p = nullptr; cap = 0; (void)hipGetLastError(); return false; }
+  cap = want; g_scratchBytes += cap;
   return true;
 }
-void DevBuf::release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+void DevBuf::release() { if (p) { (void)hipFree(p); g_scratchBytes -= cap; } p = nullptr; cap = 0; }
 
 int parse_fixed_header(const uint8_t* b, HeaderInfo* h) {
   using namespace zra_fmt;

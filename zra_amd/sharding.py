@@ -91,9 +91,17 @@ class Shard:
 class Comm:
     """ZraHipComm. All methods are collective."""
 
-    def __init__(self, handle, rank, world, keep=None):
+    def __init__(self, handle, rank, world, keep=None, engine=None):
         self.h, self.rank, self.world, self._keep = handle, rank, world, keep
+        self.engine = engine
         self.L = Z.load()
+
+    def _order(self):
+        # device buffers handed to the collective calls are usually torch tensors produced asynchronously on torch's stream: the
+        # engine's streams wait for it first (event wait, no host sync) — the same plumbing as Engine._order (found by the 8-rank dry
+        # run: content checksums taken from an input that torch was still writing)
+        if self.engine is not None:
+            self.engine._order()
 
     # ---- construction
     @classmethod
@@ -110,7 +118,7 @@ class Comm:
         ident = ctypes.create_string_buffer(box[0], 128)
         h = ctypes.c_void_p()
         Z._chk(L.ZraHipCommCreateRccl(ctypes.byref(h), engine.h, ident, rank, world), "ZraHipCommCreateRccl")
-        return cls(h, rank, world)
+        return cls(h, rank, world, engine=engine)
 
     @classmethod
     def torch_dist(cls, engine, group=None):
@@ -165,24 +173,27 @@ class Comm:
         tr = Z.ZraHipHostTransport(None, Z.ALLGATHER_FN(allgather), Z.EXCHANGE_FN(exchange))
         h = ctypes.c_void_p()
         Z._chk(Z.load().ZraHipCommCreateHost(ctypes.byref(h), engine.h, ctypes.byref(tr), rank, world), "ZraHipCommCreateHost")
-        return cls(h, rank, world, keep=tr)
+        return cls(h, rank, world, keep=tr, engine=engine)
 
     # ---- collectives
     def compress(self, d_local, local_bytes, total_bytes, level, frame_size, checksum=True):
         """ZraHipCommCompress: d_local = device pointer of this rank's frames' bytes. Returns a Shard."""
         sh = ctypes.c_void_p()
+        self._order()
         Z._chk(self.L.ZraHipCommCompress(self.h, d_local, local_bytes, total_bytes, level, frame_size, checksum, ctypes.byref(sh)), "ZraHipCommCompress")
         return Shard(sh)
 
     def gather_archive(self, shard, root=0, d_archive=0, capacity=0):
         """ZraHipCommGatherArchive: the archive in one piece on `root` (device pointer + capacity there). Returns its size on the root."""
         n = ctypes.c_size_t(0)
+        self._order()
         Z._chk(self.L.ZraHipCommGatherArchive(self.h, shard.h, root, d_archive, capacity, ctypes.byref(n)), "ZraHipCommGatherArchive")
         return n.value
 
     def serve(self, shard, offsets, sizes, out_offsets, d_out):
         """ZraHipCommServe: this rank's queries over the whole uncompressed range; answers at d_out + out_offsets[q]."""
         o = np.ascontiguousarray(offsets, dtype=np.uint64); s = np.ascontiguousarray(sizes, dtype=np.uint64); d = np.ascontiguousarray(out_offsets, dtype=np.uint64)
+        self._order()
         Z._chk(self.L.ZraHipCommServe(self.h, shard.h, _u64p(o), _u64p(s), _u64p(d), len(o), d_out), "ZraHipCommServe")
 
     def close(self):
