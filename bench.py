@@ -262,6 +262,27 @@ def ra_latency_probe(Z, eng, d_arc, arc_size, d_in, N, qb, torch):
     return out
 
 
+def choose_comm(eng, rank, world, one_gpu, dev, dist, sharding, torch, want):
+    """The communicator of a multi-rank run: RCCL called by the library itself (ncclAllGather / grouped ncclSend+ncclRecv on the engine's
+    stream), or the host transport over torch.distributed — the fallback, and the only choice when every rank sits on one GPU (RCCL
+    refuses duplicate devices). Every rank leaves with the SAME transport: one rank without an RCCL communicator sends everybody to the
+    fallback (tests/test_multi_rank.py runs this with a communicator that fails on one rank only)."""
+    comm, transport = None, "none"
+    if want == "rccl":
+        try:
+            comm, transport = sharding.Comm.rccl(eng, rank, world), "rccl (direct)"
+        except Exception as e:
+            sys.stderr.write("bench: direct RCCL communicator failed (%r); falling back to torch.distributed\n" % (e,))
+        flag = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device="cpu" if one_gpu else dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0 and comm is not None:
+            comm.close()
+            comm = None
+    if comm is None:
+        comm, transport = sharding.Comm.torch_dist(eng), "torch.distributed/" + dist.get_backend()
+    return comm, transport
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -308,22 +329,7 @@ def main():
     comm, transport = None, "none"
     if world > 1:
         from zra_amd import sharding
-        # RCCL called by the library itself (ncclAllGather / grouped ncclSend+ncclRecv on the engine's stream); the host transport over
-        # torch.distributed is the fallback (and the only choice when every rank sits on one GPU: RCCL refuses duplicate devices)
-        want = os.environ.get("ZRA_BENCH_TRANSPORT", "torch" if one_gpu else "rccl")
-        if want == "rccl":
-            try:
-                comm, transport = sharding.Comm.rccl(eng, rank, world), "rccl (direct)"
-            except Exception as e:
-                sys.stderr.write("bench: direct RCCL communicator failed (%r); falling back to torch.distributed\n" % (e,))
-            # every rank takes the same transport: one rank without a communicator sends everybody to the fallback
-            flag = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device="cpu" if one_gpu else dev)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if int(flag.item()) == 0 and comm is not None:
-                comm.close()
-                comm = None
-        if comm is None:
-            comm, transport = sharding.Comm.torch_dist(eng), "torch.distributed/" + dist.get_backend()
+        comm, transport = choose_comm(eng, rank, world, one_gpu, dev, dist, sharding, torch, os.environ.get("ZRA_BENCH_TRANSPORT", "torch" if one_gpu else "rccl"))
 
     fs = args.frame_kib << 10
     N = int(args.size_gib * GiB) // fs * fs            # per-GPU bytes (weak scaling: fixed per rank)

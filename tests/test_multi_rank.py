@@ -150,3 +150,64 @@ def test_two_rank_shard_stitch_route_serve(total, fs):
         assert p.exitcode == 0
     got = sorted(q.get(timeout=5) for _ in range(2))
     assert got == [(0, True), (1, True)]
+
+
+def test_stitched_archive_of_a_tebibyte_is_rejected():
+    """zra.cpp:227-228 after the all-gather of the frame sizes: header + bodies >= 2^40 bytes is CompressedSizeTooLarge on every rank
+    (ZraHipCommCompress stitches with the same call). Synthetic sizes: no such archive is ever materialised."""
+    import zra_amd as Z
+    fs = 1 << 30
+    sizes = np.array([1 << 38] * 4, dtype=np.uint64)                  # 2^40 bytes of frame bodies
+    with pytest.raises(Z.ZraError) as e:
+        Z.stitch_header(sizes, 4 * fs, fs)
+    assert e.value.zra == 7
+    sizes[3] -= np.uint64(4096)                                       # just below (header of 38 + 5 * 5 bytes included)
+    h = Z.stitch_header(sizes, 4 * fs, fs)
+    assert len(h) == 38 + 5 * 5 and int.from_bytes(h[38 + 20: 38 + 25], "little") == int(sizes.sum())
+
+
+def _transport_worker(rank, world, port, q):
+    sys.path.insert(0, os.path.dirname(HERE))
+    import bench
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        closed = []
+
+        class FakeComm:
+            def __init__(self, kind): self.kind = kind
+            def close(self): closed.append(self.kind)
+
+        class FakeSharding:
+            class Comm:
+                @staticmethod
+                def rccl(eng, r, w):
+                    if r == 0:
+                        raise RuntimeError("ncclCommInitRank failed on this rank only")
+                    return FakeComm("rccl")
+
+                @staticmethod
+                def torch_dist(eng):
+                    return FakeComm("host")
+        comm, transport = bench.choose_comm(None, rank, world, True, None, dist, FakeSharding, torch, "rccl")
+        q.put((rank, comm.kind, transport.split("/")[0], tuple(closed)))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_one_rank_without_rccl_sends_every_rank_to_the_host_transport():
+    """bench.py's transport choice: the RCCL communicator fails on rank 0 only; rank 1, which got one, must close it and take the
+    torch.distributed transport as well — a world with two transports would hang in the first collective."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() + 777) % 2000
+    procs = [ctx.Process(target=_transport_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    got = sorted(q.get(timeout=5) for _ in range(2))
+    assert got == [(0, "host", "torch.distributed", ()), (1, "host", "torch.distributed", ("rccl",))]
