@@ -727,3 +727,6 @@ ZraStatus ZraHipStitchHeader(const uint64_t* hFrameSizes, size_t nFramesTotal, u
   return mk(Success);
 }
 }  // extern "C"
+
+// for zra_comm.hip (the sharded serving path takes the same opt-in as ZraHipDecompressRABatch)
+bool zra_ra_whole_frames_option() { return (g_options.load() & kOptRaWholeFrames) != 0; }

@@ -54,6 +54,7 @@ using zra_eng::Engine;
 using zra_eng::Status;
 
 struct ZraHipEngine { Engine* e; };        // same layout as in zra_capi.cpp
+bool zra_ra_whole_frames_option();         // zra_capi.cpp: bit ZRA_HIP_OPT_RA_WHOLE_FRAMES of ZraHipSetOptions
 
 struct ZraHipComm {
   Engine* eng = nullptr;
@@ -142,6 +143,7 @@ struct ZraHipShard {
   std::vector<uint8_t> header;             // host copy (fixed header + seek table, CRC-32 set)
   std::vector<uint64_t> bodyBaseOf;        // [world + 1] body offset at which each rank's frames start
   DevBuf dev;                              // device: [header | table][own body]
+  ~ZraHipShard() { if (dev.p) { (void)hipSetDevice(device); dev.release(); } }   // (error paths of ZraHipCommCompress delete a half-built shard)
 };
 
 namespace {
@@ -344,6 +346,8 @@ ZraStatus ZraHipCommGatherArchive(ZraHipComm* c, const ZraHipShard* s, int root,
   return c->agree(st);
 }
 
+// (A transport failure — an allgather or exchange that returns false — leaves the ranks out of step: the call returns {ZStdError, 1}
+// on the rank that saw it and the communicator must not be used again; statuses of the ARCHIVE are agreed on and identical everywhere.)
 // Collective random access over a distributed archive: every rank passes its own queries (offset, size over the WHOLE uncompressed
 // range; any rank may ask for any byte) and gets its answers in dOut at dstOffs[q]. Bounds as DecompressRA (zra.cpp:260).
 ZraStatus ZraHipCommServe(ZraHipComm* c, const ZraHipShard* s, const uint64_t* offs, const uint64_t* sizes, const uint64_t* dstOffs, size_t nq, void* dOut) {
@@ -406,6 +410,7 @@ ZraStatus ZraHipCommServe(ZraHipComm* c, const ZraHipShard* s, const uint64_t* o
     if (!st.zra) {
       // (a query never reaches the archive's last byte — the ">=" rule of zra.cpp:260, applied to the whole query by the router — so
       // the same rule inside the batch call cannot fire for a slice)
+      c->eng->set_ra_verify_whole_frames(zra_ra_whole_frames_option());      // ZRA_HIP_OPT_RA_WHOLE_FRAMES, as in ZraHipDecompressRABatch
       st = c->eng->decompress_ra_batch_shard(s->dev.as<uint8_t>(), s->header.size(), s->dev.as<uint8_t>() + s->header.size(), s->bodyBytes, s->bodyBase,
                                              c->served.as<uint8_t>(), qo.data(), qs.data(), qd.data(), (size_t)inSl);
     }
