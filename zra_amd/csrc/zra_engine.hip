@@ -386,7 +386,10 @@ Status Engine::decode_launch(const ZraDecodeArgs& a0, const uint32_t* dExpect, u
     a.active = active; a.nActive = nActive; a.round = round;
     a.nextActive = (active == listA) ? listB : listA;
     const uint32_t gridParse = (uint32_t)std::min<uint64_t>(nActive, (uint64_t)numCUs_ * perCUParse);
-    static const uint32_t chainWaves = std::getenv("ZRA_DEC_CHAIN_WAVES") ? (uint32_t)std::atoi(std::getenv("ZRA_DEC_CHAIN_WAVES")) : 3u;   // A/B on one box, 16 GiB pass: 1 / 2 / 3 / 4 / 6 / 8 waves per CU -> 176.6 / 159.5 / 159.0 / 163.4 / 168.4 / 169.8 ms
+    // resident waves per CU of the chain kernel (lane = frame: 64 frames' tables per wave). Fewer frames in flight keep more of their
+    // table cells in the caches; A/B on one box, round 3 (parse / Huffman / execute stages already at their new occupancy): 8 GiB decode,
+    // chain stage 1 / 2 / 3 / 4 / 6 / 8 waves per CU -> 37 / 26.0 / 26.6 / 30.1 / 35.2 / 32.9 ms; 16 GiB: 74.1 / 51.9 / 53.2 / - ms
+    static const uint32_t chainWaves = std::getenv("ZRA_DEC_CHAIN_WAVES") ? (uint32_t)std::atoi(std::getenv("ZRA_DEC_CHAIN_WAVES")) : 2u;
     static const uint32_t chainGrid = std::getenv("ZRA_DEC_CHAIN_GRID") ? (uint32_t)std::atoi(std::getenv("ZRA_DEC_CHAIN_GRID")) : 0u;        // bring-up: absolute wave count
     const uint32_t gridChain = (uint32_t)std::min<uint64_t>((nActive + 63) / 64, chainGrid ? chainGrid : (uint64_t)numCUs_ * chainWaves);
     const uint32_t gridExec = (uint32_t)std::min<uint64_t>(nActive, (uint64_t)numCUs_ * perCUExec);
