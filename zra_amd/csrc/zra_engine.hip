@@ -388,7 +388,7 @@ Status Engine::decode_launch(const ZraDecodeArgs& a0, const uint32_t* dExpect, u
     const uint32_t gridParse = (uint32_t)std::min<uint64_t>(nActive, (uint64_t)numCUs_ * perCUParse);
     // resident waves per CU of the chain kernel (lane = frame: 64 frames' tables per wave). Fewer frames in flight keep more of their
     // table cells in the caches; A/B on one box, round 3 (parse / Huffman / execute stages already at their new occupancy): 8 GiB decode,
-    // chain stage 1 / 2 / 3 / 4 / 6 / 8 waves per CU -> 37 / 26.0 / 26.6 / 30.1 / 35.2 / 32.9 ms; 16 GiB: 74.1 / 51.9 / 53.2 / - ms
+    // chain stage 2 / 3 / 4 / 6 / 8 waves per CU -> 26.0 / 26.6 / 30.1 / 35.2 / 32.9 ms; 16 GiB, 1 / 1.5 / 2 / 2.5: 74.1 / 58.2 / 51.9 / 53.0 ms
     static const uint32_t chainWaves = std::getenv("ZRA_DEC_CHAIN_WAVES") ? (uint32_t)std::atoi(std::getenv("ZRA_DEC_CHAIN_WAVES")) : 2u;
     static const uint32_t chainGrid = std::getenv("ZRA_DEC_CHAIN_GRID") ? (uint32_t)std::atoi(std::getenv("ZRA_DEC_CHAIN_GRID")) : 0u;        // bring-up: absolute wave count
     const uint32_t gridChain = (uint32_t)std::min<uint64_t>((nActive + 63) / 64, chainGrid ? chainGrid : (uint64_t)numCUs_ * chainWaves);
