@@ -361,7 +361,20 @@ Status Engine::compress_persistent(const uint8_t* dIn, size_t inSize, uint8_t* d
   const uint64_t perFrame = seqStride * 8 + sizeof(ZraEncFrameState) + sizeof(ZraEncBlockOut) + 4 + 16 + 8;
   // per context (two of them); every launch boundary costs the pipeline about 7 ms (A/B on one box: 8 launches instead of 5 per 16 GiB
   // = -2 %), so the launches are as long as a scratch budget allows; bring-up knob ZRA_ENC_PBUDGET_GIB
-  static const uint64_t budget = (std::getenv("ZRA_ENC_PBUDGET_GIB") ? (uint64_t)std::max(1, std::atoi(std::getenv("ZRA_ENC_PBUDGET_GIB"))) : 8ull) << 30;
+  // Round 3: the boundary costs more than that once everything else is tuned — at 16 GiB one launch instead of five is 11-13 % of the
+  // match finder's time (A/B on one box: 5 x 200 ms vs 1 x 867-897 ms; every launch ends with a tail of straggling frames and starts
+  // with all waves in step). So the budget is what the device can spare: a third of its free memory, between 8 and 64 GiB (46 GiB of
+  // sequence scratch take 16 GiB of 64 KiB frames through in one launch; the scratch is grow-only and given back by
+  // ZraHipReleaseScratch / the engine pool's cap).
+  uint64_t budget;
+  if (const char* e = std::getenv("ZRA_ENC_PBUDGET_GIB")) budget = (uint64_t)std::max(1, std::atoi(e)) << 30;
+  else {
+    size_t freeB = 0, totalB = 0;
+    if (hipMemGetInfo(&freeB, &totalB) != hipSuccess) freeB = 24ull << 30;
+    // what this engine already holds for the purpose counts as free (the reservation below reuses it)
+    uint64_t mine = 0; for (auto& x : encCtx_) mine += x.seqs.cap;
+    budget = std::min<uint64_t>(64ull << 30, std::max<uint64_t>(8ull << 30, ((uint64_t)freeB + mine) / 3));
+  }
   uint64_t SBIG = std::max<uint64_t>(1, std::min<uint64_t>(nFramesTotal, budget / perFrame));
   if (const char* e = std::getenv("ZRA_ENC_SUPER")) SBIG = std::max<uint64_t>(1, std::min<uint64_t>(SBIG, (uint64_t)std::atoll(e)));   // bring-up knob
   if (SBIG > SB) SBIG -= SBIG % SB;
