@@ -858,3 +858,17 @@ print("OK")
     assert r.returncode == 0, (r.stdout[-500:], r.stderr[-1500:])
     assert out[0] == "ERR 1 64", out
     assert "OK" in out, out
+
+
+def test_small_inputs_through_the_four_kernel_pipeline_as_well():
+    """Everything up to 1024 frames takes the one-launch kernel now (zra_ra_small_kernel); the four-kernel pipeline still has to give
+    the same bytes and statuses on small inputs — it is where that kernel sends what it hands back, and what large archives run.
+    The differential decode, the damaged-archive statuses against libzstd, the damaged headers and the random-access cases again, in a
+    fresh process with ZRA_DEC_SMALL_MAX=0."""
+    import subprocess
+    env = dict(os.environ, ZRA_DEC_SMALL_MAX="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-x", "-q", "-k",
+                        "randomised_differential_decode or randomised_corruption_statuses or randomised_header_damage or random_access_on_damaged or ra_vs_bruteforce or golden_frames",
+                        "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout
