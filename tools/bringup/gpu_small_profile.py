@@ -10,7 +10,7 @@ d_arc = torch.empty(Z.GetOutputBufferSize(N, fs) + 64, dtype=torch.uint8, device
 n1 = eng.compress(d_in.data_ptr(), N, d_arc.data_ptr(), 3, fs, True)
 lib = ctypes.CDLL(Z.LIB_PATH)
 rng = np.random.RandomState(7)
-buf = (ctypes.c_ulonglong * 8)()
+buf = (ctypes.c_ulonglong * 16)()
 for bs in (1, 64):
     d_o = torch.empty(bs * qb + 64, dtype=torch.uint8, device=dev)
     sizes = np.full(bs, qb, dtype=np.uint64); oo = np.arange(bs, dtype=np.uint64) * qb
@@ -25,4 +25,7 @@ for bs in (1, 64):
     print("batch %d: median %.1f us  kernel ms %.3f" % (bs, ts[len(ts) // 2] * 1e6, eng.last_kernel_ms()))
     if hasattr(lib, "ZraHipDebugReadSmallProfile"):
         lib.ZraHipDebugReadSmallProfile(buf, 0); v = list(buf); nj = max(v[4], 1)
-        print("  jobs %d; cycles per job: parse %.0f  huffman %.0f  chain %.0f  execute %.0f" % (nj, v[0] / nj, v[1] / nj, v[2] / nj, v[3] / nj))
+        ns = max(v[12], 1)
+        print("  producer fast loop, cycles per sequence (%d sequences per job): cells + readfirstlane %.0f  fields + states %.0f  reload %.0f  ring write + gate %.0f" % (ns / nj, v[8] / ns, v[9] / ns, v[10] / ns, v[11] / ns))
+        print("  consumer, cycles per sequence: waiting for the producer %.0f  poll overhead %.0f  processing %.0f" % (v[13] / ns, v[14] / ns, v[15] / ns))
+        print("  jobs %d; cycles per job: parse %.0f  huffman %.0f  chain producer %.0f  chain consumer %.0f  execute %.0f" % (nj, v[0] / nj, v[1] / nj, v[2] / nj, v[5] / nj, v[3] / nj))

@@ -1296,6 +1296,12 @@ zra_dec_exec_kernel(ZraDecodeArgs a) {
 // the job BAIL: the host then takes the whole batch through the four-kernel pipeline, which is where every status of the reference is
 // reproduced. Valid archives never bail.
 namespace {
+// chain ring of the one-launch kernel (chain_produce / chain_consume below)
+constexpr u32 RING = 256;                        // ring entries (power of two)
+struct ChainRing {
+  uint4 e[RING];
+  u32 head, tail, prodDone, stop, consReady, consDone, bail, pad;
+};
 constexpr u32 SMALL_SEQ_BYTES = 40u << 10;      // sequence bitstreams up to this size are copied to LDS (a 64 KiB frame's is ~10 KiB)
 struct __attribute__((aligned(16))) SmallShared {
   ParseShared P;
@@ -1304,146 +1310,15 @@ struct __attribute__((aligned(16))) SmallShared {
   u16 hufTab[2048]; u8 hufW1[256];
   u8 bits[SMALL_SEQ_BYTES + 16];
   u32 ctl[4];                                   // [0] parse outcome, [1] bail, [2] frame goes on
+  ChainRing ring;
 };
-
-// returns 0: sequences of the block validated and stored (F->chainErr = 0 ...); 1: bail
-__device__ __forceinline__ u32 chain_job_lean(const ZraDecodeArgs& a, const u32 j, ZraDecFrame* const F, const u32* const T, u8* const bits, const int lane) {
-  const u32 nbSeq = F->nbSeq;
-  if (F->lateErr || F->longMode) return 1;
-  const u32 regen = F->litRegen, produced0 = F->produced;
-  const u32 outCap = a.outCap[j] - produced0;
-  const u32 limit = a.limit ? a.limit[j] : 0xFFFFFFFFu;
-  u64* const sq = a.seqs + F->seqBase;
-  u32 rep0 = F->rep[0], rep1 = F->rep[1], rep2 = F->rep[2];
-  u32 outPos = 0, litPos = 0, valid = 0, truncated = 0;
-  if (nbSeq) {
-    const u32 n = F->bsize - F->seqPos;
-    if (n < 8 || n > SMALL_SEQ_BYTES) return 1;
-    {
-      const u8* const g = a.body + a.frameOff[(size_t)j * a.offStride] + F->bpos + F->seqPos;
-      for (u32 o = 8u * (u32)lane; o < n; o += 8u * DEC_THREADS) {
-        if (o + 8 <= n) *(u64*)(bits + o) = ld64(g + o);
-        else for (u32 k = o; k < n; k++) bits[k] = g[k];
-      }
-      wsync();
-    }
-    Zds br;
-    if (!br.init(bits, n)) return 1;
-    u32 sLL = br.read(F->llLog); br.reload();
-    u32 sOF = br.read(F->ofLog); br.reload();
-    u32 sML = br.read(F->mlLog); br.reload();
-    u32 qlo = 0, qhi = 0;                        // sequences leave 64 at a time: lane (i & 63) keeps sequence i
-    u32 i = 0;
-    bool stop = false;
-    // ---- far from the stream's start (8 and more bytes below the container) every reload is BIT_reloadDStream's first case and no
-    // read can leave the container: the step below is the same arithmetic as the careful one further down, on wave-uniform values
-    // (scalar unit), without the cases that cannot occur here
-    {
-      u64 c = (u64)rfl((u32)br.c) | ((u64)rfl((u32)(br.c >> 32)) << 32);
-      u32 bc = rfl(br.bc), ptr = rfl(br.ptr);
-      sLL = rfl(sLL); sML = rfl(sML); sOF = rfl(sOF);
-      rep0 = rfl(rep0); rep1 = rfl(rep1); rep2 = rfl(rep2);
-      for (; i < nbSeq && ptr >= 8 && bc <= 64; i++) {
-        const uint2 vL = *(const uint2*)(T + ZRA_DEC_TBL_LL + 2 * sLL), vM = *(const uint2*)(T + ZRA_DEC_TBL_ML + 2 * sML);
-        const u32 eLx = rfl(vL.x), eLy = rfl(vL.y), eMx = rfl(vM.x), eMy = rfl(vM.y), eO = rfl(T[ZRA_DEC_TBL_OF + sOF]);
-        const u32 ofBits = (eO >> 8) & 0xFF, mlBits = (eMx >> 8) & 0xFF, llBits = (eLx >> 8) & 0xFF;
-        u32 ll = eLy, ml = eMy, off;
-        if (ofBits > 1) {
-          off = ((1u << ofBits) - 3u) + (u32)((c << (bc & 63)) >> ((64 - ofBits) & 63)); bc += ofBits;
-          rep2 = rep1; rep1 = rep0; rep0 = off;
-        } else {
-          const u32 ll0 = (ll == 0);
-          if (ofBits == 0) {
-            if (!ll0) off = rep0;
-            else { off = rep1; rep1 = rep0; rep0 = off; }
-          } else {
-            const u32 idx = 1 + ll0 + (u32)((c << (bc & 63)) >> 63); bc += 1;
-            u32 t = idx == 3 ? rep0 - 1 : idx == 1 ? rep1 : rep2;
-            t += !t;
-            if (idx != 1) rep2 = rep1;
-            rep1 = rep0; rep0 = off = t;
-          }
-        }
-        if (mlBits) { ml += (u32)((c << (bc & 63)) >> ((64 - mlBits) & 63)); bc += mlBits; }
-        if (llBits + mlBits + ofBits >= 57 - (9 + 9 + 8)) {           // BIT_reloadDStream in the middle of a long sequence
-          if (bc > 64 || ptr < 8) return 1;                             // (cannot happen: bc <= 7 + 31 + 16 here, and ptr >= 8 is the loop condition)
-          ptr -= bc >> 3; bc &= 7;
-          const u64 v = ld64(bits + ptr); c = (u64)rfl((u32)v) | ((u64)rfl((u32)(v >> 32)) << 32);
-        }
-        if (llBits) { ll += (u32)((c << (bc & 63)) >> ((64 - llBits) & 63)); bc += llBits; }
-        { const u32 nb = (eLx >> 16) & 0xF; sLL = (eLx >> 20) + ((u32)(c >> ((64u - bc - nb) & 63)) & ((1u << nb) - 1u)); bc += nb; }
-        { const u32 nb = (eMx >> 16) & 0xF; sML = (eMx >> 20) + ((u32)(c >> ((64u - bc - nb) & 63)) & ((1u << nb) - 1u)); bc += nb; }
-        { const u32 nb = (eO >> 16) & 0xF; sOF = (eO >> 20) + ((u32)(c >> ((64u - bc - nb) & 63)) & ((1u << nb) - 1u)); bc += nb; }
-        if (bc <= 64) {                                                   // (an over-read container stays as it is: reload_quiet's rule)
-          const u32 nbB = min(bc >> 3, ptr);
-          ptr -= nbB; bc -= nbB * 8;
-          if (nbB) { const u64 v = ld64(bits + ptr); c = (u64)rfl((u32)v) | ((u64)rfl((u32)(v >> 32)) << 32); }
-        }
-        if (ll + ml > outCap - outPos || ll > regen - litPos || off > produced0 + outPos + ll) return 1;
-        const u64 qv = (u64)ll | ((u64)ml << 18) | ((u64)min(off, 0x0FFFFFFFu) << 36);
-        qlo = wrlane_d(qlo, (u32)qv, i & 63u); qhi = wrlane_d(qhi, (u32)(qv >> 32), i & 63u);
-        if ((i & 63u) == 63u) sq[i - 63 + (u32)lane] = (u64)qlo | ((u64)qhi << 32);
-        outPos += ll + ml; litPos += ll;
-        valid = i + 1;
-        if (produced0 + outPos >= limit) { truncated = 1; stop = true; i++; break; }
-      }
-      br.c = c; br.bc = bc; br.ptr = ptr;
-    }
-    // ---- the stream's last bytes (and whatever the loop above did not want): the careful step
-    for (; !stop && i < nbSeq; i++) {
-      const uint2 eL = *(const uint2*)(T + ZRA_DEC_TBL_LL + 2 * sLL), eM = *(const uint2*)(T + ZRA_DEC_TBL_ML + 2 * sML);
-      const u32 eO = T[ZRA_DEC_TBL_OF + sOF];
-      const u32 ofBits = (eO >> 8) & 0xFF, mlBits = (eM.x >> 8) & 0xFF, llBits = (eL.x >> 8) & 0xFF;
-      u32 ll = eL.y, ml = eM.y, off;
-      if (ofBits > 1) {
-        off = ((1u << ofBits) - 3u) + br.read_fast(ofBits);
-        rep2 = rep1; rep1 = rep0; rep0 = off;
-      } else {
-        const u32 ll0 = (ll == 0);
-        if (ofBits == 0) {
-          if (!ll0) off = rep0;
-          else { off = rep1; rep1 = rep0; rep0 = off; }
-        } else {
-          const u32 idx = 1 + ll0 + br.read_fast(1);
-          u32 t = idx == 3 ? rep0 - 1 : idx == 1 ? rep1 : rep2;
-          t += !t;
-          if (idx != 1) rep2 = rep1;
-          rep1 = rep0; rep0 = off = t;
-        }
-      }
-      if (mlBits) ml += br.read_fast(mlBits);
-      if (llBits + mlBits + ofBits >= 57 - (9 + 9 + 8)) br.reload();
-      if (llBits) ll += br.read_fast(llBits);
-      sLL = (eL.x >> 20) + br.read((eL.x >> 16) & 0xF);
-      sML = (eM.x >> 20) + br.read((eM.x >> 16) & 0xF);
-      sOF = (eO >> 20) + br.read((eO >> 16) & 0xF);
-      br.reload_quiet(true, bits);
-      if (ll + ml > outCap - outPos || ll > regen - litPos || off > produced0 + outPos + ll) return 1;
-      const u64 qv = (u64)ll | ((u64)ml << 18) | ((u64)min(off, 0x0FFFFFFFu) << 36);
-      if (((u32)lane) == (i & 63u)) { qlo = (u32)qv; qhi = (u32)(qv >> 32); }
-      if ((i & 63u) == 63u) sq[i - 63 + (u32)lane] = (u64)qlo | ((u64)qhi << 32);
-      outPos += ll + ml; litPos += ll;
-      valid = i + 1;
-      if (produced0 + outPos >= limit) { truncated = 1; break; }       // random access: stop at the sequence that covers the last needed byte
-    }
-    if ((valid & 63u) && (u32)lane < (valid & 63u)) sq[(valid & ~63u) + (u32)lane] = (u64)qlo | ((u64)qhi << 32);
-    if (!truncated && br.reload() < Zds::COMPLETED) return 1;            // the stream must be consumed exactly
-  }
-  if (!truncated && regen - litPos > outCap - outPos) return 1;          // the tail literals need room
-  if (lane == 0) {
-    F->chainErr = 0; F->nSeqValid = valid; F->seqOut = outPos; F->seqLit = litPos; F->truncated = truncated;
-    F->repOut[0] = rep0; F->repOut[1] = rep1; F->repOut[2] = rep2;
-  }
-  return 0;
-}
-}  // namespace
 
 #ifdef ZRA_SMALL_PROFILE
 // bring-up (never in the shipped library): s_memtime sums per stage of zra_ra_small_kernel: parse, Huffman (wave 1), chain (wave 0), execute, jobs
-__device__ unsigned long long zra_small_prof[8];
-extern "C" __attribute__((visibility("default"))) void ZraHipDebugReadSmallProfile(unsigned long long* out8, int reset) {
-  (void)hipMemcpyFromSymbol(out8, HIP_SYMBOL(zra_small_prof), sizeof(unsigned long long) * 8);
-  if (reset) { unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(zra_small_prof), z, sizeof(z)); }
+__device__ unsigned long long zra_small_prof[16];
+extern "C" __attribute__((visibility("default"))) void ZraHipDebugReadSmallProfile(unsigned long long* out16, int reset) {
+  (void)hipMemcpyFromSymbol(out16, HIP_SYMBOL(zra_small_prof), sizeof(unsigned long long) * 16);
+  if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(zra_small_prof), z, sizeof(z)); }
 }
 #define SPROF(k) { __builtin_amdgcn_s_waitcnt(0); const u64 n_ = __builtin_amdgcn_s_memtime(); if (lane == 0) atomicAdd(&zra_small_prof[k], n_ - spt_); spt_ = n_; }
 #define SPROF_T0 u64 spt_ = __builtin_amdgcn_s_memtime();
@@ -1454,8 +1329,187 @@ extern "C" __attribute__((visibility("default"))) void ZraHipDebugReadSmallProfi
 #define SPROF_RESET
 #endif
 
-// grid = jobs (one workgroup each), 128 threads. *bail counts the jobs that have to go through the four-kernel pipeline.
-extern "C" __global__ void __launch_bounds__(2 * DEC_THREADS)
+// ---- the sequence chain of the one-launch kernel, split over two waves.
+// PRODUCER (wave 0): BIT_DStream arithmetic only — per sequence the three table cells, the extra bits, the state updates, the reload —
+// and hands {literal length, match length, offset code bits, raw offset bits} to an LDS ring. CONSUMER (wave 2): what the reference's
+// sequence loop does with those numbers — repeat-offset resolution, the three checks of ZSTD_execSequence, positions, the stop at a
+// random-access query's last byte — and the packed sequences for the execute stage. The chain's dependent path is the producer's; the
+// consumer is the faster of the two and only ever waits.
+__device__ __forceinline__ u32 ring_ld(const u32* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void ring_st(u32* p, u32 v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+__device__ __forceinline__ void chain_produce(const ZraDecodeArgs& a, const u32 j, ZraDecFrame* const F, const u32* const T, u8* const bits, ChainRing& R, const int lane) {
+  const u32 nbSeq = F->nbSeq;
+  auto fail = [&]() { if (lane == 0) { ring_st(&R.bail, 1u); ring_st(&R.prodDone, 1u); } };
+  if (F->lateErr || F->longMode) { fail(); return; }
+  u32 i = 0;
+  if (nbSeq) {
+    const u32 n = F->bsize - F->seqPos;
+    if (n < 8 || n > SMALL_SEQ_BYTES) { fail(); return; }
+    {
+      const u8* const g = a.body + a.frameOff[(size_t)j * a.offStride] + F->bpos + F->seqPos;
+      for (u32 o = 8u * (u32)lane; o < n; o += 8u * DEC_THREADS) {
+        if (o + 8 <= n) *(u64*)(bits + o) = ld64(g + o);
+        else for (u32 k = o; k < n; k++) bits[k] = g[k];
+      }
+      wsync();
+    }
+    Zds br;
+    if (!br.init(bits, n)) { fail(); return; }
+    u32 sLL = br.read(F->llLog); br.reload();
+    u32 sOF = br.read(F->ofLog); br.reload();
+    u32 sML = br.read(F->mlLog); br.reload();
+    bool stopped = false;
+    // room in the ring / a stop request, looked at every eighth sequence
+    auto gate = [&](u32 at) -> bool {
+      if (ring_ld(&R.stop) | ring_ld(&R.bail)) return false;
+      while (at + 8 - ring_ld(&R.tail) > RING) { if (ring_ld(&R.stop) | ring_ld(&R.bail)) return false; __builtin_amdgcn_s_sleep(1); }
+      return true;
+    };
+    // ---- far from the stream's start (8 and more bytes below the container) every reload is BIT_reloadDStream's first case and no
+    // read can leave the container: straight-line arithmetic on wave-uniform values (scalar unit)
+    {
+      u64 c = (u64)rfl((u32)br.c) | ((u64)rfl((u32)(br.c >> 32)) << 32);
+      u32 bc = rfl(br.bc), ptr = rfl(br.ptr);
+      sLL = rfl(sLL); sML = rfl(sML); sOF = rfl(sOF);
+#if defined(ZRA_SMALL_PROFILE) && ZRA_SMALL_PROFILE >= 2          // (timers inside the loop: they double its time — relative numbers only)
+      u64 pp0 = 0, pp1 = 0, pp2 = 0, pp3 = 0, ppt = __builtin_amdgcn_s_memtime(); u32 ppn = 0;
+#define PPH(v) { const u64 n_ = __builtin_amdgcn_s_memtime(); v += n_ - ppt; ppt = n_; }
+#else
+#define PPH(v)
+#endif
+      // the cells of the sequence about to be decoded are requested together with the container reload of the one before:
+      // one LDS round trip per sequence
+      uint2 vL = *(const uint2*)(T + ZRA_DEC_TBL_LL + 2 * sLL), vM = *(const uint2*)(T + ZRA_DEC_TBL_ML + 2 * sML);
+      u32 vO = T[ZRA_DEC_TBL_OF + sOF];
+      for (; i < nbSeq && ptr >= 8 && bc <= 64; i++) {
+        if ((i & 7u) == 0) { if (i) { if (lane == 0) ring_st(&R.head, i); } if (!gate(i)) { stopped = true; break; } }
+        PPH(pp3)
+        const u32 eLx = rfl(vL.x), eLy = rfl(vL.y), eMx = rfl(vM.x), eMy = rfl(vM.y), eO = rfl(vO);
+        PPH(pp0)
+        const u32 ofBits = (eO >> 8) & 0xFF, mlBits = (eMx >> 8) & 0xFF, llBits = (eLx >> 8) & 0xFF;
+        u32 ll = eLy, ml = eMy, raw = 0;
+        if (ofBits) { raw = (u32)((c << (bc & 63)) >> ((64 - ofBits) & 63)); bc += ofBits; }
+        if (mlBits) { ml += (u32)((c << (bc & 63)) >> ((64 - mlBits) & 63)); bc += mlBits; }
+        if (llBits + mlBits + ofBits >= 57 - (9 + 9 + 8)) {           // BIT_reloadDStream in the middle of a long sequence
+          if (bc > 64 || ptr < 8) { fail(); return; }                   // (cannot happen: bc <= 7 + 31 + 16 here, and ptr >= 8 is the loop condition)
+          ptr -= bc >> 3; bc &= 7;
+          const u64 v = ld64(bits + ptr); c = (u64)rfl((u32)v) | ((u64)rfl((u32)(v >> 32)) << 32);
+        }
+        if (llBits) { ll += (u32)((c << (bc & 63)) >> ((64 - llBits) & 63)); bc += llBits; }
+        { const u32 nb = (eLx >> 16) & 0xF; sLL = (eLx >> 20) + ((u32)(c >> ((64u - bc - nb) & 63)) & ((1u << nb) - 1u)); bc += nb; }
+        { const u32 nb = (eMx >> 16) & 0xF; sML = (eMx >> 20) + ((u32)(c >> ((64u - bc - nb) & 63)) & ((1u << nb) - 1u)); bc += nb; }
+        { const u32 nb = (eO >> 16) & 0xF; sOF = (eO >> 20) + ((u32)(c >> ((64u - bc - nb) & 63)) & ((1u << nb) - 1u)); bc += nb; }
+        PPH(pp1)
+        // next cells and (an over-read container stays as it is: reload_quiet's rule) the container, in flight together
+        vL = *(const uint2*)(T + ZRA_DEC_TBL_LL + 2 * sLL); vM = *(const uint2*)(T + ZRA_DEC_TBL_ML + 2 * sML); vO = T[ZRA_DEC_TBL_OF + sOF];
+        if (bc <= 64) {
+          const u32 nbB = min(bc >> 3, ptr);
+          ptr -= nbB; bc -= nbB * 8;
+          const u64 v = ld64(bits + ptr);
+          if (nbB) c = (u64)rfl((u32)v) | ((u64)rfl((u32)(v >> 32)) << 32);
+        }
+        PPH(pp2)
+        if (lane == 0) R.e[i & (RING - 1)] = make_uint4(ll, ml, ofBits, raw);
+#if defined(ZRA_SMALL_PROFILE) && ZRA_SMALL_PROFILE >= 2
+        ppn++;
+#endif
+      }
+#if defined(ZRA_SMALL_PROFILE) && ZRA_SMALL_PROFILE >= 2
+      if (lane == 0) { atomicAdd(&zra_small_prof[8], pp0); atomicAdd(&zra_small_prof[9], pp1); atomicAdd(&zra_small_prof[10], pp2); atomicAdd(&zra_small_prof[11], pp3); atomicAdd(&zra_small_prof[12], (u64)ppn); }
+#endif
+      br.c = c; br.bc = bc; br.ptr = ptr;
+    }
+    // ---- the stream's last bytes: the careful step (every case of BIT_reloadDStream)
+    for (; !stopped && i < nbSeq; i++) {
+      if ((i & 7u) == 0) { if (i) { if (lane == 0) ring_st(&R.head, i); } if (!gate(i)) { stopped = true; break; } }
+      const uint2 eL = *(const uint2*)(T + ZRA_DEC_TBL_LL + 2 * sLL), eM = *(const uint2*)(T + ZRA_DEC_TBL_ML + 2 * sML);
+      const u32 eO = T[ZRA_DEC_TBL_OF + sOF];
+      const u32 ofBits = (eO >> 8) & 0xFF, mlBits = (eM.x >> 8) & 0xFF, llBits = (eL.x >> 8) & 0xFF;
+      u32 ll = eL.y, ml = eM.y, raw = 0;
+      if (ofBits) raw = br.read_fast(ofBits);
+      if (mlBits) ml += br.read_fast(mlBits);
+      if (llBits + mlBits + ofBits >= 57 - (9 + 9 + 8)) br.reload();
+      if (llBits) ll += br.read_fast(llBits);
+      sLL = (eL.x >> 20) + br.read((eL.x >> 16) & 0xF);
+      sML = (eM.x >> 20) + br.read((eM.x >> 16) & 0xF);
+      sOF = (eO >> 20) + br.read((eO >> 16) & 0xF);
+      br.reload_quiet(true, bits);
+      if (lane == 0) R.e[i & (RING - 1)] = make_uint4(ll, ml, ofBits, raw);
+    }
+    if (!stopped && br.reload() < Zds::COMPLETED) { fail(); return; }     // the stream must be consumed exactly
+  }
+  if (lane == 0) { ring_st(&R.head, i); ring_st(&R.prodDone, 1u); }
+}
+
+__device__ __forceinline__ void chain_consume(const ZraDecodeArgs& a, const u32 j, ZraDecFrame* const F, ChainRing& R, const int lane) {
+  const u32 regen = F->litRegen, produced0 = F->produced;
+  const u32 outCap = a.outCap[j] - produced0;
+  const u32 limit = a.limit ? a.limit[j] : 0xFFFFFFFFu;
+  u64* const sq = a.seqs + F->seqBase;
+  u32 rep0 = rfl(F->rep[0]), rep1 = rfl(F->rep[1]), rep2 = rfl(F->rep[2]);
+  u32 outPos = 0, litPos = 0, valid = 0, truncated = 0;
+  u32 qlo = 0, qhi = 0;
+  u32 t = 0;
+  bool bad = false;
+#if defined(ZRA_SMALL_PROFILE) && ZRA_SMALL_PROFILE >= 2
+  u64 cp0 = 0, cp1 = 0, cp2 = 0, cpt = __builtin_amdgcn_s_memtime();
+#define CPH(v) { const u64 n_ = __builtin_amdgcn_s_memtime(); v += n_ - cpt; cpt = n_; }
+#else
+#define CPH(v)
+#endif
+  for (;;) {
+    if (ring_ld(&R.bail)) return;
+    const u32 done = ring_ld(&R.prodDone);
+    const u32 h = ring_ld(&R.head);
+    if (t == h) { if (done) break; __builtin_amdgcn_s_sleep(8); CPH(cp0) continue; }
+    CPH(cp1)
+    for (; t < h; t++) {
+      const uint4 e4 = R.e[t & (RING - 1)];
+      const u32 ll = rfl(e4.x), ml = rfl(e4.y), ofBits = rfl(e4.z), raw = rfl(e4.w);
+      u32 off;
+      if (ofBits > 1) { off = ((1u << ofBits) - 3u) + raw; rep2 = rep1; rep1 = rep0; rep0 = off; }
+      else {
+        const u32 ll0 = (ll == 0);
+        if (ofBits == 0) {
+          if (!ll0) off = rep0;
+          else { off = rep1; rep1 = rep0; rep0 = off; }
+        } else {
+          const u32 idx = 1 + ll0 + raw;
+          u32 x = idx == 3 ? rep0 - 1 : idx == 1 ? rep1 : rep2;
+          x += !x;
+          if (idx != 1) rep2 = rep1;
+          rep1 = rep0; rep0 = off = x;
+        }
+      }
+      if (ll + ml > outCap - outPos || ll > regen - litPos || off > produced0 + outPos + ll) { bad = true; break; }
+      const u64 qv = (u64)ll | ((u64)ml << 18) | ((u64)min(off, 0x0FFFFFFFu) << 36);
+      qlo = wrlane_d(qlo, (u32)qv, t & 63u); qhi = wrlane_d(qhi, (u32)(qv >> 32), t & 63u);
+      if ((t & 63u) == 63u) sq[t - 63 + (u32)lane] = (u64)qlo | ((u64)qhi << 32);
+      outPos += ll + ml; litPos += ll;
+      valid = t + 1;
+      if ((t & 7u) == 7u && lane == 0) ring_st(&R.tail, t + 1);
+      if (produced0 + outPos >= limit) { truncated = 1; break; }       // random access: stop at the sequence that covers the last needed byte
+    }
+    CPH(cp2)
+    if (bad || truncated) break;
+  }
+#if defined(ZRA_SMALL_PROFILE) && ZRA_SMALL_PROFILE >= 2
+  if (lane == 0) { atomicAdd(&zra_small_prof[13], cp0); atomicAdd(&zra_small_prof[14], cp1); atomicAdd(&zra_small_prof[15], cp2); }
+#endif
+  if (bad || (!truncated && regen - litPos > outCap - outPos)) { if (lane == 0) { ring_st(&R.bail, 1u); ring_st(&R.stop, 1u); } return; }
+  if (truncated && lane == 0) ring_st(&R.stop, 1u);
+  if ((valid & 63u) && (u32)lane < (valid & 63u)) sq[(valid & ~63u) + (u32)lane] = (u64)qlo | ((u64)qhi << 32);
+  if (lane == 0) {
+    F->chainErr = 0; F->nSeqValid = valid; F->seqOut = outPos; F->seqLit = litPos; F->truncated = truncated;
+    F->repOut[0] = rep0; F->repOut[1] = rep1; F->repOut[2] = rep2;
+  }
+}
+}  // namespace
+
+// grid = jobs (one workgroup each), 192 threads = three waves: 0 parses, produces the chain and executes; 1 decodes the Huffman
+// literals; 2 consumes the chain. *bail counts the jobs that have to go through the four-kernel pipeline.
+extern "C" __global__ void __launch_bounds__(3 * DEC_THREADS)
 zra_ra_small_kernel(ZraDecodeArgs a0, u32* bail) {
   __shared__ SmallShared S;
   const int wave = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
@@ -1469,7 +1523,14 @@ zra_ra_small_kernel(ZraDecodeArgs a0, u32* bail) {
 #endif
   for (u32 round = 0;; round++) {
     a.round = round;
-    if (wave == 0) { const u32 oc = parse_job<true>(a, j, S.P, lane, S.tabs); if (lane == 0) { S.ctl[0] = oc; S.ctl[1] = 0; } SPROF(0) }
+    if (wave == 0) {
+      const u32 oc = parse_job<true>(a, j, S.P, lane, S.tabs);
+      if (lane == 0) {
+        S.ctl[0] = oc; S.ctl[1] = 0;
+        S.ring.head = 0; S.ring.tail = 0; S.ring.prodDone = 0; S.ring.stop = 0; S.ring.consReady = 0; S.ring.consDone = 0; S.ring.bail = 0;
+      }
+      SPROF(0)
+    }
     __syncthreads();
     SPROF_RESET
     const u32 oc = S.ctl[0];
@@ -1482,13 +1543,16 @@ zra_ra_small_kernel(ZraDecodeArgs a0, u32* bail) {
         if ((u32)lane < F->litStreams && !huf_decode_stream(a, F, j, S.hufTab, S.hufW1, (u32)lane, lim)) S.ctl[1] = 1;
       }
       SPROF(1)
-    } else {
-      if (chain_job_lean(a, j, F, S.tabs, S.bits, lane) && lane == 0) S.ctl[1] = 1;
+    } else if (wave == 0) {
+      chain_produce(a, j, F, S.tabs, S.bits, S.ring, lane);
       SPROF(2)
+    } else {
+      chain_consume(a, j, F, S.ring, lane);
+      SPROF(5)
     }
     __threadfence_block();
     __syncthreads();
-    if (S.ctl[1]) { if (threadIdx.x == 0) atomicAdd(bail, 1u); return; }
+    if (S.ctl[1] | S.ring.bail) { if (threadIdx.x == 0) atomicAdd(bail, 1u); return; }
     SPROF_RESET
     if (wave == 0) { const u32 more = exec_job<true>(a, j, S.X, lane); if (lane == 0) S.ctl[2] = more; SPROF(3) }
     __syncthreads();

@@ -331,13 +331,23 @@ Status Engine::decode_scratch(ZraDecodeArgs& a, uint32_t maxFrameBytes) {
 Status Engine::decode_small(const ZraDecodeArgs& a0, const uint32_t* dExpect, uint32_t maxFrameBytes, uint32_t jobBase, unsigned long long* hResult, uint32_t* bailed) {
   ZraDecodeArgs a = a0;
   const uint32_t n = a.nFrames;
+  static const bool trace = std::getenv("ZRA_RA_TRACE") != nullptr;
+  auto t_last = std::chrono::steady_clock::now();
+  auto mark = [&](const char* what) {
+    if (!trace) return;
+    const auto t = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "    small %-12s %7.1f us\n", what, std::chrono::duration<double, std::micro>(t - t_last).count());
+    t_last = t;
+  };
   { Status st = decode_scratch(a, maxFrameBytes); if (st.zra) return st; }
+  mark("scratch");
   a.active = nullptr; a.nActive = n; a.round = 0; a.nextActive = decLists_.as<uint32_t>(); a.debugSkip = 0;
   uint32_t* dBail = a.counters + ZRA_DC_WORDS;
   HIPCHK(hipMemsetAsync(a.counters, 0, ZRA_DC_WORDS * 4 + 8, stream_));
   HIPCHK(hipEventRecord(ev0_, stream_));
-  hipLaunchKernelGGL(zra_ra_small_kernel, dim3(n), dim3(128), 0, stream_, a, dBail);
+  hipLaunchKernelGGL(zra_ra_small_kernel, dim3(n), dim3(192), 0, stream_, a, dBail);
   HIPCHK(hipEventRecord(ev1_, stream_));
+  mark("launched");
   const uint32_t tb = 256;
   hipLaunchKernelGGL(zra_xxh64_verify_kernel, dim3((n * 4 + tb - 1) / tb), dim3(tb), 0, stream_, a.out, a.outOff, dExpect,
                      produced_.as<uint32_t>(), frameMeta_.as<uint32_t>(), status_.as<uint32_t>(), n);
@@ -347,7 +357,9 @@ Status Engine::decode_small(const ZraDecodeArgs& a0, const uint32_t* dExpect, ui
   HIPCHK(hipMemcpyAsync(result_.as<uint8_t>() + 8, dBail, 4, hipMemcpyDeviceToDevice, stream_));
   unsigned long long two[2] = {~0ull, 0};
   HIPCHK(hipMemcpyAsync(two, result_.p, 16, hipMemcpyDeviceToHost, stream_));
+  mark("queued rest");
   HIPCHK(hipStreamSynchronize(stream_));
+  mark("sync");
   HIPCHK(hipGetLastError());
   *bailed = (uint32_t)two[1];
   if (!*bailed) *hResult = two[0];
