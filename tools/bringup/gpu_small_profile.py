@@ -25,7 +25,5 @@ for bs in (1, 64):
     print("batch %d: median %.1f us  kernel ms %.3f" % (bs, ts[len(ts) // 2] * 1e6, eng.last_kernel_ms()))
     if hasattr(lib, "ZraHipDebugReadSmallProfile"):
         lib.ZraHipDebugReadSmallProfile(buf, 0); v = list(buf); nj = max(v[4], 1)
-        ns = max(v[12], 1)
-        print("  producer fast loop, cycles per sequence (%d sequences per job): cells + readfirstlane %.0f  fields + states %.0f  reload %.0f  ring write + gate %.0f" % (ns / nj, v[8] / ns, v[9] / ns, v[10] / ns, v[11] / ns))
-        print("  consumer, cycles per sequence: waiting for the producer %.0f  poll overhead %.0f  processing %.0f" % (v[13] / ns, v[14] / ns, v[15] / ns))
+        print("  parse, cycles per job: to the literals header %.0f  literals header + tree %.0f  sequences header %.0f  table descriptions %.0f  table builds %.0f  hand-over %.0f" % tuple(v[k] / nj for k in (8, 9, 10, 11, 12, 13)))
         print("  jobs %d; cycles per job: parse %.0f  huffman %.0f  chain producer %.0f  chain consumer %.0f  execute %.0f" % (nj, v[0] / nj, v[1] / nj, v[2] / nj, v[5] / nj, v[3] / nj))

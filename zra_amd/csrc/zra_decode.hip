@@ -55,6 +55,28 @@ __device__ __forceinline__ u32 mk_cell(u32 sym, u32 addBits, u32 nbBits, u32 nex
   return sym | (addBits << 8) | (nbBits << 16) | (nextBase << 20);
 }
 
+#ifdef ZRA_SMALL_PROFILE
+// bring-up (never in the shipped library): s_memtime sums per stage of zra_ra_small_kernel: parse, Huffman (wave 1), chain (wave 0), execute, jobs
+__device__ unsigned long long zra_small_prof[16];
+extern "C" __attribute__((visibility("default"))) void ZraHipDebugReadSmallProfile(unsigned long long* out16, int reset) {
+  (void)hipMemcpyFromSymbol(out16, HIP_SYMBOL(zra_small_prof), sizeof(unsigned long long) * 16);
+  if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(zra_small_prof), z, sizeof(z)); }
+}
+#define SPROF(k) { __builtin_amdgcn_s_waitcnt(0); const u64 n_ = __builtin_amdgcn_s_memtime(); if (lane == 0) atomicAdd(&zra_small_prof[k], n_ - spt_); spt_ = n_; }
+#define SPROF_T0 u64 spt_ = __builtin_amdgcn_s_memtime();
+#define SPROF_RESET spt_ = __builtin_amdgcn_s_memtime();
+#else
+#define SPROF(k)
+#define SPROF_T0
+#define SPROF_RESET
+#endif
+#ifdef ZRA_SMALL_PROFILE
+#define PPROF_T0 u64 ppt_ = __builtin_amdgcn_s_memtime();
+#define PPROF(k) if (FUSED) { __builtin_amdgcn_s_waitcnt(0); const u64 n_ = __builtin_amdgcn_s_memtime(); if (lane == 0) atomicAdd(&zra_small_prof[k], n_ - ppt_); ppt_ = n_; }
+#else
+#define PPROF_T0
+#define PPROF(k)
+#endif
 constexpr u32 STAGE_BYTES = 512;     // header bytes copied to LDS per window (frame + block + literals header + tree description: <= 160)
 struct __attribute__((aligned(16))) ParseShared {
   // lane 0 parses headers byte by byte: from HBM that is a dependent round trip per byte (~1-2 us each under load), so the wave
@@ -145,36 +167,95 @@ __device__ __forceinline__ u32 read_ncount(short* norm, u32* maxSymIO, u32* tabl
   return (bitpos + 7) >> 3;
 }
 
-// Build an FSE decode table from norm[] into the LDS staging area (single wave; lanes cooperate on the final fill).
-// kind: 0 = LL, 1 = ML (two words per cell: packed fields, base value), 2 = OF (one word per cell)
-__device__ __forceinline__ void build_fse_dtable(u32* stage, const short* norm, u32 maxSym, u32 tableLog, int kind, u8* spread, int lane) {
-  u32 size = 1u << tableLog, mask = size - 1;
-  if (lane == 0) {
-    u32 high = size - 1, step = (size >> 1) + (size >> 3) + 3, pos = 0;
-    for (u32 s = 0; s <= maxSym; s++) if (norm[s] == -1) spread[high--] = (u8)s;
-    for (u32 s = 0; s <= maxSym; s++) {
-      for (int i = 0; i < norm[s]; i++) {
-        spread[pos] = (u8)s;
-        pos = (pos + step) & mask;
-        while (pos > high) pos = (pos + step) & mask;
-      }
-    }
+// wave-wide inclusive scans on the DPP network (no LDS traffic): rows of 16 by row_shr 1/2/4/8, then the row totals by row_bcast 15 / 31
+__device__ __forceinline__ u32 dpp_scan_add(u32 v) {
+  v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);
+  v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);
+  v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);
+  v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);
+  v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);
+  v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);
+  return v;
+}
+__device__ __forceinline__ u32 dpp_scan_max(u32 v) {
+  v = max(v, (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true));
+  v = max(v, (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true));
+  v = max(v, (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true));
+  v = max(v, (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true));
+  v = max(v, (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false));
+  v = max(v, (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false));
+  return v;
+}
+
+// Build an FSE decode table from norm[] into the LDS staging area — FSE_buildDTable / ZSTD_buildFSETable of the dependency, every step
+// of it wave-wide (it was one lane's 512-step walk, twice: two thirds of the parse stage):
+//  * spread: the serial walk visits pos_i = i * step mod size, i = 0, 1, ..., and hands the positions <= highThreshold, in that order, to
+//    the symbols in ascending order, norm[s] each. So the r-th valid visit belongs to the symbol whose run of ranks holds r: ranks from a
+//    ballot prefix over 64 visits at a time, rank -> symbol from a running maximum over "symbol s starts at rank cum[s]" marks.
+//  * cells: cell u takes x = next[s]++ in ascending u. 64 cells at a time: the lanes of one symbol find each other through a 64-bit
+//    mask per symbol in LDS (atomic OR), their order inside the chunk is a popcount below the lane, the run continues in next[s].
+// kind: 0 = LL, 1 = ML (two words per cell: packed fields, base value), 2 = OF (one word per cell).
+// tmp: 1 KiB of scratch that may alias `stage`; masks: 64 x u64; next: 64 x u16. maxSym <= 52.
+__device__ __forceinline__ void build_fse_dtable(u32* stage, const short* norm, u32 maxSym, u32 tableLog, int kind, u8* spread, u64* masks, u16* next, int lane) {
+  const u32 size = 1u << tableLog, mask = size - 1, step = (size >> 1) + (size >> 3) + 3;
+  const u32 s = (u32)lane;
+  const u64 lt = (1ull << lane) - 1ull;
+  const int nv = s <= maxSym ? (int)norm[s] : 0;
+  const bool low = nv == -1;
+  const u32 cnt = nv > 0 ? (u32)nv : 0u;
+  const u64 lowM = __ballot(low);
+  const u32 high = size - 1 - (u32)__popcll(lowM);
+  u8* const M = (u8*)stage;            // marks, then the symbol of every rank
+  for (u32 i = (u32)lane; i < (size >> 2); i += DEC_THREADS) ((u32*)M)[i] = 0;
+  masks[lane] = 0;
+  next[lane] = (u16)(low ? 1u : cnt);
+  if (low) spread[size - 1 - (u32)__popcll(lowM & lt)] = (u8)s;
+  const u32 cum = dpp_scan_add(cnt) - cnt;
+  wsync();
+  if (cnt) M[cum] = (u8)s;
+  wsync();
+  u32 carry = 0;
+  for (u32 c = 0; c < size; c += DEC_THREADS) {
+    const u32 r = c + (u32)lane;
+    u32 v = r < size ? M[r] : 0u;
+    v = max(dpp_scan_max(v), carry);
+    carry = bcast_u32(v, 63);
+    if (r < size) M[r] = (u8)v;
   }
   wsync();
-  // cell u gets x = next[sym]++ in ascending u. One lane per symbol walks all cells (broadcast LDS reads).
-  if ((u32)lane <= maxSym && norm[lane] != 0) {
-    const u32 s = (u32)lane;
-    u32 x = norm[s] == -1 ? 1u : (u32)norm[s];
-    const u32 add = kind == 0 ? c_ll_bits[s] : kind == 1 ? c_ml_bits[s] : s;
-    const u32 base = kind == 0 ? c_ll_base[s] : kind == 1 ? c_ml_base[s] : 0u;
-    for (u32 u = 0; u < size; u++) {
-      if (spread[u] != s) continue;
-      u32 nbBits = tableLog - hb32(x);
-      u32 nextBase = (x << nbBits) - size;
-      if (kind == 2) stage[u] = mk_cell(s, add, nbBits, nextBase);
-      else { stage[2 * u] = mk_cell(s, add, nbBits, nextBase); stage[2 * u + 1] = base; }
-      x++;
+  u32 rank0 = 0;
+  for (u32 c = 0; c < size; c += DEC_THREADS) {
+    const u32 i = c + (u32)lane;
+    const u32 p = (i * step) & mask;
+    const bool ok = i < size && p <= high;
+    const u64 bm = __ballot(ok);
+    if (ok) spread[p] = M[rank0 + (u32)__popcll(bm & lt)];
+    rank0 += (u32)__popcll(bm);
+  }
+  wsync();
+  // what a symbol's cells share: extra bits and base value, held by lane = symbol
+  const u32 addS = s <= maxSym ? (kind == 0 ? c_ll_bits[s] : kind == 1 ? c_ml_bits[s] : s) : 0u;
+  const u32 baseS = s <= maxSym ? (kind == 0 ? c_ll_base[s] : kind == 1 ? c_ml_base[s] : 0u) : 0u;
+  for (u32 c = 0; c < size; c += DEC_THREADS) {
+    const u32 u = c + (u32)lane;
+    const bool on = u < size;
+    const u32 sy = on ? (u32)spread[u] : 0u;
+    if (on) atomicOr((unsigned long long*)&masks[sy], 1ull << lane);
+    wsync();
+    const u64 m = on ? masks[sy] : 0ull;
+    const u32 x0 = next[sy];
+    wsync();
+    const u32 before = (u32)__popcll(m & lt);
+    if (on && before == 0) { next[sy] = (u16)(x0 + (u32)__popcll(m)); masks[sy] = 0; }
+    const u32 add = (u32)__shfl((int)addS, (int)sy, 64), base = (u32)__shfl((int)baseS, (int)sy, 64);
+    if (on) {
+      const u32 x = x0 + before;
+      const u32 nbBits = tableLog - hb32(x);
+      const u32 nextBase = (x << nbBits) - size;
+      if (kind == 2) stage[u] = mk_cell(sy, add, nbBits, nextBase);
+      else { stage[2 * u] = mk_cell(sy, add, nbBits, nextBase); stage[2 * u + 1] = base; }
     }
+    wsync();
   }
 }
 
@@ -476,6 +557,7 @@ __device__ __forceinline__ u32 parse_job(const ZraDecodeArgs& a, const u32 j, Pa
       if (lane < 2) *(u64*)(w + STAGE_BYTES + 8 * lane) = 0;
       return avail;
     };
+    PPROF_T0
     const u32 startPos = a.round == 0 ? 0u : F->blkPos;
     const u32 staged0 = stage(S.w0, startPos);
 
@@ -596,6 +678,7 @@ __device__ __forceinline__ u32 parse_job(const ZraDecodeArgs& a, const u32 j, Pa
       }
 
       // ------------------------------------------------------------ compressed block
+      PPROF(8)
       const u32 hv0 = S.hufValid, hmb0 = S.hufMaxBits, hns0 = S.hufNSym, hx20 = S.hufX2;     // the kept tree as of before this block
       if (lane == 0) {
         S.litStreams = 1; S.litRle = 0; S.alloc = 1; S.lateErr = 0; S.nbSeq = 0;
@@ -613,6 +696,7 @@ __device__ __forceinline__ u32 parse_job(const ZraDecodeArgs& a, const u32 j, Pa
         }
       }
       wsync();
+      PPROF(9)
       if (S.err) break;
       // ---- sequences header + table descriptions, from their own LDS window. Whatever is wrong from here on is raised only after
       //      the literals have been decoded (the reference decodes the literals section first): it travels as lateErr
@@ -647,6 +731,7 @@ __device__ __forceinline__ u32 parse_job(const ZraDecodeArgs& a, const u32 j, Pa
         break;
       }
 
+      PPROF(10)
       // ---- sequence decode tables: lane 0 parses each description, the wave builds it in LDS and stores it to the table scratch
       const u32 nbSeq = S.nbSeq, regen = S.litRegen;
       u32* const T = a.tables + (size_t)j * ZRA_DEC_TBL_WORDS;
@@ -662,6 +747,7 @@ __device__ __forceinline__ u32 parse_job(const ZraDecodeArgs& a, const u32 j, Pa
             if (S.err) { S.lateErr = S.err; S.err = 0; }
           }
           wsync();
+          PPROF(11)
           if (S.lateErr) break;
           const u32 tl = S.tl, ms = S.ms;
           u32* const G = T + (k == 0 ? ZRA_DEC_TBL_LL : k == 1 ? ZRA_DEC_TBL_ML : ZRA_DEC_TBL_OF);
@@ -672,7 +758,7 @@ __device__ __forceinline__ u32 parse_job(const ZraDecodeArgs& a, const u32 j, Pa
               if (FUSED) { u32* const GL = ldsT + (k == 0 ? ZRA_DEC_TBL_LL : k == 1 ? ZRA_DEC_TBL_ML : ZRA_DEC_TBL_OF); GL[0] = G[0]; if (k != 2) GL[1] = G[1]; }
             }
           } else if (mode != 3) {
-            build_fse_dtable(S.stage, S.norm, ms, tl, k, S.spread, lane);
+            build_fse_dtable(S.stage, S.norm, ms, tl, k, S.spread, (u64*)S.w0, S.wnext, lane);
             wsync();
             const u32 words = (k == 2 ? 1u : 2u) << tl;
             for (u32 i = lane; i < words; i += DEC_THREADS) G[i] = S.stage[i];
@@ -690,6 +776,7 @@ __device__ __forceinline__ u32 parse_job(const ZraDecodeArgs& a, const u32 j, Pa
             if (k == 0) { S.llLog = tl; S.llValid = 1; } else if (k == 1) { S.mlLog = tl; S.mlValid = 1; } else { S.ofLog = tl; S.ofValid = 1; }
           }
           wsync();
+          PPROF(12)
         }
       }
 
@@ -713,6 +800,7 @@ __device__ __forceinline__ u32 parse_job(const ZraDecodeArgs& a, const u32 j, Pa
       }
       handed = true; outcome = 1;
       wsync();
+      PPROF(13)
       break;
     }
     if (!handed) {
@@ -1313,21 +1401,6 @@ struct __attribute__((aligned(16))) SmallShared {
   ChainRing ring;
 };
 
-#ifdef ZRA_SMALL_PROFILE
-// bring-up (never in the shipped library): s_memtime sums per stage of zra_ra_small_kernel: parse, Huffman (wave 1), chain (wave 0), execute, jobs
-__device__ unsigned long long zra_small_prof[16];
-extern "C" __attribute__((visibility("default"))) void ZraHipDebugReadSmallProfile(unsigned long long* out16, int reset) {
-  (void)hipMemcpyFromSymbol(out16, HIP_SYMBOL(zra_small_prof), sizeof(unsigned long long) * 16);
-  if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(zra_small_prof), z, sizeof(z)); }
-}
-#define SPROF(k) { __builtin_amdgcn_s_waitcnt(0); const u64 n_ = __builtin_amdgcn_s_memtime(); if (lane == 0) atomicAdd(&zra_small_prof[k], n_ - spt_); spt_ = n_; }
-#define SPROF_T0 u64 spt_ = __builtin_amdgcn_s_memtime();
-#define SPROF_RESET spt_ = __builtin_amdgcn_s_memtime();
-#else
-#define SPROF(k)
-#define SPROF_T0
-#define SPROF_RESET
-#endif
 
 // ---- the sequence chain of the one-launch kernel, split over two waves.
 // PRODUCER (wave 0): BIT_DStream arithmetic only — per sequence the three table cells, the extra bits, the state updates, the reload —
@@ -1337,6 +1410,10 @@ extern "C" __attribute__((visibility("default"))) void ZraHipDebugReadSmallProfi
 // consumer is the faster of the two and only ever waits.
 __device__ __forceinline__ u32 ring_ld(const u32* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void ring_st(u32* p, u32 v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+// lane i <- lane i-n inside a row of 16 (zero where there is no such lane); lanes 0..3 <-> 7..4 inside a group of 8
+template <int N> __device__ __forceinline__ u32 dpp_row_shr(u32 v) { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x110 + N, 0xF, 0xF, true); }
+__device__ __forceinline__ u32 dpp_low4_from_mirror(u32 v) { return (u32)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x141, 0xF, 0x1, false); }
 
 __device__ __forceinline__ void chain_produce(const ZraDecodeArgs& a, const u32 j, ZraDecFrame* const F, const u32* const T, u8* const bits, ChainRing& R, const int lane) {
   const u32 nbSeq = F->nbSeq;
@@ -1360,69 +1437,54 @@ __device__ __forceinline__ void chain_produce(const ZraDecodeArgs& a, const u32 
     u32 sOF = br.read(F->ofLog); br.reload();
     u32 sML = br.read(F->mlLog); br.reload();
     bool stopped = false;
-    // room in the ring / a stop request, looked at every eighth sequence
+    // room in the ring / a stop request, looked at every sixteenth sequence
     auto gate = [&](u32 at) -> bool {
       if (ring_ld(&R.stop) | ring_ld(&R.bail)) return false;
-      while (at + 8 - ring_ld(&R.tail) > RING) { if (ring_ld(&R.stop) | ring_ld(&R.bail)) return false; __builtin_amdgcn_s_sleep(1); }
+      while (at + 16 - ring_ld(&R.tail) > RING) { if (ring_ld(&R.stop) | ring_ld(&R.bail)) return false; __builtin_amdgcn_s_sleep(1); }
       return true;
     };
-    // ---- far from the stream's start (8 and more bytes below the container) every reload is BIT_reloadDStream's first case and no
-    // read can leave the container: straight-line arithmetic on wave-uniform values (scalar unit)
-    {
-      u64 c = (u64)rfl((u32)br.c) | ((u64)rfl((u32)(br.c >> 32)) << 32);
-      u32 bc = rfl(br.bc), ptr = rfl(br.ptr);
-      sLL = rfl(sLL); sML = rfl(sML); sOF = rfl(sOF);
-#if defined(ZRA_SMALL_PROFILE) && ZRA_SMALL_PROFILE >= 2          // (timers inside the loop: they double its time — relative numbers only)
-      u64 pp0 = 0, pp1 = 0, pp2 = 0, pp3 = 0, ppt = __builtin_amdgcn_s_memtime(); u32 ppn = 0;
-#define PPH(v) { const u64 n_ = __builtin_amdgcn_s_memtime(); v += n_ - ppt; ppt = n_; }
-#else
-#define PPH(v)
-#endif
-      // the cells of the sequence about to be decoded are requested together with the container reload of the one before:
-      // one LDS round trip per sequence
-      uint2 vL = *(const uint2*)(T + ZRA_DEC_TBL_LL + 2 * sLL), vM = *(const uint2*)(T + ZRA_DEC_TBL_ML + 2 * sML);
-      u32 vO = T[ZRA_DEC_TBL_OF + sOF];
-      for (; i < nbSeq && ptr >= 8 && bc <= 64; i++) {
-        if ((i & 7u) == 0) { if (i) { if (lane == 0) ring_st(&R.head, i); } if (!gate(i)) { stopped = true; break; } }
-        PPH(pp3)
-        const u32 eLx = rfl(vL.x), eLy = rfl(vL.y), eMx = rfl(vM.x), eMy = rfl(vM.y), eO = rfl(vO);
-        PPH(pp0)
-        const u32 ofBits = (eO >> 8) & 0xFF, mlBits = (eMx >> 8) & 0xFF, llBits = (eLx >> 8) & 0xFF;
-        u32 ll = eLy, ml = eMy, raw = 0;
-        if (ofBits) { raw = (u32)((c << (bc & 63)) >> ((64 - ofBits) & 63)); bc += ofBits; }
-        if (mlBits) { ml += (u32)((c << (bc & 63)) >> ((64 - mlBits) & 63)); bc += mlBits; }
-        if (llBits + mlBits + ofBits >= 57 - (9 + 9 + 8)) {           // BIT_reloadDStream in the middle of a long sequence
-          if (bc > 64 || ptr < 8) { fail(); return; }                   // (cannot happen: bc <= 7 + 31 + 16 here, and ptr >= 8 is the loop condition)
-          ptr -= bc >> 3; bc &= 7;
-          const u64 v = ld64(bits + ptr); c = (u64)rfl((u32)v) | ((u64)rfl((u32)(v >> 32)) << 32);
+    // ---- Far from the stream's start every reload is BIT_reloadDStream's first case and no read can leave the container, so the
+    // reader is one number: `cur`, the bits still unread (container = the 8 bytes that end at bit cur rounded up to a byte, bitsConsumed =
+    // the 0..7 bits of rounding). The six fields of a sequence — extra bits of OF, ML, LL, then the state bits of LL, ML, OF, in stream
+    // order — sit on lanes 0,1,2 and 5,6,7 of the wave: each lane reads the cell of ITS stream, an 8-lane prefix sum of the widths places
+    // the fields, one 64-bit shift per lane extracts them, and the new states go back to lanes 0..2 through a half-row mirror. The
+    // dependent path of a sequence is one LDS round trip (cells and container together) and ~10 vector instructions instead of ~100.
+    const u32 k8 = (u32)lane < 8u ? (u32)lane : 3u;
+    const u32 strm = (k8 == 2 || k8 == 5) ? 0u : (k8 == 1 || k8 == 6) ? 1u : (k8 == 0 || k8 == 7) ? 2u : 3u;       // LL, ML, OF, idle
+    const u8* const tk = (const u8*)(T + (strm == 0 ? ZRA_DEC_TBL_LL : strm == 1 ? ZRA_DEC_TBL_ML : ZRA_DEC_TBL_OF));
+    const u32 shk = strm < 2 ? 3u : strm == 2 ? 2u : 0u;                         // cell size (idle lanes read the first OF cell, or junk)
+    const u32 fOff = k8 < 3 ? 8u : 16u, fWid = k8 < 3 ? 8u : k8 >= 5 ? 4u : 0u;
+    // what a lane leaves in the ring entry: lane 2 -> word 0 (literal length), lane 1 -> word 1 (match length), lane 0 -> word 2
+    // ((1 << code) + extra bits); every other lane -> word 3, which nobody reads
+    u32* const slot = (u32*)&R.e[0] + (k8 < 3 ? 2u - k8 : 3u);
+    const u32 mBase = (k8 == 1 || k8 == 2) ? ~0u : 0u, mPow = k8 == 0 ? ~0u : 0u;
+    for (;;) {
+      i32 cur = (i32)rfl(8u * br.ptr + 64u - br.bc);
+      if (i < nbSeq && cur >= 256 && br.ptr >= 8 && br.bc < 8) {
+        u32 st = strm == 0 ? sLL : strm == 1 ? sML : strm == 2 ? sOF : 0u;
+        while (i < nbSeq && cur >= 256) {
+          if ((i & 15u) == 0) { if (i) { if (lane == 0) ring_st(&R.head, i); } if (!gate(i)) { stopped = true; break; } }
+          const u32 p = (((u32)cur + 7u) >> 3) - 8u, room = (u32)cur - 8u * p;      // room = 64 - bitsConsumed
+          const u32* const cell = (const u32*)(tk + (st << shk));
+          const u32 x = cell[0], y = cell[1];
+          const u64 c = ld64(bits + p);
+          asm volatile("" :: "v"((u32)c), "v"((u32)(c >> 32)), "v"(y));               // (cells and container in flight together)
+          const u32 w = __builtin_amdgcn_ubfe(x, fOff, fWid);
+          u32 s = w; s += dpp_row_shr<1>(s); s += dpp_row_shr<2>(s); s += dpp_row_shr<4>(s);
+          const u32 total = bcast_u32(s, 7);
+          if (total > room) break;                                                    // (a sequence of more than 57 bits: the careful step)
+          const u32 val = __builtin_amdgcn_ubfe((u32)(c >> ((room - s) & 63u)), 0u, w);
+          st = dpp_low4_from_mirror((x >> 20) + val);
+          slot[4u * (i & (RING - 1))] = val + ((1u << w) & mPow) + (y & mBase);
+          cur -= (i32)total; i++;
         }
-        if (llBits) { ll += (u32)((c << (bc & 63)) >> ((64 - llBits) & 63)); bc += llBits; }
-        { const u32 nb = (eLx >> 16) & 0xF; sLL = (eLx >> 20) + ((u32)(c >> ((64u - bc - nb) & 63)) & ((1u << nb) - 1u)); bc += nb; }
-        { const u32 nb = (eMx >> 16) & 0xF; sML = (eMx >> 20) + ((u32)(c >> ((64u - bc - nb) & 63)) & ((1u << nb) - 1u)); bc += nb; }
-        { const u32 nb = (eO >> 16) & 0xF; sOF = (eO >> 20) + ((u32)(c >> ((64u - bc - nb) & 63)) & ((1u << nb) - 1u)); bc += nb; }
-        PPH(pp1)
-        // next cells and (an over-read container stays as it is: reload_quiet's rule) the container, in flight together
-        vL = *(const uint2*)(T + ZRA_DEC_TBL_LL + 2 * sLL); vM = *(const uint2*)(T + ZRA_DEC_TBL_ML + 2 * sML); vO = T[ZRA_DEC_TBL_OF + sOF];
-        if (bc <= 64) {
-          const u32 nbB = min(bc >> 3, ptr);
-          ptr -= nbB; bc -= nbB * 8;
-          const u64 v = ld64(bits + ptr);
-          if (nbB) c = (u64)rfl((u32)v) | ((u64)rfl((u32)(v >> 32)) << 32);
-        }
-        PPH(pp2)
-        if (lane == 0) R.e[i & (RING - 1)] = make_uint4(ll, ml, ofBits, raw);
-#if defined(ZRA_SMALL_PROFILE) && ZRA_SMALL_PROFILE >= 2
-        ppn++;
-#endif
+        sLL = bcast_u32(st, 2); sML = bcast_u32(st, 1); sOF = bcast_u32(st, 0);
+        br.ptr = (((u32)cur + 7u) >> 3) - 8u; br.bc = 8u * br.ptr + 64u - (u32)cur; br.c = ld64(bits + br.ptr);
+        if (stopped) break;
       }
-#if defined(ZRA_SMALL_PROFILE) && ZRA_SMALL_PROFILE >= 2
-      if (lane == 0) { atomicAdd(&zra_small_prof[8], pp0); atomicAdd(&zra_small_prof[9], pp1); atomicAdd(&zra_small_prof[10], pp2); atomicAdd(&zra_small_prof[11], pp3); atomicAdd(&zra_small_prof[12], (u64)ppn); }
-#endif
-      br.c = c; br.bc = bc; br.ptr = ptr;
-    }
-    // ---- the stream's last bytes: the careful step (every case of BIT_reloadDStream)
-    for (; !stopped && i < nbSeq; i++) {
-      if ((i & 7u) == 0) { if (i) { if (lane == 0) ring_st(&R.head, i); } if (!gate(i)) { stopped = true; break; } }
+      if (i >= nbSeq) break;
+      // ---- one careful step (every case of BIT_reloadDStream): the stream's last bytes, and sequences wider than a container
+      if ((i & 15u) == 0) { if (i) { if (lane == 0) ring_st(&R.head, i); } if (!gate(i)) { stopped = true; break; } }
       const uint2 eL = *(const uint2*)(T + ZRA_DEC_TBL_LL + 2 * sLL), eM = *(const uint2*)(T + ZRA_DEC_TBL_ML + 2 * sML);
       const u32 eO = T[ZRA_DEC_TBL_OF + sOF];
       const u32 ofBits = (eO >> 8) & 0xFF, mlBits = (eM.x >> 8) & 0xFF, llBits = (eL.x >> 8) & 0xFF;
@@ -1435,73 +1497,81 @@ __device__ __forceinline__ void chain_produce(const ZraDecodeArgs& a, const u32 
       sML = (eM.x >> 20) + br.read((eM.x >> 16) & 0xF);
       sOF = (eO >> 20) + br.read((eO >> 16) & 0xF);
       br.reload_quiet(true, bits);
-      if (lane == 0) R.e[i & (RING - 1)] = make_uint4(ll, ml, ofBits, raw);
+      if (lane == 0) R.e[i & (RING - 1)] = make_uint4(ll, ml, (1u << ofBits) + raw, 0u);
+      i++;
     }
     if (!stopped && br.reload() < Zds::COMPLETED) { fail(); return; }     // the stream must be consumed exactly
   }
   if (lane == 0) { ring_st(&R.head, i); ring_st(&R.prodDone, 1u); }
 }
 
+// ring entry: {literal length, match length, (1 << offset code) + its extra bits}: 1 = repeat offset by literal length, 2 / 3 = the
+// one-bit repeat codes, >= 4 = a new offset + 3
 __device__ __forceinline__ void chain_consume(const ZraDecodeArgs& a, const u32 j, ZraDecFrame* const F, ChainRing& R, const int lane) {
   const u32 regen = F->litRegen, produced0 = F->produced;
   const u32 outCap = a.outCap[j] - produced0;
   const u32 limit = a.limit ? a.limit[j] : 0xFFFFFFFFu;
   u64* const sq = a.seqs + F->seqBase;
   u32 rep0 = rfl(F->rep[0]), rep1 = rfl(F->rep[1]), rep2 = rfl(F->rep[2]);
-  u32 outPos = 0, litPos = 0, valid = 0, truncated = 0;
-  u32 qlo = 0, qhi = 0;
+  u32 outPos = 0, litPos = 0, truncated = 0;
   u32 t = 0;
   bool bad = false;
-#if defined(ZRA_SMALL_PROFILE) && ZRA_SMALL_PROFILE >= 2
-  u64 cp0 = 0, cp1 = 0, cp2 = 0, cpt = __builtin_amdgcn_s_memtime();
-#define CPH(v) { const u64 n_ = __builtin_amdgcn_s_memtime(); v += n_ - cpt; cpt = n_; }
-#else
-#define CPH(v)
-#endif
+  // up to 64 sequences at a time, lane = sequence: positions by prefix sums, the checks and the packing side by side; only the repeat
+  // offsets are resolved one after the other (and only the sequences that use one: between two of them every sequence pushes a new offset)
   for (;;) {
     if (ring_ld(&R.bail)) return;
     const u32 done = ring_ld(&R.prodDone);
     const u32 h = ring_ld(&R.head);
-    if (t == h) { if (done) break; __builtin_amdgcn_s_sleep(8); CPH(cp0) continue; }
-    CPH(cp1)
-    for (; t < h; t++) {
-      const uint4 e4 = R.e[t & (RING - 1)];
-      const u32 ll = rfl(e4.x), ml = rfl(e4.y), ofBits = rfl(e4.z), raw = rfl(e4.w);
-      u32 off;
-      if (ofBits > 1) { off = ((1u << ofBits) - 3u) + raw; rep2 = rep1; rep1 = rep0; rep0 = off; }
-      else {
-        const u32 ll0 = (ll == 0);
-        if (ofBits == 0) {
-          if (!ll0) off = rep0;
-          else { off = rep1; rep1 = rep0; rep0 = off; }
-        } else {
-          const u32 idx = 1 + ll0 + raw;
-          u32 x = idx == 3 ? rep0 - 1 : idx == 1 ? rep1 : rep2;
-          x += !x;
-          if (idx != 1) rep2 = rep1;
-          rep1 = rep0; rep0 = off = x;
-        }
+    if (t == h) { if (done) break; __builtin_amdgcn_s_sleep(4); continue; }
+    u32 nb = min(h - t, 64u);
+    const bool on = (u32)lane < nb;
+    const uint4 e4 = R.e[(t + (u32)lane) & (RING - 1)];
+    const u32 ll = on ? e4.x : 0u, ml = on ? e4.y : 0u, ov = on ? e4.z : 4u;
+    const u32 sOut = wave_incl_scan(ll + ml), sLit = wave_incl_scan(ll);
+    const u32 outBefore = outPos + sOut - (ll + ml), litBefore = litPos + sLit - ll;
+    // random access: stop at the sequence that covers the last needed byte
+    const u64 tm = __ballot(on && produced0 + outPos + sOut >= limit);
+    if (tm) { nb = (u32)__builtin_ctzll(tm) + 1u; truncated = 1; }
+    const bool on2 = (u32)lane < nb;
+    u32 off = ov - 3u;
+    u64 m = __ballot(on2 && ov < 4u);
+    u32 next = 0;                                          // first lane whose push is not in rep0..2 yet
+    auto catch_up = [&](u32 L) {                           // the pushes of lanes next .. L-1 (new offsets, all of them)
+      const u32 kk = L - next;
+      if (kk >= 3) { rep0 = bcast_u32(off, L - 1); rep1 = bcast_u32(off, L - 2); rep2 = bcast_u32(off, L - 3); }
+      else if (kk == 2) { rep2 = rep0; rep0 = bcast_u32(off, L - 1); rep1 = bcast_u32(off, L - 2); }
+      else if (kk == 1) { rep2 = rep1; rep1 = rep0; rep0 = bcast_u32(off, L - 1); }
+    };
+    while (m) {
+      const u32 L = (u32)__builtin_ctzll(m); m &= m - 1;
+      catch_up(L);
+      const u32 ovL = bcast_u32(ov, L), ll0 = bcast_u32(ll, L) == 0;
+      u32 x;
+      if (ovL == 1) {
+        if (!ll0) x = rep0;
+        else { x = rep1; rep1 = rep0; rep0 = x; }
+      } else {
+        const u32 idx = 1 + ll0 + (ovL - 2u);
+        x = idx == 3 ? rep0 - 1 : idx == 1 ? rep1 : rep2;
+        x += !x;
+        if (idx != 1) rep2 = rep1;
+        rep1 = rep0; rep0 = x;
       }
-      if (ll + ml > outCap - outPos || ll > regen - litPos || off > produced0 + outPos + ll) { bad = true; break; }
-      const u64 qv = (u64)ll | ((u64)ml << 18) | ((u64)min(off, 0x0FFFFFFFu) << 36);
-      qlo = wrlane_d(qlo, (u32)qv, t & 63u); qhi = wrlane_d(qhi, (u32)(qv >> 32), t & 63u);
-      if ((t & 63u) == 63u) sq[t - 63 + (u32)lane] = (u64)qlo | ((u64)qhi << 32);
-      outPos += ll + ml; litPos += ll;
-      valid = t + 1;
-      if ((t & 7u) == 7u && lane == 0) ring_st(&R.tail, t + 1);
-      if (produced0 + outPos >= limit) { truncated = 1; break; }       // random access: stop at the sequence that covers the last needed byte
+      off = wrlane_d(off, x, L);
+      next = L + 1;
     }
-    CPH(cp2)
-    if (bad || truncated) break;
+    catch_up(nb);
+    if (__ballot(on2 && (ll + ml > outCap - outBefore || ll > regen - litBefore || off > produced0 + outBefore + ll))) { bad = true; break; }
+    if (on2) sq[t + (u32)lane] = (u64)ll | ((u64)ml << 18) | ((u64)min(off, 0x0FFFFFFFu) << 36);
+    outPos += bcast_u32(sOut, nb - 1); litPos += bcast_u32(sLit, nb - 1);
+    t += nb;
+    if (lane == 0) ring_st(&R.tail, t);
+    if (truncated) break;
   }
-#if defined(ZRA_SMALL_PROFILE) && ZRA_SMALL_PROFILE >= 2
-  if (lane == 0) { atomicAdd(&zra_small_prof[13], cp0); atomicAdd(&zra_small_prof[14], cp1); atomicAdd(&zra_small_prof[15], cp2); }
-#endif
   if (bad || (!truncated && regen - litPos > outCap - outPos)) { if (lane == 0) { ring_st(&R.bail, 1u); ring_st(&R.stop, 1u); } return; }
   if (truncated && lane == 0) ring_st(&R.stop, 1u);
-  if ((valid & 63u) && (u32)lane < (valid & 63u)) sq[(valid & ~63u) + (u32)lane] = (u64)qlo | ((u64)qhi << 32);
   if (lane == 0) {
-    F->chainErr = 0; F->nSeqValid = valid; F->seqOut = outPos; F->seqLit = litPos; F->truncated = truncated;
+    F->chainErr = 0; F->nSeqValid = t; F->seqOut = outPos; F->seqLit = litPos; F->truncated = truncated;
     F->repOut[0] = rep0; F->repOut[1] = rep1; F->repOut[2] = rep2;
   }
 }

@@ -55,7 +55,7 @@ class Engine {
   uint64_t last_produced_total() const { return lastProducedTotal_; }
   // HIP-event timings of the last call on the engine's stream: {mf ms, mf launches, entropy ms, entropy launches, decode ms, decode launches}
   void kernel_stats(double out[6]) const { for (int i = 0; i < 6; i++) out[i] = kstats_[i]; }
-  // decode stages of the last call: {parse ms, Huffman ms, sequence-chain ms, execute ms, rounds, one-launch kernel ms, its launches, 0}
+  // decode stages of the last call: {parse ms, Huffman ms, sequence-chain ms, execute ms, rounds, one-launch kernel ms, its launches, pipelined first rounds}
   void decode_stage_stats(double out[8]) const { for (int i = 0; i < 8; i++) out[i] = dstats_[i]; }
   // bring-up: sequences {ll | ml<<20 | offVal<<40} the match finder left in scratch context 0 for frame `frame` of the LAST batch
   // (last block of the frame); returns the count, meta = {nbSeq, lastLL, skip}
@@ -142,6 +142,7 @@ class Engine {
   EncCtx encCtx_[2];
   DevBuf encScan_;
   hipStream_t stream2_ = nullptr;          // entropy stage / gather stream (overlaps the match finder on stream_)
+  hipStream_t pipeStreams_[3] = {nullptr, nullptr, nullptr};   // decode stage pipeline: Huffman, chain, execute (parse runs on stream_)
   std::vector<hipEvent_t> evPool_;
   DevBuf hostIn_, hostOut_, seqScratch_;
   uint64_t dbgSeqStride_ = 0; uint32_t dbgB_ = 0;

@@ -284,6 +284,7 @@ Engine::~Engine() {
   for (auto ev : evPool_) (void)hipEventDestroy(ev);
   for (auto ev : stageEv_) (void)hipEventDestroy(ev);
   if (stream2_) { (void)hipStreamSynchronize(stream2_); (void)hipStreamDestroy(stream2_); }
+  for (auto st : pipeStreams_) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
   for (auto& ev : evR_) if (ev) (void)hipEventDestroy(ev);
   if (ev0_) (void)hipEventDestroy(ev0_);
   if (ev1_) (void)hipEventDestroy(ev1_);
@@ -391,42 +392,118 @@ Status Engine::decode_launch(const ZraDecodeArgs& a0, const uint32_t* dExpect, u
   if (wavesCap > 0) { perCUParse = std::min(perCUParse, wavesCap); perCUExec = std::min(perCUExec, wavesCap); }
   { static const int skip = std::getenv("ZRA_DEC_SKIP") ? std::atoi(std::getenv("ZRA_DEC_SKIP")) : 0; a.debugSkip = (uint32_t)skip; }
   HIPCHK(hipEventRecord(ev0_, stream_));
-  uint32_t nActive = n, round = 0;
-  const uint32_t* active = nullptr;
-  while (nActive) {
-    HIPCHK(hipMemsetAsync(a.counters, 0, ZRA_DC_WORDS * 4, stream_));
-    a.active = active; a.nActive = nActive; a.round = round;
-    a.nextActive = (active == listA) ? listB : listA;
-    const uint32_t gridParse = (uint32_t)std::min<uint64_t>(nActive, (uint64_t)numCUs_ * perCUParse);
-    // resident waves per CU of the chain kernel (lane = frame: 64 frames' tables per wave). Fewer frames in flight keep more of their
-    // table cells in the caches; A/B on one box, round 3 (parse / Huffman / execute stages already at their new occupancy): 8 GiB decode,
-    // chain stage 2 / 3 / 4 / 6 / 8 waves per CU -> 26.0 / 26.6 / 30.1 / 35.2 / 32.9 ms; 16 GiB, 1 / 1.5 / 2 / 2.5: 74.1 / 58.2 / 51.9 / 53.0 ms
-    static const uint32_t chainWaves = std::getenv("ZRA_DEC_CHAIN_WAVES") ? (uint32_t)std::atoi(std::getenv("ZRA_DEC_CHAIN_WAVES")) : 2u;
-    static const uint32_t chainGrid = std::getenv("ZRA_DEC_CHAIN_GRID") ? (uint32_t)std::atoi(std::getenv("ZRA_DEC_CHAIN_GRID")) : 0u;        // bring-up: absolute wave count
-    const uint32_t gridChain = (uint32_t)std::min<uint64_t>((nActive + 63) / 64, chainGrid ? chainGrid : (uint64_t)numCUs_ * chainWaves);
-    const uint32_t gridExec = (uint32_t)std::min<uint64_t>(nActive, (uint64_t)numCUs_ * perCUExec);
-    // per-stage spans (HIP events on the engine's stream; summed into dstats_ once the round has synchronised)
-    hipEvent_t se[5];
-    for (auto& e : se) { e = stage_event(); if (!e) return zerr(1); }
-    HIPCHK(hipEventRecord(se[0], stream_));
-    hipLaunchKernelGGL(zra_dec_parse_kernel, dim3(gridParse), dim3(64), 0, stream_, a);
-    HIPCHK(hipEventRecord(se[1], stream_));
-    hipLaunchKernelGGL(zra_dec_huf_kernel, dim3((uint32_t)std::min<uint64_t>((nActive + ZRA_HUF_FRAMES - 1) / ZRA_HUF_FRAMES, (uint64_t)numCUs_ * decOccHuf_)), dim3(64), 0, stream_, a);
-    HIPCHK(hipEventRecord(se[2], stream_));
-    hipLaunchKernelGGL(zra_dec_chain_kernel, dim3(gridChain), dim3(64), 0, stream_, a);
-    HIPCHK(hipEventRecord(se[3], stream_));
-    hipLaunchKernelGGL(zra_dec_exec_kernel, dim3(gridExec), dim3(64), 0, stream_, a);
-    HIPCHK(hipEventRecord(se[4], stream_));
-    uint32_t next = 0;
-    HIPCHK(hipMemcpyAsync(&next, a.counters + ZRA_DC_NNEXT, 4, hipMemcpyDeviceToHost, stream_));
-    HIPCHK(hipStreamSynchronize(stream_));
-    HIPCHK(hipGetLastError());
-    for (int k = 0; k < 4; k++) { float m = 0; if (hipEventElapsedTime(&m, se[k], se[k + 1]) == hipSuccess) dstats_[k] += m; }
-    dstats_[4] += 1;
-    stageEvNext_ = 0;
-    active = a.nextActive; nActive = next; round++;
-    if (round > (1u << 20)) return zerr(1);          // cannot happen: every round finishes at least one block of some frame
+  static const uint32_t chainWaves = std::getenv("ZRA_DEC_CHAIN_WAVES") ? (uint32_t)std::atoi(std::getenv("ZRA_DEC_CHAIN_WAVES")) : 2u;
+  static const uint32_t chainGrid = std::getenv("ZRA_DEC_CHAIN_GRID") ? (uint32_t)std::atoi(std::getenv("ZRA_DEC_CHAIN_GRID")) : 0u;        // bring-up: absolute wave count
+  // the rounds of one set of jobs, one stage after the other on the engine's stream (resident waves per CU of the chain kernel — lane =
+  // frame, 64 frames' tables per wave: fewer frames in flight keep more of their table cells in the caches; A/B on one box, round 3,
+  // 8 GiB decode, chain stage 2 / 3 / 4 / 6 / 8 waves per CU -> 26.0 / 26.6 / 30.1 / 35.2 / 32.9 ms; 16 GiB, 1 / 1.5 / 2 / 2.5: 74.1 / 58.2 / 51.9 / 53.0 ms)
+  auto run_rounds = [&](ZraDecodeArgs& x, uint32_t nActive, const uint32_t* active, uint32_t round, uint32_t* lA, uint32_t* lB) -> Status {
+    while (nActive) {
+      HIPCHK(hipMemsetAsync(x.counters, 0, ZRA_DC_WORDS * 4, stream_));
+      x.active = active; x.nActive = nActive; x.round = round;
+      x.nextActive = (active == lA) ? lB : lA;
+      const uint32_t gridParse = (uint32_t)std::min<uint64_t>(nActive, (uint64_t)numCUs_ * perCUParse);
+      const uint32_t gridChain = (uint32_t)std::min<uint64_t>((nActive + 63) / 64, chainGrid ? chainGrid : (uint64_t)numCUs_ * chainWaves);
+      const uint32_t gridExec = (uint32_t)std::min<uint64_t>(nActive, (uint64_t)numCUs_ * perCUExec);
+      // per-stage spans (HIP events on the engine's stream; summed into dstats_ once the round has synchronised)
+      hipEvent_t se[5];
+      for (auto& e : se) { e = stage_event(); if (!e) return zerr(1); }
+      HIPCHK(hipEventRecord(se[0], stream_));
+      hipLaunchKernelGGL(zra_dec_parse_kernel, dim3(gridParse), dim3(64), 0, stream_, x);
+      HIPCHK(hipEventRecord(se[1], stream_));
+      hipLaunchKernelGGL(zra_dec_huf_kernel, dim3((uint32_t)std::min<uint64_t>((nActive + ZRA_HUF_FRAMES - 1) / ZRA_HUF_FRAMES, (uint64_t)numCUs_ * decOccHuf_)), dim3(64), 0, stream_, x);
+      HIPCHK(hipEventRecord(se[2], stream_));
+      hipLaunchKernelGGL(zra_dec_chain_kernel, dim3(gridChain), dim3(64), 0, stream_, x);
+      HIPCHK(hipEventRecord(se[3], stream_));
+      hipLaunchKernelGGL(zra_dec_exec_kernel, dim3(gridExec), dim3(64), 0, stream_, x);
+      HIPCHK(hipEventRecord(se[4], stream_));
+      uint32_t next = 0;
+      HIPCHK(hipMemcpyAsync(&next, x.counters + ZRA_DC_NNEXT, 4, hipMemcpyDeviceToHost, stream_));
+      HIPCHK(hipStreamSynchronize(stream_));
+      HIPCHK(hipGetLastError());
+      for (int k = 0; k < 4; k++) { float m = 0; if (hipEventElapsedTime(&m, se[k], se[k + 1]) == hipSuccess) dstats_[k] += m; }
+      dstats_[4] += 1;
+      stageEvNext_ = 0;
+      active = x.nextActive; nActive = next; round++;
+      if (round > (1u << 20)) return zerr(1);          // cannot happen: every round finishes at least one block of some frame
+    }
+    return ok();
+  };
+  // Stage pipeline (round 3, opt-in: ZRA_DEC_PIPE=K). With the jobs cut into K slices, slice k's parse, Huffman + chain, and execute
+  // kernels run on four streams with grids that leave room for each other, so that slice k executes while slice k+1 decodes its literals
+  // and chains and slice k+2 parses. Same kernels, same per-job results; only the first block round is pipelined (frames with more blocks
+  // finish slice by slice in the classic way afterwards). Measured, 8 GiB decode on one box: off 105 GiB/s, K = 4 / 8 / 16: 108 / 96 / 66 —
+  // the stages do not hide each other (they queue on the same request path), and slices below one chain grid (32 Ki frames) starve
+  // the lane-per-frame chain kernel. Not the default.
+  static const uint32_t pipeK = std::getenv("ZRA_DEC_PIPE") ? (uint32_t)std::atoi(std::getenv("ZRA_DEC_PIPE")) : 0u;
+  static const uint32_t pipeMin = std::getenv("ZRA_DEC_PIPE_MIN") ? (uint32_t)std::atoi(std::getenv("ZRA_DEC_PIPE_MIN")) : 16384u;
+  bool piped = false;
+  if (pipeK >= 2 && n >= pipeMin && n >= pipeK * 1024u) {
+    if (!pipeStreams_[0]) for (auto& st : pipeStreams_) if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { st = nullptr; }
+    if (pipeStreams_[0] && pipeStreams_[1] && pipeStreams_[2] && decCounters_.reserve((size_t)(pipeK + 1) * ZRA_DC_WORDS * 4 + 64)) {
+      piped = true;
+      a.counters = decCounters_.as<uint32_t>();
+      static const uint32_t wP = std::getenv("ZRA_DEC_PIPE_PARSE") ? (uint32_t)std::atoi(std::getenv("ZRA_DEC_PIPE_PARSE")) : 8u;
+      static const uint32_t wH = std::getenv("ZRA_DEC_PIPE_HUF") ? (uint32_t)std::atoi(std::getenv("ZRA_DEC_PIPE_HUF")) : 8u;
+      static const uint32_t wX = std::getenv("ZRA_DEC_PIPE_EXEC") ? (uint32_t)std::atoi(std::getenv("ZRA_DEC_PIPE_EXEC")) : 12u;
+      const uint32_t B = ((n + pipeK - 1) / pipeK + 63u) & ~63u;
+      const uint32_t K = (n + B - 1) / B;
+      hipStream_t sP = stream_, sH = pipeStreams_[0], sC = pipeStreams_[1], sX = pipeStreams_[2];
+      HIPCHK(hipMemsetAsync(a.counters, 0, (size_t)(K + 1) * ZRA_DC_WORDS * 4, stream_));
+      hipEvent_t e0 = stage_event(); if (!e0) return zerr(1);
+      HIPCHK(hipEventRecord(e0, stream_));
+      HIPCHK(hipStreamWaitEvent(sH, e0, 0)); HIPCHK(hipStreamWaitEvent(sC, e0, 0)); HIPCHK(hipStreamWaitEvent(sX, e0, 0));
+      std::vector<ZraDecodeArgs> sub(K);
+      hipEvent_t eX = nullptr;
+      for (uint32_t k = 0; k < K; k++) {
+        const uint32_t j0 = k * B, nb = std::min(B, n - j0);
+        ZraDecodeArgs x = a;
+        x.nFrames = nb;
+        x.frameOff = a.frameOff + (size_t)j0 * a.offStride; x.outOff = a.outOff + j0; x.outCap = a.outCap + j0;
+        if (a.limit) x.limit = a.limit + j0;
+        if (a.pieceBase) x.pieceBase = a.pieceBase + j0;
+        x.frames = a.frames + j0; x.tables = a.tables + (size_t)j0 * ZRA_DEC_TBL_WORDS;
+        x.status = a.status + j0; x.produced = a.produced + j0; x.frameMeta = a.frameMeta + 2 * (size_t)j0;
+        x.pending = a.pending + j0; x.hufJobs = a.hufJobs + j0;
+        x.counters = a.counters + (size_t)(k + 1) * ZRA_DC_WORDS;
+        const uint64_t litShare = (a.litCap / K) & ~255ull;
+        x.lits = a.lits + litShare * k; x.litCap = litShare;
+        x.seqs = a.seqs + (a.seqCap / K) * k; x.seqCap = a.seqCap / K;
+        x.active = nullptr; x.nActive = nb; x.round = 0; x.nextActive = listA + j0;
+        sub[k] = x;
+        hipEvent_t eP = stage_event(), eH = stage_event(), eC = stage_event(); eX = stage_event();
+        if (!eP || !eH || !eC || !eX) return zerr(1);
+        hipLaunchKernelGGL(zra_dec_parse_kernel, dim3((uint32_t)std::min<uint64_t>(nb, (uint64_t)numCUs_ * wP)), dim3(64), 0, sP, x);
+        HIPCHK(hipEventRecord(eP, sP));
+        HIPCHK(hipStreamWaitEvent(sH, eP, 0));
+        hipLaunchKernelGGL(zra_dec_huf_kernel, dim3((uint32_t)std::min<uint64_t>((nb + ZRA_HUF_FRAMES - 1) / ZRA_HUF_FRAMES, (uint64_t)numCUs_ * wH)), dim3(64), 0, sH, x);
+        HIPCHK(hipEventRecord(eH, sH));
+        HIPCHK(hipStreamWaitEvent(sC, eP, 0));
+        hipLaunchKernelGGL(zra_dec_chain_kernel, dim3((uint32_t)std::min<uint64_t>((nb + 63) / 64, chainGrid ? chainGrid : (uint64_t)numCUs_ * chainWaves)), dim3(64), 0, sC, x);
+        HIPCHK(hipEventRecord(eC, sC));
+        HIPCHK(hipStreamWaitEvent(sX, eH, 0)); HIPCHK(hipStreamWaitEvent(sX, eC, 0));
+        hipLaunchKernelGGL(zra_dec_exec_kernel, dim3((uint32_t)std::min<uint64_t>(nb, (uint64_t)numCUs_ * wX)), dim3(64), 0, sX, x);
+        HIPCHK(hipEventRecord(eX, sX));
+      }
+      // everything of the first round is behind the last execute kernel (stream order + its waits); the engine's stream takes over
+      HIPCHK(hipStreamWaitEvent(stream_, eX, 0));
+      std::vector<uint32_t> hc((size_t)(K + 1) * ZRA_DC_WORDS);
+      HIPCHK(hipMemcpyAsync(hc.data(), a.counters, hc.size() * 4, hipMemcpyDeviceToHost, stream_));
+      HIPCHK(hipStreamSynchronize(stream_));
+      HIPCHK(hipGetLastError());
+      dstats_[4] += 1; dstats_[7] += 1;
+      stageEvNext_ = 0;
+      // frames that go on (more blocks, or no scratch in their slice's share): slice by slice, the classic rounds
+      for (uint32_t k = 0; k < K; k++) {
+        const uint32_t next = hc[(size_t)(k + 1) * ZRA_DC_WORDS + ZRA_DC_NNEXT];
+        if (!next) continue;
+        const uint32_t j0 = k * B;
+        Status st = run_rounds(sub[k], next, listA + j0, 1, listA + j0, listB + j0);
+        if (st.zra) return st;
+      }
+    }
   }
+  if (!piped) { Status st = run_rounds(a, n, nullptr, 0, listA, listB); if (st.zra) return st; }
   HIPCHK(hipEventRecord(ev1_, stream_));
   const uint32_t tb = 256;
   hipLaunchKernelGGL(zra_xxh64_verify_kernel, dim3((n * 4 + tb - 1) / tb), dim3(tb), 0, stream_, a.out, a.outOff, dExpect,
