@@ -10,7 +10,7 @@ d_arc = torch.empty(Z.GetOutputBufferSize(N, fs) + 64, dtype=torch.uint8, device
 n1 = eng.compress(d_in.data_ptr(), N, d_arc.data_ptr(), 3, fs, True)
 lib = ctypes.CDLL(Z.LIB_PATH)
 rng = np.random.RandomState(7)
-buf = (ctypes.c_ulonglong * 16)()
+buf = (ctypes.c_ulonglong * 64)()
 for bs in (1, 64):
     d_o = torch.empty(bs * qb + 64, dtype=torch.uint8, device=dev)
     sizes = np.full(bs, qb, dtype=np.uint64); oo = np.arange(bs, dtype=np.uint64) * qb
@@ -26,4 +26,6 @@ for bs in (1, 64):
     if hasattr(lib, "ZraHipDebugReadSmallProfile"):
         lib.ZraHipDebugReadSmallProfile(buf, 0); v = list(buf); nj = max(v[4], 1)
         print("  parse, cycles per job: to the literals header %.0f  literals header + tree %.0f  sequences header %.0f  table descriptions %.0f  table builds %.0f  hand-over %.0f" % tuple(v[k] / nj for k in (8, 9, 10, 11, 12, 13)))
+        print("  wave-wide Huffman: done %d, handed to the serial decoders %d (reached the checks %d, not converged %d)" % (v[14], v[15], v[6], v[7]))
+        print("  wave-wide Huffman: lanes restarted after pass 1..6 (per job): %s" % " ".join("%.1f" % (v[16 + k] / nj) for k in range(6)))
         print("  jobs %d; cycles per job: parse %.0f  huffman %.0f  chain producer %.0f  chain consumer %.0f  execute %.0f" % (nj, v[0] / nj, v[1] / nj, v[2] / nj, v[5] / nj, v[3] / nj))

@@ -57,10 +57,10 @@ __device__ __forceinline__ u32 mk_cell(u32 sym, u32 addBits, u32 nbBits, u32 nex
 
 #ifdef ZRA_SMALL_PROFILE
 // bring-up (never in the shipped library): s_memtime sums per stage of zra_ra_small_kernel: parse, Huffman (wave 1), chain (wave 0), execute, jobs
-__device__ unsigned long long zra_small_prof[16];
+__device__ unsigned long long zra_small_prof[64];
 extern "C" __attribute__((visibility("default"))) void ZraHipDebugReadSmallProfile(unsigned long long* out16, int reset) {
-  (void)hipMemcpyFromSymbol(out16, HIP_SYMBOL(zra_small_prof), sizeof(unsigned long long) * 16);
-  if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(zra_small_prof), z, sizeof(z)); }
+  (void)hipMemcpyFromSymbol(out16, HIP_SYMBOL(zra_small_prof), sizeof(unsigned long long) * 64);
+  if (reset) { unsigned long long z[64] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(zra_small_prof), z, sizeof(z)); }
 }
 #define SPROF(k) { __builtin_amdgcn_s_waitcnt(0); const u64 n_ = __builtin_amdgcn_s_memtime(); if (lane == 0) atomicAdd(&zra_small_prof[k], n_ - spt_); spt_ = n_; }
 #define SPROF_T0 u64 spt_ = __builtin_amdgcn_s_memtime();
@@ -98,6 +98,7 @@ struct __attribute__((aligned(16))) ParseShared {
   u32 blkType, blkSize, blkLast, blkPos, hdrPos, frameEnd, winPos, winLen;
   u32 litType, litRegen, litComp, litHdr, litStreams, litRle;
   u32 hufValid, hufMaxBits, hufNSym, hufX2;
+  u32 hufNw, hufUsed, hufPhase;   // a tree description read by lane 0 (weights[0..hufNw)), waiting for the wave-wide part
   u32 nbSeq, seqPos, seqModes;
   u32 llLog, mlLog, ofLog, llValid, mlValid, ofValid, ofShare;
   u32 rep[3];
@@ -330,6 +331,7 @@ __device__ __forceinline__ void copy_periodic_le64(u8* dp, const u8* sp, u32 n, 
 // 32-bit arithmetic that only comes out right while it stays in the LDS address space — a real call takes them as flat pointers.)
 // Check order of ZSTD_decodeLiteralsBlock (zstd_decompress_block.c of 1.4.9).
 __device__ __forceinline__ void parse_literals_header(ParseShared& S, const u8* src, u32 n, const u8* lim) {
+  S.hufPhase = 0;
   if (n < 3) { S.err = ZE_CORRUPTION; return; }                       // MIN_CBLOCK_SIZE
   u32 b0 = src[0], type = b0 & 3, sf = (b0 >> 2) & 3;
   S.litType = type;
@@ -399,37 +401,86 @@ __device__ __forceinline__ void parse_literals_header(ParseShared& S, const u8* 
         if (br.pos < 0) { S.weights[nw++] = (u8)wt[s1]; break; }
       }
     }
-    u32 total = 0;
-    for (u32 i = 0; i < nw; i++) { u32 w = S.weights[i]; if (w > 11) { S.err = ZE_CORRUPTION; return; } total += (1u << w) >> 1; }
-    if (total == 0) { S.err = ZE_CORRUPTION; return; }
-    u32 maxBits = hb32(total) + 1;
-    if (maxBits > 12) { S.err = ZE_CORRUPTION; return; }               // HUF_TABLELOG_MAX of libzstd (the format says 11)
-    u32 rest = (1u << maxBits) - total;
-    if (rest == 0 || (rest & (rest - 1))) { S.err = ZE_CORRUPTION; return; }
-    S.weights[nw] = (u8)(hb32(rest) + 1);
+    S.hufNw = nw; S.hufUsed = used; S.hufPhase = 1;
+  }
+}
+
+// The rest of HUF_readStats / HUF_readDTableX1 for a tree description lane 0 has read (S.weights[0..hufNw)), by the whole wave: the
+// implied last weight, the per-weight counts and the first decode-table cell of every symbol (cells ordered by weight, then by symbol).
+// Every rejection here is corruption_detected, so their order does not matter.
+__device__ __forceinline__ void huf_tree_finish(ParseShared& S, const int lane) {
+  const u32 nw = S.hufNw;
+  const u64 lt = (1ull << lane) - 1ull;
+  u32 wv[4];
+  u32 part = 0; bool over = false;
+#pragma unroll
+  for (int c = 0; c < 4; c++) {
+    const u32 i = 64u * c + (u32)lane;
+    wv[c] = i < nw ? (u32)S.weights[i] : 0u;
+    over |= wv[c] > 11;
+    part += (1u << wv[c]) >> 1;
+  }
+  const u32 total = bcast_u32(dpp_scan_add(part), 63);
+  bool bad = __ballot(over) != 0 || total == 0;
+  const u32 maxBits = bad ? 1u : hb32(total) + 1;
+  bad |= maxBits > 12;                                                // HUF_TABLELOG_MAX of libzstd (the format says 11)
+  const u32 rest = (1u << (maxBits & 31)) - total;
+  bad |= rest == 0 || (rest & (rest - 1));
+  if (bad) { if (lane == 0) S.err = ZE_CORRUPTION; return; }
+  const u32 lastW = hb32(rest) + 1;
+#pragma unroll
+  for (int c = 0; c < 4; c++) if (64u * c + (u32)lane == nw) wv[c] = lastW;       // (nw <= 255: the implied symbol has a slot)
+  // counts per weight -> first cell of every weight
+  u32 start[13];
+#pragma unroll
+  for (int w = 1; w <= 12; w++) {
+    u32 n = 0;
+#pragma unroll
+    for (int c = 0; c < 4; c++) n += (u32)__popcll(__ballot(wv[c] == (u32)w));
+    start[w] = n;
+  }
+  bad = start[1] < 2;                                                 // HUF_readStats: "at least 2 elts of rank 1"
+  u32 acc = 0;
+#pragma unroll
+  for (int w = 1; w <= 12; w++) { const u32 n = start[w]; start[w] = acc; acc += n << (w - 1); }
+  bad |= acc != (1u << maxBits);
+  bad |= S.hufUsed >= S.litComp;                                      // "hSize >= cSrcSize"
+  if (bad) { if (lane == 0) S.err = ZE_CORRUPTION; return; }
+#pragma unroll
+  for (int c = 0; c < 4; c++) {
+    u32 hs = 0;
+#pragma unroll
+    for (int w = 1; w <= 12; w++) {
+      const u64 m = __ballot(wv[c] == (u32)w);
+      if (wv[c] == (u32)w) hs = start[w] + ((u32)__popcll(m & lt) << (w - 1));
+      start[w] += (u32)__popcll(m) << (w - 1);
+    }
+    const u32 i = 64u * c + (u32)lane;
+    if (i <= nw) S.hufStart[i] = (u16)hs;
+  }
+  if (lane == 0) {
+    S.weights[nw] = (u8)lastW;
     S.hufNSym = nw + 1; S.hufMaxBits = maxBits;
-    // counts per weight, then turned in place into start cells (kept in LDS: a dynamically indexed local array would live in scratch)
-    for (u32 w = 0; w <= 12; w++) S.rankStart[w] = 0;
-    for (u32 i = 0; i <= nw; i++) S.rankStart[S.weights[i]]++;
-    if (S.rankStart[1] < 2) { S.err = ZE_CORRUPTION; return; }         // HUF_readStats: "at least 2 elts of rank 1"
-    u32 acc = 0;
-    for (u32 w = 1; w <= maxBits; w++) { const u32 c = S.rankStart[w]; S.rankStart[w] = acc; acc += c << (w - 1); }
-    if (acc != (1u << maxBits)) { S.err = ZE_CORRUPTION; return; }
-    if (used >= rem) { S.err = ZE_CORRUPTION; return; }                // "hSize >= cSrcSize"
-    // first decode-table cell of every symbol: cells are ordered by weight, then by symbol (the Huffman kernel fills from this)
-    for (u32 i = 0; i <= nw; i++) { const u32 w = S.weights[i]; if (w) { S.hufStart[i] = (u16)S.rankStart[w]; S.rankStart[w] += 1u << (w - 1); } else S.hufStart[i] = 0; }
     S.hufValid = 2;   // 2 = a new tree (its description goes to the frame record)
     // which of libzstd's two decoders reads this table (they accept different DAMAGED streams): one stream -> single-symbol;
     // four streams -> HUF_selectDecoder(regenerated size, compressed size incl. the tree); treeless blocks keep the table's kind
-    if (streams == 4) {
+    const u32 regen = S.litRegen, comp = S.litComp;
+    if (S.litStreams == 4) {
       const u32 Q = comp >= regen ? 15u : (comp * 16u / regen), D256 = regen >> 8;
       const u32 d0 = c_huf_t0[Q][0] + c_huf_t0[Q][1] * D256;
       u32 d1 = c_huf_t1[Q][0] + c_huf_t1[Q][1] * D256;
       d1 += d1 >> 3;
       S.hufX2 = d1 < d0;
     } else S.hufX2 = 0;
-    p += used; rem -= used;
   }
+}
+
+// where the literal streams of a Huffman-coded section lie (lane 0, after the tree)
+__device__ __forceinline__ void literal_streams_layout(ParseShared& S, const u8* src) {
+  const u32 type = S.litType, regen = S.litRegen, streams = S.litStreams;
+  const u32 used = type == 2 ? S.hufUsed : 0u;
+  const u8* const p = src + S.litHdr + used;
+  const u32 rem = S.litComp - used;
   // stream layout
   u32 base = (u32)(p - src);
   if (streams == 1) { S.streamOff[0] = base; S.streamLen[0] = rem; }
@@ -683,6 +734,12 @@ __device__ __forceinline__ u32 parse_job(const ZraDecodeArgs& a, const u32 j, Pa
       if (lane == 0) {
         S.litStreams = 1; S.litRle = 0; S.alloc = 1; S.lateErr = 0; S.nbSeq = 0;
         parse_literals_header(S, win + bpos, bsize, S.w0 + STAGE_BYTES + 8);
+      }
+      wsync();
+      if (!S.err && S.hufPhase) huf_tree_finish(S, lane);
+      wsync();
+      if (lane == 0) {
+        if (!S.err && S.litType >= 2) literal_streams_layout(S, win + bpos);
         if (!S.err) {
           // literal scratch of this round (Huffman-coded literals only: raw ones are read in place, RLE ones are a byte)
           if (S.litType >= 2) {
@@ -921,6 +978,41 @@ __device__ __forceinline__ void huf_build_table(const ZraDecFrame* const F, u16*
     }
   }
 }
+// `count` symbols of a stream through the single-symbol table (maxBits < 12), the reader standing on the first of them:
+// 16 symbols per store (write requests are the expensive ones), 4 symbols per window reload (4*11 = 44 <= 56 guaranteed bits)
+template <typename Reader>
+__device__ __forceinline__ void huf_x1_emit(Reader& hb, const u16* const tab, const int mb, u8* const o, const u32 count) {
+  u32 i = 0;
+  for (; i + 16 <= count; i += 16) {
+    u32 pk[4];
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+      hb.ensure(4 * mb);
+      u32 packed = 0;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        u32 e = tab[hb.peek(mb)];
+        packed |= (e & 0xFF) << (8 * k);
+        hb.skip((int)(e >> 8));
+      }
+      pk[g] = packed;
+    }
+    st128(o + i, pk[0], pk[1], pk[2], pk[3]);
+  }
+  for (; i + 4 <= count; i += 4) {
+    hb.ensure(4 * mb);
+    u32 packed = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      u32 e = tab[hb.peek(mb)];
+      packed |= (e & 0xFF) << (8 * k);
+      hb.skip((int)(e >> 8));
+    }
+    st32(o + i, packed);
+  }
+  for (; i < count; i++) { hb.ensure(mb); u32 e = tab[hb.peek(mb)]; o[i] = (u8)e; hb.skip((int)(e >> 8)); }
+}
+
 // one literal stream of frame job j by ONE lane (strm < F->litStreams); returns false when libzstd would reject the stream.
 // stopAt: symbols of this stream that are needed (random access that stops early: the rest is not decoded; only without X2 fall-back)
 __device__ __forceinline__ bool huf_decode_stream(const ZraDecodeArgs& a, ZraDecFrame* const F, const u32 j, const u16* const tab, const u8* const w1,
@@ -944,35 +1036,8 @@ __device__ __forceinline__ bool huf_decode_stream(const ZraDecodeArgs& a, ZraDec
   if (!bad) {
     u32 i = 0;
     if (mb < 12) {
-      // 16 symbols per store (write requests are the expensive ones), 4 symbols per window reload (4*11 = 44 <= 56 guaranteed bits)
-      for (; i + 16 <= myLen; i += 16) {
-        u32 pk[4];
-#pragma unroll
-        for (int g = 0; g < 4; g++) {
-          hb.ensure(4 * mb);
-          u32 packed = 0;
-#pragma unroll
-          for (int k = 0; k < 4; k++) {
-            u32 e = tab[hb.peek(mb)];
-            packed |= (e & 0xFF) << (8 * k);
-            hb.skip((int)(e >> 8));
-          }
-          pk[g] = packed;
-        }
-        st128(o + i, pk[0], pk[1], pk[2], pk[3]);
-      }
-      for (; i + 4 <= myLen; i += 4) {
-        hb.ensure(4 * mb);
-        u32 packed = 0;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-          u32 e = tab[hb.peek(mb)];
-          packed |= (e & 0xFF) << (8 * k);
-          hb.skip((int)(e >> 8));
-        }
-        st32(o + i, packed);
-      }
-      for (; i < myLen; i++) { hb.ensure(mb); u32 e = tab[hb.peek(mb)]; o[i] = (u8)e; hb.skip((int)(e >> 8)); }
+      huf_x1_emit(hb, tab, mb, o, myLen);
+      i = myLen;
     } else {
       for (; i < myLen; i++) { hb.ensure(12); const u32 e = huf_lookup12(tab, w1, hb.peek(12), 12); o[i] = (u8)e; hb.skip((int)(e >> 8)); }
     }
@@ -981,6 +1046,73 @@ __device__ __forceinline__ bool huf_decode_stream(const ZraDecodeArgs& a, ZraDec
   // a stream the single-symbol rules reject may still pass libzstd's double-symbol decoder, if that is the one it would use
   if (bad && F->hufX2) bad = !huf_stream_x2(tab, w1, (u32)mb, sb, sl, lim, o, myLen);
   return !bad;
+}
+
+// The literal streams of one frame by the WHOLE wave. A Huffman stream can only be decoded from its end, one code after the other — but
+// a decoder that starts in the middle of a stream falls into step with the real code boundaries after a few codes (self-synchronisation).
+// So every stream is cut into 16 runs of bits (a lone stream: 64), every lane decodes its run from a guessed start, counts the codes
+// and notes where the first code of the NEXT run starts; the lanes then restart from their predecessor's hand-over point until nobody's
+// start moves — lane 0 of a stream starts at the true end mark, so the fixed point is the real decode — and a last pass writes the
+// symbols at the prefix sums of the counts. Returns false unless every stream regenerates exactly its share and ends on bit 0: the
+// caller then runs the serial decoders, which decide what a damaged stream returns (what was written here is overwritten or unused).
+__device__ __forceinline__ bool huf_decode_wave(const ZraDecodeArgs& a, const ZraDecFrame* const F, const u32 j, const u16* const tab, const int lane, const u8* const lim) {
+  const u32 nStreams = F->litStreams, regen = F->litRegen;
+  const int mb = (int)F->hufMaxBits;
+  if (mb >= 12 || regen < 64) return false;
+  const u32 L = nStreams == 1 ? 64u : 16u;
+  const u32 strm = nStreams == 1 ? 0u : (u32)lane >> 4, t = (u32)lane & (L - 1);
+  const u32 seg = nStreams == 1 ? regen : (regen + 3) / 4;
+  const u32 myLen = nStreams == 1 ? regen : (strm < 3 ? seg : regen - 3 * seg);
+  const u8* const blk = a.body + a.frameOff[(size_t)j * a.offStride] + F->bpos;
+  const u8* const sb = blk + F->streamOff[strm]; const u32 sl = F->streamLen[strm];
+  const u32 last = sl ? (u32)sb[sl - 1] : 0u;
+  if (__ballot(last == 0)) return false;
+  const u32 P = (sl - 1) * 8 + hb32(last);                            // unread bits under the end mark
+  const u32 C = max((P + L - 1) / L, 128u);                           // bits per run
+  const bool active = t * C < P;
+  const i32 lower = (t + 1) * C >= P ? 0 : (i32)(P - (t + 1) * C);    // codes that START above this bit are the lane's
+  i32 start = (i32)(P - t * C), end = 0;
+  u32 n = 0;
+  bool dirty = active;
+  BitRS hb;
+  for (int it = 0; it < 6 && __ballot(dirty); it++) {
+    if (dirty) {
+      hb.init_at(sb, lim, start); n = 0;
+      while (hb.pos > lower) {
+        hb.ensure(4 * mb);
+#pragma unroll
+        for (int k = 0; k < 4; k++) if (hb.pos > lower) { const u32 e = tab[hb.peek(mb)]; hb.skip((int)(e >> 8)); n++; }
+      }
+      end = hb.pos;
+    }
+    const i32 handed = (i32)__shfl_up(end, 1, 64);                   // (every lane takes part: a lane that sits out returns 0 to its reader)
+    const i32 ns = t == 0 ? (i32)P : handed;
+    dirty = active && ns != start;
+    start = ns;
+#ifdef ZRA_SMALL_PROFILE
+    { const u64 dm = __ballot(dirty); if (lane == 0) atomicAdd(&zra_small_prof[16 + it], (u64)__popcll(dm)); }
+#endif
+  }
+#ifdef ZRA_SMALL_PROFILE
+  if (lane == 0) atomicAdd(&zra_small_prof[6], 1ull);
+  if (__ballot(dirty) && lane == 0) atomicAdd(&zra_small_prof[7], 1ull);
+#endif
+  if (__ballot(dirty)) return false;
+  u32 incl = active ? n : 0u;
+  if (L == 64) incl = dpp_scan_add(incl);
+  else {
+    incl += (u32)__builtin_amdgcn_update_dpp(0, (int)incl, 0x111, 0xF, 0xF, true);
+    incl += (u32)__builtin_amdgcn_update_dpp(0, (int)incl, 0x112, 0xF, 0xF, true);
+    incl += (u32)__builtin_amdgcn_update_dpp(0, (int)incl, 0x114, 0xF, 0xF, true);
+    incl += (u32)__builtin_amdgcn_update_dpp(0, (int)incl, 0x118, 0xF, 0xF, true);
+  }
+  const u32 total = (u32)__shfl((int)incl, (int)(((u32)lane & ~(L - 1)) + L - 1), 64);
+  if (__ballot(total != myLen || (active && lower == 0 && end != 0))) return false;
+  if (active && n) {
+    hb.init_at(sb, lim, start);
+    huf_x1_emit(hb, tab, mb, a.lits + F->litBase + (size_t)strm * seg + (incl - n), n);
+  }
+  return true;
 }
 }  // namespace
 
@@ -1000,9 +1132,14 @@ zra_dec_huf_kernel(ZraDecodeArgs a) {
     // ---- the tables of this batch, one frame after the other, all lanes on each
     for (u32 s = 0; s < nHere; s++) huf_build_table(&a.frames[a.hufJobs[base + s]], S.tab[s], S.w1[s], lane);
     wsync();
-    // ---- the streams: lane -> (frame slot, stream)
+    // ---- all lanes on one frame after the other; what that leaves (damaged or unusual streams): lane -> (frame slot, stream)
+    u32 doneMask = 0;
+    for (u32 s = 0; s < nHere; s++) {
+      const u32 j = a.hufJobs[base + s];
+      if (huf_decode_wave(a, &a.frames[j], j, S.tab[s], lane, lim)) doneMask |= 1u << s;
+    }
     const u32 slot = (u32)lane >> 2, strm = (u32)lane & 3;
-    if (slot < nHere) {
+    if (slot < nHere && !((doneMask >> slot) & 1u)) {
       const u32 j = a.hufJobs[base + slot];
       ZraDecFrame* const F = &a.frames[j];
       if (strm < F->litStreams && !huf_decode_stream(a, F, j, S.tab[slot], S.w1[slot], strm, lim)) F->hufErr = 1;
@@ -1230,8 +1367,8 @@ __device__ unsigned long long zra_dec_prof[16];
 #define XCNT(k, v) { if (lane == 0) atomicAdd(&zra_dec_prof[k], (unsigned long long)(v)); }
 #define XTIME(k) { __builtin_amdgcn_s_waitcnt(0); const u64 n_ = __builtin_amdgcn_s_memtime(); if (lane == 0) atomicAdd(&zra_dec_prof[k], n_ - xpt_); xpt_ = n_; }
 extern "C" __attribute__((visibility("default"))) void ZraHipDebugReadDecProfile(unsigned long long* out16, int reset) {
-  (void)hipMemcpyFromSymbol(out16, HIP_SYMBOL(zra_dec_prof), sizeof(unsigned long long) * 16);
-  if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(zra_dec_prof), z, sizeof(z)); }
+  (void)hipMemcpyFromSymbol(out16, HIP_SYMBOL(zra_dec_prof), sizeof(unsigned long long) * 64);
+  if (reset) { unsigned long long z[64] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(zra_dec_prof), z, sizeof(z)); }
 }
 #else
 #define XCNT(k, v)
@@ -1610,7 +1747,12 @@ zra_ra_small_kernel(ZraDecodeArgs a0, u32* bail) {
       if (F->litKind == 2) {
         huf_build_table(F, S.hufTab, S.hufW1, lane);
         wsync();
-        if ((u32)lane < F->litStreams && !huf_decode_stream(a, F, j, S.hufTab, S.hufW1, (u32)lane, lim)) S.ctl[1] = 1;
+        const bool wide = huf_decode_wave(a, F, j, S.hufTab, lane, lim);
+#ifdef ZRA_SMALL_PROFILE
+        if (lane == 0) atomicAdd(&zra_small_prof[wide ? 14 : 15], 1ull);
+#endif
+        if (!wide)
+          if ((u32)lane < F->litStreams && !huf_decode_stream(a, F, j, S.hufTab, S.hufW1, (u32)lane, lim)) S.ctl[1] = 1;
       }
       SPROF(1)
     } else if (wave == 0) {

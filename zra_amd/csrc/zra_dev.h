@@ -140,6 +140,13 @@ struct BitRS {
     w = g0; wlo = gtop * 8;
     return 0;
   }
+  // the same reader, positioned on `p` unread bits of a stream whose bytes [b, ...) are readable up to bufLim
+  __device__ __forceinline__ void init_at(const u8* b, const u8* bufLim, i32 p) {
+    base = b; lim = bufLim; pos = p;
+    gtop = ((pos + 7) >> 3) - 8;
+    g0 = grid(gtop); g1 = grid(gtop - 8); g2 = grid(gtop - 16);
+    w = g0; wlo = gtop * 8;
+  }
   __device__ __forceinline__ void ensure(int nb) { if (pos - wlo < nb) reload(); }
   __device__ __forceinline__ u32 peek(int nb) const { return (u32)((w >> (pos - nb - wlo)) & ((1ull << nb) - 1)); }
   __device__ __forceinline__ void skip(int nb) { pos -= nb; }
