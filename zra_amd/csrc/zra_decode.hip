@@ -1376,117 +1376,131 @@ extern "C" __attribute__((visibility("default"))) void ZraHipDebugReadDecProfile
 #endif
 
 namespace {
-// one job (frame j, the block the chain stage left sequences for) by one wave. FUSED: a frame that goes on is not appended to the
-// next round's list; returns 1 when the frame has another block to go.
+// where a block's output and literals are, and how far its sequences have been executed (wave-uniform)
+struct ExecCtx {
+  u8* out; const u8* lit; u32 litKind; u8 rleByte;
+  u32 outBase, litBase;
+  const u8* src; u32 srcSize, produced0, regen;
+};
+__device__ __forceinline__ ExecCtx exec_begin(const ZraDecodeArgs& a, const u32 j, const ZraDecFrame* const F) {
+  ExecCtx c;
+  const size_t gj = j;
+  const u64 so = a.frameOff[gj * a.offStride], se = a.frameOff[gj * a.offStride + 1];
+  c.src = a.body + so; c.srcSize = (u32)(se - so);
+  c.produced0 = F->produced;
+  c.out = a.out + a.outOff[j] + c.produced0;                    // this block's output start
+  c.litKind = F->litKind; c.regen = F->litRegen;
+  c.lit = c.litKind == 2 ? a.lits + F->litBase : c.src + F->litArg;
+  c.rleByte = (u8)F->litArg;
+  c.outBase = 0; c.litBase = 0;
+  return c;
+}
+// up to 64 sequences, lane = sequence (act: the lane has one; oStart / lStart: where its literals go and come from)
+__device__ __forceinline__ void exec_step(const ExecCtx& c, ExecShared& S, const u32 ll, const u32 ml, const u32 off, const u32 oStart, const u32 lStart,
+                                          const bool act, const int lane, const u32 debugSkip) {
+  u8* const out = c.out; const u8* const lit = c.lit; const u32 litKind = c.litKind; const u8 rleByte = c.rleByte;
+  const u32 mdst = oStart + ll;
+  // -------- literal runs
+  {
+    u8* op = out + oStart;
+    const bool longLit = ll > 32;
+    if (!longLit && ll && !(debugSkip & 1)) {
+      if (litKind == 1) for (u32 b = 0; b < ll; b++) op[b] = rleByte;
+      else copy_le64(op, lit + lStart, ll);
+    }
+    u64 lm = (debugSkip & 8) ? 0ull : __ballot(longLit);
+    while (lm) {
+      const u32 k = (u32)__builtin_ctzll(lm); lm &= lm - 1;
+      const u32 jl = bcast_u32(ll, k), jo = bcast_u32(oStart, k), js = bcast_u32(lStart, k);
+      if (litKind == 1) fill_bytes(out + jo, rleByte, jl, lane, DEC_THREADS);
+      else copy_bytes(out + jo, lit + js, jl, lane, DEC_THREADS);
+    }
+  }
+  wsync();
+  // -------- the rest: dependency rounds — a lane is ready once its source ends before the first unfinished destination
+  {
+    const u32 msrc = mdst - off;
+    const u32 msrcEnd = min(msrc + ml, mdst);
+    u64 pending = __ballot(act);
+    while (pending) {
+      const u32 fnd = (u32)__builtin_ctzll(pending);
+      const u32 frontier = bcast_u32(mdst, fnd);
+      const bool mine = (pending >> lane) & 1;
+      const bool ready = mine && (msrcEnd <= frontier || (u32)lane == fnd);
+      const bool longM = ready && ml > 64;
+      if (ready && !longM && !(debugSkip & 2)) {
+        u8* dp = out + mdst; const u8* sp = dp - off;
+        if (off >= ml) copy_le64(dp, sp, ml);      // no overlap: all loads, then all stores
+        else copy_periodic_le64(dp, sp, ml, off, S.slot[lane]);  // overlapping match = period `off`: only the bytes in front of the destination are read
+      }
+      u64 lmk = __ballot(longM);
+      while (lmk) {                            // long matches: the whole wave copies (period-safe modular source)
+        const u32 k2 = (u32)__builtin_ctzll(lmk); lmk &= lmk - 1;
+        const u32 jml = bcast_u32(ml, k2), jd = bcast_u32(mdst, k2), jof = bcast_u32(off, k2);
+        u8* dp = out + jd; const u8* sp = dp - jof;
+        if (jof >= jml) { for (u32 k = lane; k < jml; k += WAVE) dp[k] = sp[k]; }
+        else { for (u32 k = lane; k < jml; k += WAVE) dp[k] = sp[k % jof]; }
+      }
+      pending &= ~__ballot(ready);
+      if (!(debugSkip & 4)) wsync();
+    }
+  }
+}
+// block tail (remaining literals: the chain stage checked the room) and commit: a compressed block confirms its repeat offsets; then
+// the frame ends, or takes another round. FUSED: a frame that goes on is not appended to the next round's list; returns 1 when it goes on.
+template <bool FUSED>
+__device__ __forceinline__ u32 exec_end(const ZraDecodeArgs& a, const u32 j, ZraDecFrame* const F, const ExecCtx& c, const int lane) {
+  u32 more = 0;
+  const u32 chainErr = F->chainErr, truncated = F->truncated;
+  u32 blockOut = c.outBase;
+  if (!chainErr && !truncated) {
+    const u32 tail = c.regen - c.litBase;
+    if (c.litKind == 1) fill_bytes(c.out + c.outBase, c.rleByte, tail, lane, DEC_THREADS);
+    else copy_bytes(c.out + c.outBase, c.lit + c.litBase, tail, lane, DEC_THREADS);
+    blockOut += tail;
+  }
+  wsync();
+  const u32 produced = c.produced0 + blockOut, endPos = F->bpos + F->bsize;
+  if (chainErr || truncated || F->blast) {
+    frame_finish(a, j, c.src, c.srcSize, chainErr, produced, endPos, truncated != 0, F->fcsHave, F->fcsLo, F->fcsHi, F->hasChecksum, lane);
+  } else {
+    more = 1;
+    if (lane == 0) {
+      F->produced = produced; F->blkPos = endPos;
+      F->rep[0] = F->repOut[0]; F->rep[1] = F->repOut[1]; F->rep[2] = F->repOut[2];
+      if (!FUSED) a.nextActive[atomicAdd(&a.counters[ZRA_DC_NNEXT], 1u)] = j;
+    }
+  }
+  wsync();
+  return more;
+}
+
+// one job (frame j, the block the chain stage left sequences for) by one wave
 template <bool FUSED>
 __device__ __forceinline__ u32 exec_job(const ZraDecodeArgs& a, const u32 j, ExecShared& S, const int lane) {
-  u32 more = 0;
-  {
-    const size_t gj = j;
-    ZraDecFrame* const F = &a.frames[j];
-    const u64 so = a.frameOff[gj * a.offStride], se = a.frameOff[gj * a.offStride + 1];
-    const u8* const src = a.body + so;
-    const u32 srcSize = (u32)(se - so);
-    const u32 produced0 = F->produced;
-    u8* const out = a.out + a.outOff[j] + produced0;             // this block's output start
-    const u32 litKind = F->litKind, regen = F->litRegen;
-    const u8* const lit = litKind == 2 ? a.lits + F->litBase : src + F->litArg;
-    const u8 rleByte = (u8)F->litArg;
-    const u32 nSeq = F->nSeqValid, chainErr = F->chainErr, truncated = F->truncated;
-    const u64* const sq = a.seqs + F->seqBase;
-
-    u32 outBase = 0, litBase = 0;              // running positions (wave-uniform)
+  ZraDecFrame* const F = &a.frames[j];
+  ExecCtx c = exec_begin(a, j, F);
+  const u32 nSeq = F->nSeqValid;
+  const u64* const sq = a.seqs + F->seqBase;
 #ifdef ZRA_DEC_PROFILE
-    u64 xpt_ = __builtin_amdgcn_s_memtime();
+  u64 xpt_ = __builtin_amdgcn_s_memtime();
 #endif
-    XCNT(8, 1)
-    u64 qNext = (u32)lane < nSeq ? sq[lane] : (1ull << 36);        // the next step's sequences are always in flight
-    for (u32 first = 0; first < nSeq; first += BATCH) {
-      const u32 cnt = min((u32)BATCH, nSeq - first);
-      const bool act = (u32)lane < cnt;
-      const u64 q = qNext;
-      qNext = first + BATCH + (u32)lane < nSeq ? sq[first + BATCH + lane] : (1ull << 36);
-      const u32 ll = (u32)q & 0x3FFFFu, ml = (u32)(q >> 18) & 0x3FFFFu, off = (u32)(q >> 36);
-      const u32 tot = ll + ml;
-      const u32 incT = wave_incl_scan(tot), incL = wave_incl_scan(ll);
-      const u32 oStart = outBase + incT - tot, lStart = litBase + incL - ll;
-      const u32 mdst = oStart + ll;
-      const u32 stepEnd = outBase + bcast_u32(incT, 63);
-      XTIME(0) XCNT(9, 1) XCNT(10, cnt)
-      // -------- literal runs
-      {
-        u8* op = out + oStart;
-        const bool longLit = ll > 32;
-        if (!longLit && ll && !(a.debugSkip & 1)) {
-          if (litKind == 1) for (u32 b = 0; b < ll; b++) op[b] = rleByte;
-          else copy_le64(op, lit + lStart, ll);
-        }
-        u64 lm = (a.debugSkip & 8) ? 0ull : __ballot(longLit);
-        while (lm) {
-          const u32 k = (u32)__builtin_ctzll(lm); lm &= lm - 1;
-          const u32 jl = bcast_u32(ll, k), jo = bcast_u32(oStart, k), js = bcast_u32(lStart, k);
-          if (litKind == 1) fill_bytes(out + jo, rleByte, jl, lane, DEC_THREADS);
-          else copy_bytes(out + jo, lit + js, jl, lane, DEC_THREADS);
-        }
-      }
-      wsync();
-      XTIME(2)
-      // -------- the rest: dependency rounds — a lane is ready once its source ends before the first unfinished destination
-      {
-        const u32 msrc = mdst - off;
-        const u32 msrcEnd = min(msrc + ml, mdst);
-        u64 pending = __ballot(act);
-        while (pending) {
-          const u32 fnd = (u32)__builtin_ctzll(pending);
-          const u32 frontier = bcast_u32(mdst, fnd);
-          const bool mine = (pending >> lane) & 1;
-          const bool ready = mine && (msrcEnd <= frontier || (u32)lane == fnd);
-          const bool longM = ready && ml > 64;
-          if (ready && !longM && !(a.debugSkip & 2)) {
-            u8* dp = out + mdst; const u8* sp = dp - off;
-            if (off >= ml) copy_le64(dp, sp, ml);      // no overlap: all loads, then all stores
-            else copy_periodic_le64(dp, sp, ml, off, S.slot[lane]);  // overlapping match = period `off`: only the bytes in front of the destination are read
-          }
-          u64 lmk = __ballot(longM);
-          while (lmk) {                            // long matches: the whole wave copies (period-safe modular source)
-            const u32 k2 = (u32)__builtin_ctzll(lmk); lmk &= lmk - 1;
-            const u32 jml = bcast_u32(ml, k2), jd = bcast_u32(mdst, k2), jof = bcast_u32(off, k2);
-            u8* dp = out + jd; const u8* sp = dp - jof;
-            if (jof >= jml) { for (u32 k = lane; k < jml; k += WAVE) dp[k] = sp[k]; }
-            else { for (u32 k = lane; k < jml; k += WAVE) dp[k] = sp[k % jof]; }
-          }
-          pending &= ~__ballot(ready);
-          if (!(a.debugSkip & 4)) wsync();
-          XCNT(12, 1)
-        }
-      }
-      XTIME(3)
-      outBase = stepEnd; litBase += bcast_u32(incL, 63);
-    }
-    // ---- block tail: remaining literals (the chain kernel checked the room)
-    u32 blockOut = outBase;
-    if (!chainErr && !truncated) {
-      const u32 tail = regen - litBase;
-      if (litKind == 1) fill_bytes(out + outBase, rleByte, tail, lane, DEC_THREADS);
-      else copy_bytes(out + outBase, lit + litBase, tail, lane, DEC_THREADS);
-      blockOut += tail;
-    }
-    wsync();
-    // ---- commit: a compressed block confirms its repeat offsets; then the frame ends, or takes another round
-    const u32 produced = produced0 + blockOut, endPos = F->bpos + F->bsize;
-    if (chainErr || truncated || F->blast) {
-      frame_finish(a, j, src, srcSize, chainErr, produced, endPos, truncated != 0, F->fcsHave, F->fcsLo, F->fcsHi, F->hasChecksum, lane);
-    } else {
-      more = 1;
-      if (lane == 0) {
-        F->produced = produced; F->blkPos = endPos;
-        F->rep[0] = F->repOut[0]; F->rep[1] = F->repOut[1]; F->rep[2] = F->repOut[2];
-        if (!FUSED) a.nextActive[atomicAdd(&a.counters[ZRA_DC_NNEXT], 1u)] = j;
-      }
-    }
-    wsync();
+  XCNT(8, 1)
+  u64 qNext = (u32)lane < nSeq ? sq[lane] : (1ull << 36);        // the next step's sequences are always in flight
+  for (u32 first = 0; first < nSeq; first += BATCH) {
+    const u32 cnt = min((u32)BATCH, nSeq - first);
+    const bool act = (u32)lane < cnt;
+    const u64 q = qNext;
+    qNext = first + BATCH + (u32)lane < nSeq ? sq[first + BATCH + lane] : (1ull << 36);
+    const u32 ll = (u32)q & 0x3FFFFu, ml = (u32)(q >> 18) & 0x3FFFFu, off = (u32)(q >> 36);
+    const u32 tot = ll + ml;
+    const u32 incT = dpp_scan_add(tot), incL = dpp_scan_add(ll);
+    XTIME(0) XCNT(9, 1) XCNT(10, cnt)
+    exec_step(c, S, ll, ml, off, c.outBase + incT - tot, c.litBase + incL - ll, act, lane, a.debugSkip);
+    XTIME(3)
+    c.outBase += bcast_u32(incT, 63); c.litBase += bcast_u32(incL, 63);
   }
-  return more;
+  return exec_end<FUSED>(a, j, F, c, lane);
 }
 }  // namespace
 
@@ -1644,11 +1658,14 @@ __device__ __forceinline__ void chain_produce(const ZraDecodeArgs& a, const u32 
 
 // ring entry: {literal length, match length, (1 << offset code) + its extra bits}: 1 = repeat offset by literal length, 2 / 3 = the
 // one-bit repeat codes, >= 4 = a new offset + 3
-__device__ __forceinline__ void chain_consume(const ZraDecodeArgs& a, const u32 j, ZraDecFrame* const F, ChainRing& R, const int lane) {
+// ... and, as soon as the literals are there (*litFlag: 1 = ready, 2 = the literal decoder gave up), EXECUTES them: the execute stage of
+// the block rides behind the chain instead of following it. `c` leaves with the positions the block's tail continues from.
+__device__ __forceinline__ void chain_consume(const ZraDecodeArgs& a, const u32 j, ZraDecFrame* const F, ChainRing& R, ExecShared& X, const u32* const litFlag,
+                                              ExecCtx& c, const int lane) {
   const u32 regen = F->litRegen, produced0 = F->produced;
   const u32 outCap = a.outCap[j] - produced0;
   const u32 limit = a.limit ? a.limit[j] : 0xFFFFFFFFu;
-  u64* const sq = a.seqs + F->seqBase;
+  bool litReady = false;
   u32 rep0 = rfl(F->rep[0]), rep1 = rfl(F->rep[1]), rep2 = rfl(F->rep[2]);
   u32 outPos = 0, litPos = 0, truncated = 0;
   u32 t = 0;
@@ -1664,7 +1681,7 @@ __device__ __forceinline__ void chain_consume(const ZraDecodeArgs& a, const u32 
     const bool on = (u32)lane < nb;
     const uint4 e4 = R.e[(t + (u32)lane) & (RING - 1)];
     const u32 ll = on ? e4.x : 0u, ml = on ? e4.y : 0u, ov = on ? e4.z : 4u;
-    const u32 sOut = wave_incl_scan(ll + ml), sLit = wave_incl_scan(ll);
+    const u32 sOut = dpp_scan_add(ll + ml), sLit = dpp_scan_add(ll);
     const u32 outBefore = outPos + sOut - (ll + ml), litBefore = litPos + sLit - ll;
     // random access: stop at the sequence that covers the last needed byte
     const u64 tm = __ballot(on && produced0 + outPos + sOut >= limit);
@@ -1699,7 +1716,13 @@ __device__ __forceinline__ void chain_consume(const ZraDecodeArgs& a, const u32 
     }
     catch_up(nb);
     if (__ballot(on2 && (ll + ml > outCap - outBefore || ll > regen - litBefore || off > produced0 + outBefore + ll))) { bad = true; break; }
-    if (on2) sq[t + (u32)lane] = (u64)ll | ((u64)ml << 18) | ((u64)min(off, 0x0FFFFFFFu) << 36);
+    if (!litReady) {
+      u32 v;
+      while ((v = ring_ld(litFlag)) == 0) __builtin_amdgcn_s_sleep(2);
+      if (v == 2) { if (lane == 0) { ring_st(&R.bail, 1u); ring_st(&R.stop, 1u); } return; }
+      litReady = true;
+    }
+    exec_step(c, X, on2 ? ll : 0u, on2 ? ml : 0u, on2 ? min(off, 0x0FFFFFFFu) : 1u, outBefore, litBefore, on2, lane, 0u);
     outPos += bcast_u32(sOut, nb - 1); litPos += bcast_u32(sLit, nb - 1);
     t += nb;
     if (lane == 0) ring_st(&R.tail, t);
@@ -1707,6 +1730,7 @@ __device__ __forceinline__ void chain_consume(const ZraDecodeArgs& a, const u32 
   }
   if (bad || (!truncated && regen - litPos > outCap - outPos)) { if (lane == 0) { ring_st(&R.bail, 1u); ring_st(&R.stop, 1u); } return; }
   if (truncated && lane == 0) ring_st(&R.stop, 1u);
+  c.outBase = outPos; c.litBase = litPos;
   if (lane == 0) {
     F->chainErr = 0; F->nSeqValid = t; F->seqOut = outPos; F->seqLit = litPos; F->truncated = truncated;
     F->repOut[0] = rep0; F->repOut[1] = rep1; F->repOut[2] = rep2;
@@ -1733,7 +1757,7 @@ zra_ra_small_kernel(ZraDecodeArgs a0, u32* bail) {
     if (wave == 0) {
       const u32 oc = parse_job<true>(a, j, S.P, lane, S.tabs);
       if (lane == 0) {
-        S.ctl[0] = oc; S.ctl[1] = 0;
+        S.ctl[0] = oc; S.ctl[1] = 0; S.ctl[3] = 0;
         S.ring.head = 0; S.ring.tail = 0; S.ring.prodDone = 0; S.ring.stop = 0; S.ring.consReady = 0; S.ring.consDone = 0; S.ring.bail = 0;
       }
       SPROF(0)
@@ -1743,7 +1767,9 @@ zra_ra_small_kernel(ZraDecodeArgs a0, u32* bail) {
     const u32 oc = S.ctl[0];
     if (oc == 0) return;                                   // the frame is finished (status and slices written by frame_finish)
     if (oc == 2) { if (threadIdx.x == 0) atomicAdd(bail, 1u); return; }
+    ExecCtx xc;
     if (wave == 1) {
+      u32 ok = 1;
       if (F->litKind == 2) {
         huf_build_table(F, S.hufTab, S.hufW1, lane);
         wsync();
@@ -1753,20 +1779,25 @@ zra_ra_small_kernel(ZraDecodeArgs a0, u32* bail) {
 #endif
         if (!wide)
           if ((u32)lane < F->litStreams && !huf_decode_stream(a, F, j, S.hufTab, S.hufW1, (u32)lane, lim)) S.ctl[1] = 1;
+        wsync();
+        ok = S.ctl[1] == 0;
       }
+      __threadfence_block();
+      if (lane == 0) ring_st(&S.ctl[3], ok ? 1u : 2u);             // the execute steps of the chain's consumer may read the literals
       SPROF(1)
     } else if (wave == 0) {
       chain_produce(a, j, F, S.tabs, S.bits, S.ring, lane);
       SPROF(2)
     } else {
-      chain_consume(a, j, F, S.ring, lane);
+      xc = exec_begin(a, j, F);
+      chain_consume(a, j, F, S.ring, S.X, &S.ctl[3], xc, lane);
       SPROF(5)
     }
     __threadfence_block();
     __syncthreads();
     if (S.ctl[1] | S.ring.bail) { if (threadIdx.x == 0) atomicAdd(bail, 1u); return; }
     SPROF_RESET
-    if (wave == 0) { const u32 more = exec_job<true>(a, j, S.X, lane); if (lane == 0) S.ctl[2] = more; SPROF(3) }
+    if (wave == 2) { const u32 more = exec_end<true>(a, j, F, xc, lane); if (lane == 0) S.ctl[2] = more; SPROF(3) }
     __syncthreads();
     if (!S.ctl[2]) return;
   }
