@@ -1609,25 +1609,64 @@ __device__ __forceinline__ void chain_produce(const ZraDecodeArgs& a, const u32 
     // ((1 << code) + extra bits); every other lane -> word 3, which nobody reads
     u32* const slot = (u32*)&R.e[0] + (k8 < 3 ? 2u - k8 : 3u);
     const u32 mBase = (k8 == 1 || k8 == 2) ? ~0u : 0u, mPow = k8 == 0 ? ~0u : 0u;
+    u32 checkedLeft = 0;
     for (;;) {
       i32 cur = (i32)rfl(8u * br.ptr + 64u - br.bc);
       if (i < nbSeq && cur >= 256 && br.ptr >= 8 && br.bc < 8) {
         u32 st = strm == 0 ? sLL : strm == 1 ? sML : strm == 2 ? sOF : 0u;
-        while (i < nbSeq && cur >= 256) {
-          if ((i & 15u) == 0) { if (i) { if (lane == 0) ring_st(&R.head, i); } if (!gate(i)) { stopped = true; break; } }
-          const u32 p = (((u32)cur + 7u) >> 3) - 8u, room = (u32)cur - 8u * p;      // room = 64 - bitsConsumed
-          const u32* const cell = (const u32*)(tk + (st << shk));
-          const u32 x = cell[0], y = cell[1];
-          const u64 c = ld64(bits + p);
-          asm volatile("" :: "v"((u32)c), "v"((u32)(c >> 32)), "v"(y));               // (cells and container in flight together)
-          const u32 w = __builtin_amdgcn_ubfe(x, fOff, fWid);
-          u32 s = w; s += dpp_row_shr<1>(s); s += dpp_row_shr<2>(s); s += dpp_row_shr<4>(s);
-          const u32 total = bcast_u32(s, 7);
-          if (total > room) break;                                                    // (a sequence of more than 57 bits: the careful step)
-          const u32 val = __builtin_amdgcn_ubfe((u32)(c >> ((room - s) & 63u)), 0u, w);
-          st = dpp_low4_from_mirror((x >> 20) + val);
-          slot[4u * (i & (RING - 1))] = val + ((1u << w) & mPow) + (y & mBase);
-          cur -= (i32)total; i++;
+        // ---- sixteen sequences at a time, straight-line: no loop counter, no ring arithmetic (the entry is an immediate offset), no
+        // branch on a wide sequence — the widest one of the block is looked at once, behind it, and a block that had one is run again
+        // through the checked steps below (nothing of it was published yet). 16 x 64 bits of room under the read position required.
+        for (;;) {
+          while (!checkedLeft && (i & 15u) == 0 && i + 16 <= nbSeq && cur >= 256 + 16 * 64) {
+            if (i) { if (lane == 0) ring_st(&R.head, i); }
+            if (!gate(i)) { stopped = true; break; }
+            const u32 st0 = st; const i32 cur0 = cur;
+            u32 widest = 0;
+            u32* const blockSlot = slot + 4u * (i & (RING - 1));
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+              const u32 p8 = ((u32)cur + 7u) >> 3, u = 8u * p8 - (u32)cur;             // container = the 8 bytes below byte p8; u = its 0..7 consumed bits
+              const u32* const cell = (const u32*)(tk + (st << shk));
+              const u32 x = cell[0], y = cell[1];
+              const u64 c = ld64(bits + p8 - 8u);
+              asm volatile("" :: "v"((u32)c), "v"((u32)(c >> 32)), "v"(y));             // (cells and container in flight together)
+              const u32 w = __builtin_amdgcn_ubfe(x, fOff, fWid);
+              u32 s = w + (u & mPow);                                                    // lane 0's field starts u bits below the container's top
+              s += dpp_row_shr<1>(s); s += dpp_row_shr<2>(s); s += dpp_row_shr<4>(s);
+              const u32 used = bcast_u32(s, 7);                                          // u + the sequence's bits
+              widest = max(widest, used);
+              const u32 val = __builtin_amdgcn_ubfe((u32)(c >> ((64u - s) & 63u)), 0u, w);
+              st = dpp_low4_from_mirror((x >> 20) + val);
+              blockSlot[4 * r] = val + ((1u << w) & mPow) + (y & mBase);
+              cur -= (i32)(used - u);
+            }
+            if (widest > 64) { st = st0; cur = cur0; checkedLeft = 16; break; }
+            i += 16;
+          }
+          if (stopped) break;
+          // ---- one sequence at a time, each looked at before it is taken: up to the next block boundary, near the stream's start,
+          // and through a block that holds a wide sequence
+          bool again = false;
+          while (i < nbSeq && cur >= 256) {
+            if (!checkedLeft && (i & 15u) == 0 && i + 16 <= nbSeq && cur >= 256 + 16 * 64) { again = true; break; }
+            if ((i & 15u) == 0) { if (i) { if (lane == 0) ring_st(&R.head, i); } if (!gate(i)) { stopped = true; break; } }
+            const u32 p = (((u32)cur + 7u) >> 3) - 8u, room = (u32)cur - 8u * p;      // room = 64 - bitsConsumed
+            const u32* const cell = (const u32*)(tk + (st << shk));
+            const u32 x = cell[0], y = cell[1];
+            const u64 c = ld64(bits + p);
+            asm volatile("" :: "v"((u32)c), "v"((u32)(c >> 32)), "v"(y));
+            const u32 w = __builtin_amdgcn_ubfe(x, fOff, fWid);
+            u32 s = w; s += dpp_row_shr<1>(s); s += dpp_row_shr<2>(s); s += dpp_row_shr<4>(s);
+            const u32 total = bcast_u32(s, 7);
+            if (total > room) break;                                                    // (a sequence of more than 57 bits: the careful step)
+            const u32 val = __builtin_amdgcn_ubfe((u32)(c >> ((room - s) & 63u)), 0u, w);
+            st = dpp_low4_from_mirror((x >> 20) + val);
+            slot[4u * (i & (RING - 1))] = val + ((1u << w) & mPow) + (y & mBase);
+            cur -= (i32)total; i++;
+            if (checkedLeft) checkedLeft--;
+          }
+          if (!again) break;
         }
         sLL = bcast_u32(st, 2); sML = bcast_u32(st, 1); sOF = bcast_u32(st, 0);
         br.ptr = (((u32)cur + 7u) >> 3) - 8u; br.bc = 8u * br.ptr + 64u - (u32)cur; br.c = ld64(bits + br.ptr);
