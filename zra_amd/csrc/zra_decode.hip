@@ -811,15 +811,15 @@ __device__ __forceinline__ u32 parse_job(const ZraDecodeArgs& a, const u32 j, Pa
           if (mode == 1) {
             if (lane == 0) {
               if (k == 2) { G[0] = mk_cell(ms, ms, 0, 0); S.ofShare = (ms > 22) ? 256u : 0u; }
-              else { G[0] = mk_cell(ms, k == 0 ? c_ll_bits[ms] : c_ml_bits[ms], 0, 0); G[1] = k == 0 ? c_ll_base[ms] : c_ml_base[ms]; }
-              if (FUSED) { u32* const GL = ldsT + (k == 0 ? ZRA_DEC_TBL_LL : k == 1 ? ZRA_DEC_TBL_ML : ZRA_DEC_TBL_OF); GL[0] = G[0]; if (k != 2) GL[1] = G[1]; }
+              else G[0] = mk_cell(ms, k == 0 ? c_ll_bits[ms] : c_ml_bits[ms], 0, 0);
+              if (FUSED) { u32* const GL = ldsT + (k == 0 ? ZRA_LDS_TBL_LL : k == 1 ? ZRA_LDS_TBL_ML : ZRA_LDS_TBL_OF); GL[0] = G[0]; if (k != 2) GL[1] = k == 0 ? c_ll_base[ms] : c_ml_base[ms]; }
             }
           } else if (mode != 3) {
             build_fse_dtable(S.stage, S.norm, ms, tl, k, S.spread, (u64*)S.w0, S.wnext, lane);
             wsync();
             const u32 words = (k == 2 ? 1u : 2u) << tl;
-            for (u32 i = lane; i < words; i += DEC_THREADS) G[i] = S.stage[i];
-            if (FUSED) { u32* const GL = ldsT + (k == 0 ? ZRA_DEC_TBL_LL : k == 1 ? ZRA_DEC_TBL_ML : ZRA_DEC_TBL_OF); for (u32 i = lane; i < words; i += DEC_THREADS) GL[i] = S.stage[i]; }
+            if (!FUSED) for (u32 i = lane; i < (1u << tl); i += DEC_THREADS) G[i] = S.stage[k == 2 ? i : 2 * i];      // (the one-launch kernel never reads the global copy)
+            if (FUSED) { u32* const GL = ldsT + (k == 0 ? ZRA_LDS_TBL_LL : k == 1 ? ZRA_LDS_TBL_ML : ZRA_LDS_TBL_OF); for (u32 i = lane; i < words; i += DEC_THREADS) GL[i] = S.stage[i]; }
             if (k == 2) {
               // share of long offset codes (ZSTD_getLongOffsetsShare): cells whose code needs more than 22 extra bits, scaled to 8 bits
               u32 cnt = 0;
@@ -1217,11 +1217,13 @@ zra_dec_chain_kernel(ZraDecodeArgs a) {
   // per request instead of 8
   u64 q0 = 0, q1 = 0, q2 = 0;
   // the table cells of the sequence about to be decoded: requested one step ahead, together with the container reload
-  uint2 eL = make_uint2(0, 0), eM = make_uint2(0, 0); u32 eO = 0;
+  u32 eL = 0, eM = 0, eO = 0;
   bool wide = false; const u8* pad = nullptr;
-  auto fetch_cells = [&]() {
-    eL = *(const uint2*)(T + ZRA_DEC_TBL_LL + 2 * sLL); eM = *(const uint2*)(T + ZRA_DEC_TBL_ML + 2 * sML); eO = T[ZRA_DEC_TBL_OF + sOF];
-  };
+  auto fetch_cells = [&]() { eL = T[ZRA_DEC_TBL_LL + sLL]; eM = T[ZRA_DEC_TBL_ML + sML]; eO = T[ZRA_DEC_TBL_OF + sOF]; };
+  // base values of the length codes (the cells carry the code only)
+  __shared__ u32 baseLL[64], baseML[64];
+  baseLL[lane] = lane < 36 ? c_ll_base[lane] : 0u; baseML[lane] = lane < 53 ? c_ml_base[lane] : 0u;
+  wsync();
 
   auto finish = [&]() {
     // the last one to three sequences still sit in registers
@@ -1299,8 +1301,8 @@ zra_dec_chain_kernel(ZraDecodeArgs a) {
       if (go) {
         // ZSTD_decodeSequence (64-bit path): offset bits, match-length bits, [reload], literal-length bits, then the three state
         // updates — always, the last sequence included
-        const u32 ofBits = (eO >> 8) & 0xFF, mlBits = (eM.x >> 8) & 0xFF, llBits = (eL.x >> 8) & 0xFF;
-        u32 ll = eL.y, ml = eM.y, off;
+        const u32 ofBits = (eO >> 8) & 0xFF, mlBits = (eM >> 8) & 0xFF, llBits = (eL >> 8) & 0xFF;
+        u32 ll = baseLL[eL & 63u], ml = baseML[eM & 63u], off;
         if (ofBits > 1) {
           off = ((1u << ofBits) - 3u) + br.read_fast(ofBits);
           rep2 = rep1; rep1 = rep0; rep0 = off;
@@ -1320,8 +1322,8 @@ zra_dec_chain_kernel(ZraDecodeArgs a) {
         if (mlBits) ml += br.read_fast(mlBits);
         if (llBits + mlBits + ofBits >= 57 - (9 + 9 + 8)) br.reload();
         if (llBits) ll += br.read_fast(llBits);
-        sLL = (eL.x >> 20) + br.read((eL.x >> 16) & 0xF);
-        sML = (eM.x >> 20) + br.read((eM.x >> 16) & 0xF);
+        sLL = (eL >> 20) + br.read((eL >> 16) & 0xF);
+        sML = (eM >> 20) + br.read((eM >> 16) & 0xF);
         sOF = (eO >> 20) + br.read((eO >> 16) & 0xF);
         fetch_cells();                                      // next sequence's cells and the container: one round trip
         if (!longMode) br.reload_quiet(wide, pad);
@@ -1545,7 +1547,7 @@ constexpr u32 SMALL_SEQ_BYTES = 40u << 10;      // sequence bitstreams up to thi
 struct __attribute__((aligned(16))) SmallShared {
   ParseShared P;
   ExecShared X;
-  u32 tabs[ZRA_DEC_TBL_WORDS];
+  u32 tabs[ZRA_LDS_TBL_WORDS];
   u16 hufTab[2048]; u8 hufW1[256];
   u8 bits[SMALL_SEQ_BYTES + 16];
   u32 ctl[4];                                   // [0] parse outcome, [1] bail, [2] frame goes on
@@ -1602,7 +1604,7 @@ __device__ __forceinline__ void chain_produce(const ZraDecodeArgs& a, const u32 
     // dependent path of a sequence is one LDS round trip (cells and container together) and ~10 vector instructions instead of ~100.
     const u32 k8 = (u32)lane < 8u ? (u32)lane : 3u;
     const u32 strm = (k8 == 2 || k8 == 5) ? 0u : (k8 == 1 || k8 == 6) ? 1u : (k8 == 0 || k8 == 7) ? 2u : 3u;       // LL, ML, OF, idle
-    const u8* const tk = (const u8*)(T + (strm == 0 ? ZRA_DEC_TBL_LL : strm == 1 ? ZRA_DEC_TBL_ML : ZRA_DEC_TBL_OF));
+    const u8* const tk = (const u8*)(T + (strm == 0 ? ZRA_LDS_TBL_LL : strm == 1 ? ZRA_LDS_TBL_ML : ZRA_LDS_TBL_OF));
     const u32 shk = strm < 2 ? 3u : strm == 2 ? 2u : 0u;                         // cell size (idle lanes read the first OF cell, or junk)
     const u32 fOff = k8 < 3 ? 8u : 16u, fWid = k8 < 3 ? 8u : k8 >= 5 ? 4u : 0u;
     // what a lane leaves in the ring entry: lane 2 -> word 0 (literal length), lane 1 -> word 1 (match length), lane 0 -> word 2
@@ -1675,8 +1677,8 @@ __device__ __forceinline__ void chain_produce(const ZraDecodeArgs& a, const u32 
       if (i >= nbSeq) break;
       // ---- one careful step (every case of BIT_reloadDStream): the stream's last bytes, and sequences wider than a container
       if ((i & 15u) == 0) { if (i) { if (lane == 0) ring_st(&R.head, i); } if (!gate(i)) { stopped = true; break; } }
-      const uint2 eL = *(const uint2*)(T + ZRA_DEC_TBL_LL + 2 * sLL), eM = *(const uint2*)(T + ZRA_DEC_TBL_ML + 2 * sML);
-      const u32 eO = T[ZRA_DEC_TBL_OF + sOF];
+      const uint2 eL = *(const uint2*)(T + ZRA_LDS_TBL_LL + 2 * sLL), eM = *(const uint2*)(T + ZRA_LDS_TBL_ML + 2 * sML);
+      const u32 eO = T[ZRA_LDS_TBL_OF + sOF];
       const u32 ofBits = (eO >> 8) & 0xFF, mlBits = (eM.x >> 8) & 0xFF, llBits = (eL.x >> 8) & 0xFF;
       u32 ll = eL.y, ml = eM.y, raw = 0;
       if (ofBits) raw = br.read_fast(ofBits);

@@ -17,10 +17,15 @@
 #ifndef ZRA_HUF_FRAMES
 #define ZRA_HUF_FRAMES 2        /* A/B on one box, 8 GiB decode: 16 / 8 / 4 / 2 / 1 frames per wave -> Huffman stage 20.0 / 18.4 / 14.7 / 13.3 / 15.4 ms */
 #endif
-#define ZRA_DEC_TBL_LL 0u       // 512 cells x 8 B  {sym | extraBits<<8 | stateBits<<16 | nextBase<<20, baseValue}
-#define ZRA_DEC_TBL_ML 1024u    // 512 cells x 8 B
-#define ZRA_DEC_TBL_OF 2048u    // 256 cells x 4 B  (base value = 1 << code)
-#define ZRA_DEC_TBL_WORDS 2304u // u32 words of table scratch per frame
+#define ZRA_DEC_TBL_LL 0u       // 512 cells x 4 B  sym | extraBits<<8 | stateBits<<16 | nextBase<<20 (the base value of a length code comes from a
+#define ZRA_DEC_TBL_ML 512u     // 512 cells x 4 B   constant table: 5 KiB of cells per frame instead of 9, so that the frames in flight fit the caches)
+#define ZRA_DEC_TBL_OF 1024u    // 256 cells x 4 B  (base value = 1 << code)
+#define ZRA_DEC_TBL_WORDS 1280u // u32 words of table scratch per frame
+// the one-launch kernel's copy in LDS keeps the base value next to the cell (one read per cell on its dependent path)
+#define ZRA_LDS_TBL_LL 0u       // 512 cells x 8 B  {cell, baseValue}
+#define ZRA_LDS_TBL_ML 1024u    // 512 cells x 8 B
+#define ZRA_LDS_TBL_OF 2048u    // 256 cells x 4 B
+#define ZRA_LDS_TBL_WORDS 2304u
 
 // per-frame decode state; lives in HBM scratch for the whole call (frames take one round per compressed block)
 struct ZraDecFrame {
