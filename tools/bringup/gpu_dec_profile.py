@@ -3,7 +3,7 @@ import sys, os, ctypes
 here = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"); sys.path.insert(0, here); sys.path.insert(0, os.path.dirname(here))
 import numpy as np, torch, zra_amd as Z, bench
 gib = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
-lib = ctypes.CDLL(os.path.join(os.path.dirname(here), "zra_amd", "libzra_amd.so"))
+lib = ctypes.CDLL(Z.LIB_PATH)
 dev = torch.device("cuda", 0); eng = Z.Engine(0)
 base = bench.synth_corpus(64 << 20, 1); fs = 65536; n = int(gib * (1 << 30))
 d_in = torch.from_numpy(np.resize(base, n)).to(dev)

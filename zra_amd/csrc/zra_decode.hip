@@ -30,6 +30,7 @@ namespace {
 
 constexpr int DEC_THREADS = 64;
 constexpr int BATCH = 64;           // sequences executed per step (one per lane)
+constexpr u32 XPRE = 64, XWIN = 3008; // execute stage: bytes in front of a step kept in LDS / largest step put together in LDS
 constexpr u32 BLOCK_MAX = 128u << 10;
 
 __constant__ u32 c_ll_base[36] = {0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,18,20,22,24,28,32,40,48,64,128,256,512,1024,2048,4096,8192,16384,32768,65536};
@@ -1360,6 +1361,9 @@ zra_dec_chain_kernel(ZraDecodeArgs a) {
 namespace {
 struct __attribute__((aligned(16))) ExecShared {
   u8 slot[BATCH][64];       // a lane's scratch for the first period of an overlapping match
+  u32 endAt[BATCH];         // where each sequence of the step ends in the output (ascending) ...
+  u32 matchAt[BATCH];       // ... and where its match begins (ascending): a match's source range is looked up in these
+  u8 win[XPRE + XWIN];      // the step's output while it is being put together, behind the XPRE bytes that precede it
   u32 job;
 };
 }  // namespace
@@ -1369,8 +1373,8 @@ __device__ unsigned long long zra_dec_prof[16];
 #define XCNT(k, v) { if (lane == 0) atomicAdd(&zra_dec_prof[k], (unsigned long long)(v)); }
 #define XTIME(k) { __builtin_amdgcn_s_waitcnt(0); const u64 n_ = __builtin_amdgcn_s_memtime(); if (lane == 0) atomicAdd(&zra_dec_prof[k], n_ - xpt_); xpt_ = n_; }
 extern "C" __attribute__((visibility("default"))) void ZraHipDebugReadDecProfile(unsigned long long* out16, int reset) {
-  (void)hipMemcpyFromSymbol(out16, HIP_SYMBOL(zra_dec_prof), sizeof(unsigned long long) * 64);
-  if (reset) { unsigned long long z[64] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(zra_dec_prof), z, sizeof(z)); }
+  (void)hipMemcpyFromSymbol(out16, HIP_SYMBOL(zra_dec_prof), sizeof(unsigned long long) * 16);
+  if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(zra_dec_prof), z, sizeof(z)); }
 }
 #else
 #define XCNT(k, v)
@@ -1383,6 +1387,7 @@ struct ExecCtx {
   u8* out; const u8* lit; u32 litKind; u8 rleByte;
   u32 outBase, litBase;
   const u8* src; u32 srcSize, produced0, regen;
+  bool preValid;            // the LDS window holds the XPRE bytes in front of outBase
 };
 __device__ __forceinline__ ExecCtx exec_begin(const ZraDecodeArgs& a, const u32 j, const ZraDecFrame* const F) {
   ExecCtx c;
@@ -1394,14 +1399,17 @@ __device__ __forceinline__ ExecCtx exec_begin(const ZraDecodeArgs& a, const u32 
   c.litKind = F->litKind; c.regen = F->litRegen;
   c.lit = c.litKind == 2 ? a.lits + F->litBase : c.src + F->litArg;
   c.rleByte = (u8)F->litArg;
-  c.outBase = 0; c.litBase = 0;
+  c.outBase = 0; c.litBase = 0; c.preValid = false;
   return c;
 }
 // up to 64 sequences, lane = sequence (act: the lane has one; oStart / lStart: where its literals go and come from)
-__device__ __forceinline__ void exec_step(const ExecCtx& c, ExecShared& S, const u32 ll, const u32 ml, const u32 off, const u32 oStart, const u32 lStart,
-                                          const bool act, const int lane, const u32 debugSkip) {
+__device__ __forceinline__ void exec_step_global(const ExecCtx& c, ExecShared& S, const u32 ll, const u32 ml, const u32 off, const u32 oStart, const u32 lStart,
+                                                 const bool act, const int lane, const u32 debugSkip) {
   u8* const out = c.out; const u8* const lit = c.lit; const u32 litKind = c.litKind; const u8 rleByte = c.rleByte;
   const u32 mdst = oStart + ll;
+#ifdef ZRA_DEC_PROFILE
+  u64 xpt_ = __builtin_amdgcn_s_memtime();
+#endif
   // -------- literal runs
   {
     u8* op = out + oStart;
@@ -1419,16 +1427,34 @@ __device__ __forceinline__ void exec_step(const ExecCtx& c, ExecShared& S, const
     }
   }
   wsync();
-  // -------- the rest: dependency rounds — a lane is ready once its source ends before the first unfinished destination
+  XTIME(2)
+  // -------- the rest: dependency rounds. A match may go once every sequence of this step whose output its source range touches has
+  // gone: the sequences [a, b) with a = the first one that ends behind the source's first byte, b = the first one whose match begins
+  // at or behind the source's end — two binary searches in the step's (ascending) positions, once per step. (It was: once its source
+  // ends before the FIRST unfinished match — 11 rounds per step on text, where most matches reach back a few sequences only.)
   {
-    const u32 msrc = mdst - off;
-    const u32 msrcEnd = min(msrc + ml, mdst);
+    const i32 msrc = (i32)mdst - (i32)off;
+    const i32 msrcEnd = min(msrc + (i32)ml, (i32)mdst);
+    const u32 stepStart = bcast_u32(oStart, 0);
+    S.endAt[lane] = mdst + ml; S.matchAt[lane] = mdst;
+    wsync();
+    u64 deps = 0;
+    if (act && msrcEnd > (i32)stepStart) {
+      u32 a = 0, b = 0;
+#pragma unroll
+      for (u32 st = BATCH / 2; st >= 1; st >>= 1) {
+        a += (i32)S.endAt[a + st - 1] <= msrc ? st : 0u;
+        b += (i32)S.matchAt[b + st - 1] < msrcEnd ? st : 0u;
+      }
+      a += (i32)S.endAt[a] <= msrc ? 1u : 0u;
+      b += (i32)S.matchAt[b] < msrcEnd ? 1u : 0u;
+      const u64 below_b = b >= 64 ? ~0ull : (1ull << b) - 1ull, below_a = a >= 64 ? ~0ull : (1ull << a) - 1ull;
+      deps = below_b & ~below_a & ((1ull << lane) - 1ull);
+    }
     u64 pending = __ballot(act);
     while (pending) {
-      const u32 fnd = (u32)__builtin_ctzll(pending);
-      const u32 frontier = bcast_u32(mdst, fnd);
       const bool mine = (pending >> lane) & 1;
-      const bool ready = mine && (msrcEnd <= frontier || (u32)lane == fnd);
+      const bool ready = mine && !(deps & pending);
       const bool longM = ready && ml > 64;
       if (ready && !longM && !(debugSkip & 2)) {
         u8* dp = out + mdst; const u8* sp = dp - off;
@@ -1445,9 +1471,115 @@ __device__ __forceinline__ void exec_step(const ExecCtx& c, ExecShared& S, const
       }
       pending &= ~__ballot(ready);
       if (!(debugSkip & 4)) wsync();
+      XCNT(12, 1)
     }
   }
+  XTIME(3)
 }
+// LDS traffic of the wave is complete and visible to its other lanes (global stores may still be in flight)
+__device__ __forceinline__ void lsync() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+}
+// The same step put together in LDS. A step's matches mostly copy from the step itself or from just in front of it, and every
+// dependency round of exec_step_global is a round trip through the memory system (stores drained, then dependent loads): six to seven
+// per step on text. Here the step's output — literal runs, then the matches in the same dependency rounds — is assembled in a window in
+// LDS that also holds the XPRE bytes in front of the step (a match of up to 64 bytes that begins less than 64 bytes in front of the
+// step lies in the window entirely; one that begins further back lies in finished output entirely), the rounds cost LDS round trips,
+// and the window goes out in 16-byte stores, followed by the step's ONE drain. Steps larger than the window take exec_step_global.
+__device__ __forceinline__ void exec_step(ExecCtx& c, ExecShared& S, const u32 ll, const u32 ml, const u32 off, const u32 oStart, const u32 lStart,
+                                          const bool act, const int lane, const u32 debugSkip) {
+  const u32 stepStart = bcast_u32(oStart, 0), stepLen = bcast_u32(oStart + ll + ml, 63) - stepStart;
+  if (stepLen > XWIN || debugSkip) { exec_step_global(c, S, ll, ml, off, oStart, lStart, act, lane, debugSkip); c.preValid = false; return; }
+  u8* const out = c.out; const u8* const lit = c.lit; const u32 litKind = c.litKind; const u8 rleByte = c.rleByte;
+  u8* const W = S.win;                                    // output byte x of the window sits at W[x + wb] (x >= stepStart - XPRE; plain indices:
+  const u32 wb = XPRE - stepStart;                        //  a biased LDS pointer would not survive being widened to a flat one)
+  if (!c.preValid) {
+    const i32 pos = (i32)stepStart - (i32)XPRE + lane;   // (bytes in front of the frame do not exist and are never a source)
+    W[lane] = pos >= -(i32)c.produced0 ? out[pos] : (u8)0;
+  }
+  const u32 mdst = oStart + ll;
+  // -------- literal runs
+  {
+    u8* const op = W + (oStart + wb);
+    const bool longLit = ll > 32;
+    if (!longLit && ll) {
+      if (litKind == 1) for (u32 b = 0; b < ll; b++) op[b] = rleByte;
+      else copy_le64(op, lit + lStart, ll);
+    }
+    u64 lm = __ballot(longLit);
+    while (lm) {
+      const u32 k = (u32)__builtin_ctzll(lm); lm &= lm - 1;
+      const u32 jl = bcast_u32(ll, k), jo = bcast_u32(oStart, k), js = bcast_u32(lStart, k);
+      if (litKind == 1) fill_bytes(W + (jo + wb), rleByte, jl, lane, DEC_THREADS);
+      else copy_bytes(W + (jo + wb), lit + js, jl, lane, DEC_THREADS);
+    }
+  }
+  // -------- matches, in dependency rounds (see exec_step_global)
+  {
+    const i32 msrc = (i32)mdst - (i32)off;
+    const i32 msrcEnd = min(msrc + (i32)ml, (i32)mdst);
+    S.endAt[lane] = mdst + ml; S.matchAt[lane] = mdst;
+    lsync();
+    u64 deps = 0;
+    if (act && msrcEnd > (i32)stepStart) {
+      u32 a = 0, b = 0;
+#pragma unroll
+      for (u32 st = BATCH / 2; st >= 1; st >>= 1) {
+        a += (i32)S.endAt[a + st - 1] <= msrc ? st : 0u;
+        b += (i32)S.matchAt[b + st - 1] < msrcEnd ? st : 0u;
+      }
+      a += (i32)S.endAt[a] <= msrc ? 1u : 0u;
+      b += (i32)S.matchAt[b] < msrcEnd ? 1u : 0u;
+      const u64 below_b = b >= 64 ? ~0ull : (1ull << b) - 1ull, below_a = a >= 64 ? ~0ull : (1ull << a) - 1ull;
+      deps = below_b & ~below_a & ((1ull << lane) - 1ull);
+    }
+    const bool inWin = msrc >= (i32)stepStart - (i32)XPRE;       // the source lies in the window (else: in finished output, all of it, for ml <= 64)
+    u64 pending = __ballot(act);
+    while (pending) {
+      const bool mine = (pending >> lane) & 1;
+      const bool ready = mine && !(deps & pending);
+      const bool longM = ready && ml > 64;
+      if (ready && !longM) {
+        u8* const dp = W + (mdst + wb);
+        if (inWin) {
+          const u8* const sp = W + ((u32)msrc + wb);
+          if (off >= ml) copy_le64(dp, sp, ml);
+          else copy_periodic_le64(dp, sp, ml, off, S.slot[lane]);
+        } else copy_le64(dp, out + msrc, ml);                    // (off > 64 >= ml: no overlap)
+      }
+      u64 lmk = __ballot(longM);
+      while (lmk) {                            // long matches: the whole wave copies, byte by byte from wherever the byte is
+        const u32 k2 = (u32)__builtin_ctzll(lmk); lmk &= lmk - 1;
+        const u32 jml = bcast_u32(ml, k2), jd = bcast_u32(mdst, k2), jof = bcast_u32(off, k2);
+        const i32 js = (i32)jd - (i32)jof;
+        for (u32 k = lane; k < jml; k += WAVE) {
+          const i32 q = js + (i32)(jof >= jml ? k : k % jof);
+          u8 v;
+          if (q >= (i32)stepStart - (i32)XPRE) v = W[(u32)q + wb]; else v = out[q];
+          W[jd + k + wb] = v;
+        }
+        lsync();
+      }
+      pending &= ~__ballot(ready);
+      lsync();
+    }
+  }
+  // -------- the window goes out; its last XPRE bytes stay as the next step's front
+  {
+    const u8* const ws = S.win + XPRE;
+    u8* const od = out + stepStart;
+    for (u32 i = 16u * (u32)lane; i + 16 <= stepLen; i += 16u * WAVE) { const uint4 v = *(const uint4*)(ws + i); st128(od + i, v.x, v.y, v.z, v.w); }
+    const u32 tail = stepLen & ~15u;
+    if (tail + (u32)lane < stepLen) od[tail + lane] = ws[tail + lane];
+    const u8 keep = S.win[stepLen + lane];
+    lsync();
+    S.win[lane] = keep;
+    c.preValid = true;
+  }
+  wsync();
+}
+
 // block tail (remaining literals: the chain stage checked the room) and commit: a compressed block confirms its repeat offsets; then
 // the frame ends, or takes another round. FUSED: a frame that goes on is not appended to the next round's list; returns 1 when it goes on.
 template <bool FUSED>
@@ -1499,7 +1631,9 @@ __device__ __forceinline__ u32 exec_job(const ZraDecodeArgs& a, const u32 j, Exe
     const u32 incT = dpp_scan_add(tot), incL = dpp_scan_add(ll);
     XTIME(0) XCNT(9, 1) XCNT(10, cnt)
     exec_step(c, S, ll, ml, off, c.outBase + incT - tot, c.litBase + incL - ll, act, lane, a.debugSkip);
-    XTIME(3)
+#ifdef ZRA_DEC_PROFILE
+    xpt_ = __builtin_amdgcn_s_memtime();
+#endif
     c.outBase += bcast_u32(incT, 63); c.litBase += bcast_u32(incL, 63);
   }
   return exec_end<FUSED>(a, j, F, c, lane);
@@ -1763,7 +1897,7 @@ __device__ __forceinline__ void chain_consume(const ZraDecodeArgs& a, const u32 
       if (v == 2) { if (lane == 0) { ring_st(&R.bail, 1u); ring_st(&R.stop, 1u); } return; }
       litReady = true;
     }
-    exec_step(c, X, on2 ? ll : 0u, on2 ? ml : 0u, on2 ? min(off, 0x0FFFFFFFu) : 1u, outBefore, litBefore, on2, lane, 0u);
+    c.outBase = outPos; exec_step(c, X, on2 ? ll : 0u, on2 ? ml : 0u, on2 ? min(off, 0x0FFFFFFFu) : 1u, outBefore, litBefore, on2, lane, 0u);
     outPos += bcast_u32(sOut, nb - 1); litPos += bcast_u32(sLit, nb - 1);
     t += nb;
     if (lane == 0) ring_st(&R.tail, t);
