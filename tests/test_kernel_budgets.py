@@ -20,7 +20,7 @@ BUDGET = {
     "zra_dec_chain_kernel": (72, 0),     # lane = frame FSE chains
     "zra_dec_huf_kernel": (72, 0),
     "zra_dec_parse_kernel": (96, 176),   # 5 waves per SIMD asked for: 40 spilled VGPRs bought 2.1x on the stage (frames in flight are what it needs)
-    "zra_dec_exec_kernel": (96, 96),     # 5 waves per SIMD (the LDS-window step and the in-memory one side by side: 88 B of spills, the stage still gains)
+    "zra_dec_exec_kernel": (80, 160),    # 6 waves per SIMD (the LDS-window step and the in-memory one side by side: 37 spilled VGPRs, 13.3 vs 14.3 ms at 5 waves)
     "zra_mf_dfast2_kernel": (104, 0),    # the mask-resolve parse (opt-in): meant for few resident waves
     "zra_ra_small_kernel": (256, 0),     # one-launch path for small batches: all stages of a frame in one workgroup, occupancy is not its point
     "zra_entropy_kernel": (88, 8),       # 5 waves per SIMD asked for: no spills (7 cost 8 spilled VGPRs + 72 B scratch and 2 % of the bench)

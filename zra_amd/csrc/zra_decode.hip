@@ -30,7 +30,10 @@ namespace {
 
 constexpr int DEC_THREADS = 64;
 constexpr int BATCH = 64;           // sequences executed per step (one per lane)
-constexpr u32 XPRE = 64, XWIN = 3008; // execute stage: bytes in front of a step kept in LDS / largest step put together in LDS
+#ifndef ZRA_XWIN
+#define ZRA_XWIN 4032
+#endif
+constexpr u32 XPRE = 64, XWIN = ZRA_XWIN; // execute stage: bytes in front of a step kept in LDS / largest step put together in LDS
 constexpr u32 BLOCK_MAX = 128u << 10;
 
 __constant__ u32 c_ll_base[36] = {0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,18,20,22,24,28,32,40,48,64,128,256,512,1024,2048,4096,8192,16384,32768,65536};
@@ -1360,10 +1363,12 @@ zra_dec_chain_kernel(ZraDecodeArgs a) {
 // bytes only — sources mostly straddle sequence boundaries, 1.6 % of the matches could be followed.)
 namespace {
 struct __attribute__((aligned(16))) ExecShared {
-  u8 slot[BATCH][64];       // a lane's scratch for the first period of an overlapping match
+  union {
+    u8 slot[BATCH][64];     // exec_step_global: a lane's scratch for the first period of an overlapping match
+    u8 win[XPRE + XWIN];    // exec_step: the step's output while it is being put together, behind the XPRE bytes that precede it
+  };
   u32 endAt[BATCH];         // where each sequence of the step ends in the output (ascending) ...
   u32 matchAt[BATCH];       // ... and where its match begins (ascending): a match's source range is looked up in these
-  u8 win[XPRE + XWIN];      // the step's output while it is being put together, behind the XPRE bytes that precede it
   u32 job;
 };
 }  // namespace
@@ -1545,7 +1550,8 @@ __device__ __forceinline__ void exec_step(ExecCtx& c, ExecShared& S, const u32 l
         if (inWin) {
           const u8* const sp = W + ((u32)msrc + wb);
           if (off >= ml) copy_le64(dp, sp, ml);
-          else copy_periodic_le64(dp, sp, ml, off, S.slot[lane]);
+          else if (off < 8) copy_periodic_le64(dp, sp, ml, off, nullptr);
+          else { u32 pp = 0; for (u32 k = 0; k < ml; k++) { dp[k] = sp[pp]; pp = pp + 1 == off ? 0 : pp + 1; } }     // (the first period lies in front of dp, final)
         } else copy_le64(dp, out + msrc, ml);                    // (off > 64 >= ml: no overlap)
       }
       u64 lmk = __ballot(longM);
@@ -1640,9 +1646,10 @@ __device__ __forceinline__ u32 exec_job(const ZraDecodeArgs& a, const u32 j, Exe
 }
 }  // namespace
 
-// the same for the execute kernel (per-lane copies, waits on memory): 4 waves per SIMD (114 VGPRs) 26.4 ms, 5 (96, 14 spilled) 22.9, 6 (80) 23.4
+// the same for the execute kernel (per-lane copies, waits on memory). Round 2's kernel: 4 waves per SIMD (114 VGPRs) 26.4 ms, 5 (96, 14 spilled) 22.9,
+// 6 (80) 23.4. With the LDS-window step (4.6 KiB of LDS per workgroup): 5 / 6 / 8 waves -> 14.3 / 13.3 / 17.5 ms per 8 GiB.
 #ifndef ZRA_EXEC_WAVES
-#define ZRA_EXEC_WAVES 5
+#define ZRA_EXEC_WAVES 6
 #endif
 extern "C" __global__ void __launch_bounds__(DEC_THREADS, ZRA_EXEC_WAVES)
 zra_dec_exec_kernel(ZraDecodeArgs a) {
