@@ -384,10 +384,12 @@ namespace zra {
       if (done < size && rem2) {
         auto p = piece(last - 1, last);
         multiframe_call(p.first, p.second, frameBuffer.data(), frameBuffer.size(), header.frameSize);
-        // frames that regenerate less than the header's frameSize (an inflated frameSize / uncompressedSize) leave more than one frame
-        // buffer to fill here: the reference copies past its buffer (undefined); here that is a corrupted archive
-        if (size - done > frameBuffer.size()) throw Exception(StatusCode::ZStdError, 20);
-        std::memcpy(out + done, frameBuffer.data(), size - done);
+        // frames that regenerate less than the header's frameSize (damaged frames, an inflated frameSize / uncompressedSize) leave more
+        // than one frame buffer to fill here: the reference copies past its buffer and reports success (zra.cpp:293; the bytes are
+        // whatever its heap held). Same status here, the bytes behind the buffer's end defined: zero.
+        const size_t want = size - done, have = std::min(want, frameBuffer.size());
+        std::memcpy(out + done, frameBuffer.data(), have);
+        std::memset(out + done + have, 0, want - have);
       }
     }
     // infrastructure failures (allocation, launch) are not statuses of the archive: they are not retried

@@ -1904,7 +1904,7 @@ __device__ __forceinline__ void chain_consume(const ZraDecodeArgs& a, const u32 
       if (v == 2) { if (lane == 0) { ring_st(&R.bail, 1u); ring_st(&R.stop, 1u); } return; }
       litReady = true;
     }
-    c.outBase = outPos; exec_step(c, X, on2 ? ll : 0u, on2 ? ml : 0u, on2 ? min(off, 0x0FFFFFFFu) : 1u, outBefore, litBefore, on2, lane, 0u);
+    c.outBase = outPos; exec_step(c, X, on2 ? ll : 0u, on2 ? ml : 0u, on2 ? min(off, 0x0FFFFFFFu) : 1u, outBefore, litBefore, on2, lane, a.debugSkip);
     outPos += bcast_u32(sOut, nb - 1); litPos += bcast_u32(sLit, nb - 1);
     t += nb;
     if (lane == 0) ring_st(&R.tail, t);

@@ -342,7 +342,8 @@ Status Engine::decode_small(const ZraDecodeArgs& a0, const uint32_t* dExpect, ui
   };
   { Status st = decode_scratch(a, maxFrameBytes); if (st.zra) return st; }
   mark("scratch");
-  a.active = nullptr; a.nActive = n; a.round = 0; a.nextActive = decLists_.as<uint32_t>(); a.debugSkip = 0;
+  a.active = nullptr; a.nActive = n; a.round = 0; a.nextActive = decLists_.as<uint32_t>();
+  { static const int skip = std::getenv("ZRA_DEC_SKIP") ? std::atoi(std::getenv("ZRA_DEC_SKIP")) : 0; a.debugSkip = (uint32_t)skip; }
   uint32_t* dBail = a.counters + ZRA_DC_WORDS;
   HIPCHK(hipMemsetAsync(a.counters, 0, ZRA_DC_WORDS * 4 + 8, stream_));
   HIPCHK(hipEventRecord(ev0_, stream_));
