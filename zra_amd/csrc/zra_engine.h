@@ -133,7 +133,7 @@ class Engine {
   // decode scratch
   DevBuf decFrames_, decTables_, decLists_, decCounters_, decLits_, decSeqs_;
   DevBuf raPlan_, raLimit_, raPieceBase_, raPieces_;
-  std::vector<uint64_t> raHostQ_;        // query tuples of the running batch (host side of an asynchronous copy)
+  uint64_t* pinQ_ = nullptr; size_t pinQCap_ = 0;   // page-locked query tuples of the running batch (host side of an asynchronous copy)
   int decOccParse_ = 0, decOccExec_ = 0, decOccHuf_ = 0; // resident workgroups per CU of the parse / execute kernels
   bool raVerifyWholeFrames_ = false;     // batched random access decodes every touched frame in full and checks its checksum
   DevBuf status_, produced_, frameMeta_, frameOff_, outOff_, expect_, result_, temp_, qmeta_;

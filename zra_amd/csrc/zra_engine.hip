@@ -108,7 +108,7 @@ struct RaPlan {            // device scratch of one batch
 __global__ void zra_ra_count_kernel(const u64* q, u32 nq, u64 fs, RaPlan P) {
   const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nq) return;
-  const u64 off = q[3 * (size_t)i], size = q[3 * (size_t)i + 1];
+  const u64 off = q[4 * (size_t)i], size = q[4 * (size_t)i + 1];
   if (!size) return;
   const u64 f0 = off / fs, f1 = (off + size - 1) / fs;
   for (u64 f = f0; f <= f1; f++) {
@@ -164,7 +164,7 @@ __global__ void __launch_bounds__(1024) zra_ra_plan_kernel(RaPlan P, u32 nFrames
 __global__ void zra_ra_fill_kernel(const u64* q, u32 nq, u64 fs, RaPlan P, const u32* pieceBase, ZraRaPiece* pieces) {
   const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nq) return;
-  const u64 off = q[3 * (size_t)i], size = q[3 * (size_t)i + 1], dst = q[3 * (size_t)i + 2];
+  const u64 off = q[4 * (size_t)i], size = q[4 * (size_t)i + 1], dst = q[4 * (size_t)i + 2];
   if (!size) return;
   const u64 f0 = off / fs, f1 = (off + size - 1) / fs;
   u64 done = 0;
@@ -285,6 +285,7 @@ Engine::~Engine() {
   for (auto ev : stageEv_) (void)hipEventDestroy(ev);
   if (stream2_) { (void)hipStreamSynchronize(stream2_); (void)hipStreamDestroy(stream2_); }
   for (auto st : pipeStreams_) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+  if (pinQ_) (void)hipHostFree(pinQ_);
   for (auto& ev : evR_) if (ev) (void)hipEventDestroy(ev);
   if (ev0_) (void)hipEventDestroy(ev0_);
   if (ev1_) (void)hipEventDestroy(ev1_);
@@ -677,15 +678,41 @@ Status Engine::decompress_ra_batch_shard(const uint8_t* dArc, size_t arcSize, co
   // disagree (size beyond what the table covers, table outside the header) would send it out of bounds — here it is HeaderInvalid
   if ((uint64_t)h.seekTableOffset + h.seekTableSize > h.size) return {kHeaderInvalid, 0};
   if (fs && U && (U + fs - 1) / fs != nFrames) return {kHeaderInvalid, 0};
-  for (size_t q = 0; q < nq; q++)
-    if (hSize[q] >= U || hOff[q] >= U - hSize[q]) return {kOutOfBounds, 0};   // offset + size >= uncompressedSize (">=" quirk, zra.cpp:260), overflow-safe
-  if (nq == 0 || fs == 0 || nFrames == 0) return ok();
+  if (nq == 0) return ok();
   if (nq > 0xFFFFFFF0ull) return zerr(64);
-
-  // slices: one per frame a query touches
+  // one walk over the queries: the reference's bound (offset + size >= uncompressedSize is refused: the ">=" quirk, zra.cpp:260;
+  // overflow-safe), the slices (one per frame a query touches) and the (offset, size, destination, first slice) tuples the device
+  // kernels read — written straight into page-locked memory, so that their copy runs at bus speed beside the launches that follow
+  if (pinQCap_ < 4 * nq) {
+    if (pinQ_) (void)hipHostFree(pinQ_);
+    pinQ_ = nullptr; pinQCap_ = 0;
+    void* pq = nullptr;
+    const size_t cap = std::max<size_t>(4 * nq, 4096);
+    if (hipHostMalloc(&pq, cap * 8 + 64, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return zerr(64); }
+    pinQ_ = (uint64_t*)pq; pinQCap_ = cap;
+  }
+  uint64_t* const hq = pinQ_;
   uint64_t maxPieces = 0;
-  for (size_t q = 0; q < nq; q++) maxPieces += hSize[q] ? (hOff[q] + hSize[q] - 1) / fs - hOff[q] / fs + 1 : 0;
-  if (maxPieces == 0) return ok();
+  const bool pow2 = fs && !(fs & (fs - 1));
+  const unsigned fsLog = pow2 ? (unsigned)__builtin_ctzll(fs) : 0u;
+  if (fs == 0 || nFrames == 0) {
+    for (size_t q = 0; q < nq; q++) if (hSize[q] >= U || hOff[q] >= U - hSize[q]) return {kOutOfBounds, 0};
+    return ok();
+  }
+  if (!qmeta_.reserve(4 * nq * 8 + 64)) return zerr(64);
+  constexpr size_t kChunk = 1u << 17;                   // tuples go to the device while the next ones are being written
+  for (size_t q0 = 0; q0 < nq; q0 += kChunk) {
+    const size_t q1 = std::min(nq, q0 + kChunk);
+    for (size_t q = q0; q < q1; q++) {
+      const uint64_t o = hOff[q], z = hSize[q];
+      if (z >= U || o >= U - z) { (void)hipStreamSynchronize(stream_); return {kOutOfBounds, 0}; }
+      hq[4 * q] = o; hq[4 * q + 1] = z; hq[4 * q + 2] = hOutOff[q]; hq[4 * q + 3] = maxPieces;
+      if (z) maxPieces += pow2 ? ((o + z - 1) >> fsLog) - (o >> fsLog) + 1 : (o + z - 1) / fs - o / fs + 1;
+    }
+    HIPCHK(hipMemcpyAsync(qmeta_.as<uint64_t>() + 4 * q0, hq + 4 * q0, (q1 - q0) * 32, hipMemcpyHostToDevice, stream_));
+  }
+  if (maxPieces == 0) { HIPCHK(hipStreamSynchronize(stream_)); return ok(); }
+  mark("queries");
   const uint64_t tempBudget = 16ull << 30;
   const uint32_t passSlots = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(nFrames, tempBudget / fs));
   const bool direct = maxPieces * 8 <= nFrames && maxPieces <= passSlots;
@@ -695,28 +722,14 @@ Status Engine::decompress_ra_batch_shard(const uint8_t* dArc, size_t arcSize, co
     return zerr(64);
   uint32_t touched = 0;
   if (direct) {
-    // queries -> device (offset, size, destination, first slice) tuples
-    std::vector<uint64_t>& hq = raHostQ_;            // lives until the decode below has synchronised
-    hq.resize(4 * nq);
-    uint64_t first = 0;
-    for (size_t q = 0; q < nq; q++) {
-      hq[4 * q] = hOff[q]; hq[4 * q + 1] = hSize[q]; hq[4 * q + 2] = hOutOff[q]; hq[4 * q + 3] = first;
-      first += hSize[q] ? (hOff[q] + hSize[q] - 1) / fs - hOff[q] / fs + 1 : 0;
-    }
-    if (!qmeta_.reserve(hq.size() * 8 + 64)) return zerr(64);
-    HIPCHK(hipMemcpyAsync(qmeta_.p, hq.data(), hq.size() * 8, hipMemcpyHostToDevice, stream_));
     hipLaunchKernelGGL(zra_ra_direct_kernel, dim3((uint32_t)((nq + 255) / 256)), dim3(256), 0, stream_, qmeta_.as<uint64_t>(), (u32)nq, (u32)maxPieces, (u64)fs,
                        (u64)U, dArc + h.seekTableOffset, (u64)bodyBase, raVerifyWholeFrames_ ? 1u : 0u, frameOff_.as<uint64_t>(), outOff_.as<uint64_t>(),
                        expect_.as<uint32_t>(), raLimit_.as<uint32_t>(), raPieceBase_.as<uint32_t>(), raPieces_.as<ZraRaPiece>());
     touched = (uint32_t)maxPieces;
     mark("jobs queued");
   } else {
-    // queries -> device (offset, size, destination) triples
-    std::vector<uint64_t> hq(3 * nq);
-    for (size_t q = 0; q < nq; q++) { hq[3 * q] = hOff[q]; hq[3 * q + 1] = hSize[q]; hq[3 * q + 2] = hOutOff[q]; }
     const size_t planWords = 4 * (size_t)nFrames + 16;
-    if (!qmeta_.reserve(hq.size() * 8 + 64) || !raPlan_.reserve(planWords * 4)) return zerr(64);
-    HIPCHK(hipMemcpyAsync(qmeta_.p, hq.data(), hq.size() * 8, hipMemcpyHostToDevice, stream_));
+    if (!raPlan_.reserve(planWords * 4)) return zerr(64);
     HIPCHK(hipMemsetAsync(raPlan_.p, 0, planWords * 4, stream_));
     RaPlan P;
     P.cnt = raPlan_.as<uint32_t>(); P.need = P.cnt + nFrames; P.slot = P.need + nFrames; P.cursor = P.slot + nFrames; P.totals = P.cursor + nFrames;
@@ -732,6 +745,7 @@ Status Engine::decompress_ra_batch_shard(const uint8_t* dArc, size_t arcSize, co
     HIPCHK(hipStreamSynchronize(stream_));
     HIPCHK(hipGetLastError());
     touched = totals[0];
+    mark("plan");
   }
   if (!touched) return ok();
   // decode the touched frames, a scratch window of passSlots frames at a time (only frames that are decoded in full — or larger
