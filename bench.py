@@ -166,10 +166,19 @@ def kernel_source_sha():
     return h.hexdigest()[:16]
 
 
+def under_profiler():
+    """rocprofv3 preloads a library that initialises the GPU in every process of the tree: programs started from here (rocm-smi, the
+    CLI counterpart) would then be 'an exec after the GPU was initialised', which the GPU pool refuses. The probes that start programs
+    are skipped under the profiler (the profiled run is there for the kernel table, the plain run carries the probes)."""
+    return any(k.startswith(("ROCPROFILER", "ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
+
+
 def gpu_clocks():
     """Current shader / memory clocks, power and performance level of GPU 0 as rocm-smi reports them (None when it cannot be asked):
     recorded before and after the timed region, because the same build reads two different match-finder times on different boxes."""
     import subprocess
+    if under_profiler():
+        return None
     try:
         r = subprocess.run(["rocm-smi", "-d", "0", "--showclocks", "--showpower", "--showperflevel", "--showtemp", "--json"], capture_output=True, text=True, timeout=20)
         j = json.loads(r.stdout)
@@ -190,7 +199,7 @@ def host_pointer_calls(level, fs, gib=4):
     state of the C ABI, third repetition) and the streaming Compressor / FullDecompressor with the reference tool's 10 MB buffers."""
     import subprocess, re
     tool = os.path.join(HERE, "zra_amd", "tools", "zratool_amd")
-    if not os.path.exists(tool):
+    if under_profiler() or not os.path.exists(tool):
         return None
     path = "/tmp/zra_bench_host_%d.bin" % os.getpid()
     try:
