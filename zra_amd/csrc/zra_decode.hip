@@ -1204,8 +1204,11 @@ struct Zds {
 
 }  // namespace
 
-extern "C" __global__ void __launch_bounds__(DEC_THREADS)
-zra_dec_chain_kernel(ZraDecodeArgs a) {
+namespace {
+// LDSTAB: the tables of the wave's frames live in LDS (ZRA_CHAIN_LDS_FRAMES slots of 5 KiB: lanes beyond them take no frames); a
+// frame's table is copied there by the whole wave when a lane takes the frame. The step itself is the same code.
+template <bool LDSTAB>
+__device__ __forceinline__ void chain_body(const ZraDecodeArgs& a, u32* const ldsTabs, u32* const baseLL, u32* const baseML) {
   const int lane = threadIdx.x;
   const u32 nPend = a.counters[ZRA_DC_NPENDING];
   // per-lane job state
@@ -1223,11 +1226,16 @@ zra_dec_chain_kernel(ZraDecodeArgs a) {
   // the table cells of the sequence about to be decoded: requested one step ahead, together with the container reload
   u32 eL = 0, eM = 0, eO = 0;
   bool wide = false; const u8* pad = nullptr;
-  auto fetch_cells = [&]() { eL = T[ZRA_DEC_TBL_LL + sLL]; eM = T[ZRA_DEC_TBL_ML + sML]; eO = T[ZRA_DEC_TBL_OF + sOF]; };
+  bool fresh = false; u32 freshJob = 0;
+  const u32 slotBase = (u32)lane * ZRA_DEC_TBL_WORDS;
+  auto fetch_cells = [&]() {
+    if (LDSTAB) { eL = ldsTabs[slotBase + ZRA_DEC_TBL_LL + sLL]; eM = ldsTabs[slotBase + ZRA_DEC_TBL_ML + sML]; eO = ldsTabs[slotBase + ZRA_DEC_TBL_OF + sOF]; }
+    else { eL = T[ZRA_DEC_TBL_LL + sLL]; eM = T[ZRA_DEC_TBL_ML + sML]; eO = T[ZRA_DEC_TBL_OF + sOF]; }
+  };
   // base values of the length codes (the cells carry the code only)
-  __shared__ u32 baseLL[64], baseML[64];
   baseLL[lane] = lane < 36 ? c_ll_base[lane] : 0u; baseML[lane] = lane < 53 ? c_ml_base[lane] : 0u;
   wsync();
+  if (LDSTAB && (u32)lane >= ZRA_CHAIN_LDS_FRAMES) drained = true;
 
   auto finish = [&]() {
     // the last one to three sequences still sit in registers
@@ -1279,11 +1287,24 @@ zra_dec_chain_kernel(ZraDecodeArgs a) {
               sML = br.read(F->mlLog); br.reload();
               wide = F->bsize - F->seqPos >= 8;
               pad = a.body + a.frameOff[gj * a.offStride];          // the frame's first bytes: always 8 readable ones
-              fetch_cells();
+              if (LDSTAB) { fresh = true; freshJob = j; } else fetch_cells();
             }
           }
         }
       }
+    }
+    if (LDSTAB) {
+      // the tables of the frames just taken: global scratch -> the lanes' LDS slots, 16 bytes per lane and step, the whole wave on each
+      u64 nm = __ballot(fresh);
+      while (nm) {
+        const u32 l = (u32)__builtin_ctzll(nm); nm &= nm - 1;
+        const u32 jj = bcast_u32(freshJob, l);
+        const uint4* const g4 = (const uint4*)(a.tables + (size_t)jj * ZRA_DEC_TBL_WORDS);
+        uint4* const d4 = (uint4*)(ldsTabs + l * ZRA_DEC_TBL_WORDS);
+        for (u32 i = (u32)lane; i < ZRA_DEC_TBL_WORDS / 4; i += DEC_THREADS) d4[i] = g4[i];
+      }
+      if (__ballot(fresh)) wsync();
+      if (fresh) { fetch_cells(); fresh = false; }
     }
     if (!__ballot(have)) break;
 
@@ -1353,6 +1374,21 @@ zra_dec_chain_kernel(ZraDecodeArgs a) {
       }
     }
   }
+}
+}  // namespace
+
+extern "C" __global__ void __launch_bounds__(DEC_THREADS)
+zra_dec_chain_kernel(ZraDecodeArgs a) {
+  __shared__ u32 baseLL[64], baseML[64];
+  chain_body<false>(a, nullptr, baseLL, baseML);
+}
+// the same with the tables in LDS: one workgroup per CU (dynamic LDS: ZRA_CHAIN_LDS_FRAMES tables + the two base-value tables), launched
+// beside zra_dec_chain_kernel on another stream; both pull frames from the same queue. What this wave decodes asks nothing of L2 and
+// the fabric but its bitstream and its sequences.
+extern "C" __global__ void __launch_bounds__(DEC_THREADS)
+zra_dec_chain_lds_kernel(ZraDecodeArgs a) {
+  extern __shared__ u32 chainLds[];
+  chain_body<true>(a, chainLds + 128, chainLds, chainLds + 64);
 }
 
 // =================================================================================================

@@ -13,6 +13,7 @@
 extern "C" __global__ void zra_dec_parse_kernel(ZraDecodeArgs a);
 extern "C" __global__ void zra_dec_huf_kernel(ZraDecodeArgs a);
 extern "C" __global__ void zra_dec_chain_kernel(ZraDecodeArgs a);
+extern "C" __global__ void zra_dec_chain_lds_kernel(ZraDecodeArgs a);
 extern "C" __global__ void zra_dec_exec_kernel(ZraDecodeArgs a);
 extern "C" __global__ void zra_ra_small_kernel(ZraDecodeArgs a, uint32_t* bail);
 
@@ -395,6 +396,7 @@ Status Engine::decode_launch(const ZraDecodeArgs& a0, const uint32_t* dExpect, u
   { static const int skip = std::getenv("ZRA_DEC_SKIP") ? std::atoi(std::getenv("ZRA_DEC_SKIP")) : 0; a.debugSkip = (uint32_t)skip; }
   HIPCHK(hipEventRecord(ev0_, stream_));
   static const uint32_t chainWaves = std::getenv("ZRA_DEC_CHAIN_WAVES") ? (uint32_t)std::atoi(std::getenv("ZRA_DEC_CHAIN_WAVES")) : 2u;
+  static const bool chainLdsOn = std::getenv("ZRA_DEC_CHAIN_LDS") ? std::atoi(std::getenv("ZRA_DEC_CHAIN_LDS")) != 0 : true;
   static const uint32_t chainGrid = std::getenv("ZRA_DEC_CHAIN_GRID") ? (uint32_t)std::atoi(std::getenv("ZRA_DEC_CHAIN_GRID")) : 0u;        // bring-up: absolute wave count
   // the rounds of one set of jobs, one stage after the other on the engine's stream (resident waves per CU of the chain kernel — lane =
   // frame, 64 frames' tables per wave: fewer frames in flight keep more of their table cells in the caches; A/B on one box, round 3,
@@ -415,7 +417,27 @@ Status Engine::decode_launch(const ZraDecodeArgs& a0, const uint32_t* dExpect, u
       HIPCHK(hipEventRecord(se[1], stream_));
       hipLaunchKernelGGL(zra_dec_huf_kernel, dim3((uint32_t)std::min<uint64_t>((nActive + ZRA_HUF_FRAMES - 1) / ZRA_HUF_FRAMES, (uint64_t)numCUs_ * decOccHuf_)), dim3(64), 0, stream_, x);
       HIPCHK(hipEventRecord(se[2], stream_));
-      hipLaunchKernelGGL(zra_dec_chain_kernel, dim3(gridChain), dim3(64), 0, stream_, x);
+      // beside the lane-per-frame chain kernel (tables in HBM scratch, two waves per CU) one workgroup per CU with its frames' tables in
+      // LDS, on another stream, pulling from the same queue
+      bool forked = false;
+      if (chainLdsOn && nActive >= (uint32_t)numCUs_ * 96u) {
+        if (!pipeStreams_[1]) { if (hipStreamCreateWithFlags(&pipeStreams_[1], hipStreamNonBlocking) != hipSuccess) { pipeStreams_[1] = nullptr; (void)hipGetLastError(); } }
+        const size_t ldsBytes = (128 + (size_t)ZRA_CHAIN_LDS_FRAMES * ZRA_DEC_TBL_WORDS) * 4;
+        if (pipeStreams_[1] && !chainLdsAttr_) {
+          if (hipFuncSetAttribute((const void*)zra_dec_chain_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes) == hipSuccess) chainLdsAttr_ = 1;
+          else { chainLdsAttr_ = -1; (void)hipGetLastError(); }
+        }
+        if (pipeStreams_[1] && chainLdsAttr_ > 0) {
+          hipEvent_t eJoin = stage_event(); if (!eJoin) return zerr(1);
+          HIPCHK(hipStreamWaitEvent(pipeStreams_[1], se[2], 0));
+          hipLaunchKernelGGL(zra_dec_chain_lds_kernel, dim3((uint32_t)numCUs_), dim3(64), ldsBytes, pipeStreams_[1], x);
+          HIPCHK(hipEventRecord(eJoin, pipeStreams_[1]));
+          hipLaunchKernelGGL(zra_dec_chain_kernel, dim3(gridChain), dim3(64), 0, stream_, x);
+          HIPCHK(hipStreamWaitEvent(stream_, eJoin, 0));
+          forked = true;
+        }
+      }
+      if (!forked) hipLaunchKernelGGL(zra_dec_chain_kernel, dim3(gridChain), dim3(64), 0, stream_, x);
       HIPCHK(hipEventRecord(se[3], stream_));
       hipLaunchKernelGGL(zra_dec_exec_kernel, dim3(gridExec), dim3(64), 0, stream_, x);
       HIPCHK(hipEventRecord(se[4], stream_));

@@ -26,6 +26,9 @@
 #define ZRA_LDS_TBL_ML 1024u    // 512 cells x 8 B
 #define ZRA_LDS_TBL_OF 2048u    // 256 cells x 4 B
 #define ZRA_LDS_TBL_WORDS 2304u
+// zra_dec_chain_lds_kernel: frames (= lanes) whose tables one workgroup keeps in LDS (31 x 5 KiB + 512 B of 160 KiB; the rest leaves
+// room for two workgroups of zra_dec_chain_kernel on the same CU)
+#define ZRA_CHAIN_LDS_FRAMES 31u
 
 // per-frame decode state; lives in HBM scratch for the whole call (frames take one round per compressed block)
 struct ZraDecFrame {
