@@ -19,7 +19,7 @@ BUDGET = {
     "zra_mf_opt_kernel": (136, 400),     # ... with them (levels 13-22; its scratch holds the parser's small arrays)
     "zra_dec_chain_kernel": (72, 0),     # lane = frame FSE chains
     "zra_dec_chain_lds_kernel": (80, 0), # the same with its frames' tables in LDS, one workgroup per CU beside it
-    "zra_dec_huf_kernel": (72, 0),
+    "zra_dec_huf_kernel": (88, 0),       # wave-wide literal decode (two stream readers while a restarted lane looks for its previous path); 8.5 KiB of LDS per workgroup is its occupancy limit
     "zra_dec_parse_kernel": (96, 176),   # 5 waves per SIMD asked for: 40 spilled VGPRs bought 2.1x on the stage (frames in flight are what it needs)
     "zra_dec_exec_kernel": (80, 160),    # 6 waves per SIMD (the LDS-window step and the in-memory one side by side: 37 spilled VGPRs, 13.3 vs 14.3 ms at 5 waves)
     "zra_mf_dfast2_kernel": (104, 0),    # the mask-resolve parse (opt-in): meant for few resident waves

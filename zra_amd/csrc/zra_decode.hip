@@ -1079,18 +1079,38 @@ __device__ __forceinline__ bool huf_decode_wave(const ZraDecodeArgs& a, const Zr
   u32 n = 0;
   bool dirty = active;
   BitRS hb;
+  i32 prevStart = start;
   for (int it = 0; it < 6 && __ballot(dirty); it++) {
     if (dirty) {
-      hb.init_at(sb, lim, start); n = 0;
-      while (hb.pos > lower) {
-        hb.ensure(4 * mb);
-#pragma unroll
-        for (int k = 0; k < 4; k++) if (hb.pos > lower) { const u32 e = tab[hb.peek(mb)]; hb.skip((int)(e >> 8)); n++; }
+      // a restarted lane first walks its new path and its previous one side by side, a code at a time on whichever is behind: the
+      // two fall into step after a few codes, and from there on count and hand-over point are the previous pass's — the run is not
+      // decoded again. (No meeting point within 96 codes, or the first pass: the whole run.)
+      bool merged = false;
+      if (it) {
+        BitRS ho;
+        hb.init_at(sb, lim, start); ho.init_at(sb, lim, prevStart);
+        u32 ka = 0, kb = 0;
+        for (int k = 0; k < 96; k++) {
+          if (hb.pos == ho.pos) { merged = true; break; }
+          if (hb.pos <= lower || ho.pos <= lower) break;
+          if (hb.pos > ho.pos) { hb.ensure(mb); const u32 e = tab[hb.peek(mb)]; hb.skip((int)(e >> 8)); ka++; }
+          else { ho.ensure(mb); const u32 e = tab[ho.peek(mb)]; ho.skip((int)(e >> 8)); kb++; }
+        }
+        if (merged) n = ka + (n - kb);
       }
-      end = hb.pos;
+      if (!merged) {
+        hb.init_at(sb, lim, start); n = 0;
+        while (hb.pos > lower) {
+          hb.ensure(4 * mb);
+#pragma unroll
+          for (int k = 0; k < 4; k++) if (hb.pos > lower) { const u32 e = tab[hb.peek(mb)]; hb.skip((int)(e >> 8)); n++; }
+        }
+        end = hb.pos;
+      }
     }
     const i32 handed = (i32)__shfl_up(end, 1, 64);                   // (every lane takes part: a lane that sits out returns 0 to its reader)
     const i32 ns = t == 0 ? (i32)P : handed;
+    prevStart = start;
     dirty = active && ns != start;
     start = ns;
 #ifdef ZRA_SMALL_PROFILE
