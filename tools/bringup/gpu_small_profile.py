@@ -28,4 +28,5 @@ for bs in (1, 64):
         print("  parse, cycles per job: to the literals header %.0f  literals header + tree %.0f  sequences header %.0f  table descriptions %.0f  table builds %.0f  hand-over %.0f" % tuple(v[k] / nj for k in (8, 9, 10, 11, 12, 13)))
         print("  wave-wide Huffman: done %d, handed to the serial decoders %d (reached the checks %d, not converged %d)" % (v[14], v[15], v[6], v[7]))
         print("  wave-wide Huffman: lanes restarted after pass 1..6 (per job): %s" % " ".join("%.1f" % (v[16 + k] / nj) for k in range(6)))
+        print("  literals header, lane 0, cycles per job: header fields %.0f  weight description %.0f  weight table %.0f  weight decode %.0f" % tuple(v[k] / nj for k in (20, 21, 22, 23)))
         print("  jobs %d; cycles per job: parse %.0f  huffman %.0f  chain producer %.0f  chain consumer %.0f  execute %.0f" % (nj, v[0] / nj, v[1] / nj, v[2] / nj, v[5] / nj, v[3] / nj))

@@ -77,9 +77,13 @@ extern "C" __attribute__((visibility("default"))) void ZraHipDebugReadSmallProfi
 #ifdef ZRA_SMALL_PROFILE
 #define PPROF_T0 u64 ppt_ = __builtin_amdgcn_s_memtime();
 #define PPROF(k) if (FUSED) { __builtin_amdgcn_s_waitcnt(0); const u64 n_ = __builtin_amdgcn_s_memtime(); if (lane == 0) atomicAdd(&zra_small_prof[k], n_ - ppt_); ppt_ = n_; }
+#define LPROF_T0 u64 lpt_ = __builtin_amdgcn_s_memtime();
+#define LPROF(k) { __builtin_amdgcn_s_waitcnt(0); const u64 n_ = __builtin_amdgcn_s_memtime(); atomicAdd(&zra_small_prof[k], n_ - lpt_); lpt_ = n_; }
 #else
 #define PPROF_T0
 #define PPROF(k)
+#define LPROF_T0
+#define LPROF(k)
 #endif
 constexpr u32 STAGE_BYTES = 512;     // header bytes copied to LDS per window (frame + block + literals header + tree description: <= 160)
 struct __attribute__((aligned(16))) ParseShared {
@@ -102,7 +106,8 @@ struct __attribute__((aligned(16))) ParseShared {
   u32 blkType, blkSize, blkLast, blkPos, hdrPos, frameEnd, winPos, winLen;
   u32 litType, litRegen, litComp, litHdr, litStreams, litRle;
   u32 hufValid, hufMaxBits, hufNSym, hufX2;
-  u32 hufNw, hufUsed, hufPhase;   // a tree description read by lane 0 (weights[0..hufNw)), waiting for the wave-wide part
+  u32 hufNw, hufUsed, hufPhase;   // a tree description read by lane 0 (weights[0..hufNw)), waiting for the wave-wide part (phase 1);
+  u32 hufTl, hufMaxSym, hufNcBytes, hufHbyte;   // ... or (phase 2) an FSE-coded one whose table description lane 0 has read into norm[]
   u32 nbSeq, seqPos, seqModes;
   u32 llLog, mlLog, ofLog, llValid, mlValid, ofValid, ofShare;
   u32 rep[3];
@@ -336,6 +341,7 @@ __device__ __forceinline__ void copy_periodic_le64(u8* dp, const u8* sp, u32 n, 
 // Check order of ZSTD_decodeLiteralsBlock (zstd_decompress_block.c of 1.4.9).
 __device__ __forceinline__ void parse_literals_header(ParseShared& S, const u8* src, u32 n, const u8* lim) {
   S.hufPhase = 0;
+  LPROF_T0
   if (n < 3) { S.err = ZE_CORRUPTION; return; }                       // MIN_CBLOCK_SIZE
   u32 b0 = src[0], type = b0 & 3, sf = (b0 >> 2) & 3;
   S.litType = type;
@@ -372,41 +378,76 @@ __device__ __forceinline__ void parse_literals_header(ParseShared& S, const u8* 
       used = 1 + hbyte;
       if (used > rem || hbyte < 1) { S.err = ZE_CORRUPTION; return; }
       u32 maxSym = 255, tl;
+      LPROF(20)
       u32 h = read_ncount(S.norm, &maxSym, &tl, p + 1, hbyte, 6, lim);
       if (!h) { S.err = ZE_CORRUPTION; return; }
-      // small serial FSE decode of the weights (<= 255 symbols); table of <= 64 cells
-      u64* const wt = S.wt;
-      u16* const next = S.wnext;
-      {
-        u32 size = 1u << tl, mask = size - 1, high = size - 1, step = (size >> 1) + (size >> 3) + 3, pos = 0;
-        for (u32 s = 0; s <= maxSym; s++) { next[s] = S.norm[s] == -1 ? 1 : (u16)S.norm[s]; if (S.norm[s] == -1) S.spread[high--] = (u8)s; }
-        for (u32 s = 0; s <= maxSym; s++)
-          for (int i = 0; i < S.norm[s]; i++) { S.spread[pos] = (u8)s; pos = (pos + step) & mask; while (pos > high) pos = (pos + step) & mask; }
-        if (pos != 0) { S.err = ZE_CORRUPTION; return; }
-        for (u32 u = 0; u < size; u++) {
-          u32 s = S.spread[u], x = next[s]++;
-          u32 nbBits = tl - hb32(x);
-          wt[u] = mk_seqsym(s, 0, nbBits, (x << nbBits) - size);
-        }
-      }
-      BitR br;
-      if (br.init(p + 1 + h, hbyte - h, lim)) { S.err = ZE_CORRUPTION; return; }
-      u32 s1 = br.read((int)tl), s2 = br.read((int)tl);
-      for (;;) {
-        if (nw >= 254) { S.err = ZE_CORRUPTION; return; }
-        u64 e1 = wt[s1];
-        S.weights[nw++] = (u8)e1;
-        s1 = (u32)(e1 >> 48) + br.read((int)((e1 >> 40) & 0xFF));
-        if (br.pos < 0) { S.weights[nw++] = (u8)wt[s2]; break; }
-        if (nw >= 254) { S.err = ZE_CORRUPTION; return; }
-        u64 e2 = wt[s2];
-        S.weights[nw++] = (u8)e2;
-        s2 = (u32)(e2 >> 48) + br.read((int)((e2 >> 40) & 0xFF));
-        if (br.pos < 0) { S.weights[nw++] = (u8)wt[s1]; break; }
-      }
+      LPROF(21)
+      // the FSE-coded weights themselves: huf_weights_decode, by the wave
+      S.hufTl = tl; S.hufMaxSym = maxSym; S.hufNcBytes = h; S.hufHbyte = hbyte; S.hufUsed = used; S.hufPhase = 2;
+      return;
     }
     S.hufNw = nw; S.hufUsed = used; S.hufPhase = 1;
   }
+}
+
+// FSE-coded Huffman weights (FSE_decompress_wksp inside HUF_readStats): two interleaved states over a table of <= 64 cells. The table
+// is built wave-wide (build_fse_dtable, one cell per lane) and stays in a REGISTER, cell u in lane u: the decode — serial by nature,
+// one lane's worth of work run by all lanes in step — fetches a cell with v_readlane instead of an LDS round trip per weight (it was
+// 71 k of the parse stage's 190 k cycles per frame, the serial table build 15 k more). Descriptions that name symbols beyond 63
+// (no valid tree has them) take the serial build and LDS cells.
+__device__ __forceinline__ void huf_weights_decode(ParseShared& S, const u8* src, const u8* lim, const int lane) {
+  const u32 tl = S.hufTl, maxSym = S.hufMaxSym, h = S.hufNcBytes, hbyte = S.hufHbyte;
+  const u8* const p = src + S.litHdr;
+  const u32 size = 1u << tl;
+  const bool inRegs = maxSym < 64;
+  u32 cellReg = 0;
+  if (inRegs) {
+    build_fse_dtable(S.stage, S.norm, maxSym, tl, 2, S.spread, (u64*)S.w1, S.wnext, lane);
+    wsync();
+    cellReg = (u32)lane < size ? S.stage[lane] : 0u;
+  } else {
+    if (lane == 0) {
+      u64* const wt = S.wt; u16* const next = S.wnext;
+      u32 mask = size - 1, high = size - 1, step = (size >> 1) + (size >> 3) + 3, pos = 0;
+      for (u32 s = 0; s <= maxSym; s++) { next[s] = S.norm[s] == -1 ? 1 : (u16)S.norm[s]; if (S.norm[s] == -1) S.spread[high--] = (u8)s; }
+      for (u32 s = 0; s <= maxSym; s++)
+        for (int i = 0; i < S.norm[s]; i++) { S.spread[pos] = (u8)s; pos = (pos + step) & mask; while (pos > high) pos = (pos + step) & mask; }
+      for (u32 u = 0; u < size; u++) {
+        u32 s = S.spread[u], x = next[s]++;
+        u32 nbBits = tl - hb32(x);
+        wt[u] = mk_seqsym(s, 0, nbBits, (x << nbBits) - size);
+      }
+    }
+    wsync();
+  }
+  // cell of a state: {symbol, state bits, base of the next state}
+  auto cell = [&](u32 st, u32& sym, u32& nb, u32& nextBase) {
+    if (inRegs) { const u32 e = bcast_u32(cellReg, st); sym = e & 0xFF; nb = (e >> 16) & 0xF; nextBase = e >> 20; }
+    else { const u64 e = S.wt[st]; sym = (u32)e & 0xFF; nb = (u32)(e >> 40) & 0xFF; nextBase = (u32)(e >> 48); }
+  };
+  bool bad = false;
+  u32 nw = 0;
+  BitR br;
+  if (br.init(p + 1 + h, hbyte - h, lim)) bad = true;
+  else {
+    u32 s1 = br.read((int)tl), s2 = br.read((int)tl);
+    for (;;) {
+      u32 sym, nb, nx;
+      if (nw >= 254) { bad = true; break; }
+      cell(s1, sym, nb, nx);
+      if (lane == 0) S.weights[nw] = (u8)sym;
+      nw++;
+      s1 = nx + br.read((int)nb);
+      if (br.pos < 0) { cell(s2, sym, nb, nx); if (lane == 0) S.weights[nw] = (u8)sym; nw++; break; }
+      if (nw >= 254) { bad = true; break; }
+      cell(s2, sym, nb, nx);
+      if (lane == 0) S.weights[nw] = (u8)sym;
+      nw++;
+      s2 = nx + br.read((int)nb);
+      if (br.pos < 0) { cell(s1, sym, nb, nx); if (lane == 0) S.weights[nw] = (u8)sym; nw++; break; }
+    }
+  }
+  if (lane == 0) { if (bad) S.err = ZE_CORRUPTION; else { S.hufNw = nw; S.hufPhase = 1; } }
 }
 
 // The rest of HUF_readStats / HUF_readDTableX1 for a tree description lane 0 has read (S.weights[0..hufNw)), by the whole wave: the
@@ -740,7 +781,8 @@ __device__ __forceinline__ u32 parse_job(const ZraDecodeArgs& a, const u32 j, Pa
         parse_literals_header(S, win + bpos, bsize, S.w0 + STAGE_BYTES + 8);
       }
       wsync();
-      if (!S.err && S.hufPhase) huf_tree_finish(S, lane);
+      if (!S.err && S.hufPhase == 2) { huf_weights_decode(S, win + bpos, S.w0 + STAGE_BYTES + 8, lane); wsync(); }
+      if (!S.err && S.hufPhase == 1) huf_tree_finish(S, lane);
       wsync();
       if (lane == 0) {
         if (!S.err && S.litType >= 2) literal_streams_layout(S, win + bpos);
