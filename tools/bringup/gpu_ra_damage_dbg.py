@@ -18,6 +18,10 @@ for case, a in C.mutated_archives(20000 + seed, 50, O.zra_compress):
         wq, qbytes = O.zra_ra(a, off, size, backend)
         try:
             g = Z.DecompressRA(a, off, size); mine = (0, 0, g == qbytes)
+            if wq == (0, 0) and g != qbytes:
+                other = O.zra_ra(a, off, size, "zo")[1]
+                d = [i for i in range(min(len(g), len(qbytes))) if g[i] != qbytes[i]]
+                print("   lens", len(g), len(qbytes), "zo==zl", other == qbytes, "first diff", d[:3], "ndiff", len(d), "ours", g[d[0]:d[0]+8].hex() if d else "", "oracle", qbytes[d[0]:d[0]+8].hex() if d else "")
         except Z.ZraError as e:
             mine = (e.zra, e.zstd)
         print("case", case, "U", U, "fs", fs, "len", len(a), "query", (off, size), "oracle", wq, "ours", mine, flush=True)
