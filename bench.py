@@ -156,13 +156,18 @@ def cpu_baseline(sample, frame_size, level, nq, qsize, seed=42):
 
 
 def kernel_source_sha():
-    """sha256 over the kernel sources (zra_amd/csrc, sorted by name): ties a PMC measurement in profiles/traffic.json to a build."""
-    import hashlib
+    """sha256 over the kernel sources (zra_amd/csrc, sorted by name) with comments and white space taken out: ties a PMC measurement
+    in profiles/traffic.json to the CODE of a build (a reworded comment does not make a measurement stale)."""
+    import hashlib, re
     h = hashlib.sha256()
     d = os.path.join(HERE, "zra_amd", "csrc")
     for f in sorted(os.listdir(d)):
         if f.endswith((".hip", ".h", ".cpp")):
-            h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+            t = open(os.path.join(d, f), "r", errors="replace").read()
+            t = re.sub(r"/\*.*?\*/", " ", t, flags=re.S)
+            t = re.sub(r"//[^\n]*", " ", t)
+            t = re.sub(r"\s+", " ", t)
+            h.update(f.encode()); h.update(t.encode())
     return h.hexdigest()[:16]
 
 

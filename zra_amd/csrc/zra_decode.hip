@@ -6,17 +6,25 @@
 // than half of all instructions. So the work of a frame is split by its SHAPE into four kernels that run once per round
 // (a round = one compressed block of every unfinished frame; 64 KiB ZRA frames take exactly one):
 //
-//   zra_dec_parse_kernel   wave per frame. Frame / block / literal / sequence headers (lane 0), the Huffman weights, the three FSE
-//                          decode tables (built in LDS, stored to the frame's table scratch in HBM). Raw and RLE blocks and
-//                          the frame end are handled on the way; a compressed block is handed on.
-//   zra_dec_huf_kernel     16 frames per wave, four lanes per frame (one per Huffman stream): decode tables of the batch in LDS,
-//                          literals to a bump-allocated scratch, sixteen at a time.
+//   zra_dec_parse_kernel   wave per frame. Frame / block / literal / sequence headers and the bit-serial table descriptions (lane 0);
+//                          the Huffman weights (FSE table in a register, one cell per lane), the tree's rank arithmetic and the
+//                          three FSE decode tables wave-wide (built in LDS, stored as 4-byte cells to the frame's table scratch in
+//                          HBM). Raw and RLE blocks and the frame end are handled on the way; a compressed block is handed on.
+//   zra_dec_huf_kernel     the whole wave on one frame's literal streams: 16 self-synchronising runs per stream decoded side by side
+//                          from guessed starts, restarted from the predecessor's hand-over point until nothing moves, placed by a
+//                          prefix sum of the counts (huf_decode_wave); damaged or unusual streams go to the serial X1 / X2 decoders
+//                          of libzstd, one lane per stream. Literals to a bump-allocated scratch, sixteen at a time.
 //   zra_dec_chain_kernel   LANE per frame: the FSE sequence chains of 64 frames advance together in the 64 lanes of a wave
-//                          (tables and bitstreams read from L2/HBM, one dependent round trip per sequence, thousands of frames
-//                          in flight per CU). Every check of the reference's sequence loop lives here, in its order, so the
-//                          execute kernel moves bytes without looking at them. Sequences go to a bump-allocated scratch.
-//   zra_dec_exec_kernel    wave per frame: 64 sequences per step — wave scan of the lengths, per-lane literal copies, match copies
-//                          in dependency rounds; then block commit, frame end, and (random access) the query slices.
+//   zra_dec_chain_lds_kernel  (tables read from L2/HBM — or, in the second kernel, one workgroup per CU beside the first, from 31
+//                          LDS slots — one dependent round trip per sequence). Every check of the reference's sequence loop lives
+//                          here, in its order, so the execute kernel moves bytes without looking at them. Sequences go to a
+//                          bump-allocated scratch.
+//   zra_dec_exec_kernel    wave per frame: 64 sequences per step — scan of the lengths, the step assembled in an LDS window
+//                          (literal runs, then match copies in dependency rounds: a match waits for the sequences its source
+//                          touches), 16-byte stores, one drain; then block commit, frame end, and (random access) the query slices.
+//   zra_ra_small_kernel    small random-access batches: one workgroup of three waves takes a frame through all of the above without
+//                          leaving the kernel (six-lane sequence chain out of LDS, literals on a second wave, a third wave that
+//                          validates and executes behind the chain); anything unusual is handed back to the four kernels.
 //
 // Statuses are results: the control flow restates libzstd 1.4.9's (oracle/zo_decode.c is the CPU twin, pinned against the library
 // on 44,000 damaged archives): its BIT_DStream reader incl. what an over-read returns, both of its Huffman decoders, both of its

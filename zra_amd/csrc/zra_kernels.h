@@ -4,18 +4,17 @@
 #include <stddef.h>
 
 // ------------------------------------------------------------------------------------------------ decode
-// The decoder is three kernels per ROUND (one compressed block of every unfinished frame per round; raw / RLE blocks and the frame
-// ends are consumed by the first kernel on the way):
-//   zra_dec_parse_kernel  wave per frame   headers (from an LDS copy of the header bytes), Huffman tree descriptions, FSE tables ->
-//                                          per-frame table scratch
-//   zra_dec_huf_kernel    LANE per stream  Huffman literal streams of 16 frames per wave (their 16 decode tables in LDS) -> literal scratch
-//   zra_dec_chain_kernel  LANE per frame   the serial FSE sequence chain of 64 frames in the 64 lanes of a wave, every check of
-//                                          the reference's sequence loop (its statuses, in its order) -> sequence scratch
-//   zra_dec_exec_kernel   wave per frame   pure data movement: literal + match copies of the validated sequences, frame end,
-//                                          random-access slices
-// frames whose Huffman literal streams one wave of zra_dec_huf_kernel decodes side by side (4 lanes each); its LDS = this many 4.25 KiB tables
+// The decoder is four stages per ROUND (one compressed block of every unfinished frame per round; raw / RLE blocks and the frame
+// ends are consumed by the first kernel on the way); zra_decode.hip's header describes them:
+//   zra_dec_parse_kernel      wave per frame    headers, Huffman tree descriptions, FSE tables -> per-frame table scratch
+//   zra_dec_huf_kernel        wave per frame    Huffman literal streams (16 runs per stream side by side) -> literal scratch
+//   zra_dec_chain_kernel      LANE per frame    the serial FSE sequence chains, every check of the reference's sequence loop
+//   zra_dec_chain_lds_kernel  (the same, tables in LDS, beside it)                                              -> sequence scratch
+//   zra_dec_exec_kernel       wave per frame    data movement: literal + match copies, frame end, random-access slices
+//   zra_ra_small_kernel       workgroup per frame, all stages in one launch (small random-access batches)
+// frames whose decode tables one workgroup of zra_dec_huf_kernel holds (it takes them one after the other, all lanes on each); its LDS = this many 4.25 KiB tables
 #ifndef ZRA_HUF_FRAMES
-#define ZRA_HUF_FRAMES 2        /* A/B on one box, 8 GiB decode: 16 / 8 / 4 / 2 / 1 frames per wave -> Huffman stage 20.0 / 18.4 / 14.7 / 13.3 / 15.4 ms */
+#define ZRA_HUF_FRAMES 2        /* A/B on one box, 8 GiB decode, lane-per-stream decoder: 16 / 8 / 4 / 2 / 1 frames per wave -> Huffman stage 20.0 / 18.4 / 14.7 / 13.3 / 15.4 ms; wave-wide decoder: 1 / 2 / 4 -> 12.9 / 9.8 / 10.1 */
 #endif
 #define ZRA_DEC_TBL_LL 0u       // 512 cells x 4 B  sym | extraBits<<8 | stateBits<<16 | nextBase<<20 (the base value of a length code comes from a
 #define ZRA_DEC_TBL_ML 512u     // 512 cells x 4 B   constant table: 5 KiB of cells per frame instead of 9, so that the frames in flight fit the caches)
