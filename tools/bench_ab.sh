@@ -3,7 +3,7 @@
 # AB_FLAGS (e.g. "-DZRA_ENT_WAVES=7 -DZRA_ENT_WAVES=5") rebuild and run the bench line twice without the CPU baseline
 root=$(pwd); mkdir -p $root/gpurun_out; : > $root/gpurun_out/bench_ab.txt
 for f in $AB_FLAGS; do
-  ZRA_EXTRA_CFLAGS=$f timeout 300 python zra_amd/build.py --force > /dev/null 2>&1 < /dev/null
+  ZRA_EXTRA_CFLAGS="${f//;/ }" timeout 300 python zra_amd/build.py --force > /dev/null 2>&1 < /dev/null
   for i in 1 2; do
     timeout 600 python3 bench.py --no-cpu-baseline 2>/dev/null < /dev/null | python3 -c "
 import json,sys
