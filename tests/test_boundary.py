@@ -147,3 +147,25 @@ def test_zstd_error_strings_match_dependency(zra):
         want = b"An error was returned by ZStandard: " + ref(code)
         got = L.ZraGetErrorString(zra.ZraStatus(1, code))
         assert got == want, (code, got, want)
+
+
+def test_bench_traffic_key_follows_the_code_not_the_comments(tmp_path):
+    """profiles/traffic.json entries are tied to a build by a hash of zra_amd/csrc (bench.kernel_source_sha): a reworded comment must
+    not make a PMC measurement stale, a changed statement must."""
+    import shutil, sys
+    sys.path.insert(0, ROOT)
+    import bench
+    here = bench.HERE
+    try:
+        base = bench.kernel_source_sha()
+        dst = tmp_path / "zra_amd" / "csrc"
+        shutil.copytree(os.path.join(ROOT, "zra_amd", "csrc"), dst)
+        bench.HERE = str(tmp_path)
+        assert bench.kernel_source_sha() == base
+        f = dst / "zra_kernels.h"
+        f.write_text("// a new remark\n" + f.read_text() + "\n/* and another\n   one */\n")
+        assert bench.kernel_source_sha() == base
+        f.write_text(f.read_text() + "\n#define ZRA_SOMETHING_ELSE 1\n")
+        assert bench.kernel_source_sha() != base
+    finally:
+        bench.HERE = here
