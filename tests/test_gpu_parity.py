@@ -865,7 +865,8 @@ def test_small_inputs_through_the_four_kernel_pipeline_as_well():
     The differential decode, the damaged-archive statuses against libzstd, the damaged headers and the random-access cases again, in a
     fresh process with ZRA_DEC_SMALL_MAX=0."""
     import subprocess
-    env = dict(os.environ, ZRA_DEC_SMALL_MAX="0")
+    # (ZRA_DEC_CHAIN_LDS_MIN=1: the chain kernel with its tables in LDS, which otherwise only joins from 24,576 frames on, takes part too)
+    env = dict(os.environ, ZRA_DEC_SMALL_MAX="0", ZRA_DEC_CHAIN_LDS_MIN="1")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-x", "-q", "-k",
                         "randomised_differential_decode or randomised_corruption_statuses or randomised_header_damage or random_access_on_damaged or ra_vs_bruteforce or golden_frames",
                         "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=1500)

@@ -396,6 +396,8 @@ Status Engine::decode_launch(const ZraDecodeArgs& a0, const uint32_t* dExpect, u
   { static const int skip = std::getenv("ZRA_DEC_SKIP") ? std::atoi(std::getenv("ZRA_DEC_SKIP")) : 0; a.debugSkip = (uint32_t)skip; }
   HIPCHK(hipEventRecord(ev0_, stream_));
   static const uint32_t chainWaves = std::getenv("ZRA_DEC_CHAIN_WAVES") ? (uint32_t)std::atoi(std::getenv("ZRA_DEC_CHAIN_WAVES")) : 2u;
+  // (ZRA_DEC_CHAIN_LDS_MIN: jobs from which the LDS-table chain kernel runs beside the other one; the tests set it to 1)
+  static const uint32_t chainLdsMin = std::getenv("ZRA_DEC_CHAIN_LDS_MIN") ? (uint32_t)std::atoi(std::getenv("ZRA_DEC_CHAIN_LDS_MIN")) : (uint32_t)numCUs_ * 96u;
   static const bool chainLdsOn = std::getenv("ZRA_DEC_CHAIN_LDS") ? std::atoi(std::getenv("ZRA_DEC_CHAIN_LDS")) != 0 : true;
   static const uint32_t chainGrid = std::getenv("ZRA_DEC_CHAIN_GRID") ? (uint32_t)std::atoi(std::getenv("ZRA_DEC_CHAIN_GRID")) : 0u;        // bring-up: absolute wave count
   // the rounds of one set of jobs, one stage after the other on the engine's stream (resident waves per CU of the chain kernel — lane =
@@ -420,7 +422,7 @@ Status Engine::decode_launch(const ZraDecodeArgs& a0, const uint32_t* dExpect, u
       // beside the lane-per-frame chain kernel (tables in HBM scratch, two waves per CU) one workgroup per CU with its frames' tables in
       // LDS, on another stream, pulling from the same queue
       bool forked = false;
-      if (chainLdsOn && nActive >= (uint32_t)numCUs_ * 96u) {
+      if (chainLdsOn && nActive >= chainLdsMin) {
         if (!pipeStreams_[1]) { if (hipStreamCreateWithFlags(&pipeStreams_[1], hipStreamNonBlocking) != hipSuccess) { pipeStreams_[1] = nullptr; (void)hipGetLastError(); } }
         const size_t ldsBytes = (128 + (size_t)ZRA_CHAIN_LDS_FRAMES * ZRA_DEC_TBL_WORDS) * 4;
         if (pipeStreams_[1] && !chainLdsAttr_) {
