@@ -2029,7 +2029,7 @@ __device__ __forceinline__ void chain_consume(const ZraDecodeArgs& a, const u32 
 // grid = jobs (one workgroup each), 192 threads = three waves: 0 parses, produces the chain and executes; 1 decodes the Huffman
 // literals; 2 consumes the chain. *bail counts the jobs that have to go through the four-kernel pipeline.
 extern "C" __global__ void __launch_bounds__(3 * DEC_THREADS)
-zra_ra_small_kernel(ZraDecodeArgs a0, u32* bail) {
+zra_ra_small_kernel(ZraDecodeArgs a0, u32* bail, const u32* expect, u32 jobBase, unsigned long long* result) {
   __shared__ SmallShared S;
   const int wave = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
   const u32 j = blockIdx.x;
@@ -2040,6 +2040,7 @@ zra_ra_small_kernel(ZraDecodeArgs a0, u32* bail) {
 #ifdef ZRA_SMALL_PROFILE
   if (threadIdx.x == 0) atomicAdd(&zra_small_prof[4], 1ull);
 #endif
+  bool bailed = false;
   for (u32 round = 0;; round++) {
     a.round = round;
     if (wave == 0) {
@@ -2053,8 +2054,8 @@ zra_ra_small_kernel(ZraDecodeArgs a0, u32* bail) {
     __syncthreads();
     SPROF_RESET
     const u32 oc = S.ctl[0];
-    if (oc == 0) return;                                   // the frame is finished (status and slices written by frame_finish)
-    if (oc == 2) { if (threadIdx.x == 0) atomicAdd(bail, 1u); return; }
+    if (oc == 0) break;                                    // the frame is finished (status and slices written by frame_finish)
+    if (oc == 2) { bailed = true; break; }
     ExecCtx xc;
     if (wave == 1) {
       u32 ok = 1;
@@ -2083,10 +2084,31 @@ zra_ra_small_kernel(ZraDecodeArgs a0, u32* bail) {
     }
     __threadfence_block();
     __syncthreads();
-    if (S.ctl[1] | S.ring.bail) { if (threadIdx.x == 0) atomicAdd(bail, 1u); return; }
+    if (S.ctl[1] | S.ring.bail) { bailed = true; break; }
     SPROF_RESET
     if (wave == 2) { const u32 more = exec_end<true>(a, j, F, xc, lane); if (lane == 0) S.ctl[2] = more; SPROF(3) }
     __syncthreads();
-    if (!S.ctl[2]) return;
+    if (!S.ctl[2]) break;
+  }
+  // *bail counts DOWN from 0xFFFFFFFF (one memset presets it together with the result word)
+  if (bailed) { if (threadIdx.x == 0) atomicSub(bail, 1u); return; }
+  // ---- frame end, here instead of in two more launches: what zra_xxh64_verify_kernel and zra_first_error_kernel do behind the
+  // four-kernel pipeline — content checksum over the regenerated bytes (four lanes), regenerated size against the slot, first error
+  __threadfence_block();
+  __syncthreads();
+  if (wave == 1 && lane < 4) {
+    const u32 st0 = a.status[j], meta = a.frameMeta[2 * (size_t)j];
+    const bool live = st0 == 0 && meta != 2;            // 2: stopped early (random access), nothing to check
+    const bool active = live && meta == 1;
+    const u64 h = zra_xxh64_quad(active ? a.out + a.outOff[j] : a.out, active ? a.produced[j] : 0u, lane);
+    if (lane == 0) {
+      u32 st = st0;
+      if (live) {
+        if (active && (u32)h != a.frameMeta[2 * (size_t)j + 1]) st = ZE_CHECKSUM_WRONG;
+        else if (expect && a.produced[j] != expect[j]) st = 255u;      // ZE_SIZE_MISMATCH (zra_engine.hip)
+        if (st != st0) a.status[j] = st;
+      }
+      if (st) atomicMin(result, ((unsigned long long)(jobBase + j) << 8) | (st & 0xFF));
+    }
   }
 }

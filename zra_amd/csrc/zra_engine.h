@@ -142,6 +142,7 @@ class Engine {
   EncCtx encCtx_[2];
   DevBuf encScan_;
   hipStream_t stream2_ = nullptr;          // entropy stage / gather stream (overlaps the match finder on stream_)
+  bool decCountersClean_ = false;          // the decoder's round counters are known to be zero (zeroed behind the last one-launch decode)
   int chainLdsAttr_ = 0;                   // zra_dec_chain_lds_kernel's dynamic LDS size: 0 not asked yet, 1 granted, -1 refused
   hipStream_t pipeStreams_[3] = {nullptr, nullptr, nullptr};   // decode stage pipeline: Huffman, chain, execute (parse runs on stream_)
   std::vector<hipEvent_t> evPool_;

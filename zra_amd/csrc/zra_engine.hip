@@ -15,7 +15,7 @@ extern "C" __global__ void zra_dec_huf_kernel(ZraDecodeArgs a);
 extern "C" __global__ void zra_dec_chain_kernel(ZraDecodeArgs a);
 extern "C" __global__ void zra_dec_chain_lds_kernel(ZraDecodeArgs a);
 extern "C" __global__ void zra_dec_exec_kernel(ZraDecodeArgs a);
-extern "C" __global__ void zra_ra_small_kernel(ZraDecodeArgs a, uint32_t* bail);
+extern "C" __global__ void zra_ra_small_kernel(ZraDecodeArgs a, uint32_t* bail, const uint32_t* expect, uint32_t jobBase, unsigned long long* result);
 
 using namespace zra_dev;
 
@@ -272,6 +272,7 @@ Status Engine::release_scratch() {
                     &produced_, &frameMeta_, &frameOff_, &outOff_, &expect_, &result_, &temp_, &qmeta_, &encScan_, &hostIn_, &hostOut_, &seqScratch_})
     b->release();
   for (auto& x : encCtx_) for (DevBuf* b : {&x.tables, &x.seqs, &x.lits, &x.slots, &x.misc, &x.ck, &x.sizes}) b->release();
+  decCountersClean_ = false;
   return ok();
 }
 
@@ -346,25 +347,24 @@ Status Engine::decode_small(const ZraDecodeArgs& a0, const uint32_t* dExpect, ui
   mark("scratch");
   a.active = nullptr; a.nActive = n; a.round = 0; a.nextActive = decLists_.as<uint32_t>();
   { static const int skip = std::getenv("ZRA_DEC_SKIP") ? std::atoi(std::getenv("ZRA_DEC_SKIP")) : 0; a.debugSkip = (uint32_t)skip; }
-  uint32_t* dBail = a.counters + ZRA_DC_WORDS;
-  HIPCHK(hipMemsetAsync(a.counters, 0, ZRA_DC_WORDS * 4 + 8, stream_));
+  // the round counters are zero whenever this path finds them (zeroed behind the previous use, off the caller's wait); the result
+  // word and the kernel's bail counter (counting down) were preset together by decode_jobs' one memset; frame-end checks and the
+  // first-error reduction happen inside the kernel: one launch, one copy back, one synchronisation
+  if (!decCountersClean_) HIPCHK(hipMemsetAsync(a.counters, 0, ZRA_DC_WORDS * 4, stream_));
+  decCountersClean_ = false;
+  uint32_t* dBail = (uint32_t*)(result_.as<uint8_t>() + 8);
   HIPCHK(hipEventRecord(ev0_, stream_));
-  hipLaunchKernelGGL(zra_ra_small_kernel, dim3(n), dim3(192), 0, stream_, a, dBail);
+  hipLaunchKernelGGL(zra_ra_small_kernel, dim3(n), dim3(192), 0, stream_, a, dBail, dExpect, jobBase, result_.as<unsigned long long>());
   HIPCHK(hipEventRecord(ev1_, stream_));
   mark("launched");
-  const uint32_t tb = 256;
-  hipLaunchKernelGGL(zra_xxh64_verify_kernel, dim3((n * 4 + tb - 1) / tb), dim3(tb), 0, stream_, a.out, a.outOff, dExpect,
-                     produced_.as<uint32_t>(), frameMeta_.as<uint32_t>(), status_.as<uint32_t>(), n);
-  hipLaunchKernelGGL(zra_first_error_kernel, dim3((n + tb - 1) / tb), dim3(tb), 0, stream_, status_.as<uint32_t>(), n, jobBase,
-                     result_.as<unsigned long long>());
-  // result word and bail counter come back together
-  HIPCHK(hipMemcpyAsync(result_.as<uint8_t>() + 8, dBail, 4, hipMemcpyDeviceToDevice, stream_));
-  unsigned long long two[2] = {~0ull, 0};
+  unsigned long long two[2] = {~0ull, ~0ull};
   HIPCHK(hipMemcpyAsync(two, result_.p, 16, hipMemcpyDeviceToHost, stream_));
   mark("queued rest");
   HIPCHK(hipStreamSynchronize(stream_));
   mark("sync");
   HIPCHK(hipGetLastError());
+  if (hipMemsetAsync(a.counters, 0, ZRA_DC_WORDS * 4, stream_) == hipSuccess) decCountersClean_ = true;     // (for the next call; nobody waits for it)
+  two[1] = 0xFFFFFFFFull - (two[1] & 0xFFFFFFFFull);
   *bailed = (uint32_t)two[1];
   if (!*bailed) *hResult = two[0];
   float ms = 0;
@@ -383,6 +383,7 @@ Status Engine::decode_launch(const ZraDecodeArgs& a0, const uint32_t* dExpect, u
   ZraDecodeArgs a = a0;
   const uint32_t n = a.nFrames;
   { Status st = decode_scratch(a, maxFrameBytes); if (st.zra) return st; }
+  decCountersClean_ = false;
   uint32_t* listA = decLists_.as<uint32_t>(); uint32_t* listB = listA + n;
   static const int wavesCap = std::getenv("ZRA_DEC_WAVES") ? std::atoi(std::getenv("ZRA_DEC_WAVES")) : 0;   // bring-up: occupancy sweep
   if (!decOccParse_) {
