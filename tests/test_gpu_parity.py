@@ -872,3 +872,21 @@ def test_small_inputs_through_the_four_kernel_pipeline_as_well():
                         "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-2000:]
     assert " passed" in r.stdout and "failed" not in r.stdout
+
+
+@pytest.mark.gpu
+def test_foreign_frame_size_does_not_cost_a_pass_per_frame(zra):
+    """A header whose frameSize is half of what the frames regenerate (a foreign or damaged field): DecompressBuffer then packs the frames
+    back to back like the reference's one multi-frame zstd call (zra.cpp:249). The decoder used to take one four-kernel pass per frame
+    from the first mismatch on (3 ms each: 50 s for these 16,384 frames); it now decodes the frames behind a measured one side by side
+    on the guess that they regenerate the same size, and keeps the run for which the guess held."""
+    import time
+    d = C.gen_E(1 << 20) * 64
+    fs = 4096
+    arc = bytearray(zra.CompressBuffer(d, 3, fs, True))
+    arc[30:34] = (fs // 2).to_bytes(4, "little")
+    t = time.time()
+    got = zra.DecompressBuffer(bytes(arc))
+    dt = time.time() - t
+    assert got == d
+    assert dt < 10.0, dt

@@ -603,9 +603,42 @@ Status Engine::decode_jobs(const uint8_t* dBody, uint64_t bodySize, const uint64
   uint64_t cur = 0;
   HIPCHK(hipMemcpyAsync(&cur, dOutOff + first, 8, hipMemcpyDeviceToHost, stream_));
   HIPCHK(hipStreamSynchronize(stream_));
-  if (!seqScratch_.reserve(64)) return zerr(64);
+  // One frame at a time is what the reference's multi-frame call does, and what decides a frame's status (its room is what the frames
+  // before it left) — but an archive whose frames simply regenerate another size than the header says (a damaged or foreign frameSize)
+  // would take one four-kernel pass per frame that way: hundreds of thousands of them. So after a frame has regenerated `got` bytes
+  // the frames behind it are decoded side by side, on the guess that they regenerate the same (each at its guessed place, with exactly
+  // that room); the longest run for which the guess held — no status, that size — stands as decoded; the first frame that deviates is
+  // decoded again alone with its true room, which decides what it reports, and gives the next guess.
+  constexpr uint32_t kSpec = 1u << 16;
+  if (!seqScratch_.reserve(64 + (size_t)kSpec * 12)) return zerr(64);
   uint64_t* dCur = seqScratch_.as<uint64_t>(); uint32_t* dCap = (uint32_t*)(seqScratch_.as<uint8_t>() + 16);
-  for (uint32_t f = first; f < nFrames; f++) {
+  uint64_t* dSpecOff = (uint64_t*)(seqScratch_.as<uint8_t>() + 64); uint32_t* dSpecCap = (uint32_t*)(seqScratch_.as<uint8_t>() + 64 + (size_t)kSpec * 8);
+  std::vector<uint64_t> hOff; std::vector<uint32_t> hCap, hProduced, hStatus;
+  uint32_t guess = 0;
+  for (uint32_t f = first; f < nFrames;) {
+    if (guess && nFrames - f >= 2 && seqTotal > cur) {
+      const uint32_t B = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(nFrames - f, kSpec), (seqTotal - cur) / guess);
+      if (B >= 2) {
+        hOff.resize(B); hCap.assign(B, guess); hProduced.resize(B); hStatus.resize(B);
+        for (uint32_t i = 0; i < B; i++) hOff[i] = cur + (uint64_t)i * guess;
+        HIPCHK(hipMemcpyAsync(dSpecOff, hOff.data(), (size_t)B * 8, hipMemcpyHostToDevice, stream_));
+        HIPCHK(hipMemcpyAsync(dSpecCap, hCap.data(), (size_t)B * 4, hipMemcpyHostToDevice, stream_));
+        HIPCHK(hipMemsetAsync(result_.p, 0xFF, 64, stream_));
+        ZraDecodeArgs b = a;
+        b.frameOff = dFrameOff + (size_t)f * offStride; b.outOff = dSpecOff; b.outCap = dSpecCap; b.nFrames = B;
+        b.limit = nullptr; b.pieceBase = nullptr; b.pieces = nullptr;
+        unsigned long long r2 = ~0ull;
+        Status st = decode_launch(b, nullptr, guess, f, &r2);
+        if (st.zra) return st;
+        HIPCHK(hipMemcpyAsync(hProduced.data(), produced_.p, (size_t)B * 4, hipMemcpyDeviceToHost, stream_));
+        HIPCHK(hipMemcpyAsync(hStatus.data(), status_.p, (size_t)B * 4, hipMemcpyDeviceToHost, stream_));
+        HIPCHK(hipStreamSynchronize(stream_));
+        uint32_t k = 0;
+        while (k < B && hStatus[k] == 0 && hProduced[k] == guess) k++;
+        cur += (uint64_t)k * guess; f += k;
+        if (f >= nFrames) break;
+      }
+    }
     const uint32_t cap = (uint32_t)std::min<uint64_t>(seqTotal > cur ? seqTotal - cur : 0, 0xFFFFFF00u);
     HIPCHK(hipMemcpyAsync(dCur, &cur, 8, hipMemcpyHostToDevice, stream_));
     HIPCHK(hipMemcpyAsync(dCap, &cap, 4, hipMemcpyHostToDevice, stream_));
@@ -619,7 +652,7 @@ Status Engine::decode_jobs(const uint8_t* dBody, uint64_t bodySize, const uint64
     HIPCHK(hipMemcpyAsync(&got, produced_.p, 4, hipMemcpyDeviceToHost, stream_));
     HIPCHK(hipStreamSynchronize(stream_));
     if (res != ~0ull) return zerr((int)(res & 0xFF));
-    cur += got;
+    cur += got; guess = got; f++;
   }
   lastProducedTotal_ = cur;
   return ok();
