@@ -2010,7 +2010,10 @@ __device__ __forceinline__ void chain_consume(const ZraDecodeArgs& a, const u32 
       if (v == 2) { if (lane == 0) { ring_st(&R.bail, 1u); ring_st(&R.stop, 1u); } return; }
       litReady = true;
     }
-    c.outBase = outPos; exec_step(c, X, on2 ? ll : 0u, on2 ? ml : 0u, on2 ? min(off, 0x0FFFFFFFu) : 1u, outBefore, litBefore, on2, lane, a.debugSkip);
+    // a step cut short at the query's last byte ends where its last validated sequence ends: the lanes behind it carry that position
+    // (exec_step takes the step's length from lane 63; the lengths of the unexecuted, unchecked sequences must not be in it)
+    const u32 endOut = outPos + bcast_u32(sOut, nb - 1), endLit = litPos + bcast_u32(sLit, nb - 1);
+    c.outBase = outPos; exec_step(c, X, on2 ? ll : 0u, on2 ? ml : 0u, on2 ? min(off, 0x0FFFFFFFu) : 1u, on2 ? outBefore : endOut, on2 ? litBefore : endLit, on2, lane, a.debugSkip);
     outPos += bcast_u32(sOut, nb - 1); litPos += bcast_u32(sLit, nb - 1);
     t += nb;
     if (lane == 0) ring_st(&R.tail, t);

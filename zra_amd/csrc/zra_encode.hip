@@ -21,6 +21,8 @@ extern "C" __global__ void zra_mf_dfast2_kernel(ZraEncArgs a, uint32_t block, ui
 static bool mf_v2() { static const bool v = std::getenv("ZRA_MF_V2") && std::atoi(std::getenv("ZRA_MF_V2")) != 0; return v; }
 #define ZRA_DFAST_KERNEL (mf_v2() ? zra_mf_dfast2_kernel : zra_mf_dfast_kernel)
 extern "C" __global__ void zra_entropy_kernel(ZraEncArgs a, uint32_t block);
+extern "C" __global__ void zra_lk_prepass_kernel(ZraEncArgs a, ZraLkArgs k);
+extern "C" __global__ void zra_lk_parse_kernel(ZraEncArgs a, ZraLkArgs k);
 
 using namespace zra_dev;
 
@@ -414,6 +416,43 @@ Status Engine::compress_persistent(const uint8_t* dIn, size_t inSize, uint8_t* d
   const uint32_t hl = std::max(full.hashLog, tail.hashLog), cl = std::max(full.chainLog, tail.chainLog);
   const size_t filterBytes = (2u << dupLog) + (((size_t)1 << hl) >> shL) / 8 + (((size_t)1 << cl) >> shS) / 8 + 64;
 
+  // ---- link formulation (zra_encode_lk.hip) for frames of at most 64 KiB: a parse-independent pre-pass + a parse without tables.
+  // Opt-in (ZRA_MF_LK=1): bit-exact, but measured slower than the table kernel (round 4: 7.7 against 16 GiB/s, profiles/r04_experiments.md).
+  // ZRA_LK_MODE=0: pre-pass and parse alternate over groups of ZRA_LK_GROUP frames on one stream, 1: both persistent side by side,
+  // ZRA_LK_PP_CUS workgroups of the pre-pass feeding the parse through a ring of entry slots
+  static const int lkEnv = std::getenv("ZRA_MF_LK") ? std::atoi(std::getenv("ZRA_MF_LK")) : 0;
+  static const int lkMode = std::getenv("ZRA_LK_MODE") ? std::atoi(std::getenv("ZRA_LK_MODE")) : 0;
+  static const uint32_t lkGroup = std::getenv("ZRA_LK_GROUP") ? (uint32_t)std::max(1, std::atoi(std::getenv("ZRA_LK_GROUP"))) : 4096u;
+  static const uint32_t lkWaves = std::getenv("ZRA_LK_WAVES") ? (uint32_t)std::min(8, std::max(1, std::atoi(std::getenv("ZRA_LK_WAVES")))) : ZRA_LK_PARSE_WAVES;   // waves per parse workgroup (= frames in flight per CU)
+  static const uint32_t lkPpCus = std::getenv("ZRA_LK_PP_CUS") ? (uint32_t)std::max(1, std::atoi(std::getenv("ZRA_LK_PP_CUS"))) : 32u;
+  bool useLk = lkEnv != 0 && frameSize <= ZRA_LK_MAX_FRAME && full.strategy == 2 && !mf_v2();
+  if (useLk && !lkAttr_) {
+    const bool okA = hipFuncSetAttribute((const void*)zra_lk_prepass_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ZRA_LK_PP_LDS) == hipSuccess &&
+                     hipFuncSetAttribute((const void*)zra_lk_parse_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ZRA_LK_PARSE_LDS) == hipSuccess;
+    if (!okA) (void)hipGetLastError();
+    lkAttr_ = okA ? 1 : -1;
+  }
+  if (lkAttr_ < 0) useLk = false;
+  ZraLkArgs lk{};
+  uint32_t* lkQueues = nullptr; size_t lkQueueNext = 0, lkCtlBytes = 0;
+  hipStream_t lkStream = nullptr;
+  if (useLk) {
+    lk.entPositions = (((uint64_t)frameSize + 63) & ~63ull) + 64;
+    lk.ringSlots = (uint32_t)std::min<uint64_t>(nFramesTotal, lkGroup);
+    const size_t nQueues = 2 * (size_t)(nFramesTotal / lkGroup + nSuper + 2);
+    lkCtlBytes = 64 + 4 * (nQueues + 2 * (size_t)lk.ringSlots);
+    if (!lkEnt_.reserve((size_t)lk.ringSlots * lk.entPositions * 16) || !lkTmp_.reserve((size_t)numCUs_ * 4 * 65536) || !lkCtl_.reserve(lkCtlBytes)) return zerr(64);
+    HIPCHK(hipMemsetAsync(lkCtl_.p, 0, lkCtlBytes, stream_));
+    lk.ent = lkEnt_.as<uint64_t>(); lk.lkTmp = lkTmp_.as<uint16_t>();
+    lk.fail = lkCtl_.as<uint32_t>();
+    lkQueues = lkCtl_.as<uint32_t>() + 16;
+    if (lkMode == 1) {
+      lk.ready = lkQueues + nQueues; lk.consumed = lk.ready + lk.ringSlots;
+      if (!pipeStreams_[0] && hipStreamCreateWithFlags(&pipeStreams_[0], hipStreamNonBlocking) != hipSuccess) { pipeStreams_[0] = nullptr; return zerr(1); }
+      lkStream = pipeStreams_[0];
+    }
+  }
+
   size_t evNext = 0;
   auto ev = [&]() -> hipEvent_t {
     if (evNext == evPool_.size()) { hipEvent_t e = nullptr; if (hipEventCreate(&e) != hipSuccess) return nullptr; evPool_.push_back(e); }
@@ -443,7 +482,28 @@ Status Engine::compress_persistent(const uint8_t* dIn, size_t inSize, uint8_t* d
     hipEvent_t m0 = ev(), m1 = ev();
     if (!m0 || !m1) return zerr(1);
     HIPCHK(hipEventRecord(m0, stream_));
-    hipLaunchKernelGGL(ZRA_DFAST_KERNEL, dim3(std::min<uint32_t>(n, nSlots)), dim3(64), filterBytes, stream_, a, 0u, 0xFFFFFFFFu, 0u);
+    if (!useLk) hipLaunchKernelGGL(ZRA_DFAST_KERNEL, dim3(std::min<uint32_t>(n, nSlots)), dim3(64), filterBytes, stream_, a, 0u, 0xFFFFFFFFu, 0u);
+    else if (lkMode == 1) {
+      // both kernels persistent: the pre-pass on its own stream behind everything queued on stream A so far (the ring and its flags
+      // are free then), the parse on stream A; the parse workgroups leave lkPpCus CUs to the pre-pass (one workgroup of either fits a CU)
+      if (S > 0) HIPCHK(hipMemsetAsync(lk.ready, 0, 8 * (size_t)lk.ringSlots, stream_));
+      hipEvent_t r0 = ev(); if (!r0) return zerr(1);
+      HIPCHK(hipEventRecord(r0, stream_)); HIPCHK(hipStreamWaitEvent(lkStream, r0, 0));
+      ZraLkArgs k = lk; k.first = 0; k.count = n; k.ppQueue = lkQueues + lkQueueNext++;
+      ZraEncArgs a2 = a; a2.mfQueue = lkQueues + lkQueueNext++;
+      const uint32_t ppGrid = std::min<uint32_t>({n, lkPpCus, (uint32_t)numCUs_ / 2});
+      const uint32_t paGrid = std::max<uint32_t>(1, std::min<uint32_t>((n + lkWaves - 1) / lkWaves, (uint32_t)numCUs_ - ppGrid));
+      hipLaunchKernelGGL(zra_lk_prepass_kernel, dim3(ppGrid), dim3(ZRA_LK_PP_THREADS), ZRA_LK_PP_LDS, lkStream, a, k);
+      hipLaunchKernelGGL(zra_lk_parse_kernel, dim3(paGrid), dim3(lkWaves * 64), ZRA_LK_PARSE_LDS, stream_, a2, k);
+    } else {
+      for (uint32_t g0 = 0; g0 < n; g0 += lkGroup) {
+        ZraLkArgs k = lk; k.first = g0; k.count = std::min<uint32_t>(lkGroup, n - g0); k.ppQueue = lkQueues + lkQueueNext++;
+        ZraEncArgs a2 = a; a2.mfQueue = lkQueues + lkQueueNext++;
+        hipLaunchKernelGGL(zra_lk_prepass_kernel, dim3(std::min<uint32_t>(k.count, (uint32_t)numCUs_)), dim3(ZRA_LK_PP_THREADS), ZRA_LK_PP_LDS, stream_, a, k);
+        hipLaunchKernelGGL(zra_lk_parse_kernel, dim3(std::min<uint32_t>((k.count + lkWaves - 1) / lkWaves, (uint32_t)numCUs_)),
+                           dim3(lkWaves * 64), ZRA_LK_PARSE_LDS, stream_, a2, k);
+      }
+    }
     HIPCHK(hipEventRecord(m1, stream_));
     mfSpans.push_back({m0, m1});
     // a short last frame whose cparams select another strategy: parsed by the generic kernel (table slot 0 is free by then)
@@ -485,7 +545,13 @@ Status Engine::compress_persistent(const uint8_t* dIn, size_t inSize, uint8_t* d
   HIPCHK(hipMemcpyAsync(&total, dRunning, 8, hipMemcpyDeviceToHost, stream2_));
   HIPCHK(hipStreamSynchronize(stream2_));
   HIPCHK(hipStreamSynchronize(stream_));
+  if (lkStream) HIPCHK(hipStreamSynchronize(lkStream));
   HIPCHK(hipGetLastError());
+  if (useLk) {
+    uint32_t failed = 0;
+    HIPCHK(hipMemcpy(&failed, lk.fail, 4, hipMemcpyDeviceToHost));
+    if (failed) return zerr(1);                       // a wait between the two persistent kernels ran out of patience
+  }
   double kernelMs = 0;
   kstats_[0] = kstats_[1] = kstats_[2] = kstats_[3] = 0;
   for (auto& sp : mfSpans) { float m = 0; if (hipEventElapsedTime(&m, sp.first, sp.second) == hipSuccess) { kstats_[0] += m; kstats_[1] += 1; kernelMs += m; } }

@@ -181,3 +181,26 @@ struct ZraEncArgs {
   uint32_t* mfDone;
   uint32_t mfSubFrames;
 };
+
+// ------------------------------------------------------------------------------------------------ encode, "link" dfast (zra_encode_lk.hip)
+// Frames of at most 64 KiB (one block) at a dfast level. A parse-independent pre-pass gives every position its three predecessors in
+// the long-hash and in the short-hash bucket chain; the parse keeps "was inserted" bitmaps in LDS instead of hash tables in HBM.
+// entry of position p: two u64 {long, short}: q1 | q2 << 16 | q3 << 32 | equal-content flags << 48 (bit k: predecessor k+1 carries the
+// same 8 (long) / 4 (short) bytes as p); 0 = no predecessor (position 0 is never a candidate: index > prefixLowestIndex)
+#define ZRA_LK_MAX_FRAME 65536u
+#define ZRA_LK_PP_THREADS 1024u
+#define ZRA_LK_PP_LDS (131072u + 16384u + 8192u + 64u)           // heads / links / source copy + per group and block: last lane + block masks
+#define ZRA_LK_PARSE_WAVES 8u                                  // waves of one parse workgroup = frames in flight per CU (16 KiB of bitmaps each)
+#define ZRA_LK_PARSE_LDS (ZRA_LK_PARSE_WAVES * 16384u)
+struct ZraLkArgs {
+  uint64_t* ent;          // ring of entry arrays: slot (frame % ringSlots) holds 2 * entPositions u64
+  uint64_t entPositions;  // positions per ring slot (frame size rounded up to 64, + 64)
+  uint32_t ringSlots;
+  uint16_t* lkTmp;        // per pre-pass workgroup: 2 x 65536 u16 (links of the long / the short chain)
+  uint32_t* ready;        // [ringSlots] frame + 1 whose entries the slot holds            (pre-pass -> parse); nullptr: launches are ordered
+  uint32_t* consumed;     // [ringSlots] frame + 1 that was last parsed out of the slot    (parse -> pre-pass)
+  uint32_t* ppQueue;      // frame queue of the pre-pass workgroups
+  uint32_t first, count;  // this launch covers frames [first, first + count) of the batch
+  uint32_t* fail;         // set when a wait ran out of patience (the call fails instead of hanging)
+};
+
