@@ -53,13 +53,18 @@ void* zo_libzstd_symbol(const char* name) { return (zo_libzstd_load(NULL) == 0) 
 
 /* a per-call codec context, mirroring ZCCtx / ZDCtx (zra.cpp:25-44) */
 typedef struct { int backend; void* cctx; void* dctx; int level, checksum; } codec;
-static int codec_open(codec* k, int backend, int level, int checksum) {
+/* side: 1 = a compression context only (ZCCtx, zra.cpp:209), 2 = a decompression context only (ZDCtx, zra.cpp:248, 271) — the
+   reference creates exactly one of them per call, and bench.py's CPU baseline times these calls */
+static int codec_open(codec* k, int backend, int level, int checksum, int side) {
   k->backend = backend; k->cctx = k->dctx = NULL; k->level = level; k->checksum = checksum;
   if (backend == 1) {
     if (zo_libzstd_load(NULL)) return -1;
-    k->cctx = Z.createC(); k->dctx = Z.createD();
-    /* zra.cpp:210-213: ZSTD_c_compressionLevel=100, contentSizeFlag=200, checksumFlag=201, dictIDFlag=202 */
-    Z.setparam(k->cctx, 100, level); Z.setparam(k->cctx, 200, 0); Z.setparam(k->cctx, 201, checksum); Z.setparam(k->cctx, 202, 0);
+    if (side & 1) {
+      k->cctx = Z.createC();
+      /* zra.cpp:210-213: ZSTD_c_compressionLevel=100, contentSizeFlag=200, checksumFlag=201, dictIDFlag=202 */
+      Z.setparam(k->cctx, 100, level); Z.setparam(k->cctx, 200, 0); Z.setparam(k->cctx, 201, checksum); Z.setparam(k->cctx, 202, 0);
+    }
+    if (side & 2) k->dctx = Z.createD();
   }
   return 0;
 }
@@ -113,7 +118,7 @@ static zo_status compress_buffer(int backend, const u8* in, size_t n, u8* out, s
   off += (size_t)tableSize * 5;
   size_t bodyStart = off, remaining = n;
   codec k;
-  if (codec_open(&k, backend, level, checksum)) return st(ZRA_ZStdError, ZO_E_GENERIC);
+  if (codec_open(&k, backend, level, checksum, 1)) return st(ZRA_ZStdError, ZO_E_GENERIC);
   size_t fs = frameSize;
   while (remaining) {
     if (fs > remaining) fs = remaining;
@@ -155,7 +160,7 @@ static zo_status decompress_buffer(int backend, const u8* in, size_t n, u8* out,
   if (e) return st(e, 0);
   if (outCap < h.uncompressedSize) return st(ZRA_OutputTooSmall, 0);
   codec k; int err;
-  if (codec_open(&k, backend, 0, 0)) return st(ZRA_ZStdError, ZO_E_GENERIC);
+  if (codec_open(&k, backend, 0, 0, 2)) return st(ZRA_ZStdError, ZO_E_GENERIC);
   g_last_produced = 0;
   size_t r = codec_decompress(&k, out, outCap, in + h.size, n - h.size, &err);
   if (!err) g_last_produced = r;
@@ -173,7 +178,7 @@ static zo_status decompress_ra(int backend, const u8* in, size_t n, u8* out, siz
   const u8* first = in + h.seekTableOffset + foq * 5;
   const u8* last = first + (fzq + (fzrem ? 1 : 0)) * 5;
   codec k; int err = 0;
-  if (codec_open(&k, backend, 0, 0)) return st(ZRA_ZStdError, ZO_E_GENERIC);
+  if (codec_open(&k, backend, 0, 0, 2)) return st(ZRA_ZStdError, ZO_E_GENERIC);
   u8* fb = NULL;
   if (forem || fzrem) fb = (u8*)calloc(h.frameSize ? h.frameSize : 1, 1);
   const u8* contents = in + h.size;
@@ -227,14 +232,14 @@ zo_status zl_zra_decompress_ra_many(const void* in, size_t n, void* out, size_t 
 /* raw per-frame access to the dependency, for pinning zo_compress_frame / zo_decompress */
 size_t zl_compress_frame(void* dst, size_t cap, const void* src, size_t n, int level, int checksum) {
   codec k; int err;
-  if (codec_open(&k, 1, level, checksum)) return ZO_ERR(ZO_E_GENERIC);
+  if (codec_open(&k, 1, level, checksum, 1)) return ZO_ERR(ZO_E_GENERIC);
   size_t r = codec_compress(&k, dst, cap, src, n, &err);
   codec_close(&k);
   return err ? ZO_ERR(err) : r;
 }
 size_t zl_decompress(void* dst, size_t cap, const void* src, size_t n) {
   codec k; int err;
-  if (codec_open(&k, 1, 0, 0)) return ZO_ERR(ZO_E_GENERIC);
+  if (codec_open(&k, 1, 0, 0, 2)) return ZO_ERR(ZO_E_GENERIC);
   size_t r = codec_decompress(&k, dst, cap, src, n, &err);
   codec_close(&k);
   return err ? ZO_ERR(err) : r;

@@ -14,7 +14,8 @@
 #include <stdio.h>
 
 static u64 H_L[66], H_S[66], nLook, nVisited, nSeq, nFrames, bad, insLcnt, insScnt, tagHitL, tagHitS, realHitL, realHitS;
-static u64 depL_hist[4], firstK[8];
+static u64 depL_hist[4], firstK[8], lookPredL, lookPredS, insSuccL, insSuccS, lookL, lookS;
+static u8 *sucL, *sucS;
 
 int main(int argc, char** argv) {
   if (argc < 2) return 2;
@@ -35,6 +36,9 @@ int main(int argc, char** argv) {
       u32 bl = hash8(src + p, hlog), bs = hashN(src + p, clog, mls);
       prevL[p] = headL[bl]; headL[bl] = (u32)p; prevS[p] = headS[bs]; headS[bs] = (u32)p;
     }
+    if (!sucL) { sucL = (u8*)malloc(fs); sucS = (u8*)malloc(fs); }
+    memset(sucL, 0, fs); memset(sucS, 0, fs);
+    for (size_t p = 1; p + 8 <= fs; p++) { if (prevL[p]) sucL[prevL[p]] = 1; if (prevS[p]) sucS[prevS[p]] = 1; }
     free(headL); free(headS);
     memset(insL, 0, fs); memset(insS, 0, fs);
     /* ---- the serial parse with the real tables, every lookup answered twice */
@@ -44,14 +48,14 @@ int main(int argc, char** argv) {
     u32 psi = lowest_at(&c, (u32)be + 1);
     size_t ip = mf_prologue(&c, bs0, psi - 1, &o1, &o2, &saved);
 #define WALK(prev, ins, p, out, hist) { u32 q_ = prev[p], st_ = 1; while (q_ && !ins[q_]) { q_ = prev[q_]; st_++; } out = q_; hist[st_ > 64 ? 65 : st_]++; if (q_ == 0) hist[0]++; }
-#define INS_L(p) { HL[hash8(src + (p), hlog)] = (u32)(p) + 1; insL[p] = 1; insLcnt++; }
-#define INS_S(p) { HS[hashN(src + (p), clog, mls)] = (u32)(p) + 1; insS[p] = 1; insScnt++; }
+#define INS_L(p) { HL[hash8(src + (p), hlog)] = (u32)(p) + 1; insL[p] = 1; insLcnt++; insSuccL += sucL[p]; }
+#define INS_S(p) { HS[hashN(src + (p), clog, mls)] = (u32)(p) + 1; insS[p] = 1; insScnt++; insSuccS += sucS[p]; }
     while (ip < ilimit) {
       size_t top = ip, ml; u32 offVal;
       u32 hL = hash8(src + ip, hlog), hS = hashN(src + ip, clog, mls);
       u32 mL = HL[hL], mS = HS[hS];
       u32 wL, wS; WALK(prevL, insL, ip, wL, H_L); WALK(prevS, insS, ip, wS, H_S);
-      nLook += 2; nVisited++;
+      nLook += 2; nVisited++; lookL++; lookS++; lookPredL += prevL[ip] != 0; lookPredS += prevS[ip] != 0;
       if ((mL ? mL - 1 : 0) != wL || (mS ? mS - 1 : 0) != wS) { bad++; if (bad < 5) printf("MISMATCH frame %llu ip %zu: table L %u S %u, walk L %u S %u\n", (unsigned long long)nFrames, ip, mL, mS, wL, wS); }
       INS_L(ip); INS_S(ip);
       if (mL > 1 && rd64(src + mL - 1) == rd64(src + ip)) realHitL++;
@@ -64,7 +68,7 @@ int main(int argc, char** argv) {
           m = mL - 1; ml = count_eq(src, ip + 8, m + 8, be) + 8;
         } else if (mS > psi && rd32(src + mS - 1) == rd32(src + ip)) {
           u32 h3 = hash8(src + ip + 1, hlog), m3 = HL[h3];
-          u32 w3; WALK(prevL, insL, ip + 1, w3, H_L); nLook++;
+          u32 w3; WALK(prevL, insL, ip + 1, w3, H_L); nLook++; lookL++; lookPredL += prevL[ip + 1] != 0;
           if ((m3 ? m3 - 1 : 0) != w3) { bad++; if (bad < 5) printf("MISMATCH3 frame %llu ip %zu: table %u walk %u\n", (unsigned long long)nFrames, ip, m3, w3); }
           INS_L(ip + 1);
           if (m3 > psi && rd64(src + m3 - 1) == rd64(src + ip + 1)) { m = m3 - 1; ip++; ml = count_eq(src, ip + 8, m + 8, be) + 8; }
@@ -94,6 +98,8 @@ int main(int argc, char** argv) {
   printf("frames %llu level %d fs %zu | lookup mismatches %llu | per frame: visited %.0f lookups %.0f seqs %.0f insL %.0f insS %.0f realHitL %.0f realHitS %.0f\n",
          (unsigned long long)nFrames, level, fs, (unsigned long long)bad, (double)nVisited / nFrames, (double)nLook / nFrames, (double)nSeq / nFrames,
          (double)insLcnt / nFrames, (double)insScnt / nFrames, (double)realHitL / nFrames, (double)realHitS / nFrames);
+  printf("per frame: long lookups %.0f of which the bucket has an earlier position %.0f | short %.0f / %.0f | long insertions %.0f of which the bucket has a later position %.0f | short %.0f / %.0f\n",
+         (double)lookL / nFrames, (double)lookPredL / nFrames, (double)lookS / nFrames, (double)lookPredS / nFrames, (double)insLcnt / nFrames, (double)insSuccL / nFrames, (double)insScnt / nFrames, (double)insSuccS / nFrames);
   for (int t = 0; t < 2; t++) {
     u64* H = t ? H_S : H_L; u64 tot = 0, steps = 0; for (int i = 1; i < 66; i++) { tot += H[i]; steps += (u64)i * H[i]; }
     printf("%s walk: lookups/frame %.0f  mean steps %.2f  empty-ended %.1f %%  hist(1..8, 9-16, 17-64, >64):", t ? "short" : "long ", (double)tot / nFrames, (double)steps / tot, 100.0 * H[0] / tot);

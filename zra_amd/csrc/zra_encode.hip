@@ -2,6 +2,7 @@
 // block-round driver (A.4.2) over batches of frames, and the seek-table build (device scan + gather).
 // Replaces the loop body of the reference's CompressBuffer / Compressor::Compress (zra.cpp:216-225, 329-338).
 #include <cstdio>
+#include <unistd.h>
 #include "zra_engine.h"
 #include "zra_dev.h"
 #include "zra_format.h"
@@ -453,6 +454,42 @@ Status Engine::compress_persistent(const uint8_t* dIn, size_t inSize, uint8_t* d
     }
   }
 
+  // ---- bucket flags for the table kernel (round 4): zra_lk_prepass_kernel in flags mode runs AHEAD of the match finder on ZRA_PP_CUS
+  // CUs of its own (its workgroup takes a CU's whole LDS) and tells, per position and table, whether the bucket has an earlier / a later
+  // position of the frame; the match finder skips the table reads and writes that cannot matter. Frames of at most 64 KiB, calls of at
+  // least ZRA_PP_MIN frames. Opt-in (ZRA_MF_FLAGS=1): exact, and it takes half of the table requests away (59 % of the long-table
+  // writes on the bench corpus go to buckets no later position shares) — but the match finder's time does not move (round 4: 57.1
+  // against 55.7 ms per GiB at 18 waves per CU; profiles/r04_experiments.md): the kernel is bound by dependent round trips at loaded
+  // latency (SQ_WAIT_ANY 65 % of the wave cycles, TCP pending-stall 77 %), not by the number of table requests.
+  static const int flEnv = std::getenv("ZRA_MF_FLAGS") ? std::atoi(std::getenv("ZRA_MF_FLAGS")) : 0;
+  static const uint32_t ppLdsBytes = std::getenv("ZRA_PP_LDS") ? (uint32_t)std::atoi(std::getenv("ZRA_PP_LDS")) : ZRA_LK_PP_LDS;   // bring-up knob
+  static const uint32_t flCus = std::getenv("ZRA_PP_CUS") ? (uint32_t)std::max(1, std::atoi(std::getenv("ZRA_PP_CUS"))) : 32u;
+  static const uint64_t flMin = std::getenv("ZRA_PP_MIN") ? (uint64_t)std::max(1, std::atoi(std::getenv("ZRA_PP_MIN"))) : 4096u;
+  bool useFlags = flEnv != 0 && !useLk && !mf_v2() && frameSize <= ZRA_LK_MAX_FRAME && full.strategy == 2 && nFramesTotal >= flMin && (uint32_t)numCUs_ >= 2 * flCus;
+  if (useFlags && !lkAttr_) {
+    const bool okA = hipFuncSetAttribute((const void*)zra_lk_prepass_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ZRA_LK_PP_LDS) == hipSuccess &&
+                     hipFuncSetAttribute((const void*)zra_lk_parse_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ZRA_LK_PARSE_LDS) == hipSuccess;
+    if (!okA) (void)hipGetLastError();
+    lkAttr_ = okA ? 1 : -1;
+  }
+  if (lkAttr_ < 0) useFlags = false;
+  ZraLkArgs fk{};
+  uint32_t* flQueues = nullptr;
+  if (useFlags) {
+    fk.ringSlots = (uint32_t)std::min<uint64_t>(nFramesTotal, 2ull * SB);
+    fk.flagStride = ((uint64_t)frameSize + 255) & ~255ull;
+    const size_t ctl = 64 + 4 * ((size_t)nSuper + 2 + fk.ringSlots);
+    if (!lkEnt_.reserve((size_t)fk.ringSlots * fk.flagStride) || !lkCtl_.reserve(ctl)) return zerr(64);
+    HIPCHK(hipMemsetAsync(lkCtl_.p, 0, ctl, stream_));
+    fk.flagsOut = lkEnt_.as<uint8_t>();
+    fk.fail = lkCtl_.as<uint32_t>(); fk.started = fk.fail + 1;
+    flQueues = lkCtl_.as<uint32_t>() + 16;
+    fk.ready = flQueues + nSuper + 2;
+    if (!pipeStreams_[0] && hipStreamCreateWithFlags(&pipeStreams_[0], hipStreamNonBlocking) != hipSuccess) { pipeStreams_[0] = nullptr; return zerr(1); }
+    lkStream = pipeStreams_[0];
+    if (std::getenv("ZRA_PP_SAMESTREAM")) lkStream = stream_;      // bring-up: pre-pass and match finder one after the other (needs ring >= frames)
+  }
+
   size_t evNext = 0;
   auto ev = [&]() -> hipEvent_t {
     if (evNext == evPool_.size()) { hipEvent_t e = nullptr; if (hipEventCreate(&e) != hipSuccess) return nullptr; evPool_.push_back(e); }
@@ -460,6 +497,7 @@ Status Engine::compress_persistent(const uint8_t* dIn, size_t inSize, uint8_t* d
   };
   std::vector<std::pair<hipEvent_t, hipEvent_t>> mfSpans, entSpans;
   hipEvent_t superDone[2] = {nullptr, nullptr};
+  uint32_t ppStarted = 0;
   // stream B starts after the counters are cleared and after whatever the caller queued on the engine stream
   { hipEvent_t e0 = ev(); if (!e0) return zerr(1); HIPCHK(hipEventRecord(e0, stream_)); HIPCHK(hipStreamWaitEvent(stream2_, e0, 0)); }
 
@@ -482,7 +520,31 @@ Status Engine::compress_persistent(const uint8_t* dIn, size_t inSize, uint8_t* d
     hipEvent_t m0 = ev(), m1 = ev();
     if (!m0 || !m1) return zerr(1);
     HIPCHK(hipEventRecord(m0, stream_));
-    if (!useLk) hipLaunchKernelGGL(ZRA_DFAST_KERNEL, dim3(std::min<uint32_t>(n, nSlots)), dim3(64), filterBytes, stream_, a, 0u, 0xFFFFFFFFu, 0u);
+    if (useFlags) {
+      // the pre-pass on its own stream, behind everything queued on stream A so far (the ring is free then); the match finder is
+      // launched once every pre-pass workgroup is resident (they need whole CUs: behind the match finder's waves they would never start)
+      hipEvent_t r0 = ev(); if (!r0) return zerr(1);
+      HIPCHK(hipEventRecord(r0, stream_)); HIPCHK(hipStreamWaitEvent(lkStream, r0, 0));
+      ZraLkArgs k = fk; k.first = 0; k.count = n; k.ppQueue = flQueues + S; k.subDone = a.mfDone; k.readyBase = (uint32_t)F0;
+      volatile uint32_t* dbgHost = nullptr;
+      if (std::getenv("ZRA_PP_TRACE")) { void* hp = nullptr; if (hipHostMalloc(&hp, 256, hipHostMallocMapped) == hipSuccess) { std::memset(hp, 0, 256); dbgHost = (volatile uint32_t*)hp; void* dp = nullptr; (void)hipHostGetDevicePointer(&dp, hp, 0); k.dbg = (volatile uint32_t*)dp; } }
+      k.oddTail = (tailSize && F0 + n == nFramesTotal && tail.strategy != 2) ? 1u : 0u;
+      const uint32_t ppGrid = std::min<uint32_t>(n, flCus);
+      ppStarted += ppGrid;
+      hipLaunchKernelGGL(zra_lk_prepass_kernel, dim3(ppGrid), dim3(ZRA_LK_PP_THREADS), ppLdsBytes, lkStream, a, k);
+      HIPCHK(hipGetLastError());
+      if (dbgHost) {
+        usleep(2000000);
+        std::fprintf(stderr, "pp markers after 2 s: entry %u  frame+1 pulled %u  links L begin %u  L done %u  S done %u  flags written %u  fenced %u  published %u  loop top %u | grid %u n %u\n",
+                     dbgHost[0], dbgHost[1], dbgHost[2], dbgHost[3], dbgHost[4], dbgHost[5], dbgHost[6], dbgHost[7], dbgHost[8], ppGrid, n);
+        std::fflush(stderr);
+      }
+      if (lkStream != stream_) HIPCHK(hipStreamWaitValue32(stream_, fk.started, ppStarted, hipStreamWaitValueGte, 0xFFFFFFFFu));
+      ZraEncArgs a2 = a;
+      a2.flags = fk.flagsOut; a2.flagStride = fk.flagStride; a2.flagSlots = fk.ringSlots; a2.flagReadyBase = (uint32_t)F0; a2.flagReady = fk.ready; a2.flagFail = fk.fail;
+      const uint32_t slots = (uint32_t)std::min<uint64_t>((uint64_t)((uint32_t)numCUs_ - ppGrid) * wavesPerCU, nSlots);
+      hipLaunchKernelGGL(ZRA_DFAST_KERNEL, dim3(std::min<uint32_t>(n, slots)), dim3(64), filterBytes, stream_, a2, 0u, 0xFFFFFFFFu, 0u);
+    } else if (!useLk) hipLaunchKernelGGL(ZRA_DFAST_KERNEL, dim3(std::min<uint32_t>(n, nSlots)), dim3(64), filterBytes, stream_, a, 0u, 0xFFFFFFFFu, 0u);
     else if (lkMode == 1) {
       // both kernels persistent: the pre-pass on its own stream behind everything queued on stream A so far (the ring and its flags
       // are free then), the parse on stream A; the parse workgroups leave lkPpCus CUs to the pre-pass (one workgroup of either fits a CU)
@@ -493,13 +555,13 @@ Status Engine::compress_persistent(const uint8_t* dIn, size_t inSize, uint8_t* d
       ZraEncArgs a2 = a; a2.mfQueue = lkQueues + lkQueueNext++;
       const uint32_t ppGrid = std::min<uint32_t>({n, lkPpCus, (uint32_t)numCUs_ / 2});
       const uint32_t paGrid = std::max<uint32_t>(1, std::min<uint32_t>((n + lkWaves - 1) / lkWaves, (uint32_t)numCUs_ - ppGrid));
-      hipLaunchKernelGGL(zra_lk_prepass_kernel, dim3(ppGrid), dim3(ZRA_LK_PP_THREADS), ZRA_LK_PP_LDS, lkStream, a, k);
+      hipLaunchKernelGGL(zra_lk_prepass_kernel, dim3(ppGrid), dim3(ZRA_LK_PP_THREADS), ppLdsBytes, lkStream, a, k);
       hipLaunchKernelGGL(zra_lk_parse_kernel, dim3(paGrid), dim3(lkWaves * 64), ZRA_LK_PARSE_LDS, stream_, a2, k);
     } else {
       for (uint32_t g0 = 0; g0 < n; g0 += lkGroup) {
         ZraLkArgs k = lk; k.first = g0; k.count = std::min<uint32_t>(lkGroup, n - g0); k.ppQueue = lkQueues + lkQueueNext++;
         ZraEncArgs a2 = a; a2.mfQueue = lkQueues + lkQueueNext++;
-        hipLaunchKernelGGL(zra_lk_prepass_kernel, dim3(std::min<uint32_t>(k.count, (uint32_t)numCUs_)), dim3(ZRA_LK_PP_THREADS), ZRA_LK_PP_LDS, stream_, a, k);
+        hipLaunchKernelGGL(zra_lk_prepass_kernel, dim3(std::min<uint32_t>(k.count, (uint32_t)numCUs_)), dim3(ZRA_LK_PP_THREADS), ppLdsBytes, stream_, a, k);
         hipLaunchKernelGGL(zra_lk_parse_kernel, dim3(std::min<uint32_t>((k.count + lkWaves - 1) / lkWaves, (uint32_t)numCUs_)),
                            dim3(lkWaves * 64), ZRA_LK_PARSE_LDS, stream_, a2, k);
       }
@@ -545,11 +607,16 @@ Status Engine::compress_persistent(const uint8_t* dIn, size_t inSize, uint8_t* d
   HIPCHK(hipMemcpyAsync(&total, dRunning, 8, hipMemcpyDeviceToHost, stream2_));
   HIPCHK(hipStreamSynchronize(stream2_));
   HIPCHK(hipStreamSynchronize(stream_));
-  if (lkStream) HIPCHK(hipStreamSynchronize(lkStream));
+  if (lkStream && lkStream != stream_) HIPCHK(hipStreamSynchronize(lkStream));
   HIPCHK(hipGetLastError());
-  if (useLk) {
+  if (useFlags) if (const char* dump = std::getenv("ZRA_PP_DUMP")) {      // bring-up: the flags of ring slot 0 to a file
+    std::vector<uint8_t> h(fk.flagStride);
+    HIPCHK(hipMemcpy(h.data(), fk.flagsOut, fk.flagStride, hipMemcpyDeviceToHost));
+    if (FILE* fp = std::fopen(dump, "wb")) { std::fwrite(h.data(), 1, h.size(), fp); std::fclose(fp); }
+  }
+  if (useLk || useFlags) {
     uint32_t failed = 0;
-    HIPCHK(hipMemcpy(&failed, lk.fail, 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(&failed, useLk ? lk.fail : fk.fail, 4, hipMemcpyDeviceToHost));
     if (failed) return zerr(1);                       // a wait between the two persistent kernels ran out of patience
   }
   double kernelMs = 0;

@@ -71,8 +71,10 @@ __device__ __forceinline__ void pp_wave_sync() {      // (a wave's LDS accesses 
 //      the head read in step 1; the group's last position of the chunk becomes the new head.
 // On log-like data most positions of a chunk share their bucket with a position one line further (different blocks): steps 3-4 resolve
 // all of them side by side; nothing is serial.
+// lk == nullptr: only the two bit sets are wanted (bit i = the thread's position of chunk i): pred = the bucket has an earlier position,
+// succ = it has a later one (the final head of the bucket is another position).
 template <bool LONG>
-__device__ void pp_links(const PpLds& S, const u8* src, u32 last, u32 log, u32 mls, u16* lk) {
+__device__ void pp_links(const PpLds& S, const u8* src, u32 last, u32 log, u32 mls, u16* lk, u64& predBits, u64& succBits) {
   const u32 t = threadIdx.x, blk = t >> 6, lane = t & 63;
   volatile u16* H = (volatile u16*)S.big;
   volatile u8* lastOf = S.lastOf;
@@ -82,8 +84,8 @@ __device__ void pp_links(const PpLds& S, const u8* src, u32 last, u32 log, u32 m
     for (u32 i = t; i < headBytes / 16; i += ZRA_LK_PP_THREADS) ((uint4*)S.big)[i] = make_uint4(0, 0, 0, 0);
     S.bmask[t] = 0; S.bmask[1024 + t] = 0;
     __syncthreads();
-    u32 par = 0;
-    for (u32 c0 = 1; c0 <= last; c0 += ZRA_LK_PP_THREADS, par ^= 1) {
+    u32 par = 0, ci = 0;
+    for (u32 c0 = 1; c0 <= last; c0 += ZRA_LK_PP_THREADS, par ^= 1, ci++) {
       const u32 p = c0 + t;
       bool act = p <= last;
       const u64 v = act ? ld64(src + p) : 0;
@@ -131,10 +133,22 @@ __device__ void pp_links(const PpLds& S, const u8* src, u32 last, u32 log, u32 m
           else link = h0;
         } else link = c0 + blk * 64 + predIn;
         if (lastIn && (m >> blk >> 1) == 0) H[b] = (u16)p;
-        lk[p] = (u16)link;
+        if (lk) lk[p] = (u16)link;
+        if (link) predBits |= 1ull << ci;
       }
       __syncthreads();
     }
+    // the heads are final: a position that is not its bucket's head has a successor
+    ci = 0;
+    for (u32 c0 = 1; c0 <= last; c0 += ZRA_LK_PP_THREADS, ci++) {
+      const u32 p = c0 + t;
+      bool act = p <= last;
+      const u64 v = act ? ld64(src + p) : 0;
+      u32 b = LONG ? lk_bucket_long(v, log) : lk_bucket_short(v, log, mls);
+      if (nPass > 1) { act = act && (b >> 16) == pass; b &= 0xFFFFu; }
+      if (act && H[b] != (u16)p) succBits |= 1ull << ci;
+    }
+    __syncthreads();
   }
 }
 
@@ -195,8 +209,8 @@ __device__ void pp_flags(const PpLds& S, const u8* src, u32 n, u32 last, u64* en
   __syncthreads();
 }
 
-// patience of the waits between the two persistent kernels (s_memtime ticks, 100 MHz-ish constant clock: several seconds)
-constexpr u64 LK_PATIENCE = 2000000000ull;
+// patience of the waits between the two persistent kernels (s_memtime ticks of the 100 MHz constant clock: 3 s)
+constexpr u64 LK_PATIENCE = 300000000ull;
 
 }  // namespace
 
@@ -208,13 +222,23 @@ zra_lk_prepass_kernel(ZraEncArgs a, ZraLkArgs k) {
   S.lastOf = S.big + 131072;
   S.bmask = (u32*)(S.lastOf + 16384);
   __shared__ u32 sFrame;
-  u16* lkL = k.lkTmp + (size_t)blockIdx.x * 2 * 65536;
+  u16* lkL = k.lkTmp ? k.lkTmp + (size_t)blockIdx.x * 2 * 65536 : nullptr;
   u16* lkS = lkL + 65536;
+#define PPDBG(i, v) { if (k.dbg && threadIdx.x == 0 && blockIdx.x == 0) { k.dbg[i] = (v); __threadfence_system(); } }
+  PPDBG(0, 1u)
+  if (k.started && threadIdx.x == 0) atomicAdd(k.started, 1u);
+  PPDBG(0, 2u)   // (the host launches the consumers once every workgroup of this kernel is resident)
   for (;;) {
+    PPDBG(8, 1u)
     if (threadIdx.x == 0) sFrame = atomicAdd(k.ppQueue, 1u);
+    PPDBG(8, 2u)
     __syncthreads();
-    const u32 fi = sFrame;
+    PPDBG(8, 3u)
+    // (wave-uniform for the compiler too: with the frame index in a vector register the loop's exit is "divergent", and the
+    //  structurised loop then lets thread 0 run the publish step apart from its wave — into the next iteration's barriers on its own)
+    const u32 fi = rfl(sFrame);
     __syncthreads();
+    PPDBG(1, fi + 1)
     if (fi >= k.count) return;
     const u32 f = k.first + fi;
     const u64 fstart = (u64)(a.firstFrame + f) * a.frameSize;
@@ -222,7 +246,19 @@ zra_lk_prepass_kernel(ZraEncArgs a, ZraLkArgs k) {
     const u32 n = (u32)(remaining < a.frameSize ? remaining : a.frameSize);
     const ZraEncParams& P = (n == a.frameSize) ? a.full : a.tail;
     const u32 slot = f % k.ringSlots;
-    if (k.consumed && f >= k.ringSlots) {
+    if (k.flagsOut && k.subDone && f >= k.ringSlots) {
+      // flags ring of the table kernel: the slot is free once the sub-batch of the frame that used it before is through the match finder
+      if (threadIdx.x == 0) {
+        const u32 j = (f - k.ringSlots) / a.mfSubFrames;
+        const u32 need = min(a.mfSubFrames, a.nFrames - j * a.mfSubFrames) - ((k.oddTail && (j + 1) * a.mfSubFrames >= a.nFrames) ? 1u : 0u);
+        const u64 t0 = __builtin_amdgcn_s_memtime();
+        while (__hip_atomic_load(&k.subDone[j], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < need) {
+          __builtin_amdgcn_s_sleep(64);
+          if (__builtin_amdgcn_s_memtime() - t0 > LK_PATIENCE) { atomicExch(k.fail, 1u); break; }
+        }
+      }
+      __syncthreads();
+    } else if (k.consumed && f >= k.ringSlots) {
       // the slot is free once the frame that used it before has been parsed
       if (threadIdx.x == 0) {
         const u64 t0 = __builtin_amdgcn_s_memtime();
@@ -233,22 +269,50 @@ zra_lk_prepass_kernel(ZraEncArgs a, ZraLkArgs k) {
       }
       __syncthreads();
     }
-    u64* ent = k.ent + (size_t)slot * 2 * k.entPositions;
-    if (P.strategy == 2 && n >= 9 && n <= ZRA_LK_MAX_FRAME) {
+    if (k.flagsOut) {
+      // flags for the table kernel (zra_mf_dfast_kernel): one byte per position, bit 0 / 1: the long bucket has an earlier / a later
+      // position of the frame, bit 2 / 3: the short bucket. A table read without an earlier position finds the cleared cell, a table
+      // write without a later position is never read: the kernel skips both (0x0F = no knowledge: behind the last hashed position)
+      u8* fl = k.flagsOut + (size_t)slot * k.flagStride;
+      if (P.strategy == 2 && n >= 9 && n <= ZRA_LK_MAX_FRAME) {
+        const u8* src = a.in + fstart;
+        const u32 last = n - 8;
+        u64 pL = 0, sL = 0, pS = 0, sS = 0;
+        PPDBG(2, f + 1)
+        pp_links<true>(S, src, last, P.hashLog, P.minMatch, nullptr, pL, sL);
+        PPDBG(3, f + 1)
+        pp_links<false>(S, src, last, P.chainLog, P.minMatch, nullptr, pS, sS);
+        PPDBG(4, f + 1)
+        u32 ci = 0;
+        for (u32 c0 = 1; c0 <= last; c0 += ZRA_LK_PP_THREADS, ci++) {
+          const u32 p = c0 + threadIdx.x;
+          if (p <= last) fl[p] = (u8)(((pL >> ci) & 1) | (((sL >> ci) & 1) << 1) | (((pS >> ci) & 1) << 2) | (((sS >> ci) & 1) << 3));
+        }
+        if (threadIdx.x == 0) fl[0] = 0x0F;
+        for (u32 p = last + 1 + threadIdx.x; p < n; p += ZRA_LK_PP_THREADS) fl[p] = 0x0F;
+      } else {
+        for (u32 p = threadIdx.x; p < n; p += ZRA_LK_PP_THREADS) fl[p] = 0x0F;
+      }
+    } else if (P.strategy == 2 && n >= 9 && n <= ZRA_LK_MAX_FRAME) {
+      u64* ent = k.ent + (size_t)slot * 2 * k.entPositions;
       const u8* src = a.in + fstart;
       const u32 last = n - 8;
       const u32 nEnt = (u32)min((u64)((n + 63) & ~63u), k.entPositions);
-      pp_links<true>(S, src, last, P.hashLog, P.minMatch, lkL);
-      pp_links<false>(S, src, last, P.chainLog, P.minMatch, lkS);
+      u64 d0 = 0, d1 = 0;
+      pp_links<true>(S, src, last, P.hashLog, P.minMatch, lkL, d0, d1);
+      pp_links<false>(S, src, last, P.chainLog, P.minMatch, lkS, d0, d1);
       __threadfence_block();
       pp_prefix(S, last, nEnt, lkL, ent, 0);
       pp_prefix(S, last, nEnt, lkS, ent, 1);
       pp_flags(S, src, n, last, ent);
     }
+    PPDBG(5, f + 1)
     if (k.ready) {
       __threadfence();
       __syncthreads();
-      if (threadIdx.x == 0) __hip_atomic_store(&k.ready[slot], f + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      PPDBG(6, f + 1)
+      if (threadIdx.x == 0) { *(volatile u32*)&k.ready[slot] = k.readyBase + f + 1; __threadfence(); }
+      PPDBG(7, f + 1)
     }
   }
 }
@@ -539,7 +603,7 @@ zra_lk_parse_kernel(ZraEncArgs a, ZraLkArgs k) {
         u32 ok = 1;
         if (lane == 0) {
           const u64 t0 = __builtin_amdgcn_s_memtime();
-          while (__hip_atomic_load(&k.ready[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != f + 1) {
+          while (__hip_atomic_load(&k.ready[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != k.readyBase + f + 1) {
             __builtin_amdgcn_s_sleep(32);
             if (__builtin_amdgcn_s_memtime() - t0 > LK_PATIENCE) { atomicExch(k.fail, 1u); ok = 0; break; }
           }
@@ -573,7 +637,7 @@ zra_lk_parse_kernel(ZraEncArgs a, ZraLkArgs k) {
       }
     } else if (k.consumed && lane == 0) {
       // not parsed here, but the slot's turn passes all the same (the pre-pass skipped the frame too)
-      if (k.ready) { const u64 t0 = __builtin_amdgcn_s_memtime(); while (__hip_atomic_load(&k.ready[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != f + 1) { __builtin_amdgcn_s_sleep(32); if (__builtin_amdgcn_s_memtime() - t0 > LK_PATIENCE) { atomicExch(k.fail, 1u); break; } } }
+      if (k.ready) { const u64 t0 = __builtin_amdgcn_s_memtime(); while (__hip_atomic_load(&k.ready[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != k.readyBase + f + 1) { __builtin_amdgcn_s_sleep(32); if (__builtin_amdgcn_s_memtime() - t0 > LK_PATIENCE) { atomicExch(k.fail, 1u); break; } } }
       __hip_atomic_store(&k.consumed[slot], f + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
   }

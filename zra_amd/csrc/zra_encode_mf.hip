@@ -435,7 +435,10 @@ struct LeanLds {
 #endif
 template <u32 MLS>
 __device__ u32 mf_dfast_lean(const ZraEncParams& P, u32* HL, u32* HS, const u8* src, u32 bs, u32 be, u32* rep, u64* seqs, u32* nOut,
-                             const LeanLds& W, int lane, u32 ib) {
+                             const LeanLds& W, int lane, u32 ib, const u8* flg) {
+  // flg (round 4, zra_lk_prepass_kernel's flags mode; nullptr: none): one byte per position, bit 0 / 1 = the position's long bucket has an
+  // earlier / a later position of the frame, bit 2 / 3 = its short bucket. A lookup without an earlier position would read the cleared
+  // cell; an insertion without a later position is never looked up: both are skipped — about half of the table's fabric requests.
   DfHash<MLS> H; H.init(P.hashLog, P.chainLog, ib);
   const u32 idxMask = ~H.tagMask;
   // block-level scalars arrive in VGPRs (vector loads of the frame state): pin them to SGPRs once so that the whole
@@ -459,9 +462,10 @@ __device__ u32 mf_dfast_lean(const ZraEncParams& P, u32* HL, u32* HS, const u8* 
   // scalar insertion of one position (rare paths only)
   auto insert_slow = [&](u32 pos, bool doL, bool doS) {
     if (lane == 0) {
+      const u32 fx = flg ? flg[pos] : 0x0Fu;
       u32 bl, bs_, tl, ts; H.both(ld64(src + pos), bl, bs_, tl, ts);
-      if (doL) { TST(HL + bl, (pos + 1) | tl); W.markL(bl); }
-      if (doS) { TST(HS + bs_, (pos + 1) | ts); W.markS(bs_); }
+      if (doL && (fx & 2)) { TST(HL + bl, (pos + 1) | tl); W.markL(bl); }
+      if (doS && (fx & 8)) { TST(HS + bs_, (pos + 1) | ts); W.markS(bs_); }
     }
   };
   while (ip < ilimit) {
@@ -473,6 +477,7 @@ __device__ u32 mf_dfast_lean(const ZraEncParams& P, u32* HL, u32* HS, const u8* 
     bool active = (u32)lane < nAct;
     const u32 p = wip + (u32)lane * s;
     const u64 v8 = active ? ld64(src + p) : 0;
+    const u32 fb = (flg && active) ? flg[p] : 0x0Fu;
     // rep gather for the current o1 (independent of the tables: in flight together with them)
     u32 repFor = o1;
     bool rv = active && o1 > 0 && p + 1 >= o1;
@@ -501,7 +506,7 @@ __device__ u32 mf_dfast_lean(const ZraEncParams& P, u32* HL, u32* HS, const u8* 
     const u32 wL = gL >> 5, wS = gS >> 5, qL = 1u << (gL & 31), qS = 1u << (gS & 31);
     u32 mL = 0, mS = 0;
     if (active) {
-      const bool needL = (bmL[wL] & qL) != 0, needS = (bmS[wS] & qS) != 0;
+      const bool needL = (fb & 1) && (bmL[wL] & qL) != 0, needS = (fb & 4) && (bmS[wS] & qS) != 0;
       const u32 rL = needL ? TLD(HL + bL) : 0u, rS = needS ? TLD(HS + bS) : 0u;
       mL = ((rL & H.tagMask) == tL) ? (rL & idxMask) : 0u;
       mS = ((rS & H.tagMask) == tS) ? (rS & idxMask) : 0u;
@@ -527,7 +532,7 @@ __device__ u32 mf_dfast_lean(const ZraEncParams& P, u32* HL, u32* HS, const u8* 
       const u64 live = AM & (~0ull << cur);
       const u64 hm = (RH | LH | SH) & live;
       if (!hm) {
-        if (lane_in(live)) { TST(HL + bL, valL); TST(HS + bS, valS); atomicOr(&bmL[wL], qL); atomicOr(&bmS[wS], qS); }
+        if (lane_in(live)) { if (fb & 2) { TST(HL + bL, valL); atomicOr(&bmL[wL], qL); } if (fb & 8) { TST(HS + bS, valS); atomicOr(&bmS[wS], qS); } }
         ip = wip + nAct * s; PROF(4)
         break;
       }
@@ -546,16 +551,17 @@ __device__ u32 mf_dfast_lean(const ZraEncParams& P, u32* HL, u32* HS, const u8* 
         else {
           PROF_CNT(15)
           // the probed bucket is not covered by the window's no-duplicate guarantee: commit the visited positions first
-          if (lane_in(mkL)) { TST(HL + bL, valL); atomicOr(&bmL[wL], qL); }
-          if (lane_in(mkS)) { TST(HS + bS, valS); atomicOr(&bmS[wS], qS); }
+          if (lane_in(mkL) && (fb & 2)) { TST(HL + bL, valL); atomicOr(&bmL[wL], qL); }
+          if (lane_in(mkS) && (fb & 8)) { TST(HS + bS, valS); atomicOr(&bmS[wS], qS); }
           mkL = 0; mkS = 0;
           u32 m3v = 0; bool h3v = false;                // rare: done on lane 0's vector path (keeps the parse state scalar)
           if (lane == 0) {
             const u64 v9 = ld64(src + top + 1);
+            const u32 f3 = flg ? flg[top + 1] : 0x0Fu;
             u32 b3, bx, t3, tx; H.both(v9, b3, bx, t3, tx);
-            const u32 r3 = TLD(HL + b3);
+            const u32 r3 = (f3 & 1) ? TLD(HL + b3) : 0u;
             m3v = ((r3 & H.tagMask) == t3) ? (r3 & idxMask) : 0u;
-            TST(HL + b3, (top + 2) | t3); W.markL(b3);
+            if (f3 & 2) { TST(HL + b3, (top + 2) | t3); W.markL(b3); }
             h3v = m3v > 1 && ld64(src + m3v - 1) == v9;
           }
           hit3 = __ballot(h3v) & 1; m3 = bcast(m3v, 0);
@@ -602,8 +608,8 @@ __device__ u32 mf_dfast_lean(const ZraEncParams& P, u32* HL, u32* HS, const u8* 
       ip += ml; anchor = ip;
       PROF(7) PROF_CNT(13)
       if (ip > ilimit) {
-        if (lane_in(mkL)) { TST(HL + bL, valL); atomicOr(&bmL[wL], qL); }
-        if (lane_in(mkS)) { TST(HS + bS, valS); atomicOr(&bmS[wS], qS); }
+        if (lane_in(mkL) && (fb & 2)) { TST(HL + bL, valL); atomicOr(&bmL[wL], qL); }
+        if (lane_in(mkS) && (fb & 8)) { TST(HS + bS, valS); atomicOr(&bmS[wS], qS); }
         break;
       }
       // ---- complementary insertions (top+2 into both tables, then ip-2 long / ip-1 short) and the immediate repcode test
@@ -614,8 +620,8 @@ __device__ u32 mf_dfast_lean(const ZraEncParams& P, u32* HL, u32* HS, const u8* 
       if (in2) { mkL |= bit64(f + 2); mkS |= bit64(f + 2); }
       if (s == 1 && relE - 2 < nAct) mkL |= bit64(relE - 2);
       if (inE) mkS |= bit64(relE - 1);
-      if (lane_in(mkL)) { TST(HL + bL, valL); atomicOr(&bmL[wL], qL); }
-      if (lane_in(mkS)) { TST(HS + bS, valS); atomicOr(&bmS[wS], qS); }
+      if (lane_in(mkL) && (fb & 2)) { TST(HL + bL, valL); atomicOr(&bmL[wL], qL); }
+      if (lane_in(mkS) && (fb & 8)) { TST(HS + bS, valS); atomicOr(&bmS[wS], qS); }
       u32 here = 0, there = 1;
       const bool thereIn = inI && repOldFor == o2 && ((ROV >> (relE - 1)) & 1);   // src[ip - o2] == old rep gather of lane ip-1-wip
       if (in2 && inE && (o2 == 0 || thereIn)) {
@@ -625,14 +631,16 @@ __device__ u32 mf_dfast_lean(const ZraEncParams& P, u32* HL, u32* HS, const u8* 
         PROF_CNT(14)
         const u32 ipos = lane < 2 ? top + 2 : lane == 2 ? ip - 2 : lane == 3 ? ip - 1 : lane == 4 ? ip : ip - o2;
         const u64 x = lane < 6 ? ld64(src + ipos) : 0;
+        const u32 fx = (flg && lane < 4) ? flg[ipos] : 0x0Fu;
+        const bool wr = (lane & 1) ? (fx & 8) != 0 : (fx & 2) != 0;           // the position's bucket has a later position: the cell will be read
         u32 xbL, xbS, xtL, xtS; H.both(x, xbL, xbS, xtL, xtS);
         u32* const tp = (lane & 1) ? HS + xbS : HL + xbL;
         const u32 tv = (ipos + 1) | ((lane & 1) ? xtS : xtL);
-        if (lane < 4) { if (lane & 1) W.markS(xbS); else W.markL(xbL); }     // (a superset of the stores below: harmless)
-        if (!in2 && lane < 2) TST(tp, tv);                                    // top+2 first ...
+        if (lane < 4 && wr) { if (lane & 1) W.markS(xbS); else W.markL(xbL); }  // (a superset of the stores below: harmless)
+        if (!in2 && lane < 2 && wr) TST(tp, tv);                              // top+2 first ...
         asm volatile("" ::: "memory");                                     // two instructions: lanes 0/2 (1/3) may hit the same bucket
         const u64 later = (s == 1 && relE - 2 < nAct ? 0ull : 4ull) | (inE ? 0ull : 8ull);
-        if (lane_in(later)) TST(tp, tv);                                      // ... then ip-2 / ip-1 (same-bucket order per table)
+        if (lane_in(later) && wr) TST(tp, tv);                                // ... then ip-2 / ip-1 (same-bucket order per table)
         here = bcast((u32)x, 4); there = o2 ? bcast((u32)x, 5) : here + 1;
         if (o2 == 0) { here = 0; there = 1; }
       }
@@ -1501,12 +1509,29 @@ __device__ __forceinline__ void mf_dfast_body(const ZraEncArgs& a, u32 block, u3
       u32 rep[3] = {F.st->rep[0], F.st->rep[1], F.st->rep[2]};
       u32 lastLL, nseq = 0;
       const u32 ib = 32 - __builtin_clz(F.fsize - 1);  // bits for position+1 < fsize (fsize >= 7 here)
+      // bucket flags of the frame (zra_lk_prepass_kernel runs ahead of this kernel on CUs of its own): wait for them; without them
+      // (patience over: the call fails) the parse is the same, with every table access made
+      const u8* flg = nullptr;
+      if (!MASK && a.flags && block == 0 && persistent) {
+        const u32 slot = f % a.flagSlots;
+        u32 okf = 1;
+        if (lane == 0) {
+          const u64 t0 = __builtin_amdgcn_s_memtime();
+          while (__hip_atomic_load(&a.flagReady[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != a.flagReadyBase + f + 1) {
+            __builtin_amdgcn_s_sleep(16);
+            if (__builtin_amdgcn_s_memtime() - t0 > 300000000ull) { atomicExch(a.flagFail, 1u); okf = 0; break; }   // (3 s of the 100 MHz clock)
+          }
+        }
+        okf = rfl(okf);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (okf) flg = a.flags + (size_t)slot * a.flagStride;
+      }
       if (MASK) lastLL = mf_dfast_mask(*F.P, F.hashT, F.chainT, F.src, F.fsize, F.bs, F.be, rep, F.seqs, &nseq, W, lane, ib);
       else switch (F.P->minMatch) {
-        case 5: lastLL = mf_dfast_lean<5>(*F.P, F.hashT, F.chainT, F.src, F.bs, F.be, rep, F.seqs, &nseq, W, lane, ib); break;
-        case 6: lastLL = mf_dfast_lean<6>(*F.P, F.hashT, F.chainT, F.src, F.bs, F.be, rep, F.seqs, &nseq, W, lane, ib); break;
-        case 7: lastLL = mf_dfast_lean<7>(*F.P, F.hashT, F.chainT, F.src, F.bs, F.be, rep, F.seqs, &nseq, W, lane, ib); break;
-        default: lastLL = mf_dfast_lean<4>(*F.P, F.hashT, F.chainT, F.src, F.bs, F.be, rep, F.seqs, &nseq, W, lane, ib); break;
+        case 5: lastLL = mf_dfast_lean<5>(*F.P, F.hashT, F.chainT, F.src, F.bs, F.be, rep, F.seqs, &nseq, W, lane, ib, flg); break;
+        case 6: lastLL = mf_dfast_lean<6>(*F.P, F.hashT, F.chainT, F.src, F.bs, F.be, rep, F.seqs, &nseq, W, lane, ib, flg); break;
+        case 7: lastLL = mf_dfast_lean<7>(*F.P, F.hashT, F.chainT, F.src, F.bs, F.be, rep, F.seqs, &nseq, W, lane, ib, flg); break;
+        default: lastLL = mf_dfast_lean<4>(*F.P, F.hashT, F.chainT, F.src, F.bs, F.be, rep, F.seqs, &nseq, W, lane, ib, flg); break;
       }
       if (lane == 0) {
         F.bo->nbSeq = nseq; F.bo->lastLL = lastLL; F.bo->skip = 0;

@@ -180,6 +180,9 @@ struct ZraEncArgs {
   uint32_t* mfQueue;
   uint32_t* mfDone;
   uint32_t mfSubFrames;
+  // bucket flags of zra_lk_prepass_kernel's flags mode (nullptr: none): flags + (frame % flagSlots) * flagStride holds one byte per
+  // position once flagReady[frame % flagSlots] == flagReadyBase + frame + 1
+  const uint8_t* flags; uint64_t flagStride; uint32_t flagSlots; uint32_t flagReadyBase; const uint32_t* flagReady; uint32_t* flagFail;
 };
 
 // ------------------------------------------------------------------------------------------------ encode, "link" dfast (zra_encode_lk.hip)
@@ -189,7 +192,7 @@ struct ZraEncArgs {
 // same 8 (long) / 4 (short) bytes as p); 0 = no predecessor (position 0 is never a candidate: index > prefixLowestIndex)
 #define ZRA_LK_MAX_FRAME 65536u
 #define ZRA_LK_PP_THREADS 1024u
-#define ZRA_LK_PP_LDS (131072u + 16384u + 8192u + 64u)           // heads / links / source copy + per group and block: last lane + block masks
+#define ZRA_LK_PP_LDS 158720u                                     // heads / links / source copy (128 KiB) + per group and block: last lane (16 KiB) + block masks (8 KiB); sized so that nothing else fits the CU
 #define ZRA_LK_PARSE_WAVES 8u                                  // waves of one parse workgroup = frames in flight per CU (16 KiB of bitmaps each)
 #define ZRA_LK_PARSE_LDS (ZRA_LK_PARSE_WAVES * 16384u)
 struct ZraLkArgs {
@@ -202,5 +205,12 @@ struct ZraLkArgs {
   uint32_t* ppQueue;      // frame queue of the pre-pass workgroups
   uint32_t first, count;  // this launch covers frames [first, first + count) of the batch
   uint32_t* fail;         // set when a wait ran out of patience (the call fails instead of hanging)
+  // flags mode (for zra_mf_dfast_kernel): one byte per position instead of entries, ring slot = frame % ringSlots
+  uint8_t* flagsOut; uint64_t flagStride;
+  uint32_t* subDone;      // the match finder's finished-frame counters per sub-batch (ZraEncArgs.mfDone): frees ring slots
+  uint32_t oddTail;       // the batch's last frame is parsed by another kernel (not counted in subDone)
+  uint32_t readyBase;     // ready[] holds readyBase + frame + 1 (unique within a call across super-batches)
+  uint32_t* started;      // counts the pre-pass workgroups that are resident
+  volatile uint32_t* dbg; // bring-up: progress markers in host-visible memory (nullptr otherwise)
 };
 
