@@ -94,6 +94,26 @@ def _cpu_model():
     return "unknown"
 
 
+def _cgroup_cores():
+    """CPU quota of the container in cores (cgroup v2 cpu.max), None when unlimited or unreadable."""
+    try:
+        a, b = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if a == "max" else round(int(a) / float(b), 2)
+    except Exception:
+        return None
+
+
+def _socket_cores():
+    """Physical cores of one socket as /proc/cpuinfo states them (the host's, not the container's quota)."""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("cpu cores"):
+                return int(line.split(":", 1)[1])
+    except Exception:
+        pass
+    return os.cpu_count() or 1
+
+
 def cpu_baseline(sample, frame_size, level, nq, qsize, seed=42):
     """Reference CPU path timed on the host: ZRA container logic (oracle/zo_zra.c, a port of zra.cpp:194-296) over the real
     dependency libzstd 1.4.9 when the image has it, else over the oracle's own restatement. 1 thread (the reference is single-threaded).
@@ -145,14 +165,19 @@ def cpu_baseline(sample, frame_size, level, nq, qsize, seed=42):
     ra = nq * qsize / GiB / (t3 - t2)
     combined = (n + nq * qsize) / GiB / ((t1 - t0) + (t3 - t2))
     return {"value": round(combined, 4), "unit": "GiB/s", "cores": 1, "kind": "port",
-            "sample": "%d MiB of the same corpus: CompressBuffer L%d/%d KiB + %d DecompressRA queries of %d B; container port (oracle/zo_zra.c) over %s; timed spans = the C calls only"
+            "sample": "%d MiB of the same corpus: CompressBuffer L%d/%d KiB + %d DecompressRA queries of %d B (the step's own blend of bytes to queries); container port (oracle/zo_zra.c) over %s, one ZSTD_CCtx per CompressBuffer and one ZSTD_DCtx per DecompressRA like zra.cpp:209,271; timed spans = the C calls only"
                       % (n >> 20, level, frame_size >> 10, nq, qsize, "libzstd " + O.lib().zo_libzstd_version().decode() if backend == "zl" else "the oracle's C restatement"),
             "compress_gibs": round(comp, 4), "ra_gibs": round(ra, 4), "ra_us_per_query": round((t3 - t2) / nq * 1e6, 1),
             "cpu_model": _cpu_model(), "host_cpus": os.cpu_count(),
             "best_case_all_threads": {"compress_gibs": round(mt, 3), "threads": T, "host_cpus": os.cpu_count(),
                                       "cpus_allowed": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None,
                                       "cgroup_cpu_max": (open("/sys/fs/cgroup/cpu.max").read().strip() if os.path.exists("/sys/fs/cgroup/cpu.max") else None),
-                                      "note": "not the reference (single-threaded): %d threads x %d MiB, one libzstd context each" % (T, sl >> 20)}}, arc
+                                      "cpu_limit_cores": _cgroup_cores(),
+                                      "one_thread_in_this_run_gibs": round(comp, 4),
+                                      "full_socket_extrapolation_gibs": round(comp * _socket_cores(), 2), "socket_cores_assumed": _socket_cores(),
+                                      "note": "not the reference (single-threaded): %d threads x %d MiB, one libzstd context each; the threads share the container's CPU "
+                                              "quota (cpu_limit_cores), so this is NOT what the whole socket would do — full_socket_extrapolation_gibs = the 1-thread rate x "
+                                              "the socket's physical cores (frames are independent: an upper bound that ignores memory-bandwidth and turbo effects)" % (T, sl >> 20)}}, arc
 
 
 def kernel_source_sha():
@@ -369,7 +394,9 @@ def main():
     gate = "skipped"
     if rank == 0 and world == 1 and not args.no_cpu_baseline:      # N=1 only (bench contract); N>1 runs reuse the N=1 gate
         samp = min(N, 1 << 30)
-        cpu, cpu_arc = cpu_baseline(np.resize(base, samp), fs, args.level, 50000, qb)
+        # the CPU sample keeps the step's own blend of compressed bytes to queries (16 GiB : 1 M -> 1 GiB : 62.5 k)
+        cpu_nq = max(1000, int(round(q * samp / float(N))))
+        cpu, cpu_arc = cpu_baseline(np.resize(base, samp), fs, args.level, cpu_nq, qb)
         d_s = d_in[:samp]
         d_o = torch.empty(Z.GetOutputBufferSize(samp, fs) + 64, dtype=torch.uint8, device=dev)
         n = eng.compress(d_s.data_ptr(), samp, d_o.data_ptr(), args.level, fs, True)
@@ -479,6 +506,24 @@ def main():
             ra_classes["%d_KiB" % (qsz >> 10)] = {"queries": nq2, "us_per_query": round(dq / nq2 * 1e6, 3), "gibs_returned": round(nq2 * qsz / GiB / dq, 3)}
             del d2
 
+    # like-for-like with the CPU leg (which decodes every touched frame in full and verifies its checksum, as zra.cpp:279-295 does):
+    # the same 1 M queries with ZRA_HIP_OPT_RA_WHOLE_FRAMES, outside the timed region
+    ra_whole = None
+    if world == 1 and not args.timed_only:
+        lib = Z.load()
+        old_opts = lib.ZraHipGetOptions()
+        lib.ZraHipSetOptions(old_opts | 8)
+        try:
+            eng.decompress_ra_batch(d_arc.data_ptr(), arc_size, d_ra.data_ptr(), offs, sizes, oofs)     # warm
+            torch.cuda.synchronize(); tq = time.perf_counter()
+            eng.decompress_ra_batch(d_arc.data_ptr(), arc_size, d_ra.data_ptr(), offs, sizes, oofs)
+            torch.cuda.synchronize(); dq = time.perf_counter() - tq
+            ra_whole = {"us_per_query": round(dq / q * 1e6, 3), "gibs_returned": round(q * qb / GiB / dq, 3),
+                        "note": "every touched frame decoded in full and its XXH64 verified (ZRA_HIP_OPT_RA_WHOLE_FRAMES): the like-for-like of cpu_baseline.ra_us_per_query; "
+                                "the timed step's default stops a frame at the last byte a query needs"}
+        finally:
+            lib.ZraHipSetOptions(old_opts)
+
     ra_latency = None
     if world == 1 and not args.no_cpu_baseline:
         ra_latency = ra_latency_probe(Z, eng, d_arc, arc_size, d_in, N, qb, torch)
@@ -564,6 +609,8 @@ def main():
             "compress_gibs": round(N * world / GiB / (np.mean(comp_ms) / 1e3), 3),
             "ra_gibs_returned": round(q * qb * world / GiB / (np.mean(ra_ms) / 1e3), 3),
             "ra_us_per_query": round(np.mean(ra_ms) * 1e3 / q, 3),
+            "ra_whole_frames": ra_whole,
+            "ra_whole_frames_us_per_query": ra_whole["us_per_query"] if ra_whole else None,
             "ra_size_classes": ra_classes,
             "ra_latency": ra_latency,
             "roofline": {"bound": "hbm", "kernel": mf_kernel, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -572,9 +619,14 @@ def main():
                          "launch_ms": round(mf_launch_ms, 3), "launches_per_call": launches, "algorithmic_bytes_per_launch": int(alg_per_launch),
                          "other_kernels_launch_ms": {"zra_entropy_kernel": round(ent_launch_ms, 3), "zra_dec_parse+huf+chain+exec (one decode pass)": round(dec_launch_ms, 3)}},
             "roofline_ra": {"bound": "hbm", "kernel": "zra_dec_chain_kernel", "achieved": round(ra_ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": round(ra_ach / HBM_PEAK_GBS, 5), "traffic": ra_traffic, "traffic_stale": traffic_stale, "launch_ms": round(chain_ms, 3),
+                            "frac": round(ra_ach / HBM_PEAK_GBS, 5),
+                            "achieved_whole_pass": round(ra_alg / 1e9 / (dec_launch_ms / 1e3), 2) if (ra_alg and dec_launch_ms > 0) else None,
+                            "frac_whole_pass": round(ra_alg / 1e9 / (dec_launch_ms / 1e3) / HBM_PEAK_GBS, 5) if (ra_alg and dec_launch_ms > 0) else None,
+                            "whole_pass_ms": round(dec_launch_ms, 3),
+                            "traffic": ra_traffic, "traffic_stale": traffic_stale, "launch_ms": round(chain_ms, 3),
                             "algorithmic_bytes_per_launch": ra_alg, "touched": ra_touched, "stage_ms_per_pass": stage_ms,
-                            "note": "one decode pass of the touched frames per step; algorithmic = compressed bytes of the touched frames + bytes returned"},
+                            "note": "one decode pass of the touched frames per step; algorithmic = compressed bytes of the touched frames + bytes returned; achieved / frac divide by the chain "
+                                    "kernel's span alone (the pass's dominant kernel), achieved_whole_pass / frac_whole_pass by all four kernels of the pass"},
             "clocks": {"before_timed_region": clocks_before, "after_timed_region": clocks_after},
             "host_pointer_calls": host_calls,
             "cpu_baseline": cpu,

@@ -111,7 +111,8 @@ ZRA_EXPORT ZraStatus ZraHipCommCreateRccl(ZraHipComm** comm, ZraHipEngine* engin
 /** Host transport: the exchange steps are handed to two callbacks of the host program (MPI, sockets, ...) on HOST buffers; device
  *  data is staged. Return 0 for success.
  *    allgather: every rank contributes `bytes` bytes, recv gets world*bytes in rank order.
- *    exchange:  one point-to-point round — all sends and receives of this rank; returns when all of them are complete. */
+ *    exchange:  one point-to-point round — all sends and receives of this rank; returns when all of them are complete.
+ *  engine may be NULL for a communicator that only stitches (ZraHipCommStitchSizes). */
 typedef struct ZraHipHostTransport {
   void* user;
   int (*allgather)(void* user, const void* send, void* recv, size_t bytes);
@@ -128,6 +129,11 @@ ZRA_EXPORT void ZraHipCommDestroy(ZraHipComm* comm);
  *  one GPU would write. */
 ZRA_EXPORT ZraStatus ZraHipCommCompress(ZraHipComm* comm, const void* dLocal, size_t localBytes, uint64_t totalBytes, int8_t compressionLevel,
                                         uint32_t frameSize, bool checksum, ZraHipShard** shard);
+/** The size exchange and stitch alone (zra.cpp:216-230), for frames that were compressed elsewhere: hLocalSizes = the compressed sizes
+ *  of this rank's frames [lo, hi) (nLocal = hi - lo, InputFrameSizeMismatch otherwise). Collective; every rank gets the complete
+ *  header + seek table (ZraHipShardGetHeader), the shard holds no body. Works on a communicator created without an engine. */
+ZRA_EXPORT ZraStatus ZraHipCommStitchSizes(ZraHipComm* comm, const uint64_t* hLocalSizes, size_t nLocal, uint64_t totalBytes, uint32_t frameSize,
+                                           ZraHipShard** shard);
 ZRA_EXPORT void ZraHipShardDestroy(ZraHipShard* shard);
 ZRA_EXPORT size_t ZraHipShardHeaderSize(const ZraHipShard* shard);
 /** Header + seek table of the WHOLE archive (host copy, CRC-32 set). */

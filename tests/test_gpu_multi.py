@@ -40,6 +40,11 @@ def _worker(rank, world, port, fs, level, total, q):
         same = True
         if rank == 0:
             same = n == len(ref) and d_arc[:n].cpu().numpy().tobytes() == ref
+            # ... and == what the oracle's container writes (the CPU restatement of zra.cpp:194-235): the multi-rank row stands on the
+            # oracle itself, not only on the single-engine path
+            import oracle_lib as O
+            st_o, o_ref = O.zra_compress(data, level, fs, True)
+            same = same and st_o == (0, 0) and d_arc[:n].cpu().numpy().tobytes() == o_ref
         # a root that cannot take the archive: every rank gets OutputBufferTooSmall, nobody hangs
         try:
             comm.gather_archive(shard, 0, d_arc.data_ptr() if rank == 0 else 0, 10 if rank == 0 else 0)

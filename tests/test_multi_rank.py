@@ -211,3 +211,74 @@ def test_one_rank_without_rccl_sends_every_rank_to_the_host_transport():
         assert p.exitcode == 0
     got = sorted(q.get(timeout=5) for _ in range(2))
     assert got == [(0, "host", "torch.distributed", ()), (1, "host", "torch.distributed", ("rccl",))]
+
+
+@pytest.mark.parametrize("world,nframes", [(8, 8 * 37), (8, 8 * 37 + 5), (8, 3), (8, 1), (5, 12), (2, 7)])
+def test_eight_rank_stitch_through_the_c_entry_points(world, nframes):
+    """The size exchange of the sharded CompressBuffer (zra_comm.hip: comm_stitch, the all-gather of 8 bytes per frame that replaces the
+    running offset of zra.cpp:216-230) through the C entry points themselves, W ranks as threads of this process talking through the host
+    transport callbacks — no engine, no GPU: ragged F % W, ranks without a frame, and one rank that reports a failure. Every rank must
+    end up with the same header + seek table, and it must be the one a single writer builds from the same sizes (Z.stitch_header, whose
+    bytes the oracle's container is compared with in test_two_rank_shard_stitch_route_serve)."""
+    import ctypes
+    import threading
+    import zra_amd as Z
+    L = Z.load()
+    L.ZraHipCommStitchSizes.restype = Z.ZraStatus if hasattr(Z, "ZraStatus") else L.ZraHipCommCreateHost.restype
+    fs = 4096
+    rng = np.random.RandomState(nframes * 31 + world)
+    sizes = rng.randint(20, fs + 200, size=nframes).astype(np.uint64)
+    total = (nframes - 1) * fs + 1234
+    bar = threading.Barrier(world)
+    board = [None] * world
+    results = [None] * world
+
+    def run(rank, fail_rank):
+        def allgather(user, send, recv, nbytes):
+            board[rank] = ctypes.string_at(send, nbytes)
+            bar.wait()
+            ctypes.memmove(recv, b"".join(board), nbytes * world)
+            bar.wait()
+            return 0
+
+        def exchange(*a):
+            return 1
+        tr = Z.ZraHipHostTransport(None, Z.ALLGATHER_FN(allgather), Z.EXCHANGE_FN(exchange))
+        h = ctypes.c_void_p()
+        st = L.ZraHipCommCreateHost(ctypes.byref(h), None, ctypes.byref(tr), rank, world)
+        assert (st.zra, st.zstd) == (0, 0)
+        lo, hi = sharding.shard_range(nframes, rank, world)
+        mine = np.ascontiguousarray(sizes[lo:hi])
+        n_local = hi - lo + (1 if rank == fail_rank else 0)            # a wrong share: InputFrameSizeMismatch on that rank -> on every rank
+        sh = ctypes.c_void_p()
+        st = L.ZraHipCommStitchSizes(h, mine.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(n_local), ctypes.c_uint64(total), ctypes.c_uint32(fs), ctypes.byref(sh))
+        out = (st.zra, st.zstd, None, None)
+        if st.zra == 0:
+            L.ZraHipShardHeaderSize.restype = ctypes.c_size_t
+            n = L.ZraHipShardHeaderSize(sh)
+            buf = ctypes.create_string_buffer(n)
+            L.ZraHipShardGetHeader(sh, buf)
+            L.ZraHipShardArchiveSize.restype = ctypes.c_uint64
+            out = (0, 0, buf.raw, L.ZraHipShardArchiveSize(sh))
+            L.ZraHipShardDestroy(sh)
+        L.ZraHipCommDestroy(h)
+        results[rank] = out
+
+    from zra_amd import sharding
+    for fail_rank in (-1, world - 1):
+        bar.reset()
+        th = [threading.Thread(target=run, args=(r, fail_rank)) for r in range(world)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join(60)
+        assert all(r is not None for r in results)
+        if fail_rank < 0:
+            want = Z.stitch_header(sizes, total, fs)
+            assert all(r[0] == 0 and r[2] == want and r[3] == len(want) + int(sizes.sum()) for r in results), [r[:2] for r in results]
+            # the seek table is the running offset: entry i = sum of the sizes before frame i, the last one = the body size
+            ent = [int.from_bytes(want[38 + 5 * i: 43 + 5 * i], "little") for i in range(nframes + 1)]
+            assert ent == [int(x) for x in np.concatenate([[0], np.cumsum(sizes)])]
+        else:
+            assert all(r[:2] == results[0][:2] and r[0] != 0 for r in results), [r[:2] for r in results]
+        results = [None] * world

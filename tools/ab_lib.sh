@@ -7,7 +7,7 @@ for r in $(seq 1 ${AB_REPS:-2}); do
   for e in ${AB_ENVS:--}; do
     for lib in A B; do
       L=$root/zra_amd/libzra_amd.so; [ $lib = B ] && L=$root/zra_amd/libzra_amd_B.so
-      if [ "$e" = "-" ]; then spec="ZRA_AMD_LIB=$L"; else spec="ZRA_AMD_LIB=$L;$e"; fi
+      if [ "$e" = "-" ]; then spec="ZRA_AMD_BRINGUP=1;ZRA_AMD_LIB=$L"; else spec="ZRA_AMD_BRINGUP=1;ZRA_AMD_LIB=$L;$e"; fi
       echo -n "$lib $e: " >> $out
       timeout 600 python3 tools/bringup/gpu_mf_sweep.py "$spec" 2>&1 | tail -1 >> $out
     done

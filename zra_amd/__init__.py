@@ -11,7 +11,7 @@ import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libzra_amd.so")
-if os.environ.get("ZRA_AMD_LIB"):          # bring-up A/B of two builds on one box (tools/ab_lib.sh); never set in production
+if os.environ.get("ZRA_AMD_LIB") and os.environ.get("ZRA_AMD_BRINGUP") == "1":   # bring-up A/B of two builds on one box (tools/ab_lib.sh): both variables, never in production
     LIB_PATH = os.environ["ZRA_AMD_LIB"]
 
 STATUS_NAMES = ["Success", "ZStdError", "ZraVersionLow", "HeaderInvalid", "HeaderIncomplete", "OutOfBoundsAccess",

@@ -225,20 +225,53 @@ ZraStatus ZraHipCommCreateRccl(ZraHipComm** comm, ZraHipEngine* engine, const vo
 
 ZraStatus ZraHipCommCreateHost(ZraHipComm** comm, ZraHipEngine* engine, const ZraHipHostTransport* t, int rank, int world) {
   *comm = nullptr;
-  if (!engine || !t || !t->allgather || !t->exchange || world < 1 || rank < 0 || rank >= world) return mk(ZStdError, 42);
+  // engine == NULL: a communicator for the size exchange alone (ZraHipCommStitchSizes; hosts that compress elsewhere, and the CPU tests)
+  if (!t || !t->allgather || !t->exchange || world < 1 || rank < 0 || rank >= world) return mk(ZStdError, 42);
   ZraHipComm* c = new ZraHipComm();
-  c->eng = engine->e; c->rank = rank; c->world = world; c->host = *t; c->useHost = true;
+  c->eng = engine ? engine->e : nullptr; c->rank = rank; c->world = world; c->host = *t; c->useHost = true;
   *comm = c;
   return mk(Success);
 }
 
 void ZraHipCommDestroy(ZraHipComm* c) {
   if (!c) return;
-  (void)hipSetDevice(c->eng->device());
-  (void)hipStreamSynchronize(c->eng->stream());
+  if (c->eng) { (void)hipSetDevice(c->eng->device()); (void)hipStreamSynchronize(c->eng->stream()); }
   if (c->nccl) (void)rccl().CommDestroy(c->nccl);
   for (DevBuf* b : {&c->stage, &c->stage2, &c->served, &c->received, &c->slices}) b->release();
   delete c;
+}
+
+// The size exchange + stitch of the sharded CompressBuffer (zra.cpp:216-230: the running offset that becomes the seek table): every rank
+// contributes its status and the sizes of its frames (8 bytes per frame, one all-gather), and builds the complete header + seek table.
+// Fills sh->header, bodyBaseOf, bodyBase, bodyTotal. All ranks return the same status (the first failing rank's).
+static ZraStatus comm_stitch(ZraHipComm* c, ZraHipShard* sh, Status st, const std::vector<uint64_t>& mySizes, uint64_t F, uint64_t totalBytes,
+                             uint32_t frameSize, size_t headerSize) {
+  // sizes of everybody's frames: ranks hold floor/ceil(F / W) frames, padded to the largest share
+  const size_t maxLocal = (size_t)((F + c->world - 1) / c->world) + 1;
+  std::vector<uint64_t> send(maxLocal + 2, 0), all((maxLocal + 2) * (size_t)c->world);
+  send[0] = (uint64_t)(uint32_t)st.zra | ((uint64_t)(uint32_t)st.zstd << 32); send[1] = mySizes.size();
+  std::copy(mySizes.begin(), mySizes.end(), send.begin() + 2);
+  if (!c->allgather(send.data(), all.data(), send.size() * 8)) { return mk(ZStdError, 1); }
+  for (int r = 0; r < c->world; r++) {
+    const uint64_t w = all[(maxLocal + 2) * (size_t)r];
+    if ((uint32_t)w) { return mk((int)(uint32_t)w, (int)(int32_t)(w >> 32)); }
+  }
+  std::vector<uint64_t> sizes; sizes.reserve(F);
+  sh->bodyBaseOf.assign((size_t)c->world + 1, 0);
+  uint64_t run = 0;
+  for (int r = 0; r < c->world; r++) {
+    const uint64_t* p = &all[(maxLocal + 2) * (size_t)r];
+    sh->bodyBaseOf[r] = run;
+    for (uint64_t i = 0; i < p[1]; i++) { sizes.push_back(p[2 + i]); run += p[2 + i]; }
+  }
+  sh->bodyBaseOf[c->world] = run;
+  if (sizes.size() != F) { return mk(ZStdError, 1); }
+  sh->header.resize(headerSize);
+  size_t hs = 0;
+  ZraStatus zs = ZraHipStitchHeader(sizes.data(), F, totalBytes, frameSize, sh->header.data(), &hs);     // same on every rank
+  if (zs.zra) { return zs; }
+  sh->bodyBase = sh->bodyBaseOf[c->rank]; sh->bodyTotal = run;
+  return mk(Success);
 }
 
 // The sharded CompressBuffer (zra.cpp:194-235 with its frame loop split by rank). dLocal: the uncompressed bytes of this rank's frames
@@ -269,31 +302,9 @@ ZraStatus ZraHipCommCompress(ZraHipComm* c, const void* dLocal, size_t localByte
       if (hipMemcpy(mySizes.data(), dSizes, nLocal * 8, hipMemcpyDeviceToHost) != hipSuccess) st = zra_eng::zerr(1);
     }
   }
-  // sizes of everybody's frames: ranks hold floor/ceil(F / W) frames, padded to the largest share
-  const size_t maxLocal = (size_t)((F + c->world - 1) / c->world) + 1;
-  std::vector<uint64_t> send(maxLocal + 2, 0), all((maxLocal + 2) * (size_t)c->world);
-  send[0] = (uint64_t)(uint32_t)st.zra | ((uint64_t)(uint32_t)st.zstd << 32); send[1] = mySizes.size();
-  std::copy(mySizes.begin(), mySizes.end(), send.begin() + 2);
-  if (!c->allgather(send.data(), all.data(), send.size() * 8)) { delete sh; return mk(ZStdError, 1); }
-  for (int r = 0; r < c->world; r++) {
-    const uint64_t w = all[(maxLocal + 2) * (size_t)r];
-    if ((uint32_t)w) { delete sh; return mk((int)(uint32_t)w, (int)(int32_t)(w >> 32)); }
-  }
-  std::vector<uint64_t> sizes; sizes.reserve(F);
-  sh->bodyBaseOf.assign((size_t)c->world + 1, 0);
-  uint64_t run = 0;
-  for (int r = 0; r < c->world; r++) {
-    const uint64_t* p = &all[(maxLocal + 2) * (size_t)r];
-    sh->bodyBaseOf[r] = run;
-    for (uint64_t i = 0; i < p[1]; i++) { sizes.push_back(p[2 + i]); run += p[2 + i]; }
-  }
-  sh->bodyBaseOf[c->world] = run;
-  if (sizes.size() != F) { delete sh; return mk(ZStdError, 1); }
-  sh->header.resize(headerSize);
-  size_t hs = 0;
-  ZraStatus zs = ZraHipStitchHeader(sizes.data(), F, totalBytes, frameSize, sh->header.data(), &hs);     // same on every rank
+  ZraStatus zs = comm_stitch(c, sh, st, mySizes, F, totalBytes, frameSize, headerSize);
   if (zs.zra) { delete sh; return zs; }
-  sh->bodyBase = sh->bodyBaseOf[c->rank]; sh->bodyBytes = bodyBytes; sh->bodyTotal = run;
+  sh->bodyBytes = bodyBytes;
   if (hipMemcpy(sh->dev.p, sh->header.data(), headerSize, hipMemcpyHostToDevice) != hipSuccess) { delete sh; return mk(ZStdError, 1); }
   // the shard keeps what it holds, not the compress-bound sized work buffer (a third of it at ratio 3)
   if (headerSize + bodyBytes + (64u << 20) < sh->dev.cap) {
@@ -308,10 +319,30 @@ ZraStatus ZraHipCommCompress(ZraHipComm* c, const void* dLocal, size_t localByte
   return mk(Success);
 }
 
+// The stitch alone, from frame sizes the caller already holds on the host (frames compressed elsewhere; also what the CPU tests drive with
+// eight ranks): collective like ZraHipCommCompress, the shard it returns holds the complete header + seek table and no body.
+ZraStatus ZraHipCommStitchSizes(ZraHipComm* c, const uint64_t* hLocalSizes, size_t nLocal, uint64_t totalBytes, uint32_t frameSize, ZraHipShard** shardOut) {
+  *shardOut = nullptr;
+  if (!frameSize) return c->agree(zra_eng::zerr(42));
+  const uint64_t F = (totalBytes + frameSize - 1) / frameSize;
+  uint64_t lo, hi; ZraHipShardRange(F, c->rank, c->world, &lo, &hi);
+  ZraHipShard* sh = new ZraHipShard();
+  sh->device = c->eng ? c->eng->device() : 0; sh->nFrames = F; sh->lo = lo; sh->hi = hi; sh->total = totalBytes; sh->frameSize = frameSize;
+  Status st = zra_eng::ok();
+  std::vector<uint64_t> mySizes;
+  if (nLocal != (size_t)(hi - lo)) st = Status{zra_eng::kFrameSizeMismatch, 0};
+  else mySizes.assign(hLocalSizes, hLocalSizes + nLocal);
+  const size_t headerSize = zra_fmt::kFixedSize + (size_t)(F + 1) * zra_fmt::kEntrySize;
+  ZraStatus zs = comm_stitch(c, sh, st, mySizes, F, totalBytes, frameSize, headerSize);
+  if (zs.zra) { delete sh; return zs; }
+  for (uint64_t v : mySizes) sh->bodyBytes += v;
+  *shardOut = sh;
+  return mk(Success);
+}
+
 void ZraHipShardDestroy(ZraHipShard* s) {
   if (!s) return;
-  (void)hipSetDevice(s->device);
-  s->dev.release();
+  if (s->dev.p) { (void)hipSetDevice(s->device); s->dev.release(); }
   delete s;
 }
 size_t ZraHipShardHeaderSize(const ZraHipShard* s) { return s->header.size(); }

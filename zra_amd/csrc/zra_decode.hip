@@ -1782,7 +1782,8 @@ zra_dec_exec_kernel(ZraDecodeArgs a) {
 // zra_dec_chain_kernel's step — the 64-bit sequence loop on a well-formed stream; whatever that loop would have to look at twice (a
 // sequence that fails a check, the long-offset loop, a literal stream the decoder rejects, a stream that is not consumed exactly) makes
 // the job BAIL: the host then takes the whole batch through the four-kernel pipeline, which is where every status of the reference is
-// reproduced. Valid archives never bail.
+// reproduced. Valid archives rarely bail: a sequence bitstream shorter than 8 bytes (a highly compressible frame with one to three
+// sequences) and the long-offset mode do — such a batch pays the one-launch pass and the four-kernel pass.
 namespace {
 // chain ring of the one-launch kernel (chain_produce / chain_consume below)
 constexpr u32 RING = 256;                        // ring entries (power of two)

@@ -378,20 +378,27 @@ Status Engine::compress_persistent(const uint8_t* dIn, size_t inSize, uint8_t* d
     uint64_t mine = 0; for (auto& x : encCtx_) mine += x.seqs.cap;
     budget = std::min<uint64_t>(64ull << 30, std::max<uint64_t>(8ull << 30, ((uint64_t)freeB + mine) / 3));
   }
-  uint64_t SBIG = std::max<uint64_t>(1, std::min<uint64_t>(nFramesTotal, budget / perFrame));
-  if (const char* e = std::getenv("ZRA_ENC_SUPER")) SBIG = std::max<uint64_t>(1, std::min<uint64_t>(SBIG, (uint64_t)std::atoll(e)));   // bring-up knob
-  if (SBIG > SB) SBIG -= SBIG % SB;
-  const int nCtx = nFramesTotal > SBIG ? 2 : 1;
-  const uint64_t nSuper = (nFramesTotal + SBIG - 1) / SBIG;
-  const uint64_t subsPerSuper = (SBIG + SB - 1) / SB;
+  // the budget is a wish (other engines of the pool, other ranks on the device and the caller's own buffers read the same free-memory
+  // figure): a reservation that fails is tried again with half of it, down to 1 GiB, before the call gives up with memory_allocation
+  uint64_t SBIG = 0, nSuper = 0, subsPerSuper = 0; int nCtx = 1;
   EncCtx& sh = encCtx_[0];                       // shared: table slots, and the literal / slot buffers of ONE sub-batch (stream B is in order)
-  const uint64_t subFrames = std::min<uint64_t>(SB, SBIG);
-  if (!sh.tables.reserve((size_t)nSlots * tableWords * 4) || !sh.lits.reserve(subFrames * litStride) || !sh.slots.reserve(subFrames * slotStride)) return zerr(64);
-  for (int c = 0; c < nCtx; c++) {
-    EncCtx& x = encCtx_[c];
-    if (!x.seqs.reserve(SBIG * seqStride * 8) || !x.misc.reserve(SBIG * (sizeof(ZraEncFrameState) + sizeof(ZraEncBlockOut))) ||
-        !x.ck.reserve((size_t)SBIG * 4) || !x.sizes.reserve((size_t)SBIG * 16))
-      return zerr(64);
+  for (;; budget /= 2) {
+    SBIG = std::max<uint64_t>(1, std::min<uint64_t>(nFramesTotal, budget / perFrame));
+    if (const char* e = std::getenv("ZRA_ENC_SUPER")) SBIG = std::max<uint64_t>(1, std::min<uint64_t>(SBIG, (uint64_t)std::atoll(e)));   // bring-up knob
+    if (SBIG > SB) SBIG -= SBIG % SB;
+    nCtx = nFramesTotal > SBIG ? 2 : 1;
+    nSuper = (nFramesTotal + SBIG - 1) / SBIG;
+    subsPerSuper = (SBIG + SB - 1) / SB;
+    const uint64_t subFrames = std::min<uint64_t>(SB, SBIG);
+    bool okR = sh.tables.reserve((size_t)nSlots * tableWords * 4) && sh.lits.reserve(subFrames * litStride) && sh.slots.reserve(subFrames * slotStride);
+    for (int c = 0; c < nCtx && okR; c++) {
+      EncCtx& x = encCtx_[c];
+      okR = x.seqs.reserve(SBIG * seqStride * 8) && x.misc.reserve(SBIG * (sizeof(ZraEncFrameState) + sizeof(ZraEncBlockOut))) &&
+            x.ck.reserve((size_t)SBIG * 4) && x.sizes.reserve((size_t)SBIG * 16);
+    }
+    if (okR) break;
+    if (budget <= (1ull << 30) || SBIG <= SB) return zerr(64);
+    (void)hipGetLastError();
   }
   // counters: [u64 running offset][u32 queue per super-batch][u32 done per sub-batch]
   const size_t cntBytes = 16 + 4 * (size_t)(nSuper + nSuper * subsPerSuper + 4);

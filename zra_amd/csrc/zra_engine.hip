@@ -615,9 +615,12 @@ Status Engine::decode_jobs(const uint8_t* dBody, uint64_t bodySize, const uint64
   uint64_t* dSpecOff = (uint64_t*)(seqScratch_.as<uint8_t>() + 64); uint32_t* dSpecCap = (uint32_t*)(seqScratch_.as<uint8_t>() + 64 + (size_t)kSpec * 8);
   std::vector<uint64_t> hOff; std::vector<uint32_t> hCap, hProduced, hStatus;
   uint32_t guess = 0;
+  // the side-by-side batch grows geometrically while the guess holds and starts small again after a miss: an archive whose frame sizes
+  // alternate would otherwise decode up to 64 Ki frames to advance by one (quadratic work an untrusted archive could ask for)
+  uint32_t specB = 16;
   for (uint32_t f = first; f < nFrames;) {
     if (guess && nFrames - f >= 2 && seqTotal > cur) {
-      const uint32_t B = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(nFrames - f, kSpec), (seqTotal - cur) / guess);
+      const uint32_t B = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(std::min<uint64_t>(nFrames - f, kSpec), specB), (seqTotal - cur) / guess);
       if (B >= 2) {
         hOff.resize(B); hCap.assign(B, guess); hProduced.resize(B); hStatus.resize(B);
         for (uint32_t i = 0; i < B; i++) hOff[i] = cur + (uint64_t)i * guess;
@@ -628,7 +631,8 @@ Status Engine::decode_jobs(const uint8_t* dBody, uint64_t bodySize, const uint64
         b.frameOff = dFrameOff + (size_t)f * offStride; b.outOff = dSpecOff; b.outCap = dSpecCap; b.nFrames = B;
         b.limit = nullptr; b.pieceBase = nullptr; b.pieces = nullptr;
         unsigned long long r2 = ~0ull;
-        Status st = decode_launch(b, nullptr, guess, f, &r2);
+        // (scratch sized for real frames, not for a tiny guess in front of full-size ones: a block is at most 128 KiB)
+        Status st = decode_launch(b, nullptr, std::max<uint32_t>(guess, std::min<uint32_t>(maxFrameBytes ? maxFrameBytes : (128u << 10), 128u << 10)), f, &r2);
         if (st.zra) return st;
         HIPCHK(hipMemcpyAsync(hProduced.data(), produced_.p, (size_t)B * 4, hipMemcpyDeviceToHost, stream_));
         HIPCHK(hipMemcpyAsync(hStatus.data(), status_.p, (size_t)B * 4, hipMemcpyDeviceToHost, stream_));
@@ -636,6 +640,7 @@ Status Engine::decode_jobs(const uint8_t* dBody, uint64_t bodySize, const uint64
         uint32_t k = 0;
         while (k < B && hStatus[k] == 0 && hProduced[k] == guess) k++;
         cur += (uint64_t)k * guess; f += k;
+        specB = k == B ? (uint32_t)std::min<uint64_t>((uint64_t)specB * 4, kSpec) : 16u;
         if (f >= nFrames) break;
       }
     }
