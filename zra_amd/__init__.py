@@ -154,7 +154,7 @@ C_ABI_SYMBOLS = [
 HIP_ABI_SYMBOLS = ["ZraHipDeviceCount", "ZraHipCreateEngine", "ZraHipDestroyEngine", "ZraHipSynchronize", "ZraHipGetStream", "ZraHipWaitStream", "ZraHipReleaseScratch", "ZraHipLastKernelMs", "ZraHipGetKernelStats", "ZraHipGetDecodeStageStats",
                    "ZraHipCompressBuffer", "ZraHipDecompressBuffer", "ZraHipDecompressRABatch", "ZraHipCompressFrames", "ZraHipStitchHeader", "ZraHipDebugReadSeqs", "ZraHipSetOptions", "ZraHipGetOptions",
                    "ZraHipShardRange", "ZraHipOwnerOfFrame", "ZraHipRouteQueries", "ZraHipCommGetUniqueId", "ZraHipCommCreateRccl", "ZraHipCommCreateHost", "ZraHipCommDestroy",
-                   "ZraHipCommCompress", "ZraHipShardDestroy", "ZraHipShardHeaderSize", "ZraHipShardGetHeader", "ZraHipShardArchiveSize", "ZraHipShardGetBody",
+                   "ZraHipCommCompress", "ZraHipCommStitchSizes", "ZraHipShardDestroy", "ZraHipShardHeaderSize", "ZraHipShardGetHeader", "ZraHipShardArchiveSize", "ZraHipShardGetBody",
                    "ZraHipCommGatherArchive", "ZraHipCommServe"]
 
 

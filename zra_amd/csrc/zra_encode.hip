@@ -17,6 +17,7 @@ extern "C" __global__ void zra_mf_hc_kernel(ZraEncArgs a, uint32_t block);
 extern "C" __global__ void zra_mf_fast_kernel(ZraEncArgs a, uint32_t block, uint32_t perWave);
 extern "C" __global__ void zra_mf_dfast_kernel(ZraEncArgs a, uint32_t block, uint32_t only, uint32_t onlySlot);
 extern "C" __global__ void zra_mf_dfast2_kernel(ZraEncArgs a, uint32_t block, uint32_t only, uint32_t onlySlot);
+extern "C" __global__ void zra_mf_dfast_fl_kernel(ZraEncArgs a, ZraFlagArgs g, uint32_t block, uint32_t only, uint32_t onlySlot);
 // which dfast parse runs: the window-resolve kernel, or with ZRA_MF_V2=1 the mask-resolve kernel of round 3 (bit-exact, fewer memory
 // round trips per sequence, but 45 % more instructions as compiled: slower today — profiles/r03_experiments.md)
 static bool mf_v2() { static const bool v = std::getenv("ZRA_MF_V2") && std::atoi(std::getenv("ZRA_MF_V2")) != 0; return v; }
@@ -547,10 +548,10 @@ Status Engine::compress_persistent(const uint8_t* dIn, size_t inSize, uint8_t* d
         std::fflush(stderr);
       }
       if (lkStream != stream_) HIPCHK(hipStreamWaitValue32(stream_, fk.started, ppStarted, hipStreamWaitValueGte, 0xFFFFFFFFu));
-      ZraEncArgs a2 = a;
-      a2.flags = fk.flagsOut; a2.flagStride = fk.flagStride; a2.flagSlots = fk.ringSlots; a2.flagReadyBase = (uint32_t)F0; a2.flagReady = fk.ready; a2.flagFail = fk.fail;
+      ZraFlagArgs fa{};
+      fa.flags = fk.flagsOut; fa.flagStride = fk.flagStride; fa.flagSlots = fk.ringSlots; fa.flagReadyBase = (uint32_t)F0; fa.flagReady = fk.ready; fa.flagFail = fk.fail;
       const uint32_t slots = (uint32_t)std::min<uint64_t>((uint64_t)((uint32_t)numCUs_ - ppGrid) * wavesPerCU, nSlots);
-      hipLaunchKernelGGL(ZRA_DFAST_KERNEL, dim3(std::min<uint32_t>(n, slots)), dim3(64), filterBytes, stream_, a2, 0u, 0xFFFFFFFFu, 0u);
+      hipLaunchKernelGGL(zra_mf_dfast_fl_kernel, dim3(std::min<uint32_t>(n, slots)), dim3(64), filterBytes, stream_, a, fa, 0u, 0xFFFFFFFFu, 0u);
     } else if (!useLk) hipLaunchKernelGGL(ZRA_DFAST_KERNEL, dim3(std::min<uint32_t>(n, nSlots)), dim3(64), filterBytes, stream_, a, 0u, 0xFFFFFFFFu, 0u);
     else if (lkMode == 1) {
       // both kernels persistent: the pre-pass on its own stream behind everything queued on stream A so far (the ring and its flags

@@ -433,9 +433,10 @@ struct LeanLds {
 #define TLD(p) (*(p))
 #define TST(p, v) (*(p) = (v))
 #endif
-template <u32 MLS>
+template <u32 MLS, bool FLAGS>
 __device__ u32 mf_dfast_lean(const ZraEncParams& P, u32* HL, u32* HS, const u8* src, u32 bs, u32 be, u32* rep, u64* seqs, u32* nOut,
-                             const LeanLds& W, int lane, u32 ib, const u8* flg) {
+                             const LeanLds& W, int lane, u32 ib, const u8* flgIn) {
+  const u8* const flg = FLAGS ? flgIn : nullptr;       // (the kernel without flags carries none of their code or registers)
   // flg (round 4, zra_lk_prepass_kernel's flags mode; nullptr: none): one byte per position, bit 0 / 1 = the position's long bucket has an
   // earlier / a later position of the frame, bit 2 / 3 = its short bucket. A lookup without an earlier position would read the cleared
   // cell; an insertion without a later position is never looked up: both are skipped — about half of the table's fabric requests.
@@ -1463,8 +1464,8 @@ __device__ __forceinline__ void mf_serial_block_t(const MfFrame& F, u32 ntu0) {
 
 // Match finder for strategy 2 (dfast, levels 3-4): one wave per frame, lean window-resolve parse. Launched when the batch's
 // full-size frames use dfast; a short last frame with another strategy is left to zra_mf_kernel (second launch, `only`).
-template <bool MASK>
-__device__ __forceinline__ void mf_dfast_body(const ZraEncArgs& a, u32 block, u32 only, u32 onlySlot) {
+template <bool MASK, bool FLAGS>
+__device__ __forceinline__ void mf_dfast_body(const ZraEncArgs& a, u32 block, u32 only, u32 onlySlot, const ZraFlagArgs* g = nullptr) {
   const int lane = threadIdx.x;
   // dynamic LDS: [dup bytes 2 x dupSlots][filter L][filter S]; geometry chosen by the host (a.mfFilter: shL | shS<<4 | log2(dupSlots)<<8)
   extern __shared__ u32 dynLds[];
@@ -1512,26 +1513,26 @@ __device__ __forceinline__ void mf_dfast_body(const ZraEncArgs& a, u32 block, u3
       // bucket flags of the frame (zra_lk_prepass_kernel runs ahead of this kernel on CUs of its own): wait for them; without them
       // (patience over: the call fails) the parse is the same, with every table access made
       const u8* flg = nullptr;
-      if (!MASK && a.flags && block == 0 && persistent) {
-        const u32 slot = f % a.flagSlots;
+      if (FLAGS && !MASK && g && g->flags && block == 0 && persistent) {
+        const u32 slot = f % g->flagSlots;
         u32 okf = 1;
         if (lane == 0) {
           const u64 t0 = __builtin_amdgcn_s_memtime();
-          while (__hip_atomic_load(&a.flagReady[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != a.flagReadyBase + f + 1) {
+          while (__hip_atomic_load(&g->flagReady[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != g->flagReadyBase + f + 1) {
             __builtin_amdgcn_s_sleep(16);
-            if (__builtin_amdgcn_s_memtime() - t0 > 300000000ull) { atomicExch(a.flagFail, 1u); okf = 0; break; }   // (3 s of the 100 MHz clock)
+            if (__builtin_amdgcn_s_memtime() - t0 > 300000000ull) { atomicExch(g->flagFail, 1u); okf = 0; break; }   // (3 s of the 100 MHz clock)
           }
         }
         okf = rfl(okf);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        if (okf) flg = a.flags + (size_t)slot * a.flagStride;
+        if (okf) flg = g->flags + (size_t)slot * g->flagStride;
       }
       if (MASK) lastLL = mf_dfast_mask(*F.P, F.hashT, F.chainT, F.src, F.fsize, F.bs, F.be, rep, F.seqs, &nseq, W, lane, ib);
       else switch (F.P->minMatch) {
-        case 5: lastLL = mf_dfast_lean<5>(*F.P, F.hashT, F.chainT, F.src, F.bs, F.be, rep, F.seqs, &nseq, W, lane, ib, flg); break;
-        case 6: lastLL = mf_dfast_lean<6>(*F.P, F.hashT, F.chainT, F.src, F.bs, F.be, rep, F.seqs, &nseq, W, lane, ib, flg); break;
-        case 7: lastLL = mf_dfast_lean<7>(*F.P, F.hashT, F.chainT, F.src, F.bs, F.be, rep, F.seqs, &nseq, W, lane, ib, flg); break;
-        default: lastLL = mf_dfast_lean<4>(*F.P, F.hashT, F.chainT, F.src, F.bs, F.be, rep, F.seqs, &nseq, W, lane, ib, flg); break;
+        case 5: lastLL = mf_dfast_lean<5, FLAGS>(*F.P, F.hashT, F.chainT, F.src, F.bs, F.be, rep, F.seqs, &nseq, W, lane, ib, flg); break;
+        case 6: lastLL = mf_dfast_lean<6, FLAGS>(*F.P, F.hashT, F.chainT, F.src, F.bs, F.be, rep, F.seqs, &nseq, W, lane, ib, flg); break;
+        case 7: lastLL = mf_dfast_lean<7, FLAGS>(*F.P, F.hashT, F.chainT, F.src, F.bs, F.be, rep, F.seqs, &nseq, W, lane, ib, flg); break;
+        default: lastLL = mf_dfast_lean<4, FLAGS>(*F.P, F.hashT, F.chainT, F.src, F.bs, F.be, rep, F.seqs, &nseq, W, lane, ib, flg); break;
       }
       if (lane == 0) {
         F.bo->nbSeq = nseq; F.bo->lastLL = lastLL; F.bo->skip = 0;
@@ -1552,10 +1553,13 @@ __device__ __forceinline__ void mf_dfast_body(const ZraEncArgs& a, u32 block, u3
 }
 
 extern "C" __global__ void __launch_bounds__(64)
-zra_mf_dfast_kernel(ZraEncArgs a, u32 block, u32 only, u32 onlySlot) { mf_dfast_body<false>(a, block, only, onlySlot); }
+zra_mf_dfast_kernel(ZraEncArgs a, u32 block, u32 only, u32 onlySlot) { mf_dfast_body<false, false>(a, block, only, onlySlot); }
+// the same parse fed with the pre-pass's bucket flags (round 4, opt-in ZRA_MF_FLAGS=1: skips the table reads and writes that cannot matter)
+extern "C" __global__ void __launch_bounds__(64)
+zra_mf_dfast_fl_kernel(ZraEncArgs a, ZraFlagArgs g, u32 block, u32 only, u32 onlySlot) { mf_dfast_body<false, true>(a, block, only, onlySlot, &g); }
 // the mask-resolve parse (round 3): more registers, meant for few resident waves per CU with the tables inside the Infinity Cache
 extern "C" __global__ void __launch_bounds__(64)
-zra_mf_dfast2_kernel(ZraEncArgs a, u32 block, u32 only, u32 onlySlot) { mf_dfast_body<true>(a, block, only, onlySlot); }
+zra_mf_dfast2_kernel(ZraEncArgs a, u32 block, u32 only, u32 onlySlot) { mf_dfast_body<true, false>(a, block, only, onlySlot); }
 
 // Match finder for everything the lean kernels do not take (btlazy2, the optimal parsers, frames larger than the level's window, single
 // odd tails of any strategy). The parse of a frame is one dependent pointer chase (hash head

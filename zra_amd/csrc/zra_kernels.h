@@ -180,8 +180,10 @@ struct ZraEncArgs {
   uint32_t* mfQueue;
   uint32_t* mfDone;
   uint32_t mfSubFrames;
-  // bucket flags of zra_lk_prepass_kernel's flags mode (nullptr: none): flags + (frame % flagSlots) * flagStride holds one byte per
-  // position once flagReady[frame % flagSlots] == flagReadyBase + frame + 1
+};
+// bucket flags of zra_lk_prepass_kernel's flags mode, for zra_mf_dfast_fl_kernel: flags + (frame % flagSlots) * flagStride holds one
+// byte per position once flagReady[frame % flagSlots] == flagReadyBase + frame + 1
+struct ZraFlagArgs {
   const uint8_t* flags; uint64_t flagStride; uint32_t flagSlots; uint32_t flagReadyBase; const uint32_t* flagReady; uint32_t* flagFail;
 };
 
