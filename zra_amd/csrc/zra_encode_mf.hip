@@ -478,7 +478,7 @@ __device__ u32 mf_dfast_lean(const ZraEncParams& P, u32* HL, u32* HS, const u8* 
     bool active = (u32)lane < nAct;
     const u32 p = wip + (u32)lane * s;
     const u64 v8 = active ? ld64(src + p) : 0;
-    const u32 fb = (flg && active) ? flg[p] : 0x0Fu;
+    const u32 bflags = (flg && active) ? flg[p] : 0x0Fu;   // (NOT `fb`: that name is the match's forward-compare address further down)
     // rep gather for the current o1 (independent of the tables: in flight together with them)
     u32 repFor = o1;
     bool rv = active && o1 > 0 && p + 1 >= o1;
@@ -507,7 +507,7 @@ __device__ u32 mf_dfast_lean(const ZraEncParams& P, u32* HL, u32* HS, const u8* 
     const u32 wL = gL >> 5, wS = gS >> 5, qL = 1u << (gL & 31), qS = 1u << (gS & 31);
     u32 mL = 0, mS = 0;
     if (active) {
-      const bool needL = (fb & 1) && (bmL[wL] & qL) != 0, needS = (fb & 4) && (bmS[wS] & qS) != 0;
+      const bool needL = (bflags & 1) && (bmL[wL] & qL) != 0, needS = (bflags & 4) && (bmS[wS] & qS) != 0;
       const u32 rL = needL ? TLD(HL + bL) : 0u, rS = needS ? TLD(HS + bS) : 0u;
       mL = ((rL & H.tagMask) == tL) ? (rL & idxMask) : 0u;
       mS = ((rS & H.tagMask) == tS) ? (rS & idxMask) : 0u;
@@ -533,7 +533,7 @@ __device__ u32 mf_dfast_lean(const ZraEncParams& P, u32* HL, u32* HS, const u8* 
       const u64 live = AM & (~0ull << cur);
       const u64 hm = (RH | LH | SH) & live;
       if (!hm) {
-        if (lane_in(live)) { if (fb & 2) { TST(HL + bL, valL); atomicOr(&bmL[wL], qL); } if (fb & 8) { TST(HS + bS, valS); atomicOr(&bmS[wS], qS); } }
+        if (lane_in(live)) { if (bflags & 2) { TST(HL + bL, valL); atomicOr(&bmL[wL], qL); } if (bflags & 8) { TST(HS + bS, valS); atomicOr(&bmS[wS], qS); } }
         ip = wip + nAct * s; PROF(4)
         break;
       }
@@ -552,8 +552,8 @@ __device__ u32 mf_dfast_lean(const ZraEncParams& P, u32* HL, u32* HS, const u8* 
         else {
           PROF_CNT(15)
           // the probed bucket is not covered by the window's no-duplicate guarantee: commit the visited positions first
-          if (lane_in(mkL) && (fb & 2)) { TST(HL + bL, valL); atomicOr(&bmL[wL], qL); }
-          if (lane_in(mkS) && (fb & 8)) { TST(HS + bS, valS); atomicOr(&bmS[wS], qS); }
+          if (lane_in(mkL) && (bflags & 2)) { TST(HL + bL, valL); atomicOr(&bmL[wL], qL); }
+          if (lane_in(mkS) && (bflags & 8)) { TST(HS + bS, valS); atomicOr(&bmS[wS], qS); }
           mkL = 0; mkS = 0;
           u32 m3v = 0; bool h3v = false;                // rare: done on lane 0's vector path (keeps the parse state scalar)
           if (lane == 0) {
@@ -609,8 +609,8 @@ __device__ u32 mf_dfast_lean(const ZraEncParams& P, u32* HL, u32* HS, const u8* 
       ip += ml; anchor = ip;
       PROF(7) PROF_CNT(13)
       if (ip > ilimit) {
-        if (lane_in(mkL) && (fb & 2)) { TST(HL + bL, valL); atomicOr(&bmL[wL], qL); }
-        if (lane_in(mkS) && (fb & 8)) { TST(HS + bS, valS); atomicOr(&bmS[wS], qS); }
+        if (lane_in(mkL) && (bflags & 2)) { TST(HL + bL, valL); atomicOr(&bmL[wL], qL); }
+        if (lane_in(mkS) && (bflags & 8)) { TST(HS + bS, valS); atomicOr(&bmS[wS], qS); }
         break;
       }
       // ---- complementary insertions (top+2 into both tables, then ip-2 long / ip-1 short) and the immediate repcode test
@@ -621,8 +621,8 @@ __device__ u32 mf_dfast_lean(const ZraEncParams& P, u32* HL, u32* HS, const u8* 
       if (in2) { mkL |= bit64(f + 2); mkS |= bit64(f + 2); }
       if (s == 1 && relE - 2 < nAct) mkL |= bit64(relE - 2);
       if (inE) mkS |= bit64(relE - 1);
-      if (lane_in(mkL) && (fb & 2)) { TST(HL + bL, valL); atomicOr(&bmL[wL], qL); }
-      if (lane_in(mkS) && (fb & 8)) { TST(HS + bS, valS); atomicOr(&bmS[wS], qS); }
+      if (lane_in(mkL) && (bflags & 2)) { TST(HL + bL, valL); atomicOr(&bmL[wL], qL); }
+      if (lane_in(mkS) && (bflags & 8)) { TST(HS + bS, valS); atomicOr(&bmS[wS], qS); }
       u32 here = 0, there = 1;
       const bool thereIn = inI && repOldFor == o2 && ((ROV >> (relE - 1)) & 1);   // src[ip - o2] == old rep gather of lane ip-1-wip
       if (in2 && inE && (o2 == 0 || thereIn)) {
