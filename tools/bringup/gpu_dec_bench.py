@@ -1,10 +1,11 @@
-"""bring-up: full-archive decode and batched random-access timing on the device API (not a pytest file)."""
+"""bring-up: full-archive decode and batched random-access timing on the device API (not a pytest file). usage: gpu_dec_bench.py [GiB] [frameSize] [decode-only]"""
 import sys, os, time
 here = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"); sys.path.insert(0, here); sys.path.insert(0, os.path.dirname(here))
 import numpy as np, torch, zra_amd as Z, bench
 gib = float(sys.argv[1]) if len(sys.argv) > 1 else 2.0
 dev = torch.device("cuda", 0); eng = Z.Engine(0)
-base = bench.synth_corpus(64 << 20, 1); fs = 65536; n = int(gib * (1 << 30)) // fs * fs
+fs = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
+base = bench.synth_corpus(64 << 20, 1); n = int(gib * (1 << 30)) // fs * fs
 d_in = torch.from_numpy(np.resize(base, n)).to(dev)
 d_arc = torch.empty(Z.GetOutputBufferSize(n, fs) + 64, dtype=torch.uint8, device=dev)
 asz = eng.compress(d_in.data_ptr(), n, d_arc.data_ptr(), 3, fs, True)
@@ -15,6 +16,7 @@ for i in range(3):
     sg = eng.decode_stage_stats()
     print("decode %.2f GiB: %.1f ms wall (%.1f GiB/s), kernels %.1f ms in %d passes | parse %.1f huf %.1f chain %.1f exec %.1f" % (gib, dt * 1e3, gib / dt, st["dec_ms"], st["dec_launches"], sg["parse_ms"], sg["huf_ms"], sg["chain_ms"], sg["exec_ms"]), flush=True)
 assert torch.equal(d_out, d_in)
+if len(sys.argv) > 3: sys.exit(0)
 rng = np.random.RandomState(42)
 for qb, q in ((4096, 1000000), (65536, 100000), (1 << 20, 4000)):
     q = min(q, int(4 * n / qb))
