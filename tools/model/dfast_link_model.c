@@ -23,7 +23,8 @@
 typedef struct { u16 q[3]; u8 fl; } ent;
 
 static struct { u64 frames, windows, strideWin, seqs, repSeq, immRep, rewalkEvents, rewalkLanes, deepLanes, deepResolved, deepSteps, slowProbe,
-                tripB, longFwd, backAny, visited, winWithDeep, deepAnyEq, deepHit, deepEmpty; } ST;
+                tripB, longFwd, backAny, visited, winWithDeep, deepAnyEq, deepHit, deepEmpty,
+                v2Win, v2Rep, v2Sat, v2Back, v2Deep, v2Probe, v2ImmOut, v2Seqs; } ST;
 
 static void prepass(const u8* src, u32 n, u32 hlog, u32 clog, u32 mls, ent* EL, ent* ES) {
   u16* headL = (u16*)calloc((size_t)1 << hlog, 2); u16* headS = (u16*)calloc((size_t)1 << clog, 2);
@@ -98,7 +99,7 @@ static size_t model_dfast(cctx* c, const ent* EL, const ent* ES, u64* insL, u64*
       hi = 64; { u32 a = (256 * s - run + s - 1) / s, b = (ilimit - ip + s - 1) / s; if (a < hi) hi = a; if (b < hi) hi = b; }
       ST.strideWin++;
     }
-    ST.windows++;
+    ST.windows++; ST.v2Win++;
     wres L[64], S[64]; u32 P[64];
     u64 deepL = 0, deepS = 0, LH = 0, SH = 0, AM = 0;
     for (u32 l = lo; l < hi; l++) {
@@ -130,6 +131,7 @@ static size_t model_dfast(cctx* c, const ent* EL, const ent* ES, u64* insL, u64*
         FLUSH();                                        /* (the walk reads the bitmap: pending lanes below f are all inserted — see below) */
         /* lanes cur..f-1 are literal positions: inserted; they are pending in the masks only if not yet marked — mark them now */
         { const u64 vis = live & ((1ull << f) - 1); if (s == 1) { insL[base >> 6] |= vis; insS[base >> 6] |= vis; } else for (u32 l_ = cur; l_ < f; l_++) { bit_set(insL, P[l_]); bit_set(insS, P[l_]); } }
+        ST.v2Deep++;
         if ((deepL >> f) & 1) { L[f] = walk_mem(EL, src, top, L[f].last, insL, 1); deepL &= ~(1ull << f); if (L[f].hit) LH |= 1ull << f; ST.deepResolved++; }
         if ((deepS >> f) & 1) { S[f] = walk_mem(ES, src, top, S[f].last, insS, 0); deepS &= ~(1ull << f); if (S[f].hit) SH |= 1ull << f; ST.deepResolved++; }
         continue;
@@ -137,14 +139,14 @@ static size_t model_dfast(cctx* c, const ent* EL, const ent* ES, u64* insL, u64*
       { const u64 vis = live & ((f == 63 ? 0 : (1ull << (f + 1))) - 1); mkL |= vis; mkS |= vis; ST.visited += (u64)__builtin_popcountll(vis); }
       ip = top;
       u32 m, known, offVal = 1;
-      if (isRep) { ip = top + 1; m = ip - o1; known = 4; ST.repSeq++; }
+      if (isRep) { ip = top + 1; m = ip - o1; known = 4; ST.repSeq++; ST.v2Rep++; }
       else if (((LH >> f) & 1) && !((deepL >> f) & 1)) { m = L[f].cand; known = 8; }
       else {
         /* short hit: long-table probe at top+1 */
         int hit3; u32 m3;
         if (s == 1 && f + 1 < hi && !((deepL >> (f + 1)) & 1)) { hit3 = (int)((LH >> (f + 1)) & 1); m3 = L[f + 1].cand; mkL |= 1ull << (f + 1); }
         else {
-          ST.slowProbe++;
+          ST.slowProbe++; ST.v2Probe++;
           FLUSH();
           wres r3;
           if (s == 1 && f + 1 < hi) { r3 = walk_mem(EL, src, top + 1, L[f + 1].last, insL, 1); }   /* deep lane f+1: continue its walk */
@@ -163,15 +165,18 @@ static size_t model_dfast(cctx* c, const ent* EL, const ent* ES, u64* insL, u64*
       const u32 off = ip - m;
       u32 ml = known + (u32)count_eq(src, ip + known, m + known, be);
       if (ml > known + 120) ST.longFwd++;
+      if (!isRep && ml > known + 14) ST.v2Sat++;
       if (!isRep) {
         u32 back = 0;
         while (ip - back > anchor && m - back > 0 && src[ip - back - 1] == src[m - back - 1]) back++;
         if (back) ST.backAny++;
+        if (m > 0 && ip > anchor && src[ip - 1] == src[m - 1]) ST.v2Back++;
         ip -= back; ml += back;
         o2 = o1; o1 = off; offVal = off + 3;
       }
-      emit(c, src, anchor, ip - anchor, ml, offVal); ST.seqs++;
+      emit(c, src, anchor, ip - anchor, ml, offVal); ST.seqs++; ST.v2Seqs++;
       ip += ml; anchor = ip;
+      if (ip - base >= 64 && o2) ST.v2ImmOut++;
       if (ip > ilimit) { FLUSH(); done = 1; break; }
       INS(top + 2, 1, 1); INS(ip - 2, 1, 0); INS(ip - 1, 0, 1);
       if (ip - base >= 128) ST.tripB++;
@@ -257,6 +262,12 @@ static void print_stats(void) {
          ST.windows / F, ST.strideWin / F, ST.winWithDeep / F, ST.seqs / F, ST.repSeq / F, ST.immRep / F, ST.visited / F, ST.rewalkEvents / F, ST.rewalkLanes / F,
          ST.deepLanes / F, ST.deepResolved / F, ST.deepSteps / F, ST.slowProbe / F, ST.tripB / F, ST.longFwd / F, ST.backAny / F);
   printf("deep walks: any equal-content predecessor beyond q3 %.1f, ended in a hit %.1f\n", ST.deepAnyEq / F, ST.deepHit / F);
+  /* match lengths in the entries (forward extra capped at 14, a "may extend backward" bit), the window resolved on "no repcode hit"
+     and validated by one gather, deep chains through a per-frame table of the last inserted position of heavy buckets (one read + one
+     verify). Dependent round trips per frame under those rules: */
+  { double w = ST.v2Win / F, r = 2.0 * (ST.v2Rep + ST.immRep) / F, sa = ST.v2Sat / F, b = ST.v2Back / F, d = 2.0 * ST.v2Deep / F, pr = ST.v2Probe / F, io = ST.v2ImmOut / F;
+    printf("no-load-per-sequence parse: round trips per frame %.0f = windows %.0f + repcode events x2 %.0f + saturated lengths %.0f + backward extensions %.0f + deep x2 %.0f + probes outside the window %.0f + immediate-repcode tests behind the window %.0f   (today: 3 per window + 1 per sequence + out-of-window loads = %.0f)\n",
+           w + r + sa + b + d + pr + io, w, r, sa, b, d, pr, io, 3.0 * 1354 + ST.v2Seqs / F + 920); }
 }
 
 int main(int argc, char** argv) {
