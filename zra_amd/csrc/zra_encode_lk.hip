@@ -51,7 +51,8 @@ __device__ __forceinline__ u32 lk_bucket_short(u64 v, u32 clog, u32 mls) {
 struct PpLds {
   u8* big;          // 128 KiB: bucket heads (u16) / chain links (u16 per position) / a copy of the frame
   u8* lastOf;       // [1024][16] per bucket group of the chunk and 64-position block: the block's last position of the group (lane)
-  u32* bmask;       // [2][1024]  per bucket group: which blocks of the chunk hold a position of the group (two chunks alternate)
+  u32* bmask;       // [2][512]   per bucket group, 16 bits: which blocks of the chunk hold a position of the group (two chunks alternate)
+  u32* succ;        // [2048]     one bit per position: a later position of the frame shares its bucket
 };
 
 __device__ __forceinline__ void pp_wave_sync() {      // (a wave's LDS accesses execute in issue order: volatile accesses + a scheduling barrier)
@@ -80,21 +81,27 @@ __device__ void pp_links(const PpLds& S, const u8* src, u32 last, u32 log, u32 m
   volatile u8* lastOf = S.lastOf;
   const u32 nPass = log > 16 ? 1u << (log - 16) : 1u;       // 64 Ki heads fit; a 17-bit table takes two passes over the positions
   const u32 headBytes = 2u << (log > 16 ? 16 : log);
+  // bit p of `succ`: a later position links to p (p is not the last position of its bucket)
+  for (u32 i = t; i < 2048; i += ZRA_LK_PP_THREADS) S.succ[i] = 0;
+  auto src_of = [&](u32 ci) -> u64 { const u32 p = 1 + ci * ZRA_LK_PP_THREADS + t; return p <= last ? ld64(src + p) : 0ull; };
   for (u32 pass = 0; pass < nPass; pass++) {
     for (u32 i = t; i < headBytes / 16; i += ZRA_LK_PP_THREADS) ((uint4*)S.big)[i] = make_uint4(0, 0, 0, 0);
-    S.bmask[t] = 0; S.bmask[1024 + t] = 0;
+    S.bmask[t] = 0;                                          // (two chunks' masks, 16 bits per group: 1024 words)
+    // the source bytes of the chunk after the next are requested before a chunk is worked on: a chunk is four barriers of LDS work,
+    // and nothing else would hide the load
+    u64 vA = src_of(0), vB = src_of(1);
     __syncthreads();
     u32 par = 0, ci = 0;
     for (u32 c0 = 1; c0 <= last; c0 += ZRA_LK_PP_THREADS, par ^= 1, ci++) {
       const u32 p = c0 + t;
       bool act = p <= last;
-      const u64 v = act ? ld64(src + p) : 0;
+      const u64 v = vA; vA = vB; vB = src_of(ci + 2);
       u32 b = LONG ? lk_bucket_long(v, log) : lk_bucket_short(v, log, mls);
       if (nPass > 1) { act = act && (b >> 16) == pass; b &= 0xFFFFu; }
-      u32* const BM = S.bmask + par * 1024;
+      u32* const BM = S.bmask + par * 512;
       u32 h0 = 0;
       if (act) h0 = H[b];
-      S.bmask[(par ^ 1) * 1024 + t] = 0;               // the other chunk's masks: free since the barrier that ended it
+      if (t < 512) S.bmask[(par ^ 1) * 512 + t] = 0;   // the other chunk's masks: free since the barrier that ended it
       __syncthreads();
       if (act) H[b] = (u16)t;
       __syncthreads();
@@ -122,10 +129,11 @@ __device__ void pp_links(const PpLds& S, const u8* src, u32 last, u32 log, u32 m
       }
       pp_wave_sync();
       if (lastIn) *slot = (u8)lane;
-      if (first) atomicOr(&BM[w], 1u << blk);
+      const u32 wsh = (w & 1) * 16;
+      if (first) atomicOr(&BM[(w & 1023u) >> 1], (1u << blk) << wsh);
       __syncthreads();
       if (act) {
-        const u32 m = BM[w];
+        const u32 m = (BM[w >> 1] >> wsh) & 0xFFFFu;
         u32 link;
         if (first) {
           const u32 lower = m & ((1u << blk) - 1u);
@@ -134,22 +142,19 @@ __device__ void pp_links(const PpLds& S, const u8* src, u32 last, u32 log, u32 m
         } else link = c0 + blk * 64 + predIn;
         if (lastIn && (m >> blk >> 1) == 0) H[b] = (u16)p;
         if (lk) lk[p] = (u16)link;
-        if (link) predBits |= 1ull << ci;
+        if (link) { predBits |= 1ull << ci; atomicOr(&S.succ[link >> 5], 1u << (link & 31)); }
       }
       __syncthreads();
     }
-    // the heads are final: a position that is not its bucket's head has a successor
-    ci = 0;
-    for (u32 c0 = 1; c0 <= last; c0 += ZRA_LK_PP_THREADS, ci++) {
-      const u32 p = c0 + t;
-      bool act = p <= last;
-      const u64 v = act ? ld64(src + p) : 0;
-      u32 b = LONG ? lk_bucket_long(v, log) : lk_bucket_short(v, log, mls);
-      if (nPass > 1) { act = act && (b >> 16) == pass; b &= 0xFFFFu; }
-      if (act && H[b] != (u16)p) succBits |= 1ull << ci;
-    }
-    __syncthreads();
   }
+  {
+    u32 cj = 0;
+    for (u32 c0 = 1; c0 <= last; c0 += ZRA_LK_PP_THREADS, cj++) {
+      const u32 p = c0 + t;
+      if (p <= last && ((S.succ[p >> 5] >> (p & 31)) & 1)) succBits |= 1ull << cj;
+    }
+  }
+  __syncthreads();
 }
 
 // the three nearest predecessors of every position: q1 = lk[p], q2 = lk[q1], q3 = lk[q2] with the links in LDS
@@ -221,6 +226,7 @@ zra_lk_prepass_kernel(ZraEncArgs a, ZraLkArgs k) {
   S.big = (u8*)ppLds;
   S.lastOf = S.big + 131072;
   S.bmask = (u32*)(S.lastOf + 16384);
+  S.succ = S.bmask + 1024;
   __shared__ u32 sFrame;
   u16* lkL = k.lkTmp ? k.lkTmp + (size_t)blockIdx.x * 2 * 65536 : nullptr;
   u16* lkS = lkL + 65536;

@@ -194,7 +194,7 @@ struct ZraFlagArgs {
 // same 8 (long) / 4 (short) bytes as p); 0 = no predecessor (position 0 is never a candidate: index > prefixLowestIndex)
 #define ZRA_LK_MAX_FRAME 65536u
 #define ZRA_LK_PP_THREADS 1024u
-#define ZRA_LK_PP_LDS 158720u                                     // heads / links / source copy (128 KiB) + per group and block: last lane (16 KiB) + block masks (8 KiB); sized so that nothing else fits the CU
+#define ZRA_LK_PP_LDS 159808u                                     // heads / links / source copy (128 KiB) + per group and block: last lane (16 KiB) + block masks (4 KiB) + has-successor bits (8 KiB); nothing else fits the CU
 #define ZRA_LK_PARSE_WAVES 8u                                  // waves of one parse workgroup = frames in flight per CU (16 KiB of bitmaps each)
 #define ZRA_LK_PARSE_LDS (ZRA_LK_PARSE_WAVES * 16384u)
 struct ZraLkArgs {
