@@ -84,6 +84,12 @@ __device__ void pp_links(const PpLds& S, const u8* src, u32 last, u32 log, u32 m
   // bit p of `succ`: a later position links to p (p is not the last position of its bucket)
   for (u32 i = t; i < 2048; i += ZRA_LK_PP_THREADS) S.succ[i] = 0;
   auto src_of = [&](u32 ci) -> u64 { const u32 p = 1 + ci * ZRA_LK_PP_THREADS + t; return p <= last ? ld64(src + p) : 0ull; };
+#ifdef ZRA_MF_PROFILE
+  u64 pq_[6] = {0, 0, 0, 0, 0, 0}; u64 pql_ = __builtin_amdgcn_s_memtime();
+#define PPT(k) { const u64 n_ = __builtin_amdgcn_s_memtime(); pq_[k] += n_ - pql_; pql_ = n_; }
+#else
+#define PPT(k)
+#endif
   for (u32 pass = 0; pass < nPass; pass++) {
     for (u32 i = t; i < headBytes / 16; i += ZRA_LK_PP_THREADS) ((uint4*)S.big)[i] = make_uint4(0, 0, 0, 0);
     S.bmask[t] = 0;                                          // (two chunks' masks, 16 bits per group: 1024 words)
@@ -102,9 +108,11 @@ __device__ void pp_links(const PpLds& S, const u8* src, u32 last, u32 log, u32 m
       u32 h0 = 0;
       if (act) h0 = H[b];
       if (t < 512) S.bmask[(par ^ 1) * 512 + t] = 0;   // the other chunk's masks: free since the barrier that ended it
+      PPT(0)
       __syncthreads();
       if (act) H[b] = (u16)t;
       __syncthreads();
+      PPT(1)
       const u32 w = act ? (u32)H[b] : 0xFFFFu;
       volatile u8* const slot = lastOf + (w & 1023u) * 16 + blk;
       if (act) *slot = (u8)lane;
@@ -116,7 +124,11 @@ __device__ void pp_links(const PpLds& S, const u8* src, u32 last, u32 log, u32 m
       const bool shared = act && (lost || *slot != (u8)lane);
       bool first = act, lastIn = act; u32 predIn = 0;
       u64 rem = __ballot(shared);
+      PPT(2)
       while (rem) {
+#ifdef ZRA_MF_PROFILE
+        pq_[5]++;
+#endif
         const u32 l = (u32)__builtin_ctzll(rem);
         const u32 wl = bcast(w, l);
         const u64 same = __ballot(act && w == wl);
@@ -131,6 +143,7 @@ __device__ void pp_links(const PpLds& S, const u8* src, u32 last, u32 log, u32 m
       if (lastIn) *slot = (u8)lane;
       const u32 wsh = (w & 1) * 16;
       if (first) atomicOr(&BM[(w & 1023u) >> 1], (1u << blk) << wsh);
+      PPT(3)
       __syncthreads();
       if (act) {
         const u32 m = (BM[w >> 1] >> wsh) & 0xFFFFu;
@@ -145,8 +158,12 @@ __device__ void pp_links(const PpLds& S, const u8* src, u32 last, u32 log, u32 m
         if (link) { predBits |= 1ull << ci; atomicOr(&S.succ[link >> 5], 1u << (link & 31)); }
       }
       __syncthreads();
+      PPT(4)
     }
   }
+#ifdef ZRA_MF_PROFILE
+  if (t == 0 && blockIdx.x == 0) { for (int k_ = 0; k_ < 6; k_++) atomicAdd(&zra_lk_prof[26 + k_], pq_[k_]); }
+#endif
   {
     u32 cj = 0;
     for (u32 c0 = 1; c0 <= last; c0 += ZRA_LK_PP_THREADS, cj++) {
