@@ -1,7 +1,7 @@
 #!/bin/bash
 # run on the GPU box from the repo root: HBM-side byte counters of the headline bench run itself (16 GiB, one step), one --pmc pass per
 # counter, nothing else traced; per-kernel sums and launch counts go to gpurun_out/$1
-out=${1:-r03_pmc_bench16g.txt}
+out=${1:-r04_pmc_bench16g.txt}
 root=$(pwd); export TMPDIR=/tmp; cd /tmp
 : > $root/gpurun_out/$out
 for c in FETCH_SIZE WRITE_SIZE; do

@@ -256,7 +256,15 @@ Status Engine::create(Engine** out, int device) {
   if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete e; return zerr(1); }
   e->numCUs_ = prop.multiProcessorCount;
   if (hipStreamCreateWithFlags(&e->stream_, hipStreamNonBlocking) != hipSuccess) { delete e; return zerr(1); }
-  if (hipStreamCreateWithFlags(&e->stream2_, hipStreamNonBlocking) != hipSuccess) { delete e; return zerr(1); }
+  {
+    // stream B carries the entropy stage + scan + gather under the persistent match finder. Bring-up knob ZRA_ENT_PRIO=1: at the highest
+    // stream priority, so that its short workgroups are placed ahead of nothing (the match finder is resident) but ahead of other engines
+    static const int entPrio = std::getenv("ZRA_ENT_PRIO") ? std::atoi(std::getenv("ZRA_ENT_PRIO")) : 0;
+    int lo = 0, hi = 0;
+    if (entPrio && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi != lo) {
+      if (hipStreamCreateWithPriority(&e->stream2_, hipStreamNonBlocking, hi) != hipSuccess) { delete e; return zerr(1); }
+    } else if (hipStreamCreateWithFlags(&e->stream2_, hipStreamNonBlocking) != hipSuccess) { delete e; return zerr(1); }
+  }
   if (hipEventCreate(&e->ev0_) != hipSuccess || hipEventCreate(&e->ev1_) != hipSuccess ||
       hipEventCreateWithFlags(&e->evWait_, hipEventDisableTiming) != hipSuccess) { delete e; return zerr(1); }
   for (auto& ev : e->evR_) if (hipEventCreate(&ev) != hipSuccess) { delete e; return zerr(1); }
