@@ -933,12 +933,14 @@ extern "C" __global__ void __launch_bounds__(DEC_THREADS, ZRA_PARSE_WAVES)
 zra_dec_parse_kernel(ZraDecodeArgs a) {
   __shared__ ParseShared S;
   const int lane = threadIdx.x;
+  // a round enqueued behind the previous one without a host synchronisation learns its job count on the device
+  const u32 nActive = a.nActivePtr ? __hip_atomic_load(a.nActivePtr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : a.nActive;
   for (;;) {
     if (lane == 0) S.job = atomicAdd(&a.counters[ZRA_DC_QPARSE], 1u);
     wsync();
     const u32 qi = S.job;
     wsync();
-    if (qi >= a.nActive) return;
+    if (qi >= nActive) return;
     (void)parse_job<false>(a, a.active ? a.active[qi] : qi, S, lane, nullptr);
   }
 }

@@ -131,7 +131,7 @@ class Engine {
   hipEvent_t stage_event();
   hipEvent_t evR_[17] = {nullptr};   // per-round events of one encode batch: e[2r] before mf, e[2r+1] between, e[2r+2] after entropy
   // decode scratch
-  DevBuf decFrames_, decTables_, decLists_, decCounters_, decLits_, decSeqs_;
+  DevBuf decFrames_, decTables_, decLists_, decCounters_, decLits_, decSeqs_, roundN_;
   DevBuf raPlan_, raLimit_, raPieceBase_, raPieces_;
   uint64_t* pinQ_ = nullptr; size_t pinQCap_ = 0;   // page-locked query tuples of the running batch (host side of an asynchronous copy)
   int decOccParse_ = 0, decOccExec_ = 0, decOccHuf_ = 0; // resident workgroups per CU of the parse / execute kernels

@@ -276,7 +276,7 @@ Status Engine::release_scratch() {
   HIPCHK(hipSetDevice(device_));
   HIPCHK(hipStreamSynchronize(stream_));
   HIPCHK(hipStreamSynchronize(stream2_));
-  for (DevBuf* b : {&raPlan_, &raLimit_, &raPieceBase_, &raPieces_, &decFrames_, &decTables_, &decLists_, &decCounters_, &decLits_, &decSeqs_, &status_,
+  for (DevBuf* b : {&raPlan_, &raLimit_, &raPieceBase_, &raPieces_, &decFrames_, &decTables_, &decLists_, &decCounters_, &decLits_, &decSeqs_, &roundN_, &status_,
                     &produced_, &frameMeta_, &frameOff_, &outOff_, &expect_, &result_, &temp_, &qmeta_, &encScan_, &hostIn_, &hostOut_, &seqScratch_, &lkEnt_, &lkTmp_, &lkCtl_})
     b->release();
   for (auto& x : encCtx_) for (DevBuf* b : {&x.tables, &x.seqs, &x.lits, &x.slots, &x.misc, &x.ck, &x.sizes}) b->release();
@@ -287,7 +287,7 @@ Status Engine::release_scratch() {
 Engine::~Engine() {
   (void)hipSetDevice(device_);
   if (stream_) (void)hipStreamSynchronize(stream_);
-  for (DevBuf* b : {&raPlan_, &raLimit_, &raPieceBase_, &raPieces_, &decFrames_, &decTables_, &decLists_, &decCounters_, &decLits_, &decSeqs_, &status_, &produced_, &frameMeta_, &frameOff_, &outOff_, &expect_, &result_, &temp_, &qmeta_,
+  for (DevBuf* b : {&raPlan_, &raLimit_, &raPieceBase_, &raPieces_, &decFrames_, &decTables_, &decLists_, &decCounters_, &decLits_, &decSeqs_, &roundN_, &status_, &produced_, &frameMeta_, &frameOff_, &outOff_, &expect_, &result_, &temp_, &qmeta_,
                     &encScan_, &hostIn_, &hostOut_, &seqScratch_, &lkEnt_, &lkTmp_, &lkCtl_})
     b->release();
   for (auto& x : encCtx_) for (DevBuf* b : {&x.tables, &x.seqs, &x.lits, &x.slots, &x.misc, &x.ck, &x.sizes}) b->release();
@@ -412,54 +412,72 @@ Status Engine::decode_launch(const ZraDecodeArgs& a0, const uint32_t* dExpect, u
   // the rounds of one set of jobs, one stage after the other on the engine's stream (resident waves per CU of the chain kernel — lane =
   // frame, 64 frames' tables per wave: fewer frames in flight keep more of their table cells in the caches; A/B on one box, round 3,
   // 8 GiB decode, chain stage 2 / 3 / 4 / 6 / 8 waves per CU -> 26.0 / 26.6 / 30.1 / 35.2 / 32.9 ms; 16 GiB, 1 / 1.5 / 2 / 2.5: 74.1 / 58.2 / 51.9 / 53.0 ms)
-  auto run_rounds = [&](ZraDecodeArgs& x, uint32_t nActive, const uint32_t* active, uint32_t round, uint32_t* lA, uint32_t* lB) -> Status {
+  // Rounds are enqueued `ahead` at a time without a host synchronisation in between (round 4): a frame of B blocks needs B rounds, and the
+  // job count of round r+1 is round r's counter — copied aside on the device and read by the parse kernel (the other stages always
+  // counted on the device). Grids are sized by the previous burst's job count (an upper bound: jobs only drop out). One copy back and
+  // one synchronisation per burst; frames that still go on afterwards (foreign archives with more, smaller blocks; scratch deferrals)
+  // take further bursts of one round.
+  static const uint32_t aheadCap = std::getenv("ZRA_DEC_AHEAD") ? (uint32_t)std::max(1, std::atoi(std::getenv("ZRA_DEC_AHEAD"))) : 16u;
+  if (!roundN_.reserve(4 * (aheadCap + 2) + 64)) return zerr(64);
+  auto run_rounds = [&](ZraDecodeArgs& x, uint32_t nActive, const uint32_t* active, uint32_t round, uint32_t* lA, uint32_t* lB, uint32_t ahead) -> Status {
+    uint32_t* const dN = roundN_.as<uint32_t>();
     while (nActive) {
-      HIPCHK(hipMemsetAsync(x.counters, 0, ZRA_DC_WORDS * 4, stream_));
-      x.active = active; x.nActive = nActive; x.round = round;
-      x.nextActive = (active == lA) ? lB : lA;
-      const uint32_t gridParse = (uint32_t)std::min<uint64_t>(nActive, (uint64_t)numCUs_ * perCUParse);
-      const uint32_t gridChain = (uint32_t)std::min<uint64_t>((nActive + 63) / 64, chainGrid ? chainGrid : (uint64_t)numCUs_ * chainWaves);
-      const uint32_t gridExec = (uint32_t)std::min<uint64_t>(nActive, (uint64_t)numCUs_ * perCUExec);
-      // per-stage spans (HIP events on the engine's stream; summed into dstats_ once the round has synchronised)
-      hipEvent_t se[5];
-      for (auto& e : se) { e = stage_event(); if (!e) return zerr(1); }
-      HIPCHK(hipEventRecord(se[0], stream_));
-      hipLaunchKernelGGL(zra_dec_parse_kernel, dim3(gridParse), dim3(64), 0, stream_, x);
-      HIPCHK(hipEventRecord(se[1], stream_));
-      hipLaunchKernelGGL(zra_dec_huf_kernel, dim3((uint32_t)std::min<uint64_t>((nActive + ZRA_HUF_FRAMES - 1) / ZRA_HUF_FRAMES, (uint64_t)numCUs_ * decOccHuf_)), dim3(64), 0, stream_, x);
-      HIPCHK(hipEventRecord(se[2], stream_));
-      // beside the lane-per-frame chain kernel (tables in HBM scratch, two waves per CU) one workgroup per CU with its frames' tables in
-      // LDS, on another stream, pulling from the same queue
-      bool forked = false;
-      if (chainLdsOn && nActive >= chainLdsMin) {
-        if (!pipeStreams_[1]) { if (hipStreamCreateWithFlags(&pipeStreams_[1], hipStreamNonBlocking) != hipSuccess) { pipeStreams_[1] = nullptr; (void)hipGetLastError(); } }
-        const size_t ldsBytes = (128 + (size_t)ZRA_CHAIN_LDS_FRAMES * ZRA_DEC_TBL_WORDS) * 4;
-        if (pipeStreams_[1] && !chainLdsAttr_) {
-          if (hipFuncSetAttribute((const void*)zra_dec_chain_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes) == hipSuccess) chainLdsAttr_ = 1;
-          else { chainLdsAttr_ = -1; (void)hipGetLastError(); }
+      const uint32_t burst = std::max(1u, std::min(ahead, aheadCap));
+      std::vector<hipEvent_t> evs;
+      for (uint32_t bi = 0; bi < burst; bi++) {
+        HIPCHK(hipMemsetAsync(x.counters, 0, ZRA_DC_WORDS * 4, stream_));
+        x.active = active; x.nActive = nActive; x.round = round + bi;
+        x.nActivePtr = bi ? dN + bi : nullptr;
+        x.nextActive = (active == lA) ? lB : lA;
+        const uint32_t gridParse = (uint32_t)std::min<uint64_t>(nActive, (uint64_t)numCUs_ * perCUParse);
+        const uint32_t gridChain = (uint32_t)std::min<uint64_t>((nActive + 63) / 64, chainGrid ? chainGrid : (uint64_t)numCUs_ * chainWaves);
+        const uint32_t gridExec = (uint32_t)std::min<uint64_t>(nActive, (uint64_t)numCUs_ * perCUExec);
+        // per-stage spans (HIP events on the engine's stream; summed into dstats_ once the burst has synchronised)
+        hipEvent_t se[5];
+        for (auto& e : se) { e = stage_event(); if (!e) return zerr(1); evs.push_back(e); }
+        HIPCHK(hipEventRecord(se[0], stream_));
+        hipLaunchKernelGGL(zra_dec_parse_kernel, dim3(gridParse), dim3(64), 0, stream_, x);
+        HIPCHK(hipEventRecord(se[1], stream_));
+        hipLaunchKernelGGL(zra_dec_huf_kernel, dim3((uint32_t)std::min<uint64_t>((nActive + ZRA_HUF_FRAMES - 1) / ZRA_HUF_FRAMES, (uint64_t)numCUs_ * decOccHuf_)), dim3(64), 0, stream_, x);
+        HIPCHK(hipEventRecord(se[2], stream_));
+        // beside the lane-per-frame chain kernel (tables in HBM scratch, two waves per CU) one workgroup per CU with its frames' tables in
+        // LDS, on another stream, pulling from the same queue
+        bool forked = false;
+        if (chainLdsOn && nActive >= chainLdsMin) {
+          if (!pipeStreams_[1]) { if (hipStreamCreateWithFlags(&pipeStreams_[1], hipStreamNonBlocking) != hipSuccess) { pipeStreams_[1] = nullptr; (void)hipGetLastError(); } }
+          const size_t ldsBytes = (128 + (size_t)ZRA_CHAIN_LDS_FRAMES * ZRA_DEC_TBL_WORDS) * 4;
+          if (pipeStreams_[1] && !chainLdsAttr_) {
+            if (hipFuncSetAttribute((const void*)zra_dec_chain_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes) == hipSuccess) chainLdsAttr_ = 1;
+            else { chainLdsAttr_ = -1; (void)hipGetLastError(); }
+          }
+          if (pipeStreams_[1] && chainLdsAttr_ > 0) {
+            hipEvent_t eJoin = stage_event(); if (!eJoin) return zerr(1);
+            HIPCHK(hipStreamWaitEvent(pipeStreams_[1], se[2], 0));
+            hipLaunchKernelGGL(zra_dec_chain_lds_kernel, dim3((uint32_t)numCUs_), dim3(64), ldsBytes, pipeStreams_[1], x);
+            HIPCHK(hipEventRecord(eJoin, pipeStreams_[1]));
+            hipLaunchKernelGGL(zra_dec_chain_kernel, dim3(gridChain), dim3(64), 0, stream_, x);
+            HIPCHK(hipStreamWaitEvent(stream_, eJoin, 0));
+            forked = true;
+          }
         }
-        if (pipeStreams_[1] && chainLdsAttr_ > 0) {
-          hipEvent_t eJoin = stage_event(); if (!eJoin) return zerr(1);
-          HIPCHK(hipStreamWaitEvent(pipeStreams_[1], se[2], 0));
-          hipLaunchKernelGGL(zra_dec_chain_lds_kernel, dim3((uint32_t)numCUs_), dim3(64), ldsBytes, pipeStreams_[1], x);
-          HIPCHK(hipEventRecord(eJoin, pipeStreams_[1]));
-          hipLaunchKernelGGL(zra_dec_chain_kernel, dim3(gridChain), dim3(64), 0, stream_, x);
-          HIPCHK(hipStreamWaitEvent(stream_, eJoin, 0));
-          forked = true;
-        }
+        if (!forked) hipLaunchKernelGGL(zra_dec_chain_kernel, dim3(gridChain), dim3(64), 0, stream_, x);
+        HIPCHK(hipEventRecord(se[3], stream_));
+        hipLaunchKernelGGL(zra_dec_exec_kernel, dim3(gridExec), dim3(64), 0, stream_, x);
+        HIPCHK(hipEventRecord(se[4], stream_));
+        // the next round's job count stays on the device (the counters are cleared before it starts)
+        HIPCHK(hipMemcpyAsync(dN + bi + 1, x.counters + ZRA_DC_NNEXT, 4, hipMemcpyDeviceToDevice, stream_));
+        active = x.nextActive;
       }
-      if (!forked) hipLaunchKernelGGL(zra_dec_chain_kernel, dim3(gridChain), dim3(64), 0, stream_, x);
-      HIPCHK(hipEventRecord(se[3], stream_));
-      hipLaunchKernelGGL(zra_dec_exec_kernel, dim3(gridExec), dim3(64), 0, stream_, x);
-      HIPCHK(hipEventRecord(se[4], stream_));
       uint32_t next = 0;
-      HIPCHK(hipMemcpyAsync(&next, x.counters + ZRA_DC_NNEXT, 4, hipMemcpyDeviceToHost, stream_));
+      HIPCHK(hipMemcpyAsync(&next, dN + burst, 4, hipMemcpyDeviceToHost, stream_));
       HIPCHK(hipStreamSynchronize(stream_));
       HIPCHK(hipGetLastError());
-      for (int k = 0; k < 4; k++) { float m = 0; if (hipEventElapsedTime(&m, se[k], se[k + 1]) == hipSuccess) dstats_[k] += m; }
-      dstats_[4] += 1;
+      for (uint32_t bi = 0; bi < burst; bi++)
+        for (int k = 0; k < 4; k++) { float m = 0; if (hipEventElapsedTime(&m, evs[5 * bi + k], evs[5 * bi + k + 1]) == hipSuccess) dstats_[k] += m; }
+      dstats_[4] += burst;
       stageEvNext_ = 0;
-      active = x.nextActive; nActive = next; round++;
+      x.nActivePtr = nullptr;
+      nActive = next; round += burst; ahead = 1;
       if (round > (1u << 20)) return zerr(1);          // cannot happen: every round finishes at least one block of some frame
     }
     return ok();
@@ -533,12 +551,12 @@ Status Engine::decode_launch(const ZraDecodeArgs& a0, const uint32_t* dExpect, u
         const uint32_t next = hc[(size_t)(k + 1) * ZRA_DC_WORDS + ZRA_DC_NNEXT];
         if (!next) continue;
         const uint32_t j0 = k * B;
-        Status st = run_rounds(sub[k], next, listA + j0, 1, listA + j0, listB + j0);
+        Status st = run_rounds(sub[k], next, listA + j0, 1, listA + j0, listB + j0, 1);
         if (st.zra) return st;
       }
     }
   }
-  if (!piped) { Status st = run_rounds(a, n, nullptr, 0, listA, listB); if (st.zra) return st; }
+  if (!piped) { Status st = run_rounds(a, n, nullptr, 0, listA, listB, (maxFrameBytes + (128u << 10) - 1) / (128u << 10)); if (st.zra) return st; }
   HIPCHK(hipEventRecord(ev1_, stream_));
   const uint32_t tb = 256;
   hipLaunchKernelGGL(zra_xxh64_verify_kernel, dim3((n * 4 + tb - 1) / tb), dim3(tb), 0, stream_, a.out, a.outOff, dExpect,

@@ -70,6 +70,7 @@ struct ZraDecodeArgs {
   // round machinery (device scratch)
   const uint32_t* active;    // jobs of this round (nullptr in round 0: all of them)
   uint32_t nActive;
+  const uint32_t* nActivePtr; // rounds enqueued behind another without a host synchronisation: the number of jobs is read here (nActive: upper bound)
   uint32_t round;
   uint32_t* counters;        // see ZRA_DC_* below
   uint32_t* nextActive;      // jobs that need another round
