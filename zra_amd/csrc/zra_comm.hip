@@ -279,7 +279,7 @@ static ZraStatus comm_stitch(ZraHipComm* c, ZraHipShard* sh, Status st, const st
 ZraStatus ZraHipCommCompress(ZraHipComm* c, const void* dLocal, size_t localBytes, uint64_t totalBytes, int8_t level, uint32_t frameSize, bool checksum,
                              ZraHipShard** shardOut) {
   *shardOut = nullptr;
-  if (!frameSize) return c->agree(zra_eng::zerr(42));
+  if (!frameSize || !c->eng) return c->agree(zra_eng::zerr(42));       // (a communicator without an engine only stitches)
   const uint64_t F = (totalBytes + frameSize - 1) / frameSize;
   uint64_t lo, hi; ZraHipShardRange(F, c->rank, c->world, &lo, &hi);
   const uint64_t b0 = std::min<uint64_t>(totalBytes, lo * frameSize), b1 = std::min<uint64_t>(totalBytes, hi * frameSize);
@@ -355,6 +355,7 @@ void ZraHipShardGetBody(const ZraHipShard* s, const void** dBody, uint64_t* body
 // The archive in one piece on `root` (what CompressBuffer returns): header from the root's own copy, every rank's frames to their
 // place in the body — W-1 inbound messages in one group.
 ZraStatus ZraHipCommGatherArchive(ZraHipComm* c, const ZraHipShard* s, int root, void* dArchive, size_t archiveCap, size_t* archiveSize) {
+  if (!c->eng || !s->dev.p) return c->agree(zra_eng::zerr(42));           // (nothing to gather from a stitch-only communicator or shard)
   Status st = zra_eng::ok();
   const size_t hs = s->header.size();
   std::vector<Xfer> sends, recvs;
@@ -382,6 +383,7 @@ ZraStatus ZraHipCommGatherArchive(ZraHipComm* c, const ZraHipShard* s, int root,
 // Collective random access over a distributed archive: every rank passes its own queries (offset, size over the WHOLE uncompressed
 // range; any rank may ask for any byte) and gets its answers in dOut at dstOffs[q]. Bounds as DecompressRA (zra.cpp:260).
 ZraStatus ZraHipCommServe(ZraHipComm* c, const ZraHipShard* s, const uint64_t* offs, const uint64_t* sizes, const uint64_t* dstOffs, size_t nq, void* dOut) {
+  if (!c->eng || !s->dev.p) return c->agree(zra_eng::zerr(42));           // (a stitch-only communicator or shard holds no frames to serve)
   const int W = c->world, me = c->rank;
   Status st = zra_eng::ok();
   // 1. cut my queries at ownership boundaries, grouped by owner
