@@ -13,7 +13,7 @@
 
 extern "C" __global__ void zra_mf_kernel(ZraEncArgs a, uint32_t block, uint32_t only, uint32_t onlySlot, uint32_t perWave);
 extern "C" __global__ void zra_mf_opt_kernel(ZraEncArgs a, uint32_t block, uint32_t only, uint32_t onlySlot, uint32_t perWave);
-extern "C" __global__ void zra_mf_hc_kernel(ZraEncArgs a, uint32_t block);
+extern "C" __global__ void zra_mf_hc_kernel(ZraEncArgs a, uint32_t block, uint32_t only, uint32_t onlySlot);
 extern "C" __global__ void zra_mf_fast_kernel(ZraEncArgs a, uint32_t block, uint32_t perWave);
 extern "C" __global__ void zra_mf_dfast_kernel(ZraEncArgs a, uint32_t block, uint32_t only, uint32_t onlySlot);
 extern "C" __global__ void zra_mf_dfast2_kernel(ZraEncArgs a, uint32_t block, uint32_t only, uint32_t onlySlot);
@@ -176,10 +176,11 @@ Status Engine::compress_impl_body(const uint8_t* dIn, size_t inSize, uint8_t* dB
   // per-frame table slot: hash table + chain table / tree; the optimal parsers add a 3-byte hash table and their state (ZraOptState)
   auto slotWords = [](const ZraEncParams& q) -> uint64_t {
     uint64_t w = (1ull << q.hashLog) + (1ull << q.chainLog);
+    if (q.strategy >= 3 && q.strategy <= 5) w += 1ull << q.chainLog;   // the wave-cooperative hash-chain finder keeps two links per slot
     if (q.strategy >= 7) w += (q.minMatch == 3 ? 1ull << std::min(17u, q.windowLog) : 0) + (sizeof(ZraOptState) + 3) / 4 + 16;
     return w;
   };
-  const uint64_t tableWords = std::max(slotWords(full), slotWords(tail));
+  const uint64_t tableWords = (std::max(slotWords(full), slotWords(tail)) + 3) & ~3ull;   // 16-byte slots
   const uint32_t maxBlock = std::max(full.blockSize, tail.blockSize);
   const uint64_t seqStride = maxBlock / 4 + 16;
   const uint64_t litStride = ((uint64_t)maxBlock + 64 + 15) & ~15ull;
@@ -296,9 +297,14 @@ Status Engine::compress_impl_body(const uint8_t* dIn, size_t inSize, uint8_t* dB
         const bool serialAll = std::min<uint64_t>(frameSize, inSize) > (1ull << full.windowLog);
         a.serialAll = serialAll ? 1u : 0u;
         const bool oddTail = !serialAll && hasTail && (tail.strategy == 2) != (full.strategy == 2);
+        // a lone short last frame that is not dfast: the wave-cooperative hash-chain kernel for greedy / lazy / lazy2, else the generic one
+        auto launchLone = [&](uint32_t only, uint32_t slot) {
+          if (tail.strategy >= 3 && tail.strategy <= 5) hipLaunchKernelGGL(zra_mf_hc_kernel, dim3(1), dim3(64), 0, stream_, a, blk, only, slot);
+          else hipLaunchKernelGGL(mfGeneric, dim3(1), dim3(64), 0, stream_, a, blk, only, slot, 1u);
+        };
         if (full.strategy == 2 && !serialAll) {
           hipLaunchKernelGGL(ZRA_DFAST_KERNEL, dim3(nb), dim3(64), filterBytes + dynLds, stream_, a, blk, 0xFFFFFFFFu, 0u);
-          if (oddTail) hipLaunchKernelGGL(mfGeneric, dim3(1), dim3(64), 0, stream_, a, blk, (uint32_t)(nb - 1), (uint32_t)(nb - 1), 1u);
+          if (oddTail) launchLone((uint32_t)(nb - 1), (uint32_t)(nb - 1));
         } else {
           // frames per wave: as many as it takes to have every frame of the batch resident at once (32 waves per CU)
           static const int pwEnv = std::getenv("ZRA_MF_PERWAVE") ? std::atoi(std::getenv("ZRA_MF_PERWAVE")) : 0;
@@ -309,12 +315,12 @@ Status Engine::compress_impl_body(const uint8_t* dIn, size_t inSize, uint8_t* dB
           // the hash-chain kernel and the fast kernel hold their own finder only (lean register budgets); a short last frame with any
           // other strategy goes to the generic kernel (or the dfast kernel) in a second, single-frame launch
           const bool lean = pwEnv <= 0 && (hashChain || full.strategy == 1);
-          if (hashChain && pwEnv <= 0) hipLaunchKernelGGL(zra_mf_hc_kernel, dim3(nb), dim3(64), dynLds, stream_, a, blk);
+          if (hashChain && pwEnv <= 0) hipLaunchKernelGGL(zra_mf_hc_kernel, dim3(nb), dim3(64), dynLds, stream_, a, blk, 0xFFFFFFFFu, 0u);
           else if (lean) hipLaunchKernelGGL(zra_mf_fast_kernel, dim3((nb + perWave - 1) / perWave), dim3(64), dynLds, stream_, a, blk, perWave);
           else hipLaunchKernelGGL(mfGeneric, dim3((nb + perWave - 1) / perWave), dim3(64), dynLds, stream_, a, blk, 0xFFFFFFFFu, 0u, perWave);
           if (oddTail) hipLaunchKernelGGL(ZRA_DFAST_KERNEL, dim3(1), dim3(64), filterBytes, stream_, a, blk, (uint32_t)(nb - 1), (uint32_t)(nb - 1));
           else if (lean && hasTail && (hashChain ? (tail.strategy < 3 || tail.strategy > 5) : tail.strategy != 1))
-            hipLaunchKernelGGL(mfGeneric, dim3(1), dim3(64), 0, stream_, a, blk, (uint32_t)(nb - 1), (uint32_t)(nb - 1), 1u);
+            launchLone((uint32_t)(nb - 1), (uint32_t)(nb - 1));
         }
       }
       HIPCHK(hipEventRecord(m1, stream_));
@@ -581,7 +587,8 @@ Status Engine::compress_persistent(const uint8_t* dIn, size_t inSize, uint8_t* d
     hipEvent_t tailEv = nullptr;
     if (oddTail) {
       ZraEncArgs at = a; at.mfQueue = nullptr;
-      hipLaunchKernelGGL(mfGeneric, dim3(1), dim3(64), 0, stream_, at, 0u, (uint32_t)(n - 1), 0u, 1u);
+      if (tail.strategy >= 3 && tail.strategy <= 5) hipLaunchKernelGGL(zra_mf_hc_kernel, dim3(1), dim3(64), 0, stream_, at, 0u, (uint32_t)(n - 1), 0u);
+      else hipLaunchKernelGGL(mfGeneric, dim3(1), dim3(64), 0, stream_, at, 0u, (uint32_t)(n - 1), 0u, 1u);
       tailEv = ev(); if (!tailEv) return zerr(1);
       HIPCHK(hipEventRecord(tailEv, stream_));
     }

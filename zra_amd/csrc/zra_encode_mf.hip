@@ -1135,7 +1135,11 @@ struct HCW {
 #ifdef ZRA_MF_PROFILE
   u64 pt[12]; u64 pl;
 #endif
-  u32* hashT; u32* chainT; u32 hlog, mls, cmask, chainSize, searchLog;
+  // chainT (round 4): TWO links per chain slot, link | nextLink << 32 — what the slot's index linked to when it was inserted, and what
+  // THAT index linked to. A search step is one dependent round trip; with the link after next in hand it tests two candidates per trip.
+  // nextLink is exact whenever it is used: a slot keeps its link from its index's insertion until the index + chainSize overwrites it,
+  // and the search stops behind a candidate at or below minChain (the only candidates whose slot can be gone) before it would follow it.
+  u32* hashT; u64* chainT; u32 hlog, mls, cmask, chainSize, searchLog;
   u32 insEnd;            // first index (position + 1) not inserted yet
   u32 ntuRef;            // the reference's nextToUpdate
   u32 w;                 // window: answers for positions [w, w + 64) are in rml / roff of lane p - w
@@ -1147,7 +1151,7 @@ struct HCW {
   // chain tables smaller than the frame (chainLog < windowLog): inserting index i overwrites the link of index i - chainSize. The
   // reference never follows that link once i is inserted (i - chainSize is below its minChain by then), but a window is inserted
   // AHEAD of the positions searched in it, so the links it overwrote (at most 66, ring of 128 by index) are kept in LDS
-  u32* oldLink;
+  u64* oldLink;
   volatile u8* dup;      // 1024 byte slots: which lanes of an insert step may share a bucket (hcw_insert)
 };
 
@@ -1163,7 +1167,7 @@ __device__ void hcw_undo(HCW& H, const u8* src, u32 from, int lane) {
   if (lane == 0) {
     for (u32 idx = H.insEnd; idx-- > from;) {
       const u32 h = hashN(src + idx - 1, H.hlog, H.mls);
-      H.hashT[h] = H.chainT[idx & H.cmask];
+      H.hashT[h] = (u32)H.chainT[idx & H.cmask];
       H.chainT[idx & H.cmask] = H.oldLink[idx & 127u];
     }
   }
@@ -1185,6 +1189,7 @@ __device__ void hcw_insert(HCW& H, const u8* src, u32 endIdx, int lane) {
     // plus a few that only share a slot; the exact grouping below runs over those only. (A wave's LDS accesses execute in issue
     // order: volatile accesses and a scheduling barrier are all the ordering it takes.)
     bool head = act;
+    u32 from = 64;                                       // lane whose index this lane links to (64: the bucket's head in the table)
     const u32 slot = h & 1023u;
     if (act) H.dup[slot] = (u8)lane;
     __builtin_amdgcn_wave_barrier();
@@ -1200,15 +1205,19 @@ __device__ void hcw_insert(HCW& H, const u8* src, u32 endIdx, int lane) {
       const u64 same = __ballot(act && h == hv);
       if (act && h == hv) {
         const u64 before = same & ((1ull << lane) - 1ull), after = same >> lane >> 1;
-        if (before) link = H.insEnd + (63u - (u32)__builtin_clzll(before));
+        if (before) { from = 63u - (u32)__builtin_clzll(before); link = H.insEnd + from; }
         head = after == 0;
       }
       rem &= ~same;
       HCNT(7, 1)
     }
+    // the link after next: the linked lane's own link, or what the table holds for the old head (loads before this step's stores)
+    const u32 laneLink = (u32)__shfl((int)link, (int)(from < 64 ? from : (u32)lane), 64);
+    u32 link2 = laneLink;
+    if (from >= 64) link2 = (act && link) ? (u32)H.chainT[link & H.cmask] : 0u;
     if (act) {
-      H.oldLink[idx & 127u] = idx > H.chainSize ? H.chainT[idx & H.cmask] : 0u;
-      H.chainT[idx & H.cmask] = link;
+      H.oldLink[idx & 127u] = idx > H.chainSize ? H.chainT[idx & H.cmask] : 0ull;
+      H.chainT[idx & H.cmask] = (u64)link | ((u64)link2 << 32);
       if (head) H.hashT[h] = idx;
     }
     H.insEnd = min(endIdx, H.insEnd + 64u);
@@ -1230,30 +1239,47 @@ __device__ void hcw_search_window(HCW& H, const u8* src, u32 w, u32 ilimit, u32 
   if (p <= lastPos) {
     const u32 curr = p + 1, minChain = curr > H.chainSize ? curr - H.chainSize : 0;
     int attempts = 1 << H.searchLog;
-    u32 mi = H.chainT[curr & H.cmask];
-    // the lane's own 16 bytes stay in registers; per candidate ONE round trip: its 16 bytes and its chain link are requested together
-    // (the reference's "byte at ml first" is only a shortcut: a candidate that differs there cannot be longer than ml).
+    const u64 e0 = H.chainT[curr & H.cmask];
+    u32 miA = (u32)e0, miB = (u32)(e0 >> 32);
+    // the lane's own 16 bytes stay in registers; per round trip TWO candidates: their 16 bytes each and the chain slot of the second
+    // (which names the next two) are requested together. (The reference's "byte at ml first" is only a shortcut: a candidate that
+    // differs there cannot be longer than ml.) The second candidate is touched only if the reference would reach it: the first one
+    // lies above minChain (so the link that named the second is intact) and an attempt is left.
     // (Measured and dropped: two positions per lane in one loop, window of 128 — 101 VGPRs, 4 waves per SIMD, 1.5 instead of 2.8 GiB/s.)
     const bool wide = p + 16 <= be;
     const u64 own0 = wide ? ld64(src + p) : 0ull, own1 = wide ? ld64(src + p + 8) : 0ull;
-    while (mi >= 1 && attempts > 0) {
-      const u32 over = mi + H.chainSize;                                  // the index that shares mi's chain slot
-      const u32 nxt = (over > curr && over < H.insEnd) ? H.oldLink[over & 127u] : H.chainT[mi & H.cmask];
-      const u32 m = mi - 1;
-      u32 cur = 0;
+    auto measure = [&](u32 m, u64 c0, u64 c1) -> u32 {
+      if (wide) {
+        const u64 d0 = c0 ^ own0, d1 = c1 ^ own1;
+        if (d0) return (u32)__builtin_ctzll(d0) >> 3;
+        if (d1) return 8 + ((u32)__builtin_ctzll(d1) >> 3);
+        return 16 + count_eq(src, p + 16, m + 16, be);
+      }
+      return src[m + ml] == src[p + ml] ? count_eq(src, p, m, be) : 0u;
+    };
+    while (miA >= 1 && attempts > 0) {
+      const bool two = miA > minChain && attempts > 1 && miB >= 1;
+      const u32 mA = miA - 1, mB = two ? miB - 1 : mA;
+      u64 a0 = 0, a1 = 0, b0 = 0, b1 = 0, eB = 0;
+      if (wide) { a0 = ld64(src + mA); a1 = ld64(src + mA + 8); }
+      if (two) {
+        if (wide) { b0 = ld64(src + mB); b1 = ld64(src + mB + 8); }
+        const u32 over = miB + H.chainSize;                               // the index that shares miB's chain slot
+        eB = (over > curr && over < H.insEnd) ? H.oldLink[over & 127u] : H.chainT[miB & H.cmask];
+      }
 #ifdef ZRA_MF_PROFILE
       steps_++;
 #endif
-      if (wide) {
-        const u64 d0 = ld64(src + m) ^ own0, d1 = ld64(src + m + 8) ^ own1;
-        if (d0) cur = (u32)__builtin_ctzll(d0) >> 3;
-        else if (d1) cur = 8 + ((u32)__builtin_ctzll(d1) >> 3);
-        else cur = 16 + count_eq(src, p + 16, m + 16, be);
-      } else if (src[m + ml] == src[p + ml]) cur = count_eq(src, p, m, be);
-      if (cur > ml) { ml = cur; offCode = curr - mi + 2; if (p + cur == be) break; }
-      if (mi <= minChain) break;
-      mi = nxt;
+      u32 cur = measure(mA, a0, a1);
+      if (cur > ml) { ml = cur; offCode = curr - miA + 2; if (p + cur == be) break; }
+      if (miA <= minChain) break;
       attempts--;
+      if (!two) break;                                   // (no second candidate, or no attempt left for it)
+      cur = measure(mB, b0, b1);
+      if (cur > ml) { ml = cur; offCode = curr - miB + 2; if (p + cur == be) break; }
+      if (miB <= minChain) break;
+      attempts--;
+      miA = (u32)eB; miB = (u32)(eB >> 32);
     }
   }
   HPROF(1)
@@ -1390,6 +1416,7 @@ __device__ __forceinline__ bool mf_frame_setup(const ZraEncArgs& a, u32 block, i
   if (block == 0) {
     // fresh frame: zeroed tables, repcodes {1,4,8}, nextToUpdate 1 (A.4.8); 16-byte coalesced clears by the whole wave
     size_t words = ((size_t)1 << F.P->hashLog) + ((size_t)1 << F.P->chainLog);
+    if (F.P->strategy >= 3 && F.P->strategy <= 5) words += (size_t)1 << F.P->chainLog;   // two links per chain slot (HCW)
     if (F.P->strategy >= 7)           // optimal parsers: the 3-byte hash table and the statistics of the price model behind the tree
       words += (F.P->minMatch == 3 ? (size_t)1 << min(17u, F.P->windowLog) : 0) + 512;
     uint4* t4 = (uint4*)F.hashT;
@@ -1568,7 +1595,7 @@ zra_mf_dfast2_kernel(ZraEncArgs a, u32 block, u32 only, u32 onlySlot) { mf_dfast
 // their tables. `only` = 0xFFFFFFFF: every frame of the batch; otherwise just that frame (the short last frame whose strategy differs
 // from the batch's), launched as one workgroup on table slot `onlySlot`.
 template <bool OPT>
-__device__ __forceinline__ void mf_generic(const ZraEncArgs& a, u32 block, u32 only, u32 onlySlot, u32 perWave, u32* hcOld, u8* hcDup) {
+__device__ __forceinline__ void mf_generic(const ZraEncArgs& a, u32 block, u32 only, u32 onlySlot, u32 perWave) {
   const int lane = threadIdx.x;
   const bool all = only == 0xFFFFFFFFu;
   if (!all) perWave = 1;
@@ -1581,60 +1608,20 @@ __device__ __forceinline__ void mf_generic(const ZraEncArgs& a, u32 block, u32 o
     const bool go = mf_frame_setup(a, block, lane, G, f, all ? f : onlySlot);
     if ((u32)lane == k || perWave == 1) { F = G; mine = go && (G.P->strategy != 2 || a.serialAll); }   // dfast frames belong to zra_mf_dfast_kernel
   }
-  // one frame per wave and a hash-chain strategy: the whole wave works on it
-  const bool coop = perWave == 1 && mine && F.P->strategy >= 3 && F.P->strategy <= 5 && !a.serialAll;
-  if (!mine || (!coop && lane != 0 && perWave == 1)) return;
-  const ZraEncParams& P = *F.P;
-  const u8* src = F.src; ZraEncFrameState* st = F.st; ZraEncBlockOut* bo = F.bo;
-  u32* hashT = F.hashT; u32* chainT = F.chainT; u64* seqs = F.seqs;
-  const u32 bs = F.bs, be = F.be;
-  u32 rep[3] = {st->rep[0], st->rep[1], st->rep[2]};
-  u32 lastLL;
-  if (!coop || lane == 0) bo->skip = 0;
-  Emit E; E.seqs = seqs; E.n = 0;
-  // limited update after a very long match (A.4.3 hash chain prologue; harmless for the other finders)
-  const u32 ntu0 = st->nextToUpdate;
-  u32 ntu = ntu0;
-  {
-    const u32 cur = bs + 1;
-    if (cur > ntu + 384) { const u32 d = cur - ntu - 384; ntu = cur - (d < 192 ? d : 192); }
-  }
-  if (coop) {
-    HCW H; H.oldLink = hcOld; H.dup = hcDup; H.hashT = hashT; H.chainT = chainT; H.hlog = P.hashLog; H.mls = P.minMatch < 4 ? 4 : P.minMatch > 6 ? 6 : P.minMatch;
-    H.chainSize = 1u << P.chainLog; H.cmask = H.chainSize - 1; H.searchLog = P.searchLog;
-    H.insEnd = st->insEnd; H.ntuRef = ntu;
-    for (u32 i = (u32)lane; i < 128; i += 64) hcOld[i] = st->ring[i];
-    hcw_sync();
-    if (ntu > ntu0) {
-      // indices [ntu0, ntu) are never inserted by the reference: those inserted ahead of the parse come out again, the rest is skipped
-      if (H.insEnd > ntu0) hcw_undo(H, src, ntu0, lane);
-      H.insEnd = ntu;
-    }
-    u32 nSeq = 0;
-    lastLL = mf_lazy_wave(H, src, bs, be, rep, seqs, &nSeq, (int)P.strategy - 3, lane);
-    hcw_sync();
-    for (u32 i = (u32)lane; i < 128; i += 64) st->ring[i] = hcOld[i];
-    if (lane == 0) {
-      st->nextToUpdate = H.ntuRef; st->insEnd = H.insEnd;
-      bo->nbSeq = nSeq; bo->lastLL = lastLL;
-      bo->rep[0] = rep[0]; bo->rep[1] = rep[1]; bo->rep[2] = rep[2];
-    }
-    return;
-  }
+  // (hash-chain frames — greedy / lazy / lazy2 inside the window — never come here: zra_mf_hc_kernel, also for a lone short last frame.
+  //  Reached with such a frame anyway, the serial chain finder below would read the two-link chain slots of HCW as single links.)
+  if (!mine || (lane != 0 && perWave == 1)) return;
+  const u32 ntu0 = F.st->nextToUpdate;
   mf_serial_block_t<OPT ? 0 : 2>(F, ntu0);
 }
 // the generic finder without / with the optimal parsers (215 VGPRs with them: batches and tails of levels 13-22 only)
 extern "C" __global__ void __launch_bounds__(64)
 zra_mf_kernel(ZraEncArgs a, u32 block, u32 only, u32 onlySlot, u32 perWave) {
-  __shared__ u32 hcOld[128];
-  __shared__ u8 hcDup[1024];
-  mf_generic<false>(a, block, only, onlySlot, perWave, hcOld, hcDup);
+  mf_generic<false>(a, block, only, onlySlot, perWave);
 }
 extern "C" __global__ void __launch_bounds__(64)
 zra_mf_opt_kernel(ZraEncArgs a, u32 block, u32 only, u32 onlySlot, u32 perWave) {
-  __shared__ u32 hcOld[128];
-  __shared__ u8 hcDup[1024];
-  mf_generic<true>(a, block, only, onlySlot, perWave, hcOld, hcDup);
+  mf_generic<true>(a, block, only, onlySlot, perWave);
 }
 
 // Match finder for batches whose full-size frames use "fast" (levels 1-2 and all negative levels): lane = frame, `perWave` frames in
@@ -1666,9 +1653,10 @@ zra_mf_fast_kernel(ZraEncArgs a, u32 block, u32 perWave) {
 // A short last frame whose cparams select another strategy is left to a second single-frame launch by the host
 // (zra_mf_dfast_kernel or zra_mf_kernel with `only`).
 extern "C" __global__ void __launch_bounds__(64)
-zra_mf_hc_kernel(ZraEncArgs a, u32 block) {
+zra_mf_hc_kernel(ZraEncArgs a, u32 block, u32 only, u32 onlySlot) {
   const int lane = threadIdx.x;
-  const u32 f = blockIdx.x;
+  const bool all = only == 0xFFFFFFFFu;                // else: frame `only` alone, with table slot onlySlot (a short last frame)
+  const u32 f = all ? blockIdx.x : only;
   if (f >= a.nFrames) return;
   {
     const u64 fstart = (u64)(a.firstFrame + f) * a.frameSize;
@@ -1676,7 +1664,7 @@ zra_mf_hc_kernel(ZraEncArgs a, u32 block) {
     if (Pf.strategy < 3 || Pf.strategy > 5) return;
   }
   MfFrame F;
-  if (!mf_frame_setup(a, block, lane, F, f, f)) return;
+  if (!mf_frame_setup(a, block, lane, F, f, all ? f : onlySlot)) return;
   const ZraEncParams& P = *F.P;
   ZraEncFrameState* st = F.st; ZraEncBlockOut* bo = F.bo;
   const u32 bs = F.bs, be = F.be;
@@ -1688,9 +1676,9 @@ zra_mf_hc_kernel(ZraEncArgs a, u32 block) {
     const u32 cur = bs + 1;
     if (cur > ntu + 384) { const u32 d = cur - ntu - 384; ntu = cur - (d < 192 ? d : 192); }
   }
-  __shared__ u32 hcOld[128];
+  __shared__ u64 hcOld[128];
   __shared__ u8 hcDup[1024];
-  HCW H; H.oldLink = hcOld; H.dup = hcDup; H.hashT = F.hashT; H.chainT = F.chainT; H.hlog = P.hashLog; H.mls = P.minMatch < 4 ? 4 : P.minMatch > 6 ? 6 : P.minMatch;
+  HCW H; H.oldLink = hcOld; H.dup = hcDup; H.hashT = F.hashT; H.chainT = (u64*)F.chainT; H.hlog = P.hashLog; H.mls = P.minMatch < 4 ? 4 : P.minMatch > 6 ? 6 : P.minMatch;
   H.chainSize = 1u << P.chainLog; H.cmask = H.chainSize - 1; H.searchLog = P.searchLog;
   H.insEnd = st->insEnd; H.ntuRef = ntu;
   for (u32 i = (u32)lane; i < 128; i += 64) hcOld[i] = st->ring[i];
