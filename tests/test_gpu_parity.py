@@ -894,11 +894,12 @@ def test_foreign_frame_size_does_not_cost_a_pass_per_frame(zra):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("env", [{"ZRA_MF_LK": "1"}, {"ZRA_MF_LK": "1", "ZRA_LK_MODE": "1", "ZRA_LK_GROUP": "64"}, {"ZRA_MF_FLAGS": "1", "ZRA_PP_MIN": "1"}, {"ZRA_MF_V2": "1"},
-                                 {"ZRA_DEC_PIPE": "4", "ZRA_DEC_PIPE_MIN": "1", "ZRA_DEC_SMALL_MAX": "0"}],
-                         ids=["link-dfast", "link-dfast-ring", "bucket-flags-dfast", "mask-dfast", "decode-stage-pipeline"])
+                                 {"ZRA_DEC_PIPE": "4", "ZRA_DEC_PIPE_MIN": "1", "ZRA_DEC_SMALL_MAX": "0"}, {"ZRA_MF_LS": "0"}, {"ZRA_MF_LS_MAX": "1000000"}],
+                         ids=["link-dfast", "link-dfast-ring", "bucket-flags-dfast", "mask-dfast", "decode-stage-pipeline", "dfast-small-calls-from-memory", "dfast-all-calls-from-lds"])
 def test_opt_in_kernels_are_bit_exact_too(env):
     """The kernels that ship in the library behind a bring-up knob (the round-4 link formulation of dfast in its two launch modes, the
-    table kernel fed with the pre-pass's bucket flags, the round-3 mask-resolve dfast parse, the decode stage pipeline) give the same bytes as the default ones: the compress parity cases of
+    table kernel fed with the pre-pass's bucket flags, the round-3 mask-resolve dfast parse, the decode stage pipeline; and the two dfast kernels of
+    round 4 — frame source read from memory / from a copy in LDS — each forced onto the call sizes the other one takes by default) give the same bytes as the default ones: the compress parity cases of
     levels 3-4 (archives byte-identical to the oracle's, reference call site zra.cpp:219), the sub-batch boundaries of the persistent
     pipeline, short last frames with other cparams and the differential decode again, in a fresh process with the knob set."""
     import subprocess

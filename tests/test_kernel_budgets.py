@@ -14,6 +14,7 @@ sys.path.insert(0, os.path.dirname(HERE))
 BUDGET = {
     "zra_mf_dfast_kernel": (72, 0),      # 18 resident waves per CU with 6 KiB LDS each (the allocation granule is 8 registers: 65-72 cost the same 7 waves per SIMD)
     "zra_mf_dfast_fl_kernel": (72, 0),   # the same parse fed with the pre-pass's bucket flags (opt-in)
+    "zra_mf_dfast_ls_kernel": (96, 0),   # the same parse over a copy of the frame in LDS (calls of a few hundred frames): one or two waves per CU by LDS, registers are not its limit
     "zra_lk_parse_kernel": (160, 0),     # link dfast (opt-in): 8 waves per CU by its LDS (16 KiB of bitmaps per frame), registers are not its limit
     "zra_lk_prepass_kernel": (128, 64),  # 1024 threads per workgroup: 4 waves per SIMD (a few spilled scalars live in scratch)
     "zra_mf_hc_kernel": (64, 0),         # one wave per frame, as many waves per CU as the hardware holds

@@ -13,6 +13,7 @@
 
 extern "C" __global__ void zra_mf_kernel(ZraEncArgs a, uint32_t block, uint32_t only, uint32_t onlySlot, uint32_t perWave);
 extern "C" __global__ void zra_mf_opt_kernel(ZraEncArgs a, uint32_t block, uint32_t only, uint32_t onlySlot, uint32_t perWave);
+extern "C" __global__ void zra_mf_dfast_ls_kernel(ZraEncArgs a, uint32_t block, uint32_t only, uint32_t onlySlot);
 extern "C" __global__ void zra_mf_hc_kernel(ZraEncArgs a, uint32_t block, uint32_t only, uint32_t onlySlot);
 extern "C" __global__ void zra_mf_fast_kernel(ZraEncArgs a, uint32_t block, uint32_t perWave);
 extern "C" __global__ void zra_mf_dfast_kernel(ZraEncArgs a, uint32_t block, uint32_t only, uint32_t onlySlot);
@@ -288,11 +289,11 @@ Status Engine::compress_impl_body(const uint8_t* dIn, size_t inSize, uint8_t* dB
         // strategy is parsed by the generic kernel in a second single-frame launch
         const bool hasTail = tailSize && f0 + nb == nFramesTotal;
         // LDS geometry of the dfast kernel's bucket filter (see compress_persistent)
-        uint32_t shL = 1, shS = 2, dupLog = 9;
-        if (const char* f = std::getenv("ZRA_MF_FILTER")) { unsigned x = 1, y = 1, z = 9; if (std::sscanf(f, "%u,%u,%u", &x, &y, &z) >= 1) { shL = x & 15; shS = y & 15; dupLog = z & 15; } }
+        uint32_t shL = 1, shS = 2, dupLog = 8;
+        if (const char* f = std::getenv("ZRA_MF_FILTER")) { unsigned x = 1, y = 1, z = 8; if (std::sscanf(f, "%u,%u,%u", &x, &y, &z) >= 1) { shL = x & 15; shS = y & 15; dupLog = z & 15; } }
         a.mfFilter = shL | (shS << 4) | (dupLog << 8);
         const uint32_t hl = std::max(full.hashLog, tail.hashLog), cl = std::max(full.chainLog, tail.chainLog);
-        const size_t filterBytes = (2u << dupLog) + (((size_t)1 << hl) >> shL) / 8 + (((size_t)1 << cl) >> shS) / 8 + 64;
+        const size_t filterBytes = (8u << dupLog) + (((size_t)1 << hl) >> shL) / 8 + (((size_t)1 << cl) >> shS) / 8 + 64;
         // frames larger than the level's window (0.5 - 4 MiB and more): the sliding-window rules live in the serial finders only
         const bool serialAll = std::min<uint64_t>(frameSize, inSize) > (1ull << full.windowLog);
         a.serialAll = serialAll ? 1u : 0u;
@@ -425,11 +426,26 @@ Status Engine::compress_persistent(const uint8_t* dIn, size_t inSize, uint8_t* d
   // duplicate-detection slots (1 KiB + 4 KiB + 1 KiB at hashLog 16 / chainLog 15: one bit per 2 long buckets, per 4 short buckets).
   // 18 resident waves per CU x 6 KiB leave LDS and wave slots for two entropy-stage workgroups per CU, which is what lets stream B
   // run under the match finder (round 1: profiles/r01_mf_occupancy_sweep.log; round 2 A/B on one box: profiles/r02_experiments.md)
-  uint32_t shL = 1, shS = 2, dupLog = 9;
-  if (const char* f = std::getenv("ZRA_MF_FILTER")) { unsigned x = 1, y = 1, z = 9; if (std::sscanf(f, "%u,%u,%u", &x, &y, &z) >= 1) { shL = x & 15; shS = y & 15; dupLog = z & 15; } }
+  uint32_t shL = 1, shS = 2, dupLog = 8;
+  if (const char* f = std::getenv("ZRA_MF_FILTER")) { unsigned x = 1, y = 1, z = 8; if (std::sscanf(f, "%u,%u,%u", &x, &y, &z) >= 1) { shL = x & 15; shS = y & 15; dupLog = z & 15; } }
   base.mfFilter = shL | (shS << 4) | (dupLog << 8);
   const uint32_t hl = std::max(full.hashLog, tail.hashLog), cl = std::max(full.chainLog, tail.chainLog);
-  const size_t filterBytes = (2u << dupLog) + (((size_t)1 << hl) >> shL) / 8 + (((size_t)1 << cl) >> shS) / 8 + 64;
+  const size_t filterBytes = (8u << dupLog) + (((size_t)1 << hl) >> shL) / 8 + (((size_t)1 << cl) >> shS) / 8 + 64;
+
+  // ---- latency mode (round 4): calls of at most ZRA_MF_LS_MAX frames (default: two per CU, what LDS holds at 64 KiB) run the dfast parse over
+  // a copy of the frame in LDS (zra_mf_dfast_ls_kernel). ZRA_MF_LS=0 turns it off.
+  static const int lsEnv = std::getenv("ZRA_MF_LS") ? std::atoi(std::getenv("ZRA_MF_LS")) : 1;
+  const uint32_t lsBytes = (uint32_t)((std::min<uint64_t>(frameSize, inSize) + 64 + 63) & ~63ull);
+  const uint32_t lsPerCu = (uint32_t)((160u << 10) / (lsBytes + filterBytes));
+  static const int lsMaxEnv = std::getenv("ZRA_MF_LS_MAX") ? std::atoi(std::getenv("ZRA_MF_LS_MAX")) : -1;
+  bool useLs = lsEnv != 0 && !mf_v2() && full.strategy == 2 && lsPerCu >= 1 &&
+               nFramesTotal <= (lsMaxEnv >= 0 ? (uint64_t)lsMaxEnv : (uint64_t)lsPerCu * (uint64_t)numCUs_);
+  if (useLs && lsAttr_ == 0) {
+    const bool okA = hipFuncSetAttribute((const void*)zra_mf_dfast_ls_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 << 10) == hipSuccess;
+    if (!okA) (void)hipGetLastError();
+    lsAttr_ = okA ? 1 : -1;
+  }
+  if (lsAttr_ < 0) useLs = false;
 
   // ---- link formulation (zra_encode_lk.hip) for frames of at most 64 KiB: a parse-independent pre-pass + a parse without tables.
   // Opt-in (ZRA_MF_LK=1): bit-exact, but measured slower than the table kernel (round 4: 7.7 against 16 GiB/s, profiles/r04_experiments.md).
@@ -558,6 +574,9 @@ Status Engine::compress_persistent(const uint8_t* dIn, size_t inSize, uint8_t* d
       fa.flags = fk.flagsOut; fa.flagStride = fk.flagStride; fa.flagSlots = fk.ringSlots; fa.flagReadyBase = (uint32_t)F0; fa.flagReady = fk.ready; fa.flagFail = fk.fail;
       const uint32_t slots = (uint32_t)std::min<uint64_t>((uint64_t)((uint32_t)numCUs_ - ppGrid) * wavesPerCU, nSlots);
       hipLaunchKernelGGL(zra_mf_dfast_fl_kernel, dim3(std::min<uint32_t>(n, slots)), dim3(64), filterBytes, stream_, a, fa, 0u, 0xFFFFFFFFu, 0u);
+    } else if (!useLk && useLs) {
+      ZraEncArgs al = a; al.mfFilter |= (lsBytes / 64) << 16;
+      hipLaunchKernelGGL(zra_mf_dfast_ls_kernel, dim3(std::min<uint32_t>(n, nSlots)), dim3(64), lsBytes + filterBytes, stream_, al, 0u, 0xFFFFFFFFu, 0u);
     } else if (!useLk) hipLaunchKernelGGL(ZRA_DFAST_KERNEL, dim3(std::min<uint32_t>(n, nSlots)), dim3(64), filterBytes, stream_, a, 0u, 0xFFFFFFFFu, 0u);
     else if (lkMode == 1) {
       // both kernels persistent: the pre-pass on its own stream behind everything queued on stream A so far (the ring and its flags

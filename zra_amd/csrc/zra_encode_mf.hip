@@ -450,8 +450,12 @@ __device__ u32 mf_dfast_lean(const ZraEncParams& P, u32* HL, u32* HS, const u8* 
   const u32 ilimit = be >= 8 ? be - 8 : 0;            // a 7-byte first block: iend-8 lies before the start, nothing is searched
   u32 ip = mf_prologue(bs, o1, o2, saved);
   u32 sqLo = 0, sqHi = 0;                              // pending sequences, lane = index & 63
-  u8* const dL = W.dup; u8* const dS = W.dup + W.dupSlots;
+  // duplicate detection of a window (below): one 32-bit slot per bucket class and table, keyed (round << 6) | (63 - lane) and written with
+  // an LDS max: the slot's winner is the LOWEST lane of the round, and an older round never wins. Cleared once per block.
+  u32* const dL = (u32*)W.dup; u32* const dS = dL + W.dupSlots;
   const u32 dmask = W.dupSlots - 1;
+  for (u32 i = (u32)lane; i < 2 * W.dupSlots; i += 64) dL[i] = 0;
+  u32 dupRound = 0;
   u32* const bmL = W.bmL; u32* const bmS = W.bmS;
   PROF_DECL
   auto emit = [&](u32 ll, u32 ml, u32 offVal) {
@@ -486,20 +490,35 @@ __device__ u32 mf_dfast_lean(const ZraEncParams& P, u32* HL, u32* HS, const u8* 
     PROF(0) PROF_CNT(12)
     u32 bL, bS, tL, tS; H.both(v8, bL, bS, tL, tS);
     if (nAct > 1) {
-      if (active) { dL[bL & dmask] = (u8)lane; dS[bS & dmask] = (u8)lane; }
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-      const bool suspect = active && (dL[bL & dmask] != (u8)lane || dS[bS & dmask] != (u8)lane);
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-      u64 sm = __ballot(suspect);
-      u32 cut = nAct;
-      while (sm) {                                   // exact check of the suspects (a slot collision is not yet a bucket collision)
-        const u32 i = (u32)__builtin_ctzll(sm); sm &= sm - 1;
-        if (i >= cut) break;
-        const u32 bLi = bcast(bL, i), bSi = bcast(bS, i);
-        const u64 cm = __ballot(active && (u32)lane != i && (bL == bLi || bS == bSi));
-        if (cm) { const u32 lo = (u32)__builtin_ctzll(cm); cut = min(cut, max(lo, i)); }
+      // Which is the first lane of the window that shares a bucket (of either table) with an EARLIER lane? The window ends before it.
+      // Every lane enters its bucket's slot (low bucket bits) with an LDS max of (round << 6) | (63 - lane): the slot's winner is the
+      // lowest lane of the round. A lane that finds another lane there compares BUCKETS with it (one cross-lane read): equal — it has
+      // an earlier bucket-mate, it is marked and done; different — only the slot is shared, it tries again in the next round among
+      // the lanes still unsettled. Winners are done. Exact: the first lane j with an earlier bucket-mate i meets i in the round i wins
+      // (i cannot be marked itself — it would be an earlier end of the window — and j cannot win before i), and only real mates are
+      // marked. ~2.5 rounds per window. The serial check of every lane that shared a SLOT, which stood here before, was 28 % of a lone
+      // frame's time and most of the kernel's scalar instructions (round 4, profiles/r04_experiments.md §5).
+      // (A wave's LDS accesses execute in issue order: volatile reads and a scheduling barrier are all the ordering it takes.)
+      bool pL = active, pS = active;
+      u64 mates = 0;
+      for (;;) {
+        dupRound++;
+        const u32 key = (dupRound << 6) | (63u - (u32)lane);
+        if (pL) atomicMax(&dL[bL & dmask], key);
+        if (pS) atomicMax(&dS[bS & dmask], key);
+        __builtin_amdgcn_wave_barrier();
+        const u32 wl = pL ? 63u - (((volatile u32*)dL)[bL & dmask] & 63u) : (u32)lane;
+        const u32 ws = pS ? 63u - (((volatile u32*)dS)[bS & dmask] & 63u) : (u32)lane;
+        __builtin_amdgcn_wave_barrier();
+        const u32 obL = (u32)__shfl((int)bL, (int)wl, 64), obS = (u32)__shfl((int)bS, (int)ws, 64);   // (by every lane: the lane read from must be executing)
+        const bool lostL = wl != (u32)lane, lostS = ws != (u32)lane;
+        const bool sameL = lostL && obL == bL, sameS = lostS && obS == bS;
+        mates |= __ballot(sameL || sameS);
+        pL = lostL && !sameL; pS = lostS && !sameS;
+        PROF_CNT(17)
+        if (!__ballot(pL || pS)) break;
       }
-      nAct = cut; active = (u32)lane < nAct;
+      if (mates) { nAct = (u32)__builtin_ctzll(mates); active = (u32)lane < nAct; }
     }
     PROF(1)
     // LDS filter: a clear bit means no position of this frame was ever inserted into the bucket (group) -> no table read
@@ -571,6 +590,18 @@ __device__ u32 mf_dfast_lean(const ZraEncParams& P, u32* HL, u32* HS, const u8* 
         else { m = bcast(mS, f) - 1; known = 4; }
       }
       PROF(5)
+#ifdef ZRA_MF_PAD_SALU
+      // bring-up experiment (round 4, profiles/r04_experiments.md §5): N idle scalar instructions per sequence — does the kernel's time follow
+      // its instruction count (issue-bound) or not (latency-bound)?
+      { u32 sd_ = nseq;
+#pragma unroll
+        for (int k_ = 0; k_ < ZRA_MF_PAD_SALU; k_++) asm volatile("s_add_u32 %0, %0, 1" : "+s"(sd_) :: "scc"); }
+#endif
+#ifdef ZRA_MF_PAD_VALU
+      { u32 vd_ = (u32)lane;
+#pragma unroll
+        for (int k_ = 0; k_ < ZRA_MF_PAD_VALU; k_++) asm volatile("v_add_u32 %0, %0, 1" : "+v"(vd_)); }
+#endif
       const u32 off = ip - m;
       // ---- issue together: forward compare (64 x 8 B), backward compare (64 x 1 B), rep gather for the next o1
       const u32 fa = ip + known + 8 * (u32)lane, fb = m + known + 8 * (u32)lane;
@@ -1491,15 +1522,21 @@ __device__ __forceinline__ void mf_serial_block_t(const MfFrame& F, u32 ntu0) {
 
 // Match finder for strategy 2 (dfast, levels 3-4): one wave per frame, lean window-resolve parse. Launched when the batch's
 // full-size frames use dfast; a short last frame with another strategy is left to zra_mf_kernel (second launch, `only`).
-template <bool MASK, bool FLAGS>
+// LSRC (round 4, calls of a few hundred frames at most): the frame's source bytes are copied into LDS first and the parse reads them
+// there — every source access of the parse (hash input, repcode streams, candidate compares, extensions) is an LDS access; only the
+// table gathers go to memory. A lone frame is one dependent chain of round trips: this shortens most of them from memory latency to
+// LDS latency. One or two frames per CU by LDS, so it is a latency mode, not the throughput kernel.
+template <bool MASK, bool FLAGS, bool LSRC = false>
 __device__ __forceinline__ void mf_dfast_body(const ZraEncArgs& a, u32 block, u32 only, u32 onlySlot, const ZraFlagArgs* g = nullptr) {
   const int lane = threadIdx.x;
-  // dynamic LDS: [dup bytes 2 x dupSlots][filter L][filter S]; geometry chosen by the host (a.mfFilter: shL | shS<<4 | log2(dupSlots)<<8)
+  // dynamic LDS: [LSRC: source bytes, (a.mfFilter >> 16) * 64][dup slots 2 x dupSlots x 4 B][filter L][filter S]; geometry chosen by the host
+  // (a.mfFilter: shL | shS<<4 | log2(dupSlots)<<8 | source granules << 16)
   extern __shared__ u32 dynLds[];
   LeanLds W;
   W.shL = a.mfFilter & 15; W.shS = (a.mfFilter >> 4) & 15; W.dupSlots = 1u << ((a.mfFilter >> 8) & 15);
-  W.dup = (u8*)dynLds;
-  W.bmL = dynLds + (2 * W.dupSlots) / 4;
+  u32* const fltLds = LSRC ? dynLds + (a.mfFilter >> 16) * 16 : dynLds;
+  W.dup = (u8*)fltLds;
+  W.bmL = fltLds + 2 * W.dupSlots;
   const bool persistent = a.mfQueue != nullptr;
   for (;;) {
     u32 f = only == 0xFFFFFFFFu ? blockIdx.x : only;   // `only`: a single-workgroup launch for that frame on table slot `onlySlot`
@@ -1554,12 +1591,25 @@ __device__ __forceinline__ void mf_dfast_body(const ZraEncArgs& a, u32 block, u3
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         if (okf) flg = g->flags + (size_t)slot * g->flagStride;
       }
-      if (MASK) lastLL = mf_dfast_mask(*F.P, F.hashT, F.chainT, F.src, F.fsize, F.bs, F.be, rep, F.seqs, &nseq, W, lane, ib);
+      const u8* srcP = F.src;
+      if (LSRC) {
+        // the frame into LDS, 16 bytes per lane and step (the last, partial, 16 bytes one by one: the input ends there), 64 zero bytes behind it
+        u8* const ls = (u8*)dynLds;
+        const u32 n16 = F.fsize >> 4;
+        for (u32 i = (u32)lane; i < n16; i += 64) *(uint4*)(ls + 16 * i) = ld128(F.src + 16 * i);
+        for (u32 i = (n16 << 4) + (u32)lane; i < F.fsize; i += 64) ls[i] = F.src[i];
+        ls[F.fsize + (u32)lane] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        srcP = ls;
+      }
+      if (MASK) lastLL = mf_dfast_mask(*F.P, F.hashT, F.chainT, srcP, F.fsize, F.bs, F.be, rep, F.seqs, &nseq, W, lane, ib);
       else switch (F.P->minMatch) {
-        case 5: lastLL = mf_dfast_lean<5, FLAGS>(*F.P, F.hashT, F.chainT, F.src, F.bs, F.be, rep, F.seqs, &nseq, W, lane, ib, flg); break;
-        case 6: lastLL = mf_dfast_lean<6, FLAGS>(*F.P, F.hashT, F.chainT, F.src, F.bs, F.be, rep, F.seqs, &nseq, W, lane, ib, flg); break;
-        case 7: lastLL = mf_dfast_lean<7, FLAGS>(*F.P, F.hashT, F.chainT, F.src, F.bs, F.be, rep, F.seqs, &nseq, W, lane, ib, flg); break;
-        default: lastLL = mf_dfast_lean<4, FLAGS>(*F.P, F.hashT, F.chainT, F.src, F.bs, F.be, rep, F.seqs, &nseq, W, lane, ib, flg); break;
+        case 5: lastLL = mf_dfast_lean<5, FLAGS>(*F.P, F.hashT, F.chainT, srcP, F.bs, F.be, rep, F.seqs, &nseq, W, lane, ib, flg); break;
+        case 6: lastLL = mf_dfast_lean<6, FLAGS>(*F.P, F.hashT, F.chainT, srcP, F.bs, F.be, rep, F.seqs, &nseq, W, lane, ib, flg); break;
+        case 7: lastLL = mf_dfast_lean<7, FLAGS>(*F.P, F.hashT, F.chainT, srcP, F.bs, F.be, rep, F.seqs, &nseq, W, lane, ib, flg); break;
+        default: lastLL = mf_dfast_lean<4, FLAGS>(*F.P, F.hashT, F.chainT, srcP, F.bs, F.be, rep, F.seqs, &nseq, W, lane, ib, flg); break;
       }
       if (lane == 0) {
         F.bo->nbSeq = nseq; F.bo->lastLL = lastLL; F.bo->skip = 0;
@@ -1584,6 +1634,9 @@ zra_mf_dfast_kernel(ZraEncArgs a, u32 block, u32 only, u32 onlySlot) { mf_dfast_
 // the same parse fed with the pre-pass's bucket flags (round 4, opt-in ZRA_MF_FLAGS=1: skips the table reads and writes that cannot matter)
 extern "C" __global__ void __launch_bounds__(64)
 zra_mf_dfast_fl_kernel(ZraEncArgs a, ZraFlagArgs g, u32 block, u32 only, u32 onlySlot) { mf_dfast_body<false, true>(a, block, only, onlySlot, &g); }
+// the same parse over a copy of the frame in LDS (round 4): the latency mode for calls of a few hundred frames at most
+extern "C" __global__ void __launch_bounds__(64)
+zra_mf_dfast_ls_kernel(ZraEncArgs a, u32 block, u32 only, u32 onlySlot) { mf_dfast_body<false, false, true>(a, block, only, onlySlot); }
 // the mask-resolve parse (round 3): more registers, meant for few resident waves per CU with the tables inside the Infinity Cache
 extern "C" __global__ void __launch_bounds__(64)
 zra_mf_dfast2_kernel(ZraEncArgs a, u32 block, u32 only, u32 onlySlot) { mf_dfast_body<true, false>(a, block, only, onlySlot); }
