@@ -507,8 +507,8 @@ __device__ u32 mf_dfast_lean(const ZraEncParams& P, u32* HL, u32* HS, const u8* 
         if (pL) atomicMax(&dL[bL & dmask], key);
         if (pS) atomicMax(&dS[bS & dmask], key);
         __builtin_amdgcn_wave_barrier();
-        const u32 wl = pL ? 63u - (((volatile u32*)dL)[bL & dmask] & 63u) : (u32)lane;
-        const u32 ws = pS ? 63u - (((volatile u32*)dS)[bS & dmask] & 63u) : (u32)lane;
+        const u32 wl = pL ? 63u - (lds_read32(&dL[bL & dmask]) & 63u) : (u32)lane;
+        const u32 ws = pS ? 63u - (lds_read32(&dS[bS & dmask]) & 63u) : (u32)lane;
         __builtin_amdgcn_wave_barrier();
         const u32 obL = (u32)__shfl((int)bL, (int)wl, 64), obS = (u32)__shfl((int)bS, (int)ws, 64);   // (by every lane: the lane read from must be executing)
         const bool lostL = wl != (u32)lane, lostS = ws != (u32)lane;
@@ -1183,7 +1183,7 @@ struct HCW {
   // reference never follows that link once i is inserted (i - chainSize is below its minChain by then), but a window is inserted
   // AHEAD of the positions searched in it, so the links it overwrote (at most 66, ring of 128 by index) are kept in LDS
   u64* oldLink;
-  volatile u8* dup;      // 1024 byte slots: which lanes of an insert step may share a bucket (hcw_insert)
+  u8* dup;               // 1024 byte slots: which lanes of an insert step may share a bucket (hcw_insert; accessed as volatile LDS)
 };
 
 __device__ __forceinline__ void hcw_sync() {
@@ -1222,13 +1222,13 @@ __device__ void hcw_insert(HCW& H, const u8* src, u32 endIdx, int lane) {
     bool head = act;
     u32 from = 64;                                       // lane whose index this lane links to (64: the bucket's head in the table)
     const u32 slot = h & 1023u;
-    if (act) H.dup[slot] = (u8)lane;
+    if (act) lds_write8(H.dup + slot, (u32)lane);
     __builtin_amdgcn_wave_barrier();
-    const bool lost = act && H.dup[slot] != (u8)lane;
+    const bool lost = act && lds_read8(H.dup + slot) != (u32)lane;
     __builtin_amdgcn_wave_barrier();
-    if (lost) H.dup[slot] = (u8)lane;
+    if (lost) lds_write8(H.dup + slot, (u32)lane);
     __builtin_amdgcn_wave_barrier();
-    const bool shared = act && (lost || H.dup[slot] != (u8)lane);
+    const bool shared = act && (lost || lds_read8(H.dup + slot) != (u32)lane);
     u64 rem = __ballot(shared);
     while (rem) {
       const u32 l = (u32)__builtin_ctzll(rem);
@@ -1296,7 +1296,9 @@ __device__ void hcw_search_window(HCW& H, const u8* src, u32 w, u32 ilimit, u32 
       if (two) {
         if (wide) { b0 = ld64(src + mB); b1 = ld64(src + mB + 8); }
         const u32 over = miB + H.chainSize;                               // the index that shares miB's chain slot
-        eB = (over > curr && over < H.insEnd) ? H.oldLink[over & 127u] : H.chainT[miB & H.cmask];
+        // (two loads of two kinds, not one load through a selected pointer: that would be a flat load in the search loop)
+        if (over > curr && over < H.insEnd) eB = lds_read64(&H.oldLink[over & 127u]);
+        else eB = H.chainT[miB & H.cmask];
       }
 #ifdef ZRA_MF_PROFILE
       steps_++;

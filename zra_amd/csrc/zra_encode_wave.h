@@ -5,6 +5,17 @@
 namespace zra_wave {
 using namespace zra_dev;
 
+// LDS accesses that must really happen, in program order (slots other lanes of the wave write): volatile, and typed as LDS. A volatile
+// access through a GENERIC pointer compiles to a flat load with "s_waitcnt vmcnt(0)" — the vector-memory path, and a wait for every
+// global load in flight besides — instead of a ds_read (round 4: that was what the duplicate detection of both match finders waited for).
+typedef __attribute__((address_space(3))) u32 lds_u32_t;
+typedef __attribute__((address_space(3))) u8 lds_u8_t;
+__device__ __forceinline__ u32 lds_read32(const u32* p) { return *(const volatile lds_u32_t*)p; }
+typedef __attribute__((address_space(3))) u64 lds_u64_t;
+__device__ __forceinline__ u64 lds_read64(const u64* p) { return *(const volatile lds_u64_t*)p; }
+__device__ __forceinline__ u32 lds_read8(const u8* p) { return *(const volatile lds_u8_t*)p; }
+__device__ __forceinline__ void lds_write8(u8* p, u32 v) { *(volatile lds_u8_t*)p = (u8)v; }
+
 __device__ __forceinline__ u32 rfl(u32 v) { return (u32)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ u32 bcast(u32 v, u32 l) { return (u32)__builtin_amdgcn_readlane((int)v, (int)l); }
 
