@@ -614,6 +614,10 @@ Status Engine::compress_persistent(const uint8_t* dIn, size_t inSize, uint8_t* d
     if (checksum)
       hipLaunchKernelGGL(zra_content_ck_kernel, dim3((n * 4 + 255) / 256), dim3(256), 0, stream2_, dIn, (u64)inSize, frameSize, (u32)F0, n, a.contentCk);
     const uint32_t nSub = (n + SB - 1) / SB;
+    // bring-up knob (round 4, profiles/r04_experiments.md §7): the entropy stage only behind the whole match-finder launch — what does the
+    // overlap cost the finder, and is the process-to-process spread of its launch time a property of that overlap?
+    static const bool entDefer = std::getenv("ZRA_ENT_DEFER") != nullptr;
+    if (entDefer) HIPCHK(hipStreamWaitEvent(stream2_, m1, 0));
     for (uint32_t j = 0; j < nSub; j++) {
       const uint32_t j0 = j * SB, nbj = std::min<uint32_t>(SB, n - j0);
       const bool hasOdd = oddTail && j == nSub - 1;

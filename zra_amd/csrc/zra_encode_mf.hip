@@ -1278,7 +1278,9 @@ __device__ void hcw_search_window(HCW& H, const u8* src, u32 w, u32 ilimit, u32 
     // lies above minChain (so the link that named the second is intact) and an attempt is left.
     // (Measured and dropped: two positions per lane in one loop, window of 128 — 101 VGPRs, 4 waves per SIMD, 1.5 instead of 2.8 GiB/s.)
     const bool wide = p + 16 <= be;
-    const u64 own0 = wide ? ld64(src + p) : 0ull, own1 = wide ? ld64(src + p + 8) : 0ull;
+    // (16 bytes as ONE load each: a candidate is one request to the address unit and one tag lookup, not two)
+    const uint4 ownQ = wide ? ld128(src + p) : make_uint4(0, 0, 0, 0);
+    const u64 own0 = (u64)ownQ.x | ((u64)ownQ.y << 32), own1 = (u64)ownQ.z | ((u64)ownQ.w << 32);
     auto measure = [&](u32 m, u64 c0, u64 c1) -> u32 {
       if (wide) {
         const u64 d0 = c0 ^ own0, d1 = c1 ^ own1;
@@ -1292,9 +1294,9 @@ __device__ void hcw_search_window(HCW& H, const u8* src, u32 w, u32 ilimit, u32 
       const bool two = miA > minChain && attempts > 1 && miB >= 1;
       const u32 mA = miA - 1, mB = two ? miB - 1 : mA;
       u64 a0 = 0, a1 = 0, b0 = 0, b1 = 0, eB = 0;
-      if (wide) { a0 = ld64(src + mA); a1 = ld64(src + mA + 8); }
+      if (wide) { const uint4 q = ld128(src + mA); a0 = (u64)q.x | ((u64)q.y << 32); a1 = (u64)q.z | ((u64)q.w << 32); }
       if (two) {
-        if (wide) { b0 = ld64(src + mB); b1 = ld64(src + mB + 8); }
+        if (wide) { const uint4 q = ld128(src + mB); b0 = (u64)q.x | ((u64)q.y << 32); b1 = (u64)q.z | ((u64)q.w << 32); }
         const u32 over = miB + H.chainSize;                               // the index that shares miB's chain slot
         // (two loads of two kinds, not one load through a selected pointer: that would be a flat load in the search loop)
         if (over > curr && over < H.insEnd) eB = lds_read64(&H.oldLink[over & 127u]);
