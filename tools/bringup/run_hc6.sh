@@ -1,7 +1,7 @@
 #!/bin/bash
 # A/B on one box, hash-chain search: candidates' 16 bytes as one load (A) against two (B); text-like and log-like corpora
 root=$(pwd); out=$root/gpurun_out/hc6.txt; mkdir -p $root/gpurun_out; : > $out
-( timeout 900 python3 -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "bit_exact and (5- or 6- or 7- or 9-) or differential_compress" < /dev/null 2>&1 | tail -3 ) >> $out
+( timeout 900 python3 -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "bit_exact and (5- or 6- or 7- or 8- or 9- or 10-) or differential_compress or short_last or larger_than or c4 or poisoned" < /dev/null 2>&1 | tail -3 ) >> $out
 for r in 1 2; do
   for cfg in "2 5 65536" "2 7 65536" "2 9 262144"; do
     for lib in A B; do

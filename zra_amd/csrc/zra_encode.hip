@@ -177,7 +177,7 @@ Status Engine::compress_impl_body(const uint8_t* dIn, size_t inSize, uint8_t* dB
   // per-frame table slot: hash table + chain table / tree; the optimal parsers add a 3-byte hash table and their state (ZraOptState)
   auto slotWords = [](const ZraEncParams& q) -> uint64_t {
     uint64_t w = (1ull << q.hashLog) + (1ull << q.chainLog);
-    if (q.strategy >= 3 && q.strategy <= 5) w += 1ull << q.chainLog;   // the wave-cooperative hash-chain finder keeps two links per slot
+    if (q.strategy >= 3 && q.strategy <= 5) w += 3ull << q.chainLog;   // the wave-cooperative hash-chain finder keeps four links per slot
     if (q.strategy >= 7) w += (q.minMatch == 3 ? 1ull << std::min(17u, q.windowLog) : 0) + (sizeof(ZraOptState) + 3) / 4 + 16;
     return w;
   };
@@ -278,6 +278,10 @@ Status Engine::compress_impl_body(const uint8_t* dIn, size_t inSize, uint8_t* dB
     const uint32_t rounds = (uint32_t)((firstFrameSize + P0.blockSize - 1) / P0.blockSize);
     // the context's scratch is free once the entropy stage + gather of its previous batch are done
     if (entDone[c]) HIPCHK(hipStreamWaitEvent(stream_, entDone[c], 0));
+    // test knob: the table scratch filled with a pattern before a batch — whatever a finder does not clear itself (the wave-cooperative
+    // hash-chain finder leaves its chain slots alone) must not matter (tests/test_gpu_parity.py::test_opt_in_kernels_are_bit_exact_too)
+    { static const bool poison = std::getenv("ZRA_ENC_POISON") != nullptr;
+      if (poison) HIPCHK(hipMemsetAsync(x.tables.p, 0xA5, (size_t)nb * tableWords * 4, stream_)); }
     for (uint32_t blk = 0; blk < rounds; blk++) {
       hipEvent_t m0 = ev(), m1 = ev(), e1 = ev();
       if (!m0 || !m1 || !e1) return zerr(1);

@@ -1166,11 +1166,12 @@ struct HCW {
 #ifdef ZRA_MF_PROFILE
   u64 pt[12]; u64 pl;
 #endif
-  // chainT (round 4): TWO links per chain slot, link | nextLink << 32 — what the slot's index linked to when it was inserted, and what
-  // THAT index linked to. A search step is one dependent round trip; with the link after next in hand it tests two candidates per trip.
-  // nextLink is exact whenever it is used: a slot keeps its link from its index's insertion until the index + chainSize overwrites it,
-  // and the search stops behind a candidate at or below minChain (the only candidates whose slot can be gone) before it would follow it.
-  u32* hashT; u64* chainT; u32 hlog, mls, cmask, chainSize, searchLog;
+  // chainT (round 4): FOUR links per chain slot {x, y, z, w} — what the slot's index linked to when it was inserted (x), what THAT index
+  // linked to (y), and so on: the next four candidates of the chain. A search step is one dependent round trip; with four links in hand
+  // it tests four candidates per trip. A later link is exact whenever it is used: a slot keeps its links from its index's insertion
+  // until index + chainSize overwrites it, and the search stops behind a candidate at or below minChain (the only candidates whose slot
+  // can be gone) before it would follow it. One 16-byte load costs the address unit what an 8-byte one does.
+  u32* hashT; uint4* chainT; u32 hlog, mls, cmask, chainSize, searchLog;
   u32 insEnd;            // first index (position + 1) not inserted yet
   u32 ntuRef;            // the reference's nextToUpdate
   u32 w;                 // window: answers for positions [w, w + 64) are in rml / roff of lane p - w
@@ -1182,7 +1183,7 @@ struct HCW {
   // chain tables smaller than the frame (chainLog < windowLog): inserting index i overwrites the link of index i - chainSize. The
   // reference never follows that link once i is inserted (i - chainSize is below its minChain by then), but a window is inserted
   // AHEAD of the positions searched in it, so the links it overwrote (at most 66, ring of 128 by index) are kept in LDS
-  u64* oldLink;
+  uint4* oldLink;
   u8* dup;               // 1024 byte slots: which lanes of an insert step may share a bucket (hcw_insert; accessed as volatile LDS)
 };
 
@@ -1198,7 +1199,7 @@ __device__ void hcw_undo(HCW& H, const u8* src, u32 from, int lane) {
   if (lane == 0) {
     for (u32 idx = H.insEnd; idx-- > from;) {
       const u32 h = hashN(src + idx - 1, H.hlog, H.mls);
-      H.hashT[h] = (u32)H.chainT[idx & H.cmask];
+      H.hashT[h] = H.chainT[idx & H.cmask].x;
       H.chainT[idx & H.cmask] = H.oldLink[idx & 127u];
     }
   }
@@ -1242,13 +1243,17 @@ __device__ void hcw_insert(HCW& H, const u8* src, u32 endIdx, int lane) {
       rem &= ~same;
       HCNT(7, 1)
     }
-    // the link after next: the linked lane's own link, or what the table holds for the old head (loads before this step's stores)
-    const u32 laneLink = (u32)__shfl((int)link, (int)(from < 64 ? from : (u32)lane), 64);
-    u32 link2 = laneLink;
-    if (from >= 64) link2 = (act && link) ? (u32)H.chainT[link & H.cmask] : 0u;
+    // the links behind the first: the first three of the index linked to — from the table for the bucket's old head (loads before this
+    // step's stores), from the linked lane for a bucket-mate of this step (three rounds: a lane's second link is its mate's first, ...)
+    uint4 E = make_uint4(0, 0, 0, 0);
+    if (from >= 64 && act && link) E = H.chainT[link & H.cmask];
+    const int srcLane = (int)(from < 64 ? from : (u32)lane);
+    u32 l2 = (u32)__shfl((int)link, srcLane, 64); if (from >= 64) l2 = E.x;
+    u32 l3 = (u32)__shfl((int)l2, srcLane, 64); if (from >= 64) l3 = E.y;
+    u32 l4 = (u32)__shfl((int)l3, srcLane, 64); if (from >= 64) l4 = E.z;
     if (act) {
-      H.oldLink[idx & 127u] = idx > H.chainSize ? H.chainT[idx & H.cmask] : 0ull;
-      H.chainT[idx & H.cmask] = (u64)link | ((u64)link2 << 32);
+      H.oldLink[idx & 127u] = idx > H.chainSize ? H.chainT[idx & H.cmask] : make_uint4(0, 0, 0, 0);
+      H.chainT[idx & H.cmask] = make_uint4(link, l2, l3, l4);
       if (head) H.hashT[h] = idx;
     }
     H.insEnd = min(endIdx, H.insEnd + 64u);
@@ -1270,51 +1275,66 @@ __device__ void hcw_search_window(HCW& H, const u8* src, u32 w, u32 ilimit, u32 
   if (p <= lastPos) {
     const u32 curr = p + 1, minChain = curr > H.chainSize ? curr - H.chainSize : 0;
     int attempts = 1 << H.searchLog;
-    const u64 e0 = H.chainT[curr & H.cmask];
-    u32 miA = (u32)e0, miB = (u32)(e0 >> 32);
-    // the lane's own 16 bytes stay in registers; per round trip TWO candidates: their 16 bytes each and the chain slot of the second
-    // (which names the next two) are requested together. (The reference's "byte at ml first" is only a shortcut: a candidate that
-    // differs there cannot be longer than ml.) The second candidate is touched only if the reference would reach it: the first one
-    // lies above minChain (so the link that named the second is intact) and an attempt is left.
+    uint4 e = H.chainT[curr & H.cmask];
+    // the lane's own 16 bytes stay in registers; per round trip up to FOUR candidates: their 16 bytes each (one load per candidate)
+    // and the chain slot of the fourth (which names the next four) are requested together. (The reference's "byte at ml first" is only
+    // a shortcut: a candidate that differs there cannot be longer than ml.) A candidate is touched only if the reference would reach it:
+    // the one before it lies above minChain (so the link that named it is intact), an attempt is left, and it exists.
     // (Measured and dropped: two positions per lane in one loop, window of 128 — 101 VGPRs, 4 waves per SIMD, 1.5 instead of 2.8 GiB/s.)
     const bool wide = p + 16 <= be;
-    // (16 bytes as ONE load each: a candidate is one request to the address unit and one tag lookup, not two)
     const uint4 ownQ = wide ? ld128(src + p) : make_uint4(0, 0, 0, 0);
     const u64 own0 = (u64)ownQ.x | ((u64)ownQ.y << 32), own1 = (u64)ownQ.z | ((u64)ownQ.w << 32);
-    auto measure = [&](u32 m, u64 c0, u64 c1) -> u32 {
+    auto measure = [&](u32 m, const uint4& c) -> u32 {
       if (wide) {
-        const u64 d0 = c0 ^ own0, d1 = c1 ^ own1;
+        const u64 d0 = ((u64)c.x | ((u64)c.y << 32)) ^ own0, d1 = ((u64)c.z | ((u64)c.w << 32)) ^ own1;
         if (d0) return (u32)__builtin_ctzll(d0) >> 3;
         if (d1) return 8 + ((u32)__builtin_ctzll(d1) >> 3);
         return 16 + count_eq(src, p + 16, m + 16, be);
       }
       return src[m + ml] == src[p + ml] ? count_eq(src, p, m, be) : 0u;
     };
-    while (miA >= 1 && attempts > 0) {
-      const bool two = miA > minChain && attempts > 1 && miB >= 1;
-      const u32 mA = miA - 1, mB = two ? miB - 1 : mA;
-      u64 a0 = 0, a1 = 0, b0 = 0, b1 = 0, eB = 0;
-      if (wide) { const uint4 q = ld128(src + mA); a0 = (u64)q.x | ((u64)q.y << 32); a1 = (u64)q.z | ((u64)q.w << 32); }
-      if (two) {
-        if (wide) { const uint4 q = ld128(src + mB); b0 = (u64)q.x | ((u64)q.y << 32); b1 = (u64)q.z | ((u64)q.w << 32); }
-        const u32 over = miB + H.chainSize;                               // the index that shares miB's chain slot
+    while (e.x >= 1 && attempts > 0) {
+      const bool t2 = e.x > minChain && attempts > 1 && e.y >= 1;
+      const bool t3 = t2 && e.y > minChain && attempts > 2 && e.z >= 1;
+      const bool t4 = t3 && e.z > minChain && attempts > 3 && e.w >= 1;
+      const uint4 z = make_uint4(0, 0, 0, 0);
+      uint4 qa = z, qb = z, qc = z, qd = z, en = z;
+      if (wide) {
+        qa = ld128(src + e.x - 1);
+        if (t2) qb = ld128(src + e.y - 1);
+        if (t3) qc = ld128(src + e.z - 1);
+        if (t4) qd = ld128(src + e.w - 1);
+      }
+      if (t4) {
+        const u32 over = e.w + H.chainSize;                               // the index that shares e.w's chain slot
         // (two loads of two kinds, not one load through a selected pointer: that would be a flat load in the search loop)
-        if (over > curr && over < H.insEnd) eB = lds_read64(&H.oldLink[over & 127u]);
-        else eB = H.chainT[miB & H.cmask];
+        if (over > curr && over < H.insEnd) { const u64 lo = lds_read64((const u64*)&H.oldLink[over & 127u]), hi = lds_read64((const u64*)&H.oldLink[over & 127u] + 1);
+                                              en = make_uint4((u32)lo, (u32)(lo >> 32), (u32)hi, (u32)(hi >> 32)); }
+        else en = H.chainT[e.w & H.cmask];
       }
 #ifdef ZRA_MF_PROFILE
       steps_++;
 #endif
-      u32 cur = measure(mA, a0, a1);
-      if (cur > ml) { ml = cur; offCode = curr - miA + 2; if (p + cur == be) break; }
-      if (miA <= minChain) break;
+      u32 cur = measure(e.x - 1, qa);
+      if (cur > ml) { ml = cur; offCode = curr - e.x + 2; if (p + cur == be) break; }
+      if (e.x <= minChain) break;
       attempts--;
-      if (!two) break;                                   // (no second candidate, or no attempt left for it)
-      cur = measure(mB, b0, b1);
-      if (cur > ml) { ml = cur; offCode = curr - miB + 2; if (p + cur == be) break; }
-      if (miB <= minChain) break;
+      if (!t2) break;                                    // (no further candidate, or no attempt left for it)
+      cur = measure(e.y - 1, qb);
+      if (cur > ml) { ml = cur; offCode = curr - e.y + 2; if (p + cur == be) break; }
+      if (e.y <= minChain) break;
       attempts--;
-      miA = (u32)eB; miB = (u32)(eB >> 32);
+      if (!t3) break;
+      cur = measure(e.z - 1, qc);
+      if (cur > ml) { ml = cur; offCode = curr - e.z + 2; if (p + cur == be) break; }
+      if (e.z <= minChain) break;
+      attempts--;
+      if (!t4) break;
+      cur = measure(e.w - 1, qd);
+      if (cur > ml) { ml = cur; offCode = curr - e.w + 2; if (p + cur == be) break; }
+      if (e.w <= minChain) break;
+      attempts--;
+      e = en;
     }
   }
   HPROF(1)
@@ -1433,7 +1453,8 @@ struct MfFrame {
   u32 fsize, bs, be;
 };
 // returns false when this workgroup has nothing to parse (block beyond the frame, or a block too small to compress)
-__device__ __forceinline__ bool mf_frame_setup(const ZraEncArgs& a, u32 block, int lane, MfFrame& F, u32 f, u32 tableSlot) {
+// hcwOnly: the caller is the wave-cooperative hash-chain finder — its chain slots need no clearing (below)
+__device__ __forceinline__ bool mf_frame_setup(const ZraEncArgs& a, u32 block, int lane, MfFrame& F, u32 f, u32 tableSlot, bool hcwOnly = false) {
   const u64 fstart = (u64)(a.firstFrame + f) * a.frameSize;
   const u64 remaining = a.inSize - fstart;
   F.fsize = (u32)(remaining < a.frameSize ? remaining : a.frameSize);
@@ -1450,8 +1471,13 @@ __device__ __forceinline__ bool mf_frame_setup(const ZraEncArgs& a, u32 block, i
   F.seqs = a.seqs + (size_t)f * a.seqStride;
   if (block == 0) {
     // fresh frame: zeroed tables, repcodes {1,4,8}, nextToUpdate 1 (A.4.8); 16-byte coalesced clears by the whole wave
-    size_t words = ((size_t)1 << F.P->hashLog) + ((size_t)1 << F.P->chainLog);
-    if (F.P->strategy >= 3 && F.P->strategy <= 5) words += (size_t)1 << F.P->chainLog;   // two links per chain slot (HCW)
+    // The wave-cooperative hash-chain finder (four links per chain slot: 16 bytes per position of the window, 4 MiB per 256 KiB frame
+    // at level 9) clears the hash table only: a chain slot is written when its index is inserted and read only for inserted indices —
+    // the slot of the position being searched, of a candidate above the chain's lower bound (the other candidates end the search before
+    // their links are followed), of the bucket's head at insertion. What an untouched slot holds is copied around at most (the ring of
+    // overwritten slots), never looked at. Everybody else clears hash + chain (+ what the optimal parsers keep behind them).
+    size_t words = (size_t)1 << F.P->hashLog;
+    if (!hcwOnly) words += (size_t)1 << F.P->chainLog;
     if (F.P->strategy >= 7)           // optimal parsers: the 3-byte hash table and the statistics of the price model behind the tree
       words += (F.P->minMatch == 3 ? (size_t)1 << min(17u, F.P->windowLog) : 0) + 512;
     uint4* t4 = (uint4*)F.hashT;
@@ -1721,7 +1747,7 @@ zra_mf_hc_kernel(ZraEncArgs a, u32 block, u32 only, u32 onlySlot) {
     if (Pf.strategy < 3 || Pf.strategy > 5) return;
   }
   MfFrame F;
-  if (!mf_frame_setup(a, block, lane, F, f, all ? f : onlySlot)) return;
+  if (!mf_frame_setup(a, block, lane, F, f, all ? f : onlySlot, true)) return;
   const ZraEncParams& P = *F.P;
   ZraEncFrameState* st = F.st; ZraEncBlockOut* bo = F.bo;
   const u32 bs = F.bs, be = F.be;
@@ -1733,12 +1759,12 @@ zra_mf_hc_kernel(ZraEncArgs a, u32 block, u32 only, u32 onlySlot) {
     const u32 cur = bs + 1;
     if (cur > ntu + 384) { const u32 d = cur - ntu - 384; ntu = cur - (d < 192 ? d : 192); }
   }
-  __shared__ u64 hcOld[128];
+  __shared__ uint4 hcOld[128];
   __shared__ u8 hcDup[1024];
-  HCW H; H.oldLink = hcOld; H.dup = hcDup; H.hashT = F.hashT; H.chainT = (u64*)F.chainT; H.hlog = P.hashLog; H.mls = P.minMatch < 4 ? 4 : P.minMatch > 6 ? 6 : P.minMatch;
+  HCW H; H.oldLink = hcOld; H.dup = hcDup; H.hashT = F.hashT; H.chainT = (uint4*)F.chainT; H.hlog = P.hashLog; H.mls = P.minMatch < 4 ? 4 : P.minMatch > 6 ? 6 : P.minMatch;
   H.chainSize = 1u << P.chainLog; H.cmask = H.chainSize - 1; H.searchLog = P.searchLog;
   H.insEnd = st->insEnd; H.ntuRef = ntu;
-  for (u32 i = (u32)lane; i < 128; i += 64) hcOld[i] = st->ring[i];
+  for (u32 i = (u32)lane; i < 128; i += 64) hcOld[i] = *(const uint4*)st->ring[i];
   hcw_sync();
   if (ntu > ntu0) {
     // indices [ntu0, ntu) are never inserted by the reference: those inserted ahead of the parse come out again, the rest is skipped
@@ -1748,7 +1774,7 @@ zra_mf_hc_kernel(ZraEncArgs a, u32 block, u32 only, u32 onlySlot) {
   u32 nSeq = 0;
   const u32 lastLL = mf_lazy_wave(H, F.src, bs, be, rep, F.seqs, &nSeq, (int)P.strategy - 3, lane);
   hcw_sync();
-  for (u32 i = (u32)lane; i < 128; i += 64) st->ring[i] = hcOld[i];
+  for (u32 i = (u32)lane; i < 128; i += 64) *(uint4*)st->ring[i] = hcOld[i];
   if (lane == 0) {
     st->nextToUpdate = H.ntuRef; st->insEnd = H.insEnd;
     bo->skip = 0; bo->nbSeq = nSeq; bo->lastLL = lastLL;

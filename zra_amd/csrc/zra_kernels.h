@@ -135,8 +135,8 @@ struct ZraEncFrameState {
   // the next block starts with the reference's "limited update after a very long match", the indices inserted ahead are taken out
   // of the tables again, newest first, with these values.
   uint32_t insEnd;
-  uint32_t pad0_;
-  uint64_t ring[128];              // (both links of the slot: zra_encode_mf.hip HCW)
+  uint32_t pad0_[3];
+  uint32_t ring[128][4];           // (the four links of the slot: zra_encode_mf.hip HCW; 16-byte aligned)
   uint32_t idxShift;               // optimal parsers: table index = position + 1 + idxShift (btultra2 moves the window base after its statistics pass)
   uint32_t outPos;                 // bytes of the frame already written to its slot
   uint32_t hufRepeat;              // 0 none, 1 check, 2 valid
