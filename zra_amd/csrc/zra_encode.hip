@@ -320,7 +320,14 @@ Status Engine::compress_impl_body(const uint8_t* dIn, size_t inSize, uint8_t* dB
           // the hash-chain kernel and the fast kernel hold their own finder only (lean register budgets); a short last frame with any
           // other strategy goes to the generic kernel (or the dfast kernel) in a second, single-frame launch
           const bool lean = pwEnv <= 0 && (hashChain || full.strategy == 1);
-          if (hashChain && pwEnv <= 0) hipLaunchKernelGGL(zra_mf_hc_kernel, dim3(nb), dim3(64), dynLds, stream_, a, blk, 0xFFFFFFFFu, 0u);
+          // resident waves of the hash-chain finder: 32 per CU (all the hardware holds) — except for the deep searches over big tables
+          // (search log >= 5 with >= 4 MiB of tables per frame: levels 9-10 at 256 KiB frames), which run faster with 20, five per SIMD
+          // (level 9 @ 256 KiB: 3.53 GiB/s at 32, 3.48 at 22, 3.74 at 20, 3.70 at 16, 3.21 at 14; level 10: 2.11 -> 2.29 at 16; level 6 @
+          // 256 KiB with the same tables and search log 3: 7.16 -> 6.55 at 16; level 9 @ 64 KiB: 5.20 -> 4.53 at 16 — profiles/
+          // r04_experiments.md §9). Padding each wave's LDS (3 KiB of its own) to 8 KiB sets it.
+          uint32_t hcPad = (uint32_t)dynLds;
+          if (!std::getenv("ZRA_MF_LDS") && hashChain && full.searchLog >= 5 && tableWords * 4 >= (4ull << 20)) hcPad = 5120;
+          if (hashChain && pwEnv <= 0) hipLaunchKernelGGL(zra_mf_hc_kernel, dim3(nb), dim3(64), hcPad, stream_, a, blk, 0xFFFFFFFFu, 0u);
           else if (lean) hipLaunchKernelGGL(zra_mf_fast_kernel, dim3((nb + perWave - 1) / perWave), dim3(64), dynLds, stream_, a, blk, perWave);
           else hipLaunchKernelGGL(mfGeneric, dim3((nb + perWave - 1) / perWave), dim3(64), dynLds, stream_, a, blk, 0xFFFFFFFFu, 0u, perWave);
           if (oddTail) hipLaunchKernelGGL(ZRA_DFAST_KERNEL, dim3(1), dim3(64), filterBytes, stream_, a, blk, (uint32_t)(nb - 1), (uint32_t)(nb - 1));
