@@ -10,6 +10,9 @@ iters = int(sys.argv[4]) if len(sys.argv) > 4 else 3
 eng = Z.Engine(0); dev = torch.device("cuda", 0)
 N = int(gib * (1 << 30))
 c64 = bench.synth_corpus(64 << 20, 1)
+if os.environ.get("LOGLIKE"):                         # C4's data: the log-like generator of tests/corpus.py
+    import corpus as C
+    c64 = np.frombuffer(C.gen_loglike(32 << 20, seed=4), dtype=np.uint8)
 t = torch.from_numpy(np.resize(c64, N)).to(dev)
 out = torch.empty(Z.GetOutputBufferSize(N, fs) + 64, dtype=torch.uint8, device=dev)
 import hashlib
