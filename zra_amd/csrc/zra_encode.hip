@@ -224,7 +224,9 @@ Status Engine::compress_impl_body(const uint8_t* dIn, size_t inSize, uint8_t* dB
   else if (full.strategy != 2) {
     // measured at level 9 @ 256 KiB (4 GiB input): 8 GiB -> 0.33 GiB/s, 16 -> 0.58, 32 -> 0.71, 64 -> 0.93 (all frames resident)
     size_t freeB = 0, totalB = 0;
-    if (hipMemGetInfo(&freeB, &totalB) == hipSuccess) budget = std::min<uint64_t>(64ull << 30, std::max<uint64_t>(budget, (uint64_t)(freeB * 0.25)));
+    // (what this engine's contexts hold already counts as free: a second call must not get smaller batches than the first)
+    uint64_t mine = 0; for (auto& x : encCtx_) mine += x.tables.cap + x.seqs.cap + x.lits.cap + x.slots.cap;
+    if (hipMemGetInfo(&freeB, &totalB) == hipSuccess) budget = std::min<uint64_t>(64ull << 30, std::max<uint64_t>(budget, (uint64_t)(((uint64_t)freeB + mine) * 0.25)));
   }
   uint32_t B = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>({nFramesTotal, budget / perFrame, full.strategy == 2 ? 16384ull : 65536ull}));
   if (B > 1024) B &= ~1023u;
@@ -254,8 +256,15 @@ Status Engine::compress_impl_body(const uint8_t* dIn, size_t inSize, uint8_t* dB
   };
   std::vector<std::pair<hipEvent_t, hipEvent_t>> mfSpans, entSpans;
   hipEvent_t entDone[2] = {nullptr, nullptr};
+  // the second context's match-finder stream (ZRA_MF_ONE_STREAM: bring-up knob, everything on stream A as before)
+  hipStream_t mfStream2 = nullptr;
+  if (nCtx == 2 && !std::getenv("ZRA_MF_ONE_STREAM")) {
+    if (!pipeStreams_[0] && hipStreamCreateWithFlags(&pipeStreams_[0], hipStreamNonBlocking) != hipSuccess) { pipeStreams_[0] = nullptr; (void)hipGetLastError(); }
+    mfStream2 = pipeStreams_[0];
+  }
   // make stream B's first use wait for whatever the caller queued on stream A (inputs produced on the engine stream)
-  { hipEvent_t e0 = ev(); if (!e0) return zerr(1); HIPCHK(hipEventRecord(e0, stream_)); HIPCHK(hipStreamWaitEvent(stream2_, e0, 0)); }
+  { hipEvent_t e0 = ev(); if (!e0) return zerr(1); HIPCHK(hipEventRecord(e0, stream_)); HIPCHK(hipStreamWaitEvent(stream2_, e0, 0));
+    if (mfStream2) HIPCHK(hipStreamWaitEvent(mfStream2, e0, 0)); }
 
   uint64_t batchIdx = 0;
   for (uint64_t f0 = 0; f0 < nFramesTotal; f0 += B, batchIdx++) {
@@ -276,16 +285,21 @@ Status Engine::compress_impl_body(const uint8_t* dIn, size_t inSize, uint8_t* dB
     const uint64_t firstFrameSize = std::min<uint64_t>(frameSize, inSize - f0 * frameSize);
     const ZraEncParams& P0 = firstFrameSize == frameSize ? full : tail;
     const uint32_t rounds = (uint32_t)((firstFrameSize + P0.blockSize - 1) / P0.blockSize);
+    // Match-finder launches of the two contexts go to two streams: a batch's launches wait for each other through the entropy stage
+    // (block b + 1 needs block b's confirmed state) and every launch ends in a tail of a few slow frames — with one stream the next
+    // batch's first launch sat behind all of that; on its own stream it fills the CUs the other context leaves idle (round 4: 8 GiB at
+    // level 9 / 256 KiB frames, profiles/r04_experiments.md §10).
+    hipStream_t sA = (c == 1 && mfStream2) ? mfStream2 : stream_;
     // the context's scratch is free once the entropy stage + gather of its previous batch are done
-    if (entDone[c]) HIPCHK(hipStreamWaitEvent(stream_, entDone[c], 0));
+    if (entDone[c]) HIPCHK(hipStreamWaitEvent(sA, entDone[c], 0));
     // test knob: the table scratch filled with a pattern before a batch — whatever a finder does not clear itself (the wave-cooperative
     // hash-chain finder leaves its chain slots alone) must not matter (tests/test_gpu_parity.py::test_opt_in_kernels_are_bit_exact_too)
     { static const bool poison = std::getenv("ZRA_ENC_POISON") != nullptr;
-      if (poison) HIPCHK(hipMemsetAsync(x.tables.p, 0xA5, (size_t)nb * tableWords * 4, stream_)); }
+      if (poison) HIPCHK(hipMemsetAsync(x.tables.p, 0xA5, (size_t)nb * tableWords * 4, sA)); }
     for (uint32_t blk = 0; blk < rounds; blk++) {
       hipEvent_t m0 = ev(), m1 = ev(), e1 = ev();
       if (!m0 || !m1 || !e1) return zerr(1);
-      HIPCHK(hipEventRecord(m0, stream_));
+      HIPCHK(hipEventRecord(m0, sA));
       {
         // occupancy experiment knob (bring-up): extra dynamic LDS per workgroup caps the frames in flight per CU
         static const int dynLds = std::getenv("ZRA_MF_LDS") ? std::atoi(std::getenv("ZRA_MF_LDS")) : 0;
@@ -304,11 +318,11 @@ Status Engine::compress_impl_body(const uint8_t* dIn, size_t inSize, uint8_t* dB
         const bool oddTail = !serialAll && hasTail && (tail.strategy == 2) != (full.strategy == 2);
         // a lone short last frame that is not dfast: the wave-cooperative hash-chain kernel for greedy / lazy / lazy2, else the generic one
         auto launchLone = [&](uint32_t only, uint32_t slot) {
-          if (tail.strategy >= 3 && tail.strategy <= 5) hipLaunchKernelGGL(zra_mf_hc_kernel, dim3(1), dim3(64), 0, stream_, a, blk, only, slot);
-          else hipLaunchKernelGGL(mfGeneric, dim3(1), dim3(64), 0, stream_, a, blk, only, slot, 1u);
+          if (tail.strategy >= 3 && tail.strategy <= 5) hipLaunchKernelGGL(zra_mf_hc_kernel, dim3(1), dim3(64), 0, sA, a, blk, only, slot);
+          else hipLaunchKernelGGL(mfGeneric, dim3(1), dim3(64), 0, sA, a, blk, only, slot, 1u);
         };
         if (full.strategy == 2 && !serialAll) {
-          hipLaunchKernelGGL(ZRA_DFAST_KERNEL, dim3(nb), dim3(64), filterBytes + dynLds, stream_, a, blk, 0xFFFFFFFFu, 0u);
+          hipLaunchKernelGGL(ZRA_DFAST_KERNEL, dim3(nb), dim3(64), filterBytes + dynLds, sA, a, blk, 0xFFFFFFFFu, 0u);
           if (oddTail) launchLone((uint32_t)(nb - 1), (uint32_t)(nb - 1));
         } else {
           // frames per wave: as many as it takes to have every frame of the batch resident at once (32 waves per CU)
@@ -327,15 +341,15 @@ Status Engine::compress_impl_body(const uint8_t* dIn, size_t inSize, uint8_t* dB
           // r04_experiments.md §9). Padding each wave's LDS (3 KiB of its own) to 8 KiB sets it.
           uint32_t hcPad = (uint32_t)dynLds;
           if (!std::getenv("ZRA_MF_LDS") && hashChain && full.searchLog >= 5 && tableWords * 4 >= (4ull << 20)) hcPad = 5120;
-          if (hashChain && pwEnv <= 0) hipLaunchKernelGGL(zra_mf_hc_kernel, dim3(nb), dim3(64), hcPad, stream_, a, blk, 0xFFFFFFFFu, 0u);
-          else if (lean) hipLaunchKernelGGL(zra_mf_fast_kernel, dim3((nb + perWave - 1) / perWave), dim3(64), dynLds, stream_, a, blk, perWave);
-          else hipLaunchKernelGGL(mfGeneric, dim3((nb + perWave - 1) / perWave), dim3(64), dynLds, stream_, a, blk, 0xFFFFFFFFu, 0u, perWave);
-          if (oddTail) hipLaunchKernelGGL(ZRA_DFAST_KERNEL, dim3(1), dim3(64), filterBytes, stream_, a, blk, (uint32_t)(nb - 1), (uint32_t)(nb - 1));
+          if (hashChain && pwEnv <= 0) hipLaunchKernelGGL(zra_mf_hc_kernel, dim3(nb), dim3(64), hcPad, sA, a, blk, 0xFFFFFFFFu, 0u);
+          else if (lean) hipLaunchKernelGGL(zra_mf_fast_kernel, dim3((nb + perWave - 1) / perWave), dim3(64), dynLds, sA, a, blk, perWave);
+          else hipLaunchKernelGGL(mfGeneric, dim3((nb + perWave - 1) / perWave), dim3(64), dynLds, sA, a, blk, 0xFFFFFFFFu, 0u, perWave);
+          if (oddTail) hipLaunchKernelGGL(ZRA_DFAST_KERNEL, dim3(1), dim3(64), filterBytes, sA, a, blk, (uint32_t)(nb - 1), (uint32_t)(nb - 1));
           else if (lean && hasTail && (hashChain ? (tail.strategy < 3 || tail.strategy > 5) : tail.strategy != 1))
             launchLone((uint32_t)(nb - 1), (uint32_t)(nb - 1));
         }
       }
-      HIPCHK(hipEventRecord(m1, stream_));
+      HIPCHK(hipEventRecord(m1, sA));
       mfSpans.push_back({m0, m1});
       HIPCHK(hipStreamWaitEvent(stream2_, m1, 0));
       hipEvent_t e0 = ev(); if (!e0) return zerr(1);
@@ -343,7 +357,7 @@ Status Engine::compress_impl_body(const uint8_t* dIn, size_t inSize, uint8_t* dB
       hipLaunchKernelGGL(zra_entropy_kernel, dim3(nb), dim3(256), 0, stream2_, a, blk);
       HIPCHK(hipEventRecord(e1, stream2_));
       entSpans.push_back({e0, e1});
-      if (blk + 1 < rounds) HIPCHK(hipStreamWaitEvent(stream_, e1, 0));   // next block's match finder needs the confirmed state
+      if (blk + 1 < rounds) HIPCHK(hipStreamWaitEvent(sA, e1, 0));   // next block's match finder needs the confirmed state
     }
     hipLaunchKernelGGL(zra_scan_sizes_kernel, dim3(1), dim3(64), 0, stream2_, a.sizes, nb, dOffsets, dRunning);
     hipLaunchKernelGGL(zra_gather_frames_kernel, dim3(nb), dim3(256), 0, stream2_, a.slots, slotStride, a.sizes, dOffsets, dBody,
@@ -352,12 +366,13 @@ Status Engine::compress_impl_body(const uint8_t* dIn, size_t inSize, uint8_t* dB
     HIPCHK(hipEventRecord(done, stream2_));
     entDone[c] = done;
     { static const bool serial = std::getenv("ZRA_ENC_SERIAL") != nullptr;   // bring-up knob: no mf/entropy overlap (per-kernel timing in isolation)
-      if (serial) HIPCHK(hipStreamWaitEvent(stream_, done, 0)); }
+      if (serial) { HIPCHK(hipStreamWaitEvent(stream_, done, 0)); if (mfStream2) HIPCHK(hipStreamWaitEvent(mfStream2, done, 0)); } }
   }
   uint64_t total = 0;
   HIPCHK(hipMemcpyAsync(&total, dRunning, 8, hipMemcpyDeviceToHost, stream2_));
   HIPCHK(hipStreamSynchronize(stream2_));
   HIPCHK(hipStreamSynchronize(stream_));
+  if (mfStream2) HIPCHK(hipStreamSynchronize(mfStream2));
   HIPCHK(hipGetLastError());
   double kernelMs = 0;
   kstats_[0] = kstats_[1] = kstats_[2] = kstats_[3] = 0;
