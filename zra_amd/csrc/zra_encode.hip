@@ -218,7 +218,7 @@ Status Engine::compress_impl_body(const uint8_t* dIn, size_t inSize, uint8_t* dB
   // Two scratch contexts: the match finder of batch k+1 (stream A) overlaps the entropy stage + gather of batch k (stream B);
   // both kernels are latency-bound, so they share the CUs almost for free. 8 GiB of scratch per context.
   // scratch per context: enough for one frame per resident wave (32 per CU) of the one-lane finders, whose throughput is frames in
-  // flight / frame latency (level 9 @ 256 KiB needs 3.6 MiB per frame); bring-up knob ZRA_ENC_BUDGET_GIB
+  // flight / frame latency (level 9 @ 256 KiB needs 6 MiB of tables per frame); bring-up knob ZRA_ENC_BUDGET_GIB
   uint64_t budget = 8ull << 30;
   if (const char* e = std::getenv("ZRA_ENC_BUDGET_GIB")) budget = (uint64_t)std::atoi(e) << 30;
   else if (full.strategy != 2) {

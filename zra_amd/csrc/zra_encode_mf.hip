@@ -6,8 +6,9 @@
 // budget of everything it can call (tests/test_kernel_budgets.py):
 //   zra_mf_dfast_kernel  dfast (levels 3-4): one wave per frame, window-resolve parse (64 positions looked up at once, resolved in
 //                        registers), persistent waves pulling frames from a queue
+//   zra_mf_dfast_ls_kernel  the same parse over a copy of the frame in LDS: calls of a few hundred frames at most (latency mode)
 //   zra_mf_hc_kernel     greedy / lazy / lazy2 (levels 5-10): one wave per frame, a window of 64 positions inserted and searched at
-//                        once (one lane per chain), the parse consumes the answers
+//                        once (one lane per chain, four candidates per round trip), the parse consumes the answers
 //   zra_mf_fast_kernel   fast (levels 1-2, negative levels): lane = frame, up to 8 frames per wave
 //   zra_mf_kernel        btlazy2, frames larger than the level's window (sliding-window rules), single odd tails: lane = frame
 //   zra_mf_opt_kernel    the same plus btopt / btultra / btultra2 (zra_encode_opt.h)
