@@ -131,7 +131,10 @@ ZRA_EXPORT ZraStatus ZraHipCommCompress(ZraHipComm* comm, const void* dLocal, si
                                         uint32_t frameSize, bool checksum, ZraHipShard** shard);
 /** The size exchange and stitch alone (zra.cpp:216-230), for frames that were compressed elsewhere: hLocalSizes = the compressed sizes
  *  of this rank's frames [lo, hi) (nLocal = hi - lo, InputFrameSizeMismatch otherwise). Collective; every rank gets the complete
- *  header + seek table (ZraHipShardGetHeader), the shard holds no body. Works on a communicator created without an engine. */
+ *  header + seek table (ZraHipShardGetHeader), the shard holds no body (ZraHipShardGetBody: NULL, 0 bytes). Works on a communicator
+ *  created without an engine. Engine-less communicators and stitch-only shards must be that on EVERY rank: ZraHipCommCompress /
+ *  GatherArchive / Serve return parameter_unsupported on them after one agreement round, and ranks that hold an engine or a body would
+ *  go on to larger exchanges. More than 2^32 - 2 frames, or hLocalSizes == NULL with nLocal > 0, are rejected on every rank. */
 ZRA_EXPORT ZraStatus ZraHipCommStitchSizes(ZraHipComm* comm, const uint64_t* hLocalSizes, size_t nLocal, uint64_t totalBytes, uint32_t frameSize,
                                            ZraHipShard** shard);
 ZRA_EXPORT void ZraHipShardDestroy(ZraHipShard* shard);
@@ -140,7 +143,7 @@ ZRA_EXPORT size_t ZraHipShardHeaderSize(const ZraHipShard* shard);
 ZRA_EXPORT void ZraHipShardGetHeader(const ZraHipShard* shard, void* hHeader);
 /** Size of the whole archive (header + all ranks' frames). */
 ZRA_EXPORT uint64_t ZraHipShardArchiveSize(const ZraHipShard* shard);
-/** This rank's frames: device pointer, their offset inside the archive's body, their length. */
+/** This rank's frames: device pointer, their offset inside the archive's body, their length (NULL and 0 for a stitch-only shard). */
 ZRA_EXPORT void ZraHipShardGetBody(const ZraHipShard* shard, const void** dBody, uint64_t* bodyBase, uint64_t* bodyBytes);
 /** The archive in one piece in dArchive on rank `root` (other ranks pass NULL / 0): world-1 inbound point-to-point messages in one group. */
 ZRA_EXPORT ZraStatus ZraHipCommGatherArchive(ZraHipComm* comm, const ZraHipShard* shard, int root, void* dArchive, size_t archiveCapacity,
@@ -159,6 +162,12 @@ ZRA_EXPORT void ZraHipGetKernelStats(ZraHipEngine* engine, double* out6);
 /** Decode stages of the LAST decode / random-access call on this engine (HIP events on the engine's stream, summed over its rounds):
  *  out8 = {parse ms, Huffman ms, sequence-chain ms, execute ms, rounds, one-launch small-batch kernel ms, its launches, 0}. */
 ZRA_EXPORT void ZraHipGetDecodeStageStats(ZraHipEngine* engine, double* out8);
+/** Launch telemetry of the LAST persistent level-3/4 compress on this engine, written by every wave of the match-finder launch:
+ *  u64 words [0] shader cycles summed over waves, [1] ticks of the constant 100 MHz clock summed over waves (cycles / ticks x 100 = the
+ *  effective shader MHz of the launch), [2] waves, [3] longest wave (ticks), [4] ~earliest wave start, [5] latest wave end, [6] latest
+ *  wave start, [7] ~earliest wave end, [8..15] waves per XCD, [16..23] frames taken per XCD, [24..31] ticks per XCD, [32 + k] waves on
+ *  compute unit k = xcc << 8 | se << 5 | sh << 4 | cu. Returns the words written (0: the call took another path). */
+ZRA_EXPORT size_t ZraHipGetLaunchTelemetry(ZraHipEngine* engine, uint64_t* out, size_t capWords);
 
 /* ---- opt-in integrity options (default 0: bit- and error-compatible with the reference, quirks included) ---- */
 #define ZRA_HIP_OPT_VERIFY_HEADER_CRC 1u     /* Header constructors check the CRC-32 the reference writes but never reads (zra.cpp:128-133) */

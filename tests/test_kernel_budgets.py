@@ -18,8 +18,8 @@ BUDGET = {
     "zra_lk_parse_kernel": (160, 0),     # link dfast (opt-in): 8 waves per CU by its LDS (16 KiB of bitmaps per frame), registers are not its limit
     "zra_lk_prepass_kernel": (128, 64),  # 1024 threads per workgroup: 4 waves per SIMD (a few spilled scalars live in scratch)
     "zra_mf_hc_kernel": (64, 0),         # one wave per frame, as many waves per CU as the hardware holds
-    "zra_mf_fast_kernel": (64, 232),     # lane = frame; the scratch is the per-lane frame descriptor
-    "zra_mf_kernel": (96, 240),          # generic one-lane finder without the optimal parsers (btlazy2, frames beyond the window, odd tails)
+    "zra_mf_fast_kernel": (64, 240),     # lane = frame; the scratch is the per-lane frame descriptor
+    "zra_mf_kernel": (96, 248),          # generic one-lane finder without the optimal parsers (btlazy2, frames beyond the window, odd tails)
     "zra_mf_opt_kernel": (136, 400),     # ... with them (levels 13-22; its scratch holds the parser's small arrays)
     "zra_dec_chain_kernel": (72, 0),     # lane = frame FSE chains
     "zra_dec_chain_lds_kernel": (80, 0), # the same with its frames' tables in LDS, one workgroup per CU beside it

@@ -282,3 +282,44 @@ def test_eight_rank_stitch_through_the_c_entry_points(world, nframes):
         else:
             assert all(r[:2] == results[0][:2] and r[0] != 0 for r in results), [r[:2] for r in results]
         results = [None] * world
+
+
+def test_stitch_only_shard_has_no_body_and_bad_arguments_are_rejected():
+    """ZraHipCommStitchSizes on a one-rank engine-less communicator (the all-gather of zra_comm.hip: comm_stitch degenerates to a copy):
+    the shard it returns holds the header and NO frames — ZraHipShardGetBody must say so (NULL, 0 bytes) instead of an address built from
+    a null pointer; a NULL size array with nLocal > 0 and a frame count beyond the format's u32 table (zra.cpp:118) are statuses, not
+    exceptions or reads through NULL."""
+    import ctypes
+    import zra_amd as Z
+    L = Z.load()
+    L.ZraHipCommStitchSizes.restype = Z.ZraStatus
+
+    def allgather(user, send, recv, nbytes):
+        ctypes.memmove(recv, send, nbytes)
+        return 0
+
+    def exchange(*a):
+        return 1
+    tr = Z.ZraHipHostTransport(None, Z.ALLGATHER_FN(allgather), Z.EXCHANGE_FN(exchange))
+    h = ctypes.c_void_p()
+    st = L.ZraHipCommCreateHost(ctypes.byref(h), None, ctypes.byref(tr), 0, 1)
+    assert (st.zra, st.zstd) == (0, 0)
+    fs = 4096
+    sizes = np.array([100, 200, 300], dtype=np.uint64)
+    sh = ctypes.c_void_p()
+    st = L.ZraHipCommStitchSizes(h, sizes.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(3), ctypes.c_uint64(2 * fs + 10), ctypes.c_uint32(fs), ctypes.byref(sh))
+    assert (st.zra, st.zstd) == (0, 0)
+    body, base, nbytes = ctypes.c_void_p(1), ctypes.c_uint64(7), ctypes.c_uint64(7)
+    L.ZraHipShardGetBody(sh, ctypes.byref(body), ctypes.byref(base), ctypes.byref(nbytes))
+    assert body.value is None and nbytes.value == 0 and base.value == 0
+    L.ZraHipShardArchiveSize.restype = ctypes.c_uint64
+    assert L.ZraHipShardArchiveSize(sh) == 38 + 5 * 4 + 600
+    L.ZraHipShardDestroy(sh)
+    # NULL sizes with a share to describe
+    sh = ctypes.c_void_p()
+    st = L.ZraHipCommStitchSizes(h, None, ctypes.c_size_t(3), ctypes.c_uint64(2 * fs + 10), ctypes.c_uint32(fs), ctypes.byref(sh))
+    assert st.zra != 0 and not sh.value
+    # more frames than the table's u32 count can hold: a status (the vectors sized from it would be tens of GiB)
+    st = L.ZraHipCommStitchSizes(h, sizes.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(3), ctypes.c_uint64((1 << 40) - 1), ctypes.c_uint32(1), ctypes.byref(sh))
+    assert st.zra != 0 and not sh.value
+    L.ZraHipCommDestroy(h)

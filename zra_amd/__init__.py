@@ -112,6 +112,7 @@ def load():
         "ZraHipLastKernelMs": (ctypes.c_double, [vp]),
         "ZraHipGetKernelStats": (None, [vp, ctypes.POINTER(ctypes.c_double)]),
         "ZraHipGetDecodeStageStats": (None, [vp, ctypes.POINTER(ctypes.c_double)]),
+        "ZraHipGetLaunchTelemetry": (sz, [vp, u64p, sz]),
         "ZraHipCompressBuffer": (S, [vp, vp, sz, vp, szp, ctypes.c_int8, u32, ctypes.c_bool]),
         "ZraHipDecompressBuffer": (S, [vp, vp, sz, vp, sz]),
         "ZraHipDecompressRABatch": (S, [vp, vp, sz, vp, u64p, u64p, u64p, sz]),
@@ -151,7 +152,7 @@ C_ABI_SYMBOLS = [
     "ZraDecompressWithDecompressor", "ZraCreateFullDecompressor", "ZraDeleteFullDecompressor", "ZraGetHeaderWithFullDecompressor",
     "ZraDecompressWithFullDecompressor",
 ]
-HIP_ABI_SYMBOLS = ["ZraHipDeviceCount", "ZraHipCreateEngine", "ZraHipDestroyEngine", "ZraHipSynchronize", "ZraHipGetStream", "ZraHipWaitStream", "ZraHipReleaseScratch", "ZraHipLastKernelMs", "ZraHipGetKernelStats", "ZraHipGetDecodeStageStats",
+HIP_ABI_SYMBOLS = ["ZraHipDeviceCount", "ZraHipCreateEngine", "ZraHipDestroyEngine", "ZraHipSynchronize", "ZraHipGetStream", "ZraHipWaitStream", "ZraHipReleaseScratch", "ZraHipLastKernelMs", "ZraHipGetKernelStats", "ZraHipGetDecodeStageStats", "ZraHipGetLaunchTelemetry",
                    "ZraHipCompressBuffer", "ZraHipDecompressBuffer", "ZraHipDecompressRABatch", "ZraHipCompressFrames", "ZraHipStitchHeader", "ZraHipDebugReadSeqs", "ZraHipSetOptions", "ZraHipGetOptions",
                    "ZraHipShardRange", "ZraHipOwnerOfFrame", "ZraHipRouteQueries", "ZraHipCommGetUniqueId", "ZraHipCommCreateRccl", "ZraHipCommCreateHost", "ZraHipCommDestroy",
                    "ZraHipCommCompress", "ZraHipCommStitchSizes", "ZraHipShardDestroy", "ZraHipShardHeaderSize", "ZraHipShardGetHeader", "ZraHipShardArchiveSize", "ZraHipShardGetBody",
@@ -246,6 +247,29 @@ class Engine:
         a = (ctypes.c_double * 6)()
         self.L.ZraHipGetKernelStats(self.h, a)
         return dict(mf_ms=a[0], mf_launches=int(a[1]), ent_ms=a[2], ent_launches=int(a[3]), dec_ms=a[4], dec_launches=int(a[5]))
+
+    def launch_telemetry(self):
+        """What the waves of the last persistent level-3/4 match-finder launch recorded (zra_hip.h: ZraHipGetLaunchTelemetry), reduced:
+        effective shader MHz, waves per compute unit (min / max / histogram), waves, frames and frames per wave-second per XCD, the stagger
+        of the wave starts and ends. None when the last call took another path."""
+        cap = 32 + 2048
+        a = (ctypes.c_uint64 * cap)()
+        n = self.L.ZraHipGetLaunchTelemetry(self.h, a, cap)
+        if n < 32 or a[2] == 0:
+            return None
+        M = (1 << 64) - 1
+        cu = [int(v) for v in a[32:n] if v]
+        hist = {}
+        for v in cu:
+            hist[v] = hist.get(v, 0) + 1
+        first_start, last_end, last_start, first_end = M - a[4], a[5], a[6], M - a[7]
+        return dict(shader_mhz=round(a[0] / max(1, a[1]) * 100.0, 1), waves=int(a[2]), cus=len(cu),
+                    waves_per_cu_min=min(cu) if cu else 0, waves_per_cu_max=max(cu) if cu else 0,
+                    waves_per_cu_hist={str(k): hist[k] for k in sorted(hist)},
+                    waves_per_xcd=[int(v) for v in a[8:16]], frames_per_xcd=[int(v) for v in a[16:24]],
+                    frames_per_wave_ms_per_xcd=[round(a[16 + i] / (a[24 + i] / 1e5), 4) if a[24 + i] else 0.0 for i in range(8)],
+                    span_ms=round((last_end - first_start) / 1e5, 3), start_stagger_ms=round((last_start - first_start) / 1e5, 3),
+                    end_stagger_ms=round((last_end - first_end) / 1e5, 3), longest_wave_ms=round(a[3] / 1e5, 3))
 
     def decode_stage_stats(self):
         """{parse_ms, huf_ms, chain_ms, exec_ms, rounds, small_ms, small_launches} of the last decode / random-access call."""

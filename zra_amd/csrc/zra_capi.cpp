@@ -699,6 +699,7 @@ void ZraHipSetOptions(uint32_t mask) { g_options.store(mask); }
 uint32_t ZraHipGetOptions(void) { return g_options.load(); }
 void ZraHipGetKernelStats(ZraHipEngine* engine, double* out6) { engine->e->kernel_stats(out6); }
 void ZraHipGetDecodeStageStats(ZraHipEngine* engine, double* out8) { engine->e->decode_stage_stats(out8); }
+size_t ZraHipGetLaunchTelemetry(ZraHipEngine* engine, uint64_t* out, size_t capWords) { return engine->e->launch_telemetry(out, capWords); }
 uint32_t ZraHipDebugReadSeqs(ZraHipEngine* engine, uint32_t frame, uint64_t* out, uint32_t cap, uint32_t* meta3) { return engine->e->debug_read_seqs(frame, out, cap, meta3); }
 
 ZraStatus ZraHipCompressBuffer(ZraHipEngine* engine, const void* dIn, size_t inSize, void* dOut, size_t* outSize, int8_t level, uint32_t frameSize, bool checksum) {

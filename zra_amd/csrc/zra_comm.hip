@@ -15,6 +15,7 @@
 #include <rccl/rccl.h>
 #include <algorithm>
 #include <cstring>
+#include <exception>
 #include <vector>
 
 using namespace zra_dev;
@@ -325,16 +326,27 @@ ZraStatus ZraHipCommStitchSizes(ZraHipComm* c, const uint64_t* hLocalSizes, size
   *shardOut = nullptr;
   if (!frameSize) return c->agree(zra_eng::zerr(42));
   const uint64_t F = (totalBytes + frameSize - 1) / frameSize;
+  // the format's table holds a u32 count of entries (frames + 1, zra.cpp:118); beyond it the header cannot be written, and the vectors
+  // below would be sized from a number nobody checked
+  if (F + 1 > 0xFFFFFFFFull) return c->agree(zra_eng::zerr(42));
   uint64_t lo, hi; ZraHipShardRange(F, c->rank, c->world, &lo, &hi);
-  ZraHipShard* sh = new ZraHipShard();
-  sh->device = c->eng ? c->eng->device() : 0; sh->nFrames = F; sh->lo = lo; sh->hi = hi; sh->total = totalBytes; sh->frameSize = frameSize;
+  ZraHipShard* sh = nullptr;
   Status st = zra_eng::ok();
   std::vector<uint64_t> mySizes;
-  if (nLocal != (size_t)(hi - lo)) st = Status{zra_eng::kFrameSizeMismatch, 0};
-  else mySizes.assign(hLocalSizes, hLocalSizes + nLocal);
-  const size_t headerSize = zra_fmt::kFixedSize + (size_t)(F + 1) * zra_fmt::kEntrySize;
-  ZraStatus zs = comm_stitch(c, sh, st, mySizes, F, totalBytes, frameSize, headerSize);
-  if (zs.zra) { delete sh; return zs; }
+  size_t headerSize = 0;
+  try {
+    sh = new ZraHipShard();
+    sh->device = c->eng ? c->eng->device() : 0; sh->nFrames = F; sh->lo = lo; sh->hi = hi; sh->total = totalBytes; sh->frameSize = frameSize;
+    if (nLocal != (size_t)(hi - lo) || (nLocal && !hLocalSizes)) st = Status{zra_eng::kFrameSizeMismatch, 0};
+    else mySizes.assign(hLocalSizes, hLocalSizes + nLocal);
+    headerSize = zra_fmt::kFixedSize + (size_t)(F + 1) * zra_fmt::kEntrySize;
+    ZraStatus zs = comm_stitch(c, sh, st, mySizes, F, totalBytes, frameSize, headerSize);
+    if (zs.zra) { delete sh; return zs; }
+  } catch (const std::exception&) {
+    // (memory for the size table / header: every rank sizes them from the same F, so every rank lands here or none does)
+    delete sh;
+    return c->agree(zra_eng::zerr(64));
+  }
   for (uint64_t v : mySizes) sh->bodyBytes += v;
   *shardOut = sh;
   return mk(Success);
@@ -349,6 +361,8 @@ size_t ZraHipShardHeaderSize(const ZraHipShard* s) { return s->header.size(); }
 void ZraHipShardGetHeader(const ZraHipShard* s, void* hHeader) { std::memcpy(hHeader, s->header.data(), s->header.size()); }
 uint64_t ZraHipShardArchiveSize(const ZraHipShard* s) { return s->header.size() + s->bodyTotal; }
 void ZraHipShardGetBody(const ZraHipShard* s, const void** dBody, uint64_t* bodyBase, uint64_t* bodyBytes) {
+  // a stitch-only shard (ZraHipCommStitchSizes) holds the header and no frames: no address, no bytes to copy
+  if (!s->dev.p) { *dBody = nullptr; *bodyBase = s->bodyBase; *bodyBytes = 0; return; }
   *dBody = s->dev.as<uint8_t>() + s->header.size(); *bodyBase = s->bodyBase; *bodyBytes = s->bodyBytes;
 }
 

@@ -155,6 +155,8 @@ void Engine::drain_after_error() {
   if (encCounters_ && encCountersBytes_) (void)hipMemsetAsync(encCounters_, 0x7F, encCountersBytes_, stream_);
   (void)hipStreamSynchronize(stream_);
   (void)hipStreamSynchronize(stream2_);
+  // the batch path's second match-finder stream (and whatever else runs on the side streams) reads dIn and writes the contexts' scratch too
+  for (auto st : pipeStreams_) if (st) (void)hipStreamSynchronize(st);
   (void)hipGetLastError();
 }
 
@@ -435,7 +437,8 @@ Status Engine::compress_persistent(const uint8_t* dIn, size_t inSize, uint8_t* d
     (void)hipGetLastError();
   }
   // counters: [u64 running offset][u32 queue per super-batch][u32 done per sub-batch]
-  const size_t cntBytes = 16 + 4 * (size_t)(nSuper + nSuper * subsPerSuper + 4);
+  const size_t cntCore = (16 + 4 * (size_t)(nSuper + nSuper * subsPerSuper + 4) + 15) & ~(size_t)15;
+  const size_t cntBytes = cntCore + 8 * (size_t)ZRA_TELE_WORDS;      // + the launch telemetry (ZraEncArgs::mfTele)
   if (!encScan_.reserve(cntBytes)) return zerr(64);
   uint64_t* dRunning = encScan_.as<uint64_t>();
   uint32_t* dQueue = (uint32_t*)(encScan_.as<uint8_t>() + 16);
@@ -448,6 +451,7 @@ Status Engine::compress_persistent(const uint8_t* dIn, size_t inSize, uint8_t* d
   base.full = full; base.tail = tail;
   dbgSeqStride_ = seqStride; dbgB_ = (uint32_t)SBIG;
   base.tableStride = tableWords; base.seqStride = seqStride; base.litStride = litStride; base.slotStride = slotStride;
+  base.mfTele = (uint64_t*)(encScan_.as<uint8_t>() + cntCore);
   // LDS geometry of the bucket filter: 1 bit per 2^shL long-table buckets, 1 bit per 2^shS short-table buckets, and the
   // duplicate-detection slots (1 KiB + 4 KiB + 1 KiB at hashLog 16 / chainLog 15: one bit per 2 long buckets, per 4 short buckets).
   // 18 resident waves per CU x 6 KiB leave LDS and wave slots for two entropy-stage workgroups per CU, which is what lets stream B
@@ -521,7 +525,7 @@ Status Engine::compress_persistent(const uint8_t* dIn, size_t inSize, uint8_t* d
   static const uint32_t ppLdsBytes = std::getenv("ZRA_PP_LDS") ? (uint32_t)std::atoi(std::getenv("ZRA_PP_LDS")) : ZRA_LK_PP_LDS;   // bring-up knob
   static const uint32_t flCus = std::getenv("ZRA_PP_CUS") ? (uint32_t)std::max(1, std::atoi(std::getenv("ZRA_PP_CUS"))) : 32u;
   static const uint64_t flMin = std::getenv("ZRA_PP_MIN") ? (uint64_t)std::max(1, std::atoi(std::getenv("ZRA_PP_MIN"))) : 4096u;
-  bool useFlags = flEnv != 0 && !useLk && !mf_v2() && frameSize <= ZRA_LK_MAX_FRAME && full.strategy == 2 && nFramesTotal >= flMin && (uint32_t)numCUs_ >= 2 * flCus;
+  bool useFlags = flEnv == 1 && !useLk && !mf_v2() && frameSize <= ZRA_LK_MAX_FRAME && full.strategy == 2 && nFramesTotal >= flMin && (uint32_t)numCUs_ >= 2 * flCus;
   if (useFlags && !lkAttr_) {
     const bool okA = hipFuncSetAttribute((const void*)zra_lk_prepass_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ZRA_LK_PP_LDS) == hipSuccess &&
                      hipFuncSetAttribute((const void*)zra_lk_parse_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ZRA_LK_PARSE_LDS) == hipSuccess;
@@ -544,6 +548,16 @@ Status Engine::compress_persistent(const uint8_t* dIn, size_t inSize, uint8_t* d
     if (!pipeStreams_[0] && hipStreamCreateWithFlags(&pipeStreams_[0], hipStreamNonBlocking) != hipSuccess) { pipeStreams_[0] = nullptr; return zerr(1); }
     lkStream = pipeStreams_[0];
     if (std::getenv("ZRA_PP_SAMESTREAM")) lkStream = stream_;      // bring-up: pre-pass and match finder one after the other (needs ring >= frames)
+  }
+
+  // ---- round 5: the flags computed by the match finder's own waves, ahead of each frame's parse (df_later_flags): no pre-pass kernel, no
+  // CUs set aside; one flag slot of a frame's size per resident wave
+  const bool useFlagsWave = flEnv == 2 && !useLk && !useLs && !mf_v2() && full.strategy == 2;
+  ZraFlagArgs fw{};
+  if (useFlagsWave) {
+    fw.flagStride = ((((uint64_t)std::min<uint64_t>(frameSize, inSize) + 511) / 512) * 128 + 255) & ~255ull;   // 16 bytes per window of 64 positions, whole blocks of 8 windows
+    if (!lkEnt_.reserve((size_t)nSlots * fw.flagStride)) return zerr(64);
+    fw.flags = lkEnt_.as<uint8_t>(); fw.ldsWords = (uint32_t)((filterBytes - 64) / 4);
   }
 
   size_t evNext = 0;
@@ -600,6 +614,8 @@ Status Engine::compress_persistent(const uint8_t* dIn, size_t inSize, uint8_t* d
       fa.flags = fk.flagsOut; fa.flagStride = fk.flagStride; fa.flagSlots = fk.ringSlots; fa.flagReadyBase = (uint32_t)F0; fa.flagReady = fk.ready; fa.flagFail = fk.fail;
       const uint32_t slots = (uint32_t)std::min<uint64_t>((uint64_t)((uint32_t)numCUs_ - ppGrid) * wavesPerCU, nSlots);
       hipLaunchKernelGGL(zra_mf_dfast_fl_kernel, dim3(std::min<uint32_t>(n, slots)), dim3(64), filterBytes, stream_, a, fa, 0u, 0xFFFFFFFFu, 0u);
+    } else if (useFlagsWave) {
+      hipLaunchKernelGGL(zra_mf_dfast_fl_kernel, dim3(std::min<uint32_t>(n, nSlots)), dim3(64), filterBytes, stream_, a, fw, 0u, 0xFFFFFFFFu, 0u);
     } else if (!useLk && useLs) {
       ZraEncArgs al = a; al.mfFilter |= (lsBytes / 64) << 16;
       hipLaunchKernelGGL(zra_mf_dfast_ls_kernel, dim3(std::min<uint32_t>(n, nSlots)), dim3(64), lsBytes + filterBytes, stream_, al, 0u, 0xFFFFFFFFu, 0u);
@@ -688,6 +704,8 @@ Status Engine::compress_persistent(const uint8_t* dIn, size_t inSize, uint8_t* d
   for (auto& sp : mfSpans) { float m = 0; if (hipEventElapsedTime(&m, sp.first, sp.second) == hipSuccess) { kstats_[0] += m; kstats_[1] += 1; kernelMs += m; } }
   for (auto& sp : entSpans) { float m = 0; if (hipEventElapsedTime(&m, sp.first, sp.second) == hipSuccess) { kstats_[2] += m; kstats_[3] += 1; } }
   lastKernelMs_ = kernelMs;
+  mfTele_.resize(ZRA_TELE_WORDS);
+  HIPCHK(hipMemcpy(mfTele_.data(), base.mfTele, 8 * (size_t)ZRA_TELE_WORDS, hipMemcpyDeviceToHost));
   if (std::getenv("ZRA_ENC_TRACE")) {                 // bring-up: timeline relative to the first match-finder launch
     for (auto& sp : mfSpans) { float a0 = 0, a1 = 0; (void)hipEventElapsedTime(&a0, mfSpans[0].first, sp.first); (void)hipEventElapsedTime(&a1, mfSpans[0].first, sp.second); std::fprintf(stderr, "mf  %8.2f .. %8.2f ms\n", a0, a1); }
     for (auto& sp : entSpans) { float a0 = 0, a1 = 0; (void)hipEventElapsedTime(&a0, mfSpans[0].first, sp.first); (void)hipEventElapsedTime(&a1, mfSpans[0].first, sp.second); std::fprintf(stderr, "ent %8.2f .. %8.2f ms\n", a0, a1); }

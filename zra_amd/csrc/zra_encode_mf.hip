@@ -434,6 +434,12 @@ struct LeanLds {
 #define TLD(p) (*(p))
 #define TST(p, v) (*(p) = (v))
 #endif
+// the flag nibble of one position as mf_dfast_lean reads it: bit 1 / 3 = later position in the long / short bucket (bits 0 / 2 always set)
+__device__ __forceinline__ u32 df_flags_at(const u8* flg, u32 p) {
+  const u8* const w = flg + (size_t)(p >> 6) * 16 + ((p & 63u) >> 3);
+  const u32 b = p & 7u;
+  return 0x05u | (((w[0] >> b) & 1u) << 1) | (((w[8] >> b) & 1u) << 3);
+}
 template <u32 MLS, bool FLAGS>
 __device__ u32 mf_dfast_lean(const ZraEncParams& P, u32* HL, u32* HS, const u8* src, u32 bs, u32 be, u32* rep, u64* seqs, u32* nOut,
                              const LeanLds& W, int lane, u32 ib, const u8* flgIn) {
@@ -468,7 +474,7 @@ __device__ u32 mf_dfast_lean(const ZraEncParams& P, u32* HL, u32* HS, const u8* 
   // scalar insertion of one position (rare paths only)
   auto insert_slow = [&](u32 pos, bool doL, bool doS) {
     if (lane == 0) {
-      const u32 fx = flg ? flg[pos] : 0x0Fu;
+      const u32 fx = flg ? df_flags_at(flg, pos) : 0x0Fu;
       u32 bl, bs_, tl, ts; H.both(ld64(src + pos), bl, bs_, tl, ts);
       if (doL && (fx & 2)) { TST(HL + bl, (pos + 1) | tl); W.markL(bl); }
       if (doS && (fx & 8)) { TST(HS + bs_, (pos + 1) | ts); W.markS(bs_); }
@@ -483,7 +489,7 @@ __device__ u32 mf_dfast_lean(const ZraEncParams& P, u32* HL, u32* HS, const u8* 
     bool active = (u32)lane < nAct;
     const u32 p = wip + (u32)lane * s;
     const u64 v8 = active ? ld64(src + p) : 0;
-    const u32 bflags = (flg && active) ? flg[p] : 0x0Fu;   // (NOT `fb`: that name is the match's forward-compare address further down)
+    const u32 bflags = (flg && active) ? df_flags_at(flg, p) : 0x0Fu;   // (NOT `fb`: that name is the match's forward-compare address further down)
     // rep gather for the current o1 (independent of the tables: in flight together with them)
     u32 repFor = o1;
     bool rv = active && o1 > 0 && p + 1 >= o1;
@@ -578,7 +584,7 @@ __device__ u32 mf_dfast_lean(const ZraEncParams& P, u32* HL, u32* HS, const u8* 
           u32 m3v = 0; bool h3v = false;                // rare: done on lane 0's vector path (keeps the parse state scalar)
           if (lane == 0) {
             const u64 v9 = ld64(src + top + 1);
-            const u32 f3 = flg ? flg[top + 1] : 0x0Fu;
+            const u32 f3 = flg ? df_flags_at(flg, top + 1) : 0x0Fu;
             u32 b3, bx, t3, tx; H.both(v9, b3, bx, t3, tx);
             const u32 r3 = (f3 & 1) ? TLD(HL + b3) : 0u;
             m3v = ((r3 & H.tagMask) == t3) ? (r3 & idxMask) : 0u;
@@ -664,7 +670,7 @@ __device__ u32 mf_dfast_lean(const ZraEncParams& P, u32* HL, u32* HS, const u8* 
         PROF_CNT(14)
         const u32 ipos = lane < 2 ? top + 2 : lane == 2 ? ip - 2 : lane == 3 ? ip - 1 : lane == 4 ? ip : ip - o2;
         const u64 x = lane < 6 ? ld64(src + ipos) : 0;
-        const u32 fx = (flg && lane < 4) ? flg[ipos] : 0x0Fu;
+        const u32 fx = (flg && lane < 4) ? df_flags_at(flg, ipos) : 0x0Fu;
         const bool wr = (lane & 1) ? (fx & 8) != 0 : (fx & 2) != 0;           // the position's bucket has a later position: the cell will be read
         u32 xbL, xbS, xtL, xtS; H.both(x, xbL, xbS, xtL, xtS);
         u32* const tp = (lane & 1) ? HS + xbS : HL + xbL;
@@ -1551,6 +1557,92 @@ __device__ __forceinline__ void mf_serial_block_t(const MfFrame& F, u32 ntu0) {
   bo->rep[0] = rep[0]; bo->rep[1] = rep[1]; bo->rep[2] = rep[2];   // confirmed by stage 2 only if the block is emitted compressed
 }
 
+// ---- bucket flags of a frame, computed by the frame's own wave ahead of its parse (round 5). Two bits per position for
+// mf_dfast_lean<.., FLAGS>: the position's long / short bucket has a LATER position of the frame — an insertion without one is never looked
+// up, so its table write is skipped (59 % / 43 % of the long / short table writes on the bench corpus, and the random 4-byte writes are what
+// the memory system is slowest at). "Has an earlier position" is not computed: the parse's LDS filter of inserted buckets decides the reads.
+// Layout: per window of 64 positions two u64 masks {long, short} at flg + 16 * window.
+// Backward sweep over the frame, 64 positions per window, the last window first: a "seen" bit per bucket in LDS tells whether a later WINDOW
+// holds the bucket; inside a window every lane that shares a byte counter (bucket & 255) with another lane counts as having a later mate —
+// a superset (an earlier mate or another bucket in the slot only cost an unnecessary write, never a missing one; tools/model/dfast_flags_stats.c:
+// 4-8 % more writes than the exact rule). The bitmaps of both tables are 12 KiB at hashLog 16 / chainLog 15 and the wave owns 6.5 KiB, so
+// the sweep runs `1 << npLog` times, each over the buckets whose top bits equal the pass; a pass ORs into the masks of the passes before it.
+// lds: ldsWords words — [0, 128) byte counters (256 per table), then the seen bits.
+// Source bytes: 512 positions per load (lane l holds the 8 bytes at block + 8 l; a window's own 8 bytes per lane come out of them with four
+// cross-lane reads), two blocks in flight ahead of the one being hashed (a block's eight windows take about as long as a loaded round trip): one memory round trip per 512 positions, off the critical path.
+struct DfBlock { u64 a; u64 m; };                       // the block's chunk of this lane; lanes 0..15: the 16 masks of the block's 8 windows (passes > 0)
+__device__ __forceinline__ DfBlock df_block_load(const u8* src, u32 fsize, const u8* flg, u32 blk, bool haveMasks, int lane) {
+  DfBlock B; B.a = 0; B.m = 0;
+  const u32 c = blk * 512 + 8 * (u32)lane;
+  if (c + 8 <= fsize) B.a = ld64(src + c);
+  else if (c < fsize) B.a = ld64_safe(src + c, src + fsize);
+  if (haveMasks && lane < 16) B.m = *(const u64*)(flg + (size_t)blk * 128 + 8 * (u32)lane);
+  return B;
+}
+__device__ __forceinline__ void df_later_flags(const u8* src, u32 fsize, u32 hlog, u32 clog, u32 mls, u32* lds, u32 ldsWords, u8* flg, int lane) {
+  if (fsize < 8) return;                                 // (no position is ever hashed)
+  const u32 lastPos = fsize - 8;
+  const u32 bmWords = ldsWords - 128;
+  u32 npLog = 0;
+  while ((((1u << hlog) + (1u << clog)) >> npLog) > bmWords * 32) npLog++;
+  const u32 hlogP = hlog - npLog, clogP = clog - npLog;
+  u32* const cnt = lds; u32* const bmL = lds + 128; u32* const bmS = bmL + ((1u << hlogP) >> 5);
+  const u64 primeS = mls == 5 ? 889523592379ULL : mls == 6 ? 227718039650203ULL : 58295818150454627ULL;
+  const u32 shV = 64 - 8 * min(mls, 7u);
+  const u32 nBlk = lastPos / 512 + 1;
+  const u32 srcLane = (u32)lane >> 3, sh = ((u32)lane & 7u) * 8;
+  for (u32 pass = 0; pass < (1u << npLog); pass++) {
+    for (u32 i = (u32)lane; i < 128 + ((1u << hlogP) >> 5) + ((1u << clogP) >> 5); i += 64) lds[i] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    const bool hm = pass != 0;
+    // blocks nBlk-1 .. 0; B0 is the one being hashed, B1 / B2 the next two below it
+    DfBlock B0 = df_block_load(src, fsize, flg, nBlk - 1, hm, lane), B1{0, 0}, B2{0, 0};
+    if (nBlk >= 2) B1 = df_block_load(src, fsize, flg, nBlk - 2, hm, lane);
+    u64 above = 0;                                       // the 8 bytes behind the block (lane 0 of the block above)
+    for (u32 blk = nBlk; blk-- > 0;) {
+      if (blk >= 2) B2 = df_block_load(src, fsize, flg, blk - 2, hm, lane);
+      const u32 aLo = (u32)B0.a, aHi = (u32)(B0.a >> 32);
+      u64 outM = 0;                                      // lanes 2k / 2k+1: the long / short mask of window k
+#pragma unroll 1
+      for (u32 kk = 0; kk < 8; kk++) {
+        const u32 k = 7 - kk;
+        const u32 p = blk * 512 + k * 64 + (u32)lane;
+        if (blk * 512 + k * 64 > lastPos) continue;      // (wave-uniform)
+        const bool act = p <= lastPos;
+        // this lane's 8 bytes: chunks 8k + lane/8 and the one behind it, shifted by lane % 8 bytes
+        const u32 ci = 8 * k + srcLane;
+        const u32 c0l = (u32)__builtin_amdgcn_ds_bpermute((int)(4 * ci), (int)aLo), c0h = (u32)__builtin_amdgcn_ds_bpermute((int)(4 * ci), (int)aHi);
+        u32 c1l = (u32)__builtin_amdgcn_ds_bpermute((int)(4 * ((ci + 1) & 63)), (int)aLo), c1h = (u32)__builtin_amdgcn_ds_bpermute((int)(4 * ((ci + 1) & 63)), (int)aHi);
+        if (ci == 63) { c1l = (u32)above; c1h = (u32)(above >> 32); }
+        const u64 c0 = (u64)c0l | ((u64)c0h << 32), c1 = (u64)c1l | ((u64)c1h << 32);
+        const u64 v = sh ? (c0 >> sh) | (c1 << (64 - sh)) : c0;
+        const u32 bL = (u32)((v * 0xCF1BBCDCB7A56463ULL) >> (64 - hlog));
+        const u32 bS = mls <= 4 ? ((u32)v * 2654435761u) >> (32 - clog) : (u32)(((v << shV) * primeS) >> (64 - clog));
+        const bool pL = act && (bL >> hlogP) == pass, pS = act && (bS >> clogP) == pass;
+        const u32 iL = bL & ((1u << hlogP) - 1), iS = bS & ((1u << clogP) - 1);
+        const u32 sL = iL & 255u, sS = 256u + (iS & 255u);
+        const u32 seenL = pL ? lds_read32(&bmL[iL >> 5]) : 0u, seenS = pS ? lds_read32(&bmS[iS >> 5]) : 0u;
+        if (pL) atomicAdd(&cnt[sL >> 2], 1u << (8 * (sL & 3)));
+        if (pS) atomicAdd(&cnt[sS >> 2], 1u << (8 * (sS & 3)));
+        __builtin_amdgcn_wave_barrier();
+        const u32 cL = pL ? (lds_read32(&cnt[sL >> 2]) >> (8 * (sL & 3))) & 255u : 0u;
+        const u32 cS = pS ? (lds_read32(&cnt[sS >> 2]) >> (8 * (sS & 3))) & 255u : 0u;
+        __builtin_amdgcn_wave_barrier();
+        if (pL) { atomicSub(&cnt[sL >> 2], 1u << (8 * (sL & 3))); atomicOr(&bmL[iL >> 5], 1u << (iL & 31)); }
+        if (pS) { atomicSub(&cnt[sS >> 2], 1u << (8 * (sS & 3))); atomicOr(&bmS[iS >> 5], 1u << (iS & 31)); }
+        const u64 mL = __ballot(((seenL >> (iL & 31)) & 1u) || cL > 1), mS = __ballot(((seenS >> (iS & 31)) & 1u) || cS > 1);
+        if ((u32)lane == 2 * k) outM = mL;
+        if ((u32)lane == 2 * k + 1) outM = mS;
+      }
+      if (lane < 16) *(u64*)(flg + (size_t)blk * 128 + 8 * (u32)lane) = outM | B0.m;
+      above = (u64)bcast(aLo, 0) | ((u64)bcast(aHi, 0) << 32);
+      B0 = B1; B1 = B2;
+    }
+    // the next pass reads these masks back (and the parse after the last one): stores done and visible to this CU's loads
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
+}
 // Match finder for strategy 2 (dfast, levels 3-4): one wave per frame, lean window-resolve parse. Launched when the batch's
 // full-size frames use dfast; a short last frame with another strategy is left to zra_mf_kernel (second launch, `only`).
 // LSRC (round 4, calls of a few hundred frames at most): the frame's source bytes are copied into LDS first and the parse reads them
@@ -1569,13 +1661,44 @@ __device__ __forceinline__ void mf_dfast_body(const ZraEncArgs& a, u32 block, u3
   W.dup = (u8*)fltLds;
   W.bmL = fltLds + 2 * W.dupSlots;
   const bool persistent = a.mfQueue != nullptr;
+  // launch telemetry (persistent launches): where this wave sits and its shader cycles against the constant 100 MHz clock
+  const bool tele = persistent && a.mfTele != nullptr;
+  // (start values parked in the 64 spare bytes behind the filter: nothing of this stays in registers while frames are parsed)
+  u32* const tl = W.bmL + ((1u << max(a.full.hashLog, a.tail.hashLog)) >> W.shL) / 32 + ((1u << max(a.full.chainLog, a.tail.chainLog)) >> W.shS) / 32;
+  if (tele && lane == 0) {
+    const u32 hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);          // HW_REG_HW_ID: cu [11:8], sh [12], se [15:13]
+    const u32 xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;    // HW_REG_XCC_ID [3:0]
+    const u64 tc0 = __builtin_readcyclecounter(), tr0 = wall_clock64();
+    const u32 key = (xcc << 8) | (((hw >> 13) & 7u) << 5) | (((hw >> 12) & 1u) << 4) | ((hw >> 8) & 15u);
+    atomicAdd((unsigned long long*)&a.mfTele[32 + key], 1ull);
+    atomicAdd((unsigned long long*)&a.mfTele[8 + xcc], 1ull);
+    atomicMax((unsigned long long*)&a.mfTele[4], ~tr0);
+    atomicMax((unsigned long long*)&a.mfTele[6], tr0);
+    tl[0] = (u32)tc0; tl[1] = (u32)(tc0 >> 32); tl[2] = (u32)tr0; tl[3] = (u32)(tr0 >> 32); tl[4] = xcc; tl[5] = 0;
+  }
   for (;;) {
     u32 f = only == 0xFFFFFFFFu ? blockIdx.x : only;   // `only`: a single-workgroup launch for that frame on table slot `onlySlot`
     if (persistent) {
       u32 t = 0;
       if (lane == 0) t = atomicAdd(a.mfQueue, 1u);
       f = rfl(t);
-      if (f >= a.nFrames) return;
+      if (f >= a.nFrames) {
+        if (tele && lane == 0) {
+          const u64 tc1 = __builtin_readcyclecounter(), tr1 = wall_clock64();
+          const u64 tc0 = (u64)tl[0] | ((u64)tl[1] << 32), tr0 = (u64)tl[2] | ((u64)tl[3] << 32);
+          const u32 xcc = tl[4] & 7u;
+          atomicAdd((unsigned long long*)&a.mfTele[0], tc1 - tc0);
+          atomicAdd((unsigned long long*)&a.mfTele[1], tr1 - tr0);
+          atomicAdd((unsigned long long*)&a.mfTele[2], 1ull);
+          atomicMax((unsigned long long*)&a.mfTele[3], tr1 - tr0);
+          atomicMax((unsigned long long*)&a.mfTele[5], tr1);
+          atomicMax((unsigned long long*)&a.mfTele[7], ~tr1);
+          atomicAdd((unsigned long long*)&a.mfTele[16 + xcc], (unsigned long long)tl[5]);
+          atomicAdd((unsigned long long*)&a.mfTele[24 + xcc], tr1 - tr0);
+        }
+        return;
+      }
+      if (tele && lane == 0) tl[5]++;
     }
 #ifdef ZRA_MF_PROFILE
     const u64 kt0_ = __builtin_amdgcn_s_memtime();
@@ -1596,19 +1719,19 @@ __device__ __forceinline__ void mf_dfast_body(const ZraEncArgs& a, u32 block, u3
 #endif
       const u32 wordsL = ((1u << F.P->hashLog) >> W.shL) / 32, wordsS = ((1u << F.P->chainLog) >> W.shS) / 32;
       W.bmS = W.bmL + wordsL;
-      {
-        // block 0 starts with empty tables (all bits clear); later blocks of a frame inherit tables filled by earlier launches
-        const u32 fill = block == 0 ? 0u : 0xFFFFFFFFu;
-        for (u32 i = lane; i < wordsL + wordsS; i += 64) W.bmL[i] = fill;
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-      }
       u32 rep[3] = {F.st->rep[0], F.st->rep[1], F.st->rep[2]};
       u32 lastLL, nseq = 0;
       const u32 ib = 32 - __builtin_clz(F.fsize - 1);  // bits for position+1 < fsize (fsize >= 7 here)
       // bucket flags of the frame (zra_lk_prepass_kernel runs ahead of this kernel on CUs of its own): wait for them; without them
       // (patience over: the call fails) the parse is the same, with every table access made
       const u8* flg = nullptr;
-      if (FLAGS && !MASK && g && g->flags && block == 0 && persistent) {
+      if (FLAGS && !MASK && g && g->flags && block == 0 && persistent && !g->flagReady) {
+        // round 5: the wave computes its frame's flags itself, ahead of the parse, over the LDS the parse uses afterwards (the filter is
+        // cleared below, the duplicate slots by the parse)
+        u8* const fw = const_cast<u8*>(g->flags) + (size_t)blockIdx.x * g->flagStride;
+        df_later_flags(F.src, F.fsize, F.P->hashLog, F.P->chainLog, F.P->minMatch, fltLds, g->ldsWords, fw, lane);
+        flg = fw;
+      } else if (FLAGS && !MASK && g && g->flags && block == 0 && persistent) {
         const u32 slot = f % g->flagSlots;
         u32 okf = 1;
         if (lane == 0) {
@@ -1621,6 +1744,12 @@ __device__ __forceinline__ void mf_dfast_body(const ZraEncArgs& a, u32 block, u3
         okf = rfl(okf);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         if (okf) flg = g->flags + (size_t)slot * g->flagStride;
+      }
+      {
+        // block 0 starts with empty tables (all bits clear); later blocks of a frame inherit tables filled by earlier launches
+        const u32 fill = block == 0 ? 0u : 0xFFFFFFFFu;
+        for (u32 i = lane; i < wordsL + wordsS; i += 64) W.bmL[i] = fill;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
       }
       const u8* srcP = F.src;
       if (LSRC) {

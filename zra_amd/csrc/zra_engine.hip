@@ -492,7 +492,7 @@ Status Engine::decode_launch(const ZraDecodeArgs& a0, const uint32_t* dExpect, u
   static const uint32_t pipeMin = std::getenv("ZRA_DEC_PIPE_MIN") ? (uint32_t)std::atoi(std::getenv("ZRA_DEC_PIPE_MIN")) : 16384u;
   bool piped = false;
   if (pipeK >= 2 && n >= pipeMin && n >= pipeK * 1024u) {
-    if (!pipeStreams_[0]) for (auto& st : pipeStreams_) if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { st = nullptr; }
+    for (auto& st : pipeStreams_) if (!st && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { st = nullptr; (void)hipGetLastError(); }   // (each on its own: the encode side creates [0], the LDS chain kernel [1])
     if (pipeStreams_[0] && pipeStreams_[1] && pipeStreams_[2] && decCounters_.reserve((size_t)(pipeK + 1) * ZRA_DC_WORDS * 4 + 64)) {
       piped = true;
       a.counters = decCounters_.as<uint32_t>();

@@ -127,7 +127,7 @@ struct ZraFseCTable {
 };
 
 // per-frame state carried from block to block inside a frame (A.4.8); lives in HBM scratch
-struct ZraEncFrameState {
+struct alignas(16) ZraEncFrameState {
   uint32_t rep[3];
   uint32_t nextToUpdate;
   // wave-cooperative hash-chain finder: it inserts whole windows ahead of the parse. insEnd = first index not inserted yet (at the end
@@ -146,6 +146,8 @@ struct ZraEncFrameState {
   uint16_t hufVal[256];
   ZraFseCTable ll, of, ml;
 };
+// (the hash-chain finder copies ring[] as uint4: every element of an array of these, and the ring inside it, sits on 16 bytes)
+static_assert(sizeof(ZraEncFrameState) % 16 == 0 && offsetof(ZraEncFrameState, ring) % 16 == 0, "ZraEncFrameState::ring must be 16-byte aligned in arrays");
 
 // stage 1 -> stage 2 hand-off for the block being processed
 struct ZraEncBlockOut {
@@ -182,11 +184,20 @@ struct ZraEncArgs {
   uint32_t* mfQueue;
   uint32_t* mfDone;
   uint32_t mfSubFrames;
+  // launch telemetry of the persistent match finder (nullptr: none), written by lane 0 of every wave: where the wave sat (XCD / SE / CU),
+  // its shader cycles against the constant 100 MHz clock (the effective shader clock of the launch), frames taken per XCD
+  uint64_t* mfTele;        // ZRA_TELE_WORDS u64
 };
+// mfTele layout (u64 words): [0] sum of shader cycles over waves, [1] sum of 100 MHz ticks over waves, [2] waves, [3] longest wave in ticks,
+// [4] earliest wave start (ticks, stored inverted for an atomic max), [5] latest wave end, [6] latest wave START, [7] earliest wave end (inverted),
+// [8..15] waves per XCD, [16..23] frames taken per XCD, [24..31] ticks spent per XCD, [32 + k] waves on CU key k (k = xcc << 8 | se << 5 | sh << 4 | cu)
+#define ZRA_TELE_CUKEYS 2048u
+#define ZRA_TELE_WORDS (32u + ZRA_TELE_CUKEYS)
 // bucket flags of zra_lk_prepass_kernel's flags mode, for zra_mf_dfast_fl_kernel: flags + (frame % flagSlots) * flagStride holds one
 // byte per position once flagReady[frame % flagSlots] == flagReadyBase + frame + 1
 struct ZraFlagArgs {
   const uint8_t* flags; uint64_t flagStride; uint32_t flagSlots; uint32_t flagReadyBase; const uint32_t* flagReady; uint32_t* flagFail;
+  uint32_t ldsWords;       // flagReady == nullptr (round 5): the match finder's wave computes the flags itself into flags + workgroup * flagStride, over this many words of its LDS
 };
 
 // ------------------------------------------------------------------------------------------------ encode, "link" dfast (zra_encode_lk.hip)
