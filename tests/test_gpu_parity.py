@@ -893,18 +893,20 @@ def test_foreign_frame_size_does_not_cost_a_pass_per_frame(zra):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("env", [{"ZRA_MF_LK": "1"}, {"ZRA_MF_LK": "1", "ZRA_LK_MODE": "1", "ZRA_LK_GROUP": "64"}, {"ZRA_MF_FLAGS": "1", "ZRA_PP_MIN": "1"}, {"ZRA_MF_V2": "1"},
+@pytest.mark.parametrize("env", [{"ZRA_MF_FLAGS": "0", "ZRA_MF_LS": "0"}, {"ZRA_MF_WAVES": "18", "ZRA_MF_LS": "0", "ZRA_ENT_WGS": "1", "ZRA_ENC_RING": "2"},
                                  {"ZRA_DEC_PIPE": "4", "ZRA_DEC_PIPE_MIN": "1", "ZRA_DEC_SMALL_MAX": "0"}, {"ZRA_MF_LS": "0"}, {"ZRA_MF_LS_MAX": "1000000"}, {"ZRA_ENC_POISON": "1"}],
-                         ids=["link-dfast", "link-dfast-ring", "bucket-flags-dfast", "mask-dfast", "decode-stage-pipeline", "dfast-small-calls-from-memory", "dfast-all-calls-from-lds",
+                         ids=["dfast-without-bucket-flags", "dfast-other-pipeline-geometry", "decode-stage-pipeline", "dfast-small-calls-from-memory", "dfast-all-calls-from-lds",
                               "hash-chain-over-poisoned-scratch"])
 def test_opt_in_kernels_are_bit_exact_too(env):
-    """The kernels that ship in the library behind a bring-up knob (the round-4 link formulation of dfast in its two launch modes, the
-    table kernel fed with the pre-pass's bucket flags, the round-3 mask-resolve dfast parse, the decode stage pipeline; and the two dfast kernels of
-    round 4 — frame source read from memory / from a copy in LDS — each forced onto the call sizes the other one takes by default) give the same bytes as the default ones;
-    and the wave-cooperative hash-chain finder, which does not clear its chain slots, gives them over a table scratch filled with 0xA5 before every batch
-    (a selection of the level 5-10 cases here; the randomised differential compress ran that way in the soak, profiles/r04_soak_d.txt): the compress parity cases of
-    levels 3-4 (archives byte-identical to the oracle's, reference call site zra.cpp:219), the sub-batch boundaries of the persistent
-    pipeline, short last frames with other cparams and the differential decode again, in a fresh process with the knob set."""
+    """The paths of the library that a default call of the test sizes does not take give the same bytes as the ones it does: the dfast table
+    kernel without its bucket flags (round 5: the flags are on by default for calls beyond the LDS-source kernel's size), the persistent
+    pipeline with another geometry (18 waves per CU, one entropy workgroup per CU, a slot ring of two sub-batches), the decode stage
+    pipeline, the two dfast kernels — frame source read from memory / from a copy in LDS — each forced onto the call sizes the other one
+    takes by default; and the wave-cooperative hash-chain finder, which does not clear its chain slots, over a table scratch filled with
+    0xA5 before every batch (a selection of the level 5-10 cases here; the randomised differential compress ran that way in the soak,
+    profiles/r04_soak_d.txt): the compress parity cases of levels 3-4 (archives byte-identical to the oracle's, reference call site
+    zra.cpp:219), the sub-batch boundaries of the persistent pipeline, short last frames with other cparams and the differential decode
+    again, in a fresh process with the knob set."""
     import subprocess
     sel = "randomised_differential_decode or golden_frames" if "ZRA_DEC_PIPE" in env else \
           "compress_buffer_bit_exact and (5-65536 or 9-65536 or 7-16384 or 10-) or short_last_frame or frames_larger_than_the_window" if "ZRA_ENC_POISON" in env else \

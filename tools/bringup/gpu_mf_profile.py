@@ -24,8 +24,8 @@ print("  windows/frame %.0f  cnt13 %.0f  cnt14 %.0f  cnt15 %.0f  cnt16 %.0f  cnt
 
 if hasattr(lib, "ZraHipDebugReadEntProfile"):
     eb = (ctypes.c_ulonglong * 16)(); lib.ZraHipDebugReadEntProfile(eb, 0); e = list(eb); ne = max(e[15], 1)
-    en = ["0 literal gather + histogram", "1 huffman decision + tree", "2 literal emit (stream packing)", "3 seq code histograms", "4 FSE table selection/build",
-          "5 tile load", "6 FSE chains (3 lanes)", "7 tile pack + flush", "8 tail"]
+    en = ["0 literal gather + histogram", "1 literal section: old/new table, stream sizes (2c)", "2 literal emit (stream packing)", "3 seq code histograms (1b)",
+          "4 Huffman tree on wave 0 || sequence tables on waves 1-3 (2a + 2b)", "5 tile load", "6 FSE chains (64 lanes per stream)", "7 tile pack + flush", "8 tail"]
     tot = sum(e[:9])
     print("entropy kernel: frames %d (two compress calls)  ticks/frame %.0f" % (ne, tot / ne))
     for i, nm in enumerate(en): print("  %-40s %10.0f  %5.1f %%" % (nm, e[i] / ne, 100.0 * e[i] / max(tot, 1)))

@@ -252,13 +252,19 @@ class Engine:
         """What the waves of the last persistent level-3/4 match-finder launch recorded (zra_hip.h: ZraHipGetLaunchTelemetry), reduced:
         effective shader MHz, waves per compute unit (min / max / histogram), waves, frames and frames per wave-second per XCD, the stagger
         of the wave starts and ends. None when the last call took another path."""
-        cap = 32 + 2048
+        cap = 32 + 2048 + 8 + 2048
         a = (ctypes.c_uint64 * cap)()
         n = self.L.ZraHipGetLaunchTelemetry(self.h, a, cap)
         if n < 32 or a[2] == 0:
             return None
         M = (1 << 64) - 1
-        cu = [int(v) for v in a[32:n] if v]
+        cu = [int(v) for v in a[32:32 + 2048] if v]
+        ent = None
+        if n >= 2080 + 8:
+            ecu = [int(v) for v in a[2088:n] if v]
+            ent = dict(workgroups=int(a[2080]), cus=len(ecu), workgroups_per_cu_max=max(ecu) if ecu else 0, frames=int(a[2083]),
+                       resident_ms_mean=round(a[2081] / max(1, a[2080]) / 1e5, 3), waiting_frac=round(a[2082] / max(1, a[2081]), 4),
+                       ms_per_frame=round((a[2081] - a[2082]) / max(1, a[2083]) / 1e5, 4))
         hist = {}
         for v in cu:
             hist[v] = hist.get(v, 0) + 1
@@ -269,7 +275,7 @@ class Engine:
                     waves_per_xcd=[int(v) for v in a[8:16]], frames_per_xcd=[int(v) for v in a[16:24]],
                     frames_per_wave_ms_per_xcd=[round(a[16 + i] / (a[24 + i] / 1e5), 4) if a[24 + i] else 0.0 for i in range(8)],
                     span_ms=round((last_end - first_start) / 1e5, 3), start_stagger_ms=round((last_start - first_start) / 1e5, 3),
-                    end_stagger_ms=round((last_end - first_end) / 1e5, 3), longest_wave_ms=round(a[3] / 1e5, 3))
+                    end_stagger_ms=round((last_end - first_end) / 1e5, 3), longest_wave_ms=round(a[3] / 1e5, 3), entropy=ent)
 
     def decode_stage_stats(self):
         """{parse_ms, huf_ms, chain_ms, exec_ms, rounds, small_ms, small_launches} of the last decode / random-access call."""

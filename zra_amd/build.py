@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libzra_amd.so")
 RESOURCES = os.path.join(HERE, "build", "kernel_resources.json")     # per kernel: VGPRs, scratch, spills, occupancy (from the compiler's remarks)
-SOURCES = ["zra_decode.hip", "zra_encode_mf.hip", "zra_encode_lk.hip", "zra_encode_ent.hip", "zra_encode.hip", "zra_engine.hip", "zra_hostpipe.hip", "zra_comm.hip", "zra_capi.cpp"]
+SOURCES = ["zra_decode.hip", "zra_encode_mf.hip", "zra_encode_ent.hip", "zra_encode.hip", "zra_engine.hip", "zra_hostpipe.hip", "zra_comm.hip", "zra_capi.cpp"]
 
 
 def needs_build():

@@ -17,15 +17,9 @@ extern "C" __global__ void zra_mf_dfast_ls_kernel(ZraEncArgs a, uint32_t block, 
 extern "C" __global__ void zra_mf_hc_kernel(ZraEncArgs a, uint32_t block, uint32_t only, uint32_t onlySlot);
 extern "C" __global__ void zra_mf_fast_kernel(ZraEncArgs a, uint32_t block, uint32_t perWave);
 extern "C" __global__ void zra_mf_dfast_kernel(ZraEncArgs a, uint32_t block, uint32_t only, uint32_t onlySlot);
-extern "C" __global__ void zra_mf_dfast2_kernel(ZraEncArgs a, uint32_t block, uint32_t only, uint32_t onlySlot);
 extern "C" __global__ void zra_mf_dfast_fl_kernel(ZraEncArgs a, ZraFlagArgs g, uint32_t block, uint32_t only, uint32_t onlySlot);
-// which dfast parse runs: the window-resolve kernel, or with ZRA_MF_V2=1 the mask-resolve kernel of round 3 (bit-exact, fewer memory
-// round trips per sequence, but 45 % more instructions as compiled: slower today — profiles/r03_experiments.md)
-static bool mf_v2() { static const bool v = std::getenv("ZRA_MF_V2") && std::atoi(std::getenv("ZRA_MF_V2")) != 0; return v; }
-#define ZRA_DFAST_KERNEL (mf_v2() ? zra_mf_dfast2_kernel : zra_mf_dfast_kernel)
 extern "C" __global__ void zra_entropy_kernel(ZraEncArgs a, uint32_t block);
-extern "C" __global__ void zra_lk_prepass_kernel(ZraEncArgs a, ZraLkArgs k);
-extern "C" __global__ void zra_lk_parse_kernel(ZraEncArgs a, ZraLkArgs k);
+extern "C" __global__ void zra_entropy_persist_kernel(ZraEncArgs a);
 
 using namespace zra_dev;
 
@@ -45,8 +39,9 @@ __global__ void zra_content_ck_kernel(const u8* in, u64 inSize, u32 frameSize, u
 // ---- exclusive scan of the batch's frame sizes: ONE wave (a 1024-thread workgroup cannot be placed while the persistent match
 //      finder holds wave slots on every SIMD; a single wave fits anywhere). The running body offset lives on the device
 //      (`running`), so batches chain without a host round trip: offsets[i] = *running + local prefix; *running += total.
-__global__ void __launch_bounds__(64) zra_scan_sizes_kernel(const u64* sizes, u32 n, u64* offsets, u64* running) {
+__global__ void __launch_bounds__(64) zra_scan_sizes_kernel(const u64* sizes, u32 n, u64* offsets, u64* running, const u32* abortFlag = nullptr) {
   const int lane = threadIdx.x;
+  if (abortFlag && *abortFlag) return;                 // (persistent pipeline gave up: the sizes of this sub-batch are not all written)
   u64 carry = *running;
   for (u32 base = 0; base < n; base += 64) {
     const u32 i = base + lane;
@@ -62,8 +57,9 @@ __global__ void __launch_bounds__(64) zra_scan_sizes_kernel(const u64* sizes, u3
 // ---- gather: frame f of the batch moves from its slot to body + bodyBase + offsets[f] (one workgroup per frame);
 //      optionally writes the 5-byte seek-table entry and/or the u64 size
 __global__ void zra_gather_frames_kernel(const u8* slots, u64 slotStride, const u64* sizes, const u64* offsets, u8* body, u64 bodyBase,
-                                         u8* entries, u32 firstFrame, u64* sizesOut) {
+                                         u8* entries, u32 firstFrame, u64* sizesOut, const u32* abortFlag = nullptr) {
   const u32 f = blockIdx.x;
+  if (abortFlag && *abortFlag) return;
   const u64 n = sizes[f], off = offsets[f];   // offsets are absolute within the body (running offset folded in by the scan)
   (void)bodyBase;
   const u8* s = slots + (size_t)f * slotStride; u8* d = body + off;
@@ -324,7 +320,7 @@ Status Engine::compress_impl_body(const uint8_t* dIn, size_t inSize, uint8_t* dB
           else hipLaunchKernelGGL(mfGeneric, dim3(1), dim3(64), 0, sA, a, blk, only, slot, 1u);
         };
         if (full.strategy == 2 && !serialAll) {
-          hipLaunchKernelGGL(ZRA_DFAST_KERNEL, dim3(nb), dim3(64), filterBytes + dynLds, sA, a, blk, 0xFFFFFFFFu, 0u);
+          hipLaunchKernelGGL(zra_mf_dfast_kernel, dim3(nb), dim3(64), filterBytes + dynLds, sA, a, blk, 0xFFFFFFFFu, 0u);
           if (oddTail) launchLone((uint32_t)(nb - 1), (uint32_t)(nb - 1));
         } else {
           // frames per wave: as many as it takes to have every frame of the batch resident at once (32 waves per CU)
@@ -346,7 +342,7 @@ Status Engine::compress_impl_body(const uint8_t* dIn, size_t inSize, uint8_t* dB
           if (hashChain && pwEnv <= 0) hipLaunchKernelGGL(zra_mf_hc_kernel, dim3(nb), dim3(64), hcPad, sA, a, blk, 0xFFFFFFFFu, 0u);
           else if (lean) hipLaunchKernelGGL(zra_mf_fast_kernel, dim3((nb + perWave - 1) / perWave), dim3(64), dynLds, sA, a, blk, perWave);
           else hipLaunchKernelGGL(mfGeneric, dim3((nb + perWave - 1) / perWave), dim3(64), dynLds, sA, a, blk, 0xFFFFFFFFu, 0u, perWave);
-          if (oddTail) hipLaunchKernelGGL(ZRA_DFAST_KERNEL, dim3(1), dim3(64), filterBytes, sA, a, blk, (uint32_t)(nb - 1), (uint32_t)(nb - 1));
+          if (oddTail) hipLaunchKernelGGL(zra_mf_dfast_kernel, dim3(1), dim3(64), filterBytes, sA, a, blk, (uint32_t)(nb - 1), (uint32_t)(nb - 1));
           else if (lean && hasTail && (hashChain ? (tail.strategy < 3 || tail.strategy > 5) : tail.strategy != 1))
             launchLone((uint32_t)(nb - 1), (uint32_t)(nb - 1));
         }
@@ -361,9 +357,9 @@ Status Engine::compress_impl_body(const uint8_t* dIn, size_t inSize, uint8_t* dB
       entSpans.push_back({e0, e1});
       if (blk + 1 < rounds) HIPCHK(hipStreamWaitEvent(sA, e1, 0));   // next block's match finder needs the confirmed state
     }
-    hipLaunchKernelGGL(zra_scan_sizes_kernel, dim3(1), dim3(64), 0, stream2_, a.sizes, nb, dOffsets, dRunning);
+    hipLaunchKernelGGL(zra_scan_sizes_kernel, dim3(1), dim3(64), 0, stream2_, a.sizes, nb, dOffsets, dRunning, (const u32*)nullptr);
     hipLaunchKernelGGL(zra_gather_frames_kernel, dim3(nb), dim3(256), 0, stream2_, a.slots, slotStride, a.sizes, dOffsets, dBody,
-                       bodyBase0, dEntries ? dEntries : nullptr, (u32)f0, dSizes);
+                       bodyBase0, dEntries ? dEntries : nullptr, (u32)f0, dSizes, (const u32*)nullptr);
     hipEvent_t done = ev(); if (!done) return zerr(1);
     HIPCHK(hipEventRecord(done, stream2_));
     entDone[c] = done;
@@ -417,7 +413,12 @@ Status Engine::compress_persistent(const uint8_t* dIn, size_t inSize, uint8_t* d
   // the budget is a wish (other engines of the pool, other ranks on the device and the caller's own buffers read the same free-memory
   // figure): a reservation that fails is tried again with half of it, down to 1 GiB, before the call gives up with memory_allocation
   uint64_t SBIG = 0, nSuper = 0, subsPerSuper = 0; int nCtx = 1;
-  EncCtx& sh = encCtx_[0];                       // shared: table slots, and the literal / slot buffers of ONE sub-batch (stream B is in order)
+  EncCtx& sh = encCtx_[0];                       // shared: table slots, the entropy workgroups' literal buffers, the ring of encoded-frame slots
+  // entropy stage: persistent workgroups, two per CU asked for (one fits beside the match finder's waves; the rest start when those leave)
+  static const uint32_t entPerCU = std::getenv("ZRA_ENT_WGS") ? (uint32_t)std::max(1, std::atoi(std::getenv("ZRA_ENT_WGS"))) : 2u;
+  const uint32_t entGrid = (uint32_t)std::min<uint64_t>((uint64_t)numCUs_ * entPerCU, nFramesTotal);
+  static const uint32_t ringSubsEnv = std::getenv("ZRA_ENC_RING") ? (uint32_t)std::max(2, std::atoi(std::getenv("ZRA_ENC_RING"))) : 4u;   // sub-batches the slot ring holds
+  uint64_t slotRing = 0;
   for (;; budget /= 2) {
     SBIG = std::max<uint64_t>(1, std::min<uint64_t>(nFramesTotal, budget / perFrame));
     if (const char* e = std::getenv("ZRA_ENC_SUPER")) SBIG = std::max<uint64_t>(1, std::min<uint64_t>(SBIG, (uint64_t)std::atoll(e)));   // bring-up knob
@@ -425,8 +426,9 @@ Status Engine::compress_persistent(const uint8_t* dIn, size_t inSize, uint8_t* d
     nCtx = nFramesTotal > SBIG ? 2 : 1;
     nSuper = (nFramesTotal + SBIG - 1) / SBIG;
     subsPerSuper = (SBIG + SB - 1) / SB;
-    const uint64_t subFrames = std::min<uint64_t>(SB, SBIG);
-    bool okR = sh.tables.reserve((size_t)nSlots * tableWords * 4) && sh.lits.reserve(subFrames * litStride) && sh.slots.reserve(subFrames * slotStride);
+    slotRing = std::min<uint64_t>((uint64_t)ringSubsEnv * SB, subsPerSuper * (uint64_t)SB);
+    if (SBIG <= SB) slotRing = SBIG;
+    bool okR = sh.tables.reserve((size_t)nSlots * tableWords * 4) && sh.lits.reserve((size_t)entGrid * litStride) && sh.slots.reserve(slotRing * slotStride);
     for (int c = 0; c < nCtx && okR; c++) {
       EncCtx& x = encCtx_[c];
       okR = x.seqs.reserve(SBIG * seqStride * 8) && x.misc.reserve(SBIG * (sizeof(ZraEncFrameState) + sizeof(ZraEncBlockOut))) &&
@@ -436,15 +438,18 @@ Status Engine::compress_persistent(const uint8_t* dIn, size_t inSize, uint8_t* d
     if (budget <= (1ull << 30) || SBIG <= SB) return zerr(64);
     (void)hipGetLastError();
   }
-  // counters: [u64 running offset][u32 queue per super-batch][u32 done per sub-batch]
-  const size_t cntCore = (16 + 4 * (size_t)(nSuper + nSuper * subsPerSuper + 4) + 15) & ~(size_t)15;
+  // counters: [u64 running offset][pad][abort][per super-batch: mf queue, mf started, entropy queue, gathered][entropy done per sub-batch]
+  const size_t nCnt = 4 + 4 * (size_t)nSuper + (size_t)(nSuper * subsPerSuper) + 4;
+  const size_t cntCore = (16 + 4 * nCnt + 15) & ~(size_t)15;
   const size_t cntBytes = cntCore + 8 * (size_t)ZRA_TELE_WORDS;      // + the launch telemetry (ZraEncArgs::mfTele)
   if (!encScan_.reserve(cntBytes)) return zerr(64);
   uint64_t* dRunning = encScan_.as<uint64_t>();
-  uint32_t* dQueue = (uint32_t*)(encScan_.as<uint8_t>() + 16);
-  uint32_t* dDone = dQueue + nSuper;
+  uint32_t* dCnt = (uint32_t*)(encScan_.as<uint8_t>() + 16);
+  uint32_t* dAbort = dCnt;                       // [0]
+  uint32_t* dPerSuper = dCnt + 4;                // 4 words per super-batch
+  uint32_t* dEntDone = dPerSuper + 4 * nSuper;
   HIPCHK(hipMemsetAsync(encScan_.as<uint8_t>(), 0, cntBytes, stream_));
-  encCounters_ = dDone; encCountersBytes_ = 4 * (size_t)(nSuper * subsPerSuper);
+  encCounters_ = dCnt; encCountersBytes_ = 4 * nCnt;   // (an error exit fills them with 0x7F: the abort word is set, every wait is satisfied)
 
   ZraEncArgs base{};
   base.in = dIn; base.inSize = inSize; base.frameSize = frameSize; base.checksum = checksum ? 1 : 0;
@@ -452,15 +457,16 @@ Status Engine::compress_persistent(const uint8_t* dIn, size_t inSize, uint8_t* d
   dbgSeqStride_ = seqStride; dbgB_ = (uint32_t)SBIG;
   base.tableStride = tableWords; base.seqStride = seqStride; base.litStride = litStride; base.slotStride = slotStride;
   base.mfTele = (uint64_t*)(encScan_.as<uint8_t>() + cntCore);
-  // LDS geometry of the bucket filter: 1 bit per 2^shL long-table buckets, 1 bit per 2^shS short-table buckets, and the
-  // duplicate-detection slots (1 KiB + 4 KiB + 1 KiB at hashLog 16 / chainLog 15: one bit per 2 long buckets, per 4 short buckets).
-  // 18 resident waves per CU x 6 KiB leave LDS and wave slots for two entropy-stage workgroups per CU, which is what lets stream B
-  // run under the match finder (round 1: profiles/r01_mf_occupancy_sweep.log; round 2 A/B on one box: profiles/r02_experiments.md)
-  uint32_t shL = 1, shS = 2, dupLog = 8;
+  base.pipeAbort = dAbort; base.entSubFrames = SB; base.slotRing = (uint32_t)slotRing; base.readyStamp = 1u;
+  // LDS geometry of the match finder's wave: the bucket filter — 1 bit per 2^shL long-table buckets, 1 bit per 2^shS short-table buckets —
+  // and the duplicate-detection slots: 2 KiB + 4 KiB + 0.5 KiB = 6.5 KiB at hashLog 16 / chainLog 15 (one bit per 2 long buckets, per 8
+  // short buckets; round 5: 1 per 4 short buckets made it 7 KiB + 64, and 20 waves of that leave no room for the entropy stage's
+  // workgroup on the CU). The flag sweep ahead of a frame's parse (df_later_flags) runs over the same bytes.
+  uint32_t shL = 1, shS = 3, dupLog = 8;
   if (const char* f = std::getenv("ZRA_MF_FILTER")) { unsigned x = 1, y = 1, z = 8; if (std::sscanf(f, "%u,%u,%u", &x, &y, &z) >= 1) { shL = x & 15; shS = y & 15; dupLog = z & 15; } }
   base.mfFilter = shL | (shS << 4) | (dupLog << 8);
   const uint32_t hl = std::max(full.hashLog, tail.hashLog), cl = std::max(full.chainLog, tail.chainLog);
-  const size_t filterBytes = (8u << dupLog) + (((size_t)1 << hl) >> shL) / 8 + (((size_t)1 << cl) >> shS) / 8 + 64;
+  const size_t filterBytes = (8u << dupLog) + (((size_t)1 << hl) >> shL) / 8 + (((size_t)1 << cl) >> shS) / 8;
 
   // ---- latency mode (round 4): calls of at most ZRA_MF_LS_MAX frames (default: two per CU, what LDS holds at 64 KiB) run the dfast parse over
   // a copy of the frame in LDS (zra_mf_dfast_ls_kernel). ZRA_MF_LS=0 turns it off.
@@ -468,7 +474,7 @@ Status Engine::compress_persistent(const uint8_t* dIn, size_t inSize, uint8_t* d
   const uint32_t lsBytes = (uint32_t)((std::min<uint64_t>(frameSize, inSize) + 64 + 63) & ~63ull);
   const uint32_t lsPerCu = (uint32_t)((160u << 10) / (lsBytes + filterBytes));
   static const int lsMaxEnv = std::getenv("ZRA_MF_LS_MAX") ? std::atoi(std::getenv("ZRA_MF_LS_MAX")) : -1;
-  bool useLs = lsEnv != 0 && !mf_v2() && full.strategy == 2 && lsPerCu >= 1 &&
+  bool useLs = lsEnv != 0 && full.strategy == 2 && lsPerCu >= 1 &&
                nFramesTotal <= (lsMaxEnv >= 0 ? (uint64_t)lsMaxEnv : (uint64_t)lsPerCu * (uint64_t)numCUs_);
   if (useLs && lsAttr_ == 0) {
     const bool okA = hipFuncSetAttribute((const void*)zra_mf_dfast_ls_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 << 10) == hipSuccess;
@@ -477,87 +483,15 @@ Status Engine::compress_persistent(const uint8_t* dIn, size_t inSize, uint8_t* d
   }
   if (lsAttr_ < 0) useLs = false;
 
-  // ---- link formulation (zra_encode_lk.hip) for frames of at most 64 KiB: a parse-independent pre-pass + a parse without tables.
-  // Opt-in (ZRA_MF_LK=1): bit-exact, but measured slower than the table kernel (round 4: 7.7 against 16 GiB/s, profiles/r04_experiments.md).
-  // ZRA_LK_MODE=0: pre-pass and parse alternate over groups of ZRA_LK_GROUP frames on one stream, 1: both persistent side by side,
-  // ZRA_LK_PP_CUS workgroups of the pre-pass feeding the parse through a ring of entry slots
-  static const int lkEnv = std::getenv("ZRA_MF_LK") ? std::atoi(std::getenv("ZRA_MF_LK")) : 0;
-  static const int lkMode = std::getenv("ZRA_LK_MODE") ? std::atoi(std::getenv("ZRA_LK_MODE")) : 0;
-  static const uint32_t lkGroup = std::getenv("ZRA_LK_GROUP") ? (uint32_t)std::max(1, std::atoi(std::getenv("ZRA_LK_GROUP"))) : 4096u;
-  static const uint32_t lkWaves = std::getenv("ZRA_LK_WAVES") ? (uint32_t)std::min(8, std::max(1, std::atoi(std::getenv("ZRA_LK_WAVES")))) : ZRA_LK_PARSE_WAVES;   // waves per parse workgroup (= frames in flight per CU)
-  static const uint32_t lkPpCus = std::getenv("ZRA_LK_PP_CUS") ? (uint32_t)std::max(1, std::atoi(std::getenv("ZRA_LK_PP_CUS"))) : 32u;
-  bool useLk = lkEnv != 0 && frameSize <= ZRA_LK_MAX_FRAME && full.strategy == 2 && !mf_v2();
-  if (useLk && !lkAttr_) {
-    const bool okA = hipFuncSetAttribute((const void*)zra_lk_prepass_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ZRA_LK_PP_LDS) == hipSuccess &&
-                     hipFuncSetAttribute((const void*)zra_lk_parse_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ZRA_LK_PARSE_LDS) == hipSuccess;
-    if (!okA) (void)hipGetLastError();
-    lkAttr_ = okA ? 1 : -1;
-  }
-  if (lkAttr_ < 0) useLk = false;
-  ZraLkArgs lk{};
-  uint32_t* lkQueues = nullptr; size_t lkQueueNext = 0, lkCtlBytes = 0;
-  hipStream_t lkStream = nullptr;
-  if (useLk) {
-    lk.entPositions = (((uint64_t)frameSize + 63) & ~63ull) + 64;
-    lk.ringSlots = (uint32_t)std::min<uint64_t>(nFramesTotal, lkGroup);
-    const size_t nQueues = 2 * (size_t)(nFramesTotal / lkGroup + nSuper + 2);
-    lkCtlBytes = 64 + 4 * (nQueues + 2 * (size_t)lk.ringSlots);
-    if (!lkEnt_.reserve((size_t)lk.ringSlots * lk.entPositions * 16) || !lkTmp_.reserve((size_t)numCUs_ * 4 * 65536) || !lkCtl_.reserve(lkCtlBytes)) return zerr(64);
-    HIPCHK(hipMemsetAsync(lkCtl_.p, 0, lkCtlBytes, stream_));
-    lk.ent = lkEnt_.as<uint64_t>(); lk.lkTmp = lkTmp_.as<uint16_t>();
-    lk.fail = lkCtl_.as<uint32_t>();
-    lkQueues = lkCtl_.as<uint32_t>() + 16;
-    if (lkMode == 1) {
-      lk.ready = lkQueues + nQueues; lk.consumed = lk.ready + lk.ringSlots;
-      if (!pipeStreams_[0] && hipStreamCreateWithFlags(&pipeStreams_[0], hipStreamNonBlocking) != hipSuccess) { pipeStreams_[0] = nullptr; return zerr(1); }
-      lkStream = pipeStreams_[0];
-    }
-  }
-
-  // ---- bucket flags for the table kernel (round 4): zra_lk_prepass_kernel in flags mode runs AHEAD of the match finder on ZRA_PP_CUS
-  // CUs of its own (its workgroup takes a CU's whole LDS) and tells, per position and table, whether the bucket has an earlier / a later
-  // position of the frame; the match finder skips the table reads and writes that cannot matter. Frames of at most 64 KiB, calls of at
-  // least ZRA_PP_MIN frames. Opt-in (ZRA_MF_FLAGS=1): exact, and it takes half of the table requests away (59 % of the long-table
-  // writes on the bench corpus go to buckets no later position shares) — but the match finder's time does not move (round 4: 57.1
-  // against 55.7 ms per GiB at 18 waves per CU; profiles/r04_experiments.md): the kernel is bound by dependent round trips at loaded
-  // latency (SQ_WAIT_ANY 65 % of the wave cycles, TCP pending-stall 77 %), not by the number of table requests.
-  static const int flEnv = std::getenv("ZRA_MF_FLAGS") ? std::atoi(std::getenv("ZRA_MF_FLAGS")) : 0;
-  static const uint32_t ppLdsBytes = std::getenv("ZRA_PP_LDS") ? (uint32_t)std::atoi(std::getenv("ZRA_PP_LDS")) : ZRA_LK_PP_LDS;   // bring-up knob
-  static const uint32_t flCus = std::getenv("ZRA_PP_CUS") ? (uint32_t)std::max(1, std::atoi(std::getenv("ZRA_PP_CUS"))) : 32u;
-  static const uint64_t flMin = std::getenv("ZRA_PP_MIN") ? (uint64_t)std::max(1, std::atoi(std::getenv("ZRA_PP_MIN"))) : 4096u;
-  bool useFlags = flEnv == 1 && !useLk && !mf_v2() && frameSize <= ZRA_LK_MAX_FRAME && full.strategy == 2 && nFramesTotal >= flMin && (uint32_t)numCUs_ >= 2 * flCus;
-  if (useFlags && !lkAttr_) {
-    const bool okA = hipFuncSetAttribute((const void*)zra_lk_prepass_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ZRA_LK_PP_LDS) == hipSuccess &&
-                     hipFuncSetAttribute((const void*)zra_lk_parse_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ZRA_LK_PARSE_LDS) == hipSuccess;
-    if (!okA) (void)hipGetLastError();
-    lkAttr_ = okA ? 1 : -1;
-  }
-  if (lkAttr_ < 0) useFlags = false;
-  ZraLkArgs fk{};
-  uint32_t* flQueues = nullptr;
-  if (useFlags) {
-    fk.ringSlots = (uint32_t)std::min<uint64_t>(nFramesTotal, 2ull * SB);
-    fk.flagStride = ((uint64_t)frameSize + 255) & ~255ull;
-    const size_t ctl = 64 + 4 * ((size_t)nSuper + 2 + fk.ringSlots);
-    if (!lkEnt_.reserve((size_t)fk.ringSlots * fk.flagStride) || !lkCtl_.reserve(ctl)) return zerr(64);
-    HIPCHK(hipMemsetAsync(lkCtl_.p, 0, ctl, stream_));
-    fk.flagsOut = lkEnt_.as<uint8_t>();
-    fk.fail = lkCtl_.as<uint32_t>(); fk.started = fk.fail + 1;
-    flQueues = lkCtl_.as<uint32_t>() + 16;
-    fk.ready = flQueues + nSuper + 2;
-    if (!pipeStreams_[0] && hipStreamCreateWithFlags(&pipeStreams_[0], hipStreamNonBlocking) != hipSuccess) { pipeStreams_[0] = nullptr; return zerr(1); }
-    lkStream = pipeStreams_[0];
-    if (std::getenv("ZRA_PP_SAMESTREAM")) lkStream = stream_;      // bring-up: pre-pass and match finder one after the other (needs ring >= frames)
-  }
-
-  // ---- round 5: the flags computed by the match finder's own waves, ahead of each frame's parse (df_later_flags): no pre-pass kernel, no
-  // CUs set aside; one flag slot of a frame's size per resident wave
-  const bool useFlagsWave = flEnv == 2 && !useLk && !useLs && !mf_v2() && full.strategy == 2;
+  // ---- round 5: bucket flags computed by the match finder's own waves, ahead of each frame's parse (df_later_flags): one flag slot per
+  // resident wave. ZRA_MF_FLAGS=0 turns them off (bring-up A/B).
+  static const int flEnv = std::getenv("ZRA_MF_FLAGS") ? std::atoi(std::getenv("ZRA_MF_FLAGS")) : 1;
+  const bool useFlagsWave = flEnv != 0 && !useLs && full.strategy == 2;
   ZraFlagArgs fw{};
   if (useFlagsWave) {
     fw.flagStride = ((((uint64_t)std::min<uint64_t>(frameSize, inSize) + 511) / 512) * 128 + 255) & ~255ull;   // 16 bytes per window of 64 positions, whole blocks of 8 windows
-    if (!lkEnt_.reserve((size_t)nSlots * fw.flagStride)) return zerr(64);
-    fw.flags = lkEnt_.as<uint8_t>(); fw.ldsWords = (uint32_t)((filterBytes - 64) / 4);
+    if (!mfFlags_.reserve((size_t)nSlots * fw.flagStride)) return zerr(64);
+    fw.flags = mfFlags_.as<uint8_t>(); fw.ldsWords = (uint32_t)(filterBytes / 4);
   }
 
   size_t evNext = 0;
@@ -566,10 +500,12 @@ Status Engine::compress_persistent(const uint8_t* dIn, size_t inSize, uint8_t* d
     return evPool_[evNext++];
   };
   std::vector<std::pair<hipEvent_t, hipEvent_t>> mfSpans, entSpans;
-  hipEvent_t superDone[2] = {nullptr, nullptr};
-  uint32_t ppStarted = 0;
-  // stream B starts after the counters are cleared and after whatever the caller queued on the engine stream
-  { hipEvent_t e0 = ev(); if (!e0) return zerr(1); HIPCHK(hipEventRecord(e0, stream_)); HIPCHK(hipStreamWaitEvent(stream2_, e0, 0)); }
+  hipEvent_t superDone[2] = {nullptr, nullptr}, prevGathered = nullptr;
+  // stream C: the scan + gather of each sub-batch (stream B holds the persistent entropy kernel for the whole launch)
+  if (!pipeStreams_[0] && hipStreamCreateWithFlags(&pipeStreams_[0], hipStreamNonBlocking) != hipSuccess) { pipeStreams_[0] = nullptr; return zerr(1); }
+  hipStream_t streamC = pipeStreams_[0];
+  // streams B and C start after the counters are cleared and after whatever the caller queued on the engine stream
+  { hipEvent_t e0 = ev(); if (!e0) return zerr(1); HIPCHK(hipEventRecord(e0, stream_)); HIPCHK(hipStreamWaitEvent(stream2_, e0, 0)); HIPCHK(hipStreamWaitEvent(streamC, e0, 0)); }
 
   for (uint64_t S = 0; S < nSuper; S++) {
     const uint64_t F0 = S * SBIG;
@@ -584,128 +520,79 @@ Status Engine::compress_persistent(const uint8_t* dIn, size_t inSize, uint8_t* d
     a.blockOut = (ZraEncBlockOut*)(x.misc.as<uint8_t>() + (size_t)SBIG * sizeof(ZraEncFrameState));
     a.contentCk = x.ck.as<uint32_t>();
     a.sizes = x.sizes.as<uint64_t>();
-    a.mfQueue = dQueue + S; a.mfDone = dDone + S * subsPerSuper; a.mfSubFrames = SB;
+    a.mfQueue = dPerSuper + 4 * S; a.mfStarted = a.mfQueue + 1; a.entQueue = a.mfQueue + 2; a.gatherDone = a.mfQueue + 3;
+    a.entDone = dEntDone + S * subsPerSuper;
     // the context's per-frame scratch is free once the last sub-batch that used it has been gathered
     if (superDone[c]) HIPCHK(hipStreamWaitEvent(stream_, superDone[c], 0));
+    // no frame of this launch is published yet (the stamps of an earlier call may still sit in the block records)
+    HIPCHK(hipMemsetAsync(a.blockOut, 0, (size_t)n * sizeof(ZraEncBlockOut), stream_));
     hipEvent_t m0 = ev(), m1 = ev();
     if (!m0 || !m1) return zerr(1);
     HIPCHK(hipEventRecord(m0, stream_));
-    if (useFlags) {
-      // the pre-pass on its own stream, behind everything queued on stream A so far (the ring is free then); the match finder is
-      // launched once every pre-pass workgroup is resident (they need whole CUs: behind the match finder's waves they would never start)
-      hipEvent_t r0 = ev(); if (!r0) return zerr(1);
-      HIPCHK(hipEventRecord(r0, stream_)); HIPCHK(hipStreamWaitEvent(lkStream, r0, 0));
-      ZraLkArgs k = fk; k.first = 0; k.count = n; k.ppQueue = flQueues + S; k.subDone = a.mfDone; k.readyBase = (uint32_t)F0;
-      volatile uint32_t* dbgHost = nullptr;
-      if (std::getenv("ZRA_PP_TRACE")) { void* hp = nullptr; if (hipHostMalloc(&hp, 256, hipHostMallocMapped) == hipSuccess) { std::memset(hp, 0, 256); dbgHost = (volatile uint32_t*)hp; void* dp = nullptr; (void)hipHostGetDevicePointer(&dp, hp, 0); k.dbg = (volatile uint32_t*)dp; } }
-      k.oddTail = (tailSize && F0 + n == nFramesTotal && tail.strategy != 2) ? 1u : 0u;
-      const uint32_t ppGrid = std::min<uint32_t>(n, flCus);
-      ppStarted += ppGrid;
-      hipLaunchKernelGGL(zra_lk_prepass_kernel, dim3(ppGrid), dim3(ZRA_LK_PP_THREADS), ppLdsBytes, lkStream, a, k);
-      HIPCHK(hipGetLastError());
-      if (dbgHost) {
-        usleep(2000000);
-        std::fprintf(stderr, "pp markers after 2 s: entry %u  frame+1 pulled %u  links L begin %u  L done %u  S done %u  flags written %u  fenced %u  published %u  loop top %u | grid %u n %u\n",
-                     dbgHost[0], dbgHost[1], dbgHost[2], dbgHost[3], dbgHost[4], dbgHost[5], dbgHost[6], dbgHost[7], dbgHost[8], ppGrid, n);
-        std::fflush(stderr);
-      }
-      if (lkStream != stream_) HIPCHK(hipStreamWaitValue32(stream_, fk.started, ppStarted, hipStreamWaitValueGte, 0xFFFFFFFFu));
-      ZraFlagArgs fa{};
-      fa.flags = fk.flagsOut; fa.flagStride = fk.flagStride; fa.flagSlots = fk.ringSlots; fa.flagReadyBase = (uint32_t)F0; fa.flagReady = fk.ready; fa.flagFail = fk.fail;
-      const uint32_t slots = (uint32_t)std::min<uint64_t>((uint64_t)((uint32_t)numCUs_ - ppGrid) * wavesPerCU, nSlots);
-      hipLaunchKernelGGL(zra_mf_dfast_fl_kernel, dim3(std::min<uint32_t>(n, slots)), dim3(64), filterBytes, stream_, a, fa, 0u, 0xFFFFFFFFu, 0u);
-    } else if (useFlagsWave) {
-      hipLaunchKernelGGL(zra_mf_dfast_fl_kernel, dim3(std::min<uint32_t>(n, nSlots)), dim3(64), filterBytes, stream_, a, fw, 0u, 0xFFFFFFFFu, 0u);
-    } else if (!useLk && useLs) {
+    const uint32_t mfGrid = std::min<uint32_t>(n, nSlots);
+    if (useFlagsWave) hipLaunchKernelGGL(zra_mf_dfast_fl_kernel, dim3(mfGrid), dim3(64), filterBytes, stream_, a, fw, 0u, 0xFFFFFFFFu, 0u);
+    else if (useLs) {
       ZraEncArgs al = a; al.mfFilter |= (lsBytes / 64) << 16;
-      hipLaunchKernelGGL(zra_mf_dfast_ls_kernel, dim3(std::min<uint32_t>(n, nSlots)), dim3(64), lsBytes + filterBytes, stream_, al, 0u, 0xFFFFFFFFu, 0u);
-    } else if (!useLk) hipLaunchKernelGGL(ZRA_DFAST_KERNEL, dim3(std::min<uint32_t>(n, nSlots)), dim3(64), filterBytes, stream_, a, 0u, 0xFFFFFFFFu, 0u);
-    else if (lkMode == 1) {
-      // both kernels persistent: the pre-pass on its own stream behind everything queued on stream A so far (the ring and its flags
-      // are free then), the parse on stream A; the parse workgroups leave lkPpCus CUs to the pre-pass (one workgroup of either fits a CU)
-      if (S > 0) HIPCHK(hipMemsetAsync(lk.ready, 0, 8 * (size_t)lk.ringSlots, stream_));
-      hipEvent_t r0 = ev(); if (!r0) return zerr(1);
-      HIPCHK(hipEventRecord(r0, stream_)); HIPCHK(hipStreamWaitEvent(lkStream, r0, 0));
-      ZraLkArgs k = lk; k.first = 0; k.count = n; k.ppQueue = lkQueues + lkQueueNext++;
-      ZraEncArgs a2 = a; a2.mfQueue = lkQueues + lkQueueNext++;
-      const uint32_t ppGrid = std::min<uint32_t>({n, lkPpCus, (uint32_t)numCUs_ / 2});
-      const uint32_t paGrid = std::max<uint32_t>(1, std::min<uint32_t>((n + lkWaves - 1) / lkWaves, (uint32_t)numCUs_ - ppGrid));
-      hipLaunchKernelGGL(zra_lk_prepass_kernel, dim3(ppGrid), dim3(ZRA_LK_PP_THREADS), ppLdsBytes, lkStream, a, k);
-      hipLaunchKernelGGL(zra_lk_parse_kernel, dim3(paGrid), dim3(lkWaves * 64), ZRA_LK_PARSE_LDS, stream_, a2, k);
-    } else {
-      for (uint32_t g0 = 0; g0 < n; g0 += lkGroup) {
-        ZraLkArgs k = lk; k.first = g0; k.count = std::min<uint32_t>(lkGroup, n - g0); k.ppQueue = lkQueues + lkQueueNext++;
-        ZraEncArgs a2 = a; a2.mfQueue = lkQueues + lkQueueNext++;
-        hipLaunchKernelGGL(zra_lk_prepass_kernel, dim3(std::min<uint32_t>(k.count, (uint32_t)numCUs_)), dim3(ZRA_LK_PP_THREADS), ppLdsBytes, stream_, a, k);
-        hipLaunchKernelGGL(zra_lk_parse_kernel, dim3(std::min<uint32_t>((k.count + lkWaves - 1) / lkWaves, (uint32_t)numCUs_)),
-                           dim3(lkWaves * 64), ZRA_LK_PARSE_LDS, stream_, a2, k);
-      }
-    }
+      hipLaunchKernelGGL(zra_mf_dfast_ls_kernel, dim3(mfGrid), dim3(64), lsBytes + filterBytes, stream_, al, 0u, 0xFFFFFFFFu, 0u);
+    } else hipLaunchKernelGGL(zra_mf_dfast_kernel, dim3(mfGrid), dim3(64), filterBytes, stream_, a, 0u, 0xFFFFFFFFu, 0u);
+    HIPCHK(hipGetLastError());                        // (a launch that failed would leave stream B waiting for waves that never start)
     HIPCHK(hipEventRecord(m1, stream_));
     mfSpans.push_back({m0, m1});
-    // a short last frame whose cparams select another strategy: parsed by the generic kernel (table slot 0 is free by then)
+    // a short last frame whose cparams select another strategy: parsed by the generic kernel (table slot 0 is free by then), then published
     const bool oddTail = tailSize && F0 + n == nFramesTotal && tail.strategy != 2;
-    hipEvent_t tailEv = nullptr;
     if (oddTail) {
       ZraEncArgs at = a; at.mfQueue = nullptr;
       if (tail.strategy >= 3 && tail.strategy <= 5) hipLaunchKernelGGL(zra_mf_hc_kernel, dim3(1), dim3(64), 0, stream_, at, 0u, (uint32_t)(n - 1), 0u);
       else hipLaunchKernelGGL(mfGeneric, dim3(1), dim3(64), 0, stream_, at, 0u, (uint32_t)(n - 1), 0u, 1u);
-      tailEv = ev(); if (!tailEv) return zerr(1);
-      HIPCHK(hipEventRecord(tailEv, stream_));
+      HIPCHK(hipStreamWriteValue32(stream_, &a.blockOut[n - 1].ready, a.readyStamp, 0));
     }
+    // stream B: once every wave of the match finder is resident (they are placed first, side by side: what is left of each CU is one
+    // contiguous piece), the content checksums, then the persistent entropy stage
+    HIPCHK(hipStreamWaitValue32(stream2_, a.mfStarted, mfGrid, hipStreamWaitValueGte, 0xFFFFFFFFu));
+    if (prevGathered) HIPCHK(hipStreamWaitEvent(stream2_, prevGathered, 0));      // the slot ring is shared between super-batches
     if (checksum)
       hipLaunchKernelGGL(zra_content_ck_kernel, dim3((n * 4 + 255) / 256), dim3(256), 0, stream2_, dIn, (u64)inSize, frameSize, (u32)F0, n, a.contentCk);
-    const uint32_t nSub = (n + SB - 1) / SB;
-    // bring-up knob (round 4, profiles/r04_experiments.md §7): the entropy stage only behind the whole match-finder launch — what does the
-    // overlap cost the finder, and is the process-to-process spread of its launch time a property of that overlap?
-    static const bool entDefer = std::getenv("ZRA_ENT_DEFER") != nullptr;
-    if (entDefer) HIPCHK(hipStreamWaitEvent(stream2_, m1, 0));
+    hipEvent_t e0 = ev(), e1 = ev(); if (!e0 || !e1) return zerr(1);
+    HIPCHK(hipEventRecord(e0, stream2_));
+    hipLaunchKernelGGL(zra_entropy_persist_kernel, dim3(std::min<uint32_t>(n, entGrid)), dim3(256), 0, stream2_, a);
+    HIPCHK(hipEventRecord(e1, stream2_));
+    entSpans.push_back({e0, e1});
+    // stream C: scan + gather of each sub-batch as its frames come out of the entropy stage
+    const uint32_t nSub = (n + SB - 1) / SB, ringSubs = (uint32_t)std::max<uint64_t>(1, slotRing / SB);
     for (uint32_t j = 0; j < nSub; j++) {
       const uint32_t j0 = j * SB, nbj = std::min<uint32_t>(SB, n - j0);
-      const bool hasOdd = oddTail && j == nSub - 1;
-      HIPCHK(hipStreamWaitValue32(stream2_, a.mfDone + j, nbj - (hasOdd ? 1u : 0u), hipStreamWaitValueGte, 0xFFFFFFFFu));
-      if (hasOdd) HIPCHK(hipStreamWaitEvent(stream2_, tailEv, 0));
-      ZraEncArgs aj = a;
-      aj.firstFrame = (uint32_t)(F0 + j0); aj.nFrames = nbj;
-      aj.seqs = a.seqs + (size_t)j0 * seqStride; aj.state = a.state + j0; aj.blockOut = a.blockOut + j0;
-      aj.contentCk = a.contentCk + j0; aj.sizes = a.sizes + j0;
+      HIPCHK(hipStreamWaitValue32(streamC, a.entDone + j, nbj, hipStreamWaitValueGte, 0xFFFFFFFFu));
       uint64_t* dOffsets = x.sizes.as<uint64_t>() + SBIG + j0;
-      hipEvent_t e0 = ev(), e1 = ev(); if (!e0 || !e1) return zerr(1);
-      HIPCHK(hipEventRecord(e0, stream2_));
-      hipLaunchKernelGGL(zra_entropy_kernel, dim3(nbj), dim3(256), 0, stream2_, aj, 0u);
-      HIPCHK(hipEventRecord(e1, stream2_));
-      entSpans.push_back({e0, e1});
-      hipLaunchKernelGGL(zra_scan_sizes_kernel, dim3(1), dim3(64), 0, stream2_, aj.sizes, nbj, dOffsets, dRunning);
-      hipLaunchKernelGGL(zra_gather_frames_kernel, dim3(nbj), dim3(256), 0, stream2_, aj.slots, slotStride, aj.sizes, dOffsets, dBody,
-                         bodyBase0, dEntries ? dEntries : nullptr, (u32)(F0 + j0), dSizes);
+      const uint8_t* subSlots = a.slots + (size_t)((j % ringSubs) * (uint64_t)SB) * slotStride;
+      hipLaunchKernelGGL(zra_scan_sizes_kernel, dim3(1), dim3(64), 0, streamC, a.sizes + j0, nbj, dOffsets, dRunning, (const u32*)dAbort);
+      hipLaunchKernelGGL(zra_gather_frames_kernel, dim3(nbj), dim3(256), 0, streamC, subSlots, slotStride, a.sizes + j0, dOffsets, dBody,
+                         bodyBase0, dEntries ? dEntries : nullptr, (u32)(F0 + j0), dSizes, (const u32*)dAbort);
+      HIPCHK(hipStreamWriteValue32(streamC, a.gatherDone, j + 1, 0));
     }
     hipEvent_t done = ev(); if (!done) return zerr(1);
-    HIPCHK(hipEventRecord(done, stream2_));
-    superDone[c] = done;
+    HIPCHK(hipEventRecord(done, streamC));
+    superDone[c] = done; prevGathered = done;
   }
   uint64_t total = 0;
-  HIPCHK(hipMemcpyAsync(&total, dRunning, 8, hipMemcpyDeviceToHost, stream2_));
+  HIPCHK(hipMemcpyAsync(&total, dRunning, 8, hipMemcpyDeviceToHost, streamC));
+  HIPCHK(hipStreamSynchronize(streamC));
   HIPCHK(hipStreamSynchronize(stream2_));
   HIPCHK(hipStreamSynchronize(stream_));
-  if (lkStream && lkStream != stream_) HIPCHK(hipStreamSynchronize(lkStream));
   HIPCHK(hipGetLastError());
-  if (useFlags) if (const char* dump = std::getenv("ZRA_PP_DUMP")) {      // bring-up: the flags of ring slot 0 to a file
-    std::vector<uint8_t> h(fk.flagStride);
-    HIPCHK(hipMemcpy(h.data(), fk.flagsOut, fk.flagStride, hipMemcpyDeviceToHost));
-    if (FILE* fp = std::fopen(dump, "wb")) { std::fwrite(h.data(), 1, h.size(), fp); std::fclose(fp); }
-  }
-  if (useLk || useFlags) {
-    uint32_t failed = 0;
-    HIPCHK(hipMemcpy(&failed, useLk ? lk.fail : fk.fail, 4, hipMemcpyDeviceToHost));
-    if (failed) return zerr(1);                       // a wait between the two persistent kernels ran out of patience
+  {
+    uint32_t aborted = 0;
+    HIPCHK(hipMemcpy(&aborted, dAbort, 4, hipMemcpyDeviceToHost));
+    if (aborted) return zerr(1);                      // a wait between the two persistent kernels ran out of patience
   }
   double kernelMs = 0;
   kstats_[0] = kstats_[1] = kstats_[2] = kstats_[3] = 0;
   for (auto& sp : mfSpans) { float m = 0; if (hipEventElapsedTime(&m, sp.first, sp.second) == hipSuccess) { kstats_[0] += m; kstats_[1] += 1; kernelMs += m; } }
   for (auto& sp : entSpans) { float m = 0; if (hipEventElapsedTime(&m, sp.first, sp.second) == hipSuccess) { kstats_[2] += m; kstats_[3] += 1; } }
   lastKernelMs_ = kernelMs;
-  mfTele_.resize(ZRA_TELE_WORDS);
-  HIPCHK(hipMemcpy(mfTele_.data(), base.mfTele, 8 * (size_t)ZRA_TELE_WORDS, hipMemcpyDeviceToHost));
+  // (the head — sums, per-XCD and per-CU counts of the match finder — then the entropy stage's block; the per-wave records stay on the device)
+  mfTele_.resize(ZRA_TELE_HEAD + 8 + ZRA_TELE_CUKEYS);
+  HIPCHK(hipMemcpy(mfTele_.data(), base.mfTele, 8 * (size_t)ZRA_TELE_HEAD, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(mfTele_.data() + ZRA_TELE_HEAD, base.mfTele + ZRA_TELE_ENT, 8 * (size_t)(8 + ZRA_TELE_CUKEYS), hipMemcpyDeviceToHost));
   if (std::getenv("ZRA_ENC_TRACE")) {                 // bring-up: timeline relative to the first match-finder launch
     for (auto& sp : mfSpans) { float a0 = 0, a1 = 0; (void)hipEventElapsedTime(&a0, mfSpans[0].first, sp.first); (void)hipEventElapsedTime(&a1, mfSpans[0].first, sp.second); std::fprintf(stderr, "mf  %8.2f .. %8.2f ms\n", a0, a1); }
     for (auto& sp : entSpans) { float a0 = 0, a1 = 0; (void)hipEventElapsedTime(&a0, mfSpans[0].first, sp.first); (void)hipEventElapsedTime(&a1, mfSpans[0].first, sp.second); std::fprintf(stderr, "ent %8.2f .. %8.2f ms\n", a0, a1); }

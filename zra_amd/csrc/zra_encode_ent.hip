@@ -11,8 +11,10 @@
 // Rules restated from SURVEY.md Appendix A.4.2, A.4.4-A.4.8 (validated there against libzstd 1.4.9).
 #include "zra_dev.h"
 #include "zra_kernels.h"
+#include "zra_encode_wave.h"
 
 using namespace zra_dev;
+using zra_wave::bcast;
 
 namespace {
 
@@ -59,19 +61,23 @@ struct EncLitPhase {
   u32 wCount[16], wCumul[16], rankLast[16];
   u16 nbPerRank[16], valPerRank[16];
   u8 ncTmp[192];
+  ZraFseCTable wct;           // encoding table of the weights (its own: the sequence tables are built on the other waves meanwhile)
 };
-struct EncSeqPhase {
-  u32 cnt[3][64];
+// work arrays of the three sequence-table builds: they live in the bit-staging tile, which nobody packs into while tables are built
+struct EncSeqBuild {
   short norm[3][64];
   u8 spread[3][512];
-  u8 ncount[3][192];
+  u32 cumul[3][56];           // fse_build_ctable work array (LDS, not scratch)
+};
+struct EncSeqPhase {
   u8 codes[3][SEQ_TILE];
   u16 chain[3][SEQ_TILE];
-  u32 cumul[3][56];           // fse_build_ctable work array (LDS, not scratch)
 };
 struct __attribute__((aligned(16))) EncShared {
   u32 stage[STAGE_WORDS];
   union { EncLitPhase lit; EncSeqPhase seq; };
+  u32 seqCnt[3][64];         // code histograms of the block's sequences (counted while the literals are gathered: the sequences are in registers then)
+  u8 ncount[3][192];         // table descriptions of the block's sequence section (written while the Huffman tree is built, emitted after the literals)
   u8 hNb[256];
   u16 hVal[256];
   ZraFseCTable ct[3];        // 0 LL, 1 OF, 2 ML (next-block tables)
@@ -82,6 +88,7 @@ struct __attribute__((aligned(16))) EncShared {
   // scalars shared through LDS
   u32 sc[16];
 };
+static_assert(sizeof(EncSeqBuild) <= sizeof(u32) * STAGE_WORDS, "the table builds' work arrays must fit the staging tile");
 
 // ---- workgroup exclusive scan of one u32 per thread; returns exclusive prefix, *total = sum over the workgroup
 __device__ __forceinline__ u32 block_excl_scan(EncShared& S, u32 v, u32* total) {
@@ -334,7 +341,7 @@ __device__ u32 huf_set_max_height(EncShared& S, u32 lastNonNull, u32 maxNbBits) 
   return maxNbBits;
 }
 
-// FSE-compress the weight string (one lane). 0 = not compressible, 1 = single symbol. Uses S.ct[0]/S.seq.spread[0]/S.seq.norm[0] as scratch.
+// FSE-compress the weight string (one lane). 0 = not compressible, 1 = single symbol. Its scratch is S.lit's own (w* arrays, wct).
 __device__ u32 huf_compress_weights(EncShared& S, u8* dst, u32 cap, const u8* w, u32 n) {
   u32* const count = S.lit.wCount; short* norm = S.lit.wNorm;
   u32 maxSym = 0, maxCount = 0;
@@ -350,7 +357,7 @@ __device__ u32 huf_compress_weights(EncShared& S, u8* dst, u32 cap, const u8* w,
   const u32 h = fse_write_ncount(tmp, norm, maxSym, t);
   if (!h || h > cap) return 0;
   for (u32 i = 0; i < h; i++) dst[i] = tmp[i];
-  ZraFseCTable* ct = &S.ct[0];
+  ZraFseCTable* ct = &S.lit.wct;
   if (fse_build_ctable(ct, norm, maxSym, t, S.lit.wSpread, S.lit.wCumul)) return 0;
   if (n <= 2) return 0;
   // two interleaved states, symbols consumed from the end (A.4.5 "weight serialisation")
@@ -501,17 +508,12 @@ __device__ unsigned long long zra_ent_prof[16];
 #ifndef ZRA_ENT_WAVES
 #define ZRA_ENT_WAVES 5
 #endif
-extern "C" __global__ void __launch_bounds__(ENT_THREADS, ZRA_ENT_WAVES)
-zra_entropy_kernel(ZraEncArgs a, u32 block) {
-  __shared__ EncShared S;
-  // This stage runs beside the persistent match finder, which is DRAM-bound but fills most issue slots; the one-lane serial
-  // sections here are latency-critical. Raise the wave's issue priority so they are not queued behind match-finder waves.
-  __builtin_amdgcn_s_setprio(3);
+// One block of frame `f` of the batch: literals to `lits` (this workgroup's scratch), the encoded block to `slot`.
+__device__ __forceinline__ void entropy_frame(const ZraEncArgs& a, u32 block, u32 f, u8* lits, u8* slot, EncShared& S) {
 #ifdef ZRA_MF_PROFILE
   u64 ept_ = __builtin_amdgcn_s_memtime();
 #endif
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const u32 f = blockIdx.x;
   const u64 fstart = (u64)(a.firstFrame + f) * a.frameSize;
   const u64 remaining = a.inSize - fstart;
   const u32 fsize = (u32)(remaining < a.frameSize ? remaining : a.frameSize);
@@ -523,7 +525,6 @@ zra_entropy_kernel(ZraEncArgs a, u32 block) {
   const u8* src = a.in + fstart;
   ZraEncFrameState* st = &a.state[f];
   const ZraEncBlockOut* bo = &a.blockOut[f];
-  u8* slot = a.slots + (size_t)f * a.slotStride;
   const u32 strategy = P.strategy;
 
   if (first && tid == 0) {
@@ -540,10 +541,10 @@ zra_entropy_kernel(ZraEncArgs a, u32 block) {
 
   if (!bo->skip) {
     const u64* seqs = a.seqs + (size_t)f * a.seqStride;
-    u8* lits = a.lits + (size_t)f * a.litStride;
 
     // ------------------------------------------------------------ phase 1: gather literals + histogram
     for (int i = tid; i < 4 * 256; i += ENT_THREADS) (&S.lit.hist[0][0])[i] = 0;
+    if (tid < 3 * 64) (&S.seqCnt[0][0])[tid] = 0;
     u32 litBase = 0, srcBase = bs;
     __syncthreads();
     for (u32 t0 = 0; t0 < nbSeq; t0 += SEQ_TILE) {
@@ -554,6 +555,11 @@ zra_entropy_kernel(ZraEncArgs a, u32 block) {
         const u64 q = i < nbSeq ? seqs[i] : 0;
         llv[k] = (u32)q & 0xFFFFF; mlv[k] = (u32)(q >> 20) & 0xFFFFF;
         tl += llv[k]; tt += llv[k] + mlv[k];
+        if (i < nbSeq) {                               // code histograms of the sequence section (A.4.7): the sequence is in registers here
+          atomicAdd(&S.seqCnt[0][ll_code(llv[k])], 1u);
+          atomicAdd(&S.seqCnt[1][hb32((u32)(q >> 40))], 1u);
+          atomicAdd(&S.seqCnt[2][ml_code(mlv[k] - 3)], 1u);
+        }
       }
       if (tid == 0) S.longCount = 0;
       u32 totL, totT;
@@ -582,9 +588,9 @@ zra_entropy_kernel(ZraEncArgs a, u32 block) {
       }
       __syncthreads();
       const u32 nLong = S.longCount;
-      for (u32 e = 0; e < nLong; e++) {
+      for (u32 e = (u32)wave; e < nLong; e += ENT_THREADS / 64) {      // a run per wave: four runs' round trips side by side
         const u32 lp2 = S.stage[3 * e], sp2 = S.stage[3 * e + 1], ll2 = S.stage[3 * e + 2];
-        for (u32 b = tid; b < ll2; b += ENT_THREADS) { const u8 c = src[sp2 + b]; lits[lp2 + b] = c; atomicAdd(&S.lit.hist[wave][c], 1u); }
+        for (u32 b = (u32)lane; b < ll2; b += 64) { const u8 c = src[sp2 + b]; lits[lp2 + b] = c; atomicAdd(&S.lit.hist[wave][c], 1u); }
       }
       litBase += totL; srcBase += totT;
       __syncthreads();
@@ -597,6 +603,10 @@ zra_entropy_kernel(ZraEncArgs a, u32 block) {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 
     EPROF(0)
+    // (the three sequence tables are chosen and built on waves 1-3 WHILE wave 0 builds the Huffman tree — both are one-lane sections,
+    // 28 % and 17 % of this kernel's time when they ran one after the other, and they share nothing; their work arrays sit in the staging tile)
+    EncSeqBuild& SB = *(EncSeqBuild*)S.stage;
+    EPROF(3)
     // ------------------------------------------------------------ phase 2: literals section (A.4.5)
     u32 litSec = 0;
     {
@@ -604,93 +614,144 @@ zra_entropy_kernel(ZraEncArgs a, u32 block) {
       u32 mode = 0, hSize = 0, streams = 1, encSize = 0;
       u32 ssz[4] = {0, 0, 0, 0};
       const u8* nbTab = S.hNb; const u16* valTab = S.hVal;
-      if (n > 63 && !(strategy == 1 && P.targetLength > 0)) {      // fast strategy with an acceleration (negative levels): literals stay raw
-        const u32 cntS = S.lit.hist[0][tid] + S.lit.hist[1][tid] + S.lit.hist[2][tid] + S.lit.hist[3][tid];
+      // ---- 2a (all threads): symbol counts, the cheap exits, the sort that the tree build starts from
+      const bool litTry = n > 63 && !(strategy == 1 && P.targetLength > 0);      // fast strategy with an acceleration (negative levels): literals stay raw
+      u32 cntS = 0, maxSym = 0, c = 0, repeat = 0, log = 0;   // c: compressed size candidate; 0 = not compressible
+      bool useOld = false, candidate = false, needTree = false, fail = false;
+      if (litTry) {
+        cntS = S.lit.hist[0][tid] + S.lit.hist[1][tid] + S.lit.hist[2][tid] + S.lit.hist[3][tid];
         __syncthreads();
         S.lit.hist[0][tid] = cntS;
         const u32 largest = block_max(S, cntS);
-        const u32 maxSym = block_max(S, cntS ? (u32)tid : 0u);
-        u32 c = 0;                                  // compressed size candidate; 0 = not compressible
-        bool useOld = false;
+        maxSym = block_max(S, cntS ? (u32)tid : 0u);
         if (largest == n) c = 1;
         else if (largest > (n >> 7) + 4) {
-          u32 repeat = first ? 0u : st->hufRepeat;
+          candidate = true;
+          repeat = first ? 0u : st->hufRepeat;
           if (repeat == 1) {
             const int bad = __syncthreads_or((u32)tid <= maxSym && cntS != 0 && st->hufNbBits[tid] == 0);
             if (bad) repeat = 0;
           }
           const bool preferRepeat = strategy < 4 && n <= 1024;
-          bool fail = false;
           if (preferRepeat && repeat != 0) useOld = true;
           else {
-            // ---- new tree: sort by (count desc, symbol asc), two-queue merge, depth limit, canonical codes
-            const u32 log = fse_optimal_tablelog(11, n, maxSym, 1);
+            // ---- new tree: sort by (count desc, symbol asc); the merge, the depth limit and the codes follow on wave 0 below
+            needTree = true;
+            log = fse_optimal_tablelog(11, n, maxSym, 1);
             if ((u32)tid <= maxSym) {
               u32 rank = 0;
               for (u32 t = 0; t <= maxSym; t++) { const u32 ct = S.lit.hist[0][t]; rank += (ct > cntS) || (ct == cntS && t < (u32)tid); }
               S.lit.nodeCount[1 + rank] = cntS; S.lit.nodeByte[rank] = (u8)tid;
             }
-            __syncthreads();
-            if (tid == 0) {
-              u32* cntN = S.lit.nodeCount + 1; u16* par = S.lit.nodeParent + 1; u8* nbN = S.lit.nodeBits + 1;
-              int nonNull = (int)maxSym;
-              while (cntN[nonNull] == 0) nonNull--;
-              const int START = 256;
-              int lowS = nonNull, nodeNb = START, nodeRoot = nodeNb + lowS - 1, lowN = nodeNb;
-              cntN[nodeNb] = cntN[lowS] + cntN[lowS - 1];
-              par[lowS] = par[lowS - 1] = (u16)nodeNb;
-              nodeNb++; lowS -= 2;
-              for (int k = nodeNb; k <= nodeRoot; k++) cntN[k] = 1u << 30;
-              S.lit.nodeCount[0] = 1u << 31;
-              while (nodeNb <= nodeRoot) {
-                const int n1 = (cntN[lowS] < cntN[lowN]) ? lowS-- : lowN++;
-                const int n2 = (cntN[lowS] < cntN[lowN]) ? lowS-- : lowN++;
-                cntN[nodeNb] = cntN[n1] + cntN[n2];
-                par[n1] = par[n2] = (u16)nodeNb;
-                nodeNb++;
-              }
-              nbN[nodeRoot] = 0;
-              for (int k = nodeRoot - 1; k >= START; k--) nbN[k] = nbN[par[k]] + 1;
-              for (int k = 0; k <= nonNull; k++) nbN[k] = nbN[par[k]] + 1;
-              const u32 maxBits = huf_set_max_height(S, (u32)nonNull, log);
-              u16* const nbPerRank = S.lit.nbPerRank; u16* const valPerRank = S.lit.valPerRank;
-              for (int k = 0; k < 14; k++) nbPerRank[k] = valPerRank[k] = 0;
-              for (int k = 0; k <= nonNull; k++) nbPerRank[nbN[k]]++;
-              { u16 mn = 0; for (int k = (int)maxBits; k > 0; k--) { valPerRank[k] = mn; mn += nbPerRank[k]; mn >>= 1; } }
-              for (int k = 0; k < 256; k++) S.hNb[k] = 0;
-              for (u32 k = 0; k <= maxSym; k++) S.hNb[S.lit.nodeByte[k]] = k <= (u32)nonNull ? nbN[k] : 0;
-              for (u32 k = 0; k <= maxSym; k++) S.hVal[k] = valPerRank[S.hNb[k]]++;
-              S.sc[0] = maxBits;
-              S.sc[1] = huf_write_ctable(S, maxSym, maxBits);
-            }
-            __syncthreads();
-            newHufLog = S.sc[0]; hSize = S.sc[1]; newHufMaxSym = maxSym;
-            if (!hSize) fail = true;
-            else if (repeat != 0) {
-              const u32 oldSize = block_sum(S, (u32)tid <= maxSym ? (u32)st->hufNbBits[tid] * cntS : 0u) >> 3;
-              const u32 newSize = block_sum(S, (u32)tid <= maxSym ? (u32)S.hNb[tid] * cntS : 0u) >> 3;
-              if (oldSize <= hSize + newSize || hSize + 12 >= n) useOld = true;
-            }
-            if (!fail && !useOld && hSize + 12 >= n) fail = true;   // "return 0": not compressible
-          }
-          if (!fail) {
-            if (useOld) {
-              // previous block's table -> LDS copies so both paths read the same arrays
-              S.hNb[tid] = st->hufNbBits[tid]; S.hVal[tid] = st->hufVal[tid];
-              hSize = 0;
-              __syncthreads();
-            }
-            streams = n < 256 ? 1 : 4;
-            // stream sizes from code lengths (prefix work is cheap: one pass over the literals)
-            const u32 seg = streams == 1 ? n : (n + 3) / 4;
-            u32 bits[4] = {0, 0, 0, 0};
-            for (u32 i = tid; i < n; i += ENT_THREADS) { const u32 j = streams == 1 ? 0 : min(i / seg, 3u); bits[j] += nbTab[lits[i]]; }
-            for (u32 j = 0; j < streams; j++) ssz[j] = (block_sum(S, bits[j]) + 1 + 7) >> 3;
-            encSize = streams == 1 ? ssz[0] : 6 + ssz[0] + ssz[1] + ssz[2] + ssz[3];
-            c = hSize + encSize;
-            if (c >= n - 1) c = 0;
           }
         }
+      }
+      __syncthreads();
+      // ---- 2b: wave 0 lane 0 builds the Huffman tree; waves 1-3 lane 0 choose and build the sequence tables (stream = wave - 1)
+      if (wave == 0) {
+        if (needTree && tid == 0) {
+          u32* cntN = S.lit.nodeCount + 1; u16* par = S.lit.nodeParent + 1; u8* nbN = S.lit.nodeBits + 1;
+          int nonNull = (int)maxSym;
+          while (cntN[nonNull] == 0) nonNull--;
+          const int START = 256;
+          int lowS = nonNull, nodeNb = START, nodeRoot = nodeNb + lowS - 1, lowN = nodeNb;
+          cntN[nodeNb] = cntN[lowS] + cntN[lowS - 1];
+          par[lowS] = par[lowS - 1] = (u16)nodeNb;
+          nodeNb++; lowS -= 2;
+          for (int k = nodeNb; k <= nodeRoot; k++) cntN[k] = 1u << 30;
+          S.lit.nodeCount[0] = 1u << 31;
+          while (nodeNb <= nodeRoot) {
+            const int n1 = (cntN[lowS] < cntN[lowN]) ? lowS-- : lowN++;
+            const int n2 = (cntN[lowS] < cntN[lowN]) ? lowS-- : lowN++;
+            cntN[nodeNb] = cntN[n1] + cntN[n2];
+            par[n1] = par[n2] = (u16)nodeNb;
+            nodeNb++;
+          }
+          nbN[nodeRoot] = 0;
+          for (int k = nodeRoot - 1; k >= START; k--) nbN[k] = nbN[par[k]] + 1;
+          for (int k = 0; k <= nonNull; k++) nbN[k] = nbN[par[k]] + 1;
+          const u32 maxBits = huf_set_max_height(S, (u32)nonNull, log);
+          u16* const nbPerRank = S.lit.nbPerRank; u16* const valPerRank = S.lit.valPerRank;
+          for (int k = 0; k < 14; k++) nbPerRank[k] = valPerRank[k] = 0;
+          for (int k = 0; k <= nonNull; k++) nbPerRank[nbN[k]]++;
+          { u16 mn = 0; for (int k = (int)maxBits; k > 0; k--) { valPerRank[k] = mn; mn += nbPerRank[k]; mn >>= 1; } }
+          for (int k = 0; k < 256; k++) S.hNb[k] = 0;
+          for (u32 k = 0; k <= maxSym; k++) S.hNb[S.lit.nodeByte[k]] = k <= (u32)nonNull ? nbN[k] : 0;
+          for (u32 k = 0; k <= maxSym; k++) S.hVal[k] = valPerRank[S.hNb[k]]++;
+          S.sc[0] = maxBits;
+          S.sc[1] = huf_write_ctable(S, maxSym, maxBits);
+        }
+      } else if (nbSeq && lane == 0) {
+        const int k = wave - 1;
+        const u32 maxSymK = k == 0 ? 35 : k == 1 ? 31 : 52, FSELog = k == 1 ? 8 : 9, defLog = k == 1 ? 5 : 6, defMax = k == 0 ? 35 : k == 1 ? 28 : 52;
+        const short* defNorm = k == 0 ? c_LLdef : k == 1 ? c_OFdef : c_MLdef;
+        u32* count = S.seqCnt[k];
+        u32 mx = 0, most = 0;
+        for (u32 sy = 0; sy <= maxSymK; sy++) { if (count[sy]) mx = sy; if (count[sy] > most) most = count[sy]; }
+        const u64 qLast = seqs[nbSeq - 1];
+        const u32 lastCode = k == 0 ? ll_code((u32)qLast & 0xFFFFF) : k == 1 ? hb32((u32)(qLast >> 40)) : ml_code(((u32)(qLast >> 20) & 0xFFFFF) - 3);
+        const ZraFseCTable* prevCT = k == 0 ? &st->ll : k == 1 ? &st->of : &st->ml;
+        u32 repeatMode = first ? 0 : (k == 0 ? st->llRepeat : k == 1 ? st->ofRepeat : st->mlRepeat);
+        const bool defaultAllowed = k != 1 || mx <= 28;
+        const u32 modeK = select_encoding(&repeatMode, count, mx, most, nbSeq, FSELog, prevCT, defNorm, defLog, defaultAllowed, strategy, SB.norm[k], S.ncount[k]);
+        S.mode[k] = modeK; S.nextRepeat[k] = repeatMode; S.ncountSize[k] = 0; S.tblErr[k] = 0;
+        ZraFseCTable* ct = &S.ct[k];
+        if (modeK == 1) { ct->rle = 1; ct->tableLog = 0; ct->maxSym = mx; S.ncount[k][0] = (u8)mx; S.ncountSize[k] = 1; }
+        else if (modeK == 0) { for (u32 sy = 0; sy <= defMax; sy++) SB.norm[k][sy] = defNorm[sy]; if (fse_build_ctable(ct, SB.norm[k], defMax, defLog, SB.spread[k], SB.cumul[k])) S.tblErr[k] = 1; }
+        else if (modeK == 2) {
+          u32 n1 = nbSeq;
+          const u32 tl = fse_optimal_tablelog(FSELog, nbSeq, mx, 2);
+          if (count[lastCode] > 1) { count[lastCode]--; n1--; }
+          if (fse_normalize(SB.norm[k], tl, count, n1, mx, n1 >= 2048) <= 0) S.tblErr[k] = 1;
+          else {
+            const u32 h = fse_write_ncount(S.ncount[k], SB.norm[k], mx, tl);
+            if (!h || fse_build_ctable(ct, SB.norm[k], mx, tl, SB.spread[k], SB.cumul[k])) S.tblErr[k] = 1;
+            S.ncountSize[k] = h;
+          }
+        }
+      }
+      __syncthreads();
+      EPROF(4)
+      // ---- 2c (all threads): old table or new, stream sizes, the section's mode
+      if (candidate) {
+        if (needTree) {
+          newHufLog = S.sc[0]; hSize = S.sc[1]; newHufMaxSym = maxSym;
+          if (!hSize) fail = true;
+          else if (repeat != 0) {
+            const u32 oldSize = block_sum(S, (u32)tid <= maxSym ? (u32)st->hufNbBits[tid] * cntS : 0u) >> 3;
+            const u32 newSize = block_sum(S, (u32)tid <= maxSym ? (u32)S.hNb[tid] * cntS : 0u) >> 3;
+            if (oldSize <= hSize + newSize || hSize + 12 >= n) useOld = true;
+          }
+          if (!fail && !useOld && hSize + 12 >= n) fail = true;   // "return 0": not compressible
+        }
+        if (!fail) {
+          if (useOld) {
+            // previous block's table -> LDS copies so both paths read the same arrays
+            S.hNb[tid] = st->hufNbBits[tid]; S.hVal[tid] = st->hufVal[tid];
+            hSize = 0;
+            __syncthreads();
+          }
+          streams = n < 256 ? 1 : 4;
+          // stream sizes from code lengths (prefix work is cheap: one pass over the literals)
+          const u32 seg = streams == 1 ? n : (n + 3) / 4;
+          u32 bits[4] = {0, 0, 0, 0};
+          // (16 literals per load: one round trip per 4 KiB of literals instead of one per 256 bytes)
+          for (u32 i0 = 16u * tid; i0 < n; i0 += 16u * ENT_THREADS) {
+            const uint4 v = *(const uint4*)(lits + i0);
+            const u32 w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (u32 b = 0; b < 16; b++) {
+              const u32 i = i0 + b;
+              if (i < n) { const u32 j = streams == 1 ? 0 : min(i / seg, 3u); bits[j] += nbTab[(w4[b >> 2] >> (8 * (b & 3))) & 255u]; }
+            }
+          }
+          for (u32 j = 0; j < streams; j++) ssz[j] = (block_sum(S, bits[j]) + 1 + 7) >> 3;
+          encSize = streams == 1 ? ssz[0] : 6 + ssz[0] + ssz[1] + ssz[2] + ssz[3];
+          c = hSize + encSize;
+          if (c >= n - 1) c = 0;
+        }
+      }
+      if (litTry) {
         const u32 minGain = (n >> (strategy >= 8 ? strategy - 1 : 6)) + 2;
         if (c == 0 || c >= n - minGain) mode = 0;
         else if (c == 1) mode = 1;
@@ -746,49 +807,6 @@ zra_entropy_kernel(ZraEncArgs a, u32 block) {
     bool uncompressible = false;
     if (nbSeq) {
       u8* const seqHead = op++;
-      // ---- pass A: code histograms
-      for (int i = tid; i < 3 * 64; i += ENT_THREADS) (&S.seq.cnt[0][0])[i] = 0;
-      __syncthreads();
-      for (u32 i = tid; i < nbSeq; i += ENT_THREADS) {
-        const u64 q = seqs[i];
-        const u32 ll = (u32)q & 0xFFFFF, ml = (u32)(q >> 20) & 0xFFFFF, ov = (u32)(q >> 40);
-        atomicAdd(&S.seq.cnt[0][ll_code(ll)], 1u);
-        atomicAdd(&S.seq.cnt[1][hb32(ov)], 1u);
-        atomicAdd(&S.seq.cnt[2][ml_code(ml - 3)], 1u);
-      }
-      __syncthreads();
-      EPROF(3)
-      // ---- table selection + construction: wave k lane 0 handles stream k (0 LL, 1 OF, 2 ML)
-      if (wave < 3 && lane == 0) {
-        const int k = wave;
-        const u32 maxSymK = k == 0 ? 35 : k == 1 ? 31 : 52, FSELog = k == 1 ? 8 : 9, defLog = k == 1 ? 5 : 6, defMax = k == 0 ? 35 : k == 1 ? 28 : 52;
-        const short* defNorm = k == 0 ? c_LLdef : k == 1 ? c_OFdef : c_MLdef;
-        u32* count = S.seq.cnt[k];
-        u32 mx = 0, most = 0;
-        for (u32 s = 0; s <= maxSymK; s++) { if (count[s]) mx = s; if (count[s] > most) most = count[s]; }
-        const u64 qLast = seqs[nbSeq - 1];
-        const u32 lastCode = k == 0 ? ll_code((u32)qLast & 0xFFFFF) : k == 1 ? hb32((u32)(qLast >> 40)) : ml_code(((u32)(qLast >> 20) & 0xFFFFF) - 3);
-        const ZraFseCTable* prevCT = k == 0 ? &st->ll : k == 1 ? &st->of : &st->ml;
-        u32 repeatMode = first ? 0 : (k == 0 ? st->llRepeat : k == 1 ? st->ofRepeat : st->mlRepeat);
-        const bool defaultAllowed = k != 1 || mx <= 28;
-        const u32 mode = select_encoding(&repeatMode, count, mx, most, nbSeq, FSELog, prevCT, defNorm, defLog, defaultAllowed, strategy, S.seq.norm[k], S.seq.ncount[k]);
-        S.mode[k] = mode; S.nextRepeat[k] = repeatMode; S.ncountSize[k] = 0; S.tblErr[k] = 0;
-        ZraFseCTable* ct = &S.ct[k];
-        if (mode == 1) { ct->rle = 1; ct->tableLog = 0; ct->maxSym = mx; S.seq.ncount[k][0] = (u8)mx; S.ncountSize[k] = 1; }
-        else if (mode == 0) { for (u32 s = 0; s <= defMax; s++) S.seq.norm[k][s] = defNorm[s]; if (fse_build_ctable(ct, S.seq.norm[k], defMax, defLog, S.seq.spread[k], S.seq.cumul[k])) S.tblErr[k] = 1; }
-        else if (mode == 2) {
-          u32 n1 = nbSeq;
-          const u32 tl = fse_optimal_tablelog(FSELog, nbSeq, mx, 2);
-          if (count[lastCode] > 1) { count[lastCode]--; n1--; }
-          if (fse_normalize(S.seq.norm[k], tl, count, n1, mx, n1 >= 2048) <= 0) S.tblErr[k] = 1;
-          else {
-            const u32 h = fse_write_ncount(S.seq.ncount[k], S.seq.norm[k], mx, tl);
-            if (!h || fse_build_ctable(ct, S.seq.norm[k], mx, tl, S.seq.spread[k], S.seq.cumul[k])) S.tblErr[k] = 1;
-            S.ncountSize[k] = h;
-          }
-        }
-      }
-      __syncthreads();
       // repeat mode: bring the previous table into LDS (cooperative copy), all three streams checked uniformly
       for (int k = 0; k < 3; k++) {
         if (S.mode[k] == 3) {
@@ -804,12 +822,11 @@ zra_entropy_kernel(ZraEncArgs a, u32 block) {
       for (int k = 0; k < 3; k++) {
         const u32 sz = S.ncountSize[k];
         if (S.mode[k] == 2) lastNCount = op;
-        for (u32 i = tid; i < sz; i += ENT_THREADS) op[i] = S.seq.ncount[k][i];
+        for (u32 i = tid; i < sz; i += ENT_THREADS) op[i] = S.ncount[k][i];
         op += sz;
       }
-      EPROF(4)
       // ---- pass B: FSE state chains (3 lanes) + parallel packing, 1024 sequences per tile, last sequence first
-      u32 state = 0;                       // wave 0 lanes 0..2 carry their stream's state across tiles
+      u32 state = 0;                       // waves 0..2 carry their stream's state across tiles (wave-uniform)
       u32 carryBits = 0, carryVal = 0, bytesOut = 0;
       const u32 tlog[3] = {S.ct[0].tableLog, S.ct[1].tableLog, S.ct[2].tableLog};
       for (u32 t0 = 0; t0 < nbSeq && !tblErr; t0 += SEQ_TILE) {
@@ -830,31 +847,49 @@ zra_entropy_kernel(ZraEncArgs a, u32 block) {
         }
         __syncthreads();
         EPROF(5)
-        if (wave == 0 && lane < 3) {
-          // The state chain is the one dependency that cannot be broken: state -> stateTable[(state >> nb) + dfs] -> state. Everything
-          // else a step needs (the symbol, its deltaNbBits / deltaFindState) is loaded one and two steps ahead, so a step costs one LDS
-          // round trip instead of four dependent ones.
-          const ZraFseCTable* ct = &S.ct[lane];
-          const u8* const cd = S.seq.codes[lane];
-          u16* const ch = S.seq.chain[lane];
-          u32 rl = 0;
-          if (t0 == 0) { state = fse_init_state(ct, cd[0]); ch[0] = 0; rl = 1; }      // the block's last sequence: init only
-          if (ct->rle) { for (; rl < cntT; rl++) ch[rl] = 0; }
-          else if (rl < cntT) {
-            const u32 last = cntT - 1;
-            u32 sym1 = cd[min(rl + 1, last)];
-            u32 dnb = ct->deltaNbBits[cd[rl]]; i32 dfs = ct->deltaFindState[cd[rl]];
-            for (; rl < cntT; rl++) {
-              const u32 nb = (state + dnb) >> 16;
-              const u32 bits = state & ((1u << nb) - 1);
-              state = ct->stateTable[(state >> nb) + dfs];                              // critical load first
-              const u32 dnbN = ct->deltaNbBits[sym1]; const i32 dfsN = ct->deltaFindState[sym1];   // parameters of step rl+1
-              const u32 sym2 = cd[min(rl + 2, last)];                                  // symbol of step rl+2
-              ch[rl] = (u16)((nb << 12) | bits);
-              dnb = dnbN; dfs = dfsN; sym1 = sym2;
+        if (wave < 3) {
+          // The state chain of a stream — state -> stateTable[(state >> nb) + dfs] -> state — is serial, except across a symbol with ONE
+          // cell of the table (normalised count 1 or "less than 1"): a step over such a symbol emits the whole state and lands on the
+          // symbol's only state, whatever came before. Round 5: wave k runs stream k's chain of the tile on all 64 lanes, 8 steps per
+          // lane; a lane starts behind the last one-cell symbol in front of its steps (found with one wave-wide running maximum), from
+          // that symbol's state — or at the tile's first step, from the exact incoming state, when there is none. Exact by construction,
+          // no guessing; the wave takes as long as the longest stretch without such a symbol (100-250 steps of a tile's 512 on text-like
+          // input; the whole tile, as before, when a table has no one-cell symbol). The serial form (3 lanes, one LDS round trip per
+          // sequence) was 35 % of this kernel's time.
+          const ZraFseCTable* ct = &S.ct[wave];
+          const u8* const cd = S.seq.codes[wave];
+          u16* const ch = S.seq.chain[wave];
+          const u32 first = t0 == 0 ? 1u : 0u;                                          // the block's last sequence: init only
+          if (t0 == 0) { state = fse_init_state(ct, cd[0]); if (lane == 0) ch[0] = 0; }
+          if (ct->rle) { for (u32 rl = first + (u32)lane; rl < cntT; rl += 64) ch[rl] = 0; }
+          else if (cntT > first) {
+            constexpr u32 CH = SEQ_TILE / 64;
+            const u32 start = CH * (u32)lane, end = min(start + CH, cntT);
+            const bool act = start < cntT;
+            const u32 own0 = max(start, first);                                         // first step this lane records
+            const u32 tl_ = ct->tableLog, oneCell = (tl_ << 16) - (1u << tl_);          // deltaNbBits of a symbol with one cell
+            // the last one-cell step inside this lane's own steps (+1; 0: none), then the running maximum over the lanes below
+            u32 mine = 0;
+            for (u32 rl = own0; rl < end; rl++) if (ct->deltaNbBits[cd[rl]] == oneCell) mine = rl + 1;
+            u32 below = mine;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const u32 o = (u32)__shfl_up((int)below, d, 64); if (lane >= d) below = max(below, o); }
+            below = (u32)__shfl_up((int)below, 1, 64); if (lane == 0) below = 0;        // exclusive: steps before `start`
+            u32 st = state, s0 = first;
+            if (act && below) { s0 = below; st = ct->stateTable[ct->deltaFindState[cd[below - 1]] + 1]; }   // behind step below-1: its symbol's only state
+            if (act) {
+              for (u32 rl = s0; rl < end; rl++) {
+                const u32 sym = cd[rl];
+                const u32 d = ct->deltaNbBits[sym]; const i32 f = ct->deltaFindState[sym];
+                const u32 nb = (st + d) >> 16;
+                if (rl >= own0) ch[rl] = (u16)((nb << 12) | (st & ((1u << nb) - 1)));
+                st = ct->stateTable[(st >> nb) + f];
+              }
             }
+            const u32 nC = (cntT + CH - 1) / CH;
+            state = bcast(st, nC - 1);
           }
-          if (lastTile) S.finalState[lane] = state;
+          if (lastTile && lane == 0) S.finalState[wave] = state;
         }
         __syncthreads();
         EPROF(6)
@@ -958,6 +993,87 @@ zra_entropy_kernel(ZraEncArgs a, u32 block) {
       a.sizes[f] = pos;
     }
     st->outPos = pos;
+  }
+}
+
+// (a real call from the persistent kernel: inlined into its queue loop the body spilled 66-74 vector registers under the same 5-waves budget)
+__device__ __attribute__((noinline)) void entropy_frame_call(const ZraEncArgs& a, u32 f, u8* lits, u8* slot, EncShared& S) {
+  // (arguments arrive in vector registers: pin the wave-uniform ones to the scalar unit, or the frame's whole parameter set follows them)
+  f = (u32)__builtin_amdgcn_readfirstlane((int)f);
+  const u64 lp = (u64)lits, sp = (u64)slot;
+  lits = (u8*)(((u64)(u32)__builtin_amdgcn_readfirstlane((int)(lp >> 32)) << 32) | (u32)__builtin_amdgcn_readfirstlane((int)lp));
+  slot = (u8*)(((u64)(u32)__builtin_amdgcn_readfirstlane((int)(sp >> 32)) << 32) | (u32)__builtin_amdgcn_readfirstlane((int)sp));
+  entropy_frame(a, 0u, f, lits, slot, S);
+}
+
+// batch path: one workgroup per frame of the batch, launched per block round behind the batch's match-finder launch
+extern "C" __global__ void __launch_bounds__(ENT_THREADS, ZRA_ENT_WAVES)
+zra_entropy_kernel(ZraEncArgs a, u32 block) {
+  __shared__ EncShared S;
+  // This stage runs beside the match finder of the other scratch context, which fills most issue slots; the one-lane serial
+  // sections here are latency-critical. Raise the wave's issue priority so they are not queued behind match-finder waves.
+  __builtin_amdgcn_s_setprio(3);
+  const u32 f = blockIdx.x;
+  entropy_frame(a, block, f, a.lits + (size_t)f * a.litStride, a.slots + (size_t)f * a.slotStride, S);
+}
+
+// Persistent pipeline (round 5; single-block dfast frames): the workgroups of this kernel stay resident BESIDE the persistent match
+// finder — one per CU is what a CU's LDS and registers hold next to 18-20 match-finder waves — and take frames from a queue in frame
+// order: wait until the match finder has published the frame (its stamp in the block record), encode it into the slot ring, count it for
+// the host's scan + gather of the sub-batch. Rounds 1-4 launched one workgroup per frame and sub-batch instead; whether a workgroup found
+// room on a CU then depended on how the match finder's waves had happened to land (the "two states" of the launch time of rounds 2-4:
+// profiles/r05_experiments.md), and at one workgroup per CU the stage could not keep up with the match finder.
+// Every wait gives up after ~10 s of the 100 MHz clock (pipeAbort): the call fails, the GPU does not hang.
+extern "C" __global__ void __launch_bounds__(ENT_THREADS, ZRA_ENT_WAVES)
+zra_entropy_persist_kernel(ZraEncArgs a) {
+  __shared__ EncShared S;
+  __builtin_amdgcn_s_setprio(3);
+  const int tid = threadIdx.x;
+  u8* const lits = a.lits + (size_t)blockIdx.x * a.litStride;
+  u64 tStart = 0, tWait = 0; u32 nDone = 0;            // (thread 0: telemetry)
+  if (tid == 0 && a.mfTele) {
+    const u32 hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;
+    atomicAdd((unsigned long long*)&a.mfTele[ZRA_TELE_ENT + 8 + ((xcc << 8) | (((hw >> 13) & 7u) << 5) | (((hw >> 12) & 1u) << 4) | ((hw >> 8) & 15u))], 1ull);
+    tStart = wall_clock64();
+  }
+  for (;;) {
+    __syncthreads();                                   // (S.sc of the frame before is no longer read)
+    if (tid == 0) {
+      u32 f = atomicAdd(a.entQueue, 1u);
+      if (f < a.nFrames) {
+        const u64 t0 = wall_clock64();
+        const u32 j = f / a.entSubFrames, ringSubs = max(1u, a.slotRing / a.entSubFrames);   // (a call of less than a sub-batch: one slot per frame, nothing to wait for)
+        // the slot of this frame was last used by the frame slotRing before it: gathered?
+        while (j >= ringSubs && __hip_atomic_load(a.gatherDone, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) + ringSubs <= j) {
+          __builtin_amdgcn_s_sleep(32);
+          if (__hip_atomic_load(a.pipeAbort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) || wall_clock64() - t0 > 1000000000ull) { atomicExch(a.pipeAbort, 2u); f = 0xFFFFFFFFu; break; }
+        }
+        while (f != 0xFFFFFFFFu && __hip_atomic_load(&a.blockOut[f].ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != a.readyStamp) {
+          __builtin_amdgcn_s_sleep(32);
+          if (__hip_atomic_load(a.pipeAbort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) || wall_clock64() - t0 > 1000000000ull) { atomicExch(a.pipeAbort, 2u); f = 0xFFFFFFFFu; break; }
+        }
+        tWait += wall_clock64() - t0; nDone++;
+      } else f = 0xFFFFFFFFu;
+      S.sc[15] = f;
+    }
+    __syncthreads();
+    const u32 f = (u32)__builtin_amdgcn_readfirstlane((int)S.sc[15]);   // (wave-uniform, and known to be: the frame's parameters stay on the scalar unit)
+    if (f == 0xFFFFFFFFu) {
+      // out of frames — or a wait gave up: then the host's stream waits on the sub-batch counters are let go (scan and gather return at once)
+      if (tid == 0 && __hip_atomic_load(a.pipeAbort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        for (u32 j = 0; j * a.entSubFrames < a.nFrames; j++) atomicOr(&a.entDone[j], 0x40000000u);
+      if (tid == 0 && a.mfTele && nDone > 0) {
+        u64* const t = a.mfTele + ZRA_TELE_ENT;
+        atomicAdd((unsigned long long*)&t[0], 1ull); atomicAdd((unsigned long long*)&t[1], wall_clock64() - tStart);
+        atomicAdd((unsigned long long*)&t[2], tWait); atomicAdd((unsigned long long*)&t[3], (unsigned long long)nDone);
+      }
+      return;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // what the match finder wrote for this frame (sequences, block record)
+    entropy_frame_call(a, f, lits, a.slots + (size_t)(f % a.slotRing) * a.slotStride, S);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // the slot and the frame's size, before the count
+    __syncthreads();
+    if (tid == 0) atomicAdd(&a.entDone[f / a.entSubFrames], 1u);
   }
 }
 

@@ -444,9 +444,9 @@ template <u32 MLS, bool FLAGS>
 __device__ u32 mf_dfast_lean(const ZraEncParams& P, u32* HL, u32* HS, const u8* src, u32 bs, u32 be, u32* rep, u64* seqs, u32* nOut,
                              const LeanLds& W, int lane, u32 ib, const u8* flgIn) {
   const u8* const flg = FLAGS ? flgIn : nullptr;       // (the kernel without flags carries none of their code or registers)
-  // flg (round 4, zra_lk_prepass_kernel's flags mode; nullptr: none): one byte per position, bit 0 / 1 = the position's long bucket has an
-  // earlier / a later position of the frame, bit 2 / 3 = its short bucket. A lookup without an earlier position would read the cleared
-  // cell; an insertion without a later position is never looked up: both are skipped — about half of the table's fabric requests.
+  // flg (df_later_flags' masks, read through df_flags_at; nullptr: none): per position bit 1 / bit 3 = its long / short bucket has a later
+  // position of the frame. An insertion without one is never looked up: the table write is skipped — half of the table's write requests.
+  // (Bits 0 / 2, "has an earlier position", are always set: a lookup's table read is decided by the LDS filter alone.)
   DfHash<MLS> H; H.init(P.hashLog, P.chainLog, ib);
   const u32 idxMask = ~H.tagMask;
   // block-level scalars arrive in VGPRs (vector loads of the frame state): pin them to SGPRs once so that the whole
@@ -710,443 +710,8 @@ __device__ u32 mf_dfast_lean(const ZraEncParams& P, u32* HL, u32* HS, const u8* 
 }
 
 
-// ================================================================================================
-// Mask-resolve dfast (round 3). Same exactness argument as the window-resolve parse above, restructured so that a sequence costs bit
-// operations on wave-uniform masks instead of a memory round trip, and a window costs one build (tools/model/dfast_mask_model.c is the
-// CPU restatement of THIS function, fuzzed against the oracle):
-//   * stride-1 windows sit on a fixed 64-position grid (lanes below the parse position are idle), so the source bytes of the next
-//     window are loaded one window ahead;
-//   * every lane with a table candidate loads 72 candidate bytes ONCE and keeps the byte-equality mask E against its own 72 bytes plus
-//     the backward equal count: a match length is a count of trailing ones; the rep-offset tests of the positions behind a match, the
-//     immediate-repcode test and repcode match lengths are shifts of 128-bit equality streams (EQA for offset_1, EQB for offset_2: built
-//     from byte compares at window build, replaced by the winning lane's E after a match);
-//   * lanes that share a bucket with another lane of the window are not a reason to cut the window: they are flagged (LDS slot
-//     collisions, a superset) and settled when the parse reaches them — against the insertions the window has made so far;
-//   * in-window insertions are two lane masks stored once per window (the latest position of a bucket wins); insertions behind the
-//     window's end become lanes of the next window and are stored ahead of its gather.
-struct S128 { u64 lo, hi; };
-// (e1:e0 as a 72-bit value) << sh, sh in [0, 64]
-__device__ __forceinline__ S128 s_shl72(u64 e0, u32 e1, u32 sh) {
-  S128 r;
-  if (sh == 0) { r.lo = e0; r.hi = e1; }
-  else if (sh >= 64) { r.lo = 0; r.hi = e0; }
-  else { r.lo = e0 << sh; r.hi = (e0 >> (64 - sh)) | ((u64)e1 << sh); }
-  return r;
-}
-// bits [x, x+64) of the stream (zero beyond bit 127)
-__device__ __forceinline__ u64 s_from(const S128& s, u32 x) {
-  return x == 0 ? s.lo : x >= 128 ? 0 : x >= 64 ? (s.hi >> (x - 64)) : ((s.lo >> x) | (s.hi << (64 - x)));
-}
-// consecutive ones from bit x (stops at bit 128)
-__device__ __forceinline__ u32 s_run(const S128& s, u32 x) {
-  const u64 w = ~s_from(s, x);
-  if (w) return (u32)__builtin_ctzll(w);
-  return 64 + (u32)__builtin_ctzll(~s_from(s, x + 64));
-}
-// bit l: stream bits l+1 .. l+4 all set (the 4-byte repcode test of the position of lane l)
-__device__ __forceinline__ u64 s_rephits(const S128& s) { return s_from(s, 1) & s_from(s, 2) & s_from(s, 3) & s_from(s, 4); }
-__device__ __forceinline__ bool s_four(const S128& s, u32 x) { return (s_from(s, x) & 0xF) == 0xF; }
-
 struct __attribute__((packed, aligned(1))) quad_u { u32 x, y, z, w; };
 __device__ __forceinline__ uint4 ld128(const u8* p) { const quad_u q = *(const quad_u*)p; return make_uint4(q.x, q.y, q.z, q.w); }
-// 4 bits: bytes of a and b equal
-__device__ __forceinline__ u32 eq_nib(u32 a, u32 b) {
-  const u32 t = a ^ b;
-  const u32 u = ((t & 0x7f7f7f7fu) + 0x7f7f7f7fu) | t;       // bit 7 of every byte: byte differs
-  const u32 n = ~u & 0x80808080u;
-  return (n * 0x00204081u) >> 28;
-}
-__device__ __forceinline__ u32 eq_nib4(uint4 a, uint4 b) { return eq_nib(a.x, b.x) | (eq_nib(a.y, b.y) << 4) | (eq_nib(a.z, b.z) << 8) | (eq_nib(a.w, b.w) << 12); }
-
-// bucket indices and tags with the short hash's width as a run-time value (one copy of the parse for minMatch 4..7); built from one
-// packed word (hashLog | chainLog << 8 | index bits << 16 | minMatch << 24) where it is used, so that nothing of it stays in scalar
-// registers while a window is resolved
-struct DfHashR {
-  u32 shL, shS, shT, ib, tagMask, mls, shV; u64 primeS;
-  __device__ __forceinline__ void init(u32 packed) {
-    const u32 hlog = packed & 255, clog = (packed >> 8) & 255;
-    ib = (packed >> 16) & 255; mls = packed >> 24;
-    tagMask = ~((1u << ib) - 1u); shL = 64 - hlog; shS = (mls == 4 ? 32 : 64) - clog; shT = shL - (32 - ib);
-    shV = 64 - 8 * mls;
-    primeS = mls == 5 ? 889523592379ULL : mls == 6 ? 227718039650203ULL : 58295818150454627ULL;
-  }
-  __device__ __forceinline__ void both(u64 v, u32& bL, u32& bS, u32& tL, u32& tS) const {
-    const u64 pl = v * 0xCF1BBCDCB7A56463ULL;
-    bL = (u32)(pl >> shL); tL = (u32)(pl >> shT) << ib;
-    const u32 p4 = (u32)v * 2654435761u;
-    tS = p4 & tagMask;
-    if (mls == 4) bS = p4 >> shS;
-    else bS = (u32)(((v << shV) * primeS) >> shS);
-  }
-};
-// lane l of `old` := val (val and l wave-uniform): v_writelane_b32 with the lane select in M0 (gfx9 reads one SGPR per VALU
-// instruction, and the compiler offers no builtin)
-__device__ __forceinline__ u32 wrlane(u32 old, u32 val, u32 l) {
-  asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(old) : "s"(val), "s"(l) : "m0");
-  return old;
-}
-
-__device__ u32 mf_dfast_mask(const ZraEncParams& P, u32* HL, u32* HS, const u8* src, u32 fsize, u32 bs, u32 be, u32* rep, u64* seqs, u32* nOut,
-                             const LeanLds& W, int lane, u32 ib) {
-  const u32 mlsc = P.minMatch < 4 ? 4u : P.minMatch > 7 ? 7u : P.minMatch;
-  const u32 hpack = rfl(P.hashLog | (P.chainLog << 8) | (ib << 16) | (mlsc << 24));
-  bs = rfl(bs); be = rfl(be); fsize = rfl(fsize);
-  u32 o1 = rfl(rep[0]), o2 = rfl(rep[1]), saved;
-  u32 anchor = bs, nseq = 0;
-  const u32 ilimit = be >= 8 ? be - 8 : 0;
-  u32 ip = mf_prologue(bs, o1, o2, saved);
-  u32 sqLo = 0, sqHi = 0;
-  u64 pendL = 0, pendS = 0;                           // insertions handed over by the previous window: lanes of this window's chunk
-  u32 nxtG = 0xFFFFFFFFu; u64 v8n = 0;                 // source bytes of chunk nxtG, loaded one window ahead
-  PROF_DECL
-  auto emit = [&](u32 ll, u32 ml, u32 offVal) {
-    const u64 q = (u64)ll | ((u64)ml << 20) | ((u64)offVal << 40);
-    sqLo = wrlane(sqLo, (u32)q, nseq & 63); sqHi = wrlane(sqHi, (u32)(q >> 32), nseq & 63);
-    nseq++;
-    if ((nseq & 63) == 0) seqs[nseq - 64 + (u32)lane] = (u64)sqLo | ((u64)sqHi << 32);
-  };
-  while (ip < ilimit) {
-    // ---------------------------------------------------------------- window build
-    const u32 run = ip - anchor;
-    u32 s = 1, g, l0, l1;
-    if (run < 256) { g = ip & ~63u; l0 = ip - g; l1 = min(min(64u, l0 + 256u - run), ilimit - g); }
-    else { s = (run >> 8) + 1; g = ip; l0 = 0; l1 = min(64u, min((256 * s - run + s - 1) / s, (ilimit - ip + s - 1) / s)); }
-    const u32 l1w = s == 1 ? l1 : 0u;                  // lanes that ARE consecutive positions (none in a stride window)
-    const u64 AM = (l1 >= 64 ? ~0ull : (bit64(l1) - 1)) & ~(bit64(l0) - 1);
-    const u32 p = g + (u32)lane * s;
-    const bool hashed = p + 8 <= be;
-    u64 v8;
-    if (s == 1 && g == nxtG) v8 = v8n; else v8 = hashed ? ld64(src + p) : 0;
-    S128 EQA, EQB; EQA.lo = EQA.hi = EQB.lo = EQB.hi = 0;
-    u32 hiA = 0, hiB = 0;                               // stream bits known (0 in a stride window: everything from memory)
-    u64 RHa = 0;
-    if (s == 1) {
-      const u32 q1 = p + 64;
-      v8n = q1 + 8 <= be ? ld64(src + q1) : 0; nxtG = g + 64;
-      // equality streams of the two repeat offsets over the positions g + [0, 128) (bits at and beyond the block end are 0)
-      const bool v0 = p < be, v1 = q1 < be;
-      const u32 c0 = v0 ? src[p] : 0x100u, c1 = v1 ? src[q1] : 0x100u;
-      const u32 a0 = (v0 && o1 > 0 && p >= o1) ? src[p - o1] : 0x200u, a1 = (v1 && o1 > 0 && q1 >= o1) ? src[q1 - o1] : 0x200u;
-      const u32 b0 = (v0 && o2 > 0 && p >= o2) ? src[p - o2] : 0x200u, b1 = (v1 && o2 > 0 && q1 >= o2) ? src[q1 - o2] : 0x200u;
-      EQA.lo = __ballot(c0 == a0); EQA.hi = __ballot(c1 == a1);
-      EQB.lo = __ballot(c0 == b0); EQB.hi = __ballot(c1 == b1);
-      hiA = hiB = 128;
-      RHa = s_rephits(EQA);
-    } else {
-      const bool rv = lane_in(AM) && o1 > 0 && p + 1 >= o1;
-      const u32 repVal = rv ? ld32(src + p + 1 - o1) : 0;
-      RHa = __ballot(rv && repVal == (u32)(v8 >> 8));
-    }
-    PROF(0) PROF_CNT(12)
-    u32 bL, bS, valL, valS, tagMask;
-    {
-      DfHashR H; H.init(hpack); tagMask = H.tagMask;
-      u32 tL, tS; H.both(v8, bL, bS, tL, tS); valL = (p + 1) | tL; valS = (p + 1) | tS;
-    }
-    if (!hashed) { bL = 0xFFFFFFFFu; bS = 0xFFFFFFFFu; }
-    // D: lanes whose LDS slot is shared with another lane of the window (a superset of the lanes that share a bucket): winners
-    // learn of the collision from the marker the losers leave
-    u32 dflag;
-    {
-      u8* const dL = W.dup; u8* const dS = W.dup + W.dupSlots;
-      const u32 dmask = W.dupSlots - 1;
-      const bool part = lane_in(AM | pendL | pendS);
-      if (part) { dL[bL & dmask] = (u8)lane; dS[bS & dmask] = (u8)lane; }
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-      const bool loseL = part && dL[bL & dmask] != (u8)lane, loseS = part && dS[bS & dmask] != (u8)lane;
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-      if (loseL) dL[bL & dmask] = 0xFF;
-      if (loseS) dS[bS & dmask] = 0xFF;
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-      dflag = (part && (loseL || loseS || dL[bL & dmask] == 0xFF || dS[bS & dmask] == 0xFF)) ? 1u : 0u;
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-    }
-    // masked table stores: of the lanes of a mask that share a bucket only the latest position stores
-    auto store_masked = [&](u64 mkL, u64 mkS) {
-      const u64 D = __ballot(dflag != 0);
-      u64 cl = mkL & D;
-      while (cl) {
-        const u32 l = (u32)__builtin_ctzll(cl); cl &= cl - 1;
-        if (__ballot(bL == bcast(bL, l)) & mkL & ~((bit64(l) << 1) - 1)) mkL &= ~bit64(l);
-      }
-      cl = mkS & D;
-      while (cl) {
-        const u32 l = (u32)__builtin_ctzll(cl); cl &= cl - 1;
-        if (__ballot(bS == bcast(bS, l)) & mkS & ~((bit64(l) << 1) - 1)) mkS &= ~bit64(l);
-      }
-      const u32 gL = bL >> W.shL, gS = bS >> W.shS;
-      if (lane_in(mkL)) { TST(HL + bL, valL); atomicOr(&W.bmL[gL >> 5], 1u << (gL & 31)); }
-      if (lane_in(mkS)) { TST(HS + bS, valS); atomicOr(&W.bmS[gS >> 5], 1u << (gS & 31)); }
-    };
-    if (pendL | pendS) { store_masked(pendL, pendS); pendL = 0; pendS = 0; __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); }
-    PROF(1)
-    const bool active = lane_in(AM);
-    u32 mL = 0, mS = 0;
-    if (active) {
-      const u32 gL = bL >> W.shL, gS = bS >> W.shS;
-      const bool needL = (W.bmL[gL >> 5] >> (gL & 31)) & 1, needS = (W.bmS[gS >> 5] >> (gS & 31)) & 1;
-      const u32 rL = needL ? TLD(HL + bL) : 0u, rS = needS ? TLD(HS + bS) : 0u;
-      mL = (((rL ^ valL) & tagMask) == 0) ? (rL & ~tagMask) : 0u;
-      mS = (((rS ^ valS) & tagMask) == 0) ? (rS & ~tagMask) : 0u;
-    }
-    PROF(2)
-    // candidate masks: long candidate first, the short one when there is no long one (or, second pass, when the long one fails its 8 bytes)
-    const bool hasL = mL > 1, hasS = mS > 1;
-    bool want = hasL || hasS, isLc = hasL;
-    u32 cand = hasL ? mL - 1 : mS - 1;
-    u32 e0lo = 0, e0hi = 0, ex = 0;                     // ex: E bits 64..71 | backward equal count << 8 | backward bytes compared << 12 | bytes known << 16
-    bool lhit = false, shit = false;
-    const bool fastE = g + 63 * s + 72 <= fsize;       // every lane's 72 bytes lie inside the frame
-    const bool clampE = g + 63 * s + 72 > be;          // ... but not inside the block: clear the bits at and beyond the block end
-#pragma nounroll
-    for (int pass = 0; pass < 2; pass++) {
-      if (want) {
-        const u8* pp = src + p; const u8* mp = src + cand;
-        u32 kn, e1;
-        if (fastE) {
-          const uint4 a0 = ld128(pp), a1 = ld128(pp + 16), a2 = ld128(pp + 32), a3 = ld128(pp + 48);
-          const uint4 b0 = ld128(mp), b1 = ld128(mp + 16), b2 = ld128(mp + 32), b3 = ld128(mp + 48);
-          const u64 a4 = ld64(pp + 64), b4 = ld64(mp + 64);
-          e0lo = eq_nib4(a0, b0) | (eq_nib4(a1, b1) << 16);
-          e0hi = eq_nib4(a2, b2) | (eq_nib4(a3, b3) << 16);
-          e1 = eq_nib((u32)a4, (u32)b4) | (eq_nib((u32)(a4 >> 32), (u32)(b4 >> 32)) << 4);
-          kn = 72;
-        } else {
-          // the frame's last windows: chunks [0,8) [8,16) [16,32) [32,48) [48,64) [64,72), each only if it lies inside the frame
-          kn = p + 72 <= fsize ? 72 : p + 64 <= fsize ? 64 : p + 48 <= fsize ? 48 : p + 32 <= fsize ? 32 : p + 16 <= fsize ? 16 : 8;
-          e0lo = 0; e0hi = 0; e1 = 0;
-          for (u32 j = 0; j < kn; j++) {
-            const u32 eq = pp[j] == mp[j];
-            if (j < 32) e0lo |= eq << j; else if (j < 64) e0hi |= eq << (j - 32); else e1 |= eq << (j - 64);
-          }
-        }
-        if (clampE || !fastE) {
-          const u32 rem = be - p;                       // >= 8
-          if (rem < 72) {
-            if (rem < 32) e0lo &= (1u << rem) - 1;
-            if (rem <= 32) e0hi = 0; else if (rem < 64) e0hi &= (1u << (rem - 32)) - 1;
-            if (rem <= 64) e1 = 0; else e1 &= (1u << (rem - 64)) - 1;
-          }
-        }
-        u32 bk = 0, bkK = 0;
-        if (cand >= 8) {
-          const u64 t = ld64(pp - 8) ^ ld64(mp - 8);
-          bk = t ? ((u32)__builtin_clzll(t) >> 3) : 8; bkK = 8;
-        }
-        ex = e1 | (bk << 8) | (bkK << 12) | (kn << 16);
-      }
-      const bool okL = want && isLc && (e0lo & 0xFF) == 0xFF;
-      const bool okS = want && !isLc && (e0lo & 0xF) == 0xF;
-      lhit = lhit || okL; shit = shit || okS;
-      const bool again = want && isLc && !okL && hasS;
-      if (!__ballot(again)) break;
-      want = again; if (again) { cand = mS - 1; isLc = false; }
-    }
-    u64 LH = __ballot(active && lhit), SH = __ballot(active && shit);
-    PROF(3)
-    // ---------------------------------------------------------------- resolve the window
-    u64 insL = 0, insS = 0, Dun = __ballot(dflag != 0) & AM;   // Dun: shared-slot lanes whose candidates are not settled yet
-    u32 laterV = 0, nLater = 0;                         // insertions behind the window: lane k = position | long << 30 | short << 31
-    u32 cur = l0;
-    const u32 v8lo = (u32)v8, v8hi = (u32)(v8 >> 32);
-    // the candidate of position q (origin of the mask) becomes c: equality mask and backward count by the whole wave, written into
-    // lane d's registers (one small round trip; c lies inside or just before the window, so the lines are in the vector cache)
-    auto rewrite_lane = [&](u32 d, u32 q, u32 c) {
-      const u32 qa = q + (u32)lane;
-      const bool fv = qa < be;
-      const u32 x0 = fv ? src[qa] : 0x100u, y0 = fv ? src[c + (u32)lane] : 0x200u;
-      const bool bv = (u32)lane < 8 && (u32)lane < c;
-      const u32 x1 = bv ? src[q - 1 - (u32)lane] : 0x100u, y1 = bv ? src[c - 1 - (u32)lane] : 0x200u;
-      const u64 e = __ballot(x0 == y0);
-      const u64 nb = ~__ballot(x1 == y1);
-      const u32 bk = min(8u, (u32)__builtin_ctzll(nb | 0x100ull)), bkK = min(8u, c);
-      cand = wrlane(cand, c, d); e0lo = wrlane(e0lo, (u32)e, d); e0hi = wrlane(e0hi, (u32)(e >> 32), d);
-      ex = wrlane(ex, (bk << 8) | (bkK << 12) | (64u << 16), d);
-      return e;
-    };
-    // settle lane d's table candidates against the insertions this window has made below lane `lim`
-    auto settle = [&](u32 d, u32 lim, bool doS) {
-      const u64 bel = lim ? (~0ull >> (64 - lim)) : 0ull;
-      const u64 cmL = __ballot(bL == bcast(bL, d)) & insL & bel;
-      const u64 cmS = doS ? (__ballot(bS == bcast(bS, d)) & insS & bel) : 0ull;
-      if (!(cmL | cmS)) return;
-      PROF_CNT(17)
-      u32 nL = bcast(mL, d), nS = bcast(mS, d);
-      if (cmL) { const u32 i = 63u - (u32)__builtin_clzll(cmL); nL = ((bcast(valL, i) ^ bcast(valL, d)) & tagMask) == 0 ? g + i * s + 1 : 0u; }
-      if (cmS) { const u32 i = 63u - (u32)__builtin_clzll(cmS); nS = ((bcast(valS, i) ^ bcast(valS, d)) & tagMask) == 0 ? g + i * s + 1 : 0u; }
-      const bool wasL = (LH >> d) & 1;
-      const u32 pd = g + d * s;
-      if (cmL) {
-        LH &= ~bit64(d);
-        if (nL > 1 && (rewrite_lane(d, pd, nL - 1) & 0xFF) == 0xFF) LH |= bit64(d);
-      }
-      if (!((LH >> d) & 1) && doS && (cmS || (cmL && wasL))) {
-        SH &= ~bit64(d);
-        if (nS > 1 && (rewrite_lane(d, pd, nS - 1) & 0xF) == 0xF) SH |= bit64(d);
-      }
-    };
-    auto later = [&](u32 pos, u32 flags) { laterV = wrlane(laterV, pos | flags, nLater); nLater++; };
-    // insertions behind the window's end: lanes of the next window's chunk (toNext), or stored now — in position order per table
-    auto flush_later = [&](bool toNext) {
-      const bool nextS1 = toNext && ip < ilimit && ip - anchor < 256;
-      const u32 gN = ip & ~63u;
-      const bool mine = (u32)lane < nLater;
-      const u32 e = mine ? laterV : 0u;
-      const u32 q = e & 0x3FFFFFFFu;
-      const bool inNext = mine && nextS1 && q >= gN && q < gN + 64;
-      u64 slowM = __ballot(mine && !inNext);
-      u64 nm = __ballot(inNext);
-      while (nm) {                                        // lane k holds entry k; its bit in the pending masks is bit (q - gN)
-        const u32 k = (u32)__builtin_ctzll(nm); nm &= nm - 1;
-        const u32 ek = bcast(e, k); const u32 b = (ek & 0x3FFFFFFFu) - gN;
-        if (ek & (1u << 30)) pendL |= bit64(b);
-        if (ek & (2u << 30)) pendS |= bit64(b);
-      }
-      if (slowM) {
-        PROF_CNT(18)
-        DfHashR H; H.init(hpack);
-        const u64 xv = lane_in(slowM) ? ld64(src + q) : 0;
-        u32 xbL, xbS, xtL, xtS; H.both(xv, xbL, xbS, xtL, xtS);
-        while (slowM) {                                   // one store instruction per entry: entries may share a bucket, the later one wins
-          const u32 k = (u32)__builtin_ctzll(slowM); slowM &= slowM - 1;
-          if ((u32)lane == k) {
-            if (e & (1u << 30)) { TST(HL + xbL, (q + 1) | xtL); W.markL(xbL); }
-            if (e & (2u << 30)) { TST(HS + xbS, (q + 1) | xtS); W.markS(xbS); }
-          }
-          asm volatile("" ::: "memory");
-        }
-      }
-      nLater = 0;
-    };
-    for (;;) {
-      const u64 live = AM & (~0ull << cur);
-      const u64 ev = ((RHa | LH | SH) | Dun) & live;     // first event: a hit lane or a lane that is not settled yet
-      if (!ev) { insL |= live; insS |= live; ip = g + l1 * s; PROF(4) break; }
-      const u32 f = (u32)__builtin_ctzll(ev);
-      const u64 fb = bit64(f);
-      const bool isRep = (RHa & fb) != 0;                // (a repcode hit needs no table: it wins on an unsettled lane too)
-      if (__builtin_expect((Dun & fb) != 0 && !isRep, 0)) {
-        const u64 vis = live & (fb - 1);                 // the lanes before f are visited without a hit
-        insL |= vis; insS |= vis;
-        settle(f, f, true); Dun &= ~fb; cur = f;
-        continue;
-      }
-      { const u64 upto = live & ((fb << 1) - 1); insL |= upto; insS |= upto; }
-      const u32 top = g + f * s;
-      u32 ml, offVal = 1;
-      ip = top;
-      if (isRep) {
-        ip = top + 1;
-        const u32 x0 = ip - g;
-        ml = s_run(EQA, x0);
-        if (__builtin_expect(x0 + ml >= hiA && g + hiA < be, 0)) { PROF_CNT(16) ml = wave_count_eq(src, ip + 4, ip + 4 - o1, be, lane) + 4; }
-      } else {
-        u32 fE = f;
-        if (!(LH & fb)) {
-          // short hit: the long table is probed at top + 1
-          if (f + 1 < l1w) {
-            if (__builtin_expect((Dun >> (f + 1)) & 1, 0)) { settle(f + 1, f + 1, false); Dun &= ~(fb << 1); }   // the probe reads the long table only
-            insL |= fb << 1;
-            if (LH & (fb << 1)) { fE = f + 1; ip = top + 1; }
-          } else {
-            PROF_CNT(15)
-            // top + 1 is not a lane of the window: its bucket comes from memory; what the long table holds there is the latest
-            // insertion of this window into that bucket, else the table itself
-            DfHashR H; H.init(hpack);
-            const u64 v9 = (u64)rfl(ld32(src + top + 1)) | ((u64)rfl(ld32(src + top + 5)) << 32);
-            u32 b3, bx, t3, tx; H.both(v9, b3, bx, t3, tx);
-            const u64 cm = __ballot(bL == b3) & insL;
-            u32 m3;
-            if (cm) { const u32 i = 63u - (u32)__builtin_clzll(cm); m3 = ((bcast(valL, i) & tagMask) == t3) ? g + i * s + 1 : 0u; }
-            else { const u32 r3 = rfl(TLD(HL + b3)); m3 = ((r3 & tagMask) == t3) ? (r3 & ~tagMask) : 0u; }
-            later(top + 1, 1u << 30);
-            if (m3 > 1 && (rewrite_lane(f, top + 1, m3 - 1) & 0xFF) == 0xFF) ip = top + 1;   // lane f now holds the mask of top + 1
-            else if (m3 > 1) {                           // no long match at top + 1: lane f gets the mask of its own short candidate back
-              const u32 cS = bcast(mS, f) - 1;
-              (void)rewrite_lane(f, top, cS);
-            }
-          }
-        }
-        PROF(5)
-        const u32 m = bcast(cand, fE);
-        const u64 e0 = (u64)bcast(e0lo, fE) | ((u64)bcast(e0hi, fE) << 32);
-        const u32 x = bcast(ex, fE);
-        const u32 e1 = x & 0xFF, kn = x >> 16;
-        const u32 bk = (x >> 8) & 15, bkK = (x >> 12) & 15;
-        ml = e0 != ~0ull ? (u32)__builtin_ctzll(~e0) : 64u + (u32)__builtin_ctz(~e1);
-        const u32 lim = min(kn, be - ip);
-        if (__builtin_expect(ml >= lim && ip + lim < be, 0)) { PROF_CNT(13) ml = lim + wave_count_eq(src, ip + lim, m + lim, be, lane); }
-        const u32 blim = min(ip - anchor, m);
-        u32 back = min(bk, blim);
-        if (__builtin_expect(bk == bkK && blim > bkK, 0)) { PROF_CNT(14) back = wave_count_back(src, ip, m, anchor, lane); }
-        PROF(6)
-        const u32 off = ip - m;
-        // streams: offset_2 takes over offset_1's, offset_1's comes from the mask (known for kn bytes from ip on)
-        EQB = EQA; hiB = hiA;
-        {
-          const u32 xE = ip - g;
-          EQA = s_shl72(e0, e1, xE);
-          hiA = l1w ? ((ip + kn >= be) ? 128u : min(128u, xE + kn)) : 0u;
-          RHa = l1w ? s_rephits(EQA) : 0ull;
-        }
-        ip -= back; ml += back;
-        o2 = o1; o1 = off; offVal = off + 3;
-      }
-      emit(ip - anchor, ml, offVal);
-      ip += ml; anchor = ip;
-      PROF(7)
-      if (ip > ilimit) break;
-      // ---- complementary insertions (top+2 into both tables, ip-2 long, ip-1 short) and the immediate repcode test
-      const u32 x = ip - g;
-      if (f + 2 < l1w) { insL |= fb << 2; insS |= fb << 2; } else later(top + 2, 3u << 30);
-      if (x - 2 < l1w) insL |= bit64(x - 2); else later(ip - 2, 1u << 30);
-      if (x - 1 < l1w) insS |= bit64(x - 1); else later(ip - 1, 2u << 30);
-      bool rephit;
-      if (o2 == 0) rephit = false;
-      else if (x + 4 <= hiB) rephit = s_four(EQB, x);
-      else rephit = rfl(ld32(src + ip)) == rfl(ld32(src + ip - o2));
-      while (__builtin_expect(rephit, 0)) {
-        const u32 xx = ip - g;
-        u32 rl = 0; bool slow = true;
-        if (xx + 4 <= hiB) { rl = s_run(EQB, xx); slow = (xx + rl >= hiB) && (g + hiB < be); }
-        if (slow) { PROF_CNT(16) rl = wave_count_eq(src, ip + 4, ip + 4 - o2, be, lane) + 4; }
-        { const u32 t = o2; o2 = o1; o1 = t; const S128 ts = EQA; EQA = EQB; EQB = ts; const u32 th = hiA; hiA = hiB; hiB = th; RHa = l1w ? s_rephits(EQA) : 0ull; }
-        if (xx < l1w) { insL |= bit64(xx); insS |= bit64(xx); }
-        else {
-          if (nLater >= 60) { store_masked(insL, insS); insL = 0; insS = 0; flush_later(false); }   // (a very long run of repcode sequences behind the window)
-          later(ip, 3u << 30);
-        }
-        emit(0, rl, 1);
-        ip += rl; anchor = ip;
-        if (!(ip <= ilimit && o2 > 0)) break;
-        const u32 xn = ip - g;
-        if (xn + 4 <= hiB) rephit = s_four(EQB, xn);
-        else rephit = rfl(ld32(src + ip)) == rfl(ld32(src + ip - o2));
-      }
-      PROF(8)
-      if (ip >= g + l1w || ip >= ilimit) break;
-      cur = ip - g;
-      if (__builtin_expect(hiA < l1 + 4 && o1 > 0, 0)) { // the rest of the window needs stream bits up to l1 + 3: from memory
-        const u32 q1 = p + 64;
-        const bool v0 = p < be && p >= o1, v1 = q1 < be && q1 >= o1;
-        const u32 c0 = v0 ? src[p] : 0x100u, a0 = v0 ? src[p - o1] : 0x200u;
-        const u32 c1 = v1 ? src[q1] : 0x100u, a1 = v1 ? src[q1 - o1] : 0x200u;
-        EQA.lo = __ballot(c0 == a0); EQA.hi = __ballot(c1 == a1);
-        hiA = 128; RHa = s_rephits(EQA);
-      }
-    }
-    // ---- the window's insertions, then those behind its end: lanes of the next window's chunk, or stored now
-    store_masked(insL, insS);
-    if (nLater) flush_later(true);
-    PROF(9)
-  }
-  if (nseq & 63) { if ((u32)lane < (nseq & 63)) seqs[(nseq & ~63u) + (u32)lane] = (u64)sqLo | ((u64)sqHi << 32); }
-  PROF(10) PROF_END
-  rep[0] = o1 ? o1 : saved; rep[1] = o2 ? o2 : saved;
-  *nOut = nseq;
-  return be - anchor;
-}
-
 
 // ================================================================================================
 // Wave-cooperative hash chain (greedy / lazy / lazy2, levels 5-10), bit-exact with mf_lazy + HC::search above.
@@ -1649,7 +1214,7 @@ __device__ __forceinline__ void df_later_flags(const u8* src, u32 fsize, u32 hlo
 // there — every source access of the parse (hash input, repcode streams, candidate compares, extensions) is an LDS access; only the
 // table gathers go to memory. A lone frame is one dependent chain of round trips: this shortens most of them from memory latency to
 // LDS latency. One or two frames per CU by LDS, so it is a latency mode, not the throughput kernel.
-template <bool MASK, bool FLAGS, bool LSRC = false>
+template <bool FLAGS, bool LSRC = false>
 __device__ __forceinline__ void mf_dfast_body(const ZraEncArgs& a, u32 block, u32 only, u32 onlySlot, const ZraFlagArgs* g = nullptr) {
   const int lane = threadIdx.x;
   // dynamic LDS: [LSRC: source bytes, (a.mfFilter >> 16) * 64][dup slots 2 x dupSlots x 4 B][filter L][filter S]; geometry chosen by the host
@@ -1663,8 +1228,8 @@ __device__ __forceinline__ void mf_dfast_body(const ZraEncArgs& a, u32 block, u3
   const bool persistent = a.mfQueue != nullptr;
   // launch telemetry (persistent launches): where this wave sits and its shader cycles against the constant 100 MHz clock
   const bool tele = persistent && a.mfTele != nullptr;
-  // (start values parked in the 64 spare bytes behind the filter: nothing of this stays in registers while frames are parsed)
-  u32* const tl = W.bmL + ((1u << max(a.full.hashLog, a.tail.hashLog)) >> W.shL) / 32 + ((1u << max(a.full.chainLog, a.tail.chainLog)) >> W.shS) / 32;
+  // (start values parked in the wave's own record of the telemetry buffer: nothing of this stays in registers while frames are parsed)
+  u64* const tl = tele ? a.mfTele + ZRA_TELE_HEAD + 4 * (size_t)min(blockIdx.x, ZRA_TELE_WAVES - 1u) : nullptr;
   if (tele && lane == 0) {
     const u32 hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);          // HW_REG_HW_ID: cu [11:8], sh [12], se [15:13]
     const u32 xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;    // HW_REG_XCC_ID [3:0]
@@ -1674,8 +1239,9 @@ __device__ __forceinline__ void mf_dfast_body(const ZraEncArgs& a, u32 block, u3
     atomicAdd((unsigned long long*)&a.mfTele[8 + xcc], 1ull);
     atomicMax((unsigned long long*)&a.mfTele[4], ~tr0);
     atomicMax((unsigned long long*)&a.mfTele[6], tr0);
-    tl[0] = (u32)tc0; tl[1] = (u32)(tc0 >> 32); tl[2] = (u32)tr0; tl[3] = (u32)(tr0 >> 32); tl[4] = xcc; tl[5] = 0;
+    tl[0] = tc0; tl[1] = tr0; tl[2] = xcc; tl[3] = 0;
   }
+  if (persistent && a.mfStarted && lane == 0) atomicAdd(a.mfStarted, 1u);
   for (;;) {
     u32 f = only == 0xFFFFFFFFu ? blockIdx.x : only;   // `only`: a single-workgroup launch for that frame on table slot `onlySlot`
     if (persistent) {
@@ -1685,20 +1251,20 @@ __device__ __forceinline__ void mf_dfast_body(const ZraEncArgs& a, u32 block, u3
       if (f >= a.nFrames) {
         if (tele && lane == 0) {
           const u64 tc1 = __builtin_readcyclecounter(), tr1 = wall_clock64();
-          const u64 tc0 = (u64)tl[0] | ((u64)tl[1] << 32), tr0 = (u64)tl[2] | ((u64)tl[3] << 32);
-          const u32 xcc = tl[4] & 7u;
+          const u64 tc0 = tl[0], tr0 = tl[1];
+          const u32 xcc = (u32)tl[2] & 7u;
           atomicAdd((unsigned long long*)&a.mfTele[0], tc1 - tc0);
           atomicAdd((unsigned long long*)&a.mfTele[1], tr1 - tr0);
           atomicAdd((unsigned long long*)&a.mfTele[2], 1ull);
           atomicMax((unsigned long long*)&a.mfTele[3], tr1 - tr0);
           atomicMax((unsigned long long*)&a.mfTele[5], tr1);
           atomicMax((unsigned long long*)&a.mfTele[7], ~tr1);
-          atomicAdd((unsigned long long*)&a.mfTele[16 + xcc], (unsigned long long)tl[5]);
+          atomicAdd((unsigned long long*)&a.mfTele[16 + xcc], (unsigned long long)tl[3]);
           atomicAdd((unsigned long long*)&a.mfTele[24 + xcc], tr1 - tr0);
         }
         return;
       }
-      if (tele && lane == 0) tl[5]++;
+      if (tele && lane == 0) tl[3]++;
     }
 #ifdef ZRA_MF_PROFILE
     const u64 kt0_ = __builtin_amdgcn_s_memtime();
@@ -1722,28 +1288,13 @@ __device__ __forceinline__ void mf_dfast_body(const ZraEncArgs& a, u32 block, u3
       u32 rep[3] = {F.st->rep[0], F.st->rep[1], F.st->rep[2]};
       u32 lastLL, nseq = 0;
       const u32 ib = 32 - __builtin_clz(F.fsize - 1);  // bits for position+1 < fsize (fsize >= 7 here)
-      // bucket flags of the frame (zra_lk_prepass_kernel runs ahead of this kernel on CUs of its own): wait for them; without them
-      // (patience over: the call fails) the parse is the same, with every table access made
       const u8* flg = nullptr;
-      if (FLAGS && !MASK && g && g->flags && block == 0 && persistent && !g->flagReady) {
+      if (FLAGS && g && g->flags && block == 0 && persistent) {
         // round 5: the wave computes its frame's flags itself, ahead of the parse, over the LDS the parse uses afterwards (the filter is
         // cleared below, the duplicate slots by the parse)
-        u8* const fw = const_cast<u8*>(g->flags) + (size_t)blockIdx.x * g->flagStride;
+        u8* const fw = g->flags + (size_t)blockIdx.x * g->flagStride;
         df_later_flags(F.src, F.fsize, F.P->hashLog, F.P->chainLog, F.P->minMatch, fltLds, g->ldsWords, fw, lane);
         flg = fw;
-      } else if (FLAGS && !MASK && g && g->flags && block == 0 && persistent) {
-        const u32 slot = f % g->flagSlots;
-        u32 okf = 1;
-        if (lane == 0) {
-          const u64 t0 = __builtin_amdgcn_s_memtime();
-          while (__hip_atomic_load(&g->flagReady[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != g->flagReadyBase + f + 1) {
-            __builtin_amdgcn_s_sleep(16);
-            if (__builtin_amdgcn_s_memtime() - t0 > 300000000ull) { atomicExch(g->flagFail, 1u); okf = 0; break; }   // (3 s of the 100 MHz clock)
-          }
-        }
-        okf = rfl(okf);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        if (okf) flg = g->flags + (size_t)slot * g->flagStride;
       }
       {
         // block 0 starts with empty tables (all bits clear); later blocks of a frame inherit tables filled by earlier launches
@@ -1764,8 +1315,7 @@ __device__ __forceinline__ void mf_dfast_body(const ZraEncArgs& a, u32 block, u3
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         srcP = ls;
       }
-      if (MASK) lastLL = mf_dfast_mask(*F.P, F.hashT, F.chainT, srcP, F.fsize, F.bs, F.be, rep, F.seqs, &nseq, W, lane, ib);
-      else switch (F.P->minMatch) {
+      switch (F.P->minMatch) {
         case 5: lastLL = mf_dfast_lean<5, FLAGS>(*F.P, F.hashT, F.chainT, srcP, F.bs, F.be, rep, F.seqs, &nseq, W, lane, ib, flg); break;
         case 6: lastLL = mf_dfast_lean<6, FLAGS>(*F.P, F.hashT, F.chainT, srcP, F.bs, F.be, rep, F.seqs, &nseq, W, lane, ib, flg); break;
         case 7: lastLL = mf_dfast_lean<7, FLAGS>(*F.P, F.hashT, F.chainT, srcP, F.bs, F.be, rep, F.seqs, &nseq, W, lane, ib, flg); break;
@@ -1782,24 +1332,21 @@ __device__ __forceinline__ void mf_dfast_body(const ZraEncArgs& a, u32 block, u3
     }
     if (!persistent) return;
     if (mine) {
-      // publish: every store of this frame (sequences, block record) is visible device-wide before the counter moves
+      // publish: every store of this frame (sequences, block record) is visible device-wide before its stamp
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      if (lane == 0) atomicAdd(&a.mfDone[f / a.mfSubFrames], 1u);
+      if (lane == 0) __hip_atomic_store(&a.blockOut[f].ready, a.readyStamp, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }
 
 extern "C" __global__ void __launch_bounds__(64)
-zra_mf_dfast_kernel(ZraEncArgs a, u32 block, u32 only, u32 onlySlot) { mf_dfast_body<false, false>(a, block, only, onlySlot); }
-// the same parse fed with the pre-pass's bucket flags (round 4, opt-in ZRA_MF_FLAGS=1: skips the table reads and writes that cannot matter)
+zra_mf_dfast_kernel(ZraEncArgs a, u32 block, u32 only, u32 onlySlot) { mf_dfast_body<false>(a, block, only, onlySlot); }
+// the same parse behind the wave's own bucket-flag sweep (round 5, df_later_flags): skips the table writes nobody can read
 extern "C" __global__ void __launch_bounds__(64)
-zra_mf_dfast_fl_kernel(ZraEncArgs a, ZraFlagArgs g, u32 block, u32 only, u32 onlySlot) { mf_dfast_body<false, true>(a, block, only, onlySlot, &g); }
+zra_mf_dfast_fl_kernel(ZraEncArgs a, ZraFlagArgs g, u32 block, u32 only, u32 onlySlot) { mf_dfast_body<true>(a, block, only, onlySlot, &g); }
 // the same parse over a copy of the frame in LDS (round 4): the latency mode for calls of a few hundred frames at most
 extern "C" __global__ void __launch_bounds__(64)
-zra_mf_dfast_ls_kernel(ZraEncArgs a, u32 block, u32 only, u32 onlySlot) { mf_dfast_body<false, false, true>(a, block, only, onlySlot); }
-// the mask-resolve parse (round 3): more registers, meant for few resident waves per CU with the tables inside the Infinity Cache
-extern "C" __global__ void __launch_bounds__(64)
-zra_mf_dfast2_kernel(ZraEncArgs a, u32 block, u32 only, u32 onlySlot) { mf_dfast_body<true, false>(a, block, only, onlySlot); }
+zra_mf_dfast_ls_kernel(ZraEncArgs a, u32 block, u32 only, u32 onlySlot) { mf_dfast_body<false, true>(a, block, only, onlySlot); }
 
 // Match finder for everything the lean kernels do not take (btlazy2, the optimal parsers, frames larger than the level's window, single
 // odd tails of any strategy). The parse of a frame is one dependent pointer chase (hash head

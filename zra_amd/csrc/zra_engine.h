@@ -144,8 +144,7 @@ class Engine {
   struct EncCtx { DevBuf tables, seqs, lits, slots, misc, ck, sizes; };
   EncCtx encCtx_[2];
   DevBuf encScan_;
-  DevBuf lkEnt_, lkTmp_, lkCtl_;          // link dfast (zra_encode_lk.hip): entry ring, per-workgroup link scratch, queues / ring flags
-  int lkAttr_ = 0;                         // its kernels' dynamic LDS sizes: 0 not asked yet, 1 granted, -1 refused
+  DevBuf mfFlags_;                         // bucket-flag masks of the dfast match finder: one slot per resident wave (df_later_flags)
   int lsAttr_ = 0;                  // zra_mf_dfast_ls_kernel's dynamic LDS limit raised: 1 yes, -1 refused
   hipStream_t stream2_ = nullptr;          // entropy stage / gather stream (overlaps the match finder on stream_)
   bool decCountersClean_ = false;          // the decoder's round counters are known to be zero (zeroed behind the last one-launch decode)

@@ -277,7 +277,7 @@ Status Engine::release_scratch() {
   HIPCHK(hipStreamSynchronize(stream_));
   HIPCHK(hipStreamSynchronize(stream2_));
   for (DevBuf* b : {&raPlan_, &raLimit_, &raPieceBase_, &raPieces_, &decFrames_, &decTables_, &decLists_, &decCounters_, &decLits_, &decSeqs_, &roundN_, &status_,
-                    &produced_, &frameMeta_, &frameOff_, &outOff_, &expect_, &result_, &temp_, &qmeta_, &encScan_, &hostIn_, &hostOut_, &seqScratch_, &lkEnt_, &lkTmp_, &lkCtl_})
+                    &produced_, &frameMeta_, &frameOff_, &outOff_, &expect_, &result_, &temp_, &qmeta_, &encScan_, &hostIn_, &hostOut_, &seqScratch_, &mfFlags_})
     b->release();
   for (auto& x : encCtx_) for (DevBuf* b : {&x.tables, &x.seqs, &x.lits, &x.slots, &x.misc, &x.ck, &x.sizes}) b->release();
   decCountersClean_ = false;
@@ -288,7 +288,7 @@ Engine::~Engine() {
   (void)hipSetDevice(device_);
   if (stream_) (void)hipStreamSynchronize(stream_);
   for (DevBuf* b : {&raPlan_, &raLimit_, &raPieceBase_, &raPieces_, &decFrames_, &decTables_, &decLists_, &decCounters_, &decLits_, &decSeqs_, &roundN_, &status_, &produced_, &frameMeta_, &frameOff_, &outOff_, &expect_, &result_, &temp_, &qmeta_,
-                    &encScan_, &hostIn_, &hostOut_, &seqScratch_, &lkEnt_, &lkTmp_, &lkCtl_})
+                    &encScan_, &hostIn_, &hostOut_, &seqScratch_, &mfFlags_})
     b->release();
   for (auto& x : encCtx_) for (DevBuf* b : {&x.tables, &x.seqs, &x.lits, &x.slots, &x.misc, &x.ck, &x.sizes}) b->release();
   for (auto ev : evPool_) (void)hipEventDestroy(ev);

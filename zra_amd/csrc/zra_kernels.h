@@ -153,6 +153,8 @@ static_assert(sizeof(ZraEncFrameState) % 16 == 0 && offsetof(ZraEncFrameState, r
 struct ZraEncBlockOut {
   uint32_t nbSeq, lastLL, skip;    // skip: block shorter than 7 bytes, emitted raw without entropy stage
   uint32_t rep[3];                 // repcodes after the block (confirmed only if emitted compressed)
+  uint32_t ready;                  // persistent pipeline: ZraEncArgs::readyStamp once the match finder has published the frame (release)
+  uint32_t pad_;
 };
 
 struct ZraEncArgs {
@@ -177,13 +179,21 @@ struct ZraEncArgs {
   ZraEncBlockOut* blockOut;// [nFrames]
   uint32_t* contentCk;     // [nFrames] XXH64 low 32 bits of each frame's input
   uint64_t* sizes;         // [nFrames] final frame sizes (written with the last block)
-  // persistent match-finder launch (single-block frames): workgroups pull frame indices from `mfQueue`, use the hash-table slot
-  // of their workgroup (tables = nSlots * tableStride) and count finished frames per sub-batch of `mfSubFrames` frames in
-  // mfDone[] (the entropy stage of a sub-batch is released by a stream wait on its counter). mfQueue == nullptr: one workgroup
-  // per frame, tables per frame.
+  // persistent pipeline (single-block dfast frames): TWO persistent kernels. The match finder's waves pull frame indices from `mfQueue`,
+  // use the hash-table slot of their workgroup (tables = nSlots * tableStride) and publish a finished frame by writing `readyStamp` into
+  // its block record (ZraEncBlockOut::ready). The entropy stage's workgroups (zra_entropy_persist_kernel) pull frame indices from
+  // `entQueue`, wait for the frame's stamp, encode it into slot (frame % slotRing) and count it in entDone[frame / entSubFrames]; the
+  // host's scan + gather of a sub-batch is released by a stream wait on that counter and raises `gatherDone` when the sub-batch's slots
+  // are free again. mfQueue == nullptr: one workgroup per frame, tables per frame (batch path).
   uint32_t* mfQueue;
-  uint32_t* mfDone;
-  uint32_t mfSubFrames;
+  uint32_t* mfStarted;     // counts the match finder's waves as they start (the entropy stage is launched once all of them are resident)
+  uint32_t* entQueue;
+  uint32_t* entDone;
+  uint32_t* gatherDone;    // sub-batches of this launch whose slots have been gathered
+  uint32_t* pipeAbort;     // non-zero: give up waiting (error exit of the host, or a wait that ran out of patience)
+  uint32_t entSubFrames;
+  uint32_t slotRing;       // frames the slot buffer holds
+  uint32_t readyStamp;
   // launch telemetry of the persistent match finder (nullptr: none), written by lane 0 of every wave: where the wave sat (XCD / SE / CU),
   // its shader cycles against the constant 100 MHz clock (the effective shader clock of the launch), frames taken per XCD
   uint64_t* mfTele;        // ZRA_TELE_WORDS u64
@@ -192,40 +202,14 @@ struct ZraEncArgs {
 // [4] earliest wave start (ticks, stored inverted for an atomic max), [5] latest wave end, [6] latest wave START, [7] earliest wave end (inverted),
 // [8..15] waves per XCD, [16..23] frames taken per XCD, [24..31] ticks spent per XCD, [32 + k] waves on CU key k (k = xcc << 8 | se << 5 | sh << 4 | cu)
 #define ZRA_TELE_CUKEYS 2048u
-#define ZRA_TELE_WORDS (32u + ZRA_TELE_CUKEYS)
-// bucket flags of zra_lk_prepass_kernel's flags mode, for zra_mf_dfast_fl_kernel: flags + (frame % flagSlots) * flagStride holds one
-// byte per position once flagReady[frame % flagSlots] == flagReadyBase + frame + 1
+#define ZRA_TELE_HEAD (32u + ZRA_TELE_CUKEYS)
+#define ZRA_TELE_WAVES 8192u                               /* then per wave (workgroup index): start cycles, start ticks, XCD, frames taken */
+#define ZRA_TELE_ENT (ZRA_TELE_HEAD + 4u * ZRA_TELE_WAVES)   /* then the entropy stage's persistent workgroups: [0] workgroups that took a frame, [1] their resident ticks, [2] ticks spent waiting for a frame or a slot, [3] frames, [8 + k] workgroups on CU key k */
+#define ZRA_TELE_WORDS (ZRA_TELE_ENT + 8u + ZRA_TELE_CUKEYS)
+// bucket flags of the dfast match finder (round 5): every wave computes its frame's flags itself (df_later_flags) into
+// flags + workgroup * flagStride, over ldsWords words of its LDS, ahead of the parse
 struct ZraFlagArgs {
-  const uint8_t* flags; uint64_t flagStride; uint32_t flagSlots; uint32_t flagReadyBase; const uint32_t* flagReady; uint32_t* flagFail;
-  uint32_t ldsWords;       // flagReady == nullptr (round 5): the match finder's wave computes the flags itself into flags + workgroup * flagStride, over this many words of its LDS
+  uint8_t* flags; uint64_t flagStride; uint32_t ldsWords;
 };
 
-// ------------------------------------------------------------------------------------------------ encode, "link" dfast (zra_encode_lk.hip)
-// Frames of at most 64 KiB (one block) at a dfast level. A parse-independent pre-pass gives every position its three predecessors in
-// the long-hash and in the short-hash bucket chain; the parse keeps "was inserted" bitmaps in LDS instead of hash tables in HBM.
-// entry of position p: two u64 {long, short}: q1 | q2 << 16 | q3 << 32 | equal-content flags << 48 (bit k: predecessor k+1 carries the
-// same 8 (long) / 4 (short) bytes as p); 0 = no predecessor (position 0 is never a candidate: index > prefixLowestIndex)
-#define ZRA_LK_MAX_FRAME 65536u
-#define ZRA_LK_PP_THREADS 1024u
-#define ZRA_LK_PP_LDS 159808u                                     // heads / links / source copy (128 KiB) + per group and block: last lane (16 KiB) + block masks (4 KiB) + has-successor bits (8 KiB); nothing else fits the CU
-#define ZRA_LK_PARSE_WAVES 8u                                  // waves of one parse workgroup = frames in flight per CU (16 KiB of bitmaps each)
-#define ZRA_LK_PARSE_LDS (ZRA_LK_PARSE_WAVES * 16384u)
-struct ZraLkArgs {
-  uint64_t* ent;          // ring of entry arrays: slot (frame % ringSlots) holds 2 * entPositions u64
-  uint64_t entPositions;  // positions per ring slot (frame size rounded up to 64, + 64)
-  uint32_t ringSlots;
-  uint16_t* lkTmp;        // per pre-pass workgroup: 2 x 65536 u16 (links of the long / the short chain)
-  uint32_t* ready;        // [ringSlots] frame + 1 whose entries the slot holds            (pre-pass -> parse); nullptr: launches are ordered
-  uint32_t* consumed;     // [ringSlots] frame + 1 that was last parsed out of the slot    (parse -> pre-pass)
-  uint32_t* ppQueue;      // frame queue of the pre-pass workgroups
-  uint32_t first, count;  // this launch covers frames [first, first + count) of the batch
-  uint32_t* fail;         // set when a wait ran out of patience (the call fails instead of hanging)
-  // flags mode (for zra_mf_dfast_kernel): one byte per position instead of entries, ring slot = frame % ringSlots
-  uint8_t* flagsOut; uint64_t flagStride;
-  uint32_t* subDone;      // the match finder's finished-frame counters per sub-batch (ZraEncArgs.mfDone): frees ring slots
-  uint32_t oddTail;       // the batch's last frame is parsed by another kernel (not counted in subDone)
-  uint32_t readyBase;     // ready[] holds readyBase + frame + 1 (unique within a call across super-batches)
-  uint32_t* started;      // counts the pre-pass workgroups that are resident
-  volatile uint32_t* dbg; // bring-up: progress markers in host-visible memory (nullptr otherwise)
-};
 
