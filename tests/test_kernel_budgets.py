@@ -16,17 +16,16 @@ BUDGET = {
     "zra_mf_dfast_fl_kernel": (80, 0),   # the same parse behind the wave's own bucket-flag sweep (the headline kernel since round 5): 6 waves per SIMD, 20 per CU wanted
     "zra_mf_dfast_ls_kernel": (96, 0),   # the same parse over a copy of the frame in LDS (calls of a few hundred frames): one or two waves per CU by LDS, registers are not its limit
     "zra_mf_hc_kernel": (64, 0),         # one wave per frame, as many waves per CU as the hardware holds
-    "zra_mf_fast_kernel": (64, 288),     # lane = frame; the scratch is the per-lane frame descriptor + a copy of the argument block
-    "zra_mf_kernel": (96, 296),          # generic one-lane finder without the optimal parsers (btlazy2, frames beyond the window, odd tails)
-    "zra_mf_opt_kernel": (136, 400),     # ... with them (levels 13-22; its scratch holds the parser's small arrays)
+    "zra_mf_fast_kernel": (64, 384),     # lane = frame; the scratch is the per-lane frame descriptor + a copy of the argument block
+    "zra_mf_kernel": (96, 392),          # generic one-lane finder without the optimal parsers (btlazy2, frames beyond the window, odd tails)
+    "zra_mf_opt_kernel": (136, 480),     # ... with them (levels 13-22; its scratch holds the parser's small arrays)
     "zra_dec_chain_kernel": (72, 0),     # lane = frame FSE chains
     "zra_dec_chain_lds_kernel": (80, 0), # the same with its frames' tables in LDS, one workgroup per CU beside it
     "zra_dec_huf_kernel": (88, 0),       # wave-wide literal decode (two stream readers while a restarted lane looks for its previous path); 8.5 KiB of LDS per workgroup is its occupancy limit
     "zra_dec_parse_kernel": (96, 176),   # 5 waves per SIMD asked for: 40 spilled VGPRs bought 2.1x on the stage (frames in flight are what it needs)
     "zra_dec_exec_kernel": (80, 160),    # 6 waves per SIMD (the LDS-window step and the in-memory one side by side: 37 spilled VGPRs, 13.3 vs 14.3 ms at 5 waves)
     "zra_ra_small_kernel": (256, 0),     # one-launch path for small batches: all stages of a frame in one workgroup, occupancy is not its point
-    "zra_entropy_persist_kernel": (96, 448),  # persistent entropy workgroups beside the match finder: one wave of it per SIMD next to five of the finder's (5 x 80 + 96 <= 512); the scratch is the frame body's call frame (its copy of the argument block)
-    "zra_entropy_kernel": (96, 128),      # 5 waves per SIMD asked for: no spills (7 cost 8 spilled VGPRs + 72 B scratch and 2 % of the bench)
+    "zra_entropy_kernel": (96, 512),     # the entropy stage's queue-driven workgroups: one wave of it per SIMD next to five of the match finder's (5 x 80 + 96 <= 512); the scratch is the frame body's call frame (its copy of the argument block) + a few spilled registers      # 5 waves per SIMD asked for: no spills (7 cost 8 spilled VGPRs + 72 B scratch and 2 % of the bench)
 }
 
 

@@ -19,7 +19,6 @@ extern "C" __global__ void zra_mf_fast_kernel(ZraEncArgs a, uint32_t block, uint
 extern "C" __global__ void zra_mf_dfast_kernel(ZraEncArgs a, uint32_t block, uint32_t only, uint32_t onlySlot);
 extern "C" __global__ void zra_mf_dfast_fl_kernel(ZraEncArgs a, ZraFlagArgs g, uint32_t block, uint32_t only, uint32_t onlySlot);
 extern "C" __global__ void zra_entropy_kernel(ZraEncArgs a, uint32_t block);
-extern "C" __global__ void zra_entropy_persist_kernel(ZraEncArgs a);
 
 using namespace zra_dev;
 
@@ -228,23 +227,33 @@ Status Engine::compress_impl_body(const uint8_t* dIn, size_t inSize, uint8_t* dB
   }
   uint32_t B = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>({nFramesTotal, budget / perFrame, full.strategy == 2 ? 16384ull : 65536ull}));
   if (B > 1024) B &= ~1023u;
+  // the entropy stage: workgroups that take the batch's frames from a queue — as many as the device holds at once (5 waves per SIMD by
+  // registers), each with its own literal buffer and sequence work area
+  const uint32_t entGridB = (uint32_t)std::min<uint64_t>(B, (uint64_t)numCUs_ * 5);
+  const uint64_t entWorkStride = (9 * seqStride + 255) & ~255ull;
   const int nCtx = nFramesTotal > B ? 2 : 1;
   for (int c = 0; c < nCtx; c++) {
     EncCtx& x = encCtx_[c];
-    if (!x.tables.reserve(B * tableWords * 4) || !x.seqs.reserve(B * seqStride * 8) || !x.lits.reserve(B * litStride) ||
+    if (!x.tables.reserve(B * tableWords * 4) || !x.seqs.reserve(B * seqStride * 8) || !x.lits.reserve((size_t)entGridB * litStride) ||
+        !x.work.reserve((size_t)entGridB * entWorkStride) ||
         !x.slots.reserve(B * slotStride) || !x.misc.reserve(B * (sizeof(ZraEncFrameState) + sizeof(ZraEncBlockOut))) ||
         !x.ck.reserve((size_t)B * 4) || !x.sizes.reserve((size_t)B * 16))
       return zerr(64);
   }
-  if (!encScan_.reserve(64)) return zerr(64);
+  // [u64 running offset][pad][one frame queue of the entropy stage per launch, 4 bytes each, cleared here]
+  const size_t nEntLaunches = (size_t)((nFramesTotal + B - 1) / B) * maxBlocksPerFrame + 4;
+  if (!encScan_.reserve(64 + 4 * nEntLaunches)) return zerr(64);
   uint64_t* dRunning = encScan_.as<uint64_t>();
-  HIPCHK(hipMemsetAsync(dRunning, 0, 8, stream2_));
+  uint32_t* dEntQueues = (uint32_t*)(encScan_.as<uint8_t>() + 64);
+  HIPCHK(hipMemsetAsync(encScan_.p, 0, 64 + 4 * nEntLaunches, stream2_));
+  size_t entLaunch = 0;
 
   ZraEncArgs base{};
   base.in = dIn; base.inSize = inSize; base.frameSize = frameSize; base.checksum = checksum ? 1 : 0;
   base.full = full; base.tail = tail;
   dbgSeqStride_ = seqStride; dbgB_ = (uint32_t)B;
   base.tableStride = tableWords; base.seqStride = seqStride; base.litStride = litStride; base.slotStride = slotStride;
+  base.entWorkStride = entWorkStride; base.slotRing = B; base.entSubFrames = B; base.entPrio = 3;
 
   // event pool: [2 per mf launch on stream A] [2 per entropy launch on stream B]; dependencies mfDone / entDone per context
   size_t evNext = 0;
@@ -352,7 +361,8 @@ Status Engine::compress_impl_body(const uint8_t* dIn, size_t inSize, uint8_t* dB
       HIPCHK(hipStreamWaitEvent(stream2_, m1, 0));
       hipEvent_t e0 = ev(); if (!e0) return zerr(1);
       HIPCHK(hipEventRecord(e0, stream2_));
-      hipLaunchKernelGGL(zra_entropy_kernel, dim3(nb), dim3(256), 0, stream2_, a, blk);
+      { ZraEncArgs ae = a; ae.entQueue = dEntQueues + entLaunch++; ae.entWork = x.work.as<uint8_t>();
+        hipLaunchKernelGGL(zra_entropy_kernel, dim3(std::min<uint32_t>(nb, entGridB)), dim3(256), 0, stream2_, ae, blk); }
       HIPCHK(hipEventRecord(e1, stream2_));
       entSpans.push_back({e0, e1});
       if (blk + 1 < rounds) HIPCHK(hipStreamWaitEvent(sA, e1, 0));   // next block's match finder needs the confirmed state
@@ -387,9 +397,12 @@ Status Engine::compress_persistent(const uint8_t* dIn, size_t inSize, uint8_t* d
   const uint64_t nFramesTotal = (inSize + frameSize - 1) / frameSize;
   const size_t tailSize = inSize % frameSize;
   const auto mfGeneric = (full.strategy >= 7 || tail.strategy >= 7) ? zra_mf_opt_kernel : zra_mf_kernel;
-  // 18 resident waves per CU with the 6 KiB filter below: A/B on one box (tools/bench_ab_env.sh, profiles/r02_experiments.md): +2.5-4 % over
-  // 16 waves with the 7 KiB filter; 20 and more lose it again to the entropy stage
-  static const uint32_t wavesPerCU = std::getenv("ZRA_MF_WAVES") ? (uint32_t)std::atoi(std::getenv("ZRA_MF_WAVES")) : 18u;
+  // Round 5: the entropy stage runs BEHIND the match-finder launch (pipeMode 0 below), so the finder has the CUs to itself: 22 resident
+  // waves per CU (6.5 KiB of LDS and 76 registers each). With the bucket flags fewer table requests queue up and more waves in flight
+  // pay again (one box, 16 GiB: 18 waves 922 ms, 20 waves 855, 22 waves 846, 24 waves 846; without the flags 18 = 24 waves, round 4).
+  // ZRA_PIPE=2 (entropy stage resident beside the finder, one workgroup per CU) wants 18.
+  static const int pipeMode = std::getenv("ZRA_PIPE") ? std::atoi(std::getenv("ZRA_PIPE")) : 0;
+  static const uint32_t wavesPerCU = std::getenv("ZRA_MF_WAVES") ? (uint32_t)std::atoi(std::getenv("ZRA_MF_WAVES")) : (pipeMode == 0 ? 22u : 18u);
   static const uint32_t SB = std::getenv("ZRA_ENC_SUB") ? (uint32_t)std::atoi(std::getenv("ZRA_ENC_SUB")) : 8192u;   // frames per sub-batch
   const uint32_t nSlots = (uint32_t)std::min<uint64_t>((uint64_t)numCUs_ * wavesPerCU, nFramesTotal);
   // per-frame scratch that lives from the match finder to the entropy stage: sequences + block record + checksum + size/offset
@@ -414,9 +427,15 @@ Status Engine::compress_persistent(const uint8_t* dIn, size_t inSize, uint8_t* d
   // figure): a reservation that fails is tried again with half of it, down to 1 GiB, before the call gives up with memory_allocation
   uint64_t SBIG = 0, nSuper = 0, subsPerSuper = 0; int nCtx = 1;
   EncCtx& sh = encCtx_[0];                       // shared: table slots, the entropy workgroups' literal buffers, the ring of encoded-frame slots
-  // entropy stage: persistent workgroups, two per CU asked for (one fits beside the match finder's waves; the rest start when those leave)
-  static const uint32_t entPerCU = std::getenv("ZRA_ENT_WGS") ? (uint32_t)std::max(1, std::atoi(std::getenv("ZRA_ENT_WGS"))) : 2u;
+  // entropy stage: queue-driven workgroups. Behind the match finder (pipeMode 0, the default): as many as the device holds, five per CU
+  // by registers. Resident beside it (ZRA_PIPE=2): ONE per CU — what fits next to 18 match-finder waves; workgroups that find no room
+  // would keep the launch's hardware queue busy until the finder leaves.
+  // Round 5 measured both on one box (16 GiB, profiles/r05_experiments.md): beside the finder the stage keeps up (0.92-0.97 ms per frame
+  // and workgroup), and slows the finder from 846-970 ms to 1020-1075 ms: its work is ALU and LDS work, not idle latency, and costs about
+  // what it costs alone. Behind the finder: 846 + 187 ms.
+  static const uint32_t entPerCU = std::getenv("ZRA_ENT_WGS") ? (uint32_t)std::max(1, std::atoi(std::getenv("ZRA_ENT_WGS"))) : (pipeMode == 0 ? 5u : 1u);
   const uint32_t entGrid = (uint32_t)std::min<uint64_t>((uint64_t)numCUs_ * entPerCU, nFramesTotal);
+  const uint64_t entWorkStride = (9 * seqStride + 255) & ~255ull;
   static const uint32_t ringSubsEnv = std::getenv("ZRA_ENC_RING") ? (uint32_t)std::max(2, std::atoi(std::getenv("ZRA_ENC_RING"))) : 4u;   // sub-batches the slot ring holds
   uint64_t slotRing = 0;
   for (;; budget /= 2) {
@@ -428,7 +447,8 @@ Status Engine::compress_persistent(const uint8_t* dIn, size_t inSize, uint8_t* d
     subsPerSuper = (SBIG + SB - 1) / SB;
     slotRing = std::min<uint64_t>((uint64_t)ringSubsEnv * SB, subsPerSuper * (uint64_t)SB);
     if (SBIG <= SB) slotRing = SBIG;
-    bool okR = sh.tables.reserve((size_t)nSlots * tableWords * 4) && sh.lits.reserve((size_t)entGrid * litStride) && sh.slots.reserve(slotRing * slotStride);
+    bool okR = sh.tables.reserve((size_t)nSlots * tableWords * 4) && sh.lits.reserve((size_t)entGrid * litStride) && sh.work.reserve((size_t)entGrid * entWorkStride) &&
+               sh.slots.reserve(slotRing * slotStride);
     for (int c = 0; c < nCtx && okR; c++) {
       EncCtx& x = encCtx_[c];
       okR = x.seqs.reserve(SBIG * seqStride * 8) && x.misc.reserve(SBIG * (sizeof(ZraEncFrameState) + sizeof(ZraEncBlockOut))) &&
@@ -438,18 +458,19 @@ Status Engine::compress_persistent(const uint8_t* dIn, size_t inSize, uint8_t* d
     if (budget <= (1ull << 30) || SBIG <= SB) return zerr(64);
     (void)hipGetLastError();
   }
-  // counters: [u64 running offset][pad][abort][per super-batch: mf queue, mf started, entropy queue, gathered][entropy done per sub-batch]
-  const size_t nCnt = 4 + 4 * (size_t)nSuper + (size_t)(nSuper * subsPerSuper) + 4;
+  // counters: [u64 running offset][pad][abort + 3 pad][per super-batch 8: mf queue, mf started, entropy queue, scanned, handing out,
+  // gathered, 2 pad][per sub-batch 3: encoded, handed out for copying, copied]
+  const size_t nCnt = 4 + 8 * (size_t)nSuper + 3 * (size_t)(nSuper * subsPerSuper) + 4;
   const size_t cntCore = (16 + 4 * nCnt + 15) & ~(size_t)15;
   const size_t cntBytes = cntCore + 8 * (size_t)ZRA_TELE_WORDS;      // + the launch telemetry (ZraEncArgs::mfTele)
   if (!encScan_.reserve(cntBytes)) return zerr(64);
   uint64_t* dRunning = encScan_.as<uint64_t>();
   uint32_t* dCnt = (uint32_t*)(encScan_.as<uint8_t>() + 16);
   uint32_t* dAbort = dCnt;                       // [0]
-  uint32_t* dPerSuper = dCnt + 4;                // 4 words per super-batch
-  uint32_t* dEntDone = dPerSuper + 4 * nSuper;
+  uint32_t* dPerSuper = dCnt + 4;                // 8 words per super-batch
+  uint32_t* dPerSub = dPerSuper + 8 * nSuper;    // 3 x subsPerSuper words per super-batch
   HIPCHK(hipMemsetAsync(encScan_.as<uint8_t>(), 0, cntBytes, stream_));
-  encCounters_ = dCnt; encCountersBytes_ = 4 * nCnt;   // (an error exit fills them with 0x7F: the abort word is set, every wait is satisfied)
+  encCounters_ = dCnt; encCountersBytes_ = 4 * (4 + 8 * (size_t)nSuper);   // (an error exit fills them with 0x7F: the abort word is set, the queues are past their ends, every wait of the two kernels and of stream B ends)
 
   ZraEncArgs base{};
   base.in = dIn; base.inSize = inSize; base.frameSize = frameSize; base.checksum = checksum ? 1 : 0;
@@ -457,7 +478,10 @@ Status Engine::compress_persistent(const uint8_t* dIn, size_t inSize, uint8_t* d
   dbgSeqStride_ = seqStride; dbgB_ = (uint32_t)SBIG;
   base.tableStride = tableWords; base.seqStride = seqStride; base.litStride = litStride; base.slotStride = slotStride;
   base.mfTele = (uint64_t*)(encScan_.as<uint8_t>() + cntCore);
+  base.entWorkStride = entWorkStride;
+  { static const int ep = std::getenv("ZRA_ENT_PRIO") ? std::atoi(std::getenv("ZRA_ENT_PRIO")) : 3; base.entPrio = (uint32_t)ep; }
   base.pipeAbort = dAbort; base.entSubFrames = SB; base.slotRing = (uint32_t)slotRing; base.readyStamp = 1u;
+  base.running = dRunning; base.gBody = dBody + bodyBase0; base.gEntries = dEntries; base.gSizesOut = dSizes;
   // LDS geometry of the match finder's wave: the bucket filter — 1 bit per 2^shL long-table buckets, 1 bit per 2^shS short-table buckets —
   // and the duplicate-detection slots: 2 KiB + 4 KiB + 0.5 KiB = 6.5 KiB at hashLog 16 / chainLog 15 (one bit per 2 long buckets, per 8
   // short buckets; round 5: 1 per 4 short buckets made it 7 KiB + 64, and 20 waves of that leave no room for the entropy stage's
@@ -500,12 +524,10 @@ Status Engine::compress_persistent(const uint8_t* dIn, size_t inSize, uint8_t* d
     return evPool_[evNext++];
   };
   std::vector<std::pair<hipEvent_t, hipEvent_t>> mfSpans, entSpans;
-  hipEvent_t superDone[2] = {nullptr, nullptr}, prevGathered = nullptr;
-  // stream C: the scan + gather of each sub-batch (stream B holds the persistent entropy kernel for the whole launch)
-  if (!pipeStreams_[0] && hipStreamCreateWithFlags(&pipeStreams_[0], hipStreamNonBlocking) != hipSuccess) { pipeStreams_[0] = nullptr; return zerr(1); }
-  hipStream_t streamC = pipeStreams_[0];
-  // streams B and C start after the counters are cleared and after whatever the caller queued on the engine stream
-  { hipEvent_t e0 = ev(); if (!e0) return zerr(1); HIPCHK(hipEventRecord(e0, stream_)); HIPCHK(hipStreamWaitEvent(stream2_, e0, 0)); HIPCHK(hipStreamWaitEvent(streamC, e0, 0)); }
+  static const bool traceOn = std::getenv("ZRA_ENC_TRACE") != nullptr;   // bring-up: timeline of the launches on stderr
+  hipEvent_t superDone[2] = {nullptr, nullptr};
+  // stream B starts after the counters are cleared and after whatever the caller queued on the engine stream
+  { hipEvent_t e0 = ev(); if (!e0) return zerr(1); HIPCHK(hipEventRecord(e0, stream_)); HIPCHK(hipStreamWaitEvent(stream2_, e0, 0)); }
 
   for (uint64_t S = 0; S < nSuper; S++) {
     const uint64_t F0 = S * SBIG;
@@ -514,14 +536,15 @@ Status Engine::compress_persistent(const uint8_t* dIn, size_t inSize, uint8_t* d
     EncCtx& x = encCtx_[c];
     ZraEncArgs a = base;
     a.firstFrame = (uint32_t)F0; a.nFrames = n;
-    a.tables = sh.tables.as<uint32_t>(); a.lits = sh.lits.as<uint8_t>(); a.slots = sh.slots.as<uint8_t>();
+    a.tables = sh.tables.as<uint32_t>(); a.lits = sh.lits.as<uint8_t>(); a.slots = sh.slots.as<uint8_t>(); a.entWork = sh.work.as<uint8_t>();
     a.seqs = x.seqs.as<uint64_t>();
     a.state = x.misc.as<ZraEncFrameState>();
     a.blockOut = (ZraEncBlockOut*)(x.misc.as<uint8_t>() + (size_t)SBIG * sizeof(ZraEncFrameState));
     a.contentCk = x.ck.as<uint32_t>();
     a.sizes = x.sizes.as<uint64_t>();
-    a.mfQueue = dPerSuper + 4 * S; a.mfStarted = a.mfQueue + 1; a.entQueue = a.mfQueue + 2; a.gatherDone = a.mfQueue + 3;
-    a.entDone = dEntDone + S * subsPerSuper;
+    a.mfQueue = dPerSuper + 8 * S; a.mfStarted = a.mfQueue + 1; a.entQueue = a.mfQueue + 2; a.scanDone = a.mfQueue + 3; a.gatherJ = a.mfQueue + 4; a.gatherDone = a.mfQueue + 5;
+    a.entDone = dPerSub + 3 * S * subsPerSuper; a.gQueue = a.entDone + subsPerSuper; a.gCopied = a.gQueue + subsPerSuper;
+    a.offsets = x.sizes.as<uint64_t>() + SBIG;
     // the context's per-frame scratch is free once the last sub-batch that used it has been gathered
     if (superDone[c]) HIPCHK(hipStreamWaitEvent(stream_, superDone[c], 0));
     // no frame of this launch is published yet (the stamps of an earlier call may still sit in the block records)
@@ -547,35 +570,23 @@ Status Engine::compress_persistent(const uint8_t* dIn, size_t inSize, uint8_t* d
       HIPCHK(hipStreamWriteValue32(stream_, &a.blockOut[n - 1].ready, a.readyStamp, 0));
     }
     // stream B: once every wave of the match finder is resident (they are placed first, side by side: what is left of each CU is one
-    // contiguous piece), the content checksums, then the persistent entropy stage
-    HIPCHK(hipStreamWaitValue32(stream2_, a.mfStarted, mfGrid, hipStreamWaitValueGte, 0xFFFFFFFFu));
-    if (prevGathered) HIPCHK(hipStreamWaitEvent(stream2_, prevGathered, 0));      // the slot ring is shared between super-batches
+    // contiguous piece), the content checksums, then the persistent entropy stage. ZRA_PIPE=0 (bring-up): the entropy stage only
+    // behind the whole match-finder launch, with as many workgroups as the device holds
+    if (pipeMode == 0) HIPCHK(hipStreamWaitEvent(stream2_, m1, 0));
+    else HIPCHK(hipStreamWaitValue32(stream2_, a.mfStarted, mfGrid, hipStreamWaitValueGte, 0xFFFFFFFFu));
     if (checksum)
       hipLaunchKernelGGL(zra_content_ck_kernel, dim3((n * 4 + 255) / 256), dim3(256), 0, stream2_, dIn, (u64)inSize, frameSize, (u32)F0, n, a.contentCk);
     hipEvent_t e0 = ev(), e1 = ev(); if (!e0 || !e1) return zerr(1);
     HIPCHK(hipEventRecord(e0, stream2_));
-    hipLaunchKernelGGL(zra_entropy_persist_kernel, dim3(std::min<uint32_t>(n, entGrid)), dim3(256), 0, stream2_, a);
+    hipLaunchKernelGGL(zra_entropy_kernel, dim3(std::min<uint32_t>(n, entGrid)), dim3(256), 0, stream2_, a, 0u);
+    HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(e1, stream2_));
     entSpans.push_back({e0, e1});
-    // stream C: scan + gather of each sub-batch as its frames come out of the entropy stage
-    const uint32_t nSub = (n + SB - 1) / SB, ringSubs = (uint32_t)std::max<uint64_t>(1, slotRing / SB);
-    for (uint32_t j = 0; j < nSub; j++) {
-      const uint32_t j0 = j * SB, nbj = std::min<uint32_t>(SB, n - j0);
-      HIPCHK(hipStreamWaitValue32(streamC, a.entDone + j, nbj, hipStreamWaitValueGte, 0xFFFFFFFFu));
-      uint64_t* dOffsets = x.sizes.as<uint64_t>() + SBIG + j0;
-      const uint8_t* subSlots = a.slots + (size_t)((j % ringSubs) * (uint64_t)SB) * slotStride;
-      hipLaunchKernelGGL(zra_scan_sizes_kernel, dim3(1), dim3(64), 0, streamC, a.sizes + j0, nbj, dOffsets, dRunning, (const u32*)dAbort);
-      hipLaunchKernelGGL(zra_gather_frames_kernel, dim3(nbj), dim3(256), 0, streamC, subSlots, slotStride, a.sizes + j0, dOffsets, dBody,
-                         bodyBase0, dEntries ? dEntries : nullptr, (u32)(F0 + j0), dSizes, (const u32*)dAbort);
-      HIPCHK(hipStreamWriteValue32(streamC, a.gatherDone, j + 1, 0));
-    }
-    hipEvent_t done = ev(); if (!done) return zerr(1);
-    HIPCHK(hipEventRecord(done, streamC));
-    superDone[c] = done; prevGathered = done;
+    // (the entropy launch ends when every frame of the super-batch sits in the archive: the context's scratch and the slot ring are free)
+    superDone[c] = e1;
   }
   uint64_t total = 0;
-  HIPCHK(hipMemcpyAsync(&total, dRunning, 8, hipMemcpyDeviceToHost, streamC));
-  HIPCHK(hipStreamSynchronize(streamC));
+  HIPCHK(hipMemcpyAsync(&total, dRunning, 8, hipMemcpyDeviceToHost, stream2_));
   HIPCHK(hipStreamSynchronize(stream2_));
   HIPCHK(hipStreamSynchronize(stream_));
   HIPCHK(hipGetLastError());
@@ -593,7 +604,7 @@ Status Engine::compress_persistent(const uint8_t* dIn, size_t inSize, uint8_t* d
   mfTele_.resize(ZRA_TELE_HEAD + 8 + ZRA_TELE_CUKEYS);
   HIPCHK(hipMemcpy(mfTele_.data(), base.mfTele, 8 * (size_t)ZRA_TELE_HEAD, hipMemcpyDeviceToHost));
   HIPCHK(hipMemcpy(mfTele_.data() + ZRA_TELE_HEAD, base.mfTele + ZRA_TELE_ENT, 8 * (size_t)(8 + ZRA_TELE_CUKEYS), hipMemcpyDeviceToHost));
-  if (std::getenv("ZRA_ENC_TRACE")) {                 // bring-up: timeline relative to the first match-finder launch
+  if (traceOn) {                                      // bring-up: timeline relative to the first match-finder launch
     for (auto& sp : mfSpans) { float a0 = 0, a1 = 0; (void)hipEventElapsedTime(&a0, mfSpans[0].first, sp.first); (void)hipEventElapsedTime(&a1, mfSpans[0].first, sp.second); std::fprintf(stderr, "mf  %8.2f .. %8.2f ms\n", a0, a1); }
     for (auto& sp : entSpans) { float a0 = 0, a1 = 0; (void)hipEventElapsedTime(&a0, mfSpans[0].first, sp.first); (void)hipEventElapsedTime(&a1, mfSpans[0].first, sp.second); std::fprintf(stderr, "ent %8.2f .. %8.2f ms\n", a0, a1); }
   }

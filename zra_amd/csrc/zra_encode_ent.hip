@@ -69,14 +69,11 @@ struct EncSeqBuild {
   u8 spread[3][512];
   u32 cumul[3][56];           // fse_build_ctable work array (LDS, not scratch)
 };
-struct EncSeqPhase {
-  u8 codes[3][SEQ_TILE];
-  u16 chain[3][SEQ_TILE];
-};
 struct __attribute__((aligned(16))) EncShared {
   u32 stage[STAGE_WORDS];
-  union { EncLitPhase lit; EncSeqPhase seq; };
+  EncLitPhase lit;
   u32 seqCnt[3][64];         // code histograms of the block's sequences (counted while the literals are gathered: the sequences are in registers then)
+  u8 chainCodes[3][64]; u16 chainOut[3][64];   // the state chains' current 64 sequences: codes in, results out
   u8 ncount[3][192];         // table descriptions of the block's sequence section (written while the Huffman tree is built, emitted after the literals)
   u8 hNb[256];
   u16 hVal[256];
@@ -509,7 +506,11 @@ __device__ unsigned long long zra_ent_prof[16];
 #define ZRA_ENT_WAVES 5
 #endif
 // One block of frame `f` of the batch: literals to `lits` (this workgroup's scratch), the encoded block to `slot`.
-__device__ __forceinline__ void entropy_frame(const ZraEncArgs& a, u32 block, u32 f, u8* lits, u8* slot, EncShared& S) {
+// `work`: this workgroup's scratch for the sequence section — code bytes [3][seqStride] (last sequence first), then the chains' output
+// [3][seqStride] u16 (state bits << 0 | their count << 12)
+// (the argument block is read where the kernel received it, in the constant address space: scalar loads, nothing copied into private memory)
+typedef const __attribute__((address_space(4))) ZraEncArgs KArgs;
+__device__ __forceinline__ void entropy_frame(KArgs& a, u32 block, u32 f, u8* lits, u8* slot, u8* work, EncShared& S) {
 #ifdef ZRA_MF_PROFILE
   u64 ept_ = __builtin_amdgcn_s_memtime();
 #endif
@@ -517,7 +518,10 @@ __device__ __forceinline__ void entropy_frame(const ZraEncArgs& a, u32 block, u3
   const u64 fstart = (u64)(a.firstFrame + f) * a.frameSize;
   const u64 remaining = a.inSize - fstart;
   const u32 fsize = (u32)(remaining < a.frameSize ? remaining : a.frameSize);
-  const ZraEncParams& P = (fsize == a.frameSize) ? a.full : a.tail;
+  const bool fullP = fsize == a.frameSize;
+  struct { u32 blockSize, strategy, windowLog, targetLength; } P;      // (field by field: the block sits in the constant address space)
+  P.blockSize = fullP ? a.full.blockSize : a.tail.blockSize; P.strategy = fullP ? a.full.strategy : a.tail.strategy;
+  P.windowLog = fullP ? a.full.windowLog : a.tail.windowLog; P.targetLength = fullP ? a.full.targetLength : a.tail.targetLength;
   const u32 bs = block * P.blockSize;
   if (bs >= fsize) return;
   const u32 be = min(fsize, bs + P.blockSize), L = be - bs;
@@ -543,6 +547,7 @@ __device__ __forceinline__ void entropy_frame(const ZraEncArgs& a, u32 block, u3
     const u64* seqs = a.seqs + (size_t)f * a.seqStride;
 
     // ------------------------------------------------------------ phase 1: gather literals + histogram
+    u8* const codesG = work; u16* const chainG = (u16*)(work + 3 * a.seqStride);
     for (int i = tid; i < 4 * 256; i += ENT_THREADS) (&S.lit.hist[0][0])[i] = 0;
     if (tid < 3 * 64) (&S.seqCnt[0][0])[tid] = 0;
     u32 litBase = 0, srcBase = bs;
@@ -555,10 +560,11 @@ __device__ __forceinline__ void entropy_frame(const ZraEncArgs& a, u32 block, u3
         const u64 q = i < nbSeq ? seqs[i] : 0;
         llv[k] = (u32)q & 0xFFFFF; mlv[k] = (u32)(q >> 20) & 0xFFFFF;
         tl += llv[k]; tt += llv[k] + mlv[k];
-        if (i < nbSeq) {                               // code histograms of the sequence section (A.4.7): the sequence is in registers here
-          atomicAdd(&S.seqCnt[0][ll_code(llv[k])], 1u);
-          atomicAdd(&S.seqCnt[1][hb32((u32)(q >> 40))], 1u);
-          atomicAdd(&S.seqCnt[2][ml_code(mlv[k] - 3)], 1u);
+        if (i < nbSeq) {                               // codes + code histograms of the sequence section (A.4.7): the sequence is in registers here
+          const u32 cl = ll_code(llv[k]), co = hb32((u32)(q >> 40)), cm = ml_code(mlv[k] - 3);
+          atomicAdd(&S.seqCnt[0][cl], 1u); atomicAdd(&S.seqCnt[1][co], 1u); atomicAdd(&S.seqCnt[2][cm], 1u);
+          const u32 rl = nbSeq - 1 - i;                  // the chains run from the block's last sequence to its first
+          codesG[rl] = (u8)cl; codesG[a.seqStride + rl] = (u8)co; codesG[2 * a.seqStride + rl] = (u8)cm;
         }
       }
       if (tid == 0) S.longCount = 0;
@@ -681,36 +687,101 @@ __device__ __forceinline__ void entropy_frame(const ZraEncArgs& a, u32 block, u3
           S.sc[0] = maxBits;
           S.sc[1] = huf_write_ctable(S, maxSym, maxBits);
         }
-      } else if (nbSeq && lane == 0) {
+      } else if (nbSeq) {
         const int k = wave - 1;
-        const u32 maxSymK = k == 0 ? 35 : k == 1 ? 31 : 52, FSELog = k == 1 ? 8 : 9, defLog = k == 1 ? 5 : 6, defMax = k == 0 ? 35 : k == 1 ? 28 : 52;
-        const short* defNorm = k == 0 ? c_LLdef : k == 1 ? c_OFdef : c_MLdef;
-        u32* count = S.seqCnt[k];
-        u32 mx = 0, most = 0;
-        for (u32 sy = 0; sy <= maxSymK; sy++) { if (count[sy]) mx = sy; if (count[sy] > most) most = count[sy]; }
-        const u64 qLast = seqs[nbSeq - 1];
-        const u32 lastCode = k == 0 ? ll_code((u32)qLast & 0xFFFFF) : k == 1 ? hb32((u32)(qLast >> 40)) : ml_code(((u32)(qLast >> 20) & 0xFFFFF) - 3);
-        const ZraFseCTable* prevCT = k == 0 ? &st->ll : k == 1 ? &st->of : &st->ml;
-        u32 repeatMode = first ? 0 : (k == 0 ? st->llRepeat : k == 1 ? st->ofRepeat : st->mlRepeat);
-        const bool defaultAllowed = k != 1 || mx <= 28;
-        const u32 modeK = select_encoding(&repeatMode, count, mx, most, nbSeq, FSELog, prevCT, defNorm, defLog, defaultAllowed, strategy, SB.norm[k], S.ncount[k]);
-        S.mode[k] = modeK; S.nextRepeat[k] = repeatMode; S.ncountSize[k] = 0; S.tblErr[k] = 0;
-        ZraFseCTable* ct = &S.ct[k];
-        if (modeK == 1) { ct->rle = 1; ct->tableLog = 0; ct->maxSym = mx; S.ncount[k][0] = (u8)mx; S.ncountSize[k] = 1; }
-        else if (modeK == 0) { for (u32 sy = 0; sy <= defMax; sy++) SB.norm[k][sy] = defNorm[sy]; if (fse_build_ctable(ct, SB.norm[k], defMax, defLog, SB.spread[k], SB.cumul[k])) S.tblErr[k] = 1; }
-        else if (modeK == 2) {
-          u32 n1 = nbSeq;
-          const u32 tl = fse_optimal_tablelog(FSELog, nbSeq, mx, 2);
-          if (count[lastCode] > 1) { count[lastCode]--; n1--; }
-          if (fse_normalize(SB.norm[k], tl, count, n1, mx, n1 >= 2048) <= 0) S.tblErr[k] = 1;
+        if (lane == 0) {
+          const u32 maxSymK = k == 0 ? 35 : k == 1 ? 31 : 52, FSELog = k == 1 ? 8 : 9, defLog = k == 1 ? 5 : 6, defMax = k == 0 ? 35 : k == 1 ? 28 : 52;
+          const short* defNorm = k == 0 ? c_LLdef : k == 1 ? c_OFdef : c_MLdef;
+          u32* count = S.seqCnt[k];
+          u32 mx = 0, most = 0;
+          for (u32 sy = 0; sy <= maxSymK; sy++) { if (count[sy]) mx = sy; if (count[sy] > most) most = count[sy]; }
+          const u32 lastCode = codesG[(size_t)k * a.seqStride];          // (the block's last sequence is the chains' first)
+          const ZraFseCTable* prevCT = k == 0 ? &st->ll : k == 1 ? &st->of : &st->ml;
+          u32 repeatMode = first ? 0 : (k == 0 ? st->llRepeat : k == 1 ? st->ofRepeat : st->mlRepeat);
+          const bool defaultAllowed = k != 1 || mx <= 28;
+          const u32 modeK = select_encoding(&repeatMode, count, mx, most, nbSeq, FSELog, prevCT, defNorm, defLog, defaultAllowed, strategy, SB.norm[k], S.ncount[k]);
+          S.mode[k] = modeK; S.nextRepeat[k] = repeatMode; S.ncountSize[k] = 0; S.tblErr[k] = 0;
+          ZraFseCTable* ct = &S.ct[k];
+          if (modeK == 1) { ct->rle = 1; ct->tableLog = 0; ct->maxSym = mx; S.ncount[k][0] = (u8)mx; S.ncountSize[k] = 1; }
+          else if (modeK == 0) { for (u32 sy = 0; sy <= defMax; sy++) SB.norm[k][sy] = defNorm[sy]; if (fse_build_ctable(ct, SB.norm[k], defMax, defLog, SB.spread[k], SB.cumul[k])) S.tblErr[k] = 1; }
+          else if (modeK == 2) {
+            u32 n1 = nbSeq;
+            const u32 tl = fse_optimal_tablelog(FSELog, nbSeq, mx, 2);
+            if (count[lastCode] > 1) { count[lastCode]--; n1--; }
+            if (fse_normalize(SB.norm[k], tl, count, n1, mx, n1 >= 2048) <= 0) S.tblErr[k] = 1;
+            else {
+              const u32 h = fse_write_ncount(S.ncount[k], SB.norm[k], mx, tl);
+              if (!h || fse_build_ctable(ct, SB.norm[k], mx, tl, SB.spread[k], SB.cumul[k])) S.tblErr[k] = 1;
+              S.ncountSize[k] = h;
+            }
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");            // (lane 0's table and decisions, for the wave's other lanes)
+        __builtin_amdgcn_wave_barrier();
+        ZraFseCTable* const ct = &S.ct[k];
+        if (S.mode[k] == 3) {
+          // repeat mode: the previous block's table comes into LDS (this wave copies it: it is the one that walks it next)
+          const u32* srcT = (const u32*)(k == 0 ? &st->ll : k == 1 ? &st->of : &st->ml);
+          u32* dstT = (u32*)ct;
+          for (u32 i = (u32)lane; i < sizeof(ZraFseCTable) / 4; i += 64) dstT[i] = srcT[i];
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+          __builtin_amdgcn_wave_barrier();
+        }
+        // ---- the stream's state chain over the whole block: state -> stateTable[(state >> nb) + dfs] -> state, one LDS round trip per
+        // sequence, inherently serial (a step over a probable symbol maps a state next to itself: chains from different start states
+        // do not merge, and a table kept in registers and walked with v_readlane costs more issue slots than the round trip — both
+        // measured in round 5). It ran per tile on three lanes of wave 0 with everybody else waiting: 35-47 % of this kernel's time.
+        // Now it runs HERE, beside the Huffman tree build of wave 0, which takes about as long. All lanes of the wave walk the same
+        // chain (same addresses: LDS broadcasts); 64 codes come in with one load, 64 results leave with one store.
+        if (!S.tblErr[k]) {
+          const u8* const cdG = codesG + (size_t)k * a.seqStride;
+          u16* const chG = chainG + (size_t)k * a.seqStride;
+          if (ct->rle) { for (u32 rl = (u32)lane; rl < nbSeq; rl += 64) chG[rl] = 0; if (lane == 0) S.finalState[k] = 0; }
           else {
-            const u32 h = fse_write_ncount(S.ncount[k], SB.norm[k], mx, tl);
-            if (!h || fse_build_ctable(ct, SB.norm[k], mx, tl, SB.spread[k], SB.cumul[k])) S.tblErr[k] = 1;
-            S.ncountSize[k] = h;
+            // 64 sequences at a time: their codes come in with one load (the next 64 travel meanwhile) and are parked in LDS, lane 0 walks
+            // the 64 steps (the symbol two steps ahead and its parameters one step ahead are fetched beside the critical load), the 64
+            // results leave with one store
+            u8* const cdL = S.chainCodes[k]; u16* const outL = S.chainOut[k];
+            u32 codesV = (u32)lane < nbSeq ? cdG[lane] : 0u, codesN = 0;
+            u32 state = 0;
+            for (u32 base = 0; base < nbSeq; base += 64) {
+              const u32 nIn = min(64u, nbSeq - base);
+              if (base + 64 < nbSeq) codesN = base + 64 + (u32)lane < nbSeq ? cdG[base + 64 + lane] : 0u;
+              cdL[lane] = (u8)codesV;
+              // (one wave, LDS in issue order: a wavefront-scope fence orders the compiler and waits for nothing — a workgroup-scope
+              //  one would wait for the codes in flight and for the stores of the 64 results before)
+              __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+              __builtin_amdgcn_wave_barrier();
+              if (lane == 0) {
+                u32 i = 0;
+                if (base == 0) { state = fse_init_state(ct, cdL[0]); outL[0] = 0; i = 1; }     // the block's last sequence: init only
+                if (i < nIn) {
+                  const u32 last = nIn - 1;
+                  u32 sym1 = cdL[min(i + 1, last)];
+                  u32 dnb = ct->deltaNbBits[cdL[i]]; i32 dfs = ct->deltaFindState[cdL[i]];
+                  for (; i < nIn; i++) {
+                    const u32 nb = (state + dnb) >> 16;
+                    const u32 bits = state & ((1u << nb) - 1);
+                    state = ct->stateTable[(state >> nb) + dfs];                              // critical load first
+                    const u32 dnbN = ct->deltaNbBits[sym1]; const i32 dfsN = ct->deltaFindState[sym1];   // parameters of step i+1
+                    const u32 sym2 = cdL[min(i + 2, last)];                                  // symbol of step i+2
+                    outL[i] = (u16)((nb << 12) | bits);
+                    dnb = dnbN; dfs = dfsN; sym1 = sym2;
+                  }
+                }
+              }
+              __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+              __builtin_amdgcn_wave_barrier();
+              if ((u32)lane < nIn) chG[base + lane] = outL[lane];
+              codesV = codesN;
+            }
+            if (lane == 0) S.finalState[k] = state;
           }
         }
       }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // (the chains' output in the work area, for every wave of the workgroup)
       __syncthreads();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
       EPROF(4)
       // ---- 2c (all threads): old table or new, stream sizes, the section's mode
       if (candidate) {
@@ -807,15 +878,6 @@ __device__ __forceinline__ void entropy_frame(const ZraEncArgs& a, u32 block, u3
     bool uncompressible = false;
     if (nbSeq) {
       u8* const seqHead = op++;
-      // repeat mode: bring the previous table into LDS (cooperative copy), all three streams checked uniformly
-      for (int k = 0; k < 3; k++) {
-        if (S.mode[k] == 3) {
-          const u32* srcT = (const u32*)(k == 0 ? &st->ll : k == 1 ? &st->of : &st->ml);
-          u32* dstT = (u32*)&S.ct[k];
-          for (u32 i = tid; i < sizeof(ZraFseCTable) / 4; i += ENT_THREADS) dstT[i] = srcT[i];
-        }
-      }
-      __syncthreads();
       const bool tblErr = S.tblErr[0] | S.tblErr[1] | S.tblErr[2];
       u8* lastNCount = nullptr;
       if (tid == 0) seqHead[0] = (u8)((S.mode[0] << 6) + (S.mode[1] << 4) + (S.mode[2] << 2));
@@ -825,8 +887,7 @@ __device__ __forceinline__ void entropy_frame(const ZraEncArgs& a, u32 block, u3
         for (u32 i = tid; i < sz; i += ENT_THREADS) op[i] = S.ncount[k][i];
         op += sz;
       }
-      // ---- pass B: FSE state chains (3 lanes) + parallel packing, 1024 sequences per tile, last sequence first
-      u32 state = 0;                       // waves 0..2 carry their stream's state across tiles (wave-uniform)
+      // ---- pass B: parallel packing of the chains' output + the sequences' extra bits, 512 sequences per tile, last sequence first
       u32 carryBits = 0, carryVal = 0, bytesOut = 0;
       const u32 tlog[3] = {S.ct[0].tableLog, S.ct[1].tableLog, S.ct[2].tableLog};
       for (u32 t0 = 0; t0 < nbSeq && !tblErr; t0 += SEQ_TILE) {
@@ -834,70 +895,22 @@ __device__ __forceinline__ void entropy_frame(const ZraEncArgs& a, u32 block, u3
         const bool lastTile = t0 + cntT == nbSeq;
         const u32 zw = ((7 + cntT * 90 + 28) >> 5) + 2;
         for (u32 i = tid; i < zw; i += ENT_THREADS) S.stage[i] = (i == 0) ? carryVal : 0;
-        u32 llv[SEQ_PER], mlb[SEQ_PER], ofv[SEQ_PER], llc[SEQ_PER], mlc[SEQ_PER], ofc[SEQ_PER];
+        u32 llv[SEQ_PER], mlb[SEQ_PER], ofv[SEQ_PER], cL[SEQ_PER], cO[SEQ_PER], cM[SEQ_PER];
 #pragma unroll
         for (int k = 0; k < SEQ_PER; k++) {
           const u32 rl = SEQ_PER * tid + k;                 // reversed local index
           if (rl < cntT) {
             const u64 q = seqs[nbSeq - 1 - (t0 + rl)];
             llv[k] = (u32)q & 0xFFFFF; mlb[k] = ((u32)(q >> 20) & 0xFFFFF) - 3; ofv[k] = (u32)(q >> 40);
-            llc[k] = ll_code(llv[k]); mlc[k] = ml_code(mlb[k]); ofc[k] = hb32(ofv[k]);
-            S.seq.codes[0][rl] = (u8)llc[k]; S.seq.codes[1][rl] = (u8)ofc[k]; S.seq.codes[2][rl] = (u8)mlc[k];
-          } else { llv[k] = mlb[k] = ofv[k] = llc[k] = mlc[k] = ofc[k] = 0; }
+            cL[k] = chainG[t0 + rl]; cO[k] = chainG[a.seqStride + t0 + rl]; cM[k] = chainG[2 * a.seqStride + t0 + rl];
+          } else { llv[k] = mlb[k] = ofv[k] = cL[k] = cO[k] = cM[k] = 0; }
         }
-        __syncthreads();
         EPROF(5)
-        if (wave < 3) {
-          // The state chain of a stream — state -> stateTable[(state >> nb) + dfs] -> state — is serial, except across a symbol with ONE
-          // cell of the table (normalised count 1 or "less than 1"): a step over such a symbol emits the whole state and lands on the
-          // symbol's only state, whatever came before. Round 5: wave k runs stream k's chain of the tile on all 64 lanes, 8 steps per
-          // lane; a lane starts behind the last one-cell symbol in front of its steps (found with one wave-wide running maximum), from
-          // that symbol's state — or at the tile's first step, from the exact incoming state, when there is none. Exact by construction,
-          // no guessing; the wave takes as long as the longest stretch without such a symbol (100-250 steps of a tile's 512 on text-like
-          // input; the whole tile, as before, when a table has no one-cell symbol). The serial form (3 lanes, one LDS round trip per
-          // sequence) was 35 % of this kernel's time.
-          const ZraFseCTable* ct = &S.ct[wave];
-          const u8* const cd = S.seq.codes[wave];
-          u16* const ch = S.seq.chain[wave];
-          const u32 first = t0 == 0 ? 1u : 0u;                                          // the block's last sequence: init only
-          if (t0 == 0) { state = fse_init_state(ct, cd[0]); if (lane == 0) ch[0] = 0; }
-          if (ct->rle) { for (u32 rl = first + (u32)lane; rl < cntT; rl += 64) ch[rl] = 0; }
-          else if (cntT > first) {
-            constexpr u32 CH = SEQ_TILE / 64;
-            const u32 start = CH * (u32)lane, end = min(start + CH, cntT);
-            const bool act = start < cntT;
-            const u32 own0 = max(start, first);                                         // first step this lane records
-            const u32 tl_ = ct->tableLog, oneCell = (tl_ << 16) - (1u << tl_);          // deltaNbBits of a symbol with one cell
-            // the last one-cell step inside this lane's own steps (+1; 0: none), then the running maximum over the lanes below
-            u32 mine = 0;
-            for (u32 rl = own0; rl < end; rl++) if (ct->deltaNbBits[cd[rl]] == oneCell) mine = rl + 1;
-            u32 below = mine;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) { const u32 o = (u32)__shfl_up((int)below, d, 64); if (lane >= d) below = max(below, o); }
-            below = (u32)__shfl_up((int)below, 1, 64); if (lane == 0) below = 0;        // exclusive: steps before `start`
-            u32 st = state, s0 = first;
-            if (act && below) { s0 = below; st = ct->stateTable[ct->deltaFindState[cd[below - 1]] + 1]; }   // behind step below-1: its symbol's only state
-            if (act) {
-              for (u32 rl = s0; rl < end; rl++) {
-                const u32 sym = cd[rl];
-                const u32 d = ct->deltaNbBits[sym]; const i32 f = ct->deltaFindState[sym];
-                const u32 nb = (st + d) >> 16;
-                if (rl >= own0) ch[rl] = (u16)((nb << 12) | (st & ((1u << nb) - 1)));
-                st = ct->stateTable[(st >> nb) + f];
-              }
-            }
-            const u32 nC = (cntT + CH - 1) / CH;
-            state = bcast(st, nC - 1);
-          }
-          if (lastTile && lane == 0) S.finalState[wave] = state;
-        }
-        __syncthreads();
-        EPROF(6)
         u32 nbits = 0;
 #pragma unroll
         for (int k = 0; k < SEQ_PER; k++) {
           const u32 rl = SEQ_PER * tid + k;
-          if (rl < cntT) nbits += (S.seq.chain[0][rl] >> 12) + (S.seq.chain[1][rl] >> 12) + (S.seq.chain[2][rl] >> 12) + c_LLbits[llc[k]] + c_MLbits[mlc[k]] + ofc[k];
+          if (rl < cntT) nbits += (cL[k] >> 12) + (cO[k] >> 12) + (cM[k] >> 12) + c_LLbits[ll_code(llv[k])] + c_MLbits[ml_code(mlb[k])] + hb32(ofv[k]);
         }
         u32 tot;
         const u32 ex = block_excl_scan(S, nbits, &tot);
@@ -906,9 +919,8 @@ __device__ __forceinline__ void entropy_frame(const ZraEncArgs& a, u32 block, u3
         for (int k = 0; k < SEQ_PER; k++) {
           const u32 rl = SEQ_PER * tid + k;
           if (rl < cntT) {
-            const u32 cO = S.seq.chain[1][rl], cM = S.seq.chain[2][rl], cL = S.seq.chain[0][rl];
-            bw.add(cO & 0xFFF, cO >> 12); bw.add(cM & 0xFFF, cM >> 12); bw.add(cL & 0xFFF, cL >> 12);
-            const u32 lb = c_LLbits[llc[k]], mb = c_MLbits[mlc[k]], ob = ofc[k];
+            bw.add(cO[k] & 0xFFF, cO[k] >> 12); bw.add(cM[k] & 0xFFF, cM[k] >> 12); bw.add(cL[k] & 0xFFF, cL[k] >> 12);
+            const u32 lb = c_LLbits[ll_code(llv[k])], mb = c_MLbits[ml_code(mlb[k])], ob = hb32(ofv[k]);
             bw.add(llv[k] & ((1u << lb) - 1), lb);
             bw.add(mlb[k] & ((1u << mb) - 1), mb);
             bw.add(ofv[k] & (ob >= 32 ? 0xFFFFFFFFu : ((1u << ob) - 1)), ob);
@@ -996,72 +1008,128 @@ __device__ __forceinline__ void entropy_frame(const ZraEncArgs& a, u32 block, u3
   }
 }
 
-// (a real call from the persistent kernel: inlined into its queue loop the body spilled 66-74 vector registers under the same 5-waves budget)
-__device__ __attribute__((noinline)) void entropy_frame_call(const ZraEncArgs& a, u32 f, u8* lits, u8* slot, EncShared& S) {
+// (a real call: inlined into the kernel's queue loop the body spilled 66-74 vector registers under the same 5-waves budget)
+__device__ __attribute__((noinline)) void entropy_frame_call(KArgs& a, u32 block, u32 f, u8* lits, u8* slot, u8* work, EncShared& S) {
   // (arguments arrive in vector registers: pin the wave-uniform ones to the scalar unit, or the frame's whole parameter set follows them)
-  f = (u32)__builtin_amdgcn_readfirstlane((int)f);
-  const u64 lp = (u64)lits, sp = (u64)slot;
-  lits = (u8*)(((u64)(u32)__builtin_amdgcn_readfirstlane((int)(lp >> 32)) << 32) | (u32)__builtin_amdgcn_readfirstlane((int)lp));
-  slot = (u8*)(((u64)(u32)__builtin_amdgcn_readfirstlane((int)(sp >> 32)) << 32) | (u32)__builtin_amdgcn_readfirstlane((int)sp));
-  entropy_frame(a, 0u, f, lits, slot, S);
+  f = (u32)__builtin_amdgcn_readfirstlane((int)f); block = (u32)__builtin_amdgcn_readfirstlane((int)block);
+  auto pin = [](u8* p) { const u64 v = (u64)p; return (u8*)(((u64)(u32)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (u32)__builtin_amdgcn_readfirstlane((int)v)); };
+  KArgs& au = *(KArgs*)(((u64)(u32)__builtin_amdgcn_readfirstlane((int)((u64)&a >> 32)) << 32) | (u32)__builtin_amdgcn_readfirstlane((int)(u64)&a));
+  entropy_frame(au, block, f, pin(lits), pin(slot), pin(work), S);
 }
 
-// batch path: one workgroup per frame of the batch, launched per block round behind the batch's match-finder launch
-extern "C" __global__ void __launch_bounds__(ENT_THREADS, ZRA_ENT_WAVES)
-zra_entropy_kernel(ZraEncArgs a, u32 block) {
-  __shared__ EncShared S;
-  // This stage runs beside the match finder of the other scratch context, which fills most issue slots; the one-lane serial
-  // sections here are latency-critical. Raise the wave's issue priority so they are not queued behind match-finder waves.
-  __builtin_amdgcn_s_setprio(3);
-  const u32 f = blockIdx.x;
-  entropy_frame(a, block, f, a.lits + (size_t)f * a.litStride, a.slots + (size_t)f * a.slotStride, S);
+// The entropy stage: workgroups that take frames from a queue, each with its own literal buffer and sequence work area.
+//  * Batch path (multi-block frames, the other strategies): launched per block round behind the batch's match-finder launch; the queue
+//    hands out the batch's frames, nothing to wait for (readyStamp == 0), a slot per frame.
+//  * Persistent pipeline (round 5; single-block dfast frames): the workgroups stay resident BESIDE the persistent match finder — one
+//    per CU is what a CU's LDS and registers hold next to 18-20 match-finder waves — and take frames in frame order: wait until the
+//    match finder has published the frame (its stamp in the block record), encode it into the slot ring, count it for the host's scan +
+//    gather of the sub-batch. Rounds 1-4 launched one workgroup per frame and sub-batch instead; whether a workgroup found room on a CU
+//    then depended on how the match finder's waves had happened to land, and at one workgroup per CU the stage could not keep up.
+//    Every wait gives up after ~10 s of the 100 MHz clock (pipeAbort): the call fails, the GPU does not hang.
+// ---- the pipeline's seek-table build, done by the entropy stage's own workgroups (round 5: launches of a scan / gather kernel on a
+// third stream were not placed while the two persistent kernels held the device — the first gather ran until the match finder left)
+// exclusive scan of the sizes of sub-batch j -> a.offsets (absolute inside the body), *a.running += the sub-batch's bytes
+__device__ __forceinline__ void pipe_scan_subbatch(KArgs& a, u32 j, EncShared& S) {
+  const u32 j0 = j * a.entSubFrames, nbj = min(a.entSubFrames, a.nFrames - j0);
+  const u32 per = (nbj + ENT_THREADS - 1) / ENT_THREADS, i0 = j0 + per * threadIdx.x, i1 = min(i0 + per, j0 + nbj);
+  u32 sum = 0;
+  for (u32 i = i0; i < i1; i++) sum += (u32)a.sizes[i];
+  u32 tot;
+  const u32 ex = block_excl_scan(S, sum, &tot);
+  u64 off = *a.running + ex;
+  for (u32 i = i0; i < i1; i++) { a.offsets[i] = off; off += a.sizes[i]; }
+  __syncthreads();
+  if (threadIdx.x == 0) *a.running += tot;
+}
+// frame `fi` of the launch: from its slot to body + offsets[fi]; seek-table entry and size
+__device__ __forceinline__ void pipe_gather_frame(KArgs& a, u32 fi) {
+  const u64 n = a.sizes[fi], off = a.offsets[fi];
+  const u8* s = a.slots + (size_t)(fi % a.slotRing) * a.slotStride; u8* d = a.gBody + off;
+  const u64 n16 = n >> 4;
+  for (u64 i = threadIdx.x; i < n16; i += ENT_THREADS) {
+    const uint4 v = ((const uint4*)s)[i];
+    st64(d + 16 * i, (u64)v.x | ((u64)v.y << 32)); st64(d + 16 * i + 8, (u64)v.z | ((u64)v.w << 32));
+  }
+  for (u64 i = (n16 << 4) + threadIdx.x; i < n; i += ENT_THREADS) d[i] = s[i];
+  if (threadIdx.x == 0) {
+    if (a.gEntries) { u8* e = a.gEntries + (size_t)(a.firstFrame + fi) * 5; st32(e, (u32)off); e[4] = (u8)(off >> 32); }
+    if (a.gSizesOut) a.gSizesOut[a.firstFrame + fi] = n;
+  }
 }
 
-// Persistent pipeline (round 5; single-block dfast frames): the workgroups of this kernel stay resident BESIDE the persistent match
-// finder — one per CU is what a CU's LDS and registers hold next to 18-20 match-finder waves — and take frames from a queue in frame
-// order: wait until the match finder has published the frame (its stamp in the block record), encode it into the slot ring, count it for
-// the host's scan + gather of the sub-batch. Rounds 1-4 launched one workgroup per frame and sub-batch instead; whether a workgroup found
-// room on a CU then depended on how the match finder's waves had happened to land (the "two states" of the launch time of rounds 2-4:
-// profiles/r05_experiments.md), and at one workgroup per CU the stage could not keep up with the match finder.
-// Every wait gives up after ~10 s of the 100 MHz clock (pipeAbort): the call fails, the GPU does not hang.
+// The entropy stage: workgroups that take frames from a queue, each with its own literal buffer and sequence work area.
+//  * Batch path (multi-block frames, the other strategies): launched per block round behind the batch's match-finder launch; the queue
+//    hands out the batch's frames, nothing to wait for (readyStamp == 0), a slot per frame; the host launches scan and gather.
+//  * Persistent pipeline (round 5; single-block dfast frames): the workgroups stay resident BESIDE the persistent match finder — one
+//    per CU is what a CU's LDS and registers hold next to 18-20 match-finder waves — and take frames in frame order: wait until the
+//    match finder has published the frame (its stamp in the block record), encode it into the slot ring, count it; the workgroup that
+//    completes a sub-batch scans its sizes, and everybody copies encoded frames of scanned sub-batches into the archive between two
+//    frames of their own. Rounds 1-4 launched one workgroup per frame and sub-batch instead; whether a workgroup found room on a CU
+//    then depended on how the match finder's waves had happened to land, and at one workgroup per CU the stage could not keep up.
+//    Nothing waits without doing the other work that is ready, and every wait gives up after ~10 s of the 100 MHz clock (pipeAbort):
+//    the call fails, the GPU does not hang.
 extern "C" __global__ void __launch_bounds__(ENT_THREADS, ZRA_ENT_WAVES)
-zra_entropy_persist_kernel(ZraEncArgs a) {
+zra_entropy_kernel(ZraEncArgs a_, u32 block) {
+  KArgs& a = *(KArgs*)__builtin_amdgcn_kernarg_segment_ptr();     // (= a_, where it arrived)
+  (void)a_;
   __shared__ EncShared S;
-  __builtin_amdgcn_s_setprio(3);
+  // This stage runs beside the match finder, which fills most issue slots; the one-lane serial sections here are latency-critical.
+  // Raise the wave's issue priority so they are not queued behind match-finder waves (a.entPrio: bring-up knob ZRA_ENT_PRIO, default 3).
+  switch (a.entPrio) { case 0: __builtin_amdgcn_s_setprio(0); break; case 1: __builtin_amdgcn_s_setprio(1); break; case 2: __builtin_amdgcn_s_setprio(2); break; default: __builtin_amdgcn_s_setprio(3); break; }
   const int tid = threadIdx.x;
   u8* const lits = a.lits + (size_t)blockIdx.x * a.litStride;
-  u64 tStart = 0, tWait = 0; u32 nDone = 0;            // (thread 0: telemetry)
+  u8* const work = a.entWork + (size_t)blockIdx.x * a.entWorkStride;
+  const bool pipe = a.readyStamp != 0;
+  const u32 SBF = a.entSubFrames, nSub = pipe ? (a.nFrames + SBF - 1) / SBF : 0u, ringSubs = max(1u, a.slotRing / SBF);
+  // thread 0's bookkeeping
+  u32 pend = 0xFFFFFFFFu; bool dry = false;
+  u64 tStart = 0, tWait = 0, idleSince = 0; u32 nDone = 0;
   if (tid == 0 && a.mfTele) {
     const u32 hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;
     atomicAdd((unsigned long long*)&a.mfTele[ZRA_TELE_ENT + 8 + ((xcc << 8) | (((hw >> 13) & 7u) << 5) | (((hw >> 12) & 1u) << 4) | ((hw >> 8) & 15u))], 1ull);
     tStart = wall_clock64();
   }
   for (;;) {
-    __syncthreads();                                   // (S.sc of the frame before is no longer read)
+    __syncthreads();                                   // (S.sc of the step before is no longer read)
     if (tid == 0) {
-      u32 f = atomicAdd(a.entQueue, 1u);
-      if (f < a.nFrames) {
-        const u64 t0 = wall_clock64();
-        const u32 j = f / a.entSubFrames, ringSubs = max(1u, a.slotRing / a.entSubFrames);   // (a call of less than a sub-batch: one slot per frame, nothing to wait for)
-        // the slot of this frame was last used by the frame slotRing before it: gathered?
-        while (j >= ringSubs && __hip_atomic_load(a.gatherDone, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) + ringSubs <= j) {
-          __builtin_amdgcn_s_sleep(32);
-          if (__hip_atomic_load(a.pipeAbort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) || wall_clock64() - t0 > 1000000000ull) { atomicExch(a.pipeAbort, 2u); f = 0xFFFFFFFFu; break; }
+      u32 act = 0, arg = 0;                            // 0 nothing ready (slept), 1 copy frame arg, 2 encode frame arg, 4 leave
+      if (pipe) {
+        // 1. an encoded frame of a scanned sub-batch to copy?
+        u32 j = __hip_atomic_load(a.gatherJ, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while (j < nSub && j < __hip_atomic_load(a.scanDone, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) {
+          const u32 nbj = min(SBF, a.nFrames - j * SBF);
+          const u32 g = __hip_atomic_load(&a.gQueue[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nbj ? atomicAdd(&a.gQueue[j], 1u) : nbj;
+          if (g < nbj) { act = 1; arg = j * SBF + g; break; }
+          atomicCAS(a.gatherJ, j, j + 1);
+          j = __hip_atomic_load(a.gatherJ, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        while (f != 0xFFFFFFFFu && __hip_atomic_load(&a.blockOut[f].ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != a.readyStamp) {
-          __builtin_amdgcn_s_sleep(32);
-          if (__hip_atomic_load(a.pipeAbort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) || wall_clock64() - t0 > 1000000000ull) { atomicExch(a.pipeAbort, 2u); f = 0xFFFFFFFFu; break; }
-        }
-        tWait += wall_clock64() - t0; nDone++;
-      } else f = 0xFFFFFFFFu;
-      S.sc[15] = f;
+      }
+      if (!act) {
+        // 2. a frame to encode: the next of the queue, once its slot is free and the match finder has published it
+        if (pend == 0xFFFFFFFFu && !dry) { const u32 f = atomicAdd(a.entQueue, 1u); if (f < a.nFrames) pend = f; else dry = true; }
+        if (pend != 0xFFFFFFFFu) {
+          bool okF = true;
+          if (pipe) {
+            const u32 j = pend / SBF;
+            if (j >= ringSubs && __hip_atomic_load(a.gatherDone, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) + ringSubs <= j) okF = false;
+            else if (__hip_atomic_load(&a.blockOut[pend].ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != a.readyStamp) okF = false;
+          }
+          if (okF) { act = 2; arg = pend; pend = 0xFFFFFFFFu; nDone++; }
+        } else if (!pipe || __hip_atomic_load(a.gatherDone, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= nSub) act = 4;   // nothing left anywhere
+      }
+      if (pipe && __hip_atomic_load(a.pipeAbort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) act = 4;
+      if (!act) {
+        const u64 t = wall_clock64();
+        if (!idleSince) idleSince = t;
+        else if (t - idleSince > 1000000000ull) { atomicExch(a.pipeAbort, 2u); act = 4; }
+        __builtin_amdgcn_s_sleep(64);
+        tWait += wall_clock64() - t;
+      } else idleSince = 0;
+      S.sc[15] = act; S.sc[14] = arg;
     }
     __syncthreads();
-    const u32 f = (u32)__builtin_amdgcn_readfirstlane((int)S.sc[15]);   // (wave-uniform, and known to be: the frame's parameters stay on the scalar unit)
-    if (f == 0xFFFFFFFFu) {
-      // out of frames — or a wait gave up: then the host's stream waits on the sub-batch counters are let go (scan and gather return at once)
-      if (tid == 0 && __hip_atomic_load(a.pipeAbort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-        for (u32 j = 0; j * a.entSubFrames < a.nFrames; j++) atomicOr(&a.entDone[j], 0x40000000u);
+    const u32 act = (u32)__builtin_amdgcn_readfirstlane((int)S.sc[15]), arg = (u32)__builtin_amdgcn_readfirstlane((int)S.sc[14]);
+    if (act == 4) {
       if (tid == 0 && a.mfTele && nDone > 0) {
         u64* const t = a.mfTele + ZRA_TELE_ENT;
         atomicAdd((unsigned long long*)&t[0], 1ull); atomicAdd((unsigned long long*)&t[1], wall_clock64() - tStart);
@@ -1069,11 +1137,51 @@ zra_entropy_persist_kernel(ZraEncArgs a) {
       }
       return;
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // what the match finder wrote for this frame (sequences, block record)
-    entropy_frame_call(a, f, lits, a.slots + (size_t)(f % a.slotRing) * a.slotStride, S);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // the slot and the frame's size, before the count
-    __syncthreads();
-    if (tid == 0) atomicAdd(&a.entDone[f / a.entSubFrames], 1u);
+    if (act == 0) continue;
+    if (act == 1) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");             // the frame's slot, size and offset (other workgroups wrote them)
+      pipe_gather_frame(a, arg);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");             // (the slot has been read: it may be written again once the sub-batch is through)
+      __syncthreads();
+      if (tid == 0) {
+        const u32 j = arg / SBF, nbj = min(SBF, a.nFrames - j * SBF);
+        if (atomicAdd(&a.gCopied[j], 1u) + 1 == nbj) {
+          // sub-batches finish in any order: move the count of finished ones over every one that is complete
+          for (;;) {
+            const u32 d = __hip_atomic_load(a.gatherDone, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+            if (d >= nSub || __hip_atomic_load(&a.gCopied[d], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != min(SBF, a.nFrames - d * SBF)) break;
+            atomicCAS(a.gatherDone, d, d + 1);
+          }
+        }
+      }
+      continue;
+    }
+    // act == 2: encode frame `arg`
+    if (pipe) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");     // what the match finder wrote for this frame (sequences, block record)
+    entropy_frame_call(a, block, arg, lits, a.slots + (size_t)(arg % a.slotRing) * a.slotStride, work, S);
+    if (pipe) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");             // the slot and the frame's size, before the count
+      __syncthreads();
+      const u32 j = arg / SBF, nbj = min(SBF, a.nFrames - j * SBF);
+      if (tid == 0) S.sc[13] = atomicAdd(&a.entDone[j], 1u) + 1 == nbj ? 1u : 0u;
+      __syncthreads();
+      if (S.sc[13]) {
+        // this workgroup encoded the sub-batch's last frame: it scans the sizes, behind the scan of the sub-batch before
+        if (tid == 0) {
+          const u64 t0 = wall_clock64();
+          while (__hip_atomic_load(a.scanDone, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != j) {
+            __builtin_amdgcn_s_sleep(16);
+            if (__hip_atomic_load(a.pipeAbort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) || wall_clock64() - t0 > 1000000000ull) { atomicExch(a.pipeAbort, 2u); break; }
+          }
+        }
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");           // every frame size of the sub-batch, the running offset
+        pipe_scan_subbatch(a, j, S);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(a.scanDone, j + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
   }
 }
 

@@ -257,11 +257,12 @@ Status Engine::create(Engine** out, int device) {
   e->numCUs_ = prop.multiProcessorCount;
   if (hipStreamCreateWithFlags(&e->stream_, hipStreamNonBlocking) != hipSuccess) { delete e; return zerr(1); }
   {
-    // stream B carries the entropy stage + scan + gather under the persistent match finder. Bring-up knob ZRA_ENT_PRIO=1: at the highest
-    // stream priority, so that its short workgroups are placed ahead of nothing (the match finder is resident) but ahead of other engines
-    static const int entPrio = std::getenv("ZRA_ENT_PRIO") ? std::atoi(std::getenv("ZRA_ENT_PRIO")) : 0;
+    // Stream B carries the persistent entropy stage (which also scans and gathers) beside the persistent match finder of stream A.
+    // The runtime multiplexes streams onto a handful of hardware queues per priority class, and two streams that land on one queue run
+    // their kernels one after the other — two persistent kernels that wait for each other must not: B gets the highest priority class,
+    // a queue that stream A (normal priority) is never put on.
     int lo = 0, hi = 0;
-    if (entPrio && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi != lo) {
+    if (hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi != lo) {
       if (hipStreamCreateWithPriority(&e->stream2_, hipStreamNonBlocking, hi) != hipSuccess) { delete e; return zerr(1); }
     } else if (hipStreamCreateWithFlags(&e->stream2_, hipStreamNonBlocking) != hipSuccess) { delete e; return zerr(1); }
   }
@@ -279,7 +280,7 @@ Status Engine::release_scratch() {
   for (DevBuf* b : {&raPlan_, &raLimit_, &raPieceBase_, &raPieces_, &decFrames_, &decTables_, &decLists_, &decCounters_, &decLits_, &decSeqs_, &roundN_, &status_,
                     &produced_, &frameMeta_, &frameOff_, &outOff_, &expect_, &result_, &temp_, &qmeta_, &encScan_, &hostIn_, &hostOut_, &seqScratch_, &mfFlags_})
     b->release();
-  for (auto& x : encCtx_) for (DevBuf* b : {&x.tables, &x.seqs, &x.lits, &x.slots, &x.misc, &x.ck, &x.sizes}) b->release();
+  for (auto& x : encCtx_) for (DevBuf* b : {&x.tables, &x.seqs, &x.lits, &x.work, &x.slots, &x.misc, &x.ck, &x.sizes}) b->release();
   decCountersClean_ = false;
   return ok();
 }
@@ -290,7 +291,7 @@ Engine::~Engine() {
   for (DevBuf* b : {&raPlan_, &raLimit_, &raPieceBase_, &raPieces_, &decFrames_, &decTables_, &decLists_, &decCounters_, &decLits_, &decSeqs_, &roundN_, &status_, &produced_, &frameMeta_, &frameOff_, &outOff_, &expect_, &result_, &temp_, &qmeta_,
                     &encScan_, &hostIn_, &hostOut_, &seqScratch_, &mfFlags_})
     b->release();
-  for (auto& x : encCtx_) for (DevBuf* b : {&x.tables, &x.seqs, &x.lits, &x.slots, &x.misc, &x.ck, &x.sizes}) b->release();
+  for (auto& x : encCtx_) for (DevBuf* b : {&x.tables, &x.seqs, &x.lits, &x.work, &x.slots, &x.misc, &x.ck, &x.sizes}) b->release();
   for (auto ev : evPool_) (void)hipEventDestroy(ev);
   for (auto ev : stageEv_) (void)hipEventDestroy(ev);
   if (stream2_) { (void)hipStreamSynchronize(stream2_); (void)hipStreamDestroy(stream2_); }

@@ -171,29 +171,43 @@ struct ZraEncArgs {
   uint64_t tableStride;    // words per frame
   uint64_t* seqs;          // nFrames * seqStride packed sequences: ll | ml<<20 | offsetValue<<40
   uint64_t seqStride;
-  uint8_t* lits;           // nFrames * litStride literal bytes of the current block
+  uint8_t* lits;           // per entropy-stage workgroup: litStride literal bytes of the block it is encoding
   uint64_t litStride;
-  uint8_t* slots;          // nFrames * slotStride: the encoded frames, one per slot
+  uint8_t* entWork;        // per entropy-stage workgroup: the sequence section's codes [3][seqStride] u8 + chain output [3][seqStride] u16
+  uint64_t entWorkStride;
+  uint8_t* slots;          // slotRing * slotStride: the encoded frames, frame f in slot f % slotRing
   uint64_t slotStride;
   ZraEncFrameState* state; // [nFrames]
   ZraEncBlockOut* blockOut;// [nFrames]
   uint32_t* contentCk;     // [nFrames] XXH64 low 32 bits of each frame's input
   uint64_t* sizes;         // [nFrames] final frame sizes (written with the last block)
-  // persistent pipeline (single-block dfast frames): TWO persistent kernels. The match finder's waves pull frame indices from `mfQueue`,
-  // use the hash-table slot of their workgroup (tables = nSlots * tableStride) and publish a finished frame by writing `readyStamp` into
-  // its block record (ZraEncBlockOut::ready). The entropy stage's workgroups (zra_entropy_persist_kernel) pull frame indices from
-  // `entQueue`, wait for the frame's stamp, encode it into slot (frame % slotRing) and count it in entDone[frame / entSubFrames]; the
-  // host's scan + gather of a sub-batch is released by a stream wait on that counter and raises `gatherDone` when the sub-batch's slots
-  // are free again. mfQueue == nullptr: one workgroup per frame, tables per frame (batch path).
+  // persistent pipeline (single-block dfast frames): TWO persistent kernels and nothing else. The match finder's waves pull frame indices
+  // from `mfQueue`, use the hash-table slot of their workgroup (tables = nSlots * tableStride) and publish a finished frame by writing
+  // `readyStamp` into its block record (ZraEncBlockOut::ready). The entropy stage's workgroups (zra_entropy_kernel) pull frame indices
+  // from `entQueue`, wait for the frame's stamp, encode it into slot (frame % slotRing) and count it in entDone[frame / entSubFrames];
+  // the workgroup that completes a sub-batch scans its frame sizes (offsets[], *running; sub-batches in order: scanDone), and every
+  // workgroup, between two frames, copies encoded frames of scanned sub-batches to their place in the archive (gQueue / gCopied per
+  // sub-batch, gatherJ = the sub-batch being handed out, gatherDone = sub-batches whose slots are free again).
+  // mfQueue == nullptr: one workgroup per frame, tables per frame (batch path; its entropy launches use entQueue alone, readyStamp 0).
   uint32_t* mfQueue;
   uint32_t* mfStarted;     // counts the match finder's waves as they start (the entropy stage is launched once all of them are resident)
   uint32_t* entQueue;
-  uint32_t* entDone;
-  uint32_t* gatherDone;    // sub-batches of this launch whose slots have been gathered
+  uint32_t* entDone;       // [sub-batches]
+  uint32_t* scanDone;
+  uint32_t* gatherJ;
+  uint32_t* gQueue;        // [sub-batches]
+  uint32_t* gCopied;       // [sub-batches]
+  uint32_t* gatherDone;
   uint32_t* pipeAbort;     // non-zero: give up waiting (error exit of the host, or a wait that ran out of patience)
+  uint64_t* offsets;       // [nFrames] offset of each frame inside the body (written by the scans)
+  uint64_t* running;       // body bytes so far (carried from launch to launch)
+  uint8_t* gBody;          // the archive's body
+  uint8_t* gEntries;       // seek-table entries (5 bytes per frame of the call) or nullptr
+  uint64_t* gSizesOut;     // u64 size per frame of the call, or nullptr
   uint32_t entSubFrames;
   uint32_t slotRing;       // frames the slot buffer holds
   uint32_t readyStamp;
+  uint32_t entPrio;        // issue priority of the entropy stage's waves (s_setprio 0..3)
   // launch telemetry of the persistent match finder (nullptr: none), written by lane 0 of every wave: where the wave sat (XCD / SE / CU),
   // its shader cycles against the constant 100 MHz clock (the effective shader clock of the launch), frames taken per XCD
   uint64_t* mfTele;        // ZRA_TELE_WORDS u64
