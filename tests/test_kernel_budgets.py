@@ -13,7 +13,7 @@ sys.path.insert(0, os.path.dirname(HERE))
 # kernel -> (max VGPRs, max scratch bytes per lane)
 BUDGET = {
     "zra_mf_dfast_kernel": (72, 0),      # 18 resident waves per CU with 6 KiB LDS each (the allocation granule is 8 registers: 65-72 cost the same 7 waves per SIMD)
-    "zra_mf_dfast_fl_kernel": (80, 0),   # the same parse behind the wave's own bucket-flag sweep (the headline kernel since round 5): 6 waves per SIMD, 20 per CU wanted
+    "zra_mf_dfast_fl_kernel": (80, 64),  # the same parse behind the wave own bucket-flag sweep (the headline kernel since round 5): 80 registers so that five of its waves leave room for the entropy stage wave on a SIMD (two registers spilled for it, in the sweep)
     "zra_mf_dfast_ls_kernel": (96, 0),   # the same parse over a copy of the frame in LDS (calls of a few hundred frames): one or two waves per CU by LDS, registers are not its limit
     "zra_mf_hc_kernel": (64, 0),         # one wave per frame, as many waves per CU as the hardware holds
     "zra_mf_fast_kernel": (64, 384),     # lane = frame; the scratch is the per-lane frame descriptor + a copy of the argument block

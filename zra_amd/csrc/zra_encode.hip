@@ -397,11 +397,16 @@ Status Engine::compress_persistent(const uint8_t* dIn, size_t inSize, uint8_t* d
   const uint64_t nFramesTotal = (inSize + frameSize - 1) / frameSize;
   const size_t tailSize = inSize % frameSize;
   const auto mfGeneric = (full.strategy >= 7 || tail.strategy >= 7) ? zra_mf_opt_kernel : zra_mf_kernel;
-  // Round 5: the entropy stage runs BEHIND the match-finder launch (pipeMode 0 below), so the finder has the CUs to itself: 22 resident
-  // waves per CU (6.5 KiB of LDS and 76 registers each). With the bucket flags fewer table requests queue up and more waves in flight
-  // pay again (one box, 16 GiB: 18 waves 922 ms, 20 waves 855, 22 waves 846, 24 waves 846; without the flags 18 = 24 waves, round 4).
-  // ZRA_PIPE=2 (entropy stage resident beside the finder, one workgroup per CU) wants 18.
-  static const int pipeMode = std::getenv("ZRA_PIPE") ? std::atoi(std::getenv("ZRA_PIPE")) : 0;
+  // How the entropy stage shares the device with the match finder (ZRA_PIPE; one box, 16 GiB, round 4's library 997-999 ms in its slower
+  // state on that box — profiles/r05_experiments.md):
+  //   1 (default)  round 4's overlap: per sub-batch of 8192 frames one entropy launch + scan + gather on stream B, released by the
+  //                finder's count of finished frames; 18 finder waves per CU leave room for one entropy workgroup.  938 ms
+  //   0            the entropy stage behind the whole finder launch: 22 finder waves per CU (842 ms) + 190 ms.       1038 ms
+  //   2            the entropy stage resident beside the finder, one queue-driven workgroup per CU, scanning and gathering itself:
+  //                the finder loses what the stage gains.                                                      988-1075 ms
+  // With the bucket flags fewer table requests queue up and more finder waves pay again (alone: 18 waves 880-897 ms, 20 waves 855-862,
+  // 22 and 24 waves 824-846; without the flags 18 = 24 waves, round 4) — but the entropy stage needs its room: at 20 waves it falls behind.
+  static const int pipeMode = std::getenv("ZRA_PIPE") ? std::atoi(std::getenv("ZRA_PIPE")) : 1;
   static const uint32_t wavesPerCU = std::getenv("ZRA_MF_WAVES") ? (uint32_t)std::atoi(std::getenv("ZRA_MF_WAVES")) : (pipeMode == 0 ? 22u : 18u);
   static const uint32_t SB = std::getenv("ZRA_ENC_SUB") ? (uint32_t)std::atoi(std::getenv("ZRA_ENC_SUB")) : 8192u;   // frames per sub-batch
   const uint32_t nSlots = (uint32_t)std::min<uint64_t>((uint64_t)numCUs_ * wavesPerCU, nFramesTotal);
@@ -433,7 +438,7 @@ Status Engine::compress_persistent(const uint8_t* dIn, size_t inSize, uint8_t* d
   // Round 5 measured both on one box (16 GiB, profiles/r05_experiments.md): beside the finder the stage keeps up (0.92-0.97 ms per frame
   // and workgroup), and slows the finder from 846-970 ms to 1020-1075 ms: its work is ALU and LDS work, not idle latency, and costs about
   // what it costs alone. Behind the finder: 846 + 187 ms.
-  static const uint32_t entPerCU = std::getenv("ZRA_ENT_WGS") ? (uint32_t)std::max(1, std::atoi(std::getenv("ZRA_ENT_WGS"))) : (pipeMode == 0 ? 5u : 1u);
+  static const uint32_t entPerCU = std::getenv("ZRA_ENT_WGS") ? (uint32_t)std::max(1, std::atoi(std::getenv("ZRA_ENT_WGS"))) : (pipeMode == 0 ? 5u : pipeMode == 1 ? 8u : 1u);
   const uint32_t entGrid = (uint32_t)std::min<uint64_t>((uint64_t)numCUs_ * entPerCU, nFramesTotal);
   const uint64_t entWorkStride = (9 * seqStride + 255) & ~255ull;
   static const uint32_t ringSubsEnv = std::getenv("ZRA_ENC_RING") ? (uint32_t)std::max(2, std::atoi(std::getenv("ZRA_ENC_RING"))) : 4u;   // sub-batches the slot ring holds
@@ -459,8 +464,8 @@ Status Engine::compress_persistent(const uint8_t* dIn, size_t inSize, uint8_t* d
     (void)hipGetLastError();
   }
   // counters: [u64 running offset][pad][abort + 3 pad][per super-batch 8: mf queue, mf started, entropy queue, scanned, handing out,
-  // gathered, 2 pad][per sub-batch 3: encoded, handed out for copying, copied]
-  const size_t nCnt = 4 + 8 * (size_t)nSuper + 3 * (size_t)(nSuper * subsPerSuper) + 4;
+  // gathered, 2 pad][per sub-batch 4: encoded, handed out for copying, copied, finished by the match finder]
+  const size_t nCnt = 4 + 8 * (size_t)nSuper + 4 * (size_t)(nSuper * subsPerSuper) + 4;
   const size_t cntCore = (16 + 4 * nCnt + 15) & ~(size_t)15;
   const size_t cntBytes = cntCore + 8 * (size_t)ZRA_TELE_WORDS;      // + the launch telemetry (ZraEncArgs::mfTele)
   if (!encScan_.reserve(cntBytes)) return zerr(64);
@@ -468,7 +473,7 @@ Status Engine::compress_persistent(const uint8_t* dIn, size_t inSize, uint8_t* d
   uint32_t* dCnt = (uint32_t*)(encScan_.as<uint8_t>() + 16);
   uint32_t* dAbort = dCnt;                       // [0]
   uint32_t* dPerSuper = dCnt + 4;                // 8 words per super-batch
-  uint32_t* dPerSub = dPerSuper + 8 * nSuper;    // 3 x subsPerSuper words per super-batch
+  uint32_t* dPerSub = dPerSuper + 8 * nSuper;    // 4 x subsPerSuper words per super-batch
   HIPCHK(hipMemsetAsync(encScan_.as<uint8_t>(), 0, cntBytes, stream_));
   encCounters_ = dCnt; encCountersBytes_ = 4 * (4 + 8 * (size_t)nSuper);   // (an error exit fills them with 0x7F: the abort word is set, the queues are past their ends, every wait of the two kernels and of stream B ends)
 
@@ -543,7 +548,8 @@ Status Engine::compress_persistent(const uint8_t* dIn, size_t inSize, uint8_t* d
     a.contentCk = x.ck.as<uint32_t>();
     a.sizes = x.sizes.as<uint64_t>();
     a.mfQueue = dPerSuper + 8 * S; a.mfStarted = a.mfQueue + 1; a.entQueue = a.mfQueue + 2; a.scanDone = a.mfQueue + 3; a.gatherJ = a.mfQueue + 4; a.gatherDone = a.mfQueue + 5;
-    a.entDone = dPerSub + 3 * S * subsPerSuper; a.gQueue = a.entDone + subsPerSuper; a.gCopied = a.gQueue + subsPerSuper;
+    a.entDone = dPerSub + 4 * S * subsPerSuper; a.gQueue = a.entDone + subsPerSuper; a.gCopied = a.gQueue + subsPerSuper;
+    a.mfDone = pipeMode == 1 ? a.gCopied + subsPerSuper : nullptr;
     a.offsets = x.sizes.as<uint64_t>() + SBIG;
     // the context's per-frame scratch is free once the last sub-batch that used it has been gathered
     if (superDone[c]) HIPCHK(hipStreamWaitEvent(stream_, superDone[c], 0));
@@ -569,9 +575,45 @@ Status Engine::compress_persistent(const uint8_t* dIn, size_t inSize, uint8_t* d
       else hipLaunchKernelGGL(mfGeneric, dim3(1), dim3(64), 0, stream_, at, 0u, (uint32_t)(n - 1), 0u, 1u);
       HIPCHK(hipStreamWriteValue32(stream_, &a.blockOut[n - 1].ready, a.readyStamp, 0));
     }
+    if (pipeMode == 1) {
+      // ---- round 4's overlap, with this round's kernels: per sub-batch of 8192 frames, released by the match finder's own count of
+      // finished frames, one entropy launch + scan + gather on stream B. The stage's workgroups come and go: they sit where a CU has
+      // room beside the finder's waves, and nowhere when there is nothing to do.
+      if (checksum)
+        hipLaunchKernelGGL(zra_content_ck_kernel, dim3((n * 4 + 255) / 256), dim3(256), 0, stream2_, dIn, (u64)inSize, frameSize, (u32)F0, n, a.contentCk);
+      const uint32_t nSub1 = (n + SB - 1) / SB;
+      hipEvent_t eLast = nullptr;
+      for (uint32_t j = 0; j < nSub1; j++) {
+        const uint32_t j0 = j * SB, nbj = std::min<uint32_t>(SB, n - j0);
+        const bool hasOdd = oddTail && j == nSub1 - 1;
+        HIPCHK(hipStreamWaitValue32(stream2_, a.mfDone + j, nbj - (hasOdd ? 1u : 0u), hipStreamWaitValueGte, 0xFFFFFFFFu));
+        if (hasOdd) { hipEvent_t te = ev(); if (!te) return zerr(1); HIPCHK(hipEventRecord(te, stream_)); HIPCHK(hipStreamWaitEvent(stream2_, te, 0)); }
+        ZraEncArgs aj = a;
+        aj.firstFrame = (uint32_t)(F0 + j0); aj.nFrames = nbj;
+        aj.seqs = a.seqs + (size_t)j0 * seqStride; aj.state = a.state + j0; aj.blockOut = a.blockOut + j0;
+        aj.contentCk = a.contentCk + j0; aj.sizes = a.sizes + j0;
+        aj.readyStamp = 0; aj.slotRing = (uint32_t)std::min<uint64_t>(SB, slotRing); aj.entSubFrames = SB;
+        aj.entQueue = a.entDone + j;                     // (a zeroed word per sub-batch: the launch's frame queue)
+        uint64_t* dOffsets = x.sizes.as<uint64_t>() + SBIG + j0;
+        hipEvent_t e0 = ev(), e1 = ev(); if (!e0 || !e1) return zerr(1);
+        HIPCHK(hipEventRecord(e0, stream2_));
+        hipLaunchKernelGGL(zra_entropy_kernel, dim3(std::min<uint32_t>(nbj, entGrid)), dim3(256), 0, stream2_, aj, 0u);
+        HIPCHK(hipEventRecord(e1, stream2_));
+        entSpans.push_back({e0, e1});
+        hipLaunchKernelGGL(zra_scan_sizes_kernel, dim3(1), dim3(64), 0, stream2_, aj.sizes, nbj, dOffsets, dRunning, (const u32*)nullptr);
+        hipLaunchKernelGGL(zra_gather_frames_kernel, dim3(nbj), dim3(256), 0, stream2_, aj.slots, slotStride, aj.sizes, dOffsets, dBody,
+                           bodyBase0, dEntries ? dEntries : nullptr, (u32)(F0 + j0), dSizes, (const u32*)nullptr);
+        eLast = e1;
+      }
+      hipEvent_t done = ev(); if (!done) return zerr(1);
+      HIPCHK(hipEventRecord(done, stream2_));
+      superDone[c] = done;
+      (void)eLast;
+      continue;
+    }
     // stream B: once every wave of the match finder is resident (they are placed first, side by side: what is left of each CU is one
-    // contiguous piece), the content checksums, then the persistent entropy stage. ZRA_PIPE=0 (bring-up): the entropy stage only
-    // behind the whole match-finder launch, with as many workgroups as the device holds
+    // contiguous piece), the content checksums, then the queue-driven entropy stage. pipeMode 0: only behind the whole match-finder
+    // launch, with as many workgroups as the device holds; pipeMode 2: at once, resident beside the finder
     if (pipeMode == 0) HIPCHK(hipStreamWaitEvent(stream2_, m1, 0));
     else HIPCHK(hipStreamWaitValue32(stream2_, a.mfStarted, mfGrid, hipStreamWaitValueGte, 0xFFFFFFFFu));
     if (checksum)

@@ -687,9 +687,12 @@ __device__ __forceinline__ void entropy_frame(KArgs& a, u32 block, u32 f, u8* li
           S.sc[0] = maxBits;
           S.sc[1] = huf_write_ctable(S, maxSym, maxBits);
         }
-      } else if (nbSeq) {
-        const int k = wave - 1;
-        if (lane == 0) {
+      } else if (nbSeq && wave == 1) {
+        // ---- wave 1: the three sequence tables and the three state chains, stream k on lane k. ONE wave (beside wave 0's tree build),
+        // not three: this stage runs beside the match finder, and every wave that issues one-lane code at a raised priority takes issue
+        // slots from it (round 5: with a wave per stream the finder lost 10-25 %, with round 4's single wave nothing measurable)
+        const int k = lane;
+        if (lane < 3) {
           const u32 maxSymK = k == 0 ? 35 : k == 1 ? 31 : 52, FSELog = k == 1 ? 8 : 9, defLog = k == 1 ? 5 : 6, defMax = k == 0 ? 35 : k == 1 ? 28 : 52;
           const short* defNorm = k == 0 ? c_LLdef : k == 1 ? c_OFdef : c_MLdef;
           u32* count = S.seqCnt[k];
@@ -716,67 +719,72 @@ __device__ __forceinline__ void entropy_frame(KArgs& a, u32 block, u32 f, u8* li
             }
           }
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");            // (lane 0's table and decisions, for the wave's other lanes)
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");            // (the three lanes' tables and decisions, for the wave's other lanes)
         __builtin_amdgcn_wave_barrier();
-        ZraFseCTable* const ct = &S.ct[k];
-        if (S.mode[k] == 3) {
-          // repeat mode: the previous block's table comes into LDS (this wave copies it: it is the one that walks it next)
-          const u32* srcT = (const u32*)(k == 0 ? &st->ll : k == 1 ? &st->of : &st->ml);
-          u32* dstT = (u32*)ct;
-          for (u32 i = (u32)lane; i < sizeof(ZraFseCTable) / 4; i += 64) dstT[i] = srcT[i];
-          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-          __builtin_amdgcn_wave_barrier();
+        for (int kk = 0; kk < 3; kk++) {
+          if (S.mode[kk] == 3) {
+            // repeat mode: the previous block's table comes into LDS
+            const u32* srcT = (const u32*)(kk == 0 ? &st->ll : kk == 1 ? &st->of : &st->ml);
+            u32* dstT = (u32*)&S.ct[kk];
+            for (u32 i = (u32)lane; i < sizeof(ZraFseCTable) / 4; i += 64) dstT[i] = srcT[i];
+          }
         }
-        // ---- the stream's state chain over the whole block: state -> stateTable[(state >> nb) + dfs] -> state, one LDS round trip per
-        // sequence, inherently serial (a step over a probable symbol maps a state next to itself: chains from different start states
-        // do not merge, and a table kept in registers and walked with v_readlane costs more issue slots than the round trip — both
-        // measured in round 5). It ran per tile on three lanes of wave 0 with everybody else waiting: 35-47 % of this kernel's time.
-        // Now it runs HERE, beside the Huffman tree build of wave 0, which takes about as long. All lanes of the wave walk the same
-        // chain (same addresses: LDS broadcasts); 64 codes come in with one load, 64 results leave with one store.
-        if (!S.tblErr[k]) {
-          const u8* const cdG = codesG + (size_t)k * a.seqStride;
-          u16* const chG = chainG + (size_t)k * a.seqStride;
-          if (ct->rle) { for (u32 rl = (u32)lane; rl < nbSeq; rl += 64) chG[rl] = 0; if (lane == 0) S.finalState[k] = 0; }
-          else {
-            // 64 sequences at a time: their codes come in with one load (the next 64 travel meanwhile) and are parked in LDS, lane 0 walks
-            // the 64 steps (the symbol two steps ahead and its parameters one step ahead are fetched beside the critical load), the 64
-            // results leave with one store
-            u8* const cdL = S.chainCodes[k]; u16* const outL = S.chainOut[k];
-            u32 codesV = (u32)lane < nbSeq ? cdG[lane] : 0u, codesN = 0;
-            u32 state = 0;
-            for (u32 base = 0; base < nbSeq; base += 64) {
-              const u32 nIn = min(64u, nbSeq - base);
-              if (base + 64 < nbSeq) codesN = base + 64 + (u32)lane < nbSeq ? cdG[base + 64 + lane] : 0u;
-              cdL[lane] = (u8)codesV;
-              // (one wave, LDS in issue order: a wavefront-scope fence orders the compiler and waits for nothing — a workgroup-scope
-              //  one would wait for the codes in flight and for the stores of the 64 results before)
-              __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-              __builtin_amdgcn_wave_barrier();
-              if (lane == 0) {
-                u32 i = 0;
-                if (base == 0) { state = fse_init_state(ct, cdL[0]); outL[0] = 0; i = 1; }     // the block's last sequence: init only
-                if (i < nIn) {
-                  const u32 last = nIn - 1;
-                  u32 sym1 = cdL[min(i + 1, last)];
-                  u32 dnb = ct->deltaNbBits[cdL[i]]; i32 dfs = ct->deltaFindState[cdL[i]];
-                  for (; i < nIn; i++) {
-                    const u32 nb = (state + dnb) >> 16;
-                    const u32 bits = state & ((1u << nb) - 1);
-                    state = ct->stateTable[(state >> nb) + dfs];                              // critical load first
-                    const u32 dnbN = ct->deltaNbBits[sym1]; const i32 dfsN = ct->deltaFindState[sym1];   // parameters of step i+1
-                    const u32 sym2 = cdL[min(i + 2, last)];                                  // symbol of step i+2
-                    outL[i] = (u16)((nb << 12) | bits);
-                    dnb = dnbN; dfs = dfsN; sym1 = sym2;
-                  }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        // ---- the state chains over the whole block: state -> stateTable[(state >> nb) + dfs] -> state, one LDS round trip per sequence,
+        // inherently serial (a step over a probable symbol maps a state next to itself: chains from different start states do not merge,
+        // and a table kept in registers and walked with v_readlane costs more issue slots than the round trip — both measured in round
+        // 5). It ran per tile with everybody else waiting: 35-47 % of this kernel's time. Now it runs HERE, beside the Huffman tree build
+        // of wave 0, which takes about as long. 64 sequences at a time: their codes come in with one load per stream (the next 64
+        // travel meanwhile) and are parked in LDS, lanes 0-2 walk the 64 steps of their streams (the symbol two steps ahead and its
+        // parameters one step ahead are fetched beside the critical load), the results leave with one store per stream.
+        {
+          const bool runK = lane < 3 && !S.tblErr[k] && !S.ct[lane < 3 ? k : 0].rle;
+          const ZraFseCTable* const ct = &S.ct[lane < 3 ? k : 0];
+          u8* const cdL = S.chainCodes[lane < 3 ? k : 0]; u16* const outL = S.chainOut[lane < 3 ? k : 0];
+          u32 cV[3], cN[3] = {0, 0, 0};
+#pragma unroll
+          for (int kk = 0; kk < 3; kk++) cV[kk] = (u32)lane < nbSeq ? codesG[(size_t)kk * a.seqStride + lane] : 0u;
+          u32 state = 0;
+          for (u32 base = 0; base < nbSeq; base += 64) {
+            const u32 nIn = min(64u, nbSeq - base);
+#pragma unroll
+            for (int kk = 0; kk < 3; kk++) {
+              if (base + 64 < nbSeq) cN[kk] = base + 64 + (u32)lane < nbSeq ? codesG[(size_t)kk * a.seqStride + base + 64 + lane] : 0u;
+              S.chainCodes[kk][lane] = (u8)cV[kk];
+            }
+            // (one wave, LDS in issue order: a wavefront-scope fence orders the compiler and waits for nothing — a workgroup-scope one
+            //  would wait for the codes in flight and for the stores of the 64 results before)
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (runK) {
+              u32 i = 0;
+              if (base == 0) { state = fse_init_state(ct, cdL[0]); outL[0] = 0; i = 1; }     // the block's last sequence: init only
+              if (i < nIn) {
+                const u32 last = nIn - 1;
+                u32 sym1 = cdL[min(i + 1, last)];
+                u32 dnb = ct->deltaNbBits[cdL[i]]; i32 dfs = ct->deltaFindState[cdL[i]];
+                for (; i < nIn; i++) {
+                  const u32 nb = (state + dnb) >> 16;
+                  const u32 bits = state & ((1u << nb) - 1);
+                  state = ct->stateTable[(state >> nb) + dfs];                              // critical load first
+                  const u32 dnbN = ct->deltaNbBits[sym1]; const i32 dfsN = ct->deltaFindState[sym1];   // parameters of step i+1
+                  const u32 sym2 = cdL[min(i + 2, last)];                                  // symbol of step i+2
+                  outL[i] = (u16)((nb << 12) | bits);
+                  dnb = dnbN; dfs = dfsN; sym1 = sym2;
                 }
               }
-              __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-              __builtin_amdgcn_wave_barrier();
-              if ((u32)lane < nIn) chG[base + lane] = outL[lane];
-              codesV = codesN;
             }
-            if (lane == 0) S.finalState[k] = state;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int kk = 0; kk < 3; kk++) {
+              // (a one-symbol table emits no state bits; after a table error the section is dropped: zeros either way)
+              if ((u32)lane < nIn) chainG[(size_t)kk * a.seqStride + base + lane] = (S.ct[kk].rle || S.tblErr[kk]) ? (u16)0 : S.chainOut[kk][lane];
+              cV[kk] = cN[kk];
+            }
           }
+          if (lane < 3) S.finalState[k] = runK ? state : 0u;
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // (the chains' output in the work area, for every wave of the workgroup)

@@ -1160,48 +1160,67 @@ __device__ __forceinline__ void df_later_flags(const u8* src, u32 fsize, u32 hlo
     for (u32 i = (u32)lane; i < 128 + ((1u << hlogP) >> 5) + ((1u << clogP) >> 5); i += 64) lds[i] = 0;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     const bool hm = pass != 0;
-    // blocks nBlk-1 .. 0; B0 is the one being hashed, B1 / B2 the next two below it
-    DfBlock B0 = df_block_load(src, fsize, flg, nBlk - 1, hm, lane), B1{0, 0}, B2{0, 0};
-    if (nBlk >= 2) B1 = df_block_load(src, fsize, flg, nBlk - 2, hm, lane);
+    // blocks nBlk-1 .. 0; B0 is the one being hashed, B1 the next one below it (in flight meanwhile)
+    DfBlock B0 = df_block_load(src, fsize, flg, nBlk - 1, hm, lane), B1{0, 0};
     u64 above = 0;                                       // the 8 bytes behind the block (lane 0 of the block above)
     for (u32 blk = nBlk; blk-- > 0;) {
-      if (blk >= 2) B2 = df_block_load(src, fsize, flg, blk - 2, hm, lane);
+      if (blk >= 1) B1 = df_block_load(src, fsize, flg, blk - 1, hm, lane);
       const u32 aLo = (u32)B0.a, aHi = (u32)(B0.a >> 32);
       u64 outM = 0;                                      // lanes 2k / 2k+1: the long / short mask of window k
+      // two windows per step, the upper one first: their cross-lane reads go out together, then their LDS sequences back to back (LDS
+      // executes a wave's operations in issue order: the lower window's "seen" reads come behind the upper window's marks), one wait
+      // for all of it — the sweep is a chain of LDS round trips, and at 22 waves per CU each one costs hundreds of cycles
 #pragma unroll 1
-      for (u32 kk = 0; kk < 8; kk++) {
-        const u32 k = 7 - kk;
-        const u32 p = blk * 512 + k * 64 + (u32)lane;
-        if (blk * 512 + k * 64 > lastPos) continue;      // (wave-uniform)
-        const bool act = p <= lastPos;
-        // this lane's 8 bytes: chunks 8k + lane/8 and the one behind it, shifted by lane % 8 bytes
-        const u32 ci = 8 * k + srcLane;
-        const u32 c0l = (u32)__builtin_amdgcn_ds_bpermute((int)(4 * ci), (int)aLo), c0h = (u32)__builtin_amdgcn_ds_bpermute((int)(4 * ci), (int)aHi);
-        u32 c1l = (u32)__builtin_amdgcn_ds_bpermute((int)(4 * ((ci + 1) & 63)), (int)aLo), c1h = (u32)__builtin_amdgcn_ds_bpermute((int)(4 * ((ci + 1) & 63)), (int)aHi);
-        if (ci == 63) { c1l = (u32)above; c1h = (u32)(above >> 32); }
-        const u64 c0 = (u64)c0l | ((u64)c0h << 32), c1 = (u64)c1l | ((u64)c1h << 32);
-        const u64 v = sh ? (c0 >> sh) | (c1 << (64 - sh)) : c0;
-        const u32 bL = (u32)((v * 0xCF1BBCDCB7A56463ULL) >> (64 - hlog));
-        const u32 bS = mls <= 4 ? ((u32)v * 2654435761u) >> (32 - clog) : (u32)(((v << shV) * primeS) >> (64 - clog));
-        const bool pL = act && (bL >> hlogP) == pass, pS = act && (bS >> clogP) == pass;
-        const u32 iL = bL & ((1u << hlogP) - 1), iS = bS & ((1u << clogP) - 1);
-        const u32 sL = iL & 255u, sS = 256u + (iS & 255u);
-        const u32 seenL = pL ? lds_read32(&bmL[iL >> 5]) : 0u, seenS = pS ? lds_read32(&bmS[iS >> 5]) : 0u;
-        if (pL) atomicAdd(&cnt[sL >> 2], 1u << (8 * (sL & 3)));
-        if (pS) atomicAdd(&cnt[sS >> 2], 1u << (8 * (sS & 3)));
-        __builtin_amdgcn_wave_barrier();
-        const u32 cL = pL ? (lds_read32(&cnt[sL >> 2]) >> (8 * (sL & 3))) & 255u : 0u;
-        const u32 cS = pS ? (lds_read32(&cnt[sS >> 2]) >> (8 * (sS & 3))) & 255u : 0u;
-        __builtin_amdgcn_wave_barrier();
-        if (pL) { atomicSub(&cnt[sL >> 2], 1u << (8 * (sL & 3))); atomicOr(&bmL[iL >> 5], 1u << (iL & 31)); }
-        if (pS) { atomicSub(&cnt[sS >> 2], 1u << (8 * (sS & 3))); atomicOr(&bmS[iS >> 5], 1u << (iS & 31)); }
-        const u64 mL = __ballot(((seenL >> (iL & 31)) & 1u) || cL > 1), mS = __ballot(((seenS >> (iS & 31)) & 1u) || cS > 1);
-        if ((u32)lane == 2 * k) outM = mL;
-        if ((u32)lane == 2 * k + 1) outM = mS;
+      for (u32 kk = 0; kk < 4; kk++) {
+        if (blk * 512 + (6 - 2 * kk) * 64 > lastPos) continue;      // (wave-uniform: both windows of the pair lie behind the last position)
+        u32 iLw[2], iSw[2]; bool pLw[2], pSw[2];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+          const u32 k = 7 - 2 * kk - h;
+          const u32 p = blk * 512 + k * 64 + (u32)lane;
+          const bool act = p <= lastPos;
+          // this lane's 8 bytes: chunks 8k + lane/8 and the one behind it, shifted by lane % 8 bytes
+          const u32 ci = 8 * k + srcLane;
+          const u32 c0l = (u32)__builtin_amdgcn_ds_bpermute((int)(4 * ci), (int)aLo), c0h = (u32)__builtin_amdgcn_ds_bpermute((int)(4 * ci), (int)aHi);
+          u32 c1l = (u32)__builtin_amdgcn_ds_bpermute((int)(4 * ((ci + 1) & 63)), (int)aLo), c1h = (u32)__builtin_amdgcn_ds_bpermute((int)(4 * ((ci + 1) & 63)), (int)aHi);
+          if (ci == 63) { c1l = (u32)above; c1h = (u32)(above >> 32); }
+          const u64 c0 = (u64)c0l | ((u64)c0h << 32), c1 = (u64)c1l | ((u64)c1h << 32);
+          const u64 v = sh ? (c0 >> sh) | (c1 << (64 - sh)) : c0;
+          const u32 bL = (u32)((v * 0xCF1BBCDCB7A56463ULL) >> (64 - hlog));
+          const u32 bS = mls <= 4 ? ((u32)v * 2654435761u) >> (32 - clog) : (u32)(((v << shV) * primeS) >> (64 - clog));
+          pLw[h] = act && (bL >> hlogP) == pass; pSw[h] = act && (bS >> clogP) == pass;
+          iLw[h] = bL & ((1u << hlogP) - 1); iSw[h] = bS & ((1u << clogP) - 1);
+        }
+        u32 seenL[2], seenS[2], cL[2], cS[2];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+          const u32 iL = iLw[h], iS = iSw[h], sL = iL & 255u, sS = 256u + (iS & 255u);
+          const bool pL = pLw[h], pS = pSw[h];
+          seenL[h] = pL ? lds_read32(&bmL[iL >> 5]) : 0u; seenS[h] = pS ? lds_read32(&bmS[iS >> 5]) : 0u;
+          if (pL) atomicAdd(&cnt[sL >> 2], 1u << (8 * (sL & 3)));
+          if (pS) atomicAdd(&cnt[sS >> 2], 1u << (8 * (sS & 3)));
+          __builtin_amdgcn_wave_barrier();
+          cL[h] = pL ? lds_read32(&cnt[sL >> 2]) : 0u;
+          cS[h] = pS ? lds_read32(&cnt[sS >> 2]) : 0u;
+          __builtin_amdgcn_wave_barrier();
+          if (pL) { atomicSub(&cnt[sL >> 2], 1u << (8 * (sL & 3))); atomicOr(&bmL[iL >> 5], 1u << (iL & 31)); }
+          if (pS) { atomicSub(&cnt[sS >> 2], 1u << (8 * (sS & 3))); atomicOr(&bmS[iS >> 5], 1u << (iS & 31)); }
+          __builtin_amdgcn_wave_barrier();
+        }
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+          const u32 k = 7 - 2 * kk - h;
+          if (blk * 512 + k * 64 > lastPos) continue;    // (the pair's upper window alone lies behind the last position)
+          const u32 iL = iLw[h], iS = iSw[h], sL = iL & 255u, sS = iS & 255u;
+          const u64 mL = __ballot(((seenL[h] >> (iL & 31)) & 1u) || ((cL[h] >> (8 * (sL & 3))) & 255u) > 1);
+          const u64 mS = __ballot(((seenS[h] >> (iS & 31)) & 1u) || ((cS[h] >> (8 * (sS & 3))) & 255u) > 1);
+          if ((u32)lane == 2 * k) outM = mL;
+          if ((u32)lane == 2 * k + 1) outM = mS;
+        }
       }
       if (lane < 16) *(u64*)(flg + (size_t)blk * 128 + 8 * (u32)lane) = outM | B0.m;
       above = (u64)bcast(aLo, 0) | ((u64)bcast(aHi, 0) << 32);
-      B0 = B1; B1 = B2;
+      B0 = B1;
     }
     // the next pass reads these masks back (and the parse after the last one): stores done and visible to this CU's loads
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -1334,7 +1353,7 @@ __device__ __forceinline__ void mf_dfast_body(const ZraEncArgs& a, u32 block, u3
     if (mine) {
       // publish: every store of this frame (sequences, block record) is visible device-wide before its stamp
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      if (lane == 0) __hip_atomic_store(&a.blockOut[f].ready, a.readyStamp, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      if (lane == 0) { __hip_atomic_store(&a.blockOut[f].ready, a.readyStamp, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); if (a.mfDone) atomicAdd(&a.mfDone[f / a.entSubFrames], 1u); }
     }
   }
 }
@@ -1342,7 +1361,7 @@ __device__ __forceinline__ void mf_dfast_body(const ZraEncArgs& a, u32 block, u3
 extern "C" __global__ void __launch_bounds__(64)
 zra_mf_dfast_kernel(ZraEncArgs a, u32 block, u32 only, u32 onlySlot) { mf_dfast_body<false>(a, block, only, onlySlot); }
 // the same parse behind the wave's own bucket-flag sweep (round 5, df_later_flags): skips the table writes nobody can read
-extern "C" __global__ void __launch_bounds__(64)
+extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6)))   // (22 resident waves per CU: six on two of the SIMDs)
 zra_mf_dfast_fl_kernel(ZraEncArgs a, ZraFlagArgs g, u32 block, u32 only, u32 onlySlot) { mf_dfast_body<true>(a, block, only, onlySlot, &g); }
 // the same parse over a copy of the frame in LDS (round 4): the latency mode for calls of a few hundred frames at most
 extern "C" __global__ void __launch_bounds__(64)

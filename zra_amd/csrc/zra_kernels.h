@@ -191,6 +191,7 @@ struct ZraEncArgs {
   // mfQueue == nullptr: one workgroup per frame, tables per frame (batch path; its entropy launches use entQueue alone, readyStamp 0).
   uint32_t* mfQueue;
   uint32_t* mfStarted;     // counts the match finder's waves as they start (the entropy stage is launched once all of them are resident)
+  uint32_t* mfDone;        // [sub-batches] frames the match finder has finished (pipeMode 1: the host releases a sub-batch's entropy launch by a stream wait on it); may be nullptr
   uint32_t* entQueue;
   uint32_t* entDone;       // [sub-batches]
   uint32_t* scanDone;
