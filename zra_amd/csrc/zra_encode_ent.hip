@@ -73,6 +73,7 @@ struct __attribute__((aligned(16))) EncShared {
   u32 stage[STAGE_WORDS];
   EncLitPhase lit;
   u32 seqCnt[3][64];         // code histograms of the block's sequences (counted while the literals are gathered: the sequences are in registers then)
+  u32 tblReady[4];           // sequence table k built (lane 0 of wave k + 1 sets it; wave 1 walks the chains behind all three)
   u8 chainCodes[3][64]; u16 chainOut[3][64];   // the state chains' current 64 sequences: codes in, results out
   u8 ncount[3][192];         // table descriptions of the block's sequence section (written while the Huffman tree is built, emitted after the literals)
   u8 hNb[256];
@@ -550,6 +551,7 @@ __device__ __forceinline__ void entropy_frame(KArgs& a, u32 block, u32 f, u8* li
     u8* const codesG = work; u16* const chainG = (u16*)(work + 3 * a.seqStride);
     for (int i = tid; i < 4 * 256; i += ENT_THREADS) (&S.lit.hist[0][0])[i] = 0;
     if (tid < 3 * 64) (&S.seqCnt[0][0])[tid] = 0;
+    if (tid < 4) S.tblReady[tid] = 0;
     u32 litBase = 0, srcBase = bs;
     __syncthreads();
     for (u32 t0 = 0; t0 < nbSeq; t0 += SEQ_TILE) {
@@ -687,12 +689,15 @@ __device__ __forceinline__ void entropy_frame(KArgs& a, u32 block, u32 f, u8* li
           S.sc[0] = maxBits;
           S.sc[1] = huf_write_ctable(S, maxSym, maxBits);
         }
-      } else if (nbSeq && wave == 1) {
+      } else if (nbSeq) {
         // ---- wave 1: the three sequence tables and the three state chains, stream k on lane k. ONE wave (beside wave 0's tree build),
         // not three: this stage runs beside the match finder, and every wave that issues one-lane code at a raised priority takes issue
         // slots from it (round 5: with a wave per stream the finder lost 10-25 %, with round 4's single wave nothing measurable)
-        const int k = lane;
-        if (lane < 3) {
+        // (the three tables are chosen and built side by side, stream k by lane 0 of wave k + 1 — short — and reported through an LDS
+        //  flag; the three chains then run on lanes 0-2 of wave 1 alone)
+        const int k = wave == 1 ? lane : wave - 1;
+        if (lane == 0) {
+          const int k = wave - 1;
           const u32 maxSymK = k == 0 ? 35 : k == 1 ? 31 : 52, FSELog = k == 1 ? 8 : 9, defLog = k == 1 ? 5 : 6, defMax = k == 0 ? 35 : k == 1 ? 28 : 52;
           const short* defNorm = k == 0 ? c_LLdef : k == 1 ? c_OFdef : c_MLdef;
           u32* count = S.seqCnt[k];
@@ -718,8 +723,14 @@ __device__ __forceinline__ void entropy_frame(KArgs& a, u32 block, u32 f, u8* li
               S.ncountSize[k] = h;
             }
           }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          __hip_atomic_store(&S.tblReady[k], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");            // (the three lanes' tables and decisions, for the wave's other lanes)
+        if (wave == 1) {
+        // wave 1 waits for the three tables (its own lane 0 built the first)
+        while (__hip_atomic_load(&S.tblReady[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) + __hip_atomic_load(&S.tblReady[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) +
+               __hip_atomic_load(&S.tblReady[2], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != 3u) __builtin_amdgcn_s_sleep(4);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");            // (the tables and decisions, for every lane of this wave)
         __builtin_amdgcn_wave_barrier();
         for (int kk = 0; kk < 3; kk++) {
           if (S.mode[kk] == 3) {
@@ -785,6 +796,7 @@ __device__ __forceinline__ void entropy_frame(KArgs& a, u32 block, u32 f, u8* li
             }
           }
           if (lane < 3) S.finalState[k] = runK ? state : 0u;
+        }
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // (the chains' output in the work area, for every wave of the workgroup)

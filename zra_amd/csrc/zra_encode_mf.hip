@@ -539,8 +539,13 @@ __device__ u32 mf_dfast_lean(const ZraEncParams& P, u32* HL, u32* HS, const u8* 
       mS = ((rS & H.tagMask) == tS) ? (rS & idxMask) : 0u;
     }
     PROF(2)
-    const u64 LH = __ballot(active && mL > 1 && ld64(src + mL - 1) == v8);
-    const u64 SH = __ballot(active && mS > 1 && ld32(src + mS - 1) == (u32)v8);
+    // PROBABLE hits (round 5): a cell whose tag — 16 further bits of the position's hash — equals the lane's own is a candidate whose
+    // bytes match with all but 2^-16 of the chance, so they are not fetched here. The candidate a sequence takes is checked by the
+    // loads that measure its length anyway (they start at the match's first byte instead of behind the 8 / 4 known ones); one that
+    // fails loses its bit and the window is resolved again from where it stood. A lane without a tag match has no match: exact.
+    // Rounds 1-4 verified every candidate here: a third dependent memory round trip per window, 9-11 % of a frame's time.
+    u64 LH = __ballot(active && mL > 1);
+    u64 SH = __ballot(active && mS > 1);
     const u32 valL = (p + 1) | tL, valS = (p + 1) | tS;
     const u32 v8s = (u32)(v8 >> 8);
     const u64 AM = nAct >= 64 ? ~0ull : (bit64(nAct) - 1);
@@ -569,14 +574,21 @@ __device__ u32 mf_dfast_lean(const ZraEncParams& P, u32* HL, u32* HS, const u8* 
       const bool isRep = (RH >> f) & 1, isLong = (LH >> f) & 1;
       ip = top;
       u32 m, known, offVal = 1;
+      u32 vneed = 0, mS2 = 0; bool dual = false;         // vneed: bytes that must be equal from the candidate's first byte for a probable hit to be one
       if (isRep) { ip = top + 1; m = ip - o1; known = 4; }
-      else if (isLong) { m = bcast(mL, f) - 1; known = 8; }
-      else {
-        // short hit: long-table probe at ip+1 (A.4.3 case 3). In the window this IS lane f+1's long test.
+      else if (isLong) { m = bcast(mL, f) - 1; known = 0; vneed = 8; }
+      else if (s == 1 && f + 1 < nAct) {
+        // short hit: long-table probe at ip+1 (A.4.3 case 3). In the window this IS lane f+1's long test. Both candidates are checked by
+        // one trip: the probed long match on lanes 0-15, the short one on lanes 16-31 (the probe happens only behind a REAL short hit)
+        mkL |= bit64(f + 1);
+        if ((LH >> (f + 1)) & 1) { m = bcast(mL, f + 1) - 1; ip = top + 1; known = 0; vneed = 8; dual = true; mS2 = bcast(mS, f) - 1; }
+        else { m = bcast(mS, f) - 1; known = 0; vneed = 4; }
+      } else {
         bool hit3; u32 m3;
-        if (s == 1 && f + 1 < nAct) { hit3 = (LH >> (f + 1)) & 1; m3 = bcast(mL, f + 1); mkL |= bit64(f + 1); }
-        else {
+        {
           PROF_CNT(15)
+          // (this path stores before it knows the match: the short hit is checked first, with a load of its own)
+          if (rfl(ld32(src + bcast(mS, f) - 1)) != bcast((u32)v8, f)) { SH &= ~bit64(f); continue; }
           // the probed bucket is not covered by the window's no-duplicate guarantee: commit the visited positions first
           if (lane_in(mkL) && (bflags & 2)) { TST(HL + bL, valL); atomicOr(&bmL[wL], qL); }
           if (lane_in(mkS) && (bflags & 8)) { TST(HS + bS, valS); atomicOr(&bmS[wS], qS); }
@@ -609,12 +621,15 @@ __device__ u32 mf_dfast_lean(const ZraEncParams& P, u32* HL, u32* HS, const u8* 
 #pragma unroll
         for (int k_ = 0; k_ < ZRA_MF_PAD_VALU; k_++) asm volatile("v_add_u32 %0, %0, 1" : "+v"(vd_)); }
 #endif
-      const u32 off = ip - m;
-      // ---- issue together: forward compare (64 x 8 B), backward compare (64 x 1 B), rep gather for the next o1
-      const u32 fa = ip + known + 8 * (u32)lane, fb = m + known + 8 * (u32)lane;
+      u32 off = ip - m;
+      // ---- issue together: forward compare (16 lanes x 8 B; with a probed long match a second one for the short match on lanes 16-31),
+      // backward compare (64 x 1 B), rep gather for the next o1
+      const u32 l16 = (u32)lane & 15u;
+      const bool sec = dual && (u32)lane >= 16 && (u32)lane < 32;
+      const u32 fa = sec ? top + 8 * l16 : ip + known + 8 * (u32)lane, fb = sec ? mS2 + 8 * l16 : m + known + 8 * (u32)lane;
       // 16 lanes x 8 B: matches are ~10 bytes on average, and every 64-byte line of the match source is a likely DRAM request
       // (the kernel is bound by the DRAM request rate); longer matches take the wave_count_eq loop below
-      const bool fv = (u32)lane < 16 && fa + 8 <= be;
+      const bool fv = ((u32)lane < 16 || sec) && fa + 8 <= be;
       const u64 xa = fv ? ld64(src + fa) : 0, xb = fv ? ld64(src + fb) : 0;
       const u32 lim = isRep ? 0u : min(ip - anchor, m);
       u32 ya = 0, yb = 1;
@@ -622,19 +637,35 @@ __device__ u32 mf_dfast_lean(const ZraEncParams& P, u32* HL, u32* HS, const u8* 
       u32 rnext = 0; bool rvn = false;
       if (!isRep) { rvn = active && p + 1 >= off; rnext = rvn ? ld32(src + p + 1 - off) : 0; }
       u32 ml;
+      bool redo = false;                                 // the short match stands behind a probed long candidate that was none: lengths again
       {
         const u64 d = xa ^ xb;
         const u32 eq = d ? ((u32)__builtin_ctzll(d) >> 3) : 8;
-        const u64 stop = __ballot(!fv || d != 0);
-        const u32 l = stop ? (u32)__builtin_ctzll(stop) : 64u;
-        const bool clean = stop && ((__ballot(fv) >> l) & 1);       // first stopping lane compared a full 8-byte word
+        const u64 stopAll = __ballot(!fv || d != 0), fvAll = __ballot(fv);
+        const u64 stop = stopAll & 0xFFFFull;            // the taken candidate: lanes 0-15 (no stop among them: more than 128 equal bytes)
+        const u32 l = stop ? (u32)__builtin_ctzll(stop) : 16u;
+        const bool clean = stop && ((fvAll >> l) & 1);              // first stopping lane compared a full 8-byte word
         if (clean) ml = known + 8 * l + bcast(eq, l);
-        else ml = known + wave_count_eq(src, ip + known, m + known, be, lane);   // block end inside the window, or > 512 equal bytes
+        else ml = known + wave_count_eq(src, ip + known, m + known, be, lane);   // block end inside the compare, or > 128 equal bytes
+        if (dual) {
+          const u64 stopS = (stopAll >> 16) & 0xFFFFull;
+          const u32 lS = stopS ? (u32)__builtin_ctzll(stopS) : 16u;
+          const bool cleanS = stopS && ((fvAll >> (16 + lS)) & 1);
+          const u32 mlS = cleanS ? 8 * lS + bcast(eq, 16 + lS) : wave_count_eq(src, top, mS2, be, lane);
+          if (mlS < 4) { SH &= ~bit64(f); continue; }     // the short hit was none: the reference does not probe ip+1, nothing has happened yet
+          if (ml < 8) { m = mS2; ip = top; ml = mlS; off = ip - m; redo = true; }   // the probe misses (its insertion stays): the short match
+        } else if (ml < vneed) {                          // a tag without its bytes (2^-16): not a hit
+          if (isLong) LH &= ~bit64(f); else SH &= ~bit64(f);
+          continue;
+        }
       }
       PROF(6)
       if (!isRep) {
         u32 back = 0;
-        if (lim) {
+        if (redo) {
+          back = wave_count_back(src, ip, m, anchor, lane);
+          rvn = active && p + 1 >= off; rnext = rvn ? ld32(src + p + 1 - off) : 0;
+        } else if (lim) {
           const u64 bad = ~__ballot(ya == yb);
           back = bad ? (u32)__builtin_ctzll(bad) : wave_count_back(src, ip, m, anchor, lane);
         }
