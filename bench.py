@@ -180,6 +180,61 @@ def cpu_baseline(sample, frame_size, level, nq, qsize, seed=42):
                                               "the socket's physical cores (frames are independent: an upper bound that ignores memory-bandwidth and turbo effects)" % (T, sl >> 20)}}, arc
 
 
+def c4_share(Z, eng, torch, dev, gib=2.0, cpu_mib=32):
+    """BASELINE config 4's one-GPU share, outside the timed region: log-like synthetic data (tests/corpus.py: gen_loglike), level 9 at
+    256 KiB frames — the second compress configuration BASELINE.json names (reference call site zra.cpp:219 at :210 level 9). GPU:
+    CompressBuffer and full DecompressBuffer on `gib` GiB; CPU leg: the same container port as cpu_baseline() over a `cpu_mib` MiB sample
+    (level 9 runs at ~0.03 GiB/s on one core), which is also the bit-exactness gate of this configuration."""
+    sys.path.insert(0, os.path.join(HERE, "tests"))
+    import corpus as C
+    import oracle_lib as O
+    fs, level = 262144, 9
+    base = np.frombuffer(C.gen_loglike(32 << 20, seed=4), dtype=np.uint8)
+    N = int(gib * GiB) // fs * fs
+    d_in = torch.from_numpy(np.resize(base, N)).to(dev)
+    d_arc = torch.empty(Z.GetOutputBufferSize(N, fs) + 64, dtype=torch.uint8, device=dev)
+    n = eng.compress(d_in.data_ptr(), N, d_arc.data_ptr(), level, fs, True)                 # warm (scratch of this configuration)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    n = eng.compress(d_in.data_ptr(), N, d_arc.data_ptr(), level, fs, True)
+    torch.cuda.synchronize(); tc = time.perf_counter() - t0
+    ks = eng.kernel_stats()
+    d_out = torch.empty(N, dtype=torch.uint8, device=dev)
+    eng.decompress(d_arc.data_ptr(), n, d_out.data_ptr(), N)                                   # warm
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    eng.decompress(d_arc.data_ptr(), n, d_out.data_ptr(), N)
+    torch.cuda.synchronize(); td = time.perf_counter() - t0
+    if not torch.equal(d_out, d_in):
+        raise SystemExit("c4_share: GPU decompress does not restore the input")
+    # CPU leg + gate on a sample
+    samp = min(N, cpu_mib << 20) // fs * fs
+    backend = "zl" if O.have_libzstd() else "zo"
+    L = O.lib()
+    vp, sz = ctypes.c_void_p, ctypes.c_size_t
+    data = np.ascontiguousarray(np.resize(base, samp))
+    cap = L.zo_zra_output_bound(samp, fs, 0)
+    out = np.zeros(cap, dtype=np.uint8)
+    osz = sz(0)
+    fcomp = getattr(L, backend + "_zra_compress_buffer")
+    fcomp.argtypes = [vp, sz, vp, sz, ctypes.POINTER(sz), ctypes.c_int, ctypes.c_uint32, ctypes.c_int, sz]
+    t0 = time.perf_counter()
+    st = fcomp(data.ctypes.data, samp, out.ctypes.data, cap, ctypes.byref(osz), level, fs, 1, 0)
+    tcpu = time.perf_counter() - t0
+    assert st.tup() == (0, 0), st.tup()
+    d_s = torch.empty(Z.GetOutputBufferSize(samp, fs) + 64, dtype=torch.uint8, device=dev)
+    ns = eng.compress(d_in.data_ptr(), samp, d_s.data_ptr(), level, fs, True)
+    same = d_s[:ns].cpu().numpy().tobytes() == out[: osz.value].tobytes()
+    if not same:
+        raise SystemExit("c4_share: GPU archive differs from the CPU path")
+    del d_in, d_arc, d_out, d_s
+    eng.release_scratch()
+    return {"workload": "%.3g GiB log-like synthetic (tests/corpus.py gen_loglike, 32 MiB tiled), frameSize=256 KiB, level 9, checksum on" % (N / GiB),
+            "compress_gibs": round(N / GiB / tc, 3), "decompress_gibs": round(N / GiB / td, 3), "compression_ratio": round(N / n, 3),
+            "mf_ms": round(ks["mf_ms"], 1), "mf_launches": ks["mf_launches"],
+            "cpu": {"compress_gibs": round(samp / GiB / tcpu, 4), "cores": 1, "kind": "port", "sample_mib": samp >> 20,
+                    "over": "libzstd " + O.lib().zo_libzstd_version().decode() if backend == "zl" else "the oracle's C restatement"},
+            "bit_exact_gate": "archive bytes identical to CPU path (%d MiB sample)" % (samp >> 20)}
+
+
 def kernel_source_sha():
     """sha256 over the kernel sources (zra_amd/csrc, sorted by name) with comments and white space taken out: ties a PMC measurement
     in profiles/traffic.json to the CODE of a build (a reworded comment does not make a measurement stale)."""
@@ -335,6 +390,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--timed-only", action="store_true", help="nothing but the timed steps (PMC passes: tools/pmc_bench.sh)")
     ap.add_argument("--no-host-calls", action="store_true", help="skip the host-pointer extras (4 GiB through zratool_amd b, outside the timed region)")
+    ap.add_argument("--no-c4", action="store_true", help="skip BASELINE config 4's one-GPU share (2 GiB log-like, level 9 @ 256 KiB, outside the timed region)")
     args = ap.parse_args()
 
     # stdout carries exactly one line, the JSON: libraries that print banners on first use (RCCL's version block, gloo's rank lines)
@@ -428,6 +484,7 @@ def main():
         if world == 1:
             arc_size = eng.compress(d_in.data_ptr(), N, d_arc.data_ptr(), args.level, fs, True)
             mf_ms.append(eng.kernel_stats())
+            step.tele = eng.launch_telemetry()
         else:
             # sharded (include/zra_hip.h, distributed archive): local frames through the same kernels, all-gather of the frame sizes,
             # seek table stitched on every rank, frame bodies gathered to rank 0 behind the header (north_star: "final gather")
@@ -532,6 +589,11 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.no_host_calls:
         host_calls = host_pointer_calls(args.level, fs)
 
+    # BASELINE config 4's one-GPU share (level 9 @ 256 KiB, log-like), outside the timed region; needs the oracle for its gate + CPU leg
+    c4 = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.timed_only and not args.no_c4:
+        c4 = c4_share(Z, eng, torch, dev)
+
     # compressed bytes of the frames the timed queries touch (for the random-access leg's roofline): the archive's own seek table
     ra_touched = None
     if rank == 0 and world == 1:
@@ -567,10 +629,10 @@ def main():
         # commit they were taken at (profiles/traffic.json, tools/pmc_bench.sh); per-frame scaling only if the size differs
         # which match finder the level runs (frame sizes of the 128 KiB class; the kernel-per-strategy table of zra_encode.hip)
         lv = 3 if args.level == 0 else args.level
-        mf_kernel = ("zra_mf_fast_kernel" if lv <= 2 else "zra_mf_dfast_kernel" if lv <= 4 else "zra_mf_hc_kernel" if lv <= 10 else
+        mf_kernel = ("zra_mf_fast_kernel" if lv <= 2 else "zra_mf_dfast_fl_kernel" if lv <= 4 else "zra_mf_hc_kernel" if lv <= 10 else
                      "zra_mf_kernel" if lv <= 12 or lv == 15 else "zra_mf_opt_kernel")
-        if os.environ.get("ZRA_MF_V2", "0") not in ("", "0") and mf_kernel == "zra_mf_dfast_kernel":
-            mf_kernel = "zra_mf_dfast2_kernel"
+        if os.environ.get("ZRA_MF_FLAGS", "1") in ("0",) and mf_kernel == "zra_mf_dfast_fl_kernel":
+            mf_kernel = "zra_mf_dfast_kernel"
         traffic, traffic_src, traffic_stale, ra_traffic = None, None, None, None
         tpath = os.path.join(HERE, "profiles", "traffic.json")
         wkey = "L%d_fs%d" % (args.level, fs)
@@ -628,6 +690,10 @@ def main():
                             "note": "one decode pass of the touched frames per step; algorithmic = compressed bytes of the touched frames + bytes returned; achieved / frac divide by the chain "
                                     "kernel's span alone (the pass's dominant kernel), achieved_whole_pass / frac_whole_pass by all four kernels of the pass"},
             "clocks": {"before_timed_region": clocks_before, "after_timed_region": clocks_after},
+            # what the waves of the last timed match-finder launch recorded themselves (ZraHipGetLaunchTelemetry): the effective shader
+            # clock DURING the launch (cycles against the constant 100 MHz clock), where the waves sat, frames taken per XCD
+            "launch": getattr(step, "tele", None),
+            "c4_share": c4,
             "host_pointer_calls": host_calls,
             "cpu_baseline": cpu,
         }

@@ -484,7 +484,9 @@ Status Engine::compress_persistent(const uint8_t* dIn, size_t inSize, uint8_t* d
   base.tableStride = tableWords; base.seqStride = seqStride; base.litStride = litStride; base.slotStride = slotStride;
   base.mfTele = (uint64_t*)(encScan_.as<uint8_t>() + cntCore);
   base.entWorkStride = entWorkStride;
-  { static const int ep = std::getenv("ZRA_ENT_PRIO") ? std::atoi(std::getenv("ZRA_ENT_PRIO")) : 3; base.entPrio = (uint32_t)ep; }
+  // issue priority of the entropy stage's waves beside the finder: 1 (one box, alternating processes: priority 3 -> 903-911 ms, 1 -> 879-880,
+  // 0 -> 919 with the stage falling behind)
+  { static const int ep = std::getenv("ZRA_ENT_PRIO") ? std::atoi(std::getenv("ZRA_ENT_PRIO")) : 1; base.entPrio = (uint32_t)ep; }
   base.pipeAbort = dAbort; base.entSubFrames = SB; base.slotRing = (uint32_t)slotRing; base.readyStamp = 1u;
   base.running = dRunning; base.gBody = dBody + bodyBase0; base.gEntries = dEntries; base.gSizesOut = dSizes;
   // LDS geometry of the match finder's wave: the bucket filter — 1 bit per 2^shL long-table buckets, 1 bit per 2^shS short-table buckets —
