@@ -120,6 +120,9 @@ typedef struct ZraHipHostTransport {
                   int nRecv, const int* recvPeer, void* const* recvBuf, const size_t* recvBytes);
 } ZraHipHostTransport;
 ZRA_EXPORT ZraStatus ZraHipCommCreateHost(ZraHipComm** comm, ZraHipEngine* engine, const ZraHipHostTransport* transport, int rank, int world);
+/** Diagnostic (RCCL transport): bytes from dSrc to dDst through the point-to-point path, this rank sending to itself — what a one-rank
+ *  run can exercise of the transport's message chunking (pieces of at most 1 GiB per ncclSend / ncclRecv; ZRA_COMM_CHUNK_MIB). */
+ZRA_EXPORT ZraStatus ZraHipCommLoopback(ZraHipComm* comm, const void* dSrc, void* dDst, size_t bytes);
 ZRA_EXPORT void ZraHipCommDestroy(ZraHipComm* comm);
 
 /** Sharded CompressBuffer (zra.cpp:194-235): dLocal = the uncompressed bytes of this rank's frames, i.e. bytes

@@ -132,3 +132,29 @@ def test_rccl_transport_with_one_rank(zra, gpu_engine):
     host = d_out.cpu().numpy().tobytes()
     assert all(host[int(oo[i]): int(oo[i]) + int(sizes[i])] == data[int(offs[i]): int(offs[i]) + int(sizes[i])] for i in range(nq))
     shard.close(); comm.close()
+
+
+@pytest.mark.gpu
+def test_rccl_messages_are_cut_into_pieces(zra):
+    """zra_comm.hip sends a peer's message as pieces of at most 1 GiB inside the one group (at the headline configuration a rank's frames
+    are 5.6 GiB: ZraHipCommGatherArchive, the final gather of zra.cpp:216-230 spread over ranks). With one GPU the only peer is the rank
+    itself: ZraHipCommLoopback moves a buffer through grouped ncclSend / ncclRecv to its own rank, here with pieces of 4,000 bytes
+    (ZRA_COMM_CHUNK_BYTES, read at the first exchange: a fresh process) over lengths around the piece boundaries."""
+    import subprocess
+    code = """
+import sys, os
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np, torch, zra_amd as Z
+from zra_amd import sharding
+eng = Z.Engine(0); comm = sharding.Comm.rccl(eng, 0, 1)
+dev = torch.device('cuda', 0)
+for n in (1, 3999, 4000, 4001, 8000, 123457, 4000 * 64 + 17):
+    src = torch.from_numpy(np.random.RandomState(n).randint(0, 256, size=n).astype(np.uint8)).to(dev)
+    dst = torch.zeros(n + 64, dtype=torch.uint8, device=dev)
+    comm.loopback(src.data_ptr(), dst.data_ptr(), n)
+    torch.cuda.synchronize()
+    assert torch.equal(dst[:n], src) and int(dst[n:].sum()) == 0, n
+comm.close(); print('ok')
+""" % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, ZRA_COMM_CHUNK_BYTES="4000"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])

@@ -894,9 +894,10 @@ def test_foreign_frame_size_does_not_cost_a_pass_per_frame(zra):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("env", [{"ZRA_MF_FLAGS": "0", "ZRA_MF_LS": "0"}, {"ZRA_MF_WAVES": "18", "ZRA_MF_LS": "0", "ZRA_ENT_WGS": "1", "ZRA_ENC_RING": "2"},
-                                 {"ZRA_DEC_PIPE": "4", "ZRA_DEC_PIPE_MIN": "1", "ZRA_DEC_SMALL_MAX": "0"}, {"ZRA_MF_LS": "0"}, {"ZRA_MF_LS_MAX": "1000000"}, {"ZRA_ENC_POISON": "1"}],
+                                 {"ZRA_DEC_PIPE": "4", "ZRA_DEC_PIPE_MIN": "1", "ZRA_DEC_SMALL_MAX": "0"}, {"ZRA_MF_LS": "0"}, {"ZRA_MF_LS_MAX": "1000000"}, {"ZRA_ENC_POISON": "1"},
+                                 {"ZRA_PIPE": "0"}, {"ZRA_PIPE": "2"}, {"ZRA_PIPE": "2", "ZRA_ENC_RING": "2", "ZRA_ENT_WGS": "2"}],
                          ids=["dfast-without-bucket-flags", "dfast-other-pipeline-geometry", "decode-stage-pipeline", "dfast-small-calls-from-memory", "dfast-all-calls-from-lds",
-                              "hash-chain-over-poisoned-scratch"])
+                              "hash-chain-over-poisoned-scratch", "dfast-stages-in-sequence", "dfast-resident-entropy-stage", "dfast-resident-entropy-small-ring"])
 def test_opt_in_kernels_are_bit_exact_too(env):
     """The paths of the library that a default call of the test sizes does not take give the same bytes as the ones it does: the dfast table
     kernel without its bucket flags (round 5: the flags are on by default for calls beyond the LDS-source kernel's size), the persistent
@@ -915,3 +916,34 @@ def test_opt_in_kernels_are_bit_exact_too(env):
                        env=dict(os.environ, **env), capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-2000:]
     assert " passed" in r.stdout and "failed" not in r.stdout
+
+
+@pytest.mark.gpu
+def test_error_exit_between_two_scratch_contexts_drains_every_stream(zra, gpu_engine):
+    """compress_impl_body's batch path (levels other than 3-4; zra.cpp:216-225 per frame) alternates two scratch contexts and, since
+    round 4, launches the second context's match finder on a side stream. An error exit must leave NOTHING of the call running — the
+    caller may free its buffers, and the next call reuses the scratch: the test hook ZRA_ENC_FAIL_BATCH gives up behind a batch whose
+    kernels (both contexts, three streams) are in flight; the input is then overwritten and released at once, and the next call on the
+    same engine has to produce the oracle's bytes."""
+    import torch
+    import corpus as C
+    dev = torch.device("cuda", 0)
+    fs, level = 65536, 9
+    data = (C.gen_E(1 << 20) * 96)                       # 96 MiB: many batches of 1 GiB of scratch each
+    N = len(data)
+    os.environ["ZRA_ENC_BUDGET_GIB"] = "1"
+    try:
+        d_in = torch.from_numpy(np.frombuffer(data, dtype=np.uint8).copy()).to(dev)
+        d_arc = torch.zeros(zra.GetOutputBufferSize(N, fs) + 64, dtype=torch.uint8, device=dev)
+        os.environ["ZRA_ENC_FAIL_BATCH"] = "2"
+        with pytest.raises(zra.ZraError):
+            gpu_engine.compress(d_in.data_ptr(), N, d_arc.data_ptr(), level, fs, True)
+        del os.environ["ZRA_ENC_FAIL_BATCH"]
+        d_in.fill_(0xEE); del d_in                       # what a caller does after an error: the buffer is gone
+        small = C.gen_E(1 << 20) * 8
+        d2 = torch.from_numpy(np.frombuffer(small, dtype=np.uint8).copy()).to(dev)
+        n = gpu_engine.compress(d2.data_ptr(), len(small), d_arc.data_ptr(), level, fs, True)
+        st, ref = O.zra_compress(small, level, fs, True)
+        assert st == (0, 0) and d_arc[:n].cpu().numpy().tobytes() == ref
+    finally:
+        os.environ.pop("ZRA_ENC_FAIL_BATCH", None); os.environ.pop("ZRA_ENC_BUDGET_GIB", None)

@@ -1,0 +1,22 @@
+#!/bin/bash
+# The soaks of tools/bringup/gpu_soak*.py behind one script (run on the GPU box from the repo root):
+#   tools/soak.sh [-b SEED_BASE] [-e "ENV=1,ENV2=2"] [-o FILE] SET...
+# SET = compress | compress2 (second generator) | corrupt | tiny | determinism | headers | ra_damage | all (every one of them)
+# -e runs the sets with library knobs set (e.g. ZRA_ENC_POISON=1, ZRA_MF_LS=0, ZRA_PIPE=2); -b shifts the seed ranges so that a new round soaks
+# seeds no earlier round has seen. One line per set ("soak done ... 0 failures"); FAIL lines are printed in full.
+root=$(pwd); b=0; words=""; outn=soak.txt
+while getopts "b:e:o:" o; do case $o in b) b=$OPTARG;; e) words=$(echo $OPTARG | tr ',' ' ');; o) outn=$OPTARG;; esac; done
+shift $((OPTIND - 1)); sets="$@"; [ -z "$sets" ] && sets=all
+[ "$sets" = all ] && sets="compress compress2 corrupt tiny determinism headers ra_damage"
+out=$root/gpurun_out/$outn; mkdir -p $root/gpurun_out; : > $out
+run() { echo "== $1 [$words] seeds +$b" >> $out; shift; env $words timeout 500 "$@" < /dev/null 2>&1 | grep -v amdgpu.ids | grep "FAIL\|soak done\|Error\|done\|failures" | tail -4 >> $out; }
+for s in $sets; do case $s in
+  compress)    run $s python3 tools/bringup/gpu_soak.py $((30000 + b)) $((30400 + b));;
+  compress2)   run $s python3 tools/bringup/gpu_soak.py $((40000 + b)) $((40400 + b)) v2;;
+  corrupt)     run $s python3 tools/bringup/gpu_soak_corrupt.py $((20000 + b)) $((22000 + b));;
+  tiny)        run $s python3 tools/bringup/gpu_soak_tiny.py $((77 + b)) 1500;;
+  determinism) run $s python3 tools/bringup/gpu_soak_determinism.py 2 12;;
+  headers)     run $s python3 tools/bringup/gpu_soak_headers.py $((1000 + b)) $((4000 + b));;
+  ra_damage)   run $s python3 tools/bringup/gpu_soak_ra_damage.py $((1000 + b)) $((2500 + b));;
+esac; done
+cat $out

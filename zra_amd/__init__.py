@@ -125,6 +125,7 @@ def load():
         "ZraHipCommGetUniqueId": (S, [vp]),
         "ZraHipCommCreateRccl": (S, [ctypes.POINTER(vp), vp, vp, ctypes.c_int, ctypes.c_int]),
         "ZraHipCommCreateHost": (S, [ctypes.POINTER(vp), vp, ctypes.POINTER(ZraHipHostTransport), ctypes.c_int, ctypes.c_int]),
+        "ZraHipCommLoopback": (S, [vp, vp, vp, sz]),
         "ZraHipCommDestroy": (None, [vp]),
         "ZraHipCommCompress": (S, [vp, vp, sz, ctypes.c_uint64, ctypes.c_int8, u32, ctypes.c_bool, ctypes.POINTER(vp)]),
         "ZraHipShardDestroy": (None, [vp]),
@@ -154,7 +155,7 @@ C_ABI_SYMBOLS = [
 ]
 HIP_ABI_SYMBOLS = ["ZraHipDeviceCount", "ZraHipCreateEngine", "ZraHipDestroyEngine", "ZraHipSynchronize", "ZraHipGetStream", "ZraHipWaitStream", "ZraHipReleaseScratch", "ZraHipLastKernelMs", "ZraHipGetKernelStats", "ZraHipGetDecodeStageStats", "ZraHipGetLaunchTelemetry",
                    "ZraHipCompressBuffer", "ZraHipDecompressBuffer", "ZraHipDecompressRABatch", "ZraHipCompressFrames", "ZraHipStitchHeader", "ZraHipDebugReadSeqs", "ZraHipSetOptions", "ZraHipGetOptions",
-                   "ZraHipShardRange", "ZraHipOwnerOfFrame", "ZraHipRouteQueries", "ZraHipCommGetUniqueId", "ZraHipCommCreateRccl", "ZraHipCommCreateHost", "ZraHipCommDestroy",
+                   "ZraHipShardRange", "ZraHipOwnerOfFrame", "ZraHipRouteQueries", "ZraHipCommGetUniqueId", "ZraHipCommCreateRccl", "ZraHipCommCreateHost", "ZraHipCommLoopback", "ZraHipCommDestroy",
                    "ZraHipCommCompress", "ZraHipCommStitchSizes", "ZraHipShardDestroy", "ZraHipShardHeaderSize", "ZraHipShardGetHeader", "ZraHipShardArchiveSize", "ZraHipShardGetBody",
                    "ZraHipCommGatherArchive", "ZraHipCommServe"]
 

@@ -14,6 +14,7 @@
 #include "zra_hip.h"
 #include <rccl/rccl.h>
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <exception>
 #include <vector>
@@ -93,10 +94,16 @@ struct ZraHipComm {
         for (auto& x : r) { x.buf = stage.as<uint8_t>() + o; o += (x.bytes + 63) & ~(size_t)63; }
       }
       Rccl& R = rccl();
+      // Every message goes as pieces of at most 1 GiB (ZRA_COMM_CHUNK_MIB; the tests use 1 MiB and smaller): at the headline configuration
+      // a rank's frames are 5.6 GiB in ONE send to the root, and nothing says a single ncclSend takes that. Both sides cut a message
+      // the same way (they know its length), all pieces of all peers inside the one group: transfers to different peers still run side
+      // by side, each on its own xGMI link.
+      static const size_t chunk = (std::getenv("ZRA_COMM_CHUNK_MIB") ? (size_t)std::max(1, std::atoi(std::getenv("ZRA_COMM_CHUNK_MIB"))) : (size_t)1024) << 20;
+      static const size_t chunkB = std::getenv("ZRA_COMM_CHUNK_BYTES") ? (size_t)std::max(64, std::atoi(std::getenv("ZRA_COMM_CHUNK_BYTES"))) : chunk;   // (test hook: pieces of a few KiB)
       if (R.GroupStart() != ncclSuccess) return false;
       bool good = true;
-      for (auto& x : r) if (x.bytes) good &= R.Recv(x.buf, x.bytes, ncclUint8, x.peer, nccl, st) == ncclSuccess;
-      for (auto& x : s) if (x.bytes) good &= R.Send(x.buf, x.bytes, ncclUint8, x.peer, nccl, st) == ncclSuccess;
+      for (auto& x : r) for (size_t o = 0; o < x.bytes; o += chunkB) good &= R.Recv((uint8_t*)x.buf + o, std::min(chunkB, x.bytes - o), ncclUint8, x.peer, nccl, st) == ncclSuccess;
+      for (auto& x : s) for (size_t o = 0; o < x.bytes; o += chunkB) good &= R.Send((const uint8_t*)x.buf + o, std::min(chunkB, x.bytes - o), ncclUint8, x.peer, nccl, st) == ncclSuccess;
       if (R.GroupEnd() != ncclSuccess || !good) return false;
       if (!onDevice)
         for (size_t i = 0; i < r.size(); i++)
@@ -232,6 +239,15 @@ ZraStatus ZraHipCommCreateHost(ZraHipComm** comm, ZraHipEngine* engine, const Zr
   c->eng = engine ? engine->e : nullptr; c->rank = rank; c->world = world; c->host = *t; c->useHost = true;
   *comm = c;
   return mk(Success);
+}
+
+// Diagnostic: `bytes` bytes from dSrc to dDst through the transport's point-to-point path, this rank sending to ITSELF (RCCL transport
+// only: a send and a receive of one rank inside one group). With one rank nothing else exercises that path — the gather and the serve
+// exchange have no peer — and this is what lets a single-GPU test walk the message chunking (ZRA_COMM_CHUNK_BYTES).
+ZraStatus ZraHipCommLoopback(ZraHipComm* c, const void* dSrc, void* dDst, size_t bytes) {
+  if (!c || !c->eng || c->useHost) return mk(ZStdError, 42);
+  std::vector<Xfer> sends{{c->rank, const_cast<void*>(dSrc), bytes}}, recvs{{c->rank, dDst, bytes}};
+  return c->exchange(sends, recvs, true) ? mk(Success) : mk(ZStdError, 1);
 }
 
 void ZraHipCommDestroy(ZraHipComm* c) {

@@ -373,6 +373,8 @@ Status Engine::compress_impl_body(const uint8_t* dIn, size_t inSize, uint8_t* dB
     hipEvent_t done = ev(); if (!done) return zerr(1);
     HIPCHK(hipEventRecord(done, stream2_));
     entDone[c] = done;
+    // test hook: give up behind batch ZRA_ENC_FAIL_BATCH with its kernels in flight (the error exit must drain every stream: tests/test_gpu_parity.py)
+    if (const char* fb = std::getenv("ZRA_ENC_FAIL_BATCH")) if ((uint64_t)std::atoll(fb) == batchIdx) return zerr(1);
     { static const bool serial = std::getenv("ZRA_ENC_SERIAL") != nullptr;   // bring-up knob: no mf/entropy overlap (per-kernel timing in isolation)
       if (serial) { HIPCHK(hipStreamWaitEvent(stream_, done, 0)); if (mfStream2) HIPCHK(hipStreamWaitEvent(mfStream2, done, 0)); } }
   }

@@ -225,7 +225,11 @@ bool DevBuf::reserve(size_t n) {
   size_t want = n + n / 8 + 256;
   // bring-up / test knob: ZRA_ALLOC_LIMIT_MIB makes any single reservation above the limit fail (memory_allocation paths without a full device)
   static const uint64_t limit = std::getenv("ZRA_ALLOC_LIMIT_MIB") ? (uint64_t)std::atoll(std::getenv("ZRA_ALLOC_LIMIT_MIB")) << 20 : ~0ull;
-  if (want > limit || hipMalloc(&p, want) != hipSuccess) { p = nullptr; cap = 0; (void)hipGetLastError(); return false; }
+  // bring-up knob ZRA_ALLOC_MODE (round 5, the launch-time states of the match finder): 1 = hipDeviceMallocUncached, 2 = fine-grained
+  static const int mode = std::getenv("ZRA_ALLOC_MODE") ? std::atoi(std::getenv("ZRA_ALLOC_MODE")) : 0;
+  const hipError_t ea = want > limit ? hipErrorOutOfMemory : mode == 1 ? hipExtMallocWithFlags(&p, want, hipDeviceMallocUncached)
+                        : mode == 2 ? hipExtMallocWithFlags(&p, want, hipDeviceMallocFinegrained) : hipMalloc(&p, want);
+  if (ea != hipSuccess) { p = nullptr; cap = 0; (void)hipGetLastError(); return false; }
   cap = want; g_scratchBytes += cap;
   return true;
 }

@@ -190,6 +190,11 @@ class Comm:
         Z._chk(self.L.ZraHipCommGatherArchive(self.h, shard.h, root, d_archive, capacity, ctypes.byref(n)), "ZraHipCommGatherArchive")
         return n.value
 
+    def loopback(self, d_src, d_dst, nbytes):
+        """ZraHipCommLoopback: nbytes from d_src to d_dst through the RCCL point-to-point path, this rank to itself (diagnostic)."""
+        self._order()
+        Z._chk(self.L.ZraHipCommLoopback(self.h, d_src, d_dst, nbytes), "ZraHipCommLoopback")
+
     def serve(self, shard, offsets, sizes, out_offsets, d_out):
         """ZraHipCommServe: this rank's queries over the whole uncompressed range; answers at d_out + out_offsets[q]."""
         o = np.ascontiguousarray(offsets, dtype=np.uint64); s = np.ascontiguousarray(sizes, dtype=np.uint64); d = np.ascontiguousarray(out_offsets, dtype=np.uint64)
