@@ -169,7 +169,7 @@ ZRA_EXPORT void ZraHipGetDecodeStageStats(ZraHipEngine* engine, double* out8);
  *  u64 words [0] shader cycles summed over waves, [1] ticks of the constant 100 MHz clock summed over waves (cycles / ticks x 100 = the
  *  effective shader MHz of the launch), [2] waves, [3] longest wave (ticks), [4] ~earliest wave start, [5] latest wave end, [6] latest
  *  wave start, [7] ~earliest wave end, [8..15] waves per XCD, [16..23] frames taken per XCD, [24..31] ticks per XCD, [32 + k] waves on
- *  compute unit k = xcc << 8 | se << 5 | sh << 4 | cu (2048 words); then the entropy stage's persistent workgroups: [2080] workgroups
+ *  compute unit k = xcc << 8 | se << 5 | sh << 4 | cu (2048 words, each four 16-bit counts: the unit's four SIMDs); then the entropy stage's persistent workgroups: [2080] workgroups
  *  that took a frame, [2081] their resident ticks, [2082] ticks they spent waiting for a frame or a slot, [2083] frames, [2088 + k]
  *  workgroups on compute unit k. Returns the words written (0: the call took another path). */
 ZRA_EXPORT size_t ZraHipGetLaunchTelemetry(ZraHipEngine* engine, uint64_t* out, size_t capWords);

@@ -4,7 +4,7 @@
 # A box differs from the next one by more than most changes do, and a process from the next one by 5-10 % (profiles/r05_experiments.md §1),
 # so a change is judged only against the other build / knob setting on the same box, several processes each.
 #   -v NAME            a variant. "A" = the in-tree build; any other name N = zra_amd/libzra_amd_N.so (a build copied aside; r4 = round 4's).
-#                      NAME may carry environment words: "A:ZRA_MF_WAVES=20,ZRA_ENT_WGS=8"
+#                      NAME may carry environment words: "A:ZRA_MF_WAVES=20+ZRA_ENT_WGS=8"
 #   -c "GiB L FS"      a configuration for tools/bringup/gpu_speed.py (bench corpus; LOGLIKE=1 in the variant's words for C4's data);
 #                      without -c: the headline call (16 GiB, level 3, 64 KiB) through tools/r5/gpu_ab_lib.py, which prints wall / mf / entropy
 #   -k "selection"     a pytest selection of tests/test_gpu_parity.py run first on the in-tree build (-x)
@@ -16,7 +16,7 @@ while getopts "v:c:k:r:o:" o; do case $o in v) variants+=("$OPTARG");; c) cfgs+=
 out=$root/gpurun_out/$outn; mkdir -p $root/gpurun_out; : > $out; export TMPDIR=/tmp
 if [ -n "$sel" ]; then ( timeout 1500 python3 -m pytest tests/test_gpu_parity.py -x -q -m gpu -p no:cacheprovider -k "$sel" < /dev/null 2>&1 | tail -3 ) >> $out; fi
 one() {   # variant, command...
-  local v=$1; shift; local name=${v%%:*}; local words=""; [ "$v" != "$name" ] && words=$(echo "${v#*:}" | tr ',' ' ')
+  local v=$1; shift; local name=${v%%:*}; local words=""; [ "$v" != "$name" ] && words=$(echo "${v#*:}" | tr '+' ' ')
   local L=$root/zra_amd/libzra_amd.so; [ "$name" != A ] && L=$root/zra_amd/libzra_amd_$name.so
   local cmd=(); for a in "$@"; do [ "$a" = "@LIB@" ] && a=$L; cmd+=("$a"); done
   echo -n "$v [$CFG]: " >> $out

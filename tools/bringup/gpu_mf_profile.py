@@ -15,12 +15,12 @@ eng.compress(d_in.data_ptr(), n, d_arc.data_ptr(), 3, fs, True)
 print("stats", eng.kernel_stats())
 lib.ZraHipDebugReadMfProfile(buf, 1)
 v = list(buf); nf = max(v[22], 1)
-names = ["0 src load", "1 dup detect (LDS)", "2 table gather", "3 candidate loads", "4 rep gather+ballot+visited stores", "5 which match / short probe",
+names = ["0 src load", "1 dup detect (LDS)", "2 table gather", "3 ballots (probable hits)", "4 rep gather+ballot+visited stores", "5 which match / short probe",
          "6 count loads", "7 ml/back/seq store", "8 complementary inserts", "9 rep loop", "10 tail"]
 tot = v[21] / nf
 print("frames %d  total/frame %.0f memtime ticks; clear %.0f" % (nf, tot, v[20] / nf))
 for i, nm in enumerate(names): print("  %-40s %10.0f  %5.1f %%" % (nm, v[i] / nf, 100.0 * v[i] / max(v[21], 1)))
-print("  windows/frame %.0f  cnt13 %.0f  cnt14 %.0f  cnt15 %.0f  cnt16 %.0f  cnt17 %.0f  cnt18 %.0f  (window-resolve kernel: seqs, out-of-window loads, probe loads, rep-loop seqs; mask-resolve kernel: slow forward counts, slow backward counts, slow probes, slow repcode counts, settled lanes with an insertion, stored hand-over batches)" % (v[12] / nf, v[13] / nf, v[14] / nf, v[15] / nf, v[16] / nf, v[17] / nf, v[18] / nf))
+print("  windows/frame %.0f  cnt13 %.0f  cnt14 %.0f  cnt15 %.0f  cnt16 %.0f  cnt17 %.0f  cnt18 %.0f  (seqs, out-of-window loads, probe loads, rep-loop seqs, duplicate rounds)" % (v[12] / nf, v[13] / nf, v[14] / nf, v[15] / nf, v[16] / nf, v[17] / nf, v[18] / nf))
 
 if hasattr(lib, "ZraHipDebugReadEntProfile"):
     eb = (ctypes.c_ulonglong * 16)(); lib.ZraHipDebugReadEntProfile(eb, 0); e = list(eb); ne = max(e[15], 1)

@@ -1,11 +1,11 @@
 #!/bin/bash
 # The soaks of tools/bringup/gpu_soak*.py behind one script (run on the GPU box from the repo root):
-#   tools/soak.sh [-b SEED_BASE] [-e "ENV=1,ENV2=2"] [-o FILE] SET...
+#   tools/soak.sh [-b SEED_BASE] [-e "ENV=1+ENV2=2"] [-o FILE] SET...
 # SET = compress | compress2 (second generator) | corrupt | tiny | determinism | headers | ra_damage | all (every one of them)
 # -e runs the sets with library knobs set (e.g. ZRA_ENC_POISON=1, ZRA_MF_LS=0, ZRA_PIPE=2); -b shifts the seed ranges so that a new round soaks
 # seeds no earlier round has seen. One line per set ("soak done ... 0 failures"); FAIL lines are printed in full.
 root=$(pwd); b=0; words=""; outn=soak.txt
-while getopts "b:e:o:" o; do case $o in b) b=$OPTARG;; e) words=$(echo $OPTARG | tr ',' ' ');; o) outn=$OPTARG;; esac; done
+while getopts "b:e:o:" o; do case $o in b) b=$OPTARG;; e) words=$(echo $OPTARG | tr '+' ' ');; o) outn=$OPTARG;; esac; done
 shift $((OPTIND - 1)); sets="$@"; [ -z "$sets" ] && sets=all
 [ "$sets" = all ] && sets="compress compress2 corrupt tiny determinism headers ra_damage"
 out=$root/gpurun_out/$outn; mkdir -p $root/gpurun_out; : > $out

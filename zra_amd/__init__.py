@@ -259,7 +259,12 @@ class Engine:
         if n < 32 or a[2] == 0:
             return None
         M = (1 << 64) - 1
-        cu = [int(v) for v in a[32:32 + 2048] if v]
+        cuw = [int(v) for v in a[32:32 + 2048] if v]
+        simd = [[(v >> (16 * k)) & 0xFFFF for k in range(4)] for v in cuw]        # a CU's word: four 16-bit counts, one per SIMD
+        cu = [sum(q) for q in simd]
+        shist = {}
+        for q in simd:
+            k = "/".join(str(x) for x in sorted(q, reverse=True)); shist[k] = shist.get(k, 0) + 1
         ent = None
         if n >= 2080 + 8:
             ecu = [int(v) for v in a[2088:n] if v]
@@ -272,7 +277,7 @@ class Engine:
         first_start, last_end, last_start, first_end = M - a[4], a[5], a[6], M - a[7]
         return dict(shader_mhz=round(a[0] / max(1, a[1]) * 100.0, 1), waves=int(a[2]), cus=len(cu),
                     waves_per_cu_min=min(cu) if cu else 0, waves_per_cu_max=max(cu) if cu else 0,
-                    waves_per_cu_hist={str(k): hist[k] for k in sorted(hist)},
+                    waves_per_cu_hist={str(k): hist[k] for k in sorted(hist)}, waves_per_simd_hist=shist,
                     waves_per_xcd=[int(v) for v in a[8:16]], frames_per_xcd=[int(v) for v in a[16:24]],
                     frames_per_wave_ms_per_xcd=[round(a[16 + i] / (a[24 + i] / 1e5), 4) if a[24 + i] else 0.0 for i in range(8)],
                     span_ms=round((last_end - first_start) / 1e5, 3), start_stagger_ms=round((last_start - first_start) / 1e5, 3),

@@ -493,8 +493,9 @@ Status Engine::compress_persistent(const uint8_t* dIn, size_t inSize, uint8_t* d
   base.running = dRunning; base.gBody = dBody + bodyBase0; base.gEntries = dEntries; base.gSizesOut = dSizes;
   // LDS geometry of the match finder's wave: the bucket filter — 1 bit per 2^shL long-table buckets, 1 bit per 2^shS short-table buckets —
   // and the duplicate-detection slots: 2 KiB + 4 KiB + 0.5 KiB = 6.5 KiB at hashLog 16 / chainLog 15 (one bit per 2 long buckets, per 8
-  // short buckets; round 5: 1 per 4 short buckets made it 7 KiB + 64, and 20 waves of that leave no room for the entropy stage's
-  // workgroup on the CU). The flag sweep ahead of a frame's parse (df_later_flags) runs over the same bytes.
+  // short buckets). The flag sweep ahead of a frame's parse (df_later_flags) runs over the same bytes. What fits a CU beside the entropy
+  // stage's workgroup is decided by LDS in pieces of 1,280 bytes (below): 18 waves of <= 7,680 bytes, or 20 of <= 6,400 — and 20 were
+  // measured slower whichever part paid for it (128 duplicate slots: + 9 %; 1 filter bit per 16 short buckets: + 3 %).
   uint32_t shL = 1, shS = 3, dupLog = 8;
   if (const char* f = std::getenv("ZRA_MF_FILTER")) { unsigned x = 1, y = 1, z = 8; if (std::sscanf(f, "%u,%u,%u", &x, &y, &z) >= 1) { shL = x & 15; shS = y & 15; dupLog = z & 15; } }
   base.mfFilter = shL | (shS << 4) | (dupLog << 8);
@@ -525,7 +526,14 @@ Status Engine::compress_persistent(const uint8_t* dIn, size_t inSize, uint8_t* d
     fw.flagStride = ((((uint64_t)std::min<uint64_t>(frameSize, inSize) + 511) / 512) * 128 + 255) & ~255ull;   // 16 bytes per window of 64 positions, whole blocks of 8 windows
     if (!mfFlags_.reserve((size_t)nSlots * fw.flagStride)) return zerr(64);
     fw.flags = mfFlags_.as<uint8_t>(); fw.ldsWords = (uint32_t)(filterBytes / 4);
+    // the parse's source span in LDS behind the filter (mf_dfast_lean): 768 bytes + their flags = 992 bytes per wave. LDS is handed out
+    // in pieces of 1,280 bytes on this chip (measured, profiles/r05_experiments.md §6: 21 waves of 6.5 KiB fit a CU, not 24), so a wave
+    // holds 7,680 bytes with or without the span, and 18 waves + the entropy stage's workgroup (24,320) fill the CU's 163,840 to within
+    // 1,280 bytes. ZRA_MF_SPAN=<bytes> (multiple of 64, <= 1024; 0: none)
+    static const int spEnv = std::getenv("ZRA_MF_SPAN") ? std::atoi(std::getenv("ZRA_MF_SPAN")) : 768;
+    fw.spanBytes = (uint32_t)std::min(1024, std::max(0, spEnv)) & ~63u;
   }
+  const size_t spanLds = fw.spanBytes ? fw.spanBytes + 16 + (fw.spanBytes / 64 + 1) * 16 : 0;
 
   size_t evNext = 0;
   auto ev = [&]() -> hipEvent_t {
@@ -563,7 +571,7 @@ Status Engine::compress_persistent(const uint8_t* dIn, size_t inSize, uint8_t* d
     if (!m0 || !m1) return zerr(1);
     HIPCHK(hipEventRecord(m0, stream_));
     const uint32_t mfGrid = std::min<uint32_t>(n, nSlots);
-    if (useFlagsWave) hipLaunchKernelGGL(zra_mf_dfast_fl_kernel, dim3(mfGrid), dim3(64), filterBytes, stream_, a, fw, 0u, 0xFFFFFFFFu, 0u);
+    if (useFlagsWave) hipLaunchKernelGGL(zra_mf_dfast_fl_kernel, dim3(mfGrid), dim3(64), filterBytes + spanLds, stream_, a, fw, 0u, 0xFFFFFFFFu, 0u);
     else if (useLs) {
       ZraEncArgs al = a; al.mfFilter |= (lsBytes / 64) << 16;
       hipLaunchKernelGGL(zra_mf_dfast_ls_kernel, dim3(mfGrid), dim3(64), lsBytes + filterBytes, stream_, al, 0u, 0xFFFFFFFFu, 0u);

@@ -28,6 +28,12 @@ __device__ unsigned long long zra_mf_prof[24];
 #define PROF(k) { __builtin_amdgcn_s_waitcnt(0); const u64 n_ = __builtin_amdgcn_s_memtime(); pt_[k] += n_ - pl_; pl_ = n_; }
 #define PROF_CNT(k) { pt_[k]++; }
 #define PROF_END { if (lane == 0) for (int k_ = 0; k_ < 20; k_++) atomicAdd(&zra_mf_prof[k_], pt_[k_]); }
+#elif defined(ZRA_MF_MARK)
+// (-DZRA_MF_MARK with -S: the phase boundaries as comments in the assembly, for tools/isa_phases.py — never built into the library)
+#define PROF_DECL
+#define PROF(k) asm volatile("; ZMARK " #k);
+#define PROF_CNT(k)
+#define PROF_END
 #else
 #define PROF_DECL
 #define PROF(k)
@@ -418,9 +424,15 @@ struct DfHash {
   }
 };
 
+struct __attribute__((packed, aligned(1))) quad_u { u32 x, y, z, w; };
+__device__ __forceinline__ uint4 ld128(const u8* p) { const quad_u q = *(const quad_u*)p; return make_uint4(q.x, q.y, q.z, q.w); }
+
 // LDS working set of one frame's parse: duplicate-bucket scratch + the bucket filter (1 bit per 2^sh buckets)
 struct LeanLds {
   u8* dup; u32 dupSlots; u32* bmL; u32* bmS; u32 shL, shS;
+  // round 5: a span of the frame's source bytes (and of the bucket flags that go with them) kept in LDS ahead of the parse: [span:
+  // spanBytes + 16][flags: 16 per window of 64 positions, spanBytes / 64 + 1 windows]; spanBytes == 0: none
+  u8* span; u8* spanFlg; u32 spanBytes;
   __device__ __forceinline__ void markL(u32 b) const { const u32 g = b >> shL; atomicOr(&bmL[g >> 5], 1u << (g & 31)); }
   __device__ __forceinline__ void markS(u32 b) const { const u32 g = b >> shS; atomicOr(&bmS[g >> 5], 1u << (g & 31)); }
 };
@@ -480,6 +492,29 @@ __device__ u32 mf_dfast_lean(const ZraEncParams& P, u32* HL, u32* HS, const u8* 
       if (doS && (fx & 8)) { TST(HS + bs_, (pos + 1) | ts); W.markS(bs_); }
     }
   };
+  // SOURCE SPAN (round 5). A window's first dependent memory round trip was the load of its own 64 + 8 source bytes (and of its flag
+  // bytes): the address is the end of the previous window's last match. The parse moves forward ~40 bytes per window, so the wave keeps
+  // the next spanBytes of the frame in LDS — one 16-byte load per lane, every ~(spanBytes - 72) bytes of progress, instead of one trip per
+  // window (1,626 per 64 KiB frame of the bench corpus) — and a window reads its bytes with one ds_read. Windows in stride mode (s > 1:
+  // behind 256 literals without a match) read from memory as before.
+  const bool useSpan = FLAGS && W.spanBytes != 0;
+  u32 sBase = 0, sEnd = 0;                              // the span holds positions [sBase, sEnd)
+  auto span_fill = [&](u32 at) {
+    // (start on a 16-byte boundary of the ADDRESS where the frame allows it: the loads are then whole 16-byte pieces of one line)
+    const u32 mis = (u32)((uintptr_t)(src + at) & 15u);
+    const u32 base = rfl(at - min(at, mis));
+    const u32 len = min(W.spanBytes, be - base);
+    const u32 o = 16u * (u32)lane;
+    if (o + 16 <= len) lds_write128(W.span + o, ld128(src + base + o));
+    else if (o < len) { for (u32 k = o; k < len; k++) lds_write8(W.span + k, src[base + k]); }      // (the frame's last, partial piece: the input may end there)
+    if (flg) {
+      // the flag bytes of the windows [base / 64, ...) the span touches, 16 per window, by the first lanes
+      const u32 l2 = (u32)lane, w0 = base >> 6;
+      if (l2 <= (W.spanBytes >> 6) && (w0 + l2) * 64u < be) lds_write128(W.spanFlg + 16u * l2, *(const uint4*)(flg + 16u * (size_t)(w0 + l2)));
+    }
+    __builtin_amdgcn_wave_barrier();
+    sBase = base; sEnd = base + len;
+  };
   while (ip < ilimit) {
     // ---------------------------------------------------------------- window build
     const u32 wip = ip, run = ip - anchor;
@@ -488,8 +523,21 @@ __device__ u32 mf_dfast_lean(const ZraEncParams& P, u32* HL, u32* HS, const u8* 
     else { s = (run >> 8) + 1; nAct = min(64u, min((256 * s - run + s - 1) / s, (ilimit - ip + s - 1) / s)); }
     bool active = (u32)lane < nAct;
     const u32 p = wip + (u32)lane * s;
-    const u64 v8 = active ? ld64(src + p) : 0;
-    const u32 bflags = (flg && active) ? df_flags_at(flg, p) : 0x0Fu;   // (NOT `fb`: that name is the match's forward-compare address further down)
+    u64 v8; u32 bflags;
+    if (useSpan && s == 1) {
+      if (wip < sBase || wip + nAct + 7 > sEnd) span_fill(wip);
+      const u32 r = p - sBase;
+      v8 = active ? *(const lds_u64u_t*)(W.span + r) : 0;
+      bflags = 0x0Fu;
+      if (flg && active) {
+        const u8* const w = W.spanFlg + ((p >> 6) - (sBase >> 6)) * 16u + ((p & 63u) >> 3);
+        const u32 b = p & 7u;
+        bflags = 0x05u | (((lds_read8(w) >> b) & 1u) << 1) | (((lds_read8(w + 8) >> b) & 1u) << 3);
+      }
+    } else {
+      v8 = active ? ld64(src + p) : 0;
+      bflags = (flg && active) ? df_flags_at(flg, p) : 0x0Fu;   // (NOT `fb`: that name is the match's forward-compare address further down)
+    }
     // rep gather for the current o1 (independent of the tables: in flight together with them)
     u32 repFor = o1;
     bool rv = active && o1 > 0 && p + 1 >= o1;
@@ -741,8 +789,6 @@ __device__ u32 mf_dfast_lean(const ZraEncParams& P, u32* HL, u32* HS, const u8* 
 }
 
 
-struct __attribute__((packed, aligned(1))) quad_u { u32 x, y, z, w; };
-__device__ __forceinline__ uint4 ld128(const u8* p) { const quad_u q = *(const quad_u*)p; return make_uint4(q.x, q.y, q.z, q.w); }
 
 // ================================================================================================
 // Wave-cooperative hash chain (greedy / lazy / lazy2, levels 5-10), bit-exact with mf_lazy + HC::search above.
@@ -1275,6 +1321,8 @@ __device__ __forceinline__ void mf_dfast_body(const ZraEncArgs& a, u32 block, u3
   u32* const fltLds = LSRC ? dynLds + (a.mfFilter >> 16) * 16 : dynLds;
   W.dup = (u8*)fltLds;
   W.bmL = fltLds + 2 * W.dupSlots;
+  W.span = nullptr; W.spanFlg = nullptr; W.spanBytes = 0;
+  if (FLAGS && g && g->spanBytes) { W.spanBytes = g->spanBytes; W.span = (u8*)(fltLds + g->ldsWords); W.spanFlg = W.span + g->spanBytes + 16; }
   const bool persistent = a.mfQueue != nullptr;
   // launch telemetry (persistent launches): where this wave sits and its shader cycles against the constant 100 MHz clock
   const bool tele = persistent && a.mfTele != nullptr;
@@ -1285,7 +1333,7 @@ __device__ __forceinline__ void mf_dfast_body(const ZraEncArgs& a, u32 block, u3
     const u32 xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;    // HW_REG_XCC_ID [3:0]
     const u64 tc0 = __builtin_readcyclecounter(), tr0 = wall_clock64();
     const u32 key = (xcc << 8) | (((hw >> 13) & 7u) << 5) | (((hw >> 12) & 1u) << 4) | ((hw >> 8) & 15u);
-    atomicAdd((unsigned long long*)&a.mfTele[32 + key], 1ull);
+    atomicAdd((unsigned long long*)&a.mfTele[32 + key], 1ull << (16u * ((hw >> 4) & 3u)));   // four 16-bit counts: the CU's SIMDs (HW_ID simd_id [5:4])
     atomicAdd((unsigned long long*)&a.mfTele[8 + xcc], 1ull);
     atomicMax((unsigned long long*)&a.mfTele[4], ~tr0);
     atomicMax((unsigned long long*)&a.mfTele[6], tr0);

@@ -13,6 +13,10 @@ typedef __attribute__((address_space(3))) u8 lds_u8_t;
 __device__ __forceinline__ u32 lds_read32(const u32* p) { return *(const volatile lds_u32_t*)p; }
 typedef __attribute__((address_space(3))) u64 lds_u64_t;
 __device__ __forceinline__ u64 lds_read64(const u64* p) { return *(const volatile lds_u64_t*)p; }
+typedef u32 v4u32_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) v4u32_t lds_v4u32_t;
+__device__ __forceinline__ void lds_write128(u8* p, uint4 q) { v4u32_t v = {q.x, q.y, q.z, q.w}; *(lds_v4u32_t*)p = v; }
+typedef __attribute__((address_space(3))) u64_u lds_u64u_t;          // 8 bytes at any LDS address (one ds_read_b64: the hardware splits it)
 __device__ __forceinline__ u32 lds_read8(const u8* p) { return *(const volatile lds_u8_t*)p; }
 __device__ __forceinline__ void lds_write8(u8* p, u32 v) { *(volatile lds_u8_t*)p = (u8)v; }
 

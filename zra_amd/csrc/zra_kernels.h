@@ -225,6 +225,7 @@ struct ZraEncArgs {
 // flags + workgroup * flagStride, over ldsWords words of its LDS, ahead of the parse
 struct ZraFlagArgs {
   uint8_t* flags; uint64_t flagStride; uint32_t ldsWords;
+  uint32_t spanBytes;      // source span of the parse in LDS behind the filter (mf_dfast_lean; 0: none): spanBytes + 16 + (spanBytes / 64 + 1) * 16 bytes
 };
 
 
