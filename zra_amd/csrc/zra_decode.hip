@@ -1230,15 +1230,65 @@ namespace {
 // libzstd's BIT_DStream_t (bitstream.h of 1.4.9), restated field for field: a 64-bit container refilled from the END of the stream
 // towards its start. Exact, because an over-read stream is not an error inside the sequence loop of 1.4.9: the wrapped container
 // bits it then reads decide what the frame finally returns (oracle/zo_decode.c: zds).
-struct Zds {
+// RING (round 5, the LDS-table chain kernel): the stream's bytes reach the container through a per-lane ring of CHAIN_RING bytes in LDS
+// that is filled AHEAD of the read position — the stream is read strictly from its end towards its start, so the next 16 bytes below
+// the ring's lowest offset are always the right ones to fetch — instead of through one dependent global load per sequence. ring[s & (R-1)]
+// = byte s of the stream for s in [rLo, rLo + R) (the first 8 bytes are mirrored behind the ring so that a container that wraps reads
+// straight on). Every container read is ONE ds_read without a branch around it; a read below rLo (the prefetch fell behind: more than
+// 4 bytes consumed per step for a while) first refills the ring at the read position (ring_resync), so nothing depends on timing.
+constexpr u32 CHAIN_RING = 128, CHAIN_RING_WORDS = (CHAIN_RING + 16) / 4;
+static_assert(CHAIN_RING_WORDS == ZRA_CHAIN_RING_WORDS, "ring size: zra_kernels.h");
+__device__ __attribute__((noinline)) uint4 chain_ld128_tail(const u8* p, const u8* lim) {   // 16 bytes at p, zeros beyond the readable body (the archive's last bytes)
+  u32 w[4] = {0, 0, 0, 0};
+  for (u32 k = 0; k < 16; k++) if (p + k < lim) w[k >> 2] |= (u32)p[k] << (8 * (k & 3));
+  return make_uint4(w[0], w[1], w[2], w[3]);
+}
+template <bool RING>
+struct ZdsT {
   u64 c; u32 bc; u32 ptr;      // ptr: byte offset of the container inside the stream (libzstd: ptr - start)
   const u8* base;
+  // RING only: the lane's ring, the lowest stream offset it holds, the readable end of the body, the piece on its way from memory
+  u8* ring; u32 rLo; const u8* lim; uint4 pf; u32 pfState, pfAge;
   enum : int { UNFINISHED = 0, ENDOFBUFFER = 1, COMPLETED = 2, OVERFLOW = 3 };
+  __device__ __forceinline__ uint4 ld16(const u8* p) const {
+    if (p + 16 <= lim) { const u128_u q = *(const u128_u*)p; return make_uint4(q.a, q.b, q.c, q.d); }
+    return chain_ld128_tail(p, lim);
+  }
+  __device__ __forceinline__ void ring_write(u32 off, uint4 q) {   // stream bytes [off, off + 16), off a multiple of 16
+    const u32 o = off & (CHAIN_RING - 1);
+    lds_st128(ring + o, q);
+    if (o == 0) lds_st64(ring + CHAIN_RING, (u64)q.x | ((u64)q.y << 32));
+  }
+  // the ring around position p (the start of a stream, or the prefetch fell behind): five pieces from 48 bytes below p's piece upwards
+  __device__ __forceinline__ void ring_resync(u32 p) {
+    const u32 pc = p & ~15u, lo = pc >= 48 ? pc - 48 : 0u;
+    uint4 q[5];
+#pragma unroll
+    for (u32 k = 0; k < 5; k++) q[k] = ld16(base + lo + 16 * k);
+#pragma unroll
+    for (u32 k = 0; k < 5; k++) ring_write(lo + 16 * k, q[k]);
+    rLo = lo; pfState = 0;
+  }
+  // once per decoded sequence: a piece is asked for when fewer than 64 bytes lie below the read position, and written two steps later
+  // (it has arrived by then) once the bytes it overwrites — the ring's top 16 — are behind the container
+  __device__ __forceinline__ void ring_advance() {
+    if (pfState) {
+      if (++pfAge >= 2 && ptr + 8 + 16 <= rLo + CHAIN_RING) { ring_write(rLo - 16, pf); rLo -= 16; pfState = 0; }
+    } else if (rLo >= 16 && ptr < rLo + 64) { pf = ld16(base + rLo - 16); pfState = 1; pfAge = 0; }
+  }
+  __device__ __forceinline__ u64 fetch(u32 p) {
+    if (RING) {
+      if (p < rLo) ring_resync(p);
+      return *(const zra_lds_u64u_t*)(ring + (p & (CHAIN_RING - 1)));
+    }
+    return ld64(base + p);
+  }
   __device__ __forceinline__ bool init(const u8* b, u32 n) {
     base = b;
     if (n < 1) return false;
-    if (n >= 8) { ptr = n - 8; c = ld64(b + ptr); }
-    else { ptr = 0; c = 0; for (u32 i = 0; i < n; i++) c |= (u64)b[i] << (8 * i); }
+    if (RING) { rLo = 0xFFFFFFFFu; pfState = 0; }          // (the first fetch fills the ring)
+    if (n >= 8) { ptr = n - 8; c = fetch(ptr); }
+    else { ptr = 0; c = 0; for (u32 i = 0; i < n; i++) c |= (u64)b[i] << (8 * i); if (RING) ring_resync(0); }
     const u32 last = b[n - 1];
     if (last == 0) return false;
     bc = 8 - hb32(last);
@@ -1256,11 +1306,11 @@ struct Zds {
   }
   __device__ __forceinline__ int reload() {
     if (bc > 64) return OVERFLOW;
-    if (ptr >= 8) { ptr -= bc >> 3; bc &= 7; c = ld64(base + ptr); return UNFINISHED; }
+    if (ptr >= 8) { ptr -= bc >> 3; bc &= 7; c = fetch(ptr); return UNFINISHED; }
     if (ptr == 0) return bc < 64 ? ENDOFBUFFER : COMPLETED;
     u32 nbBytes = bc >> 3; int r = UNFINISHED;
     if (ptr < nbBytes) { nbBytes = ptr; r = ENDOFBUFFER; }
-    ptr -= nbBytes; bc -= nbBytes * 8; c = ld64(base + ptr);
+    ptr -= nbBytes; bc -= nbBytes * 8; c = fetch(ptr);
     return r;
   }
   // the same transition without its status and without control flow around the load (so that the load can be in flight together with
@@ -1269,10 +1319,11 @@ struct Zds {
   __device__ __forceinline__ void reload_quiet(bool wide, const u8* pad) {
     const u32 nb = bc <= 64 ? min(bc >> 3, ptr) : 0u;
     ptr -= nb; bc -= nb * 8;
-    const u64 v = ld64(wide ? base + ptr : pad);
+    const u64 v = RING ? fetch(ptr) : ld64(wide ? base + ptr : pad);      // (RING, a short stream: reads what lies in the ring; nb is 0)
     c = nb ? v : c;
   }
 };
+typedef ZdsT<false> Zds;
 
 }  // namespace
 
@@ -1280,7 +1331,7 @@ namespace {
 // LDSTAB: the tables of the wave's frames live in LDS (ZRA_CHAIN_LDS_FRAMES slots of 5 KiB: lanes beyond them take no frames); a
 // frame's table is copied there by the whole wave when a lane takes the frame. The step itself is the same code.
 template <bool LDSTAB>
-__device__ __forceinline__ void chain_body(const ZraDecodeArgs& a, u32* const ldsTabs, u32* const baseLL, u32* const baseML) {
+__device__ __forceinline__ void chain_body(const ZraDecodeArgs& a, u32* const ldsTabs, u32* const baseLL, u32* const baseML, u32* const ldsRings = nullptr) {
   const int lane = threadIdx.x;
   const u32 nPend = a.counters[ZRA_DC_NPENDING];
   // per-lane job state
@@ -1288,7 +1339,9 @@ __device__ __forceinline__ void chain_body(const ZraDecodeArgs& a, u32* const ld
   ZraDecFrame* F = nullptr;
   const u32* T = nullptr;
   u64* sq = nullptr;
-  Zds br; br.c = 0; br.bc = 0; br.ptr = 0; br.base = nullptr;
+  ZdsT<LDSTAB> br; br.c = 0; br.bc = 0; br.ptr = 0; br.base = nullptr; br.ring = nullptr; br.rLo = 0xFFFFFFFFu;
+  br.lim = a.body + a.bodySize; br.pf = make_uint4(0, 0, 0, 0); br.pfState = 0; br.pfAge = 0;
+  if (LDSTAB) br.ring = (u8*)(ldsRings + (u32)lane * CHAIN_RING_WORDS);
   u32 sLL = 0, sOF = 0, sML = 0, rep0 = 1, rep1 = 4, rep2 = 8;
   u32 i = 0, nbSeq = 0, outPos = 0, litPos = 0, outCap = 0, regen = 0, produced0 = 0, limit = 0;
   u32 longMode = 0, err = 0, jErr = 0xFFFFFFFFu, valid = 0, validOut = 0, validLit = 0, truncated = 0;
@@ -1395,6 +1448,7 @@ __device__ __forceinline__ void chain_body(const ZraDecodeArgs& a, u32* const ld
           finish(); go = false;
         } else if (jErr != 0xFFFFFFFFu && i > jErr + 4) { finish(); go = false; }
       }
+      if (LDSTAB && go) br.ring_advance();
       if (go) {
         // ZSTD_decodeSequence (64-bit path): offset bits, match-length bits, [reload], literal-length bits, then the three state
         // updates — always, the last sequence included
@@ -1454,13 +1508,17 @@ zra_dec_chain_kernel(ZraDecodeArgs a) {
   __shared__ u32 baseLL[64], baseML[64];
   chain_body<false>(a, nullptr, baseLL, baseML);
 }
-// the same with the tables in LDS: one workgroup per CU (dynamic LDS: ZRA_CHAIN_LDS_FRAMES tables + the two base-value tables), launched
-// beside zra_dec_chain_kernel on another stream; both pull frames from the same queue. What this wave decodes asks nothing of L2 and
-// the fabric but its bitstream and its sequences.
+// the same with the tables in LDS: one workgroup per CU (dynamic LDS: ZRA_CHAIN_LDS_FRAMES tables and bitstream rings + the two base-value
+// tables), launched beside zra_dec_chain_kernel on another stream; both pull frames from the same queue. What this wave decodes asks
+// nothing of L2 and the fabric but 16-byte pieces of its bitstream, ahead of their use, and its sequences.
+// Round 5, measured (profiles/r05_experiments.md §10): this kernel ALONE takes 56-58 ms per 8 GiB (64 KiB frames) — 0.97 us per sequence
+// and lane, with or without its sequence stores, with the bitstream from the ring or from memory: a lone wave per CU is bound by the
+// ~500 instructions of a step, not by memory. Beside the HBM-table kernel (30 frames: 31 with rings no longer fit a CU next to that
+// kernel's two waves, LDS comes in pieces of 1,280 bytes) it takes 18 % of the frames: stage 23.6 -> 19.4 ms (20.4 without the ring).
 extern "C" __global__ void __launch_bounds__(DEC_THREADS)
 zra_dec_chain_lds_kernel(ZraDecodeArgs a) {
   extern __shared__ u32 chainLds[];
-  chain_body<true>(a, chainLds + 128, chainLds, chainLds + 64);
+  chain_body<true>(a, chainLds + 128, chainLds, chainLds + 64, chainLds + 128 + ZRA_CHAIN_LDS_FRAMES * ZRA_DEC_TBL_WORDS);
 }
 
 // =================================================================================================

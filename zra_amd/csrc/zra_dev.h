@@ -39,6 +39,14 @@ __device__ __forceinline__ u64 ld64_safe(const u8* p, const u8* end) {
   for (int i = 0; i < 8; i++) if (p + i < end) v |= (u64)p[i] << (8 * i);
   return v;
 }
+// LDS accesses typed as LDS (a generic pointer would compile to flat instructions): 8 bytes at any LDS address (one ds_read_b64, the
+// hardware splits it), 16- and 8-byte stores to aligned addresses
+typedef __attribute__((address_space(3))) u64_u zra_lds_u64u_t;
+typedef u32 zra_v4u32_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) zra_v4u32_t zra_lds_v4u32_t;
+typedef __attribute__((address_space(3))) u64 zra_lds_u64_t;
+__device__ __forceinline__ void lds_st128(u8* p, uint4 q) { zra_v4u32_t v = {q.x, q.y, q.z, q.w}; *(zra_lds_v4u32_t*)p = v; }
+__device__ __forceinline__ void lds_st64(u8* p, u64 v) { *(zra_lds_u64_t*)p = v; }
 __device__ __forceinline__ void st32(u8* p, u32 v) { *(u32_u*)p = v; }
 __device__ __forceinline__ void st64(u8* p, u64 v) { *(u64_u*)p = v; }
 struct __attribute__((packed, aligned(1))) u128_u { u32 a, b, c, d; };

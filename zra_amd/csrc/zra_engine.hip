@@ -412,7 +412,8 @@ Status Engine::decode_launch(const ZraDecodeArgs& a0, const uint32_t* dExpect, u
   static const uint32_t chainWaves = std::getenv("ZRA_DEC_CHAIN_WAVES") ? (uint32_t)std::atoi(std::getenv("ZRA_DEC_CHAIN_WAVES")) : 2u;
   // (ZRA_DEC_CHAIN_LDS_MIN: jobs from which the LDS-table chain kernel runs beside the other one; the tests set it to 1)
   static const uint32_t chainLdsMin = std::getenv("ZRA_DEC_CHAIN_LDS_MIN") ? (uint32_t)std::atoi(std::getenv("ZRA_DEC_CHAIN_LDS_MIN")) : (uint32_t)numCUs_ * 96u;
-  static const bool chainLdsOn = std::getenv("ZRA_DEC_CHAIN_LDS") ? std::atoi(std::getenv("ZRA_DEC_CHAIN_LDS")) != 0 : true;
+  static const int chainLdsMode = std::getenv("ZRA_DEC_CHAIN_LDS") ? std::atoi(std::getenv("ZRA_DEC_CHAIN_LDS")) : 1;   // 0: without the LDS-table kernel; 2 (bring-up): that kernel alone
+  static const bool chainLdsOn = chainLdsMode != 0;
   static const uint32_t chainGrid = std::getenv("ZRA_DEC_CHAIN_GRID") ? (uint32_t)std::atoi(std::getenv("ZRA_DEC_CHAIN_GRID")) : 0u;        // bring-up: absolute wave count
   // the rounds of one set of jobs, one stage after the other on the engine's stream (resident waves per CU of the chain kernel — lane =
   // frame, 64 frames' tables per wave: fewer frames in flight keep more of their table cells in the caches; A/B on one box, round 3,
@@ -450,7 +451,7 @@ Status Engine::decode_launch(const ZraDecodeArgs& a0, const uint32_t* dExpect, u
         bool forked = false;
         if (chainLdsOn && nActive >= chainLdsMin) {
           if (!pipeStreams_[1]) { if (hipStreamCreateWithFlags(&pipeStreams_[1], hipStreamNonBlocking) != hipSuccess) { pipeStreams_[1] = nullptr; (void)hipGetLastError(); } }
-          const size_t ldsBytes = (128 + (size_t)ZRA_CHAIN_LDS_FRAMES * ZRA_DEC_TBL_WORDS) * 4;
+          const size_t ldsBytes = (128 + (size_t)ZRA_CHAIN_LDS_FRAMES * (ZRA_DEC_TBL_WORDS + ZRA_CHAIN_RING_WORDS)) * 4;   // + a 144-byte bitstream ring per frame
           if (pipeStreams_[1] && !chainLdsAttr_) {
             if (hipFuncSetAttribute((const void*)zra_dec_chain_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes) == hipSuccess) chainLdsAttr_ = 1;
             else { chainLdsAttr_ = -1; (void)hipGetLastError(); }
@@ -460,7 +461,7 @@ Status Engine::decode_launch(const ZraDecodeArgs& a0, const uint32_t* dExpect, u
             HIPCHK(hipStreamWaitEvent(pipeStreams_[1], se[2], 0));
             hipLaunchKernelGGL(zra_dec_chain_lds_kernel, dim3((uint32_t)numCUs_), dim3(64), ldsBytes, pipeStreams_[1], x);
             HIPCHK(hipEventRecord(eJoin, pipeStreams_[1]));
-            hipLaunchKernelGGL(zra_dec_chain_kernel, dim3(gridChain), dim3(64), 0, stream_, x);
+            if (chainLdsMode != 2) hipLaunchKernelGGL(zra_dec_chain_kernel, dim3(gridChain), dim3(64), 0, stream_, x);
             HIPCHK(hipStreamWaitEvent(stream_, eJoin, 0));
             forked = true;
           }
