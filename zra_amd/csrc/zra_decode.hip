@@ -1234,8 +1234,8 @@ namespace {
 // that is filled AHEAD of the read position — the stream is read strictly from its end towards its start, so the next 16 bytes below
 // the ring's lowest offset are always the right ones to fetch — instead of through one dependent global load per sequence. ring[s & (R-1)]
 // = byte s of the stream for s in [rLo, rLo + R) (the first 8 bytes are mirrored behind the ring so that a container that wraps reads
-// straight on). Every container read is ONE ds_read without a branch around it; a read below rLo (the prefetch fell behind: more than
-// 4 bytes consumed per step for a while) first refills the ring at the read position (ring_resync), so nothing depends on timing.
+// straight on). Every container read is ONE ds_read without a branch around it; once per step ring_guard looks whether the prefetch fell
+// behind (more than 4 bytes consumed per step for a while) and then refills the ring at the read position, so nothing depends on timing.
 constexpr u32 CHAIN_RING = 128, CHAIN_RING_WORDS = (CHAIN_RING + 16) / 4;
 static_assert(CHAIN_RING_WORDS == ZRA_CHAIN_RING_WORDS, "ring size: zra_kernels.h");
 __device__ __attribute__((noinline)) uint4 chain_ld128_tail(const u8* p, const u8* lim) {   // 16 bytes at p, zeros beyond the readable body (the archive's last bytes)
@@ -1276,19 +1276,18 @@ struct ZdsT {
       if (++pfAge >= 2 && ptr + 8 + 16 <= rLo + CHAIN_RING) { ring_write(rLo - 16, pf); rLo -= 16; pfState = 0; }
     } else if (rLo >= 16 && ptr < rLo + 64) { pf = ld16(base + rLo - 16); pfState = 1; pfAge = 0; }
   }
+  // (RING: no test here — ring_guard, once per step of the caller, keeps 16 bytes of margin below the container, more than a step consumes)
   __device__ __forceinline__ u64 fetch(u32 p) {
-    if (RING) {
-      if (p < rLo) ring_resync(p);
-      return *(const zra_lds_u64u_t*)(ring + (p & (CHAIN_RING - 1)));
-    }
+    if (RING) return *(const zra_lds_u64u_t*)(ring + (p & (CHAIN_RING - 1)));
     return ld64(base + p);
   }
+  __device__ __forceinline__ void ring_guard() { if (rLo && ptr < rLo + 16) ring_resync(ptr); }
   __device__ __forceinline__ bool init(const u8* b, u32 n) {
     base = b;
     if (n < 1) return false;
-    if (RING) { rLo = 0xFFFFFFFFu; pfState = 0; }          // (the first fetch fills the ring)
+    if (RING) ring_resync(n >= 8 ? n - 8 : 0u);            // the top of the stream into the ring
     if (n >= 8) { ptr = n - 8; c = fetch(ptr); }
-    else { ptr = 0; c = 0; for (u32 i = 0; i < n; i++) c |= (u64)b[i] << (8 * i); if (RING) ring_resync(0); }
+    else { ptr = 0; c = 0; for (u32 i = 0; i < n; i++) c |= (u64)b[i] << (8 * i); }
     const u32 last = b[n - 1];
     if (last == 0) return false;
     bc = 8 - hb32(last);
@@ -1339,7 +1338,7 @@ __device__ __forceinline__ void chain_body(const ZraDecodeArgs& a, u32* const ld
   ZraDecFrame* F = nullptr;
   const u32* T = nullptr;
   u64* sq = nullptr;
-  ZdsT<LDSTAB> br; br.c = 0; br.bc = 0; br.ptr = 0; br.base = nullptr; br.ring = nullptr; br.rLo = 0xFFFFFFFFu;
+  ZdsT<LDSTAB> br; br.c = 0; br.bc = 0; br.ptr = 0; br.base = nullptr; br.ring = nullptr; br.rLo = 0;      // (rLo == 0: nothing to guard or prefetch — no stream yet, or the ring holds the stream's start)
   br.lim = a.body + a.bodySize; br.pf = make_uint4(0, 0, 0, 0); br.pfState = 0; br.pfAge = 0;
   if (LDSTAB) br.ring = (u8*)(ldsRings + (u32)lane * CHAIN_RING_WORDS);
   u32 sLL = 0, sOF = 0, sML = 0, rep0 = 1, rep1 = 4, rep2 = 8;
@@ -1400,7 +1399,7 @@ __device__ __forceinline__ void chain_body(const ZraDecodeArgs& a, u32* const ld
           sq = a.seqs + F->seqBase;
           rep0 = F->rep[0]; rep1 = F->rep[1]; rep2 = F->rep[2];
           i = 0; outPos = 0; litPos = 0; err = 0; jErr = 0xFFFFFFFFu; valid = 0; validOut = 0; validLit = 0; truncated = 0;
-          have = true;
+          have = true; br.rLo = 0; br.pfState = 0;      // (a block without sequences never opens its stream)
           // what went wrong before the sequences, in the reference's order: the literal streams, then the sequences header / tables
           if (F->hufErr) { err = ZE_CORRUPTION; nbSeq = 0; finish(); }
           else if (F->lateErr) { err = F->lateErr; nbSeq = 0; finish(); }
@@ -1436,6 +1435,7 @@ __device__ __forceinline__ void chain_body(const ZraDecodeArgs& a, u32* const ld
     // ---- one step of the lane's frame (no wave-level operation below: lanes are at different points of different frames)
     if (have) {
       bool go = true;
+      if (LDSTAB) { br.ring_guard(); br.ring_advance(); }
       if (i >= nbSeq) {
         // all sequences decoded. Short loop: the stream must be consumed (over-read passes); long loop: no such check.
         if (!err && nbSeq && !longMode && br.reload() < Zds::COMPLETED) err = ZE_CORRUPTION;
@@ -1448,7 +1448,6 @@ __device__ __forceinline__ void chain_body(const ZraDecodeArgs& a, u32* const ld
           finish(); go = false;
         } else if (jErr != 0xFFFFFFFFu && i > jErr + 4) { finish(); go = false; }
       }
-      if (LDSTAB && go) br.ring_advance();
       if (go) {
         // ZSTD_decodeSequence (64-bit path): offset bits, match-length bits, [reload], literal-length bits, then the three state
         // updates — always, the last sequence included
