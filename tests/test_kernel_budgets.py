@@ -20,7 +20,7 @@ BUDGET = {
     "zra_mf_kernel": (96, 392),          # generic one-lane finder without the optimal parsers (btlazy2, frames beyond the window, odd tails)
     "zra_mf_opt_kernel": (136, 480),     # ... with them (levels 13-22; its scratch holds the parser's small arrays)
     "zra_dec_chain_kernel": (72, 0),     # lane = frame FSE chains
-    "zra_dec_chain_lds_kernel": (80, 0), # the same with its frames' tables in LDS, one workgroup per CU beside it
+    "zra_dec_chain_lds_kernel": (112, 0), # the same with its frames' tables and bitstream rings in LDS, ONE wave per CU beside it (no occupancy to protect: 98 with the ring's piece in flight)
     "zra_dec_huf_kernel": (88, 0),       # wave-wide literal decode (two stream readers while a restarted lane looks for its previous path); 8.5 KiB of LDS per workgroup is its occupancy limit
     "zra_dec_parse_kernel": (96, 176),   # 5 waves per SIMD asked for: 40 spilled VGPRs bought 2.1x on the stage (frames in flight are what it needs)
     "zra_dec_exec_kernel": (80, 160),    # 6 waves per SIMD (the LDS-window step and the in-memory one side by side: 37 spilled VGPRs, 13.3 vs 14.3 ms at 5 waves)
