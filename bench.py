@@ -235,6 +235,22 @@ def c4_share(Z, eng, torch, dev, gib=2.0, cpu_mib=32):
             "bit_exact_gate": "archive bytes identical to CPU path (%d MiB sample)" % (samp >> 20)}
 
 
+def request_roofline(req, launch_ms):
+    """HBM-side request rates of the dominant launch (PMC bytes of profiles/traffic.json over the launch time measured in THIS run) as
+    fractions of the chip's measured random-request ceilings. None without a traffic entry."""
+    if not req or launch_ms <= 0:
+        return None
+    t = launch_ms / 1e3
+    r = dict(req)
+    r["fetch_per_s"] = round(req["fetch_lines_per_launch"] / t / 1e9, 2)
+    r["write_per_s_low_high"] = [round(req["write_bytes_per_launch"] / 64 / t / 1e9, 2), round(req["write_bytes_per_launch"] / 32 / t / 1e9, 2)]
+    r["unit"] = "1e9 requests/s"
+    fr = req["fetch_lines_per_launch"] / t / req["read_ceiling_per_s"]
+    r["frac_of_ceilings_low_high"] = [round(fr + req["write_bytes_per_launch"] / 64 / t / req["write_ceiling_per_s"], 3),
+                                      round(fr + req["write_bytes_per_launch"] / 32 / t / req["write_ceiling_per_s"], 3)]
+    return r
+
+
 def kernel_source_sha():
     """sha256 over the kernel sources (zra_amd/csrc, sorted by name) with comments and white space taken out: ties a PMC measurement
     in profiles/traffic.json to the CODE of a build (a reworded comment does not make a measurement stale)."""
@@ -634,6 +650,7 @@ def main():
         if os.environ.get("ZRA_MF_FLAGS", "1") in ("0",) and mf_kernel == "zra_mf_dfast_fl_kernel":
             mf_kernel = "zra_mf_dfast_kernel"
         traffic, traffic_src, traffic_stale, ra_traffic = None, None, None, None
+        req = None      # the launch's HBM-side REQUESTS against the chip's random-request ceilings (what actually bounds the kernel: DESIGN.md 4, "Round 5")
         tpath = os.path.join(HERE, "profiles", "traffic.json")
         wkey = "L%d_fs%d" % (args.level, fs)
         if os.path.exists(tpath):
@@ -647,6 +664,13 @@ def main():
                     traffic_stale = tj.get("kernel_source_sha") != kernel_source_sha()
                     traffic_src = "rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE (separate passes) of bench.py --steps 1 (%s); kernel sources %s at measurement, %s now" % (
                         tj.get("raw", "profiles/"), tj.get("kernel_source_sha", "unrecorded (commit %s)" % tj.get("measured_at_commit")), kernel_source_sha())
+                    e = tj[mf_kernel]
+                    if "fetch_kib" in e and "write_kib" in e:
+                        scale = nframes / launches / tj["frames"] * e["launches"]
+                        fl, wb = e["fetch_kib"] * 1024 / 64 * scale, e["write_kib"] * 1024 * scale
+                        req = {"fetch_lines_per_launch": int(fl), "write_bytes_per_launch": int(wb), "read_ceiling_per_s": 48.3e9, "write_ceiling_per_s": 23.0e9,
+                               "ceilings_from": "profiles/r02_pmc_calibration.txt (tools/pmc_calib.cpp, 4 GiB region: random 4-byte reads / partial-line writes per second)",
+                               "note": "fetches as 64-byte lines; writes between 64 B (full lines: the table clears) and 32 B (partial-line stores) per request: low / high"}
                     d1 = tj.get("decode_one_pass_of_16GiB", {}).get("zra_dec_chain_kernel")
                     if d1:
                         ra_traffic = int((d1["fetch_kib"] + d1["write_kib"]) * 1024 * nframes / tj["frames"])
@@ -677,7 +701,7 @@ def main():
             "ra_latency": ra_latency,
             "roofline": {"bound": "hbm", "kernel": mf_kernel, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "frac_of_measured_6290": round(achieved / 6290.0, 5), "traffic": traffic, "traffic_source": traffic_src,
-                         "traffic_stale": traffic_stale,
+                         "traffic_stale": traffic_stale, "requests": request_roofline(req, mf_launch_ms),
                          "launch_ms": round(mf_launch_ms, 3), "launches_per_call": launches, "algorithmic_bytes_per_launch": int(alg_per_launch),
                          "other_kernels_launch_ms": {"zra_entropy_kernel": round(ent_launch_ms, 3), "zra_dec_parse+huf+chain+exec (one decode pass)": round(dec_launch_ms, 3)}},
             "roofline_ra": {"bound": "hbm", "kernel": "zra_dec_chain_kernel", "achieved": round(ra_ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
