@@ -895,14 +895,17 @@ def test_foreign_frame_size_does_not_cost_a_pass_per_frame(zra):
 @pytest.mark.gpu
 @pytest.mark.parametrize("env", [{"ZRA_MF_FLAGS": "0", "ZRA_MF_LS": "0"}, {"ZRA_MF_WAVES": "18", "ZRA_MF_LS": "0", "ZRA_ENT_WGS": "1", "ZRA_ENC_RING": "2"},
                                  {"ZRA_DEC_PIPE": "4", "ZRA_DEC_PIPE_MIN": "1", "ZRA_DEC_SMALL_MAX": "0"}, {"ZRA_MF_LS": "0"}, {"ZRA_MF_LS_MAX": "1000000"}, {"ZRA_ENC_POISON": "1"},
-                                 {"ZRA_PIPE": "0"}, {"ZRA_PIPE": "2"}, {"ZRA_PIPE": "2", "ZRA_ENC_RING": "2", "ZRA_ENT_WGS": "2"}],
+                                 {"ZRA_PIPE": "0"}, {"ZRA_PIPE": "2"}, {"ZRA_PIPE": "2", "ZRA_ENC_RING": "2", "ZRA_ENT_WGS": "2"},
+                                 {"ZRA_DEC_SMALL_MAX": "0", "ZRA_DEC_CHAIN_LDS_MIN": "1", "ZRA_DEC_CHAIN_LDS": "2"}],
                          ids=["dfast-without-bucket-flags", "dfast-other-pipeline-geometry", "decode-stage-pipeline", "dfast-small-calls-from-memory", "dfast-all-calls-from-lds",
-                              "hash-chain-over-poisoned-scratch", "dfast-stages-in-sequence", "dfast-resident-entropy-stage", "dfast-resident-entropy-small-ring"])
+                              "hash-chain-over-poisoned-scratch", "dfast-stages-in-sequence", "dfast-resident-entropy-stage", "dfast-resident-entropy-small-ring",
+                              "decode-lds-table-chain-kernel-alone"])
 def test_opt_in_kernels_are_bit_exact_too(env):
     """The paths of the library that a default call of the test sizes does not take give the same bytes as the ones it does: the dfast table
     kernel without its bucket flags (round 5: the flags are on by default for calls beyond the LDS-source kernel's size), the persistent
-    pipeline with another geometry (18 waves per CU, one entropy workgroup per CU, a slot ring of two sub-batches), the decode stage
-    pipeline, the two dfast kernels — frame source read from memory / from a copy in LDS — each forced onto the call sizes the other one
+    pipeline with another geometry (18 waves per CU, one entropy workgroup per CU, a slot ring of two sub-batches) and in its other two
+    modes (stages in sequence; one resident entropy launch that scans and gathers itself), the decode stage pipeline, the sequence-chain
+    kernel with its tables (two-byte cells) and bitstream rings in LDS ALONE on every job (by default it takes a share of large passes only), the two dfast kernels — frame source read from memory / from a copy in LDS — each forced onto the call sizes the other one
     takes by default; and the wave-cooperative hash-chain finder, which does not clear its chain slots, over a table scratch filled with
     0xA5 before every batch (a selection of the level 5-10 cases here; the randomised differential compress ran that way in the soak,
     profiles/r04_soak_d.txt): the compress parity cases of levels 3-4 (archives byte-identical to the oracle's, reference call site
@@ -910,6 +913,7 @@ def test_opt_in_kernels_are_bit_exact_too(env):
     again, in a fresh process with the knob set."""
     import subprocess
     sel = "randomised_differential_decode or golden_frames" if "ZRA_DEC_PIPE" in env else \
+          "randomised_differential_decode or randomised_corruption_statuses or random_access_on_damaged or ra_vs_bruteforce or golden_frames or libzstd_frames" if "ZRA_DEC_CHAIN_LDS" in env else \
           "compress_buffer_bit_exact and (5-65536 or 9-65536 or 7-16384 or 10-) or short_last_frame or frames_larger_than_the_window" if "ZRA_ENC_POISON" in env else \
           "compress_buffer_bit_exact and (3-65536 or 4-65536 or 3-16384 or 0-16384) or sub_batch_boundaries or short_last_frame or match_finder_sequences and (3-65536 or 3-16384) or randomised_differential_compress"
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-x", "-q", "-k", sel, "-p", "no:cacheprovider"],
@@ -947,3 +951,37 @@ def test_error_exit_between_two_scratch_contexts_drains_every_stream(zra, gpu_en
         assert st == (0, 0) and d_arc[:n].cpu().numpy().tobytes() == ref
     finally:
         os.environ.pop("ZRA_ENC_FAIL_BATCH", None); os.environ.pop("ZRA_ENC_BUDGET_GIB", None)
+
+
+@pytest.mark.gpu
+def test_dfast_flag_sweep_at_frame_sizes_just_past_a_block():
+    """Found by the round-5 soak (seed 90047, case 6: level 3, 50,000-byte frames, a last frame of 40,967 bytes): the bucket-flag sweep of
+    the dfast table kernel (df_later_flags) loads the frame 512 positions at a time, and the last hashed position's 8 bytes reach up to 7
+    bytes past its block when frameSize % 512 is 1..7 — the bytes behind the TOP block were taken as zeros, the last positions marked the
+    wrong buckets, and an earlier bucket-mate's table write was skipped as dead. Every residue of the frame size around a block boundary,
+    whole frames and short last frames, levels 3 and 4, and the soak's seed itself — on the table kernel (ZRA_MF_LS=0: calls this small take
+    the LDS-source kernel by default), compared with the oracle (reference call site zra.cpp:219)."""
+    import subprocess
+    code = r"""
+import sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np
+import zra_amd as Z, oracle_lib as O, corpus as C
+import test_gpu_parity as T
+src = C.gen_E(1 << 20) + C.gen_C(1 << 20) + C.gen_loglike(1 << 20)
+bad = 0
+for level in (3, 4):
+    for r in list(range(0, 10)) + [255, 256, 257, 503, 504, 505, 511]:
+        for fs, n in ((40960 + r, 3 * (40960 + r)), (16384, 3 * 16384 + 4096 + r), (65536, 65536 + 512 * 9 + r)):
+            for base in (0, 1 << 20, 2 << 20):
+                d = src[base + 7 * r: base + 7 * r + n]
+                st, ref = O.zra_compress(d, level, fs, True)
+                assert st == (0, 0)
+                if Z.CompressBuffer(d, level, fs, True) != ref:
+                    bad += 1; print("MISMATCH", level, fs, n, base)
+T.test_randomised_differential_compress(Z, 90047)
+print("bad", bad)
+""" % (HERE, os.path.dirname(HERE))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, ZRA_MF_LS="0"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-800:], r.stderr[-1500:])
+    assert r.stdout.strip().endswith("bad 0"), r.stdout[-800:]

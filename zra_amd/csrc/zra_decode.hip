@@ -1351,13 +1351,25 @@ __device__ __forceinline__ void chain_body(const ZraDecodeArgs& a, u32* const ld
   u32 eL = 0, eM = 0, eO = 0;
   bool wide = false; const u8* pad = nullptr;
   bool fresh = false; u32 freshJob = 0;
-  const u32 slotBase = (u32)lane * ZRA_DEC_TBL_WORDS;
+  // LDSTAB (round 5): TWO-byte cells in LDS, so that 59 frames' tables fit a CU instead of 31 — code | v << 6, where v = the state's
+  // base >> width under a leading one at bit (tableLog - width): FSE's base is a multiple of 2^width and smaller than 2^tableLog, so the
+  // leading one's place gives the width and the bits under it the base. The code's extra-bit count rides in the base-value tables.
+  const u16* const cells16 = (const u16*)ldsTabs + (size_t)lane * ZRA_DEC_TBL_WORDS;
+  u32 logLL = 0, logML = 0, logOF = 0;                  // LDSTAB: the frame's table logs (the cells' widths are relative to them)
   auto fetch_cells = [&]() {
-    if (LDSTAB) { eL = ldsTabs[slotBase + ZRA_DEC_TBL_LL + sLL]; eM = ldsTabs[slotBase + ZRA_DEC_TBL_ML + sML]; eO = ldsTabs[slotBase + ZRA_DEC_TBL_OF + sOF]; }
+    if (LDSTAB) { eL = cells16[ZRA_DEC_TBL_LL + sLL]; eM = cells16[ZRA_DEC_TBL_ML + sML]; eO = cells16[ZRA_DEC_TBL_OF + sOF]; }
     else { eL = T[ZRA_DEC_TBL_LL + sLL]; eM = T[ZRA_DEC_TBL_ML + sML]; eO = T[ZRA_DEC_TBL_OF + sOF]; }
   };
-  // base values of the length codes (the cells carry the code only)
-  baseLL[lane] = lane < 36 ? c_ll_base[lane] : 0u; baseML[lane] = lane < 53 ? c_ml_base[lane] : 0u;
+  // a cell's fields, whichever layout: code, extra bits of the code, state bits, state base
+  auto c_code = [&](u32 e) -> u32 { return e & 63u; };
+  auto c_sbits = [&](u32 e, u32 lg) -> u32 { if (LDSTAB) return lg - (31u - (u32)__builtin_clz(e >> 6)); return (e >> 16) & 0xF; };
+  auto c_sbase = [&](u32 e, u32 lg) -> u32 {
+    if (LDSTAB) { const u32 v = e >> 6, hb = 31u - (u32)__builtin_clz(v); return (v ^ (1u << hb)) << (lg - hb); }
+    return e >> 20;
+  };
+  // base values of the length codes (the cells carry the code only); LDSTAB: the code's extra-bit count in the top byte
+  baseLL[lane] = lane < 36 ? c_ll_base[lane] | (LDSTAB ? (u32)c_ll_bits[lane] << 24 : 0u) : 0u;
+  baseML[lane] = lane < 53 ? c_ml_base[lane] | (LDSTAB ? (u32)c_ml_bits[lane] << 24 : 0u) : 0u;
   wsync();
   if (LDSTAB && (u32)lane >= ZRA_CHAIN_LDS_FRAMES) drained = true;
 
@@ -1406,9 +1418,10 @@ __device__ __forceinline__ void chain_body(const ZraDecodeArgs& a, u32* const ld
           else if (nbSeq) {
             if (!br.init(blk + F->seqPos, F->bsize - F->seqPos)) { err = ZE_CORRUPTION; finish(); }
             else {
-              sLL = br.read(F->llLog); br.reload();
-              sOF = br.read(F->ofLog); br.reload();
-              sML = br.read(F->mlLog); br.reload();
+              logLL = F->llLog; logOF = F->ofLog; logML = F->mlLog;
+              sLL = br.read(logLL); br.reload();
+              sOF = br.read(logOF); br.reload();
+              sML = br.read(logML); br.reload();
               wide = F->bsize - F->seqPos >= 8;
               pad = a.body + a.frameOff[gj * a.offStride];          // the frame's first bytes: always 8 readable ones
               if (LDSTAB) { fresh = true; freshJob = j; } else fetch_cells();
@@ -1424,8 +1437,17 @@ __device__ __forceinline__ void chain_body(const ZraDecodeArgs& a, u32* const ld
         const u32 l = (u32)__builtin_ctzll(nm); nm &= nm - 1;
         const u32 jj = bcast_u32(freshJob, l);
         const uint4* const g4 = (const uint4*)(a.tables + (size_t)jj * ZRA_DEC_TBL_WORDS);
-        uint4* const d4 = (uint4*)(ldsTabs + l * ZRA_DEC_TBL_WORDS);
-        for (u32 i = (u32)lane; i < ZRA_DEC_TBL_WORDS / 4; i += DEC_THREADS) d4[i] = g4[i];
+        uint2* const d2 = (uint2*)((u16*)ldsTabs + (size_t)l * ZRA_DEC_TBL_WORDS);
+        const ZraDecFrame* const Fj = &a.frames[jj];
+        const u32 lgL = Fj->llLog, lgM = Fj->mlLog, lgO = Fj->ofLog;
+        for (u32 i = (u32)lane; i < ZRA_DEC_TBL_WORDS / 4; i += DEC_THREADS) {
+          const uint4 q = g4[i];
+          const u32 lg = 4 * i < ZRA_DEC_TBL_ML ? lgL : 4 * i < ZRA_DEC_TBL_OF ? lgM : lgO;
+          // (sym | extraBits << 8 | stateBits << 16 | base << 20) -> (sym | ((1 << (log - stateBits)) | base >> stateBits) << 6); cells beyond the
+          // table's 2^log (never read) may hold anything: their shift is clamped
+          auto pk = [&](u32 x) -> u32 { const u32 nb = min((x >> 16) & 0xFu, lg); return (x & 63u) | (((1u << (lg - nb)) | ((x >> 20) >> nb)) << 6); };
+          d2[i] = make_uint2(pk(q.x) | (pk(q.y) << 16), pk(q.z) | (pk(q.w) << 16));
+        }
       }
       if (__ballot(fresh)) wsync();
       if (fresh) { fetch_cells(); fresh = false; }
@@ -1451,8 +1473,9 @@ __device__ __forceinline__ void chain_body(const ZraDecodeArgs& a, u32* const ld
       if (go) {
         // ZSTD_decodeSequence (64-bit path): offset bits, match-length bits, [reload], literal-length bits, then the three state
         // updates — always, the last sequence included
-        const u32 ofBits = (eO >> 8) & 0xFF, mlBits = (eM >> 8) & 0xFF, llBits = (eL >> 8) & 0xFF;
-        u32 ll = baseLL[eL & 63u], ml = baseML[eM & 63u], off;
+        u32 ll = baseLL[c_code(eL)], ml = baseML[c_code(eM)], off;
+        const u32 ofBits = LDSTAB ? c_code(eO) : (eO >> 8) & 0xFF, mlBits = LDSTAB ? ml >> 24 : (eM >> 8) & 0xFF, llBits = LDSTAB ? ll >> 24 : (eL >> 8) & 0xFF;
+        if (LDSTAB) { ll &= 0xFFFFFFu; ml &= 0xFFFFFFu; }
         if (ofBits > 1) {
           off = ((1u << ofBits) - 3u) + br.read_fast(ofBits);
           rep2 = rep1; rep1 = rep0; rep0 = off;
@@ -1472,9 +1495,9 @@ __device__ __forceinline__ void chain_body(const ZraDecodeArgs& a, u32* const ld
         if (mlBits) ml += br.read_fast(mlBits);
         if (llBits + mlBits + ofBits >= 57 - (9 + 9 + 8)) br.reload();
         if (llBits) ll += br.read_fast(llBits);
-        sLL = (eL >> 20) + br.read((eL >> 16) & 0xF);
-        sML = (eM >> 20) + br.read((eM >> 16) & 0xF);
-        sOF = (eO >> 20) + br.read((eO >> 16) & 0xF);
+        sLL = c_sbase(eL, logLL) + br.read(c_sbits(eL, logLL));
+        sML = c_sbase(eM, logML) + br.read(c_sbits(eM, logML));
+        sOF = c_sbase(eO, logOF) + br.read(c_sbits(eO, logOF));
         fetch_cells();                                      // next sequence's cells and the container: one round trip
         if (!longMode) br.reload_quiet(wide, pad);
         // ZSTD_execSequence / ZSTD_execSequenceEnd, checks only (the execute kernel moves the bytes): destination room, literal
@@ -1517,7 +1540,7 @@ zra_dec_chain_kernel(ZraDecodeArgs a) {
 extern "C" __global__ void __launch_bounds__(DEC_THREADS)
 zra_dec_chain_lds_kernel(ZraDecodeArgs a) {
   extern __shared__ u32 chainLds[];
-  chain_body<true>(a, chainLds + 128, chainLds, chainLds + 64, chainLds + 128 + ZRA_CHAIN_LDS_FRAMES * ZRA_DEC_TBL_WORDS);
+  chain_body<true>(a, chainLds + 128, chainLds, chainLds + 64, chainLds + 128 + ZRA_CHAIN_LDS_FRAMES * (ZRA_DEC_TBL_WORDS / 2));
 }
 
 // =================================================================================================

@@ -1239,7 +1239,10 @@ __device__ __forceinline__ void df_later_flags(const u8* src, u32 fsize, u32 hlo
     const bool hm = pass != 0;
     // blocks nBlk-1 .. 0; B0 is the one being hashed, B1 the next one below it (in flight meanwhile)
     DfBlock B0 = df_block_load(src, fsize, flg, nBlk - 1, hm, lane), B1{0, 0};
-    u64 above = 0;                                       // the 8 bytes behind the block (lane 0 of the block above)
+    // the 8 bytes behind the block (lane 0 of the block above). Behind the TOP block: the frame's own bytes there — the last hashed
+    // position's 8 bytes reach up to 7 bytes past its block when fsize % 512 is 1..7 (found by the round-5 soak, seed 90047: a tail frame
+    // of 40,967 bytes; with zeros here its last positions marked the wrong buckets and an earlier bucket-mate's write was skipped)
+    u64 above = nBlk * 512 < fsize ? ld64_safe(src + nBlk * 512, src + fsize) : 0;
     for (u32 blk = nBlk; blk-- > 0;) {
       if (blk >= 1) B1 = df_block_load(src, fsize, flg, blk - 1, hm, lane);
       const u32 aLo = (u32)B0.a, aHi = (u32)(B0.a >> 32);

@@ -451,7 +451,7 @@ Status Engine::decode_launch(const ZraDecodeArgs& a0, const uint32_t* dExpect, u
         bool forked = false;
         if (chainLdsOn && nActive >= chainLdsMin) {
           if (!pipeStreams_[1]) { if (hipStreamCreateWithFlags(&pipeStreams_[1], hipStreamNonBlocking) != hipSuccess) { pipeStreams_[1] = nullptr; (void)hipGetLastError(); } }
-          const size_t ldsBytes = (128 + (size_t)ZRA_CHAIN_LDS_FRAMES * (ZRA_DEC_TBL_WORDS + ZRA_CHAIN_RING_WORDS)) * 4;   // + a 144-byte bitstream ring per frame
+          const size_t ldsBytes = (128 + (size_t)ZRA_CHAIN_LDS_FRAMES * (ZRA_DEC_TBL_WORDS / 2 + ZRA_CHAIN_RING_WORDS)) * 4;   // two-byte cells + a 144-byte bitstream ring per frame
           if (pipeStreams_[1] && !chainLdsAttr_) {
             if (hipFuncSetAttribute((const void*)zra_dec_chain_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes) == hipSuccess) chainLdsAttr_ = 1;
             else { chainLdsAttr_ = -1; (void)hipGetLastError(); }

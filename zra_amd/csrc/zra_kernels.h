@@ -27,7 +27,7 @@
 #define ZRA_LDS_TBL_WORDS 2304u
 // zra_dec_chain_lds_kernel: frames (= lanes) whose tables one workgroup keeps in LDS (31 x 5 KiB + 512 B of 160 KiB; the rest leaves
 // room for two workgroups of zra_dec_chain_kernel on the same CU)
-#define ZRA_CHAIN_LDS_FRAMES 30u
+#define ZRA_CHAIN_LDS_FRAMES 59u   // lanes of the LDS-table chain kernel's wave that take frames: 59 x (2,560 B of two-byte cells + 144 B of ring) + 512 B beside the other chain kernel's two waves
 #define ZRA_CHAIN_RING_WORDS 36u   // per frame of the LDS-table chain kernel: a 128-byte ring of its sequence bitstream + 16 (zra_decode.hip: CHAIN_RING)
 
 // per-frame decode state; lives in HBM scratch for the whole call (frames take one round per compressed block)
