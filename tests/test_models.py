@@ -1,6 +1,7 @@
 """The CPU restatements of the wave-parallel dfast parses (tools/model/) against the oracle, a few seeds each: the kernels' exactness
 arguments are fuzzed here on every CPU run of the suite, not only when somebody remembers to run tools/model/run*.sh.
-(Bring-up models of zra_amd/csrc/zra_encode_lk.hip and of mf_dfast_mask in zra_encode_mf.hip — test infrastructure, like the oracle.)"""
+(Bring-up models of two dfast formulations that were built, measured and deleted from the library again — the link parse of round 4 and the
+mask parse of round 3, both last present at commit d26905f — and of round 5's bucket-flag statistics; test infrastructure, like the oracle.)"""
 import os
 import subprocess
 import sys

@@ -1,4 +1,4 @@
-// zra_amd — wave-level helpers shared by the match-finder kernels (zra_encode_mf.hip, zra_encode_lk.hip). wave = 64 lanes.
+// zra_amd — wave-level helpers of the match-finder kernels (zra_encode_mf.hip). wave = 64 lanes.
 #pragma once
 #include "zra_dev.h"
 
