@@ -227,6 +227,13 @@ Status Engine::compress_impl_body(const uint8_t* dIn, size_t inSize, uint8_t* dB
   }
   uint32_t B = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>({nFramesTotal, budget / perFrame, full.strategy == 2 ? 16384ull : 65536ull}));
   if (B > 1024) B &= ~1023u;
+  // Frames of several blocks whose batch would hold the whole call: two half batches instead. Block b + 1's match finder waits for block
+  // b's entropy stage (the confirmed repcodes: a block stored raw does not move them), so ONE batch runs finder and entropy stage strictly
+  // in turns; two contexts fill each other's gaps — as long as half a batch still fills the chip (16 frames per CU). Measured on one box
+  // (profiles/r05_experiments.md §9; log-like data, 256 KiB frames): 8,192 frames at level 9 3.69-3.80 -> 3.89-3.98 GiB/s, at level 5
+  // 8.14-8.18 -> 8.94-8.99; 4,096 frames at level 3 12.8 -> 10.6 (hence the bound). ZRA_ENC_SPLIT=0: off.
+  { static const bool split = !(std::getenv("ZRA_ENC_SPLIT") && std::atoi(std::getenv("ZRA_ENC_SPLIT")) == 0);
+    if (split && maxBlocksPerFrame > 1 && nFramesTotal <= B && nFramesTotal >= 32ull * (uint64_t)numCUs_) B = (uint32_t)(((nFramesTotal + 1) / 2 + 63) & ~63ull); }
   // the entropy stage: workgroups that take the batch's frames from a queue — as many as the device holds at once (5 waves per SIMD by
   // registers), each with its own literal buffer and sequence work area
   const uint32_t entGridB = (uint32_t)std::min<uint64_t>(B, (uint64_t)numCUs_ * 5);
