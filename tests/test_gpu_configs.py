@@ -267,3 +267,27 @@ def test_input_with_a_short_tail_stays_on_the_persistent_pipeline(zra, gpu_engin
     n = gpu_engine.compress(d_in.data_ptr(), len(data), d_arc.data_ptr(), 3, fs, True)
     assert d_arc[:n].cpu().numpy().tobytes() == ref
     assert gpu_engine.kernel_stats()["mf_launches"] == 1
+
+
+@pytest.mark.gpu
+def test_multi_block_frames_in_two_half_batches(zra, gpu_engine):
+    """Round 5: frames of several blocks whose batch would hold the whole call run as two half batches on the two scratch contexts (block
+    b + 1's match finder waits for block b's entropy stage; two contexts fill each other's gaps) — from 32 frames per CU on. 8,192 frames
+    of 132 KiB (two blocks each: 128 KiB + 4 KiB) at level 3, 1.03 GiB of log-like data: the archive is the oracle's, byte for byte
+    (reference call site zra.cpp:216-225), the call took the match finder's 2 x 2 launches, and it decodes back."""
+    import torch
+    dev = torch.device("cuda", 0)
+    fs, nfr = 135168, 8192
+    base = np.frombuffer(C.gen_loglike(33 << 20, seed=9), dtype=np.uint8)
+    data = np.resize(base, fs * nfr).tobytes()
+    st, ref = O.zra_compress(data, 3, fs, True)
+    assert st == (0, 0)
+    d_in = torch.from_numpy(np.frombuffer(data, dtype=np.uint8).copy()).to(dev)
+    d_arc = torch.empty(zra.GetOutputBufferSize(len(data), fs) + 64, dtype=torch.uint8, device=dev)
+    n = gpu_engine.compress(d_in.data_ptr(), len(data), d_arc.data_ptr(), 3, fs, True)
+    assert n == len(ref)
+    assert hashlib.sha256(d_arc[:n].cpu().numpy().tobytes()).digest() == hashlib.sha256(ref).digest()
+    assert gpu_engine.kernel_stats()["mf_launches"] == 4
+    d_back = torch.empty(len(data), dtype=torch.uint8, device=dev)
+    gpu_engine.decompress(d_arc.data_ptr(), n, d_back.data_ptr(), len(data))
+    assert torch.equal(d_back, d_in)

@@ -232,8 +232,12 @@ Status Engine::compress_impl_body(const uint8_t* dIn, size_t inSize, uint8_t* dB
   // in turns; two contexts fill each other's gaps — as long as half a batch still fills the chip (16 frames per CU). Measured on one box
   // (profiles/r05_experiments.md §9; log-like data, 256 KiB frames): 8,192 frames at level 9 3.69-3.80 -> 3.89-3.98 GiB/s, at level 5
   // 8.14-8.18 -> 8.94-8.99; 4,096 frames at level 3 12.8 -> 10.6 (hence the bound). ZRA_ENC_SPLIT=0: off.
+  // And batches of EQUAL size whenever there are several: a call of 8,192 frames with room for 7,168 ran as 7,168 + 1,024 (the bench's
+  // c4_share, where the timed buffers leave less free memory than a lone call finds), and the small batch left its context idle.
   { static const bool split = !(std::getenv("ZRA_ENC_SPLIT") && std::atoi(std::getenv("ZRA_ENC_SPLIT")) == 0);
-    if (split && maxBlocksPerFrame > 1 && nFramesTotal <= B && nFramesTotal >= 32ull * (uint64_t)numCUs_) B = (uint32_t)(((nFramesTotal + 1) / 2 + 63) & ~63ull); }
+    uint64_t nBatches = (nFramesTotal + B - 1) / B;
+    if (split && maxBlocksPerFrame > 1 && nBatches == 1 && nFramesTotal >= 32ull * (uint64_t)numCUs_) nBatches = 2;
+    if (split && nBatches > 1) B = (uint32_t)std::min<uint64_t>(B, ((nFramesTotal + nBatches - 1) / nBatches + 63) & ~63ull); }
   // the entropy stage: workgroups that take the batch's frames from a queue — as many as the device holds at once (5 waves per SIMD by
   // registers), each with its own literal buffer and sequence work area
   const uint32_t entGridB = (uint32_t)std::min<uint64_t>(B, (uint64_t)numCUs_ * 5);
