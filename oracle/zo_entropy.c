@@ -192,52 +192,81 @@ size_t zo_fse_write_ncount(u8* out, size_t cap, const s16* norm, unsigned maxSym
   return pos;
 }
 
-/* A.3 "FSE table description" reader. returns bytes consumed, 0 on corruption. */
+/* A.3 "FSE table description" reader. returns bytes consumed, 0 on corruption.
+ * Restates FSE_readNCount of libzstd 1.4.9 (lib/common/entropy_common.c, FSE_readNCount_body) INCLUDING what it does near the end of its
+ * input, which a reader written from the format description does not: it reads 32 bits at a byte pointer that never passes end - 4, and
+ * when a read position would, the pointer is clamped there and the bit offset taken modulo 32 — a description that runs past the end of
+ * the input then reads bits it has read before instead of failing, and only the position behind the LAST symbol is checked (> 32).
+ * Inputs shorter than 8 bytes are read from a zero-padded copy. Round 5: the plain reader (zeros past the end, every overrun an error)
+ * refused a damaged frame that libzstd decodes (soak seed 91417: checksum_wrong there, corruption_detected here). */
+static u32 zo_rd32le(const u8* p) { return (u32)p[0] | ((u32)p[1] << 8) | ((u32)p[2] << 16) | ((u32)p[3] << 24); }
 size_t zo_fse_read_ncount(s16* norm, unsigned* maxSymPtr, unsigned* tPtr, const u8* src, size_t n, unsigned maxAL) {
-  /* bits are consumed LSB-first from a forward cursor; peeking past the end yields zeros */
-  size_t bitpos = 0, nbits = n * 8;
-#define PEEK(k) ((u32)((zo_peek_fwd(src, n, bitpos)) & ((1u << (k)) - 1)))
+  u8 pad[8];
   if (n < 1) return 0;
-  unsigned AL = PEEK(4) + 5; bitpos += 4;
-  if (AL > maxAL) return 0;
-  int remaining = (1 << AL) + 1, thr = 1 << AL, nb = (int)AL + 1;
-  unsigned sym = 0, maxSym = *maxSymPtr;
-  int prev0 = 0;
-  while (remaining > 1 && sym <= maxSym) {
-    if (prev0) {
-      for (;;) {
-        unsigned f = PEEK(2); bitpos += 2;
-        sym += f;
-        if (f != 3) break;
-        if (bitpos > nbits) return 0;
-      }
-      if (sym > maxSym) return 0; /* zeros ran past the alphabet (zeros need no explicit store: norm pre-zeroed) */
-    }
-    {
-      int max = (2 * thr - 1) - remaining;
-      int v;
-      u32 lowbits = PEEK(nb - 1);
-      if ((int)lowbits < max) { v = (int)lowbits; bitpos += nb - 1; }
-      else {
-        v = (int)PEEK(nb);
-        if (v >= thr) v -= max;
-        bitpos += nb;
-      }
-      v--; /* prob */
-      remaining -= v < 0 ? -v : v;
-      norm[sym++] = (s16)v;
-      prev0 = (v == 0);
-      if (remaining < 1) return 0;
-      while (remaining < thr) { nb--; thr >>= 1; }
-    }
-    if (bitpos > nbits) return 0;
+  if (n < 8) {
+    memset(pad, 0, 8); memcpy(pad, src, n);
+    { const size_t h = zo_fse_read_ncount(norm, maxSymPtr, tPtr, pad, 8, maxAL);
+      return (h == 0 || h > n) ? 0 : h; }
   }
-#undef PEEK
-  if (remaining != 1) return 0;
-  if (bitpos > nbits) return 0;
-  *maxSymPtr = sym - 1;
-  *tPtr = AL;
-  return (bitpos + 7) / 8;
+  {
+    const u8* const iend = src + n;
+    const u8* ip = src;
+    const unsigned maxSV1 = *maxSymPtr + 1;
+    u32 bitStream = zo_rd32le(ip);
+    int nbBits = (int)(bitStream & 0xF) + 5, remaining, threshold, bitCount = 4, previous0 = 0;
+    memset(norm, 0, (size_t)maxSV1 * sizeof(norm[0]));          /* symbols the description does not reach have probability 0 */
+    unsigned charnum = 0;
+    if (nbBits > 15) return 0;                                   /* FSE_TABLELOG_ABSOLUTE_MAX: tableLog_tooLarge */
+    bitStream >>= 4;
+    *tPtr = (unsigned)nbBits;
+    remaining = (1 << nbBits) + 1; threshold = 1 << nbBits; nbBits++;
+    for (;;) {
+      if (previous0) {
+        /* pairs of 11 = three more zero-probability symbols each */
+        int repeats = __builtin_ctz(~bitStream | 0x80000000u) >> 1;
+        while (repeats >= 12) {
+          charnum += 3 * 12;
+          if (ip <= iend - 7) ip += 3;
+          else { bitCount -= (int)(8 * (iend - 7 - ip)); bitCount &= 31; ip = iend - 4; }
+          bitStream = zo_rd32le(ip) >> bitCount;
+          repeats = __builtin_ctz(~bitStream | 0x80000000u) >> 1;
+        }
+        charnum += 3 * (unsigned)repeats;
+        bitStream >>= 2 * repeats; bitCount += 2 * repeats;
+        charnum += bitStream & 3; bitCount += 2;
+        if (charnum >= maxSV1) break;
+        if (ip <= iend - 7 || ip + (bitCount >> 3) <= iend - 4) { ip += bitCount >> 3; bitCount &= 7; }
+        else { bitCount -= (int)(8 * (iend - 4 - ip)); bitCount &= 31; ip = iend - 4; }
+        bitStream = zo_rd32le(ip) >> bitCount;
+      }
+      {
+        const int max = (2 * threshold - 1) - remaining;
+        int count;
+        if ((bitStream & (u32)(threshold - 1)) < (u32)max) { count = (int)(bitStream & (u32)(threshold - 1)); bitCount += nbBits - 1; }
+        else { count = (int)(bitStream & (u32)(2 * threshold - 1)); if (count >= threshold) count -= max; bitCount += nbBits; }
+        count--;
+        if (count >= 0) remaining -= count; else remaining += count;
+        norm[charnum++] = (s16)count;
+        previous0 = !count;
+        if (remaining < threshold) {
+          if (remaining <= 1) break;
+          nbBits = (31 - __builtin_clz((u32)remaining)) + 1;
+          threshold = 1 << (nbBits - 1);
+        }
+        if (charnum >= maxSV1) break;
+        if (ip <= iend - 7 || ip + (bitCount >> 3) <= iend - 4) { ip += bitCount >> 3; bitCount &= 7; }
+        else { bitCount -= (int)(8 * (iend - 4 - ip)); bitCount &= 31; ip = iend - 4; }
+        bitStream = zo_rd32le(ip) >> bitCount;
+      }
+    }
+    if (remaining != 1) return 0;
+    if (charnum > maxSV1) return 0;                              /* maxSymbolValue_tooSmall */
+    if (bitCount > 32) return 0;
+    if (*tPtr > maxAL) return 0;                                 /* the callers' "tableLog > maxLog" (checked behind the read there) */
+    *maxSymPtr = charnum - 1;
+    ip += (bitCount + 7) >> 3;
+    return (size_t)(ip - src);
+  }
 }
 
 /* symbol spreading shared by encode and decode tables (A.3) */

@@ -22,7 +22,7 @@ BUDGET = {
     "zra_dec_chain_kernel": (72, 0),     # lane = frame FSE chains
     "zra_dec_chain_lds_kernel": (112, 0), # the same with its frames' tables and bitstream rings in LDS, ONE wave per CU beside it (no occupancy to protect: 98 with the ring's piece in flight)
     "zra_dec_huf_kernel": (88, 0),       # wave-wide literal decode (two stream readers while a restarted lane looks for its previous path); 8.5 KiB of LDS per workgroup is its occupancy limit
-    "zra_dec_parse_kernel": (96, 176),   # 5 waves per SIMD asked for: 40 spilled VGPRs bought 2.1x on the stage (frames in flight are what it needs)
+    "zra_dec_parse_kernel": (96, 256),   # 5 waves per SIMD asked for: 40 spilled VGPRs bought 2.1x on the stage (frames in flight are what it needs); round 5: 63 with libzstd's FSE_readNCount restated in full
     "zra_dec_exec_kernel": (80, 160),    # 6 waves per SIMD (the LDS-window step and the in-memory one side by side: 37 spilled VGPRs, 13.3 vs 14.3 ms at 5 waves)
     "zra_ra_small_kernel": (256, 0),     # one-launch path for small batches: all stages of a frame in one workgroup, occupancy is not its point
     "zra_entropy_kernel": (96, 512),     # the entropy stage's queue-driven workgroups: one wave of it per SIMD next to five of the match finder's (5 x 80 + 96 <= 512); the scratch is the frame body's call frame (its copy of the argument block) + a few spilled registers      # 5 waves per SIMD asked for: no spills (7 cost 8 spilled VGPRs + 72 B scratch and 2 % of the bench)

@@ -142,47 +142,73 @@ __device__ __forceinline__ u32 wrlane_d(u32 old, u32 val, u32 l) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// FSE table description (A.3) -> norm[] ; single thread. returns bytes consumed, 0 on corruption
+// FSE table description -> normalised counts; bytes consumed, 0 = corruption. One lane.
+// Restates FSE_readNCount of libzstd 1.4.9 (lib/common/entropy_common.c) including its behaviour near the END of its input (oracle/
+// zo_entropy.c: zo_fse_read_ncount has the long version): 32 bits are read at a byte position that never passes end - 4; a read position
+// behind that is clamped there with the bit offset taken modulo 32, so a description that runs past the end re-reads earlier bits instead
+// of failing, and only the position behind the last symbol is checked. Inputs shorter than 8 bytes are read from a zero-padded copy.
+// (Round 5: the reader written from the format description — zeros past the end, every overrun an error — called a damaged frame corrupt
+// that libzstd decodes: soak seed 91417.)
 __device__ __forceinline__ u32 read_ncount(short* norm, u32* maxSymIO, u32* tableLogOut, const u8* src, u32 n, u32 maxAL, const u8* lim) {
   if (n < 1) return 0;
-  u32 bitpos = 0, nbits = n * 8;
-  auto peekf = [&](u32 k) -> u32 {
-    u32 byte = bitpos >> 3;
-    u64 v = byte < n ? ld64_safe(src + byte, src + n < lim ? src + n : lim) : 0;
-    return (u32)((v >> (bitpos & 7)) & ((1u << k) - 1));
+  const bool small = n < 8;
+  u64 padv = 0;
+  if (small) for (u32 i = 0; i < n; i++) padv |= (u64)src[i] << (8 * i);
+  const i32 iend = small ? 8 : (i32)n;                   // positions are byte offsets from src
+  auto rd32 = [&](i32 off) -> u32 { return small ? (u32)(padv >> (8 * off)) : ld32(src + off); };
+  i32 ip = 0;
+  const u32 maxSV1 = *maxSymIO + 1;
+  u32 bitStream = rd32(0);
+  i32 nbBits = (i32)(bitStream & 0xF) + 5, remaining, threshold, bitCount = 4;
+  bool previous0 = false;
+  u32 charnum = 0;
+  if (nbBits > 15) return 0;
+  bitStream >>= 4;
+  const u32 AL = (u32)nbBits;
+  remaining = (1 << nbBits) + 1; threshold = 1 << nbBits; nbBits++;
+  for (u32 s = 0; s < maxSV1; s++) norm[s] = 0;
+  auto advance = [&]() {
+    if (ip <= iend - 7 || ip + (bitCount >> 3) <= iend - 4) { ip += bitCount >> 3; bitCount &= 7; }
+    else { bitCount -= 8 * (iend - 4 - ip); bitCount &= 31; ip = iend - 4; }
+    bitStream = rd32(ip) >> bitCount;
   };
-  u32 AL = peekf(4) + 5; bitpos += 4;
-  if (AL > maxAL) return 0;
-  i32 remaining = (1 << AL) + 1, thr = 1 << AL, nb = (i32)AL + 1;
-  u32 sym = 0, maxSym = *maxSymIO;
-  bool prev0 = false;
-  for (u32 s = 0; s <= maxSym; s++) norm[s] = 0;
-  while (remaining > 1 && sym <= maxSym) {
-    if (prev0) {
-      for (;;) {
-        u32 f = peekf(2); bitpos += 2;
-        sym += f;
-        if (f != 3) break;
-        if (bitpos > nbits) return 0;
+  for (;;) {
+    if (previous0) {
+      i32 repeats = (i32)__builtin_ctz(~bitStream | 0x80000000u) >> 1;
+      while (repeats >= 12) {
+        charnum += 3 * 12;
+        if (ip <= iend - 7) ip += 3;
+        else { bitCount -= 8 * (iend - 7 - ip); bitCount &= 31; ip = iend - 4; }
+        bitStream = rd32(ip) >> bitCount;
+        repeats = (i32)__builtin_ctz(~bitStream | 0x80000000u) >> 1;
       }
-      if (sym > maxSym) return 0;
+      charnum += 3 * (u32)repeats;
+      bitStream >>= 2 * repeats; bitCount += 2 * repeats;
+      charnum += bitStream & 3; bitCount += 2;
+      if (charnum >= maxSV1) break;
+      advance();
     }
-    i32 max = (2 * thr - 1) - remaining, v;
-    u32 low = peekf(nb - 1);
-    if ((i32)low < max) { v = (i32)low; bitpos += nb - 1; }
-    else { v = (i32)peekf(nb); if (v >= thr) v -= max; bitpos += nb; }
-    v--;
-    remaining -= v < 0 ? -v : v;
-    norm[sym++] = (short)v;
-    prev0 = (v == 0);
-    if (remaining < 1) return 0;
-    while (remaining < thr) { nb--; thr >>= 1; }
-    if (bitpos > nbits) return 0;
+    const i32 mx = (2 * threshold - 1) - remaining;
+    i32 count;
+    if ((bitStream & (u32)(threshold - 1)) < (u32)mx) { count = (i32)(bitStream & (u32)(threshold - 1)); bitCount += nbBits - 1; }
+    else { count = (i32)(bitStream & (u32)(2 * threshold - 1)); if (count >= threshold) count -= mx; bitCount += nbBits; }
+    count--;
+    if (count >= 0) remaining -= count; else remaining += count;
+    norm[charnum++] = (short)count;
+    previous0 = count == 0;
+    if (remaining < threshold) {
+      if (remaining <= 1) break;
+      nbBits = (i32)hb32((u32)remaining) + 1;
+      threshold = 1 << (nbBits - 1);
+    }
+    if (charnum >= maxSV1) break;
+    advance();
   }
-  if (remaining != 1 || bitpos > nbits) return 0;
-  *maxSymIO = sym - 1;
+  if (remaining != 1 || charnum > maxSV1 || bitCount > 32 || AL > maxAL) return 0;
+  *maxSymIO = charnum - 1;
   *tableLogOut = AL;
-  return (bitpos + 7) >> 3;
+  const u32 h = (u32)ip + (u32)((bitCount + 7) >> 3);
+  return (small && h > n) ? 0u : h;
 }
 
 // wave-wide inclusive scans on the DPP network (no LDS traffic): rows of 16 by row_shr 1/2/4/8, then the row totals by row_bcast 15 / 31
@@ -622,8 +648,13 @@ __device__ __forceinline__ void frame_finish(const ZraDecodeArgs& a, u32 j, cons
       const u32 p0 = a.pieceBase[j], p1 = a.pieceBase[j + 1];
       for (u32 p = p0; p < p1; p++) {
         const ZraRaPiece q = a.pieces[p];
-        if ((u64)q.srcOff + q.len > produced) continue;
-        copy_bytes(a.raOut + q.dstOff, a.out + a.outOff[j] + q.srcOff, q.len, lane, nthreads);
+        // A frame that regenerated fewer bytes than a slice asks for, without an error (only a damaged frame can): what there is, then
+        // zeros — deterministic, whatever the caller's buffer held (round 5: such a slice used to be left out). What the REFERENCE
+        // returns there is its reused frame buffer's earlier content (zra.cpp:272-295: the first frame's bytes, or what libzstd's wide
+        // copies scribbled) — not something a batch of independent queries can reproduce; the host-pointer call does not come here.
+        const u32 have = q.srcOff >= produced ? 0u : min(q.len, produced - q.srcOff);
+        if (have) copy_bytes(a.raOut + q.dstOff, a.out + a.outOff[j] + q.srcOff, have, lane, nthreads);
+        if (have < q.len) fill_bytes(a.raOut + q.dstOff + have, 0, q.len - have, lane, nthreads);
       }
     }
   }
