@@ -985,3 +985,22 @@ print("bad", bad)
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, ZRA_MF_LS="0"), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout[-800:], r.stderr[-1500:])
     assert r.stdout.strip().endswith("bad 0"), r.stdout[-800:]
+
+
+@pytest.mark.gpu
+def test_table_description_that_runs_past_its_input(zra):
+    """Round 5 (soak seed 91417, tests/test_oracle.py has the CPU half): libzstd's FSE_readNCount re-reads earlier bits when a table
+    description runs past the end of its input, accepts the table and fails the frame's checksum later; the parse kernel's reader
+    (read_ncount) does the same now — the query's status is checksum_wrong (22), not corruption_detected (20), in both decode paths."""
+    import subprocess
+    arc = None
+    for case, a in C.mutated_archives(20000 + 91417, 50, O.zra_compress):
+        if case == 1:
+            arc = a
+    assert arc is not None
+    with pytest.raises(zra.ZraError) as e:
+        zra.DecompressRA(arc, 541, 1)
+    assert (e.value.zra, e.value.zstd) == O.zra_ra(arc, 541, 1, "zl" if O.have_libzstd() else "zo")[0] == (1, 22)
+    code = "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import zra_amd as Z\ntry:\n    Z.DecompressRA(bytes.fromhex(%r), 541, 1); print('none')\nexcept Z.ZraError as e: print(e.zra, e.zstd)" % (HERE, os.path.dirname(HERE), arc.hex())
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, ZRA_DEC_SMALL_MAX="0"), capture_output=True, text=True, timeout=300)
+    assert r.stdout.strip().endswith("1 22"), (r.stdout[-300:], r.stderr[-500:])
