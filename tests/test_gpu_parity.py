@@ -896,10 +896,11 @@ def test_foreign_frame_size_does_not_cost_a_pass_per_frame(zra):
 @pytest.mark.parametrize("env", [{"ZRA_MF_FLAGS": "0", "ZRA_MF_LS": "0"}, {"ZRA_MF_WAVES": "18", "ZRA_MF_LS": "0", "ZRA_ENT_WGS": "1", "ZRA_ENC_RING": "2"},
                                  {"ZRA_DEC_PIPE": "4", "ZRA_DEC_PIPE_MIN": "1", "ZRA_DEC_SMALL_MAX": "0"}, {"ZRA_MF_LS": "0"}, {"ZRA_MF_LS_MAX": "1000000"}, {"ZRA_ENC_POISON": "1"},
                                  {"ZRA_PIPE": "0"}, {"ZRA_PIPE": "2"}, {"ZRA_PIPE": "2", "ZRA_ENC_RING": "2", "ZRA_ENT_WGS": "2"},
-                                 {"ZRA_DEC_SMALL_MAX": "0", "ZRA_DEC_CHAIN_LDS_MIN": "1", "ZRA_DEC_CHAIN_LDS": "2"}],
+                                 {"ZRA_DEC_SMALL_MAX": "0", "ZRA_DEC_CHAIN_LDS_MIN": "1", "ZRA_DEC_CHAIN_LDS": "2"},
+                                 {"ZRA_MF_LS": "0", "ZRA_MF_WAVES": "1"}, {"ZRA_MF_LS": "0", "ZRA_MF_EPOCH": "0"}],
                          ids=["dfast-without-bucket-flags", "dfast-other-pipeline-geometry", "decode-stage-pipeline", "dfast-small-calls-from-memory", "dfast-all-calls-from-lds",
                               "hash-chain-over-poisoned-scratch", "dfast-stages-in-sequence", "dfast-resident-entropy-stage", "dfast-resident-entropy-small-ring",
-                              "decode-lds-table-chain-kernel-alone"])
+                              "decode-lds-table-chain-kernel-alone", "dfast-one-wave-per-cu-many-epochs", "dfast-tables-cleared-per-frame"])
 def test_opt_in_kernels_are_bit_exact_too(env):
     """The paths of the library that a default call of the test sizes does not take give the same bytes as the ones it does: the dfast table
     kernel without its bucket flags (round 5: the flags are on by default for calls beyond the LDS-source kernel's size), the persistent
@@ -1004,3 +1005,46 @@ def test_table_description_that_runs_past_its_input(zra):
     code = "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import zra_amd as Z\ntry:\n    Z.DecompressRA(bytes.fromhex(%r), 541, 1); print('none')\nexcept Z.ZraError as e: print(e.zra, e.zstd)" % (HERE, os.path.dirname(HERE), arc.hex())
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, ZRA_DEC_SMALL_MAX="0"), capture_output=True, text=True, timeout=300)
     assert r.stdout.strip().endswith("1 22"), (r.stdout[-300:], r.stderr[-500:])
+
+
+@pytest.mark.gpu
+def test_dfast_epoch_cells_over_identical_and_similar_frames():
+    """Round 6: the dfast table kernel's waves no longer clear their 384 KiB table slot per frame — a cell carries the epoch of the frame
+    that wrote it (4 bits of its tag field), a cell of another epoch reads as empty, and the slot is cleared every 16th frame. The worst
+    case for a stale cell is a wave that parses the SAME bytes again: every stale cell then has the hash bits a lookup asks for and a
+    position whose bytes in the new frame match. One resident wave per CU (ZRA_MF_WAVES=1) so that every wave takes dozens of frames —
+    through more than one wrap of the epoch —, identical frames, frames that differ in a few bytes, a ragged last frame with other cparams
+    in the middle of a wave's run, levels 3 and 4; archives byte-identical to the oracle's (reference call site zra.cpp:219)."""
+    import subprocess
+    code = r"""
+import sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np
+import zra_amd as Z, oracle_lib as O, corpus as C
+bad = 0
+base = C.gen_loglike(1 << 16) + C.gen_E(1 << 16) + C.gen_struct(1 << 16)
+for level in (3, 4):
+    for fs, nfr, tail in ((4096, 12000, 0), (16384, 6000, 777), (65536, 1500, 40000), (2048, 20000, 5)):
+        fr = bytearray(base[:fs])
+        parts = []
+        rng = np.random.default_rng(fs + level)
+        for i in range(nfr):
+            if i %% 3 == 1:                                # a few bytes changed: most stale cells still "look right"
+                g = bytearray(fr)
+                for k in rng.integers(0, fs, 6): g[int(k)] ^= 0x55
+                parts.append(bytes(g))
+            elif i %% 7 == 5: parts.append(base[fs * (i %% 5): fs * (i %% 5) + fs].ljust(fs, b"x"))
+            else: parts.append(bytes(fr))
+        d = b"".join(parts) + base[:tail]
+        st, ref = O.zra_compress(d, level, fs, True)
+        assert st == (0, 0)
+        got = Z.CompressBuffer(d, level, fs, True)
+        if got != ref:
+            bad += 1; print("MISMATCH", level, fs, nfr, tail)
+        elif Z.DecompressBuffer(got) != d:
+            bad += 1; print("ROUNDTRIP", level, fs, nfr, tail)
+print("bad", bad)
+""" % (HERE, os.path.dirname(HERE))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, ZRA_MF_LS="0", ZRA_MF_WAVES="1"), capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, (r.stdout[-800:], r.stderr[-1500:])
+    assert r.stdout.strip().endswith("bad 0"), r.stdout[-800:]

@@ -265,25 +265,27 @@ static ZraStatus comm_stitch(ZraHipComm* c, ZraHipShard* sh, Status st, const st
                              uint32_t frameSize, size_t headerSize) {
   // sizes of everybody's frames: ranks hold floor/ceil(F / W) frames, padded to the largest share
   const size_t maxLocal = (size_t)((F + c->world - 1) / c->world) + 1;
-  std::vector<uint64_t> send(maxLocal + 2, 0), all((maxLocal + 2) * (size_t)c->world);
-  send[0] = (uint64_t)(uint32_t)st.zra | ((uint64_t)(uint32_t)st.zstd << 32); send[1] = mySizes.size();
+  // Every allocation of the stitch happens HERE, before the first collective, and its outcome travels with the rank's status: a rank that
+  // runs out of memory must not leave the others inside an exchange it never joins (allocation failure is per rank, not per call).
+  std::vector<uint64_t> send, all, sizes;
+  try {
+    send.assign(maxLocal + 2, 0); all.resize((maxLocal + 2) * (size_t)c->world); sizes.reserve(F);
+    if (sh) { sh->bodyBaseOf.assign((size_t)c->world + 1, 0); sh->header.resize(headerSize); }
+  } catch (const std::exception&) { if (!st.zra) st = zra_eng::zerr(64); }
+  if (!sh && !st.zra) st = zra_eng::zerr(64);
+  { const ZraStatus pre = c->agree(st); if (pre.zra) return pre; }
+  send[0] = 0; send[1] = mySizes.size();
   std::copy(mySizes.begin(), mySizes.end(), send.begin() + 2);
   if (!c->allgather(send.data(), all.data(), send.size() * 8)) { return mk(ZStdError, 1); }
-  for (int r = 0; r < c->world; r++) {
-    const uint64_t w = all[(maxLocal + 2) * (size_t)r];
-    if ((uint32_t)w) { return mk((int)(uint32_t)w, (int)(int32_t)(w >> 32)); }
-  }
-  std::vector<uint64_t> sizes; sizes.reserve(F);
-  sh->bodyBaseOf.assign((size_t)c->world + 1, 0);
   uint64_t run = 0;
   for (int r = 0; r < c->world; r++) {
     const uint64_t* p = &all[(maxLocal + 2) * (size_t)r];
     sh->bodyBaseOf[r] = run;
+    if (p[1] > maxLocal || sizes.size() + p[1] > F) { return mk(ZStdError, 1); }      // (nothing below grows a vector)
     for (uint64_t i = 0; i < p[1]; i++) { sizes.push_back(p[2 + i]); run += p[2 + i]; }
   }
   sh->bodyBaseOf[c->world] = run;
   if (sizes.size() != F) { return mk(ZStdError, 1); }
-  sh->header.resize(headerSize);
   size_t hs = 0;
   ZraStatus zs = ZraHipStitchHeader(sizes.data(), F, totalBytes, frameSize, sh->header.data(), &hs);     // same on every rank
   if (zs.zra) { return zs; }
@@ -349,20 +351,17 @@ ZraStatus ZraHipCommStitchSizes(ZraHipComm* c, const uint64_t* hLocalSizes, size
   ZraHipShard* sh = nullptr;
   Status st = zra_eng::ok();
   std::vector<uint64_t> mySizes;
-  size_t headerSize = 0;
+  const size_t headerSize = zra_fmt::kFixedSize + (size_t)(F + 1) * zra_fmt::kEntrySize;
+  // (this rank's own allocations; a failure becomes its status, which comm_stitch agrees on before any exchange — the stitch itself is
+  //  collective and stays outside the try: a handler that starts another collective after some of the stitch's ran would mis-pair the ranks)
   try {
     sh = new ZraHipShard();
     sh->device = c->eng ? c->eng->device() : 0; sh->nFrames = F; sh->lo = lo; sh->hi = hi; sh->total = totalBytes; sh->frameSize = frameSize;
     if (nLocal != (size_t)(hi - lo) || (nLocal && !hLocalSizes)) st = Status{zra_eng::kFrameSizeMismatch, 0};
     else mySizes.assign(hLocalSizes, hLocalSizes + nLocal);
-    headerSize = zra_fmt::kFixedSize + (size_t)(F + 1) * zra_fmt::kEntrySize;
-    ZraStatus zs = comm_stitch(c, sh, st, mySizes, F, totalBytes, frameSize, headerSize);
-    if (zs.zra) { delete sh; return zs; }
-  } catch (const std::exception&) {
-    // (memory for the size table / header: every rank sizes them from the same F, so every rank lands here or none does)
-    delete sh;
-    return c->agree(zra_eng::zerr(64));
-  }
+  } catch (const std::exception&) { st = zra_eng::zerr(64); mySizes.clear(); }
+  { ZraStatus zs = comm_stitch(c, sh, st, mySizes, F, totalBytes, frameSize, headerSize);
+    if (zs.zra) { delete sh; return zs; } }
   for (uint64_t v : mySizes) sh->bodyBytes += v;
   *shardOut = sh;
   return mk(Success);

@@ -135,6 +135,7 @@ Status Engine::compress_frames(const uint8_t* dIn, size_t inSize, uint8_t* dBody
 Status Engine::compress_impl(const uint8_t* dIn, size_t inSize, uint8_t* dBody, uint64_t bodyBase0, uint8_t* dEntries, uint64_t* dSizes,
                              size_t* bodySize, int level, uint32_t frameSize, bool checksum) {
   encCounters_ = nullptr; encCountersBytes_ = 0;
+  mfTele_.clear(); mfTeleDev_ = nullptr;               // (a call that takes another path, or fails, leaves no telemetry of an earlier launch behind)
   Status s = compress_impl_body(dIn, inSize, dBody, bodyBase0, dEntries, dSizes, bodySize, level, frameSize, checksum);
   if (s.zra) drain_after_error();
   return s;
@@ -180,7 +181,7 @@ Status Engine::compress_impl_body(const uint8_t* dIn, size_t inSize, uint8_t* dB
   };
   const uint64_t tableWords = (std::max(slotWords(full), slotWords(tail)) + 3) & ~3ull;   // 16-byte slots
   const uint32_t maxBlock = std::max(full.blockSize, tail.blockSize);
-  const uint64_t seqStride = maxBlock / 4 + 16;
+  const uint64_t seqStride = (maxBlock / 4 + 16 + 1) & ~1ull;   // (even: the entropy stage's u16 chain output sits behind 3 * seqStride code bytes)
   const uint64_t litStride = ((uint64_t)maxBlock + 64 + 15) & ~15ull;
   // blocks per frame, per size class (a short last frame has its own, smaller, block size but is still one block)
   const uint64_t fullFrame = std::min<uint64_t>(frameSize, inSize);
@@ -488,7 +489,7 @@ Status Engine::compress_persistent(const uint8_t* dIn, size_t inSize, uint8_t* d
   uint32_t* dPerSuper = dCnt + 4;                // 8 words per super-batch
   uint32_t* dPerSub = dPerSuper + 8 * nSuper;    // 4 x subsPerSuper words per super-batch
   HIPCHK(hipMemsetAsync(encScan_.as<uint8_t>(), 0, cntBytes, stream_));
-  encCounters_ = dCnt; encCountersBytes_ = 4 * (4 + 8 * (size_t)nSuper);   // (an error exit fills them with 0x7F: the abort word is set, the queues are past their ends, every wait of the two kernels and of stream B ends)
+  encCounters_ = dCnt; encCountersBytes_ = 4 * (4 + 8 * (size_t)nSuper + 4 * (size_t)(nSuper * subsPerSuper));   // (... the per-sub-batch words too: stream B waits on the finder's mfDone counts)   // (an error exit fills them with 0x7F: the abort word is set, the queues are past their ends, every wait of the two kernels and of stream B ends)
 
   ZraEncArgs base{};
   base.in = dIn; base.inSize = inSize; base.frameSize = frameSize; base.checksum = checksum ? 1 : 0;
@@ -543,6 +544,13 @@ Status Engine::compress_persistent(const uint8_t* dIn, size_t inSize, uint8_t* d
     // 1,280 bytes. ZRA_MF_SPAN=<bytes> (multiple of 64, <= 1024; 0: none)
     static const int spEnv = std::getenv("ZRA_MF_SPAN") ? std::atoi(std::getenv("ZRA_MF_SPAN")) : 768;
     fw.spanBytes = (uint32_t)std::min(1024, std::max(0, spEnv)) & ~63u;
+    // (advisor, round 5: the parse needs 15 bytes of alignment slack + a window's 64 + 7 bytes in the span; a shorter one could never be filled)
+    if (fw.spanBytes < 128) fw.spanBytes = 0;
+    // round 6: epoch bits in the cells' tag field — a wave clears its 384 KiB table slot once per 2^epochBits frames instead of per frame.
+    // The tag keeps >= 10 hash bits (position + 1 takes 16-17 bits of a cell at 64-128 KiB frames). ZRA_MF_EPOCH=<bits> (0: clear per frame)
+    static const int epEnv = std::getenv("ZRA_MF_EPOCH") ? std::atoi(std::getenv("ZRA_MF_EPOCH")) : 4;
+    const uint32_t ibMax = 32u - (uint32_t)__builtin_clz((uint32_t)std::max<uint64_t>(2, std::min<uint64_t>(frameSize, inSize)) - 1u);
+    fw.epochBits = (uint32_t)std::max(0, std::min(epEnv, (int)(32u - ibMax) - 10));   // (the kernel holds ZRA_DF_EPOCH_BITS = 4 of them)
   }
   const size_t spanLds = fw.spanBytes ? fw.spanBytes + 16 + (fw.spanBytes / 64 + 1) * 16 : 0;
 
@@ -666,15 +674,28 @@ Status Engine::compress_persistent(const uint8_t* dIn, size_t inSize, uint8_t* d
   for (auto& sp : entSpans) { float m = 0; if (hipEventElapsedTime(&m, sp.first, sp.second) == hipSuccess) { kstats_[2] += m; kstats_[3] += 1; } }
   lastKernelMs_ = kernelMs;
   // (the head — sums, per-XCD and per-CU counts of the match finder — then the entropy stage's block; the per-wave records stay on the device)
-  mfTele_.resize(ZRA_TELE_HEAD + 8 + ZRA_TELE_CUKEYS);
-  HIPCHK(hipMemcpy(mfTele_.data(), base.mfTele, 8 * (size_t)ZRA_TELE_HEAD, hipMemcpyDeviceToHost));
-  HIPCHK(hipMemcpy(mfTele_.data() + ZRA_TELE_HEAD, base.mfTele + ZRA_TELE_ENT, 8 * (size_t)(8 + ZRA_TELE_CUKEYS), hipMemcpyDeviceToHost));
+  mfTeleDev_ = base.mfTele;                            // fetched by launch_telemetry() if anybody asks
   if (traceOn) {                                      // bring-up: timeline relative to the first match-finder launch
     for (auto& sp : mfSpans) { float a0 = 0, a1 = 0; (void)hipEventElapsedTime(&a0, mfSpans[0].first, sp.first); (void)hipEventElapsedTime(&a1, mfSpans[0].first, sp.second); std::fprintf(stderr, "mf  %8.2f .. %8.2f ms\n", a0, a1); }
     for (auto& sp : entSpans) { float a0 = 0, a1 = 0; (void)hipEventElapsedTime(&a0, mfSpans[0].first, sp.first); (void)hipEventElapsedTime(&a1, mfSpans[0].first, sp.second); std::fprintf(stderr, "ent %8.2f .. %8.2f ms\n", a0, a1); }
   }
   *bodySize = total;
   return ok();
+}
+
+size_t Engine::launch_telemetry(uint64_t* out, size_t cap) {
+  if (mfTeleDev_) {
+    // (the head — sums, per-XCD and per-CU counts of the match finder — then the entropy stage's block; the per-wave records stay on the device)
+    (void)hipSetDevice(device_);
+    mfTele_.resize(ZRA_TELE_HEAD + 8 + ZRA_TELE_CUKEYS);
+    const bool okT = hipMemcpy(mfTele_.data(), mfTeleDev_, 8 * (size_t)ZRA_TELE_HEAD, hipMemcpyDeviceToHost) == hipSuccess &&
+                     hipMemcpy(mfTele_.data() + ZRA_TELE_HEAD, mfTeleDev_ + ZRA_TELE_ENT, 8 * (size_t)(8 + ZRA_TELE_CUKEYS), hipMemcpyDeviceToHost) == hipSuccess;
+    if (!okT) { (void)hipGetLastError(); mfTele_.clear(); }
+    mfTeleDev_ = nullptr;
+  }
+  const size_t n = mfTele_.size() < cap ? mfTele_.size() : cap;
+  for (size_t i = 0; i < n; i++) out[i] = mfTele_[i];
+  return n;
 }
 
 uint32_t Engine::debug_read_seqs(uint32_t frame, uint64_t* out, uint32_t cap, uint32_t meta[3]) {

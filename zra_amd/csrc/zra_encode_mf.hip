@@ -405,18 +405,30 @@ __device__ u32 mf_lazy(HC& H, const u8* src, u32 bs, u32 be, u32* rep, Emit& E, 
 //   * duplicate-bucket detection uses byte-wide LDS slots (2048 per table, no epochs, no atomics);
 //   * tags use all bits above the index (ib = bits needed for position+1), so every dfast frame size is tagged.
 
-template <u32 MLS>
+// EB (round 6): the lowest EB bits of a cell's tag field hold the EPOCH of the frame that wrote the cell (0: none), so that the persistent
+// kernel's waves clear their table slot once per 2^EB frames instead of once per frame (384 KiB of full-line writes per 64 KiB frame at
+// level 3). A cell of another epoch can never equal a lane's tag: it reads as empty. (The epoch needs bits of its own: folded into the hash
+// bits — XOR — a stale cell could pass the tag test with OTHER bytes behind it, and the bytes that are then checked are the current frame's.)
+template <u32 MLS, u32 EB = 0>
 struct DfHash {
   u32 shL, shS, shT, ib, tagMask;
-  __device__ __forceinline__ void init(u32 hlog, u32 clog, u32 ibits) {
+  u32 epoch;
+  __device__ __forceinline__ void init(u32 hlog, u32 clog, u32 ibits, u32 ep = 0) {
     ib = ibits; tagMask = ~((1u << ib) - 1u); shL = 64 - hlog; shS = (MLS == 4 ? 32 : 64) - clog; shT = shL - (32 - ib);
+    epoch = ep;
   }
   // bucket indices and tags (tag = the hash bits just below the bucket bits, moved above the index bits)
   __device__ __forceinline__ void both(u64 v, u32& bL, u32& bS, u32& tL, u32& tS) const {
     const u64 pl = v * 0xCF1BBCDCB7A56463ULL;
-    bL = (u32)(pl >> shL); tL = (u32)(pl >> shT) << ib;
     const u32 p4 = (u32)v * 2654435761u;
-    tS = p4 & tagMask;
+    bL = (u32)(pl >> shL);
+    if (EB == 0) { tL = (u32)(pl >> shT) << ib; tS = p4 & tagMask; }
+    else {
+      // (one scalar operand per instruction: the epoch goes in below the shift)
+      constexpr u32 keep = ~((1u << EB) - 1u);
+      tL = (((u32)(pl >> shT) & keep) | epoch) << ib;
+      tS = (((p4 >> ib) & keep) | epoch) << ib;
+    }
     if (MLS == 5) bS = (u32)(((v << 24) * 889523592379ULL) >> shS);
     else if (MLS == 6) bS = (u32)(((v << 16) * 227718039650203ULL) >> shS);
     else if (MLS == 7) bS = (u32)(((v << 8) * 58295818150454627ULL) >> shS);
@@ -452,14 +464,15 @@ __device__ __forceinline__ u32 df_flags_at(const u8* flg, u32 p) {
   const u32 b = p & 7u;
   return 0x05u | (((w[0] >> b) & 1u) << 1) | (((w[8] >> b) & 1u) << 3);
 }
+#define ZRA_DF_EPOCH_BITS 4u      /* epoch bits in the flag kernel's cells: a wave's table slot is cleared every 16th frame */
 template <u32 MLS, bool FLAGS>
 __device__ u32 mf_dfast_lean(const ZraEncParams& P, u32* HL, u32* HS, const u8* src, u32 bs, u32 be, u32* rep, u64* seqs, u32* nOut,
-                             const LeanLds& W, int lane, u32 ib, const u8* flgIn) {
+                             const LeanLds& W, int lane, u32 ib, const u8* flgIn, u32 epoch = 0) {
   const u8* const flg = FLAGS ? flgIn : nullptr;       // (the kernel without flags carries none of their code or registers)
   // flg (df_later_flags' masks, read through df_flags_at; nullptr: none): per position bit 1 / bit 3 = its long / short bucket has a later
   // position of the frame. An insertion without one is never looked up: the table write is skipped — half of the table's write requests.
   // (Bits 0 / 2, "has an earlier position", are always set: a lookup's table read is decided by the LDS filter alone.)
-  DfHash<MLS> H; H.init(P.hashLog, P.chainLog, ib);
+  DfHash<MLS, FLAGS ? ZRA_DF_EPOCH_BITS : 0u> H; H.init(P.hashLog, P.chainLog, ib, FLAGS ? rfl(epoch) : 0u);
   const u32 idxMask = ~H.tagMask;
   // block-level scalars arrive in VGPRs (vector loads of the frame state): pin them to SGPRs once so that the whole
   // parse state stays on the scalar unit instead of being dragged onto the VALU
@@ -1103,7 +1116,7 @@ struct MfFrame {
 };
 // returns false when this workgroup has nothing to parse (block beyond the frame, or a block too small to compress)
 // hcwOnly: the caller is the wave-cooperative hash-chain finder — its chain slots need no clearing (below)
-__device__ __forceinline__ bool mf_frame_setup(const ZraEncArgs& a, u32 block, int lane, MfFrame& F, u32 f, u32 tableSlot, bool hcwOnly = false) {
+__device__ __forceinline__ bool mf_frame_setup(const ZraEncArgs& a, u32 block, int lane, MfFrame& F, u32 f, u32 tableSlot, bool hcwOnly = false, bool keepTables = false) {
   const u64 fstart = (u64)(a.firstFrame + f) * a.frameSize;
   const u64 remaining = a.inSize - fstart;
   F.fsize = (u32)(remaining < a.frameSize ? remaining : a.frameSize);
@@ -1129,6 +1142,9 @@ __device__ __forceinline__ bool mf_frame_setup(const ZraEncArgs& a, u32 block, i
     if (!hcwOnly) words += (size_t)1 << F.P->chainLog;
     if (F.P->strategy >= 7)           // optimal parsers: the 3-byte hash table and the statistics of the price model behind the tree
       words += (F.P->minMatch == 3 ? (size_t)1 << min(17u, F.P->windowLog) : 0) + 512;
+    // (keepTables, round 6: the dfast kernel's cells carry the epoch of the frame that wrote them — what an earlier frame of this wave left
+    //  in the slot reads as empty, nothing to clear)
+    if (keepTables) words = 0;
     uint4* t4 = (uint4*)F.hashT;
     for (size_t i = lane; i < words / 4; i += 64) t4[i] = make_uint4(0, 0, 0, 0);
     for (size_t i = (words / 4) * 4 + lane; i < words; i += 64) F.hashT[i] = 0;
@@ -1343,6 +1359,10 @@ __device__ __forceinline__ void mf_dfast_body(const ZraEncArgs& a, u32 block, u3
     tl[0] = tc0; tl[1] = tr0; tl[2] = xcc; tl[3] = 0;
   }
   if (persistent && a.mfStarted && lane == 0) atomicAdd(a.mfStarted, 1u);
+  // round 6: epoch-tagged cells (DfHash). The wave's table slot is cleared before the first frame it takes and then once per 2^epochBits
+  // full-size frames; a short last frame (other cparams: another cell layout) clears before and forces a clear behind it.
+  const u32 epochBits = (FLAGS && g && persistent) ? min(g->epochBits, ZRA_DF_EPOCH_BITS) : 0u;   // (host knob: fewer than the cell holds, 0 = clear per frame)
+  u32 epochCtr = 0;                                    // full-size frames parsed since the slot's last clear
   for (;;) {
     u32 f = only == 0xFFFFFFFFu ? blockIdx.x : only;   // `only`: a single-workgroup launch for that frame on table slot `onlySlot`
     if (persistent) {
@@ -1379,7 +1399,16 @@ __device__ __forceinline__ void mf_dfast_body(const ZraEncArgs& a, u32 block, u3
       if (Pf.strategy != 2) mine = false;
     }
     MfFrame F;
-    if (mine && mf_frame_setup(a, block, lane, F, f, persistent ? blockIdx.x : only == 0xFFFFFFFFu ? f : onlySlot)) {
+    bool keepTables = false; u32 epoch = 0;
+    if (epochBits && mine) {
+      const u64 fstart = (u64)(a.firstFrame + f) * a.frameSize;
+      const bool fullFrame = a.inSize - fstart >= a.frameSize;
+      if (!fullFrame) epochCtr = 0;                   // (cleared now; epoch 0)
+      epoch = epochCtr & ((1u << epochBits) - 1u);
+      keepTables = epoch != 0;
+      epochCtr = fullFrame ? epochCtr + 1 : 0;
+    }
+    if (mine && mf_frame_setup(a, block, lane, F, f, persistent ? blockIdx.x : only == 0xFFFFFFFFu ? f : onlySlot, false, keepTables)) {
 #ifdef ZRA_MF_PROFILE
       __builtin_amdgcn_s_waitcnt(0);
       if (lane == 0) atomicAdd(&zra_mf_prof[20], __builtin_amdgcn_s_memtime() - kt0_);
@@ -1417,10 +1446,10 @@ __device__ __forceinline__ void mf_dfast_body(const ZraEncArgs& a, u32 block, u3
         srcP = ls;
       }
       switch (F.P->minMatch) {
-        case 5: lastLL = mf_dfast_lean<5, FLAGS>(*F.P, F.hashT, F.chainT, srcP, F.bs, F.be, rep, F.seqs, &nseq, W, lane, ib, flg); break;
-        case 6: lastLL = mf_dfast_lean<6, FLAGS>(*F.P, F.hashT, F.chainT, srcP, F.bs, F.be, rep, F.seqs, &nseq, W, lane, ib, flg); break;
-        case 7: lastLL = mf_dfast_lean<7, FLAGS>(*F.P, F.hashT, F.chainT, srcP, F.bs, F.be, rep, F.seqs, &nseq, W, lane, ib, flg); break;
-        default: lastLL = mf_dfast_lean<4, FLAGS>(*F.P, F.hashT, F.chainT, srcP, F.bs, F.be, rep, F.seqs, &nseq, W, lane, ib, flg); break;
+        case 5: lastLL = mf_dfast_lean<5, FLAGS>(*F.P, F.hashT, F.chainT, srcP, F.bs, F.be, rep, F.seqs, &nseq, W, lane, ib, flg, epoch); break;
+        case 6: lastLL = mf_dfast_lean<6, FLAGS>(*F.P, F.hashT, F.chainT, srcP, F.bs, F.be, rep, F.seqs, &nseq, W, lane, ib, flg, epoch); break;
+        case 7: lastLL = mf_dfast_lean<7, FLAGS>(*F.P, F.hashT, F.chainT, srcP, F.bs, F.be, rep, F.seqs, &nseq, W, lane, ib, flg, epoch); break;
+        default: lastLL = mf_dfast_lean<4, FLAGS>(*F.P, F.hashT, F.chainT, srcP, F.bs, F.be, rep, F.seqs, &nseq, W, lane, ib, flg, epoch); break;
       }
       if (lane == 0) {
         F.bo->nbSeq = nseq; F.bo->lastLL = lastLL; F.bo->skip = 0;

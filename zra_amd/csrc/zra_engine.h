@@ -51,7 +51,8 @@ class Engine {
   Status release_scratch();
   double last_kernel_ms() const { return lastKernelMs_; }
   // launch telemetry of the last persistent dfast compress (ZraEncArgs::mfTele); empty when the call took another path
-  size_t launch_telemetry(uint64_t* out, size_t cap) const { const size_t n = mfTele_.size() < cap ? mfTele_.size() : cap; for (size_t i = 0; i < n; i++) out[i] = mfTele_[i]; return n; }
+  // (fetched from the device here, on demand: the two blocking copies used to be paid by every persistent call, the small ones included)
+  size_t launch_telemetry(uint64_t* out, size_t cap);
   // after a whole-archive decode_host(): bytes regenerated when frames had to be packed one after the other (a frame regenerated
   // another size than its slot), ~0 when every frame filled exactly its slot
   uint64_t last_produced_total() const { return lastProducedTotal_; }
@@ -128,6 +129,7 @@ class Engine {
   hipEvent_t ev0_ = nullptr, ev1_ = nullptr, evWait_ = nullptr;
   double lastKernelMs_ = 0;
   std::vector<uint64_t> mfTele_;
+  const uint64_t* mfTeleDev_ = nullptr;   // the last persistent launch's telemetry block on the device (inside encScan_), not fetched yet; nullptr: none / fetched
   double kstats_[6] = {0, 0, 0, 0, 0, 0};
   double dstats_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   std::vector<hipEvent_t> stageEv_; size_t stageEvNext_ = 0;

@@ -227,6 +227,7 @@ struct ZraEncArgs {
 struct ZraFlagArgs {
   uint8_t* flags; uint64_t flagStride; uint32_t ldsWords;
   uint32_t spanBytes;      // source span of the parse in LDS behind the filter (mf_dfast_lean; 0: none): spanBytes + 16 + (spanBytes / 64 + 1) * 16 bytes
+  uint32_t epochBits;      // round 6: bits of a cell's tag field that hold the writing frame's epoch (0: none, the slot is cleared per frame); a wave clears its slot once per 2^epochBits frames
 };
 
 
