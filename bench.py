@@ -267,6 +267,16 @@ def kernel_source_sha():
     return h.hexdigest()[:16]
 
 
+def kernel_resources(names):
+    """VGPRs / scratch / spill counts of the named kernels as the compiler reported them for THIS build (zra_amd/build/kernel_resources.json,
+    written by zra_amd/build.py from -Rpass-analysis=kernel-resource-usage): in the line so that a reader sees them without a rebuild."""
+    try:
+        res = json.load(open(os.path.join(HERE, "zra_amd", "build", "kernel_resources.json")))
+        return {k: {f: res[k].get(f) for f in ("vgprs", "sgpr_spill", "vgpr_spill", "scratch_bytes", "lds_bytes", "waves_per_simd")} for k in names if k in res}
+    except Exception:
+        return None
+
+
 def under_profiler():
     """rocprofv3 preloads a library that initialises the GPU in every process of the tree: programs started from here (rocm-smi, the
     CLI counterpart) would then be 'an exec after the GPU was initialised', which the GPU pool refuses. The probes that start programs
@@ -528,6 +538,14 @@ def main():
         comp_ms.append((t1 - t0) * 1e3)
         ra_ms.append((t2 - t1) * 1e3)
 
+    # The timed RA leg decodes every touched frame IN FULL and verifies its XXH64 (ZRA_HIP_OPT_RA_WHOLE_FRAMES), which is what the reference's
+    # DecompressRA does (zra.cpp:280-293) and what cpu_baseline times; the library's default for batches — stop a frame at the last byte a
+    # query needs — is reported beside it as ra_early_stop, outside the timed region. (ZRA_BENCH_RA_EARLY=1: round 5's headline, for A/Bs.)
+    lib_opts = Z.load()
+    opts_before = lib_opts.ZraHipGetOptions()
+    ra_whole_timed = os.environ.get("ZRA_BENCH_RA_EARLY") != "1"
+    if ra_whole_timed:
+        lib_opts.ZraHipSetOptions(opts_before | 8)
     for _ in range(args.warmup):
         step()
     comp_ms.clear(); ra_ms.clear(); mf_ms.clear(); dec_stats.clear(); dec_stage.clear()
@@ -579,24 +597,26 @@ def main():
             ra_classes["%d_KiB" % (qsz >> 10)] = {"queries": nq2, "us_per_query": round(dq / nq2 * 1e6, 3), "gibs_returned": round(nq2 * qsz / GiB / dq, 3)}
             del d2
 
-    # like-for-like with the CPU leg (which decodes every touched frame in full and verifies its checksum, as zra.cpp:279-295 does):
-    # the same 1 M queries with ZRA_HIP_OPT_RA_WHOLE_FRAMES, outside the timed region
-    ra_whole = None
+    # the other RA mode, outside the timed region: the same 1 M queries with the option flipped (whole frames when the timed leg stopped
+    # early, early stop when the timed leg — the default since round 6 — decoded whole frames)
+    ra_other = None
     if world == 1 and not args.timed_only:
-        lib = Z.load()
-        old_opts = lib.ZraHipGetOptions()
-        lib.ZraHipSetOptions(old_opts | 8)
+        lib_opts.ZraHipSetOptions((opts_before & ~8) if ra_whole_timed else (opts_before | 8))
         try:
             eng.decompress_ra_batch(d_arc.data_ptr(), arc_size, d_ra.data_ptr(), offs, sizes, oofs)     # warm
             torch.cuda.synchronize(); tq = time.perf_counter()
             eng.decompress_ra_batch(d_arc.data_ptr(), arc_size, d_ra.data_ptr(), offs, sizes, oofs)
             torch.cuda.synchronize(); dq = time.perf_counter() - tq
-            ra_whole = {"us_per_query": round(dq / q * 1e6, 3), "gibs_returned": round(q * qb / GiB / dq, 3),
-                        "note": "every touched frame decoded in full and its XXH64 verified (ZRA_HIP_OPT_RA_WHOLE_FRAMES): the like-for-like of cpu_baseline.ra_us_per_query; "
-                                "the timed step's default stops a frame at the last byte a query needs"}
+            ra_other = {"us_per_query": round(dq / q * 1e6, 3), "gibs_returned": round(q * qb / GiB / dq, 3),
+                        "note": ("a frame stops at the last byte a query needs and its XXH64 is not seen (the library's default for batches); the timed leg decodes whole frames"
+                                 if ra_whole_timed else
+                                 "every touched frame decoded in full and its XXH64 verified (ZRA_HIP_OPT_RA_WHOLE_FRAMES): the like-for-like of cpu_baseline.ra_us_per_query")}
         finally:
-            lib.ZraHipSetOptions(old_opts)
+            lib_opts.ZraHipSetOptions(opts_before | 8 if ra_whole_timed else opts_before)
+    ra_whole = ra_other if not ra_whole_timed else None
+    ra_early = ra_other if ra_whole_timed else None
 
+    lib_opts.ZraHipSetOptions(opts_before)              # (the probes below measure the library's defaults)
     ra_latency = None
     if world == 1 and not args.no_cpu_baseline:
         ra_latency = ra_latency_probe(Z, eng, d_arc, arc_size, d_in, N, qb, torch)
@@ -649,7 +669,7 @@ def main():
                      "zra_mf_kernel" if lv <= 12 or lv == 15 else "zra_mf_opt_kernel")
         if os.environ.get("ZRA_MF_FLAGS", "1") in ("0",) and mf_kernel == "zra_mf_dfast_fl_kernel":
             mf_kernel = "zra_mf_dfast_kernel"
-        traffic, traffic_src, traffic_stale, ra_traffic = None, None, None, None
+        traffic, traffic_src, traffic_stale, ra_traffic, ra_traffic_chain, ra_traffic_mode = None, None, None, None, None, None
         req = None      # the launch's HBM-side REQUESTS against the chip's random-request ceilings (what actually bounds the kernel: DESIGN.md 4, "Round 5")
         tpath = os.path.join(HERE, "profiles", "traffic.json")
         wkey = "L%d_fs%d" % (args.level, fs)
@@ -671,9 +691,16 @@ def main():
                         req = {"fetch_lines_per_launch": int(fl), "write_bytes_per_launch": int(wb), "read_ceiling_per_s": 48.3e9, "write_ceiling_per_s": 23.0e9,
                                "ceilings_from": "profiles/r02_pmc_calibration.txt (tools/pmc_calib.cpp, 4 GiB region: random 4-byte reads / partial-line writes per second)",
                                "note": "fetches as 64-byte lines; writes between 64 B (full lines: the table clears) and 32 B (partial-line stores) per request: low / high"}
-                    d1 = tj.get("decode_one_pass_of_16GiB", {}).get("zra_dec_chain_kernel")
-                    if d1:
-                        ra_traffic = int((d1["fetch_kib"] + d1["write_kib"]) * 1024 * nframes / tj["frames"])
+                    # the decode pass: every stage kernel's bytes, the two chain kernels (HBM tables / LDS tables: a frame runs on one of them,
+                    # and under --pmc the split differs from pass to pass) summed INSIDE each counter pass — never one kernel's halves
+                    # from two different executions (round 5's figure fell below the bytes the stage must move that way)
+                    dpass = tj.get("decode_one_pass_of_16GiB", {})
+                    if dpass:
+                        tot = sum((e.get("fetch_kib", 0) + e.get("write_kib", 0)) for k, e in dpass.items() if k.startswith("zra_dec_"))
+                        chn = sum((e.get("fetch_kib", 0) + e.get("write_kib", 0)) for k, e in dpass.items() if k.startswith("zra_dec_chain"))
+                        ra_traffic = int(tot * 1024 * nframes / tj["frames"])
+                        ra_traffic_chain = int(chn * 1024 * nframes / tj["frames"])
+                        ra_traffic_mode = tj.get("ra_mode", "early stop (measured before round 6's whole-frame headline)")
             except Exception:
                 traffic = None
         # second roofline object: the random-access leg's dominant kernel (the sequence chains). Algorithmic bytes = compressed bytes
@@ -695,8 +722,10 @@ def main():
             "compress_gibs": round(N * world / GiB / (np.mean(comp_ms) / 1e3), 3),
             "ra_gibs_returned": round(q * qb * world / GiB / (np.mean(ra_ms) / 1e3), 3),
             "ra_us_per_query": round(np.mean(ra_ms) * 1e3 / q, 3),
-            "ra_whole_frames": ra_whole,
-            "ra_whole_frames_us_per_query": ra_whole["us_per_query"] if ra_whole else None,
+            "ra_mode_timed": "whole frames, XXH64 verified (zra.cpp:280-293)" if ra_whole_timed else "early stop",
+            "ra_early_stop": ra_early,
+            "ra_whole_frames": ra_whole if not ra_whole_timed else {"us_per_query": round(np.mean(ra_ms) * 1e3 / q, 3), "note": "= the timed leg"},
+            "ra_whole_frames_us_per_query": (ra_whole["us_per_query"] if ra_whole else None) if not ra_whole_timed else round(np.mean(ra_ms) * 1e3 / q, 3),
             "ra_size_classes": ra_classes,
             "ra_latency": ra_latency,
             "roofline": {"bound": "hbm", "kernel": mf_kernel, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -709,14 +738,17 @@ def main():
                             "achieved_whole_pass": round(ra_alg / 1e9 / (dec_launch_ms / 1e3), 2) if (ra_alg and dec_launch_ms > 0) else None,
                             "frac_whole_pass": round(ra_alg / 1e9 / (dec_launch_ms / 1e3) / HBM_PEAK_GBS, 5) if (ra_alg and dec_launch_ms > 0) else None,
                             "whole_pass_ms": round(dec_launch_ms, 3),
-                            "traffic": ra_traffic, "traffic_stale": traffic_stale, "launch_ms": round(chain_ms, 3),
+                            "traffic": ra_traffic, "traffic_chain_kernels": ra_traffic_chain, "traffic_measured_in_mode": ra_traffic_mode,
+                            "traffic_stale": traffic_stale, "launch_ms": round(chain_ms, 3),
                             "algorithmic_bytes_per_launch": ra_alg, "touched": ra_touched, "stage_ms_per_pass": stage_ms,
                             "note": "one decode pass of the touched frames per step; algorithmic = compressed bytes of the touched frames + bytes returned; achieved / frac divide by the chain "
-                                    "kernel's span alone (the pass's dominant kernel), achieved_whole_pass / frac_whole_pass by all four kernels of the pass"},
+                                    "kernel's span alone (the pass's dominant kernel), achieved_whole_pass / frac_whole_pass by all four kernels of the pass; traffic = PMC bytes of "
+                                    "ALL stage kernels of the pass (a query returns 4 KiB of a 64 KiB frame that is decoded whole: the pass writes the frames, not the answers)"},
             "clocks": {"before_timed_region": clocks_before, "after_timed_region": clocks_after},
             # what the waves of the last timed match-finder launch recorded themselves (ZraHipGetLaunchTelemetry): the effective shader
             # clock DURING the launch (cycles against the constant 100 MHz clock), where the waves sat, frames taken per XCD
             "launch": getattr(step, "tele", None),
+            "kernel_resources": kernel_resources([mf_kernel, "zra_entropy_kernel", "zra_dec_chain_kernel", "zra_dec_chain_lds_kernel", "zra_dec_exec_kernel"]),
             "c4_share": c4,
             "host_pointer_calls": host_calls,
             "cpu_baseline": cpu,

@@ -897,16 +897,20 @@ def test_foreign_frame_size_does_not_cost_a_pass_per_frame(zra):
                                  {"ZRA_DEC_PIPE": "4", "ZRA_DEC_PIPE_MIN": "1", "ZRA_DEC_SMALL_MAX": "0"}, {"ZRA_MF_LS": "0"}, {"ZRA_MF_LS_MAX": "1000000"}, {"ZRA_ENC_POISON": "1"},
                                  {"ZRA_PIPE": "0"}, {"ZRA_PIPE": "2"}, {"ZRA_PIPE": "2", "ZRA_ENC_RING": "2", "ZRA_ENT_WGS": "2"},
                                  {"ZRA_DEC_SMALL_MAX": "0", "ZRA_DEC_CHAIN_LDS_MIN": "1", "ZRA_DEC_CHAIN_LDS": "2"},
-                                 {"ZRA_MF_LS": "0", "ZRA_MF_WAVES": "1"}, {"ZRA_MF_LS": "0", "ZRA_MF_EPOCH": "0"}],
+                                 {"ZRA_MF_LS": "0", "ZRA_MF_WAVES": "1"}, {"ZRA_MF_LS": "0", "ZRA_MF_EPOCH": "0"},
+                                 {"ZRA_ENT_SPLIT": "2"}, {"ZRA_ENT_SPLIT": "2", "ZRA_MF_LS": "0"}, {"ZRA_ENT_SPLIT": "0"}],
                          ids=["dfast-without-bucket-flags", "dfast-other-pipeline-geometry", "decode-stage-pipeline", "dfast-small-calls-from-memory", "dfast-all-calls-from-lds",
                               "hash-chain-over-poisoned-scratch", "dfast-stages-in-sequence", "dfast-resident-entropy-stage", "dfast-resident-entropy-small-ring",
-                              "decode-lds-table-chain-kernel-alone", "dfast-one-wave-per-cu-many-epochs", "dfast-tables-cleared-per-frame"])
+                              "decode-lds-table-chain-kernel-alone", "dfast-one-wave-per-cu-many-epochs", "dfast-tables-cleared-per-frame",
+                              "entropy-front-chain-back-on-every-call", "entropy-front-chain-back-table-finder", "entropy-one-launch-on-every-call"])
 def test_opt_in_kernels_are_bit_exact_too(env):
     """The paths of the library that a default call of the test sizes does not take give the same bytes as the ones it does: the dfast table
     kernel without its bucket flags (round 5: the flags are on by default for calls beyond the LDS-source kernel's size), the persistent
     pipeline with another geometry (18 waves per CU, one entropy workgroup per CU, a slot ring of two sub-batches) and in its other two
     modes (stages in sequence; one resident entropy launch that scans and gathers itself), the decode stage pipeline, the sequence-chain
-    kernel with its tables (two-byte cells) and bitstream rings in LDS ALONE on every job (by default it takes a share of large passes only), the two dfast kernels — frame source read from memory / from a copy in LDS — each forced onto the call sizes the other one
+    (round 6) the entropy stage as three launches per sub-batch — front, state chains with lane = (frame, stream), back — forced onto calls of
+    every size (by default: calls of 256 frames and more) and switched off; the epoch cells of the dfast table kernel with one wave per CU
+    (every wave through many epochs) and switched off; kernel with its tables (two-byte cells) and bitstream rings in LDS ALONE on every job (by default it takes a share of large passes only), the two dfast kernels — frame source read from memory / from a copy in LDS — each forced onto the call sizes the other one
     takes by default; and the wave-cooperative hash-chain finder, which does not clear its chain slots, over a table scratch filled with
     0xA5 before every batch (a selection of the level 5-10 cases here; the randomised differential compress ran that way in the soak,
     profiles/r04_soak_d.txt): the compress parity cases of levels 3-4 (archives byte-identical to the oracle's, reference call site

@@ -25,6 +25,9 @@ BUDGET = {
     "zra_dec_parse_kernel": (96, 256),   # 5 waves per SIMD asked for: 40 spilled VGPRs bought 2.1x on the stage (frames in flight are what it needs); round 5: 63 with libzstd's FSE_readNCount restated in full
     "zra_dec_exec_kernel": (80, 160),    # 6 waves per SIMD (the LDS-window step and the in-memory one side by side: 37 spilled VGPRs, 13.3 vs 14.3 ms at 5 waves)
     "zra_ra_small_kernel": (256, 0),     # one-launch path for small batches: all stages of a frame in one workgroup, occupancy is not its point
+    "zra_entropy_front_kernel": (96, 512),  # round 6, the split stage of the persistent pipeline: the same body up to the table descriptions ...
+    "zra_entropy_back_kernel": (96, 512),   # ... and from the sequence bitstream on; same budget as the one-launch kernel (one wave of it per SIMD beside the finder's five)
+    "zra_ent_chain_kernel": (64, 0),        # lane = (frame, stream) state chains between the two: one wave per workgroup, its LDS (21 KiB of tables) is the occupancy limit
     "zra_entropy_kernel": (96, 512),     # the entropy stage's queue-driven workgroups: one wave of it per SIMD next to five of the match finder's (5 x 80 + 96 <= 512); the scratch is the frame body's call frame (its copy of the argument block) + a few spilled registers      # 5 waves per SIMD asked for: no spills (7 cost 8 spilled VGPRs + 72 B scratch and 2 % of the bench)
 }
 

@@ -19,6 +19,9 @@ extern "C" __global__ void zra_mf_fast_kernel(ZraEncArgs a, uint32_t block, uint
 extern "C" __global__ void zra_mf_dfast_kernel(ZraEncArgs a, uint32_t block, uint32_t only, uint32_t onlySlot);
 extern "C" __global__ void zra_mf_dfast_fl_kernel(ZraEncArgs a, ZraFlagArgs g, uint32_t block, uint32_t only, uint32_t onlySlot);
 extern "C" __global__ void zra_entropy_kernel(ZraEncArgs a, uint32_t block);
+extern "C" __global__ void zra_entropy_front_kernel(ZraEncArgs a, uint32_t block);
+extern "C" __global__ void zra_entropy_back_kernel(ZraEncArgs a, uint32_t block);
+extern "C" __global__ void zra_ent_chain_kernel(ZraEncArgs a);
 
 using namespace zra_dev;
 
@@ -181,7 +184,7 @@ Status Engine::compress_impl_body(const uint8_t* dIn, size_t inSize, uint8_t* dB
   };
   const uint64_t tableWords = (std::max(slotWords(full), slotWords(tail)) + 3) & ~3ull;   // 16-byte slots
   const uint32_t maxBlock = std::max(full.blockSize, tail.blockSize);
-  const uint64_t seqStride = (maxBlock / 4 + 16 + 1) & ~1ull;   // (even: the entropy stage's u16 chain output sits behind 3 * seqStride code bytes)
+  const uint64_t seqStride = (maxBlock / 4 + 16 + 7) & ~7ull;   // (a multiple of 8: the entropy stage's u16 chain output sits behind 3 * seqStride code bytes, and the chain kernel moves 8 bytes at a time)
   const uint64_t litStride = ((uint64_t)maxBlock + 64 + 15) & ~15ull;
   // blocks per frame, per size class (a short last frame has its own, smaller, block size but is still one block)
   const uint64_t fullFrame = std::min<uint64_t>(frameSize, inSize);
@@ -455,6 +458,11 @@ Status Engine::compress_persistent(const uint8_t* dIn, size_t inSize, uint8_t* d
   static const uint32_t entPerCU = std::getenv("ZRA_ENT_WGS") ? (uint32_t)std::max(1, std::atoi(std::getenv("ZRA_ENT_WGS"))) : (pipeMode == 0 ? 5u : pipeMode == 1 ? 8u : 1u);
   const uint32_t entGrid = (uint32_t)std::min<uint64_t>((uint64_t)numCUs_ * entPerCU, nFramesTotal);
   const uint64_t entWorkStride = (9 * seqStride + 255) & ~255ull;
+  // round 6: the split entropy stage (pipeMode 1 only): per sub-batch a FRONT launch (literals, tables), zra_ent_chain_kernel (the state chains,
+  // lane = (frame, stream)), a BACK launch (sequence bitstream, block / frame end). The work area and a record are then per FRAME of the
+  // sub-batch. ZRA_ENT_SPLIT: 0 never, 1 (default) calls of at least 256 frames, 2 always.
+  static const int splitEnv = std::getenv("ZRA_ENT_SPLIT") ? std::atoi(std::getenv("ZRA_ENT_SPLIT")) : 1;
+  const bool entSplit = pipeMode == 1 && (splitEnv >= 2 || (splitEnv == 1 && nFramesTotal >= 256));
   static const uint32_t ringSubsEnv = std::getenv("ZRA_ENC_RING") ? (uint32_t)std::max(2, std::atoi(std::getenv("ZRA_ENC_RING"))) : 4u;   // sub-batches the slot ring holds
   uint64_t slotRing = 0;
   for (;; budget /= 2) {
@@ -466,8 +474,9 @@ Status Engine::compress_persistent(const uint8_t* dIn, size_t inSize, uint8_t* d
     subsPerSuper = (SBIG + SB - 1) / SB;
     slotRing = std::min<uint64_t>((uint64_t)ringSubsEnv * SB, subsPerSuper * (uint64_t)SB);
     if (SBIG <= SB) slotRing = SBIG;
-    bool okR = sh.tables.reserve((size_t)nSlots * tableWords * 4) && sh.lits.reserve((size_t)entGrid * litStride) && sh.work.reserve((size_t)entGrid * entWorkStride) &&
-               sh.slots.reserve(slotRing * slotStride);
+    const uint64_t workUnits = entSplit ? std::min<uint64_t>(SB, nFramesTotal) : entGrid;
+    bool okR = sh.tables.reserve((size_t)nSlots * tableWords * 4) && sh.lits.reserve((size_t)entGrid * litStride) && sh.work.reserve((size_t)workUnits * entWorkStride) &&
+               sh.slots.reserve(slotRing * slotStride) && (!entSplit || sh.rec.reserve((size_t)workUnits * sizeof(ZraEntRec)));
     for (int c = 0; c < nCtx && okR; c++) {
       EncCtx& x = encCtx_[c];
       okR = x.seqs.reserve(SBIG * seqStride * 8) && x.misc.reserve(SBIG * (sizeof(ZraEncFrameState) + sizeof(ZraEncBlockOut))) &&
@@ -628,7 +637,14 @@ Status Engine::compress_persistent(const uint8_t* dIn, size_t inSize, uint8_t* d
         uint64_t* dOffsets = x.sizes.as<uint64_t>() + SBIG + j0;
         hipEvent_t e0 = ev(), e1 = ev(); if (!e0 || !e1) return zerr(1);
         HIPCHK(hipEventRecord(e0, stream2_));
-        hipLaunchKernelGGL(zra_entropy_kernel, dim3(std::min<uint32_t>(nbj, entGrid)), dim3(256), 0, stream2_, aj, 0u);
+        if (entSplit) {
+          aj.entRec = sh.rec.as<ZraEntRec>();
+          hipLaunchKernelGGL(zra_entropy_front_kernel, dim3(std::min<uint32_t>(nbj, entGrid)), dim3(256), 0, stream2_, aj, 0u);
+          hipLaunchKernelGGL(zra_ent_chain_kernel, dim3((nbj + ZRA_CHAIN_FRAMES - 1) / ZRA_CHAIN_FRAMES), dim3(64), 0, stream2_, aj);
+          ZraEncArgs ab = aj; ab.entQueue = a.gQueue + j;   // (another zeroed word of the sub-batch: the BACK launch's frame queue)
+          hipLaunchKernelGGL(zra_entropy_back_kernel, dim3(std::min<uint32_t>(nbj, entGrid)), dim3(256), 0, stream2_, ab, 0u);
+        } else
+          hipLaunchKernelGGL(zra_entropy_kernel, dim3(std::min<uint32_t>(nbj, entGrid)), dim3(256), 0, stream2_, aj, 0u);
         HIPCHK(hipEventRecord(e1, stream2_));
         entSpans.push_back({e0, e1});
         hipLaunchKernelGGL(zra_scan_sizes_kernel, dim3(1), dim3(64), 0, stream2_, aj.sizes, nbj, dOffsets, dRunning, (const u32*)nullptr);

@@ -251,30 +251,68 @@ __device__ u32 fse_write_ncount(u8* out, const short* norm, u32 maxSym, u32 t) {
   return pos;
 }
 
-// serial (one lane) encoding-table build: spread, state table, per-symbol transforms
-__device__ int fse_build_ctable(ZraFseCTable* ct, const short* norm, u32 maxSym, u32 t, u8* cell, u32* cumul) {
+// (one wave, LDS in issue order: a wavefront-scope fence orders the compiler and waits for nothing)
+__device__ __forceinline__ void wave_order() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+
+// The same table as fse_build_ctable, built by all 64 lanes of ONE wave (round 6; arguments wave-uniform, every lane calls). The serial
+// build was 512 cells x two passes of dependent LDS round trips on one lane — the longest part of the entropy stage's one-lane sections
+// beside the state chains. Here: the symbols' cell counts are prefix-scanned across lanes (lane = symbol, <= 53 of them); the spread's
+// position sequence q(t) = t * step mod size is known for every t at once, the t-th VALID position (<= high: the low-probability symbols
+// own the cells above) takes the symbol whose range of occurrences holds its rank (binary search through the lanes' inclusive sums);
+// a cell's state index is its symbol's first index + its rank among the symbol's cells in cell order (one ballot per distinct symbol of
+// 64 cells); the per-symbol transforms are one lane each.
+__device__ int fse_build_ctable_wave(ZraFseCTable* ct, const short* norm, u32 maxSym, u32 t, u8* cell, int lane) {
   const u32 size = 1u << t, mask = size - 1, step = (size >> 1) + (size >> 3) + 3;
-  u32 high = size - 1, pos = 0;
-  ct->tableLog = t; ct->maxSym = maxSym; ct->rle = 0;
-  cumul[0] = 0;
-  for (u32 u = 1; u <= maxSym + 1; u++) cumul[u] = cumul[u - 1] + (norm[u - 1] == -1 ? 1u : (u32)norm[u - 1]);
-  for (u32 s = 0; s <= maxSym; s++) if (norm[s] == -1) cell[high--] = (u8)s;
-  for (u32 s = 0; s <= maxSym; s++)
-    for (int i = 0; i < norm[s]; i++) { cell[pos] = (u8)s; pos = (pos + step) & mask; while (pos > high) pos = (pos + step) & mask; }
-  if (pos != 0) return -1;
-  for (u32 u = 0; u < size; u++) ct->stateTable[cumul[cell[u]]++] = (u16)(size + u);
-  u32 total = 0;
-  for (u32 s = 0; s <= maxSym; s++) {
-    const int p = norm[s];
-    if (p == 0) { ct->deltaNbBits[s] = ((t + 1) << 16) - (1u << t); ct->deltaFindState[s] = 0; }
-    else if (p == 1 || p == -1) { ct->deltaNbBits[s] = (t << 16) - (1u << t); ct->deltaFindState[s] = (int)total - 1; total++; }
-    else {
-      const u32 maxBitsOut = t - hb32((u32)p - 1);
-      ct->deltaNbBits[s] = (maxBitsOut << 16) - ((u32)p << maxBitsOut);
-      ct->deltaFindState[s] = (int)total - p;
-      total += (u32)p;
-    }
+  const u64 lt = (1ull << lane) - 1ull;
+  const int p = (u32)lane <= maxSym ? (int)norm[lane] : 0;
+  const u32 wAll = p == -1 ? 1u : (u32)(p > 0 ? p : 0), wN = p > 0 ? (u32)p : 0u;
+  const u32 incAll = wave_incl_scan(wAll), incN = wave_incl_scan(wN);
+  const u32 startAll = incAll - wAll;
+  const u64 lowM = __ballot(p == -1);
+  const u32 nLow = (u32)__popcll(lowM), high = size - 1 - nLow;
+  const u32 totalN = bcast(incN, 63);
+  if (lane == 0) { ct->tableLog = t; ct->maxSym = maxSym; ct->rle = 0; }
+  if (totalN + nLow != size) return -1;                 // (fse_build_ctable: the spread does not come back to cell 0)
+  if (p == -1) cell[size - 1 - (u32)__popcll(lowM & lt)] = (u8)lane;
+  u32 carry = 0;
+  for (u32 c = 0; c < size; c += 64) {
+    const u32 tt = c + (u32)lane, q = (tt * step) & mask;
+    const bool valid = tt < size && q <= high;
+    const u64 vm = __ballot(valid);
+    const u32 i = carry + (u32)__popcll(vm & lt);
+    // symbol of occurrence i: the number of symbols whose inclusive sum is <= i (by every lane: the lanes read from must be executing)
+    u32 sy = 0;
+#pragma unroll
+    for (u32 b = 32; b >= 1; b >>= 1) { const u32 v = (u32)__shfl((int)incN, (int)min(sy + b - 1, 63u), 64); if (sy + b <= 64 && v <= i) sy += b; }
+    if (valid) cell[q] = (u8)sy;
+    carry += (u32)__popcll(vm);
   }
+  wave_order();
+  u32 run = startAll;                                   // lane s: next state index of symbol s
+  for (u32 c = 0; c < size; c += 64) {
+    const u32 u = c + (u32)lane;
+    const bool act = u < size;
+    const u32 sy = act ? (u32)cell[u] : 0xFFu;
+    u64 rem = __ballot(act);
+    u32 idx = 0;
+    while (rem) {
+      const u32 l = (u32)__builtin_ctzll(rem), sv = bcast(sy, l);
+      const u64 m = __ballot(act && sy == sv);
+      const u32 base = bcast(run, sv);
+      if (act && sy == sv) idx = base + (u32)__popcll(m & lt);
+      if ((u32)lane == sv) run += (u32)__popcll(m);
+      rem &= ~m;
+    }
+    if (act) ct->stateTable[idx] = (u16)(size + u);
+  }
+  if ((u32)lane <= maxSym) {
+    u32 dnb; int dfs;
+    if (p == 0) { dnb = ((t + 1) << 16) - (1u << t); dfs = 0; }
+    else if (p == 1 || p == -1) { dnb = (t << 16) - (1u << t); dfs = (int)startAll - 1; }
+    else { const u32 mbo = t - hb32((u32)p - 1); dnb = (mbo << 16) - ((u32)p << mbo); dfs = (int)startAll - p; }
+    ct->deltaNbBits[lane] = dnb; ct->deltaFindState[lane] = dfs;
+  }
+  wave_order();
   return 0;
 }
 __device__ __forceinline__ u32 fse_init_state(const ZraFseCTable* ct, u32 sym) {
@@ -339,56 +377,177 @@ __device__ u32 huf_set_max_height(EncShared& S, u32 lastNonNull, u32 maxNbBits) 
   return maxNbBits;
 }
 
-// FSE-compress the weight string (one lane). 0 = not compressible, 1 = single symbol. Its scratch is S.lit's own (w* arrays, wct).
-__device__ u32 huf_compress_weights(EncShared& S, u8* dst, u32 cap, const u8* w, u32 n) {
-  u32* const count = S.lit.wCount; short* norm = S.lit.wNorm;
-  u32 maxSym = 0, maxCount = 0;
+// ---- the Huffman build of a block's literals by ONE wave (round 6). Rounds 1-5 ran it on one lane: ~700 k cycles of dependent LDS round
+// trips per 64 KiB frame, as long as the three sequence-state chains beside it. Only the two-queue merge is inherently serial (<= 255
+// steps, the queue heads kept in registers); depths come from pointer jumping over the internal nodes, code values from a rank among
+// the symbols of equal length, the weight header's two FSE state chains run on two lanes and their bits are packed by a prefix scan.
+// Scratch of the wave in the upper part of the bit-staging tile (the sequence-table builds of waves 1-3 use its first 2.6 KiB meanwhile).
+struct HufWaveScratch { u16 P[256]; u16 D[256]; u16 wOut[256]; u32 wStage[64]; u32 rankCnt[16]; };
+static_assert(sizeof(EncSeqBuild) <= 4096 && 4096 + sizeof(HufWaveScratch) <= sizeof(u32) * STAGE_WORDS, "Huffman wave scratch must fit behind the table builds' arrays");
+
+// FSE-compress the weight string (all lanes of one wave; wave-uniform result). 0 = not compressible, 1 = single symbol.
+__device__ u32 huf_compress_weights_wave(EncShared& S, HufWaveScratch& H, u8* dst, u32 cap, const u8* w, u32 n, int lane) {
+  u32* const count = S.lit.wCount; short* const norm = S.lit.wNorm;
+  const u64 lt = (1ull << lane) - 1ull;
   if (n <= 1) return 0;
-  for (int s = 0; s < 13; s++) count[s] = 0;
-  for (u32 i = 0; i < n; i++) count[w[i]]++;
-  for (u32 s = 0; s <= 12; s++) { if (count[s]) maxSym = s; if (count[s] > maxCount) maxCount = count[s]; }
+  if (lane < 16) count[lane] = 0;
+  wave_order();
+  for (u32 i = (u32)lane; i < n; i += 64) atomicAdd(&count[w[i]], 1u);
+  wave_order();
+  const u32 cMine = lane < 13 ? count[lane] : 0u;
+  const u32 maxSym = wave_max(cMine ? (u32)lane : 0u), maxCount = wave_max(cMine);
   if (maxCount == n) return 1;
   if (maxCount == 1) return 0;
   const u32 t = fse_optimal_tablelog(6, n, maxSym, 2);
-  if (fse_normalize(norm, t, count, n, maxSym, false) <= 0) return 0;
   u8* const tmp = S.lit.ncTmp;
-  const u32 h = fse_write_ncount(tmp, norm, maxSym, t);
-  if (!h || h > cap) return 0;
-  for (u32 i = 0; i < h; i++) dst[i] = tmp[i];
-  ZraFseCTable* ct = &S.lit.wct;
-  if (fse_build_ctable(ct, norm, maxSym, t, S.lit.wSpread, S.lit.wCumul)) return 0;
-  if (n <= 2) return 0;
-  // two interleaved states, symbols consumed from the end (A.4.5 "weight serialisation")
-  u64 acc = 0; u32 nacc = 0, pos = h;
-  auto put = [&](u32 v, u32 nb) { acc |= (u64)(v & ((1u << nb) - 1)) << nacc; nacc += nb; while (nacc >= 8) { if (pos < cap) dst[pos] = (u8)acc; pos++; acc >>= 8; nacc -= 8; } };
-  const u8* ip = w + n;
-  u32 s1, s2, bits, nb;
-  if (n & 1) {
-    s1 = fse_init_state(ct, *--ip); s2 = fse_init_state(ct, *--ip);
-    nb = fse_encode(ct, s1, *--ip, bits); put(bits, nb);
-  } else { s2 = fse_init_state(ct, *--ip); s1 = fse_init_state(ct, *--ip); }
-  while (ip > w) {
-    nb = fse_encode(ct, s2, *--ip, bits); put(bits, nb);
-    if (ip > w) { nb = fse_encode(ct, s1, *--ip, bits); put(bits, nb); }
+  u32 h = 0;
+  if (lane == 0) {
+    if (fse_normalize(norm, t, count, n, maxSym, false) > 0) { h = fse_write_ncount(tmp, norm, maxSym, t); if (h > cap) h = 0; }
   }
-  put(s2, t); put(s1, t);
-  put(1, 1);
-  if (nacc > 0) { if (pos < cap) dst[pos] = (u8)acc; pos++; }
+  h = (u32)__builtin_amdgcn_readfirstlane((int)h);
+  if (!h) return 0;
+  wave_order();
+  for (u32 i = (u32)lane; i < h; i += 64) dst[i] = tmp[i];
+  ZraFseCTable* const ct = &S.lit.wct;
+  if (fse_build_ctable_wave(ct, norm, maxSym, t, S.lit.wSpread, lane)) return 0;
+  if (n <= 2) return 0;
+  // two interleaved states, symbols consumed from the end (A.4.5 "weight serialisation"): state 1 owns the even positions, state 2 the odd
+  // ones; each starts at its highest position and encodes downwards; the bits leave in position order, n - 3 first. Lane 0 / 1 walk them.
+  u32 state = 0;
+  if (lane < 2) {
+    int j = (int)n - 1; if ((j & 1) != lane) j--;
+    state = fse_init_state(ct, w[j]);
+    for (j -= 2; j >= 0; j -= 2) { u32 bits; const u32 nb = fse_encode(ct, state, w[j], bits); H.wOut[j] = (u16)(bits | (nb << 8)); }
+  }
+  for (u32 i = (u32)lane; i < 64; i += 64) H.wStage[i] = 0;
+  wave_order();
+  u32 total = 0;
+  for (u32 c = 0; c + 2 < n; c += 64) {
+    const u32 r = c + (u32)lane;                         // r-th encoded symbol = position n - 3 - r
+    const bool act = r + 2 < n;
+    const u32 e = act ? (u32)H.wOut[n - 3 - r] : 0u, nb = e >> 8;
+    const u32 inc = wave_incl_scan(nb);
+    if (act && nb) {
+      const u32 at = total + inc - nb;
+      const u64 v = (u64)(e & 0xFFu) << (at & 31);
+      atomicOr(&H.wStage[at >> 5], (u32)v);
+      if (v >> 32) atomicOr(&H.wStage[(at >> 5) + 1], (u32)(v >> 32));
+    }
+    total += bcast(inc, 63);
+  }
+  const u32 s1 = bcast(state, 0), s2 = bcast(state, 1);
+  if (lane == 0) {
+    const u64 fin = (u64)(s2 & ((1u << t) - 1)) | ((u64)(s1 & ((1u << t) - 1)) << t) | (1ull << (2 * t));
+    const u64 v = fin << (total & 31);                   // 2 t + 1 <= 13 bits
+    atomicOr(&H.wStage[total >> 5], (u32)v);
+    if (v >> 32) atomicOr(&H.wStage[(total >> 5) + 1], (u32)(v >> 32));
+  }
+  total += 2 * t + 1;
+  const u32 nbytes = (total + 7) >> 3, pos = h + nbytes;
   if (pos > cap) return 0;
+  wave_order();
+  for (u32 i = (u32)lane; i < nbytes; i += 64) dst[h + i] = (u8)(H.wStage[i >> 2] >> (8 * (i & 3)));
+  (void)lt;
   return pos;
 }
 
-// HUF_writeCTable into S.lit.hufHdr (one lane); returns size, 0 on failure
-__device__ u32 huf_write_ctable(EncShared& S, u32 maxSym, u32 log) {
-  u8* w = S.lit.weights; u8* dst = S.lit.hufHdr;
-  for (u32 n = 0; n < maxSym; n++) w[n] = S.hNb[n] ? (u8)(log + 1 - S.hNb[n]) : 0;
-  const u32 h = huf_compress_weights(S, dst + 1, 190, w, maxSym);
-  if (h > 1 && h < maxSym / 2) { dst[0] = (u8)h; return h + 1; }
+// HUF_writeCTable into S.lit.hufHdr (all lanes of one wave; wave-uniform result); returns size, 0 on failure
+__device__ u32 huf_write_ctable_wave(EncShared& S, HufWaveScratch& H, u32 maxSym, u32 log, int lane) {
+  u8* const w = S.lit.weights; u8* const dst = S.lit.hufHdr;
+  for (u32 n = (u32)lane; n < maxSym; n += 64) w[n] = S.hNb[n] ? (u8)(log + 1 - S.hNb[n]) : 0;
+  wave_order();
+  const u32 h = huf_compress_weights_wave(S, H, dst + 1, 190, w, maxSym, lane);
+  if (h > 1 && h < maxSym / 2) { if (lane == 0) dst[0] = (u8)h; return h + 1; }
   if (maxSym > 128) return 0;
-  dst[0] = (u8)(128 + (maxSym - 1));
-  w[maxSym] = 0;
-  for (u32 n = 0; n < maxSym; n += 2) dst[(n / 2) + 1] = (u8)((w[n] << 4) + w[n + 1]);
+  if (lane == 0) { dst[0] = (u8)(128 + (maxSym - 1)); w[maxSym] = 0; }
+  wave_order();
+  for (u32 n = 2 * (u32)lane; n < maxSym; n += 128) dst[(n / 2) + 1] = (u8)((w[n] << 4) + w[n + 1]);
   return ((maxSym + 1) / 2) + 1;
+}
+
+// The tree, the code lengths (depth-limited to `log`), the codes and the table description of the block's literals, from the symbols
+// sorted by (count desc, symbol asc) in S.lit.nodeCount[1 + rank] / nodeByte[rank]. All lanes of one wave; results: S.hNb, S.hVal,
+// S.lit.hufHdr, S.sc[0] = code length limit in use, S.sc[1] = header bytes (0: failure).
+__device__ void huf_build_wave(EncShared& S, u32 maxSym, u32 log, int lane) {
+  HufWaveScratch& H = *(HufWaveScratch*)((u8*)S.stage + 4096);
+  u32* const cntN = S.lit.nodeCount + 1; u16* const par = S.lit.nodeParent + 1; u8* const nbN = S.lit.nodeBits + 1;
+  const u64 lt = (1ull << lane) - 1ull;
+  u32 nn = 0;
+  for (u32 k = (u32)lane; k <= maxSym; k += 64) if (cntN[k]) nn = k;      // (sorted by count: the zeros are at the end)
+  const int nonNull = (int)wave_max(nn);
+  const int START = 256, nodeRoot = START + nonNull - 1;
+  for (int k = START + 1 + lane; k <= nodeRoot; k += 64) cntN[k] = 1u << 30;
+  if (lane == 0) S.lit.nodeCount[0] = 1u << 31;
+  wave_order();
+  if (lane == 0) {
+    // two-queue merge (leaves from the smallest, made nodes in the order they were made); the heads of both queues stay in registers
+    int lowS = nonNull, lowN = START, nodeNb = START;
+    const u32 c0 = cntN[lowS] + cntN[lowS - 1];
+    cntN[nodeNb] = c0; par[lowS] = par[lowS - 1] = (u16)nodeNb;
+    nodeNb++; lowS -= 2;
+    u32 cS = cntN[lowS], cN = c0;
+    while (nodeNb <= nodeRoot) {
+      int n1, n2; u32 c1, c2;
+      if (cS < cN) { n1 = lowS--; c1 = cS; cS = cntN[lowS]; } else { n1 = lowN++; c1 = cN; cN = cntN[lowN]; }
+      if (cS < cN) { n2 = lowS--; c2 = cS; cS = cntN[lowS]; } else { n2 = lowN++; c2 = cN; cN = cntN[lowN]; }
+      cntN[nodeNb] = c1 + c2;
+      par[n1] = par[n2] = (u16)nodeNb;
+      if (lowN == nodeNb) cN = c1 + c2;                  // (the head of the node queue is the node just made: its count was read as "not made yet")
+      nodeNb++;
+    }
+  }
+  wave_order();
+  // depth of the internal nodes START + i, i < nonNull (root = the last): pointer jumping, 2^r ancestors per round
+  const u32 nInt = (u32)nonNull;
+  for (u32 i = (u32)lane; i < nInt; i += 64) { const bool root = i + 1 == nInt; H.P[i] = root ? (u16)i : (u16)(par[START + i] - START); H.D[i] = root ? 0 : 1; }
+  wave_order();
+  for (u32 r = 1; r < nInt; r <<= 1) {
+    u32 nd[4], np[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) { const u32 i = (u32)lane + 64u * j; if (i < nInt) { const u32 pp = H.P[i]; nd[j] = H.D[i] + H.D[pp]; np[j] = H.P[pp]; } else { nd[j] = 0; np[j] = 0; } }
+    wave_order();
+#pragma unroll
+    for (int j = 0; j < 4; j++) { const u32 i = (u32)lane + 64u * j; if (i < nInt) { H.D[i] = (u16)nd[j]; H.P[i] = (u16)np[j]; } }
+    wave_order();
+  }
+  for (int k = lane; k <= nonNull; k += 64) nbN[k] = (u8)(H.D[par[k] - START] + 1);
+  wave_order();
+  u32 maxBits = 0;
+  if (lane == 0) maxBits = huf_set_max_height(S, (u32)nonNull, log);
+  maxBits = (u32)__builtin_amdgcn_readfirstlane((int)maxBits);
+  if (lane < 16) H.rankCnt[lane] = 0;
+  wave_order();
+  for (int k = lane; k <= nonNull; k += 64) atomicAdd(&H.rankCnt[nbN[k]], 1u);
+  for (u32 k = (u32)lane; k < 256; k += 64) S.hNb[k] = 0;
+  wave_order();
+  u16* const valPerRank = S.lit.valPerRank;
+  if (lane == 0) {
+    for (int k = 0; k < 14; k++) valPerRank[k] = 0;
+    u32 mn = 0;
+    for (int k = (int)maxBits; k > 0; k--) { valPerRank[k] = (u16)mn; mn += H.rankCnt[k]; mn >>= 1; }
+  }
+  for (u32 k = (u32)lane; k <= maxSym; k += 64) S.hNb[S.lit.nodeByte[k]] = k <= (u32)nonNull ? nbN[k] : 0;
+  wave_order();
+  // code of symbol k = first code of its length + its rank among the symbols of that length, in symbol order
+  for (u32 c = 0; c <= maxSym; c += 64) {
+    const u32 sym = c + (u32)lane;
+    const bool act = sym <= maxSym;
+    const u32 len = act ? (u32)S.hNb[sym] : 0xFFu;
+    u64 rem = __ballot(act);
+    while (rem) {
+      const u32 l = (u32)__builtin_ctzll(rem), lv = bcast(len, l);
+      const u64 m = __ballot(act && len == lv);
+      const u32 base = valPerRank[lv];
+      if (act && len == lv) S.hVal[sym] = (u16)(base + (u32)__popcll(m & lt));
+      wave_order();
+      if ((u32)lane == l) valPerRank[lv] = (u16)(base + (u32)__popcll(m));
+      wave_order();
+      rem &= ~m;
+    }
+  }
+  wave_order();
+  const u32 hs = huf_write_ctable_wave(S, H, maxSym, maxBits, lane);
+  if (lane == 0) { S.sc[0] = maxBits; S.sc[1] = hs; }
 }
 
 // Encode `len` literal symbols (reverse order, A.4.5) as one Huffman stream into dst; all 256 threads. Returns bytes.
@@ -511,7 +670,13 @@ __device__ unsigned long long zra_ent_prof[16];
 // [3][seqStride] u16 (state bits << 0 | their count << 12)
 // (the argument block is read where the kernel received it, in the constant address space: scalar loads, nothing copied into private memory)
 typedef const __attribute__((address_space(4))) ZraEncArgs KArgs;
-__device__ __forceinline__ void entropy_frame(KArgs& a, u32 block, u32 f, u8* lits, u8* slot, u8* work, EncShared& S) {
+// PHASE (round 6, the split stage of the persistent pipeline): 0 = the whole block in one go; 1 = FRONT: everything up to the sequence
+// section's table descriptions — literals section emitted, the three encoding tables handed to zra_ent_chain_kernel through the frame's
+// record `rec`; 2 = BACK: the sequence bitstream from the chain kernel's output, block header, frame end. The state chains — three lanes
+// of one wave for three quarters of a frame's time when they ran in here — are walked by zra_ent_chain_kernel between the two, lane =
+// (frame, stream) over several frames per wave.
+template <int PHASE>
+__device__ __forceinline__ void entropy_frame(KArgs& a, u32 block, u32 f, u8* lits, u8* slot, u8* work, EncShared& S, ZraEntRec* rec) {
 #ifdef ZRA_MF_PROFILE
   u64 ept_ = __builtin_amdgcn_s_memtime();
 #endif
@@ -532,7 +697,7 @@ __device__ __forceinline__ void entropy_frame(KArgs& a, u32 block, u32 f, u8* li
   const ZraEncBlockOut* bo = &a.blockOut[f];
   const u32 strategy = P.strategy;
 
-  if (first && tid == 0) {
+  if (PHASE != 2 && first && tid == 0) {
     st32(slot, 0xFD2FB528u); slot[4] = a.checksum ? 4 : 0; slot[5] = (u8)((P.windowLog - 10) << 3);   // A.4.2 frame header
     st->outPos = 6; st->hufRepeat = 0; st->llRepeat = st->ofRepeat = st->mlRepeat = 0;
   }
@@ -547,8 +712,10 @@ __device__ __forceinline__ void entropy_frame(KArgs& a, u32 block, u32 f, u8* li
   if (!bo->skip) {
     const u64* seqs = a.seqs + (size_t)f * a.seqStride;
 
-    // ------------------------------------------------------------ phase 1: gather literals + histogram
     u8* const codesG = work; u16* const chainG = (u16*)(work + 3 * a.seqStride);
+    u8* op = blk; bool tblErr = false; u8* lastNCount = nullptr; u32 tlog[3] = {0, 0, 0}, fin[3] = {0, 0, 0};
+    if constexpr (PHASE != 2) {
+    // ------------------------------------------------------------ phase 1: gather literals + histogram
     for (int i = tid; i < 4 * 256; i += ENT_THREADS) (&S.lit.hist[0][0])[i] = 0;
     if (tid < 3 * 64) (&S.seqCnt[0][0])[tid] = 0;
     if (tid < 4) S.tblReady[tid] = 0;
@@ -657,38 +824,7 @@ __device__ __forceinline__ void entropy_frame(KArgs& a, u32 block, u32 f, u8* li
       __syncthreads();
       // ---- 2b: wave 0 lane 0 builds the Huffman tree; waves 1-3 lane 0 choose and build the sequence tables (stream = wave - 1)
       if (wave == 0) {
-        if (needTree && tid == 0) {
-          u32* cntN = S.lit.nodeCount + 1; u16* par = S.lit.nodeParent + 1; u8* nbN = S.lit.nodeBits + 1;
-          int nonNull = (int)maxSym;
-          while (cntN[nonNull] == 0) nonNull--;
-          const int START = 256;
-          int lowS = nonNull, nodeNb = START, nodeRoot = nodeNb + lowS - 1, lowN = nodeNb;
-          cntN[nodeNb] = cntN[lowS] + cntN[lowS - 1];
-          par[lowS] = par[lowS - 1] = (u16)nodeNb;
-          nodeNb++; lowS -= 2;
-          for (int k = nodeNb; k <= nodeRoot; k++) cntN[k] = 1u << 30;
-          S.lit.nodeCount[0] = 1u << 31;
-          while (nodeNb <= nodeRoot) {
-            const int n1 = (cntN[lowS] < cntN[lowN]) ? lowS-- : lowN++;
-            const int n2 = (cntN[lowS] < cntN[lowN]) ? lowS-- : lowN++;
-            cntN[nodeNb] = cntN[n1] + cntN[n2];
-            par[n1] = par[n2] = (u16)nodeNb;
-            nodeNb++;
-          }
-          nbN[nodeRoot] = 0;
-          for (int k = nodeRoot - 1; k >= START; k--) nbN[k] = nbN[par[k]] + 1;
-          for (int k = 0; k <= nonNull; k++) nbN[k] = nbN[par[k]] + 1;
-          const u32 maxBits = huf_set_max_height(S, (u32)nonNull, log);
-          u16* const nbPerRank = S.lit.nbPerRank; u16* const valPerRank = S.lit.valPerRank;
-          for (int k = 0; k < 14; k++) nbPerRank[k] = valPerRank[k] = 0;
-          for (int k = 0; k <= nonNull; k++) nbPerRank[nbN[k]]++;
-          { u16 mn = 0; for (int k = (int)maxBits; k > 0; k--) { valPerRank[k] = mn; mn += nbPerRank[k]; mn >>= 1; } }
-          for (int k = 0; k < 256; k++) S.hNb[k] = 0;
-          for (u32 k = 0; k <= maxSym; k++) S.hNb[S.lit.nodeByte[k]] = k <= (u32)nonNull ? nbN[k] : 0;
-          for (u32 k = 0; k <= maxSym; k++) S.hVal[k] = valPerRank[S.hNb[k]]++;
-          S.sc[0] = maxBits;
-          S.sc[1] = huf_write_ctable(S, maxSym, maxBits);
-        }
+        if (needTree) huf_build_wave(S, maxSym, log, lane);
       } else if (nbSeq) {
         // ---- wave 1: the three sequence tables and the three state chains, stream k on lane k. ONE wave (beside wave 0's tree build),
         // not three: this stage runs beside the match finder, and every wave that issues one-lane code at a raised priority takes issue
@@ -696,35 +832,46 @@ __device__ __forceinline__ void entropy_frame(KArgs& a, u32 block, u32 f, u8* li
         // (the three tables are chosen and built side by side, stream k by lane 0 of wave k + 1 — short — and reported through an LDS
         //  flag; the three chains then run on lanes 0-2 of wave 1 alone)
         const int k = wave == 1 ? lane : wave - 1;
-        if (lane == 0) {
-          const int k = wave - 1;
-          const u32 maxSymK = k == 0 ? 35 : k == 1 ? 31 : 52, FSELog = k == 1 ? 8 : 9, defLog = k == 1 ? 5 : 6, defMax = k == 0 ? 35 : k == 1 ? 28 : 52;
-          const short* defNorm = k == 0 ? c_LLdef : k == 1 ? c_OFdef : c_MLdef;
-          u32* count = S.seqCnt[k];
-          u32 mx = 0, most = 0;
-          for (u32 sy = 0; sy <= maxSymK; sy++) { if (count[sy]) mx = sy; if (count[sy] > most) most = count[sy]; }
-          const u32 lastCode = codesG[(size_t)k * a.seqStride];          // (the block's last sequence is the chains' first)
-          const ZraFseCTable* prevCT = k == 0 ? &st->ll : k == 1 ? &st->of : &st->ml;
-          u32 repeatMode = first ? 0 : (k == 0 ? st->llRepeat : k == 1 ? st->ofRepeat : st->mlRepeat);
-          const bool defaultAllowed = k != 1 || mx <= 28;
-          const u32 modeK = select_encoding(&repeatMode, count, mx, most, nbSeq, FSELog, prevCT, defNorm, defLog, defaultAllowed, strategy, SB.norm[k], S.ncount[k]);
-          S.mode[k] = modeK; S.nextRepeat[k] = repeatMode; S.ncountSize[k] = 0; S.tblErr[k] = 0;
-          ZraFseCTable* ct = &S.ct[k];
-          if (modeK == 1) { ct->rle = 1; ct->tableLog = 0; ct->maxSym = mx; S.ncount[k][0] = (u8)mx; S.ncountSize[k] = 1; }
-          else if (modeK == 0) { for (u32 sy = 0; sy <= defMax; sy++) SB.norm[k][sy] = defNorm[sy]; if (fse_build_ctable(ct, SB.norm[k], defMax, defLog, SB.spread[k], SB.cumul[k])) S.tblErr[k] = 1; }
-          else if (modeK == 2) {
-            u32 n1 = nbSeq;
-            const u32 tl = fse_optimal_tablelog(FSELog, nbSeq, mx, 2);
-            if (count[lastCode] > 1) { count[lastCode]--; n1--; }
-            if (fse_normalize(SB.norm[k], tl, count, n1, mx, n1 >= 2048) <= 0) S.tblErr[k] = 1;
-            else {
-              const u32 h = fse_write_ncount(S.ncount[k], SB.norm[k], mx, tl);
-              if (!h || fse_build_ctable(ct, SB.norm[k], mx, tl, SB.spread[k], SB.cumul[k])) S.tblErr[k] = 1;
-              S.ncountSize[k] = h;
+        {
+          // (round 6: lane 0 chooses the encoding and normalises the counts — short —, the whole wave builds the table: fse_build_ctable_wave)
+          const int kw = wave - 1;
+          u32 doBuild = 0, buildT = 0, buildMax = 0;
+          if (lane == 0) {
+            const int k = kw;
+            const u32 maxSymK = k == 0 ? 35 : k == 1 ? 31 : 52, FSELog = k == 1 ? 8 : 9, defLog = k == 1 ? 5 : 6, defMax = k == 0 ? 35 : k == 1 ? 28 : 52;
+            const short* defNorm = k == 0 ? c_LLdef : k == 1 ? c_OFdef : c_MLdef;
+            u32* count = S.seqCnt[k];
+            u32 mx = 0, most = 0;
+            for (u32 sy = 0; sy <= maxSymK; sy++) { if (count[sy]) mx = sy; if (count[sy] > most) most = count[sy]; }
+            const u32 lastCode = codesG[(size_t)k * a.seqStride];          // (the block's last sequence is the chains' first)
+            const ZraFseCTable* prevCT = k == 0 ? &st->ll : k == 1 ? &st->of : &st->ml;
+            u32 repeatMode = first ? 0 : (k == 0 ? st->llRepeat : k == 1 ? st->ofRepeat : st->mlRepeat);
+            const bool defaultAllowed = k != 1 || mx <= 28;
+            const u32 modeK = select_encoding(&repeatMode, count, mx, most, nbSeq, FSELog, prevCT, defNorm, defLog, defaultAllowed, strategy, SB.norm[k], S.ncount[k]);
+            S.mode[k] = modeK; S.nextRepeat[k] = repeatMode; S.ncountSize[k] = 0; S.tblErr[k] = 0;
+            ZraFseCTable* ct = &S.ct[k];
+            if (modeK == 1) { ct->rle = 1; ct->tableLog = 0; ct->maxSym = mx; S.ncount[k][0] = (u8)mx; S.ncountSize[k] = 1; }
+            else if (modeK == 0) { for (u32 sy = 0; sy <= defMax; sy++) SB.norm[k][sy] = defNorm[sy]; doBuild = 1; buildT = defLog; buildMax = defMax; }
+            else if (modeK == 2) {
+              u32 n1 = nbSeq;
+              const u32 tl = fse_optimal_tablelog(FSELog, nbSeq, mx, 2);
+              if (count[lastCode] > 1) { count[lastCode]--; n1--; }
+              if (fse_normalize(SB.norm[k], tl, count, n1, mx, n1 >= 2048) <= 0) S.tblErr[k] = 1;
+              else {
+                const u32 h = fse_write_ncount(S.ncount[k], SB.norm[k], mx, tl);
+                if (!h) S.tblErr[k] = 1; else { doBuild = 1; buildT = tl; buildMax = mx; }
+                S.ncountSize[k] = h;
+              }
             }
           }
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-          __hip_atomic_store(&S.tblReady[k], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+          doBuild = (u32)__builtin_amdgcn_readfirstlane((int)doBuild); buildT = (u32)__builtin_amdgcn_readfirstlane((int)buildT);
+          buildMax = (u32)__builtin_amdgcn_readfirstlane((int)buildMax);
+          wave_order();
+          if (doBuild && fse_build_ctable_wave(&S.ct[kw], SB.norm[kw], buildMax, buildT, SB.spread[kw], lane)) { if (lane == 0) S.tblErr[kw] = 1; }
+          if (lane == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __hip_atomic_store(&S.tblReady[kw], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
         }
         if (wave == 1) {
         // wave 1 waits for the three tables (its own lane 0 built the first)
@@ -749,7 +896,7 @@ __device__ __forceinline__ void entropy_frame(KArgs& a, u32 block, u32 f, u8* li
         // of wave 0, which takes about as long. 64 sequences at a time: their codes come in with one load per stream (the next 64
         // travel meanwhile) and are parked in LDS, lanes 0-2 walk the 64 steps of their streams (the symbol two steps ahead and its
         // parameters one step ahead are fetched beside the critical load), the results leave with one store per stream.
-        {
+        if constexpr (PHASE != 1) {
           const bool runK = lane < 3 && !S.tblErr[k] && !S.ct[lane < 3 ? k : 0].rle;
           const ZraFseCTable* const ct = &S.ct[lane < 3 ? k : 0];
           u8* const cdL = S.chainCodes[lane < 3 ? k : 0]; u16* const outL = S.chainOut[lane < 3 ? k : 0];
@@ -888,18 +1035,16 @@ __device__ __forceinline__ void entropy_frame(KArgs& a, u32 block, u32 f, u8* li
 
     EPROF(2)
     // ------------------------------------------------------------ phase 3: sequences section (A.4.7)
-    u8* op = blk + litSec;
+    op = blk + litSec;
     if (tid == 0) {
       if (nbSeq < 128) op[0] = (u8)nbSeq;
       else if (nbSeq < 0x7F00) { op[0] = (u8)((nbSeq >> 8) + 0x80); op[1] = (u8)nbSeq; }
       else { op[0] = 0xFF; op[1] = (u8)(nbSeq - 0x7F00); op[2] = (u8)((nbSeq - 0x7F00) >> 8); }
     }
     op += nbSeq < 128 ? 1 : nbSeq < 0x7F00 ? 2 : 3;
-    bool uncompressible = false;
     if (nbSeq) {
       u8* const seqHead = op++;
-      const bool tblErr = S.tblErr[0] | S.tblErr[1] | S.tblErr[2];
-      u8* lastNCount = nullptr;
+      tblErr = S.tblErr[0] | S.tblErr[1] | S.tblErr[2];
       if (tid == 0) seqHead[0] = (u8)((S.mode[0] << 6) + (S.mode[1] << 4) + (S.mode[2] << 2));
       for (int k = 0; k < 3; k++) {
         const u32 sz = S.ncountSize[k];
@@ -907,9 +1052,35 @@ __device__ __forceinline__ void entropy_frame(KArgs& a, u32 block, u32 f, u8* li
         for (u32 i = tid; i < sz; i += ENT_THREADS) op[i] = S.ncount[k][i];
         op += sz;
       }
+      for (int k = 0; k < 3; k++) { tlog[k] = S.ct[k].tableLog; fin[k] = S.finalState[k]; }
+    }
+    if constexpr (PHASE == 1) {
+      // FRONT ends here: the tables and where the bitstream goes, for the chain kernel and the BACK launch
+      if (nbSeq && !tblErr) {
+        for (int k = 0; k < 3; k++) {
+          const u32* srcT = (const u32*)&S.ct[k]; u32* dstT = (u32*)&rec->ct[k];
+          for (u32 i = tid; i < sizeof(ZraFseCTable) / 4; i += ENT_THREADS) dstT[i] = srcT[i];
+        }
+      }
+      if (tid == 0) {
+        rec->nChain = (nbSeq && !tblErr) ? nbSeq : 0u;
+        for (int k = 0; k < 3; k++) { rec->run[k] = (nbSeq && !tblErr && !S.ct[k].rle) ? 1u : 0u; rec->tlog[k] = tlog[k]; rec->finalState[k] = 0; }
+        rec->tblErr = tblErr ? 1u : 0u; rec->opOff = (u32)(op - blk); rec->lastNCountOff = lastNCount ? (u32)(lastNCount - blk) : 0xFFFFFFFFu;
+        rec->newHuf = newHuf ? 1u : 0u; rec->newHufMaxSym = newHufMaxSym;
+      }
+      return;
+    }
+    } else {
+      // BACK: where FRONT stopped
+      op = blk + rec->opOff; tblErr = rec->tblErr != 0;
+      lastNCount = rec->lastNCountOff == 0xFFFFFFFFu ? nullptr : blk + rec->lastNCountOff;
+      for (int k = 0; k < 3; k++) { tlog[k] = rec->tlog[k]; fin[k] = rec->finalState[k]; }
+      newHuf = rec->newHuf != 0; newHufMaxSym = rec->newHufMaxSym;
+    }
+    bool uncompressible = false;
+    if (nbSeq) {
       // ---- pass B: parallel packing of the chains' output + the sequences' extra bits, 512 sequences per tile, last sequence first
       u32 carryBits = 0, carryVal = 0, bytesOut = 0;
-      const u32 tlog[3] = {S.ct[0].tableLog, S.ct[1].tableLog, S.ct[2].tableLog};
       for (u32 t0 = 0; t0 < nbSeq && !tblErr; t0 += SEQ_TILE) {
         const u32 cntT = min((u32)SEQ_TILE, nbSeq - t0);
         const bool lastTile = t0 + cntT == nbSeq;
@@ -951,9 +1122,9 @@ __device__ __forceinline__ void entropy_frame(KArgs& a, u32 block, u32 f, u8* li
         if (lastTile) {
           if (tid == 0) {
             LaneBitW fw; fw.init(S.stage, total);
-            fw.add(S.finalState[2] & ((1u << tlog[2]) - 1), tlog[2]);
-            fw.add(S.finalState[1] & ((1u << tlog[1]) - 1), tlog[1]);
-            fw.add(S.finalState[0] & ((1u << tlog[0]) - 1), tlog[0]);
+            fw.add(fin[2] & ((1u << tlog[2]) - 1), tlog[2]);
+            fw.add(fin[1] & ((1u << tlog[1]) - 1), tlog[1]);
+            fw.add(fin[0] & ((1u << tlog[0]) - 1), tlog[0]);
             fw.add(1, 1);
             fw.finish();
           }
@@ -982,6 +1153,7 @@ __device__ __forceinline__ void entropy_frame(KArgs& a, u32 block, u32 f, u8* li
       if (!__syncthreads_or((int)diff)) { cSize = 1; if (tid == 0) blk[0] = b0; }
     }
   }
+  if constexpr (PHASE == 1) { if (tid == 0) rec->nChain = 0; return; }      // (a block too small to compress: nothing for the chain kernel)
   __syncthreads();
 
   // ---------------------------------------------------------------- block header, state confirmation, frame tail
@@ -996,7 +1168,7 @@ __device__ __forceinline__ void entropy_frame(KArgs& a, u32 block, u32 f, u8* li
   } else {
     if (tid == 0) { const u32 h = (u32)last + (2u << 1) + (cSize << 3); op0[0] = (u8)h; op0[1] = (u8)(h >> 8); op0[2] = (u8)(h >> 16); }
     blockBytes = 3 + cSize;
-    if (!last) {
+    if (PHASE != 2 && !last) {      // (the split stage takes single-block frames only: nothing to confirm for a next block)
       // a compressed block confirms repcodes + entropy tables for the next block (A.4.2 / A.4.8)
       if (tid == 0) { st->rep[0] = bo->rep[0]; st->rep[1] = bo->rep[1]; st->rep[2] = bo->rep[2]; }
       if (newHuf) {
@@ -1029,12 +1201,13 @@ __device__ __forceinline__ void entropy_frame(KArgs& a, u32 block, u32 f, u8* li
 }
 
 // (a real call: inlined into the kernel's queue loop the body spilled 66-74 vector registers under the same 5-waves budget)
-__device__ __attribute__((noinline)) void entropy_frame_call(KArgs& a, u32 block, u32 f, u8* lits, u8* slot, u8* work, EncShared& S) {
+template <int PHASE>
+__device__ __attribute__((noinline)) void entropy_frame_call(KArgs& a, u32 block, u32 f, u8* lits, u8* slot, u8* work, EncShared& S, ZraEntRec* rec) {
   // (arguments arrive in vector registers: pin the wave-uniform ones to the scalar unit, or the frame's whole parameter set follows them)
   f = (u32)__builtin_amdgcn_readfirstlane((int)f); block = (u32)__builtin_amdgcn_readfirstlane((int)block);
   auto pin = [](u8* p) { const u64 v = (u64)p; return (u8*)(((u64)(u32)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (u32)__builtin_amdgcn_readfirstlane((int)v)); };
   KArgs& au = *(KArgs*)(((u64)(u32)__builtin_amdgcn_readfirstlane((int)((u64)&a >> 32)) << 32) | (u32)__builtin_amdgcn_readfirstlane((int)(u64)&a));
-  entropy_frame(au, block, f, pin(lits), pin(slot), pin(work), S);
+  entropy_frame<PHASE>(au, block, f, pin(lits), pin(slot), pin(work), S, (ZraEntRec*)pin((u8*)rec));
 }
 
 // The entropy stage: workgroups that take frames from a queue, each with its own literal buffer and sequence work area.
@@ -1088,17 +1261,16 @@ __device__ __forceinline__ void pipe_gather_frame(KArgs& a, u32 fi) {
 //    then depended on how the match finder's waves had happened to land, and at one workgroup per CU the stage could not keep up.
 //    Nothing waits without doing the other work that is ready, and every wait gives up after ~10 s of the 100 MHz clock (pipeAbort):
 //    the call fails, the GPU does not hang.
-extern "C" __global__ void __launch_bounds__(ENT_THREADS, ZRA_ENT_WAVES)
-zra_entropy_kernel(ZraEncArgs a_, u32 block) {
-  KArgs& a = *(KArgs*)__builtin_amdgcn_kernarg_segment_ptr();     // (= a_, where it arrived)
-  (void)a_;
+template <int PHASE>
+__device__ __forceinline__ void entropy_kernel_body(u32 block) {
+  KArgs& a = *(KArgs*)__builtin_amdgcn_kernarg_segment_ptr();     // (the kernel's first argument, where it arrived)
   __shared__ EncShared S;
   // This stage runs beside the match finder, which fills most issue slots; the one-lane serial sections here are latency-critical.
   // Raise the wave's issue priority so they are not queued behind match-finder waves (a.entPrio: bring-up knob ZRA_ENT_PRIO, default 3).
   switch (a.entPrio) { case 0: __builtin_amdgcn_s_setprio(0); break; case 1: __builtin_amdgcn_s_setprio(1); break; case 2: __builtin_amdgcn_s_setprio(2); break; default: __builtin_amdgcn_s_setprio(3); break; }
   const int tid = threadIdx.x;
   u8* const lits = a.lits + (size_t)blockIdx.x * a.litStride;
-  u8* const work = a.entWork + (size_t)blockIdx.x * a.entWorkStride;
+  u8* const workWg = a.entWork + (size_t)blockIdx.x * a.entWorkStride;      // (split stage: a work area per FRAME, below)
   const bool pipe = a.readyStamp != 0;
   const u32 SBF = a.entSubFrames, nSub = pipe ? (a.nFrames + SBF - 1) / SBF : 0u, ringSubs = max(1u, a.slotRing / SBF);
   // thread 0's bookkeeping
@@ -1178,7 +1350,8 @@ zra_entropy_kernel(ZraEncArgs a_, u32 block) {
     }
     // act == 2: encode frame `arg`
     if (pipe) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");     // what the match finder wrote for this frame (sequences, block record)
-    entropy_frame_call(a, block, arg, lits, a.slots + (size_t)(arg % a.slotRing) * a.slotStride, work, S);
+    entropy_frame_call<PHASE>(a, block, arg, lits, a.slots + (size_t)(arg % a.slotRing) * a.slotStride,
+                              PHASE ? a.entWork + (size_t)arg * a.entWorkStride : workWg, S, PHASE ? a.entRec + arg : nullptr);
     if (pipe) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");             // the slot and the frame's size, before the count
       __syncthreads();
@@ -1203,6 +1376,109 @@ zra_entropy_kernel(ZraEncArgs a_, u32 block) {
       }
     }
   }
+}
+
+extern "C" __global__ void __launch_bounds__(ENT_THREADS, ZRA_ENT_WAVES)
+zra_entropy_kernel(ZraEncArgs a_, u32 block) { (void)a_; entropy_kernel_body<0>(block); }
+// the split stage of the persistent pipeline (round 6): FRONT, zra_ent_chain_kernel, BACK — one launch each per sub-batch
+extern "C" __global__ void __launch_bounds__(ENT_THREADS, ZRA_ENT_WAVES)
+zra_entropy_front_kernel(ZraEncArgs a_, u32 block) { (void)a_; entropy_kernel_body<1>(block); }
+extern "C" __global__ void __launch_bounds__(ENT_THREADS, ZRA_ENT_WAVES)
+zra_entropy_back_kernel(ZraEncArgs a_, u32 block) { (void)a_; entropy_kernel_body<2>(block); }
+
+// The three FSE state chains of a block: state -> stateTable[(state >> nb) + dfs] -> state, one dependent LDS round trip per sequence and
+// stream, inherently serial (chains from different start states do not merge; a table walked through v_readlane costs more than the
+// round trip — round 5). Inside the frame's workgroup they kept three lanes busy for three quarters of the stage while 253 waited.
+// Here lane = (frame, stream): ZRA_CHAIN_FRAMES frames per wave, their tables (FRONT left them in the frames' records) in 3.5 KiB of LDS
+// each, the code bytes read 8 at a time and the results written 4 at a time per lane. One wave per workgroup; 21 KiB of LDS: one per CU
+// beside the match finder's 18 waves, as many as fit otherwise.
+#define ZRA_CHAIN_TBL_BYTES 3528u      /* per frame: state tables LL 512 + OF 256 + ML 512 u16; {deltaNbBits, deltaFindState} LL 36 + OF 32 + ML 53 */
+extern "C" __global__ void __launch_bounds__(64)
+zra_ent_chain_kernel(ZraEncArgs a_) {
+  (void)a_;
+  KArgs& a = *(KArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+  __shared__ __attribute__((aligned(16))) u8 T[ZRA_CHAIN_FRAMES * ZRA_CHAIN_TBL_BYTES];
+  const int lane = threadIdx.x;
+  switch (a.entPrio) { case 0: __builtin_amdgcn_s_setprio(0); break; case 1: __builtin_amdgcn_s_setprio(1); break; case 2: __builtin_amdgcn_s_setprio(2); break; default: __builtin_amdgcn_s_setprio(3); break; }
+  const u32 f0 = blockIdx.x * ZRA_CHAIN_FRAMES;
+  // ---- tables into LDS, all lanes: per frame and stream the state table (2^tableLog entries) and the per-symbol pairs
+  for (u32 g = 0; g < ZRA_CHAIN_FRAMES; g++) {
+    const u32 f = f0 + g;
+    if (f >= a.nFrames) break;
+    const ZraEntRec* const r = a.entRec + f;
+    if (!r->nChain) continue;
+    u8* const Tf = T + g * ZRA_CHAIN_TBL_BYTES;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      if (!r->run[k]) continue;
+      const ZraFseCTable* const ct = &r->ct[k];
+      u16* const stL = (u16*)(Tf + (k == 0 ? 0u : k == 1 ? 1024u : 1536u));
+      u64* const symL = (u64*)(Tf + (k == 0 ? 2560u : k == 1 ? 2848u : 3104u));
+      const u32 nState = min(1u << r->tlog[k], k == 1 ? 256u : 512u), nSym = k == 0 ? 36u : k == 1 ? 32u : 53u;
+      for (u32 i = (u32)lane; i < nState / 2; i += 64) ((u32*)stL)[i] = ((const u32*)ct->stateTable)[i];
+      for (u32 i = (u32)lane; i < nSym; i += 64) symL[i] = (u64)ct->deltaNbBits[i] | ((u64)(u32)ct->deltaFindState[i] << 32);
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  // ---- the chains
+  const u32 g = (u32)lane / 3u, k = (u32)lane % 3u, f = f0 + g;
+  if (g >= ZRA_CHAIN_FRAMES || f >= a.nFrames) return;
+  ZraEntRec* const r = a.entRec + f;
+  const u32 n = r->nChain;
+  if (!n) return;
+  u8* const work = a.entWork + (size_t)f * a.entWorkStride;
+  const u8* const codes = work + (size_t)k * a.seqStride;
+  u16* const out = (u16*)(work + 3 * a.seqStride) + (size_t)k * a.seqStride;
+  if (!r->run[k]) {
+    // (a one-symbol table emits no state bits: zeros; the BACK launch reads them like any other stream's)
+    for (u32 i = 0; i < n; i++) out[i] = 0;
+    r->finalState[k] = 0;
+    return;
+  }
+  const u8* const Tf = T + g * ZRA_CHAIN_TBL_BYTES;
+  const u16* const stL = (const u16*)(Tf + (k == 0 ? 0u : k == 1 ? 1024u : 1536u));
+  const u64* const symL = (const u64*)(Tf + (k == 0 ? 2560u : k == 1 ? 2848u : 3104u));
+  // code bytes: 8 per load (the work area is 256-byte aligned per frame, seqStride even: 2-byte aligned streams -> byte-assembled head)
+  u64 cw = 0; u32 cHave = 0, cPos = 0;
+  auto next_code = [&]() -> u32 {
+    if (!cHave) {
+      const u32 left = n - cPos;
+      if (left >= 8 && (((uintptr_t)(codes + cPos)) & 7u) == 0) { cw = *(const u64*)(codes + cPos); cHave = 8; }
+      else { cw = codes[cPos]; cHave = 1; }
+      cPos += cHave;
+    }
+    const u32 c = (u32)cw & 255u; cw >>= 8; cHave--;
+    return c;
+  };
+  u32 sym = next_code();
+  u32 state;
+  {
+    const u64 sp = symL[sym];
+    const u32 d = (u32)sp, nb = (d + (1u << 15)) >> 16, v = (nb << 16) - d;
+    state = stL[(v >> nb) + (u32)(i32)(u32)(sp >> 32)];
+  }
+  u64 ow = 0; u32 oHave = 1;                            // out[0] = 0: the block's last sequence only initialises the states
+  u32 oPos = 0;
+  auto put_out = [&](u32 v16) {
+    ow |= (u64)v16 << (16 * oHave); oHave++;
+    if (oHave == 4) { st64((u8*)(out + oPos), ow); oPos += 4; ow = 0; oHave = 0; }
+  };
+  if (n > 1) {
+    u32 symN = next_code();
+    u64 sp = symL[symN];
+    for (u32 i = 1; i < n; i++) {
+      const u32 dnb = (u32)sp; const i32 dfs = (i32)(u32)(sp >> 32);
+      const u32 nb = (state + dnb) >> 16;
+      const u32 bits = state & ((1u << nb) - 1);
+      state = stL[(state >> nb) + dfs];                  // critical load first
+      if (i + 1 < n) { symN = next_code(); sp = symL[symN]; }
+      put_out((nb << 12) | bits);
+    }
+  }
+  for (u32 j = 0; j < oHave; j++) out[oPos + j] = (u16)(ow >> (16 * j));
+  r->finalState[k] = state;
 }
 
 #ifdef ZRA_MF_PROFILE

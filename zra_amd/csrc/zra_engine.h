@@ -143,7 +143,7 @@ class Engine {
   bool raVerifyWholeFrames_ = false;     // batched random access decodes every touched frame in full and checks its checksum
   DevBuf status_, produced_, frameMeta_, frameOff_, outOff_, expect_, result_, temp_, qmeta_;
   // encode scratch (see zra_encode.hip)
-  struct EncCtx { DevBuf tables, seqs, lits, work, slots, misc, ck, sizes; };
+  struct EncCtx { DevBuf tables, seqs, lits, work, slots, misc, ck, sizes, rec; };   // rec: the split entropy stage's per-frame records (ZraEntRec)
   EncCtx encCtx_[2];
   DevBuf encScan_;
   DevBuf mfFlags_;                         // bucket-flag masks of the dfast match finder: one slot per resident wave (df_later_flags)

@@ -285,7 +285,7 @@ Status Engine::release_scratch() {
                     &produced_, &frameMeta_, &frameOff_, &outOff_, &expect_, &result_, &temp_, &qmeta_, &encScan_, &hostIn_, &hostOut_, &seqScratch_, &mfFlags_})
     b->release();
   mfTeleDev_ = nullptr;                                // (lived inside encScan_)
-  for (auto& x : encCtx_) for (DevBuf* b : {&x.tables, &x.seqs, &x.lits, &x.work, &x.slots, &x.misc, &x.ck, &x.sizes}) b->release();
+  for (auto& x : encCtx_) for (DevBuf* b : {&x.tables, &x.seqs, &x.lits, &x.work, &x.slots, &x.misc, &x.ck, &x.sizes, &x.rec}) b->release();
   decCountersClean_ = false;
   return ok();
 }
@@ -296,7 +296,7 @@ Engine::~Engine() {
   for (DevBuf* b : {&raPlan_, &raLimit_, &raPieceBase_, &raPieces_, &decFrames_, &decTables_, &decLists_, &decCounters_, &decLits_, &decSeqs_, &roundN_, &status_, &produced_, &frameMeta_, &frameOff_, &outOff_, &expect_, &result_, &temp_, &qmeta_,
                     &encScan_, &hostIn_, &hostOut_, &seqScratch_, &mfFlags_})
     b->release();
-  for (auto& x : encCtx_) for (DevBuf* b : {&x.tables, &x.seqs, &x.lits, &x.work, &x.slots, &x.misc, &x.ck, &x.sizes}) b->release();
+  for (auto& x : encCtx_) for (DevBuf* b : {&x.tables, &x.seqs, &x.lits, &x.work, &x.slots, &x.misc, &x.ck, &x.sizes, &x.rec}) b->release();
   for (auto ev : evPool_) (void)hipEventDestroy(ev);
   for (auto ev : stageEv_) (void)hipEventDestroy(ev);
   if (stream2_) { (void)hipStreamSynchronize(stream2_); (void)hipStreamDestroy(stream2_); }

@@ -150,6 +150,20 @@ struct alignas(16) ZraEncFrameState {
 // (the hash-chain finder copies ring[] as uint4: every element of an array of these, and the ring inside it, sits on 16 bytes)
 static_assert(sizeof(ZraEncFrameState) % 16 == 0 && offsetof(ZraEncFrameState, ring) % 16 == 0, "ZraEncFrameState::ring must be 16-byte aligned in arrays");
 
+#define ZRA_CHAIN_FRAMES 6u   // zra_ent_chain_kernel: frames (x 3 streams = lanes) per wave; their tables take 6 x 3.5 KiB of LDS
+// split entropy stage of the persistent pipeline (round 6): what the FRONT launch leaves per frame for zra_ent_chain_kernel and the BACK launch
+struct ZraEntRec {
+  ZraFseCTable ct[3];        // 0 LL, 1 OF, 2 ML: the block's encoding tables (valid when nChain != 0)
+  uint32_t nChain;           // sequences whose state chains are to be walked (0: none — raw or skipped block, no sequences, table error)
+  uint32_t run[3];           // stream k has a real table (not a one-symbol one)
+  uint32_t finalState[3];    // written by the chain kernel
+  uint32_t tlog[3];
+  uint32_t tblErr;
+  uint32_t opOff, lastNCountOff;   // offsets in the block content: where the sequence bitstream starts; the last table description (0xFFFFFFFF: none)
+  uint32_t newHuf, newHufMaxSym;
+  uint32_t pad_;
+};
+
 // stage 1 -> stage 2 hand-off for the block being processed
 struct ZraEncBlockOut {
   uint32_t nbSeq, lastLL, skip;    // skip: block shorter than 7 bytes, emitted raw without entropy stage
@@ -213,6 +227,7 @@ struct ZraEncArgs {
   // launch telemetry of the persistent match finder (nullptr: none), written by lane 0 of every wave: where the wave sat (XCD / SE / CU),
   // its shader cycles against the constant 100 MHz clock (the effective shader clock of the launch), frames taken per XCD
   uint64_t* mfTele;        // ZRA_TELE_WORDS u64
+  ZraEntRec* entRec;       // split entropy stage: [nFrames] records (nullptr: the one-launch stage); entWork is then per FRAME, not per workgroup
 };
 // mfTele layout (u64 words): [0] sum of shader cycles over waves, [1] sum of 100 MHz ticks over waves, [2] waves, [3] longest wave in ticks,
 // [4] earliest wave start (ticks, stored inverted for an atomic max), [5] latest wave end, [6] latest wave START, [7] earliest wave end (inverted),
