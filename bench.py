@@ -227,7 +227,29 @@ def c4_share(Z, eng, torch, dev, gib=2.0, cpu_mib=32):
         raise SystemExit("c4_share: GPU archive differs from the CPU path")
     del d_in, d_arc, d_out, d_s
     eng.release_scratch()
-    return {"workload": "%.3g GiB log-like synthetic (tests/corpus.py gen_loglike, 32 MiB tiled), frameSize=256 KiB, level 9, checksum on" % (N / GiB),
+    # roofline of this configuration's dominant kernel (zra_mf_hc_kernel, the wave-cooperative hash-chain finder): algorithmic bytes =
+    # N_in + C_out per call over its launches' HIP-event time in THIS run; traffic = HBM-side requests of the same kernel
+    # from the counter passes stored in profiles/traffic.json (c4_hc_r06: level 9 @ 256 KiB, 1 GiB), scaled by input size
+    roof = None
+    try:
+        mf_ms, nl = float(ks["mf_ms"]), max(1, int(ks["mf_launches"]))
+        alg = N + n
+        ach = alg / 1e9 / (mf_ms / 1e3) if mf_ms > 0 else 0.0
+        traffic, reqs = None, None
+        tj = json.load(open(os.path.join(HERE, "profiles", "traffic.json"))).get("c4_hc_r06")
+        if tj:
+            e = tj["zra_mf_hc_kernel"]; sc = N / float(tj["input_bytes"])
+            traffic = int((e["ea_rdreq"] * 64 + e["ea_wrreq"] * 32) * sc / nl)
+            rd_s, wr_s = e["ea_rdreq"] * sc / (mf_ms / 1e3), e["ea_wrreq"] * sc / (mf_ms / 1e3)
+            reqs = {"reads_per_s": round(rd_s / 1e9, 2), "read_ceiling_per_s": 48.3, "writes_per_s": round(wr_s / 1e9, 2), "write_ceiling_per_s": 23.0, "unit": "1e9 requests/s",
+                    "sum_of_fractions": round(rd_s / 48.3e9 + wr_s / 23.0e9, 3), "l2_hit_rate": round(e["tcc_hit"] / (e["tcc_hit"] + e["tcc_miss"]), 3),
+                    "wave_cycles_waiting": round(e["sq_wait_any"] / e["sq_wave_cycles"], 3),
+                    "note": "requests from profiles/r06_pmc_hc.txt (1 GiB of the same data and configuration) over this run's launch time; ceilings: profiles/r02_pmc_calibration.txt"}
+        roof = {"bound": "hbm", "kernel": "zra_mf_hc_kernel", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 6),
+                "traffic": traffic, "launch_ms": round(mf_ms / nl, 3), "launches_per_call": nl, "algorithmic_bytes_per_launch": int(alg / nl), "requests": reqs}
+    except Exception:
+        roof = None
+    return {"roofline": roof, "workload": "%.3g GiB log-like synthetic (tests/corpus.py gen_loglike, 32 MiB tiled), frameSize=256 KiB, level 9, checksum on" % (N / GiB),
             "compress_gibs": round(N / GiB / tc, 3), "decompress_gibs": round(N / GiB / td, 3), "compression_ratio": round(N / n, 3),
             "mf_ms": round(ks["mf_ms"], 1), "mf_launches": ks["mf_launches"],
             "cpu": {"compress_gibs": round(samp / GiB / tcpu, 4), "cores": 1, "kind": "port", "sample_mib": samp >> 20,
