@@ -404,7 +404,7 @@ def ra_latency_probe(Z, eng, d_arc, arc_size, d_in, N, qb, torch):
     return out
 
 
-def choose_comm(eng, rank, world, one_gpu, dev, dist, sharding, torch, want):
+def choose_comm(eng, rank, world, one_gpu, dev, dist, sharding, torch, want, group=None):
     """The communicator of a multi-rank run: RCCL called by the library itself (ncclAllGather / grouped ncclSend+ncclRecv on the engine's
     stream), or the host transport over torch.distributed — the fallback, and the only choice when every rank sits on one GPU (RCCL
     refuses duplicate devices). Every rank leaves with the SAME transport: one rank without an RCCL communicator sends everybody to the
@@ -421,7 +421,8 @@ def choose_comm(eng, rank, world, one_gpu, dev, dist, sharding, torch, want):
             comm.close()
             comm = None
     if comm is None:
-        comm, transport = sharding.Comm.torch_dist(eng), "torch.distributed/" + dist.get_backend()
+        comm = sharding.Comm.torch_dist(eng, group=group) if group is not None else sharding.Comm.torch_dist(eng)
+        transport = "torch.distributed/" + dist.get_backend()
     return comm, transport
 
 
@@ -469,10 +470,23 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
     Z.load()
     eng = Z.Engine(local_rank)
-    comm, transport = None, "none"
+    comm, comm_side, transport = None, None, "none"
     if world > 1:
         from zra_amd import sharding
-        comm, transport = choose_comm(eng, rank, world, one_gpu, dev, dist, sharding, torch, os.environ.get("ZRA_BENCH_TRANSPORT", "torch" if one_gpu else "rccl"))
+        want_tr = os.environ.get("ZRA_BENCH_TRANSPORT", "torch" if one_gpu else "rccl")
+        comm, transport = choose_comm(eng, rank, world, one_gpu, dev, dist, sharding, torch, want_tr)
+        # a second communicator with a stream of its own: the archive's bodies travel to the root on it WHILE the ranks serve queries from their
+        # shards on the first one (round 6; ZRA_BENCH_GATHER_SYNC=1: gather, then serve, as before). Its host transport gets a group of its own:
+        # the two communicators' collectives run from two threads.
+        if os.environ.get("ZRA_BENCH_GATHER_SYNC") != "1":
+            try:
+                g2 = dist.new_group(backend=dist.get_backend()) if not transport.startswith("rccl") else None
+                comm_side, tr2 = choose_comm(eng, rank, world, one_gpu, dev, dist, sharding, torch, want_tr if transport.startswith("rccl") else "torch", group=g2)
+                comm_side.use_own_stream()
+                transport += " + a second communicator (%s) for the gather, beside the serving" % tr2
+            except Exception as e:
+                sys.stderr.write("bench: no second communicator (%r): gather and serve in sequence\n" % (e,))
+                comm_side = None
 
     fs = args.frame_kib << 10
     N = int(args.size_gib * GiB) // fs * fs            # per-GPU bytes (weak scaling: fixed per rank)
@@ -544,7 +558,10 @@ def main():
             arc_size = step.shard.archive_size()
             if rank == 0 and (getattr(step, "root", None) is None or step.root.numel() < arc_size):
                 step.root = torch.empty(arc_size + (arc_size >> 4) + 64, dtype=torch.uint8, device=dev)
-            comm.gather_archive(step.shard, 0, step.root.data_ptr() if rank == 0 else 0, step.root.numel() if rank == 0 else 0)
+            if comm_side is not None:
+                comm_side.gather_archive_begin(step.shard, 0, step.root.data_ptr() if rank == 0 else 0, step.root.numel() if rank == 0 else 0)
+            else:
+                comm.gather_archive(step.shard, 0, step.root.data_ptr() if rank == 0 else 0, step.root.numel() if rank == 0 else 0)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         # RA over this rank's own shard (the archive stays sharded for serving; queries are routed to the owner)
@@ -555,6 +572,12 @@ def main():
             # sharded serving: this rank's queries go over the WHOLE range; slices travel to the owners, answers come back
             comm.serve(step.shard, offs, sizes, oofs, d_ra.data_ptr())
             dec_stats.append(eng.kernel_stats()); dec_stage.append(eng.decode_stage_stats())
+            if comm_side is not None:
+                t_s = time.perf_counter()
+                got = comm_side.gather_archive_end()       # one join at the end of the step
+                step.gather_wait_ms = getattr(step, "gather_wait_ms", []) + [(time.perf_counter() - t_s) * 1e3]
+                if rank == 0 and got != arc_size:
+                    raise SystemExit("gathered archive has %d bytes, the shards say %d" % (got, arc_size))
         torch.cuda.synchronize()
         t2 = time.perf_counter()
         comp_ms.append((t1 - t0) * 1e3)
@@ -741,6 +764,9 @@ def main():
                        "frame_size": fs, "level": args.level, "bytes_per_gpu": N, "queries_per_gpu": q, "query_bytes": qb,
                        "parallelism": "frames sharded by index, %d rank(s)" % world, "transport": transport, "compression_ratio": round(ratio, 3),
                        "bit_exact_gate": gate},
+            "gather_overlap": ({"mode": "gather on a second communicator's stream beside the serving, one join at the end of the step",
+                                "join_wait_ms": round(float(np.mean(getattr(step, "gather_wait_ms", [0.0])[-args.steps:])), 3)} if comm_side is not None else
+                               ({"mode": "in sequence"} if world > 1 else None)),
             "compress_gibs": round(N * world / GiB / (np.mean(comp_ms) / 1e3), 3),
             "ra_gibs_returned": round(q * qb * world / GiB / (np.mean(ra_ms) / 1e3), 3),
             "ra_us_per_query": round(np.mean(ra_ms) * 1e3 / q, 3),
@@ -781,6 +807,8 @@ def main():
         sh = getattr(step, "shard", None)
         if sh is not None:
             sh.close()
+        if comm_side is not None:
+            comm_side.close()
         comm.close()
         dist.barrier()
         dist.destroy_process_group()

@@ -151,6 +151,13 @@ ZRA_EXPORT void ZraHipShardGetBody(const ZraHipShard* shard, const void** dBody,
 /** The archive in one piece in dArchive on rank `root` (other ranks pass NULL / 0): world-1 inbound point-to-point messages in one group. */
 ZRA_EXPORT ZraStatus ZraHipCommGatherArchive(ZraHipComm* comm, const ZraHipShard* shard, int root, void* dArchive, size_t archiveCapacity,
                                              size_t* archiveSize);
+/** The gather beside other work (round 6): a SECOND communicator of the process gets a stream of its own (UseOwnStream); Begin starts
+ *  ZraHipCommGatherArchive on it (a worker thread drives the collective; every rank calls Begin and End) and returns at once, so that the
+ *  ranks can serve queries from their shards on the first communicator meanwhile (ZraHipCommServe works on the shards, not on the gathered
+ *  archive); End joins and returns the gather's status and, on the root, the archive's size. */
+ZRA_EXPORT ZraStatus ZraHipCommUseOwnStream(ZraHipComm* comm);
+ZRA_EXPORT ZraStatus ZraHipCommGatherArchiveBegin(ZraHipComm* comm, const ZraHipShard* shard, int root, void* dArchive, size_t archiveCapacity);
+ZRA_EXPORT ZraStatus ZraHipCommGatherArchiveEnd(ZraHipComm* comm, size_t* archiveSize);
 /** Sharded serving (BASELINE config C5): every rank passes its own queries over the WHOLE uncompressed range; slices go to the ranks
  *  that own the frames, are decoded there (ZraHipDecompressRABatch semantics on the shard) and come back; answer q lands at
  *  dOut + hOutOffsets[q]. Bounds as DecompressRA (zra.cpp:260). */

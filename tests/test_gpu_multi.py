@@ -83,7 +83,22 @@ def _worker(rank, world, port, fs, level, total, q):
             comm.serve(shard, offs[:50], sizes[:50], oo[:50], d_out.data_ptr())
             host = d_out.cpu().numpy().tobytes()
             empty_ok = all(host[int(oo[i]): int(oo[i]) + int(sizes[i])] == data[int(offs[i]): int(offs[i]) + int(sizes[i])] for i in range(50))
+        # round 6: the gather on a second communicator's own stream WHILE both ranks serve on the first (the sharded bench step): the
+        # archive on rank 0 and every answer as before
+        side = sharding.Comm.torch_dist(eng, group=dist.new_group(backend="gloo")).use_own_stream()
+        if rank == 0:
+            d_arc.zero_()
+        d_out.zero_()
+        side.gather_archive_begin(shard, 0, d_arc.data_ptr() if rank == 0 else 0, len(ref) + 64 if rank == 0 else 0)
+        comm.serve(shard, offs, sizes, oo, d_out.data_ptr())
+        n2 = side.gather_archive_end()
+        host = d_out.cpu().numpy().tobytes()
+        overlap_ok = all(host[int(oo[i]): int(oo[i]) + int(sizes[i])] == data[int(offs[i]): int(offs[i]) + int(sizes[i])] for i in range(nq))
+        if rank == 0:
+            overlap_ok = overlap_ok and n2 == len(ref) and d_arc[:n2].cpu().numpy().tobytes() == ref
+        same = same and overlap_ok
         q.put((rank, same, refused, served, oob, empty_ok))
+        side.close()
         shard.close(); comm.close()
         dist.barrier()
     finally:

@@ -134,6 +134,9 @@ def load():
         "ZraHipShardArchiveSize": (ctypes.c_uint64, [vp]),
         "ZraHipShardGetBody": (None, [vp, ctypes.POINTER(vp), u64p, u64p]),
         "ZraHipCommGatherArchive": (S, [vp, vp, ctypes.c_int, vp, sz, szp]),
+        "ZraHipCommUseOwnStream": (S, [vp]),
+        "ZraHipCommGatherArchiveBegin": (S, [vp, vp, ctypes.c_int, vp, sz]),
+        "ZraHipCommGatherArchiveEnd": (S, [vp, szp]),
         "ZraHipCommServe": (S, [vp, vp, u64p, u64p, u64p, sz, vp]),
     }
     for name, (res, args) in sig.items():
@@ -157,7 +160,7 @@ HIP_ABI_SYMBOLS = ["ZraHipDeviceCount", "ZraHipCreateEngine", "ZraHipDestroyEngi
                    "ZraHipCompressBuffer", "ZraHipDecompressBuffer", "ZraHipDecompressRABatch", "ZraHipCompressFrames", "ZraHipStitchHeader", "ZraHipDebugReadSeqs", "ZraHipSetOptions", "ZraHipGetOptions",
                    "ZraHipShardRange", "ZraHipOwnerOfFrame", "ZraHipRouteQueries", "ZraHipCommGetUniqueId", "ZraHipCommCreateRccl", "ZraHipCommCreateHost", "ZraHipCommLoopback", "ZraHipCommDestroy",
                    "ZraHipCommCompress", "ZraHipCommStitchSizes", "ZraHipShardDestroy", "ZraHipShardHeaderSize", "ZraHipShardGetHeader", "ZraHipShardArchiveSize", "ZraHipShardGetBody",
-                   "ZraHipCommGatherArchive", "ZraHipCommServe"]
+                   "ZraHipCommGatherArchive", "ZraHipCommUseOwnStream", "ZraHipCommGatherArchiveBegin", "ZraHipCommGatherArchiveEnd", "ZraHipCommServe"]
 
 
 def _chk(st, what=""):

@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <exception>
+#include <thread>
 #include <vector>
 
 using namespace zra_dev;
@@ -66,11 +67,16 @@ struct ZraHipComm {
   bool useHost = false;
   DevBuf stage, stage2, served, received, slices;   // grow-only scratch
   std::vector<uint8_t> hstage;
+  // round 6: a communicator may run its exchanges on a stream of its own (ZraHipCommUseOwnStream) — the second communicator of a process,
+  // whose archive gather then runs beside the first one's serving (ZraHipCommGatherArchiveBegin / End: a worker thread drives it)
+  hipStream_t own = nullptr;
+  hipStream_t st() const { return own ? own : eng->stream(); }
+  std::thread worker; ZraStatus asyncStatus{Success, 0}; size_t asyncSize = 0;
 
   // every rank contributes `bytes` bytes of host memory; `recv` gets world * bytes, rank order
   bool allgather(const void* send, void* recv, size_t bytes) {
     if (useHost) { if (world == 1) { std::memcpy(recv, send, bytes); return true; } return host.allgather(host.user, send, recv, bytes) == 0; }
-    hipStream_t st = eng->stream();
+    hipStream_t st = this->st();
     if (!stage.reserve(bytes + 64) || !stage2.reserve(bytes * world + 64)) return false;
     if (hipMemcpyAsync(stage.p, send, bytes, hipMemcpyHostToDevice, st) != hipSuccess) return false;
     if (rccl().AllGather(stage.p, stage2.p, bytes, ncclUint8, nccl, st) != ncclSuccess) return false;
@@ -81,7 +87,7 @@ struct ZraHipComm {
   // side by side, each on its own xGMI link). onDevice: the buffers are device memory.
   bool exchange(const std::vector<Xfer>& sends, const std::vector<Xfer>& recvs, bool onDevice) {
     if (sends.empty() && recvs.empty()) return true;
-    hipStream_t st = eng->stream();
+    hipStream_t st = this->st();
     if (!useHost) {
       std::vector<Xfer> s = sends, r = recvs;
       if (!onDevice) {                       // host buffers ride through device scratch
@@ -253,6 +259,8 @@ ZraStatus ZraHipCommLoopback(ZraHipComm* c, const void* dSrc, void* dDst, size_t
 void ZraHipCommDestroy(ZraHipComm* c) {
   if (!c) return;
   if (c->eng) { (void)hipSetDevice(c->eng->device()); (void)hipStreamSynchronize(c->eng->stream()); }
+  if (c->worker.joinable()) c->worker.join();
+  if (c->own) { (void)hipStreamSynchronize(c->own); (void)hipStreamDestroy(c->own); }
   if (c->nccl) (void)rccl().CommDestroy(c->nccl);
   for (DevBuf* b : {&c->stage, &c->stage2, &c->served, &c->received, &c->slices}) b->release();
   delete c;
@@ -392,8 +400,8 @@ ZraStatus ZraHipCommGatherArchive(ZraHipComm* c, const ZraHipShard* s, int root,
     if (archiveCap < hs + s->bodyTotal) st = Status{zra_eng::kOutputTooSmall, 0};
     else {
       uint8_t* d = (uint8_t*)dArchive;
-      if (hipMemcpyAsync(d, s->dev.p, hs + 0, hipMemcpyDeviceToDevice, c->eng->stream()) != hipSuccess ||
-          (s->bodyBytes && hipMemcpyAsync(d + hs + s->bodyBase, s->dev.as<uint8_t>() + hs, s->bodyBytes, hipMemcpyDeviceToDevice, c->eng->stream()) != hipSuccess))
+      if (hipMemcpyAsync(d, s->dev.p, hs + 0, hipMemcpyDeviceToDevice, c->st()) != hipSuccess ||
+          (s->bodyBytes && hipMemcpyAsync(d + hs + s->bodyBase, s->dev.as<uint8_t>() + hs, s->bodyBytes, hipMemcpyDeviceToDevice, c->st()) != hipSuccess))
         st = zra_eng::zerr(1);
       for (int r = 0; r < c->world; r++)
         if (r != root) recvs.push_back({r, d + hs + s->bodyBaseOf[r], (size_t)(s->bodyBaseOf[r + 1] - s->bodyBaseOf[r])});
@@ -403,8 +411,38 @@ ZraStatus ZraHipCommGatherArchive(ZraHipComm* c, const ZraHipShard* s, int root,
   ZraStatus agreed = c->agree(st);                     // nobody starts a transfer the root cannot take
   if (agreed.zra) return agreed;
   if (!c->exchange(sends, recvs, true)) st = zra_eng::zerr(1);
-  if (hipStreamSynchronize(c->eng->stream()) != hipSuccess) st = zra_eng::zerr(1);
+  if (hipStreamSynchronize(c->st()) != hipSuccess) st = zra_eng::zerr(1);
   return c->agree(st);
+}
+
+// The gather beside other work of the process (round 6: in a sharded step the archive's bodies travel to the root WHILE the ranks serve
+// queries from their shards — ZraHipCommServe on another communicator; the serve works on the shards, not on the gathered archive).
+// `c` must be a communicator with a stream of its own (ZraHipCommUseOwnStream) that no other call uses until End returns; Begin returns
+// at once, a worker thread runs ZraHipCommGatherArchive (collective: every rank calls Begin and End); End joins it and returns its status.
+ZraStatus ZraHipCommUseOwnStream(ZraHipComm* c) {
+  if (!c || !c->eng) return mk(ZStdError, 42);
+  if (c->own) return mk(Success);
+  if (hipSetDevice(c->eng->device()) != hipSuccess || hipStreamCreateWithFlags(&c->own, hipStreamNonBlocking) != hipSuccess) { c->own = nullptr; (void)hipGetLastError(); return mk(ZStdError, 1); }
+  return mk(Success);
+}
+ZraStatus ZraHipCommGatherArchiveBegin(ZraHipComm* c, const ZraHipShard* s, int root, void* dArchive, size_t archiveCap) {
+  if (!c || !c->eng || !c->own || c->worker.joinable()) return mk(ZStdError, 42);
+  // what the caller queued on the engine's stream (the shard's frames, the destination buffer) is done before the side stream touches it
+  if (hipSetDevice(c->eng->device()) != hipSuccess || hipStreamSynchronize(c->eng->stream()) != hipSuccess) return mk(ZStdError, 1);
+  c->asyncStatus = mk(Success); c->asyncSize = 0;
+  try {
+    c->worker = std::thread([c, s, root, dArchive, archiveCap]() {
+      (void)hipSetDevice(c->eng->device());
+      c->asyncStatus = ZraHipCommGatherArchive(c, s, root, dArchive, archiveCap, &c->asyncSize);
+    });
+  } catch (const std::exception&) { return mk(ZStdError, 64); }
+  return mk(Success);
+}
+ZraStatus ZraHipCommGatherArchiveEnd(ZraHipComm* c, size_t* archiveSize) {
+  if (!c || !c->worker.joinable()) return mk(ZStdError, 42);
+  c->worker.join();
+  if (archiveSize) *archiveSize = c->asyncSize;
+  return c->asyncStatus;
 }
 
 // (A transport failure — an allgather or exchange that returns false — leaves the ranks out of step: the call returns {ZStdError, 1}

@@ -190,6 +190,22 @@ class Comm:
         Z._chk(self.L.ZraHipCommGatherArchive(self.h, shard.h, root, d_archive, capacity, ctypes.byref(n)), "ZraHipCommGatherArchive")
         return n.value
 
+    def use_own_stream(self):
+        """ZraHipCommUseOwnStream: this (second) communicator's exchanges run on a stream of its own, beside the engine's."""
+        Z._chk(self.L.ZraHipCommUseOwnStream(self.h), "ZraHipCommUseOwnStream")
+        return self
+
+    def gather_archive_begin(self, shard, root=0, d_archive=0, capacity=0):
+        """ZraHipCommGatherArchiveBegin: the gather starts on this communicator's own stream and the call returns; serve on ANOTHER
+        communicator meanwhile, then gather_archive_end()."""
+        self._order()
+        Z._chk(self.L.ZraHipCommGatherArchiveBegin(self.h, shard.h, root, d_archive, capacity), "ZraHipCommGatherArchiveBegin")
+
+    def gather_archive_end(self):
+        n = ctypes.c_size_t(0)
+        Z._chk(self.L.ZraHipCommGatherArchiveEnd(self.h, ctypes.byref(n)), "ZraHipCommGatherArchiveEnd")
+        return n.value
+
     def loopback(self, d_src, d_dst, nbytes):
         """ZraHipCommLoopback: nbytes from d_src to d_dst through the RCCL point-to-point path, this rank to itself (diagnostic)."""
         self._order()
