@@ -898,16 +898,21 @@ def test_foreign_frame_size_does_not_cost_a_pass_per_frame(zra):
                                  {"ZRA_PIPE": "0"}, {"ZRA_PIPE": "2"}, {"ZRA_PIPE": "2", "ZRA_ENC_RING": "2", "ZRA_ENT_WGS": "2"},
                                  {"ZRA_DEC_SMALL_MAX": "0", "ZRA_DEC_CHAIN_LDS_MIN": "1", "ZRA_DEC_CHAIN_LDS": "2"},
                                  {"ZRA_MF_LS": "0", "ZRA_MF_WAVES": "1"}, {"ZRA_MF_LS": "0", "ZRA_MF_EPOCH": "0"},
-                                 {"ZRA_ENT_SPLIT": "2"}, {"ZRA_ENT_SPLIT": "2", "ZRA_MF_LS": "0"}, {"ZRA_ENT_SPLIT": "0"}],
+                                 {"ZRA_ENT_SPLIT": "2"}, {"ZRA_ENT_SPLIT": "2", "ZRA_MF_LS": "0"}, {"ZRA_ENT_SPLIT": "0"},
+                                 {"ZRA_DEC_SMALL_MAX": "0", "ZRA_DEC_FMB_MIN": "1"}, {"ZRA_DEC_SMALL_MAX": "0", "ZRA_DEC_FMB": "0"}],
                          ids=["dfast-without-bucket-flags", "dfast-other-pipeline-geometry", "decode-stage-pipeline", "dfast-small-calls-from-memory", "dfast-all-calls-from-lds",
                               "hash-chain-over-poisoned-scratch", "dfast-stages-in-sequence", "dfast-resident-entropy-stage", "dfast-resident-entropy-small-ring",
                               "decode-lds-table-chain-kernel-alone", "dfast-one-wave-per-cu-many-epochs", "dfast-tables-cleared-per-frame",
-                              "entropy-front-chain-back-on-every-call", "entropy-front-chain-back-table-finder", "entropy-one-launch-on-every-call"])
+                              "entropy-front-chain-back-on-every-call", "entropy-front-chain-back-table-finder", "entropy-one-launch-on-every-call",
+                              "decode-block-parallel-pass-on-every-call", "decode-rounds-only"])
 def test_opt_in_kernels_are_bit_exact_too(env):
     """The paths of the library that a default call of the test sizes does not take give the same bytes as the ones it does: the dfast table
     kernel without its bucket flags (round 5: the flags are on by default for calls beyond the LDS-source kernel's size), the persistent
     pipeline with another geometry (18 waves per CU, one entropy workgroup per CU, a slot ring of two sub-batches) and in its other two
     modes (stages in sequence; one resident entropy launch that scans and gathers itself), the decode stage pipeline, the sequence-chain
+    (round 6) the decoder's block-parallel pass for frames of several blocks (every compressed block a job of the Huffman and chain stages,
+    repeat offsets as markers, a bail list for anything but clean frames) forced onto calls of every size — by default it takes calls of
+    more than 1,024 jobs — with the damaged-archive, header-damage and random-access cases, and switched off;
     (round 6) the entropy stage as three launches per sub-batch — front, state chains with lane = (frame, stream), back — forced onto calls of
     every size (by default: calls of 256 frames and more) and switched off; the epoch cells of the dfast table kernel with one wave per CU
     (every wave through many epochs) and switched off; kernel with its tables (two-byte cells) and bitstream rings in LDS ALONE on every job (by default it takes a share of large passes only), the two dfast kernels — frame source read from memory / from a copy in LDS — each forced onto the call sizes the other one
@@ -918,6 +923,7 @@ def test_opt_in_kernels_are_bit_exact_too(env):
     again, in a fresh process with the knob set."""
     import subprocess
     sel = "randomised_differential_decode or golden_frames" if "ZRA_DEC_PIPE" in env else \
+          "randomised_differential_decode or randomised_corruption_statuses or random_access_on_damaged or ra_vs_bruteforce or golden_frames or libzstd_frames or frames_larger_than_the_window or inflated_frame_size or randomised_header_damage or randomised_batched_random_access or (compress_buffer_bit_exact and (262144 or 524288 or 1048576 or 2097152 or 400000 or 300000 or 200000))" if "ZRA_DEC_FMB_MIN" in env or "ZRA_DEC_FMB" in env else \
           "randomised_differential_decode or randomised_corruption_statuses or random_access_on_damaged or ra_vs_bruteforce or golden_frames or libzstd_frames" if "ZRA_DEC_CHAIN_LDS" in env else \
           "compress_buffer_bit_exact and (5-65536 or 9-65536 or 7-16384 or 10-) or short_last_frame or frames_larger_than_the_window" if "ZRA_ENC_POISON" in env else \
           "compress_buffer_bit_exact and (3-65536 or 4-65536 or 3-16384 or 0-16384) or sub_batch_boundaries or short_last_frame or match_finder_sequences and (3-65536 or 3-16384) or randomised_differential_compress"

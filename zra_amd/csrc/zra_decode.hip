@@ -134,6 +134,8 @@ __device__ __forceinline__ void wsync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 __device__ __forceinline__ u32 bcast_u32(u32 v, u32 l) { return (u32)__builtin_amdgcn_readlane((int)v, (int)l); }
+// the frame a job belongs to: jobs are frames — or, in the block-parallel pass (a.bpf > 1), blocks: job = frame * bpf + ordinal
+__device__ __forceinline__ size_t frame_of(const ZraDecodeArgs& a, u32 j) { return a.bpf > 1 ? (size_t)(j / a.bpf) : (size_t)j; }
 __device__ __forceinline__ u32 rfl(u32 v) { return (u32)__builtin_amdgcn_readfirstlane((int)v); }
 // lane l of `old` := val (val and l wave-uniform): v_writelane_b32 with the lane select in M0
 __device__ __forceinline__ u32 wrlane_d(u32 old, u32 val, u32 l) {
@@ -668,7 +670,14 @@ __device__ __forceinline__ void frame_finish(const ZraDecodeArgs& a, u32 j, cons
 // outcome comes back as a code: 0 = the frame is finished (frame_finish has run), 1 = a compressed block was handed on,
 // 2 = no scratch for it in this round.
 namespace {
-template <bool FUSED>
+// ALL (round 6, the block-parallel pass for frames of several blocks, zra_dec_parse_all_kernel): the wave walks ALL blocks of the frame in
+// one go instead of one per round. Every compressed block becomes a job of its own for the Huffman and chain stages (record and tables
+// in a.blkRecs / a.blkTables at frame * bpf + ordinal), on two assumptions that the execute stage verifies and that hold for every frame
+// zstd itself writes: a compressed block that is not the frame's last regenerates ZRA_FMB_BLOCK bytes (so the next block's place in the
+// output is known), and nothing is wrong with the frame. A frame that breaks either — or needs more block jobs than bpf, the long-offset
+// mode, more scratch than there is — goes on the bail list (a.nextActive) and takes the classic rounds afterwards, where every status of
+// the reference is reproduced. A block's initial repeat offsets are markers (ZRA_REP_MARK) from the second compressed block on.
+template <bool FUSED, bool ALL = false>
 __device__ __forceinline__ u32 parse_job(const ZraDecodeArgs& a, const u32 j, ParseShared& S, const int lane, u32* ldsT) {
   u32 outcome = 0;
   {
@@ -680,6 +689,8 @@ __device__ __forceinline__ u32 parse_job(const ZraDecodeArgs& a, const u32 j, Pa
     const u32 dstCap = a.outCap[j];
     const u32 limit = a.limit ? a.limit[j] : 0xFFFFFFFFu;
     ZraDecFrame* const F = &a.frames[j];
+    u32 nBlk = 0; bool bail = false;                     // ALL: compressed blocks handed on so far; the frame leaves the pass
+    const u32* prevT[3] = {nullptr, nullptr, nullptr};  // ALL: the block tables that hold the current LL / ML / OF table (repeat mode copies from there)
 
     // copy of [pos, pos + STAGE_BYTES) of the frame (clipped to its end) into an LDS window: one coalesced load for the wave
     auto stage = [&](u8* w, u32 pos) -> u32 {
@@ -756,7 +767,7 @@ __device__ __forceinline__ u32 parse_job(const ZraDecodeArgs& a, const u32 j, Pa
     wsync();
 
     // what a frame carries from round to round (lane 0)
-    auto save_persistent = [&](u32 blkPos, u32 produced, u32 hv, u32 hmb, u32 hns, u32 hx2) {
+    auto save_persistent_to = [&](ZraDecFrame* F, u32 blkPos, u32 produced, u32 hv, u32 hmb, u32 hns, u32 hx2) {
       F->blkPos = blkPos; F->produced = produced; F->done = 0;
       F->hufValid = hv ? 1u : 0u; F->hufMaxBits = hmb; F->hufNSym = hns; F->hufX2 = hx2;
       F->llValid = S.llValid; F->mlValid = S.mlValid; F->ofValid = S.ofValid; F->llLog = S.llLog; F->mlLog = S.mlLog; F->ofLog = S.ofLog;
@@ -764,6 +775,8 @@ __device__ __forceinline__ u32 parse_job(const ZraDecodeArgs& a, const u32 j, Pa
       F->rep[0] = S.rep[0]; F->rep[1] = S.rep[1]; F->rep[2] = S.rep[2];
       F->fcsLo = S.fcsLo; F->fcsHi = S.fcsHi; F->fcsHave = S.fcsHave; F->hasChecksum = S.hasChecksum; F->bigWindow = S.bigWindow;
     };
+    auto save_persistent = [&](u32 blkPos, u32 produced, u32 hv, u32 hmb, u32 hns, u32 hx2) { save_persistent_to(F, blkPos, produced, hv, hmb, hns, hx2); };
+    if (ALL && S.bigWindow) bail = true;                 // (the long-offset sequence loop: the classic rounds)
 
     // ------------------------------------------------------------------ block loop: until a compressed block is handed on,
     //                                                                    the frame ends, or an error stops it
@@ -771,7 +784,7 @@ __device__ __forceinline__ u32 parse_job(const ZraDecodeArgs& a, const u32 j, Pa
     for (;;) {
       const bool stop = S.err || S.frameEnd;    // sampled by every lane before lane 0 may overwrite it
       wsync();
-      if (stop) break;
+      if (stop || (ALL && bail)) break;
       if (S.produced >= limit) { truncated = true; break; }        // random access: every byte a query needs exists
       // the header window must hold this block's header, literals header and tree description (<= 160 bytes) or reach the frame's end
       if (S.blkPos < S.winPos || S.blkPos + 160 > S.winPos + S.winLen) {
@@ -862,6 +875,7 @@ __device__ __forceinline__ u32 parse_job(const ZraDecodeArgs& a, const u32 j, Pa
         }
       }
       wsync();
+      if (ALL && (!S.alloc || nBlk >= a.bpf)) { bail = true; break; }      // (no scratch for the whole frame at once / more blocks than jobs)
       if (!S.alloc) {
         // this round's scratch is full: the frame keeps its state as of this block's header and takes the next round
         if (lane == 0) {
@@ -876,7 +890,8 @@ __device__ __forceinline__ u32 parse_job(const ZraDecodeArgs& a, const u32 j, Pa
       PPROF(10)
       // ---- sequence decode tables: lane 0 parses each description, the wave builds it in LDS and stores it to the table scratch
       const u32 nbSeq = S.nbSeq, regen = S.litRegen;
-      u32* const T = a.tables + (size_t)j * ZRA_DEC_TBL_WORDS;
+      const size_t jb = ALL ? (size_t)j * a.bpf + nBlk : (size_t)j;
+      u32* const T = ALL ? a.blkTables + jb * ZRA_DEC_TBL_WORDS : a.tables + (size_t)j * ZRA_DEC_TBL_WORDS;
       if (nbSeq) {
         for (int kind = 0; kind < 3; kind++) {
           const int k = kind == 0 ? 0 : kind == 1 ? 2 : 1;          // wire order is LL, OF, ML
@@ -917,12 +932,46 @@ __device__ __forceinline__ u32 parse_job(const ZraDecodeArgs& a, const u32 j, Pa
           if (lane == 0 && mode != 3) {
             if (k == 0) { S.llLog = tl; S.llValid = 1; } else if (k == 1) { S.mlLog = tl; S.mlValid = 1; } else { S.ofLog = tl; S.ofValid = 1; }
           }
+          if (ALL) {
+            // a repeated table lives in the tables of the block that built it: into this block's own
+            if (mode == 3 && prevT[k] && prevT[k] != G) {
+              const u32 lg = k == 0 ? S.llLog : k == 1 ? S.mlLog : S.ofLog;
+              for (u32 i = lane; i < (1u << lg); i += DEC_THREADS) G[i] = prevT[k][i];
+            }
+            prevT[k] = G;
+          }
           wsync();
           PPROF(12)
         }
       }
 
       // ---- hand the block on: persistent state + the block record; Huffman-coded literals go through the Huffman kernel first
+      if (ALL) {
+        ZraDecFrame* const D = &a.blkRecs[jb];
+        if (lane == 0) {
+          save_persistent_to(D, S.hdrPos, produced0, S.hufValid, S.hufMaxBits, S.hufNSym, S.hufX2);
+          if (nBlk) { D->rep[0] = ZRA_REP_MARK(0); D->rep[1] = ZRA_REP_MARK(1); D->rep[2] = ZRA_REP_MARK(2); }
+          D->bpos = bpos; D->bsize = bsize; D->blast = S.blkLast;
+          D->litKind = S.litKind; D->litRegen = regen; D->litArg = S.litArg; D->litBase = S.litBase;
+          D->litStreams = S.litStreams;
+          for (int k = 0; k < 4; k++) { D->streamOff[k] = S.streamOff[k]; D->streamLen[k] = S.streamLen[k]; }
+          D->hufErr = 0; D->lateErr = S.lateErr;
+          D->nbSeq = S.lateErr ? 0u : nbSeq; D->seqPos = S.seqPos; D->seqBase = S.seqBase;
+          D->longMode = 0;
+          D->chainErr = 0; D->nSeqValid = 0; D->seqOut = 0; D->seqLit = 0; D->truncated = 0;
+          a.pending[atomicAdd(&a.counters[ZRA_DC_NPENDING], 1u)] = (u32)jb;
+          if (S.litKind == 2) a.hufJobs[atomicAdd(&a.counters[ZRA_DC_NHUF], 1u)] = (u32)jb;
+          // where the next block goes: this one regenerates a whole block unless it is the frame's last (the execute stage checks)
+          S.produced = produced0 + (S.blkLast ? 0u : ZRA_FMB_BLOCK); S.blkPos = bpos + bsize; S.frameEnd = S.blkLast;
+        }
+        if (S.litKind == 2) {                             // the tree in use (new, or kept from an earlier block of this walk) travels with the block
+          for (u32 i = lane; i < 256; i += DEC_THREADS) { D->weights[i] = S.weights[i]; D->hufStart[i] = S.hufStart[i]; }
+        }
+        if (S.lateErr) bail = true;                       // (a status of the reference: the classic rounds report it)
+        nBlk++;
+        wsync();
+        continue;
+      }
       if (lane == 0) {
         save_persistent(S.hdrPos, produced0, S.hufValid, S.hufMaxBits, S.hufNSym, S.hufX2);
         F->bpos = bpos; F->bsize = bsize; F->blast = S.blkLast;
@@ -945,7 +994,17 @@ __device__ __forceinline__ u32 parse_job(const ZraDecodeArgs& a, const u32 j, Pa
       PPROF(13)
       break;
     }
-    if (!handed) {
+    if (ALL) {
+      if (bail || (S.err && nBlk)) {
+        if (lane == 0) a.nextActive[atomicAdd(&a.counters[ZRA_DC_NNEXT], 1u)] = j;
+      } else if (nBlk == 0) {
+        frame_finish(a, j, src, srcSize, S.err, S.produced, S.blkPos, truncated, S.fcsHave, S.fcsLo, S.fcsHi, S.hasChecksum, lane);
+      } else if (lane == 0) {
+        save_persistent(S.blkPos, S.produced, S.hufValid, S.hufMaxBits, S.hufNSym, S.hufX2);
+        F->nBlk = nBlk; F->endPos = S.blkPos; F->parseTrunc = truncated ? 1u : 0u;
+        a.execList[atomicAdd(&a.counters[ZRA_DC_NEXEC], 1u)] = j;
+      }
+    } else if (!handed) {
       frame_finish(a, j, src, srcSize, S.err, S.produced, S.blkPos, truncated, S.fcsHave, S.fcsLo, S.fcsHi, S.hasChecksum, lane);
     }
     wsync();
@@ -973,6 +1032,21 @@ zra_dec_parse_kernel(ZraDecodeArgs a) {
     wsync();
     if (qi >= nActive) return;
     (void)parse_job<false>(a, a.active ? a.active[qi] : qi, S, lane, nullptr);
+  }
+}
+
+// the block-parallel pass's parse: every block of every frame in one launch (parse_job<.., ALL>)
+extern "C" __global__ void __launch_bounds__(DEC_THREADS, ZRA_PARSE_WAVES)
+zra_dec_parse_all_kernel(ZraDecodeArgs a) {
+  __shared__ ParseShared S;
+  const int lane = threadIdx.x;
+  for (;;) {
+    if (lane == 0) S.job = atomicAdd(&a.counters[ZRA_DC_QPARSE], 1u);
+    wsync();
+    const u32 qi = S.job;
+    wsync();
+    if (qi >= a.nActive) return;
+    (void)parse_job<false, true>(a, a.active ? a.active[qi] : qi, S, lane, nullptr);
   }
 }
 
@@ -1108,7 +1182,7 @@ __device__ __forceinline__ bool huf_decode_stream(const ZraDecodeArgs& a, ZraDec
   const u32 seg = nStreams == 1 ? regen : (regen + 3) / 4;
   const u32 myLen = nStreams == 1 ? regen : (strm < 3 ? seg : regen - 3 * seg);
   u8* o = a.lits + F->litBase + (size_t)strm * seg;
-  const u8* const blk = a.body + a.frameOff[(size_t)j * a.offStride] + F->bpos;
+  const u8* const blk = a.body + a.frameOff[frame_of(a, j) * a.offStride] + F->bpos;
   const u8* const sb = blk + F->streamOff[strm]; const u32 sl = F->streamLen[strm];
   const int mb = (int)F->hufMaxBits;
 #ifndef ZRA_HUF_READER_AHEAD
@@ -1150,7 +1224,7 @@ __device__ __forceinline__ bool huf_decode_wave(const ZraDecodeArgs& a, const Zr
   const u32 strm = nStreams == 1 ? 0u : (u32)lane >> 4, t = (u32)lane & (L - 1);
   const u32 seg = nStreams == 1 ? regen : (regen + 3) / 4;
   const u32 myLen = nStreams == 1 ? regen : (strm < 3 ? seg : regen - 3 * seg);
-  const u8* const blk = a.body + a.frameOff[(size_t)j * a.offStride] + F->bpos;
+  const u8* const blk = a.body + a.frameOff[frame_of(a, j) * a.offStride] + F->bpos;
   const u8* const sb = blk + F->streamOff[strm]; const u32 sl = F->streamLen[strm];
   const u32 last = sl ? (u32)sb[sl - 1] : 0u;
   if (__ballot(last == 0)) return false;
@@ -1432,13 +1506,13 @@ __device__ __forceinline__ void chain_body(const ZraDecodeArgs& a, u32* const ld
         if (idx >= nPend) drained = true;
         else {
           const u32 j = a.pending[idx];
-          const size_t gj = j;
+          const size_t gj = frame_of(a, j);               // (block-parallel pass: the job is a block, gj its frame)
           F = &a.frames[j];
           T = a.tables + (size_t)j * ZRA_DEC_TBL_WORDS;
           const u8* const blk = a.body + a.frameOff[gj * a.offStride] + F->bpos;
           nbSeq = F->nbSeq; regen = F->litRegen; produced0 = F->produced; longMode = F->longMode;
-          outCap = a.outCap[j] - produced0;
-          limit = a.limit ? a.limit[j] : 0xFFFFFFFFu;
+          outCap = a.outCap[gj] - produced0;
+          limit = a.limit ? a.limit[gj] : 0xFFFFFFFFu;
           sq = a.seqs + F->seqBase;
           rep0 = F->rep[0]; rep1 = F->rep[1]; rep2 = F->rep[2];
           i = 0; outPos = 0; litPos = 0; err = 0; jErr = 0xFFFFFFFFu; valid = 0; validOut = 0; validLit = 0; truncated = 0;
@@ -1507,8 +1581,10 @@ __device__ __forceinline__ void chain_body(const ZraDecodeArgs& a, u32* const ld
         u32 ll = baseLL[c_code(eL)], ml = baseML[c_code(eM)], off;
         const u32 ofBits = LDSTAB ? c_code(eO) : (eO >> 8) & 0xFF, mlBits = LDSTAB ? ml >> 24 : (eM >> 8) & 0xFF, llBits = LDSTAB ? ll >> 24 : (eL >> 8) & 0xFF;
         if (LDSTAB) { ll &= 0xFFFFFFu; ml &= 0xFFFFFFu; }
+        bool badOff = false;
         if (ofBits > 1) {
           off = ((1u << ofBits) - 3u) + br.read_fast(ofBits);
+          if (a.bpf > 1 && off >= ZRA_REP_MARK_LO) badOff = true;      // (block-parallel pass: beyond any frame it takes — and it would read as a marker)
           rep2 = rep1; rep1 = rep0; rep0 = off;
         } else {
           const u32 ll0 = (ll == 0);                       // the BASE value (code 0)
@@ -1537,7 +1613,7 @@ __device__ __forceinline__ void chain_body(const ZraDecodeArgs& a, u32* const ld
           u32 e = 0;
           if (ll + ml > outCap - outPos) e = ZE_DSTSIZE_TOOSMALL;
           else if (ll > regen - litPos) e = ZE_CORRUPTION;
-          else if (off > produced0 + outPos + ll) e = ZE_CORRUPTION;
+          else if (badOff || (off > produced0 + outPos + ll && !(a.bpf > 1 && off >= ZRA_REP_MARK_LO))) e = ZE_CORRUPTION;   // (a marker: the execute stage checks the value it stands for)
           if (e) { jErr = i; err = e; if (!longMode) finish(); }
           else {
             const u64 qv = (u64)ll | ((u64)ml << 18) | ((u64)min(off, 0x0FFFFFFFu) << 36);
@@ -1882,6 +1958,97 @@ zra_dec_exec_kernel(ZraDecodeArgs a) {
     wsync();
     if (qi >= nPend) return;
     (void)exec_job<false>(a, a.pending[qi], S, lane);
+  }
+}
+
+// ---- block-parallel pass (round 6): the execute stage of a WHOLE frame — its compressed blocks in order (zra_dec_parse_all_kernel made
+// each one a job of the Huffman and chain stages; raw and RLE blocks are in place already). What the chain stage could not know is settled
+// here: a block's initial repeat offsets (the previous block's last three: markers in the sequences and in repOut get their values, and a
+// marker's offset is checked against the bytes that exist), and that every compressed block but the frame's last regenerated a whole
+// block (its successors were placed on that assumption). Anything else than a clean frame — a stage reported an error, a check fails —
+// puts the frame on the bail list: the classic rounds decode it again and report what the reference reports.
+namespace {
+__device__ __forceinline__ void exec_frame_all(const ZraDecodeArgs& a, const u32 j, ExecShared& S, const int lane) {
+  ZraDecFrame* const F = &a.frames[j];
+  const u32 nBlk = F->nBlk;
+  const u64 so = a.frameOff[(size_t)j * a.offStride], se = a.frameOff[(size_t)j * a.offStride + 1];
+  const u8* const src = a.body + so; const u32 srcSize = (u32)(se - so);
+  u32 C0 = 1, C1 = 4, C2 = 8;                           // the repeat offsets at the start of the block being executed
+  auto resolve = [&](u32 v) -> u32 {
+    if (v < ZRA_REP_MARK_LO) return v;
+    const u32 k = (v - ZRA_REP_MARK_LO) >> 24, d = ZRA_REP_MARK(k) - v, ck = k == 0 ? C0 : k == 1 ? C1 : C2;
+    return ck > d ? ck - d : 1u;                        // "offset - 1" d times, each time "0 -> 1"
+  };
+  bool bail = false, truncated = false;
+  u32 produced = 0;
+  for (u32 b = 0; b < nBlk; b++) {
+    ZraDecFrame* const R = &a.blkRecs[(size_t)j * a.bpf + b];
+    if (R->hufErr | R->lateErr | R->chainErr) { bail = true; break; }
+    ExecCtx c;
+    c.src = src; c.srcSize = srcSize; c.produced0 = R->produced;
+    c.out = a.out + a.outOff[j] + c.produced0;
+    c.litKind = R->litKind; c.regen = R->litRegen;
+    c.lit = c.litKind == 2 ? a.lits + R->litBase : c.src + R->litArg;
+    c.rleByte = (u8)R->litArg;
+    c.outBase = 0; c.litBase = 0; c.preValid = false;
+    const u32 nSeq = R->nSeqValid;
+    const u64* const sq = a.seqs + R->seqBase;
+    bool bad = false;
+    u64 qNext = (u32)lane < nSeq ? sq[lane] : (1ull << 36);
+    for (u32 first = 0; first < nSeq; first += BATCH) {
+      const u32 cnt = min((u32)BATCH, nSeq - first);
+      const bool act = (u32)lane < cnt;
+      const u64 q = qNext;
+      qNext = first + BATCH + (u32)lane < nSeq ? sq[first + BATCH + lane] : (1ull << 36);
+      const u32 ll = (u32)q & 0x3FFFFu, ml = (u32)(q >> 18) & 0x3FFFFu, offRaw = (u32)(q >> 36);
+      const u32 tot = ll + ml;
+      const u32 incT = dpp_scan_add(tot), incL = dpp_scan_add(ll);
+      const u32 oStart = c.outBase + incT - tot;
+      const u32 off = resolve(offRaw);
+      if (__ballot(act && offRaw >= ZRA_REP_MARK_LO && off > c.produced0 + oStart + ll)) { bad = true; break; }
+      exec_step(c, S, ll, ml, off, oStart, c.litBase + incL - ll, act, lane, a.debugSkip);
+      c.outBase += bcast_u32(incT, 63); c.litBase += bcast_u32(incL, 63);
+    }
+    if (bad) { bail = true; break; }
+    u32 blockOut = c.outBase;
+    const u32 trunc = R->truncated;
+    if (!trunc) {
+      const u32 tail = c.regen - c.litBase;
+      if (c.litKind == 1) fill_bytes(c.out + c.outBase, c.rleByte, tail, lane, DEC_THREADS);
+      else copy_bytes(c.out + c.outBase, c.lit + c.litBase, tail, lane, DEC_THREADS);
+      blockOut += tail;
+    }
+    wsync();
+    if (!trunc && !R->blast && blockOut != ZRA_FMB_BLOCK) { bail = true; break; }      // (its successors were placed behind a whole block)
+    produced = c.produced0 + blockOut;
+    if (trunc) { truncated = true; break; }
+    const u32 n0 = resolve(R->repOut[0]), n1 = resolve(R->repOut[1]), n2 = resolve(R->repOut[2]);
+    C0 = n0; C1 = n1; C2 = n2;
+  }
+  if (bail) {
+    if (lane == 0) a.nextActive[atomicAdd(&a.counters[ZRA_DC_NNEXT], 1u)] = j;
+    wsync();
+    return;
+  }
+  // raw / RLE blocks behind the last compressed one are counted in the frame record's (assumed, now verified) total
+  const u32 total = max(produced, F->produced);
+  frame_finish(a, j, src, srcSize, 0, total, F->endPos, truncated || F->parseTrunc != 0, F->fcsHave, F->fcsLo, F->fcsHi, F->hasChecksum, lane);
+  wsync();
+}
+}  // namespace
+
+extern "C" __global__ void __launch_bounds__(DEC_THREADS, ZRA_EXEC_WAVES)
+zra_dec_exec_all_kernel(ZraDecodeArgs a) {
+  __shared__ ExecShared S;
+  const int lane = threadIdx.x;
+  const u32 nExec = a.counters[ZRA_DC_NEXEC];
+  for (;;) {
+    if (lane == 0) S.job = atomicAdd(&a.counters[ZRA_DC_QEXECALL], 1u);
+    wsync();
+    const u32 qi = S.job;
+    wsync();
+    if (qi >= nExec) return;
+    exec_frame_all(a, a.execList[qi], S, lane);
   }
 }
 

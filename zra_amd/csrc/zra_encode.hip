@@ -792,6 +792,41 @@ Status Engine::decode_host(const uint8_t* hSpan, size_t spanSize, const std::vec
     Status s = decode_host_pipelined(hSpan, starts, ends, frameSize, total, hOut, &fallBack);
     if (!fallBack) return s;
   }
+  // ---- small calls (round 6; the reference's own calling convention, one query of a few KiB through ZraDecompressRA): the four pageable
+  // host-to-device copies (each staged and waited for by the runtime), the synchronisation behind them and the pageable copy back were
+  // ~40 % of such a call. Here the job arrays and the compressed span travel in ONE copy from page-locked memory, the kernel is queued
+  // straight behind it, and the answer comes back through page-locked memory: one copy in, one launch, one copy out, one wait.
+  constexpr size_t kSmallSpan = 768u << 10, kSmallOut = 1u << 20, kSmallJobs = 16;
+  static const bool smallHostOff = std::getenv("ZRA_HOST_SMALL") && std::atoi(std::getenv("ZRA_HOST_SMALL")) == 0;
+  if (!smallHostOff && !wholeArchive && nFrames <= kSmallJobs && spanSize <= kSmallSpan && size <= kSmallOut && (uint64_t)nFrames * frameSize <= (64ull << 20)) {
+    const size_t metaBytes = (size_t)kSmallJobs * (16 + 8 + 4 + 4);                   // frameOff pairs, outOff, expect (padded)
+    const size_t inBytes = metaBytes + ((spanSize + 63) & ~(size_t)63);
+    if (!pinSmall_) {
+      void* pq = nullptr;
+      if (hipHostMalloc(&pq, metaBytes + kSmallSpan + 64 + kSmallOut + 64, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); pq = nullptr; }
+      pinSmall_ = (uint8_t*)pq;
+    }
+    if (pinSmall_ && hostIn_.reserve(metaBytes + kSmallSpan + 128) && hostOut_.reserve((size_t)nFrames * frameSize + 64)) {
+      uint8_t* const hp = pinSmall_;
+      std::memcpy(hp, se.data(), se.size() * 8);
+      std::memcpy(hp + kSmallJobs * 16, oo.data(), (size_t)nFrames * 8);
+      std::memcpy(hp + kSmallJobs * 24, ex.data(), (size_t)nFrames * 4);
+      std::memcpy(hp + metaBytes, hSpan, spanSize);
+      uint8_t* const dIn = hostIn_.as<uint8_t>();
+      HIPCHK(hipMemcpyAsync(dIn, hp, inBytes, hipMemcpyHostToDevice, stream_));
+      Status s = decode_jobs(dIn + metaBytes, spanSize, (const uint64_t*)dIn, hostOut_.as<uint8_t>(), (const uint64_t*)(dIn + kSmallJobs * 16),
+                             (const uint32_t*)(dIn + kSmallJobs * 24), nFrames, frameSize, 2, 0);
+      if (s.zra) return s;
+      if (skip + size > (uint64_t)nFrames * frameSize) return {kOutOfBounds, 0};
+      if (size) {
+        uint8_t* const ho = pinSmall_ + metaBytes + kSmallSpan + 64;
+        HIPCHK(hipMemcpyAsync(ho, hostOut_.as<uint8_t>() + skip, size, hipMemcpyDeviceToHost, stream_));
+        HIPCHK(hipStreamSynchronize(stream_));
+        std::memcpy(hOut, ho, size);
+      }
+      return ok();
+    }
+  }
   // whole-archive mode never writes at or beyond `total` (slots past it have no room), whatever the header's frameSize claims
   if (!hostIn_.reserve(spanSize + 64) || !hostOut_.reserve((wholeArchive ? (size_t)total : (size_t)nFrames * frameSize) + 64) || !frameOff_.reserve(se.size() * 8) ||
       !outOff_.reserve((size_t)nFrames * 8) || !expect_.reserve((size_t)nFrames * 4))

@@ -137,7 +137,9 @@ class Engine {
   hipEvent_t evR_[17] = {nullptr};   // per-round events of one encode batch: e[2r] before mf, e[2r+1] between, e[2r+2] after entropy
   // decode scratch
   DevBuf decFrames_, decTables_, decLists_, decCounters_, decLits_, decSeqs_, roundN_;
+  DevBuf decBlkRecs_, decBlkTables_, decBlkLists_;   // block-parallel pass (frames of several blocks): per-block records, tables, job lists
   DevBuf raPlan_, raLimit_, raPieceBase_, raPieces_;
+  uint8_t* pinSmall_ = nullptr;             // page-locked staging of small host-pointer decodes (decode_host: job arrays + compressed span in, answer out)
   uint64_t* pinQ_ = nullptr; size_t pinQCap_ = 0;   // page-locked query tuples of the running batch (host side of an asynchronous copy)
   int decOccParse_ = 0, decOccExec_ = 0, decOccHuf_ = 0; // resident workgroups per CU of the parse / execute kernels
   bool raVerifyWholeFrames_ = false;     // batched random access decodes every touched frame in full and checks its checksum

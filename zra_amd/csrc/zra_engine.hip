@@ -15,6 +15,8 @@ extern "C" __global__ void zra_dec_huf_kernel(ZraDecodeArgs a);
 extern "C" __global__ void zra_dec_chain_kernel(ZraDecodeArgs a);
 extern "C" __global__ void zra_dec_chain_lds_kernel(ZraDecodeArgs a);
 extern "C" __global__ void zra_dec_exec_kernel(ZraDecodeArgs a);
+extern "C" __global__ void zra_dec_parse_all_kernel(ZraDecodeArgs a);
+extern "C" __global__ void zra_dec_exec_all_kernel(ZraDecodeArgs a);
 extern "C" __global__ void zra_ra_small_kernel(ZraDecodeArgs a, uint32_t* bail, const uint32_t* expect, uint32_t jobBase, unsigned long long* result);
 
 using namespace zra_dev;
@@ -282,7 +284,7 @@ Status Engine::release_scratch() {
   HIPCHK(hipStreamSynchronize(stream_));
   HIPCHK(hipStreamSynchronize(stream2_));
   for (DevBuf* b : {&raPlan_, &raLimit_, &raPieceBase_, &raPieces_, &decFrames_, &decTables_, &decLists_, &decCounters_, &decLits_, &decSeqs_, &roundN_, &status_,
-                    &produced_, &frameMeta_, &frameOff_, &outOff_, &expect_, &result_, &temp_, &qmeta_, &encScan_, &hostIn_, &hostOut_, &seqScratch_, &mfFlags_})
+                    &produced_, &frameMeta_, &frameOff_, &outOff_, &expect_, &result_, &temp_, &qmeta_, &encScan_, &hostIn_, &hostOut_, &seqScratch_, &mfFlags_, &decBlkRecs_, &decBlkTables_, &decBlkLists_})
     b->release();
   mfTeleDev_ = nullptr;                                // (lived inside encScan_)
   for (auto& x : encCtx_) for (DevBuf* b : {&x.tables, &x.seqs, &x.lits, &x.work, &x.slots, &x.misc, &x.ck, &x.sizes, &x.rec}) b->release();
@@ -302,6 +304,7 @@ Engine::~Engine() {
   if (stream2_) { (void)hipStreamSynchronize(stream2_); (void)hipStreamDestroy(stream2_); }
   for (auto st : pipeStreams_) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
   if (pinQ_) (void)hipHostFree(pinQ_);
+  if (pinSmall_) (void)hipHostFree(pinSmall_);
   for (auto& ev : evR_) if (ev) (void)hipEventDestroy(ev);
   if (ev0_) (void)hipEventDestroy(ev0_);
   if (ev1_) (void)hipEventDestroy(ev1_);
@@ -563,7 +566,84 @@ Status Engine::decode_launch(const ZraDecodeArgs& a0, const uint32_t* dExpect, u
       }
     }
   }
-  if (!piped) { Status st = run_rounds(a, n, nullptr, 0, listA, listB, (maxFrameBytes + (128u << 10) - 1) / (128u << 10)); if (st.zra) return st; }
+  // ---- Block-parallel pass (round 6) for frames of several blocks. The rounds below take one block of every frame per round, and their
+  // chain stage runs one LANE per frame: at 256 KiB frames a pass of 8 GiB has 32 Ki lanes walking a 128 KiB block each, twice in a row (47 of
+  // 76 ms), at 2 MiB frames 4 Ki lanes, sixteen times (168 of 208 ms). Here every compressed block of every frame is a job of the Huffman
+  // and chain stages at once — one parse launch that walks all blocks of a frame, one Huffman launch, one chain launch over the blocks
+  // (their initial repeat offsets as markers), one execute launch that walks a frame's blocks in order and puts the markers' values in.
+  // A frame that is not a clean frame of zstd's own making (an error anywhere, a compressed block that regenerates something else than
+  // 128 KiB, the long-offset mode) comes back on a list and takes the rounds below, where every status of the reference is reproduced.
+  // ZRA_DEC_FMB=0 turns the pass off.
+  static const int fmbEnv = std::getenv("ZRA_DEC_FMB") ? std::atoi(std::getenv("ZRA_DEC_FMB")) : 1;
+  static const uint32_t fmbMin = std::getenv("ZRA_DEC_FMB_MIN") ? (uint32_t)std::atoi(std::getenv("ZRA_DEC_FMB_MIN")) : 64u;
+  const uint32_t bpf = (uint32_t)(((uint64_t)maxFrameBytes + ZRA_FMB_BLOCK - 1) / ZRA_FMB_BLOCK);
+  bool fmb = fmbEnv != 0 && !piped && bpf >= 2 && maxFrameBytes <= (64u << 20) && n >= fmbMin && (uint64_t)n * bpf < (1ull << 30);
+  uint32_t nRest = n;
+  if (fmb) {
+    const uint64_t nb = (uint64_t)n * bpf;
+    // scratch for every block of every frame at once (the rounds size theirs for one block per frame)
+    const uint64_t litAll = std::max<uint64_t>((uint64_t)n * ((uint64_t)maxFrameBytes + 16) / 2, 1u << 20);
+    const uint64_t seqAll = std::max<uint64_t>((uint64_t)n * ((uint64_t)maxFrameBytes + 16) * 3 / 32, 1u << 20);
+    if (!decBlkRecs_.reserve((size_t)nb * sizeof(ZraDecFrame)) || !decBlkTables_.reserve((size_t)nb * ZRA_DEC_TBL_WORDS * 4) ||
+        !decBlkLists_.reserve((size_t)(2 * nb + n) * 4 + 64) || !decLits_.reserve(litAll + 64) || !decSeqs_.reserve(seqAll * 8 + 64)) {
+      (void)hipGetLastError();
+      fmb = false;                                      // (no memory for it: the rounds)
+    }
+    a.lits = decLits_.as<uint8_t>(); a.seqs = decSeqs_.as<uint64_t>();       // (the buffers may have moved)
+    if (fmb) {
+      ZraDecodeArgs x = a;
+      x.bpf = bpf; x.blkRecs = decBlkRecs_.as<ZraDecFrame>(); x.blkTables = decBlkTables_.as<uint32_t>();
+      uint32_t* bl = decBlkLists_.as<uint32_t>();
+      x.pending = bl; x.hufJobs = bl + nb; x.execList = bl + 2 * nb;
+      x.litCap = litAll; x.seqCap = seqAll;
+      x.active = nullptr; x.nActive = n; x.round = 0; x.nActivePtr = nullptr; x.nextActive = listA;
+      HIPCHK(hipMemsetAsync(x.counters, 0, ZRA_DC_WORDS * 4, stream_));
+      hipEvent_t se[5];
+      for (auto& e : se) { e = stage_event(); if (!e) return zerr(1); }
+      HIPCHK(hipEventRecord(se[0], stream_));
+      hipLaunchKernelGGL(zra_dec_parse_all_kernel, dim3((uint32_t)std::min<uint64_t>(n, (uint64_t)numCUs_ * perCUParse)), dim3(64), 0, stream_, x);
+      HIPCHK(hipEventRecord(se[1], stream_));
+      ZraDecodeArgs y = x; y.frames = x.blkRecs; y.tables = x.blkTables;      // the Huffman and chain stages: jobs are blocks
+      hipLaunchKernelGGL(zra_dec_huf_kernel, dim3((uint32_t)std::min<uint64_t>((nb + ZRA_HUF_FRAMES - 1) / ZRA_HUF_FRAMES, (uint64_t)numCUs_ * decOccHuf_)), dim3(64), 0, stream_, y);
+      HIPCHK(hipEventRecord(se[2], stream_));
+      const uint32_t gridChain = (uint32_t)std::min<uint64_t>((nb + 63) / 64, chainGrid ? chainGrid : (uint64_t)numCUs_ * chainWaves);
+      bool forked = false;
+      if (chainLdsOn && nb >= chainLdsMin) {
+        if (!pipeStreams_[1]) { if (hipStreamCreateWithFlags(&pipeStreams_[1], hipStreamNonBlocking) != hipSuccess) { pipeStreams_[1] = nullptr; (void)hipGetLastError(); } }
+        const size_t ldsBytes = (128 + (size_t)ZRA_CHAIN_LDS_FRAMES * (ZRA_DEC_TBL_WORDS / 2 + ZRA_CHAIN_RING_WORDS)) * 4;
+        if (pipeStreams_[1] && !chainLdsAttr_) {
+          if (hipFuncSetAttribute((const void*)zra_dec_chain_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes) == hipSuccess) chainLdsAttr_ = 1;
+          else { chainLdsAttr_ = -1; (void)hipGetLastError(); }
+        }
+        if (pipeStreams_[1] && chainLdsAttr_ > 0) {
+          hipEvent_t eJoin = stage_event(); if (!eJoin) return zerr(1);
+          HIPCHK(hipStreamWaitEvent(pipeStreams_[1], se[2], 0));
+          hipLaunchKernelGGL(zra_dec_chain_lds_kernel, dim3((uint32_t)numCUs_), dim3(64), ldsBytes, pipeStreams_[1], y);
+          HIPCHK(hipEventRecord(eJoin, pipeStreams_[1]));
+          if (chainLdsMode != 2) hipLaunchKernelGGL(zra_dec_chain_kernel, dim3(gridChain), dim3(64), 0, stream_, y);
+          HIPCHK(hipStreamWaitEvent(stream_, eJoin, 0));
+          forked = true;
+        }
+      }
+      if (!forked) hipLaunchKernelGGL(zra_dec_chain_kernel, dim3(gridChain), dim3(64), 0, stream_, y);
+      HIPCHK(hipEventRecord(se[3], stream_));
+      hipLaunchKernelGGL(zra_dec_exec_all_kernel, dim3((uint32_t)std::min<uint64_t>(n, (uint64_t)numCUs_ * perCUExec)), dim3(64), 0, stream_, x);
+      HIPCHK(hipEventRecord(se[4], stream_));
+      uint32_t back = 0;
+      HIPCHK(hipMemcpyAsync(&back, x.counters + ZRA_DC_NNEXT, 4, hipMemcpyDeviceToHost, stream_));
+      HIPCHK(hipStreamSynchronize(stream_));
+      HIPCHK(hipGetLastError());
+      for (int k = 0; k < 4; k++) { float m = 0; if (hipEventElapsedTime(&m, se[k], se[k + 1]) == hipSuccess) dstats_[k] += m; }
+      dstats_[4] += 1;
+      stageEvNext_ = 0;
+      nRest = back;
+    }
+  }
+  if (!piped) {
+    Status st = fmb ? run_rounds(a, nRest, listA, 0, listA, listB, 1)
+                    : run_rounds(a, n, nullptr, 0, listA, listB, (maxFrameBytes + (128u << 10) - 1) / (128u << 10));
+    if (st.zra) return st;
+  }
   HIPCHK(hipEventRecord(ev1_, stream_));
   const uint32_t tb = 256;
   hipLaunchKernelGGL(zra_xxh64_verify_kernel, dim3((n * 4 + tb - 1) / tb), dim3(tb), 0, stream_, a.out, a.outOff, dExpect,

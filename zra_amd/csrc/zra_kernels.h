@@ -47,9 +47,19 @@ struct ZraDecFrame {
   // results of the chain kernel
   uint32_t chainErr, nSeqValid, seqOut, seqLit, truncated;
   uint32_t repOut[3];
+  // block-parallel pass (round 6; frame records only): compressed blocks handed on as jobs, where the frame's last block ends, the
+  // random-access limit was reached before a block
+  uint32_t nBlk, endPos, parseTrunc, pad1_;
   alignas(8) uint8_t weights[256];      // kept Huffman description: weight and first decode-table cell of every symbol
   alignas(8) uint16_t hufStart[256];
 };
+// Block-parallel pass: a block's repeat offsets at its start are not known while its sequences are decoded (they are the previous block's
+// last three) — the chain stage runs on MARKERS, the execute stage, which walks a frame's blocks in order, puts the values in. A marker =
+// centre of band k (k = which of the block's three initial offsets) minus the number of times "offset - 1" was applied to it
+// (ZSTD_decodeSequence's third repeat code); real offsets of such a frame lie below the bands (frames of at most 128 MiB take this pass).
+#define ZRA_REP_MARK_LO 0x0C000000u
+#define ZRA_REP_MARK(k) (ZRA_REP_MARK_LO + ((uint32_t)(k) << 24) + 0x00800000u)
+#define ZRA_FMB_BLOCK (128u << 10)     /* what every compressed block but a frame's last regenerates in frames this pass finishes itself (zstd's block size; checked) */
 
 // one random-access slice: `len` bytes at `srcOff` inside decoded frame job `job` go to raOut + dstOff
 struct ZraRaPiece { uint64_t dstOff; uint32_t srcOff, len; };
@@ -85,6 +95,13 @@ struct ZraDecodeArgs {
   uint32_t* produced;        // [nFrames] bytes regenerated
   uint32_t* frameMeta;       // [2*nFrames] {1 = has checksum / 2 = stopped early (no frame-end checks), stored checksum}
   uint32_t debugSkip;        // bring-up timing knob (ZRA_DEC_SKIP): execute kernel stage ablation; 0 in production
+  // block-parallel pass (round 6, frames of several blocks): the Huffman and chain stages take BLOCKS as jobs — job = frame * bpf + the
+  // compressed block's ordinal, its record in `frames`, its tables in `tables` (the host points both at the block arrays for those two
+  // launches) —, zra_dec_parse_all_kernel writes them from the frame records, zra_dec_exec_all_kernel walks a frame's blocks in order
+  uint32_t bpf;              // block jobs per frame (0 / 1: jobs are frames)
+  ZraDecFrame* blkRecs;      // [nFrames * bpf]
+  uint32_t* blkTables;       // [nFrames * bpf * ZRA_DEC_TBL_WORDS]
+  uint32_t* execList;        // frames whose blocks were all handed on (count: counters[ZRA_DC_NEXEC]); the others are in nextActive (bail list)
 };
 // counters[]: u32 words, zeroed before every round
 #define ZRA_DC_QPARSE 0
@@ -96,6 +113,8 @@ struct ZraDecodeArgs {
 #define ZRA_DC_QHUF 10
 #define ZRA_DC_LITCUR 6      // u64 (words 6,7)
 #define ZRA_DC_SEQCUR 8      // u64 (words 8,9)
+#define ZRA_DC_NEXEC 11
+#define ZRA_DC_QEXECALL 12
 #define ZRA_DC_WORDS 16
 
 // ------------------------------------------------------------------------------------------------ encode
