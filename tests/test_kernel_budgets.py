@@ -19,7 +19,9 @@ BUDGET = {
     "zra_mf_fast_kernel": (64, 384),     # lane = frame; the scratch is the per-lane frame descriptor + a copy of the argument block
     "zra_mf_kernel": (96, 392),          # generic one-lane finder without the optimal parsers (btlazy2, frames beyond the window, odd tails)
     "zra_mf_opt_kernel": (136, 480),     # ... with them (levels 13-22; its scratch holds the parser's small arrays)
-    "zra_dec_chain_kernel": (72, 0),     # lane = frame FSE chains
+    "zra_dec_chain_kernel": (80, 0),     # lane = frame FSE chains (two waves per CU are launched: registers are not its limit; 78 since round 6's block jobs — a job's frame is job / bpf, marker-aware offset check)
+    "zra_dec_parse_all_kernel": (96, 256),  # round 6, block-parallel pass: the parse of every block of a frame in one go (same body, same budget as the parse kernel)
+    "zra_dec_exec_all_kernel": (80, 160),   # ... and the execute stage over a frame's blocks in order (the execute kernel's step, same budget)
     "zra_dec_chain_lds_kernel": (112, 0), # the same with its frames' tables and bitstream rings in LDS, ONE wave per CU beside it (no occupancy to protect: 98 with the ring's piece in flight)
     "zra_dec_huf_kernel": (88, 0),       # wave-wide literal decode (two stream readers while a restarted lane looks for its previous path); 8.5 KiB of LDS per workgroup is its occupancy limit
     "zra_dec_parse_kernel": (96, 256),   # 5 waves per SIMD asked for: 40 spilled VGPRs bought 2.1x on the stage (frames in flight are what it needs); round 5: 63 with libzstd's FSE_readNCount restated in full
