@@ -175,7 +175,17 @@ __device__ inline u64 zra_xxh64_quad(const u8* p, u32 n, int j) {
   u64 v = j == 0 ? XP1 + XP2 : j == 1 ? XP2 : j == 2 ? 0 : (0 - XP1);
   const u32 stripes = n >> 5;
   const u8* q = p + 8 * j;
-  for (u32 s = 0; s < stripes; s++) v = xxround(v, ld64(q + 32 * (size_t)s));
+  // (eight stripes' loads in flight per lane: the accumulator chain is ~60 cycles per stripe, a lone dependent load was ~700 — frames of
+  //  256 KiB and more spent longer in their checksum than in their execute stage, round 6)
+  u32 s = 0;
+  for (; s + 8 <= stripes; s += 8) {
+    u64 x[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) x[k] = ld64(q + 32 * (size_t)(s + k));
+#pragma unroll
+    for (int k = 0; k < 8; k++) v = xxround(v, x[k]);
+  }
+  for (; s < stripes; s++) v = xxround(v, ld64(q + 32 * (size_t)s));
   const int base = (threadIdx.x & 63) & ~3;
   u64 v1 = __shfl(v, base + 0, 64), v2 = __shfl(v, base + 1, 64), v3 = __shfl(v, base + 2, 64), v4 = __shfl(v, base + 3, 64);
   u64 h;
