@@ -17,6 +17,7 @@ for line in open(src):
         e["fetch_kib" if c == "FETCH_SIZE" else "write_kib" if c == "WRITE_SIZE" else c] = float(v)
 entry = {"source": "tools/pmc_bench.sh: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (one pass each, nothing else traced) of 'bench.py --steps 1 --warmup 0 --no-cpu-baseline'",
          "raw": "profiles/" + os.path.basename(src), "workload_key": "L3_fs65536", "frames": frames, "kernel_source_sha": bench.kernel_source_sha(),
+         "ra_mode": "whole frames, XXH64 verified (the timed RA leg since round 6)",
          "calibration": "profiles/r02_pmc_calibration.txt: FETCH_SIZE counts 64 B per narrow random read request, WRITE_SIZE 32 B per partial-line store and 64 B per full line"}
 dec = {}
 for k, e in acc.items():
