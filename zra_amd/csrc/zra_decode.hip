@@ -785,6 +785,9 @@ __device__ __forceinline__ u32 parse_job(const ZraDecodeArgs& a, const u32 j, Pa
       const bool stop = S.err || S.frameEnd;    // sampled by every lane before lane 0 may overwrite it
       wsync();
       if (stop || (ALL && bail)) break;
+      // (ALL: the positions are assumed ones; one beyond the frame's room means the frame is not what the pass takes — and every
+      //  "room left" below is a subtraction from dstCap)
+      if (ALL && S.produced > dstCap) { bail = true; break; }
       if (S.produced >= limit) { truncated = true; break; }        // random access: every byte a query needs exists
       // the header window must hold this block's header, literals header and tree description (<= 160 bytes) or reach the frame's end
       if (S.blkPos < S.winPos || S.blkPos + 160 > S.winPos + S.winLen) {

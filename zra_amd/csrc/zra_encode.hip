@@ -22,6 +22,9 @@ extern "C" __global__ void zra_entropy_kernel(ZraEncArgs a, uint32_t block);
 extern "C" __global__ void zra_entropy_front_kernel(ZraEncArgs a, uint32_t block);
 extern "C" __global__ void zra_entropy_back_kernel(ZraEncArgs a, uint32_t block);
 extern "C" __global__ void zra_ent_chain_kernel(ZraEncArgs a);
+extern "C" __global__ void zra_ent_chain3_kernel(ZraEncArgs a);
+extern "C" __global__ void zra_ent_chain2_kernel(ZraEncArgs a);
+extern "C" __global__ void zra_ent_chain1_kernel(ZraEncArgs a);
 
 using namespace zra_dev;
 
@@ -640,7 +643,11 @@ Status Engine::compress_persistent(const uint8_t* dIn, size_t inSize, uint8_t* d
         if (entSplit) {
           aj.entRec = sh.rec.as<ZraEntRec>();
           hipLaunchKernelGGL(zra_entropy_front_kernel, dim3(std::min<uint32_t>(nbj, entGrid)), dim3(256), 0, stream2_, aj, 0u);
-          hipLaunchKernelGGL(zra_ent_chain_kernel, dim3((nbj + ZRA_CHAIN_FRAMES - 1) / ZRA_CHAIN_FRAMES), dim3(64), 0, stream2_, aj);
+          // frames per wave of the chain kernel (6 / 3 / 2 / 1: the same LDS per CU as 1 / 2 / 3 / 6 waves)
+          static const uint32_t chainG = std::getenv("ZRA_CHAIN_G") ? (uint32_t)std::atoi(std::getenv("ZRA_CHAIN_G")) : 6u;
+          const uint32_t cg = chainG <= 1 ? 1u : chainG == 2 ? 2u : chainG <= 4 ? 3u : 6u;
+          const auto chainK = cg == 1 ? zra_ent_chain1_kernel : cg == 2 ? zra_ent_chain2_kernel : cg == 3 ? zra_ent_chain3_kernel : zra_ent_chain_kernel;
+          hipLaunchKernelGGL(chainK, dim3((nbj + cg - 1) / cg), dim3(64), 0, stream2_, aj);
           ZraEncArgs ab = aj; ab.entQueue = a.gQueue + j;   // (another zeroed word of the sub-batch: the BACK launch's frame queue)
           hipLaunchKernelGGL(zra_entropy_back_kernel, dim3(std::min<uint32_t>(nbj, entGrid)), dim3(256), 0, stream2_, ab, 0u);
         } else

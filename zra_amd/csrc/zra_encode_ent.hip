@@ -1393,9 +1393,10 @@ zra_entropy_back_kernel(ZraEncArgs a_, u32 block) { (void)a_; entropy_kernel_bod
 // each, the code bytes read 8 at a time and the results written 4 at a time per lane. One wave per workgroup; 21 KiB of LDS: one per CU
 // beside the match finder's 18 waves, as many as fit otherwise.
 #define ZRA_CHAIN_TBL_BYTES 3528u      /* per frame: state tables LL 512 + OF 256 + ML 512 u16; {deltaNbBits, deltaFindState} LL 36 + OF 32 + ML 53 */
-extern "C" __global__ void __launch_bounds__(64)
-zra_ent_chain_kernel(ZraEncArgs a_) {
-  (void)a_;
+// (G frames per wave. Beside the match finder a lone wave's step is bound by its issue slots, not by lanes: fewer frames per wave and more
+//  waves per CU — same LDS — buy issue share; zra_encode.hip picks the instantiation: ZRA_CHAIN_G)
+template <u32 ZRA_CHAIN_FRAMES>
+__device__ __forceinline__ void ent_chain_body() {
   KArgs& a = *(KArgs*)__builtin_amdgcn_kernarg_segment_ptr();
   __shared__ __attribute__((aligned(16))) u8 T[ZRA_CHAIN_FRAMES * ZRA_CHAIN_TBL_BYTES];
   const int lane = threadIdx.x;
@@ -1480,6 +1481,10 @@ zra_ent_chain_kernel(ZraEncArgs a_) {
   for (u32 j = 0; j < oHave; j++) out[oPos + j] = (u16)(ow >> (16 * j));
   r->finalState[k] = state;
 }
+extern "C" __global__ void __launch_bounds__(64) zra_ent_chain_kernel(ZraEncArgs a_) { (void)a_; ent_chain_body<6>(); }
+extern "C" __global__ void __launch_bounds__(64) zra_ent_chain3_kernel(ZraEncArgs a_) { (void)a_; ent_chain_body<3>(); }
+extern "C" __global__ void __launch_bounds__(64) zra_ent_chain2_kernel(ZraEncArgs a_) { (void)a_; ent_chain_body<2>(); }
+extern "C" __global__ void __launch_bounds__(64) zra_ent_chain1_kernel(ZraEncArgs a_) { (void)a_; ent_chain_body<1>(); }
 
 #ifdef ZRA_MF_PROFILE
 extern "C" __attribute__((visibility("default"))) void ZraHipDebugReadEntProfile(unsigned long long* out16, int reset) {

@@ -169,7 +169,6 @@ struct alignas(16) ZraEncFrameState {
 // (the hash-chain finder copies ring[] as uint4: every element of an array of these, and the ring inside it, sits on 16 bytes)
 static_assert(sizeof(ZraEncFrameState) % 16 == 0 && offsetof(ZraEncFrameState, ring) % 16 == 0, "ZraEncFrameState::ring must be 16-byte aligned in arrays");
 
-#define ZRA_CHAIN_FRAMES 6u   // zra_ent_chain_kernel: frames (x 3 streams = lanes) per wave; their tables take 6 x 3.5 KiB of LDS
 // split entropy stage of the persistent pipeline (round 6): what the FRONT launch leaves per frame for zra_ent_chain_kernel and the BACK launch
 struct ZraEntRec {
   ZraFseCTable ct[3];        // 0 LL, 1 OF, 2 ML: the block's encoding tables (valid when nChain != 0)
