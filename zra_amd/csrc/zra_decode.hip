@@ -966,6 +966,9 @@ __device__ __forceinline__ u32 parse_job(const ZraDecodeArgs& a, const u32 j, Pa
           if (S.litKind == 2) a.hufJobs[atomicAdd(&a.counters[ZRA_DC_NHUF], 1u)] = (u32)jb;
           // where the next block goes: this one regenerates a whole block unless it is the frame's last (the execute stage checks)
           S.produced = produced0 + (S.blkLast ? 0u : ZRA_FMB_BLOCK); S.blkPos = bpos + bsize; S.frameEnd = S.blkLast;
+          // (the table builds used the header window as scratch — build_fse_dtable's masks — and a highly compressible block's successor
+          //  starts inside the same 512 bytes: stage again. Found by the round's soak, seed 150028: periodic data, blocks of ~50 bytes)
+          S.winLen = 0;
         }
         if (S.litKind == 2) {                             // the tree in use (new, or kept from an earlier block of this walk) travels with the block
           for (u32 i = lane; i < 256; i += DEC_THREADS) { D->weights[i] = S.weights[i]; D->hufStart[i] = S.hufStart[i]; }
