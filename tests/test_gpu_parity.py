@@ -1058,3 +1058,45 @@ print("bad", bad)
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, ZRA_MF_LS="0", ZRA_MF_WAVES="1"), capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, (r.stdout[-800:], r.stderr[-1500:])
     assert r.stdout.strip().endswith("bad 0"), r.stdout[-800:]
+
+
+@pytest.mark.gpu
+def test_block_parallel_pass_over_tiny_compressed_blocks():
+    """Found by the round-6 soak (second generator, seed 150028: `srcSize_wrong` on a valid archive): the decoder's block-parallel pass
+    (zra_dec_parse_all_kernel) walks ALL blocks of a frame in one go, the FSE table builds use the header staging window as scratch, and a
+    highly compressible block's successor starts inside the same 512 bytes — the next block header was read from the clobbered window.
+    Frames of several blocks whose compressed blocks are a few dozen bytes each (periodic data, long runs), frames that mix them with
+    incompressible blocks (raw) and one-byte runs (RLE), with the pass forced onto calls of every size; full decode and random access
+    against the oracle's bytes (reference call sites zra.cpp:249,280-293), and the soak's seed itself."""
+    import subprocess
+    code = r"""
+import sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np
+import zra_amd as Z, oracle_lib as O, corpus as C
+import test_gpu_parity as T
+rng = np.random.RandomState(7)
+pat = bytes(rng.randint(0, 256, size=100).astype(np.uint8).tolist())
+noise = bytes(rng.randint(0, 256, size=300000).astype(np.uint8).tolist())
+bad = 0
+for fs in (262144, 524288, 1 << 20, 300000):
+    for level in (3, 5):
+        parts = [pat * 6000, b"\0" * 400000, noise, pat * 2000 + noise[:1000] + pat * 3000, C.gen_loglike(1 << 19), (pat[:7] * 40000)]
+        d = b"".join(parts)
+        d = d[: (len(d) // fs) * fs + 12345]
+        st, arc = O.zra_compress(d, level, fs, True)
+        assert st == (0, 0)
+        if Z.DecompressBuffer(arc) != d:
+            bad += 1; print("FULL", fs, level)
+        for _ in range(40):
+            off = int(rng.randint(0, len(d) - 2)); sz = int(min(rng.choice([1, 4096, fs, 2 * fs + 3]), len(d) - off - 1))
+            if sz > 0 and Z.DecompressRA(arc, off, sz) != d[off:off + sz]:
+                bad += 1; print("RA", fs, level, off, sz)
+import corpus
+T._random_input = corpus.random_lz_input_far
+T.test_randomised_differential_compress(Z, 150028)
+print("bad", bad)
+""" % (HERE, os.path.dirname(HERE))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, ZRA_DEC_SMALL_MAX="0", ZRA_DEC_FMB_MIN="1"), capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, (r.stdout[-800:], r.stderr[-1500:])
+    assert r.stdout.strip().endswith("bad 0"), r.stdout[-800:]
