@@ -923,7 +923,8 @@ def test_opt_in_kernels_are_bit_exact_too(env):
     again, in a fresh process with the knob set."""
     import subprocess
     sel = "randomised_differential_decode or golden_frames" if "ZRA_DEC_PIPE" in env else \
-          "randomised_differential_decode or randomised_corruption_statuses or random_access_on_damaged or ra_vs_bruteforce or golden_frames or libzstd_frames or frames_larger_than_the_window or inflated_frame_size or randomised_header_damage or randomised_batched_random_access or (compress_buffer_bit_exact and (262144 or 524288 or 1048576 or 2097152 or 400000 or 300000 or 200000))" if "ZRA_DEC_FMB_MIN" in env or "ZRA_DEC_FMB" in env else \
+          "randomised_differential_decode or randomised_corruption_statuses or random_access_on_damaged or ra_vs_bruteforce or golden_frames or libzstd_frames or frames_larger_than_the_window or inflated_frame_size or randomised_header_damage or randomised_batched_random_access or (compress_buffer_bit_exact and (262144 or 524288 or 1048576 or 2097152 or 400000 or 300000 or 200000))" if "ZRA_DEC_FMB_MIN" in env else \
+          "randomised_differential_decode or golden_frames or frames_larger_than_the_window or (compress_buffer_bit_exact and (524288 or 2097152))" if "ZRA_DEC_FMB" in env else \
           "randomised_differential_decode or randomised_corruption_statuses or random_access_on_damaged or ra_vs_bruteforce or golden_frames or libzstd_frames" if "ZRA_DEC_CHAIN_LDS" in env else \
           "compress_buffer_bit_exact and (5-65536 or 9-65536 or 7-16384 or 10-) or short_last_frame or frames_larger_than_the_window" if "ZRA_ENC_POISON" in env else \
           "compress_buffer_bit_exact and (3-65536 or 4-65536 or 3-16384 or 0-16384) or sub_batch_boundaries or short_last_frame or match_finder_sequences and (3-65536 or 3-16384) or randomised_differential_compress"
