@@ -271,12 +271,16 @@ static size_t decode_block(dctx* d, u8* out, size_t outCap, const u8* frameOut, 
 #define FAIL(code) do { free(lit); return ZO_ERR(code); } while (0)
   if (rem < 1) FAIL(ZO_E_SRCSIZE_WRONG);
   size_t nbSeq = p[0];
+  /* ZSTD_decodeSeqHeaders leaves early only for a FIRST BYTE of zero; a count of zero in the two-byte form (0x80 0x00 — never written by an
+     encoder, found by the round-6 soak on damaged archives, seeds 145238 / 146031) goes on through the table descriptions — whose errors
+     count and whose tables stay for later blocks' repeat modes — and then decodes no sequence and never opens the bitstream */
+  const int seqTables = p[0] != 0;
   if (nbSeq == 0) { p++; rem--; if (rem) FAIL(ZO_E_SRCSIZE_WRONG); }   /* ZSTD_decodeSeqHeaders: "srcSize != 1" */
   else if (nbSeq < 128) { p++; rem--; }
   else if (nbSeq < 255) { if (rem < 2) FAIL(ZO_E_SRCSIZE_WRONG); nbSeq = ((nbSeq - 128) << 8) + p[1]; p += 2; rem -= 2; }
   else { if (rem < 3) FAIL(ZO_E_SRCSIZE_WRONG); nbSeq = (size_t)p[1] + ((size_t)p[2] << 8) + 0x7F00; p += 3; rem -= 3; }
   size_t litPos = 0;
-  if (nbSeq) {
+  if (seqTables) {
     if (rem < 1) FAIL(ZO_E_SRCSIZE_WRONG);
     unsigned modes = p[0]; p++; rem--;      /* the two reserved bits are not looked at by libzstd 1.4.9 */
     size_t h;
@@ -291,6 +295,7 @@ static size_t decode_block(dctx* d, u8* out, size_t outCap, const u8* frameOut, 
        - long loop (ZSTD_decompressSequencesLong, chosen by ZSTD_decompressBlock_internal for frames declaring a window above 16 MiB
          whose offset table holds enough long codes): sequences are decoded four ahead of their execution, the loop stops with
          corruption_detected as soon as the stream is over-read, and there is no "stream consumed" check at all. */
+    if (nbSeq) {
     zds br;
     if (zds_init(&br, p, rem)) FAIL(ZO_E_CORRUPTION);
     seqstate q; q.d = d; q.br = &br;
@@ -327,6 +332,7 @@ static size_t decode_block(dctx* d, u8* out, size_t outCap, const u8* frameOut, 
       for (i -= 4; i < nbSeq; i++) { const int e = exec_sequence(&x, ring[i & 3]); if (e) FAIL(e); }
     }
     produced = x.produced; litPos = x.litPos;
+    }
   }
   if (litSize - litPos > outCap - produced) FAIL(ZO_E_DSTSIZE_TOOSMALL);
   memcpy(out + produced, lit + litPos, litSize - litPos);

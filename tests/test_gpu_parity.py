@@ -225,7 +225,7 @@ def test_damaged_frame_size_field_streaming_full_decompressor(zra):
             os.environ.pop("ZRA_STREAM_AHEAD_MIB", None)
 
 
-@pytest.mark.parametrize("seed", list(range(6)) + [13141])
+@pytest.mark.parametrize("seed", list(range(6)) + [13141, 145238, 146031])   # (the last two: round-6 soak — a sequence count of zero in the two-byte form)
 def test_randomised_corruption_statuses(zra, seed):
     """Mutated archives (bit flips, byte overwrites, truncation): DecompressBuffer must report the (zra, zstd) status of the REAL
     dependency (libzstd 1.4.9 behind the oracle's container code, backend "zl") — and the same bytes wherever the decode is defined —

@@ -116,7 +116,7 @@ struct __attribute__((aligned(16))) ParseShared {
   u32 hufValid, hufMaxBits, hufNSym, hufX2;
   u32 hufNw, hufUsed, hufPhase;   // a tree description read by lane 0 (weights[0..hufNw)), waiting for the wave-wide part (phase 1);
   u32 hufTl, hufMaxSym, hufNcBytes, hufHbyte;   // ... or (phase 2) an FSE-coded one whose table description lane 0 has read into norm[]
-  u32 nbSeq, seqPos, seqModes;
+  u32 nbSeq, seqPos, seqModes, seqTables;
   u32 llLog, mlLog, ofLog, llValid, mlValid, ofValid, ofShare;
   u32 rep[3];
   u32 streamOff[4], streamLen[4];
@@ -588,8 +588,12 @@ __device__ __forceinline__ void parse_seq_header(ParseShared& S, const u8* p, u3
   else if (nb < 255) { if (rem < 2) { S.err = ZE_SRCSIZE_WRONG; return; } nb = ((nb - 128) << 8) + p[1]; used = 2; }
   else { if (rem < 3) { S.err = ZE_SRCSIZE_WRONG; return; } nb = (u32)p[1] + ((u32)p[2] << 8) + 0x7F00; used = 3; }
   S.nbSeq = nb;
-  if (nb) {
-    if (rem < used + 1) { S.err = ZE_SRCSIZE_WRONG; return; }
+  // ZSTD_decodeSeqHeaders leaves early only for a FIRST BYTE of zero: a count of zero in the two-byte form (0x80 0x00; no encoder writes
+  // it — round-6 soak on damaged archives, seeds 145238 / 146031) still goes through the table descriptions (their errors count, their
+  // tables stay for later blocks' repeat modes), then no sequence is decoded and the bitstream is never opened
+  S.seqTables = p[0] != 0;
+  if (S.seqTables) {
+    if (rem < used + 1) { S.err = ZE_SRCSIZE_WRONG; S.seqTables = 0; return; }
     S.seqModes = p[used]; used++;          // the two reserved bits are not looked at by libzstd 1.4.9
   }
   S.seqPos += used;
@@ -868,7 +872,7 @@ __device__ __forceinline__ u32 parse_job(const ZraDecodeArgs& a, const u32 j, Pa
       const u8* const swLim = S.w1 + STAGE_BYTES + 8;
       if (lane == 0) {
         parse_seq_header(S, sw + S.seqPos, bsize - S.seqPos);
-        if (S.err) { S.lateErr = S.err; S.err = 0; S.nbSeq = 0; }
+        if (S.err) { S.lateErr = S.err; S.err = 0; S.nbSeq = 0; S.seqTables = 0; }
         if (S.alloc && S.nbSeq) {
           // multiples of four entries per frame: the chain kernel writes its sequences four at a time (aligned 32 bytes)
           const u64 take = ((u64)S.nbSeq + 3) & ~3ull;
@@ -895,7 +899,7 @@ __device__ __forceinline__ u32 parse_job(const ZraDecodeArgs& a, const u32 j, Pa
       const u32 nbSeq = S.nbSeq, regen = S.litRegen;
       const size_t jb = ALL ? (size_t)j * a.bpf + nBlk : (size_t)j;
       u32* const T = ALL ? a.blkTables + jb * ZRA_DEC_TBL_WORDS : a.tables + (size_t)j * ZRA_DEC_TBL_WORDS;
-      if (nbSeq) {
+      if (S.seqTables) {                                   // (uniform: written by lane 0 before the wave sync above)
         for (int kind = 0; kind < 3; kind++) {
           const int k = kind == 0 ? 0 : kind == 1 ? 2 : 1;          // wire order is LL, OF, ML
           const u32 mode = k == 0 ? (S.seqModes >> 6) : k == 2 ? ((S.seqModes >> 4) & 3) : ((S.seqModes >> 2) & 3);

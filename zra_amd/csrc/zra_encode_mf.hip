@@ -454,6 +454,15 @@ struct LeanLds {
 #ifdef ZRA_MF_NT
 #define TLD(p) __builtin_nontemporal_load(p)
 #define TST(p, v) __builtin_nontemporal_store((u32)(v), p)
+#elif defined(ZRA_MF_SC1ST)
+// bring-up A/B (round 6): table stores with the sc1 policy — the line leaves the XCD's L2 behind the write (MI355X_MICROARCH.md, "stores of
+// each flavour") instead of staying as a single-use line that pushes the frame's source lines out
+#ifdef ZRA_MF_SC1LD
+#define TLD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)     /* ... and table loads past the L1 */
+#else
+#define TLD(p) (*(p))
+#endif
+#define TST(p, v) __hip_atomic_store((p), (u32)(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #else
 #define TLD(p) (*(p))
 #define TST(p, v) (*(p) = (v))
