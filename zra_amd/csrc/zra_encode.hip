@@ -22,6 +22,7 @@ extern "C" __global__ void zra_entropy_kernel(ZraEncArgs a, uint32_t block);
 extern "C" __global__ void zra_entropy_front_kernel(ZraEncArgs a, uint32_t block);
 extern "C" __global__ void zra_entropy_back_kernel(ZraEncArgs a, uint32_t block);
 extern "C" __global__ void zra_ent_chain_kernel(ZraEncArgs a);
+extern "C" __global__ void zra_ent_chain5_kernel(ZraEncArgs a);
 extern "C" __global__ void zra_ent_chain3_kernel(ZraEncArgs a);
 extern "C" __global__ void zra_ent_chain2_kernel(ZraEncArgs a);
 extern "C" __global__ void zra_ent_chain1_kernel(ZraEncArgs a);
@@ -427,7 +428,9 @@ Status Engine::compress_persistent(const uint8_t* dIn, size_t inSize, uint8_t* d
   // With the bucket flags fewer table requests queue up and more finder waves pay again (alone: 18 waves 880-897 ms, 20 waves 855-862,
   // 22 and 24 waves 824-846; without the flags 18 = 24 waves, round 4) — but the entropy stage needs its room: at 20 waves it falls behind.
   static const int pipeMode = std::getenv("ZRA_PIPE") ? std::atoi(std::getenv("ZRA_PIPE")) : 1;
-  static const uint32_t wavesPerCU = std::getenv("ZRA_MF_WAVES") ? (uint32_t)std::atoi(std::getenv("ZRA_MF_WAVES")) : (pipeMode == 0 ? 22u : 18u);
+  // (round 6: 19 beside the entropy stage — its workgroup takes 14 of the CU's 128 LDS pieces since the histograms share storage with the
+  //  tables, a finder wave 6: 19 x 6 + 14 = 128; it was 18 x 6 + 19)
+  static const uint32_t wavesPerCU = std::getenv("ZRA_MF_WAVES") ? (uint32_t)std::atoi(std::getenv("ZRA_MF_WAVES")) : (pipeMode == 0 ? 22u : 19u);
   static const uint32_t SB = std::getenv("ZRA_ENC_SUB") ? (uint32_t)std::atoi(std::getenv("ZRA_ENC_SUB")) : 8192u;   // frames per sub-batch
   const uint32_t nSlots = (uint32_t)std::min<uint64_t>((uint64_t)numCUs_ * wavesPerCU, nFramesTotal);
   // per-frame scratch that lives from the match finder to the entropy stage: sequences + block record + checksum + size/offset
@@ -644,9 +647,10 @@ Status Engine::compress_persistent(const uint8_t* dIn, size_t inSize, uint8_t* d
           aj.entRec = sh.rec.as<ZraEntRec>();
           hipLaunchKernelGGL(zra_entropy_front_kernel, dim3(std::min<uint32_t>(nbj, entGrid)), dim3(256), 0, stream2_, aj, 0u);
           // frames per wave of the chain kernel (6 / 3 / 2 / 1: the same LDS per CU as 1 / 2 / 3 / 6 waves)
-          static const uint32_t chainG = std::getenv("ZRA_CHAIN_G") ? (uint32_t)std::atoi(std::getenv("ZRA_CHAIN_G")) : 6u;
-          const uint32_t cg = chainG <= 1 ? 1u : chainG == 2 ? 2u : chainG <= 4 ? 3u : 6u;
-          const auto chainK = cg == 1 ? zra_ent_chain1_kernel : cg == 2 ? zra_ent_chain2_kernel : cg == 3 ? zra_ent_chain3_kernel : zra_ent_chain_kernel;
+          // (5 by default: 17,640 B of LDS, what is left of a CU beside 19 finder waves; 6 needs the room 18 waves leave)
+          static const uint32_t chainG = std::getenv("ZRA_CHAIN_G") ? (uint32_t)std::atoi(std::getenv("ZRA_CHAIN_G")) : (wavesPerCU >= 19 ? 5u : 6u);
+          const uint32_t cg = chainG <= 1 ? 1u : chainG == 2 ? 2u : chainG <= 4 ? 3u : chainG == 5 ? 5u : 6u;
+          const auto chainK = cg == 1 ? zra_ent_chain1_kernel : cg == 2 ? zra_ent_chain2_kernel : cg == 3 ? zra_ent_chain3_kernel : cg == 5 ? zra_ent_chain5_kernel : zra_ent_chain_kernel;
           hipLaunchKernelGGL(chainK, dim3((nbj + cg - 1) / cg), dim3(64), 0, stream2_, aj);
           ZraEncArgs ab = aj; ab.entQueue = a.gQueue + j;   // (another zeroed word of the sub-batch: the BACK launch's frame queue)
           hipLaunchKernelGGL(zra_entropy_back_kernel, dim3(std::min<uint32_t>(nbj, entGrid)), dim3(256), 0, stream2_, ab, 0u);

@@ -46,7 +46,13 @@ __device__ __forceinline__ u32 hb32z(u32 x) { return x ? hb32(x) : 0; }
 // LDS of one frame-block (~20 KiB: up to 7 workgroups per CU). The literal-phase arrays and the sequence-phase arrays are never
 // live at the same time and share storage.
 struct EncLitPhase {
-  u32 hist[4][256];
+  // (round 6) the literal histograms (gather phase, dead once the symbols are sorted) and the block's three sequence encoding tables (built
+  // after that, alive to the block's end) share storage: with it the workgroup takes 14 of the CU's 1,280-byte LDS pieces instead of 19 —
+  // room for a 19th match-finder wave beside it
+  union {
+    u32 hist[4][256];
+    ZraFseCTable ct[3];      // 0 LL, 1 OF, 2 ML (next-block tables)
+  };
   // Huffman construction (index 0 of node* is the sentinel "huffNode[-1]")
   u32 nodeCount[514];
   u16 nodeParent[514];
@@ -58,10 +64,10 @@ struct EncLitPhase {
   u8 wSpread[64];
   // small work arrays of the one-lane sections: in LDS, because a per-thread array that is indexed dynamically lives in scratch
   // (HBM-backed private memory) and every access then costs a memory round trip
-  u32 wCount[16], wCumul[16], rankLast[16];
+  u32 wCount[16], rankLast[16];
   u16 nbPerRank[16], valPerRank[16];
   u8 ncTmp[192];
-  ZraFseCTable wct;           // encoding table of the weights (its own: the sequence tables are built on the other waves meanwhile)
+  // (the encoding table of the Huffman weights lives in the bit-staging tile between the table builds' arrays and the Huffman wave's scratch: ENT_WCT_OFF)
 };
 // work arrays of the three sequence-table builds: they live in the bit-staging tile, which nobody packs into while tables are built
 struct EncSeqBuild {
@@ -74,11 +80,11 @@ struct __attribute__((aligned(16))) EncShared {
   EncLitPhase lit;
   u32 seqCnt[3][64];         // code histograms of the block's sequences (counted while the literals are gathered: the sequences are in registers then)
   u32 tblReady[4];           // sequence table k built (lane 0 of wave k + 1 sets it; wave 1 walks the chains behind all three)
-  u8 chainCodes[3][64]; u16 chainOut[3][64];   // the state chains' current 64 sequences: codes in, results out
+  // (the one-launch kernel's state chains keep their current 64 sequences — codes in, results out — at the start of the staging tile, where
+  //  the table builds' arrays are dead by then: ENT_CHAIN_CODES / ENT_CHAIN_OUT)
   u8 ncount[3][192];         // table descriptions of the block's sequence section (written while the Huffman tree is built, emitted after the literals)
   u8 hNb[256];
   u16 hVal[256];
-  ZraFseCTable ct[3];        // 0 LL, 1 OF, 2 ML (next-block tables)
   u32 ncountSize[3], mode[3], nextRepeat[3], tblErr[3];
   u32 finalState[3];
   u32 wsum[16];
@@ -87,6 +93,11 @@ struct __attribute__((aligned(16))) EncShared {
   u32 sc[16];
 };
 static_assert(sizeof(EncSeqBuild) <= sizeof(u32) * STAGE_WORDS, "the table builds' work arrays must fit the staging tile");
+// staging-tile tenants while tables are built (phase 2b): [0, 2592) EncSeqBuild (waves 1-3), [ENT_WCT_OFF, +1460) the weights' encoding
+// table (wave 0), [4096, 6016) HufWaveScratch (wave 0); behind the builds, [0, 576) the one-launch kernel's chain arrays (wave 1)
+constexpr u32 ENT_WCT_OFF = 2624;
+static_assert(sizeof(EncSeqBuild) <= ENT_WCT_OFF && ENT_WCT_OFF + sizeof(ZraFseCTable) <= 4096, "the weights' table must fit between the table builds' arrays and the Huffman wave's scratch");
+static_assert(sizeof(EncShared) <= 14 * 1280, "the entropy workgroup must fit 14 LDS pieces: 19 match-finder waves x 6 pieces + 14 = the CU's 128");
 
 // ---- workgroup exclusive scan of one u32 per thread; returns exclusive prefix, *total = sum over the workgroup
 __device__ __forceinline__ u32 block_excl_scan(EncShared& S, u32 v, u32* total) {
@@ -408,7 +419,7 @@ __device__ u32 huf_compress_weights_wave(EncShared& S, HufWaveScratch& H, u8* ds
   if (!h) return 0;
   wave_order();
   for (u32 i = (u32)lane; i < h; i += 64) dst[i] = tmp[i];
-  ZraFseCTable* const ct = &S.lit.wct;
+  ZraFseCTable* const ct = (ZraFseCTable*)((u8*)S.stage + ENT_WCT_OFF);
   if (fse_build_ctable_wave(ct, norm, maxSym, t, S.lit.wSpread, lane)) return 0;
   if (n <= 2) return 0;
   // two interleaved states, symbols consumed from the end (A.4.5 "weight serialisation"): state 1 owns the even positions, state 2 the odd
@@ -849,7 +860,7 @@ __device__ __forceinline__ void entropy_frame(KArgs& a, u32 block, u32 f, u8* li
             const bool defaultAllowed = k != 1 || mx <= 28;
             const u32 modeK = select_encoding(&repeatMode, count, mx, most, nbSeq, FSELog, prevCT, defNorm, defLog, defaultAllowed, strategy, SB.norm[k], S.ncount[k]);
             S.mode[k] = modeK; S.nextRepeat[k] = repeatMode; S.ncountSize[k] = 0; S.tblErr[k] = 0;
-            ZraFseCTable* ct = &S.ct[k];
+            ZraFseCTable* ct = &S.lit.ct[k];
             if (modeK == 1) { ct->rle = 1; ct->tableLog = 0; ct->maxSym = mx; S.ncount[k][0] = (u8)mx; S.ncountSize[k] = 1; }
             else if (modeK == 0) { for (u32 sy = 0; sy <= defMax; sy++) SB.norm[k][sy] = defNorm[sy]; doBuild = 1; buildT = defLog; buildMax = defMax; }
             else if (modeK == 2) {
@@ -867,7 +878,7 @@ __device__ __forceinline__ void entropy_frame(KArgs& a, u32 block, u32 f, u8* li
           doBuild = (u32)__builtin_amdgcn_readfirstlane((int)doBuild); buildT = (u32)__builtin_amdgcn_readfirstlane((int)buildT);
           buildMax = (u32)__builtin_amdgcn_readfirstlane((int)buildMax);
           wave_order();
-          if (doBuild && fse_build_ctable_wave(&S.ct[kw], SB.norm[kw], buildMax, buildT, SB.spread[kw], lane)) { if (lane == 0) S.tblErr[kw] = 1; }
+          if (doBuild && fse_build_ctable_wave(&S.lit.ct[kw], SB.norm[kw], buildMax, buildT, SB.spread[kw], lane)) { if (lane == 0) S.tblErr[kw] = 1; }
           if (lane == 0) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __hip_atomic_store(&S.tblReady[kw], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -883,7 +894,7 @@ __device__ __forceinline__ void entropy_frame(KArgs& a, u32 block, u32 f, u8* li
           if (S.mode[kk] == 3) {
             // repeat mode: the previous block's table comes into LDS
             const u32* srcT = (const u32*)(kk == 0 ? &st->ll : kk == 1 ? &st->of : &st->ml);
-            u32* dstT = (u32*)&S.ct[kk];
+            u32* dstT = (u32*)&S.lit.ct[kk];
             for (u32 i = (u32)lane; i < sizeof(ZraFseCTable) / 4; i += 64) dstT[i] = srcT[i];
           }
         }
@@ -897,9 +908,10 @@ __device__ __forceinline__ void entropy_frame(KArgs& a, u32 block, u32 f, u8* li
         // travel meanwhile) and are parked in LDS, lanes 0-2 walk the 64 steps of their streams (the symbol two steps ahead and its
         // parameters one step ahead are fetched beside the critical load), the results leave with one store per stream.
         if constexpr (PHASE != 1) {
-          const bool runK = lane < 3 && !S.tblErr[k] && !S.ct[lane < 3 ? k : 0].rle;
-          const ZraFseCTable* const ct = &S.ct[lane < 3 ? k : 0];
-          u8* const cdL = S.chainCodes[lane < 3 ? k : 0]; u16* const outL = S.chainOut[lane < 3 ? k : 0];
+          const bool runK = lane < 3 && !S.tblErr[k] && !S.lit.ct[lane < 3 ? k : 0].rle;
+          const ZraFseCTable* const ct = &S.lit.ct[lane < 3 ? k : 0];
+          u8 (*const chainCodes)[64] = (u8 (*)[64])S.stage; u16 (*const chainOut)[64] = (u16 (*)[64])((u8*)S.stage + 192);
+          u8* const cdL = chainCodes[lane < 3 ? k : 0]; u16* const outL = chainOut[lane < 3 ? k : 0];
           u32 cV[3], cN[3] = {0, 0, 0};
 #pragma unroll
           for (int kk = 0; kk < 3; kk++) cV[kk] = (u32)lane < nbSeq ? codesG[(size_t)kk * a.seqStride + lane] : 0u;
@@ -909,7 +921,7 @@ __device__ __forceinline__ void entropy_frame(KArgs& a, u32 block, u32 f, u8* li
 #pragma unroll
             for (int kk = 0; kk < 3; kk++) {
               if (base + 64 < nbSeq) cN[kk] = base + 64 + (u32)lane < nbSeq ? codesG[(size_t)kk * a.seqStride + base + 64 + lane] : 0u;
-              S.chainCodes[kk][lane] = (u8)cV[kk];
+              chainCodes[kk][lane] = (u8)cV[kk];
             }
             // (one wave, LDS in issue order: a wavefront-scope fence orders the compiler and waits for nothing — a workgroup-scope one
             //  would wait for the codes in flight and for the stores of the 64 results before)
@@ -938,7 +950,7 @@ __device__ __forceinline__ void entropy_frame(KArgs& a, u32 block, u32 f, u8* li
 #pragma unroll
             for (int kk = 0; kk < 3; kk++) {
               // (a one-symbol table emits no state bits; after a table error the section is dropped: zeros either way)
-              if ((u32)lane < nIn) chainG[(size_t)kk * a.seqStride + base + lane] = (S.ct[kk].rle || S.tblErr[kk]) ? (u16)0 : S.chainOut[kk][lane];
+              if ((u32)lane < nIn) chainG[(size_t)kk * a.seqStride + base + lane] = (S.lit.ct[kk].rle || S.tblErr[kk]) ? (u16)0 : chainOut[kk][lane];
               cV[kk] = cN[kk];
             }
           }
@@ -1052,19 +1064,19 @@ __device__ __forceinline__ void entropy_frame(KArgs& a, u32 block, u32 f, u8* li
         for (u32 i = tid; i < sz; i += ENT_THREADS) op[i] = S.ncount[k][i];
         op += sz;
       }
-      for (int k = 0; k < 3; k++) { tlog[k] = S.ct[k].tableLog; fin[k] = S.finalState[k]; }
+      for (int k = 0; k < 3; k++) { tlog[k] = S.lit.ct[k].tableLog; fin[k] = S.finalState[k]; }
     }
     if constexpr (PHASE == 1) {
       // FRONT ends here: the tables and where the bitstream goes, for the chain kernel and the BACK launch
       if (nbSeq && !tblErr) {
         for (int k = 0; k < 3; k++) {
-          const u32* srcT = (const u32*)&S.ct[k]; u32* dstT = (u32*)&rec->ct[k];
+          const u32* srcT = (const u32*)&S.lit.ct[k]; u32* dstT = (u32*)&rec->ct[k];
           for (u32 i = tid; i < sizeof(ZraFseCTable) / 4; i += ENT_THREADS) dstT[i] = srcT[i];
         }
       }
       if (tid == 0) {
         rec->nChain = (nbSeq && !tblErr) ? nbSeq : 0u;
-        for (int k = 0; k < 3; k++) { rec->run[k] = (nbSeq && !tblErr && !S.ct[k].rle) ? 1u : 0u; rec->tlog[k] = tlog[k]; rec->finalState[k] = 0; }
+        for (int k = 0; k < 3; k++) { rec->run[k] = (nbSeq && !tblErr && !S.lit.ct[k].rle) ? 1u : 0u; rec->tlog[k] = tlog[k]; rec->finalState[k] = 0; }
         rec->tblErr = tblErr ? 1u : 0u; rec->opOff = (u32)(op - blk); rec->lastNCountOff = lastNCount ? (u32)(lastNCount - blk) : 0xFFFFFFFFu;
         rec->newHuf = newHuf ? 1u : 0u; rec->newHufMaxSym = newHufMaxSym;
       }
@@ -1178,7 +1190,7 @@ __device__ __forceinline__ void entropy_frame(KArgs& a, u32 block, u32 f, u8* li
       if (nbSeq) {
         for (int k = 0; k < 3; k++) {
           u32* dstT = (u32*)(k == 0 ? &st->ll : k == 1 ? &st->of : &st->ml);
-          const u32* srcT = (const u32*)&S.ct[k];
+          const u32* srcT = (const u32*)&S.lit.ct[k];
           for (u32 i = tid; i < sizeof(ZraFseCTable) / 4; i += ENT_THREADS) dstT[i] = srcT[i];
         }
         if (tid == 0) { st->llRepeat = S.nextRepeat[0]; st->ofRepeat = S.nextRepeat[1]; st->mlRepeat = S.nextRepeat[2]; }
@@ -1482,6 +1494,7 @@ __device__ __forceinline__ void ent_chain_body() {
   r->finalState[k] = state;
 }
 extern "C" __global__ void __launch_bounds__(64) zra_ent_chain_kernel(ZraEncArgs a_) { (void)a_; ent_chain_body<6>(); }
+extern "C" __global__ void __launch_bounds__(64) zra_ent_chain5_kernel(ZraEncArgs a_) { (void)a_; ent_chain_body<5>(); }   // 17,640 B: beside 19 finder waves
 extern "C" __global__ void __launch_bounds__(64) zra_ent_chain3_kernel(ZraEncArgs a_) { (void)a_; ent_chain_body<3>(); }
 extern "C" __global__ void __launch_bounds__(64) zra_ent_chain2_kernel(ZraEncArgs a_) { (void)a_; ent_chain_body<2>(); }
 extern "C" __global__ void __launch_bounds__(64) zra_ent_chain1_kernel(ZraEncArgs a_) { (void)a_; ent_chain_body<1>(); }
