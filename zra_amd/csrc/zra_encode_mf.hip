@@ -1039,17 +1039,22 @@ __device__ u32 mf_lazy_wave(HCW& H, const u8* src, u32 bs, u32 be, u32* rep, u64
   auto put = [&](u32 ll, u32 ml, u32 offVal) { if (lane == 0) seqs[n] = (u64)ll | ((u64)ml << 20) | ((u64)offVal << 40); n++; };
   // repcode tests "4 bytes at t equal 4 bytes at t - o": the parse asks them at consecutive positions (ip+1, then ip+1 again from the
   // lazy loop, ip+2, after a match ip with the second offset, ...), one dependent round trip each in the serial form. Here one round
-  // trip fetches 8 bytes at cb and at cb - o1 and cb - o2 together and answers the tests at cb .. cb+4 for both offsets.
-  u32 cb = 0xFFFFFFF0u, cbO1 = 0, cbO2 = 0; u64 cs = 0, c1 = 0, c2 = 0;
+  // trip (rounds 2-5) fetched 8 bytes at cb and at cb - o1 and cb - o2 together and answered the tests at cb .. cb+4 for both offsets.
+  // Round 6: the whole wave answers them — lane l compares the 4 bytes at cb + l with those at cb + l - o1 and cb + l - o2, two ballots
+  // hold the answers for cb .. cb + 63 and both offsets: one round trip per 64 positions (and per change of the offsets) instead of
+  // one per 5. The same tests, bit for bit: 4 bytes at t against 4 bytes at t - o for 0 < o <= t; t + 4 <= be holds for every t asked.
+  u32 cb = 0xFFFFFFF0u, cbO1 = 0, cbO2 = 0; u64 m1 = 0, m2r = 0;
   auto rep_test = [&](u32 t, bool first) -> bool {          // first: against o1, else against o2 (the offset is > 0 and <= t)
-    if (t < cb || t > cb + 4 || cbO1 != o1 || cbO2 != o2) {
+    if (t < cb || t > cb + 63 || cbO1 != o1 || cbO2 != o2) {
       cb = t; cbO1 = o1; cbO2 = o2;
-      cs = ld64(src + t);
-      c1 = (o1 > 0 && o1 <= t) ? ld64(src + t - o1) : 0ull;
-      c2 = (o2 > 0 && o2 <= t) ? ld64(src + t - o2) : 0ull;
+      const u32 q = t + (u32)lane;
+      const bool in = q + 4 <= be;
+      const u32 vs = in ? ld32(src + q) : 0u;
+      const bool a1 = in && o1 > 0 && o1 <= q, a2 = in && o2 > 0 && o2 <= q;
+      const u32 v1 = a1 ? ld32(src + q - o1) : 0u, v2 = a2 ? ld32(src + q - o2) : 0u;
+      m1 = __ballot(a1 && v1 == vs); m2r = __ballot(a2 && v2 == vs);
     }
-    const u32 sh = (t - cb) * 8;
-    return (u32)(cs >> sh) == (u32)((first ? c1 : c2) >> sh);
+    return (((first ? m1 : m2r) >> (t - cb)) & 1ull) != 0;
   };
   while (ip < ilimit) {
     u32 ml = 0, start = ip + 1, off = 0; bool stored = false;
