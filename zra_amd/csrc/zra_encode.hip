@@ -625,6 +625,11 @@ Status Engine::compress_persistent(const uint8_t* dIn, size_t inSize, uint8_t* d
       // ---- round 4's overlap, with this round's kernels: per sub-batch of 8192 frames, released by the match finder's own count of
       // finished frames, one entropy launch + scan + gather on stream B. The stage's workgroups come and go: they sit where a CU has
       // room beside the finder's waves, and nowhere when there is nothing to do.
+      // (round 6: the checksum kernel — 4 x n lanes, ~2 ms of the whole chip — only once every wave of the finder is resident. Queued at once it
+      //  could reach the CUs first, the dispatcher then placed the finder's waves unevenly (20 on most CUs, 12-18 on the ones the checksum
+      //  blocks were leaving), and a CU with 20 has no room for the entropy workgroup: one process of the round ended 31 ms behind that way,
+      //  profiles/r06_experiments.md §0)
+      HIPCHK(hipStreamWaitValue32(stream2_, a.mfStarted, mfGrid, hipStreamWaitValueGte, 0xFFFFFFFFu));
       if (checksum)
         hipLaunchKernelGGL(zra_content_ck_kernel, dim3((n * 4 + 255) / 256), dim3(256), 0, stream2_, dIn, (u64)inSize, frameSize, (u32)F0, n, a.contentCk);
       const uint32_t nSub1 = (n + SB - 1) / SB;
