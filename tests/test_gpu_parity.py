@@ -1101,3 +1101,34 @@ print("bad", bad)
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, ZRA_DEC_SMALL_MAX="0", ZRA_DEC_FMB_MIN="1"), capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, (r.stdout[-800:], r.stderr[-1500:])
     assert r.stdout.strip().endswith("bad 0"), r.stdout[-800:]
+
+
+def test_destroying_an_engine_returns_all_of_its_device_memory(zra):
+    """ZraHipDestroyEngine (include/zra_hip.h) frees every scratch reservation the engine made — the compressor's contexts, the four-kernel
+    decoder's buffers, the block-parallel pass's per-block records / tables / lists (round 6: they were missing from the destructor's
+    list), the batched random access's plans. Two identical engine lifetimes in a row: the first one also pays the runtime's own one-off
+    allocations (code objects, stream pools), the second must leave the device's free memory where the first left it."""
+    import torch
+    import bench
+    dev = torch.device("cuda", 0)
+    fs, N = 262144, 256 << 20                             # 1,024 frames of two blocks: the block-parallel pass takes them
+    d_in = torch.from_numpy(bench.synth_corpus(N, seed=5)).to(dev)
+    d_arc = torch.empty(zra.GetOutputBufferSize(N, fs) + 64, dtype=torch.uint8, device=dev)
+    d_out = torch.empty(N, dtype=torch.uint8, device=dev)
+    Q, qb = 4096, 4096
+    d_ra = torch.empty(Q * qb + 64, dtype=torch.uint8, device=dev)
+    offs = np.random.RandomState(1).randint(0, N - qb - 1, size=Q).astype(np.uint64)
+
+    def lifetime():
+        e = zra.Engine(0)
+        n = e.compress(d_in.data_ptr(), N, d_arc.data_ptr(), 3, fs, True)
+        e.decompress(d_arc.data_ptr(), n, d_out.data_ptr(), N)
+        assert torch.equal(d_out, d_in)
+        e.decompress_ra_batch(d_arc.data_ptr(), n, d_ra.data_ptr(), offs, np.full(Q, qb, dtype=np.uint64), np.arange(Q, dtype=np.uint64) * qb)
+        e.close()
+        torch.cuda.synchronize()
+        return torch.cuda.mem_get_info(0)[0]
+
+    free1 = lifetime()
+    free2 = lifetime()
+    assert free1 - free2 < (2 << 20), (free1, free2)

@@ -629,6 +629,8 @@ Status Engine::compress_persistent(const uint8_t* dIn, size_t inSize, uint8_t* d
       //  could reach the CUs first, the dispatcher then placed the finder's waves unevenly (20 on most CUs, 12-18 on the ones the checksum
       //  blocks were leaving), and a CU with 20 has no room for the entropy workgroup: one process of the round ended 31 ms behind that way,
       //  profiles/r06_experiments.md §0)
+      // (no wait of the finder depends on stream B inside a super-batch, so this cannot hang; with a bring-up ZRA_MF_WAVES beyond what a CU
+      //  holds — 21 by LDS — the last waves start when the first ones leave, and the stage then runs BEHIND the finder instead of beside it)
       HIPCHK(hipStreamWaitValue32(stream2_, a.mfStarted, mfGrid, hipStreamWaitValueGte, 0xFFFFFFFFu));
       if (checksum)
         hipLaunchKernelGGL(zra_content_ck_kernel, dim3((n * 4 + 255) / 256), dim3(256), 0, stream2_, dIn, (u64)inSize, frameSize, (u32)F0, n, a.contentCk);

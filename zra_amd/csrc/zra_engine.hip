@@ -296,7 +296,7 @@ Engine::~Engine() {
   (void)hipSetDevice(device_);
   if (stream_) (void)hipStreamSynchronize(stream_);
   for (DevBuf* b : {&raPlan_, &raLimit_, &raPieceBase_, &raPieces_, &decFrames_, &decTables_, &decLists_, &decCounters_, &decLits_, &decSeqs_, &roundN_, &status_, &produced_, &frameMeta_, &frameOff_, &outOff_, &expect_, &result_, &temp_, &qmeta_,
-                    &encScan_, &hostIn_, &hostOut_, &seqScratch_, &mfFlags_})
+                    &encScan_, &hostIn_, &hostOut_, &seqScratch_, &mfFlags_, &decBlkRecs_, &decBlkTables_, &decBlkLists_})
     b->release();
   for (auto& x : encCtx_) for (DevBuf* b : {&x.tables, &x.seqs, &x.lits, &x.work, &x.slots, &x.misc, &x.ck, &x.sizes, &x.rec}) b->release();
   for (auto ev : evPool_) (void)hipEventDestroy(ev);
