@@ -167,6 +167,30 @@ def mutated_archives(seed, cases, compress):
         yield case, a
 
 
+def ra_defined_prefix(a, off, size, decompress):
+    """How many leading bytes of DecompressRA(a, off, size)'s answer the reference's call DEFINES (zra.cpp:258-296), for an archive whose
+    header seek_table_consistent() accepts and whose touched frames all decode without an error: all `size` of them — unless a touched
+    frame regenerates another size than its slot (a damaged frame can regenerate fewer bytes and still end properly). Behind such a
+    frame's own bytes the answer holds whatever the reference's buffers held: the frame buffer of the first / last phase is reused from
+    one to the other (zra.cpp:280, :291), the middle phase packs its frames back to back (:288), and libzstd's copies overrun a
+    sequence's end by up to 32 bytes — two correct decoders behind the same container code already differ there (zl / zo on one host:
+    profiles/r06_soak_bisect3.txt). Everything IN FRONT of that point is full frames in their places and is compared byte for byte.
+    `decompress(frame_bytes, cap) -> (bytes or None, error)` = the dependency's one-shot call (tests/oracle_lib.py decompress)."""
+    U = int.from_bytes(a[18:26], "little"); ts = int.from_bytes(a[26:30], "little"); fs = int.from_bytes(a[30:34], "little")
+    ents = [int.from_bytes(a[38 + 5 * k:43 + 5 * k], "little") for k in range(ts)]
+    body = 38 + 5 * ts
+    f, pos, start = off // fs, 0, off % fs
+    while pos < size and f < ts - 1:
+        slot = min(fs, U - f * fs)
+        out, err = decompress(a[body + ents[f]: body + ents[f + 1]], fs)
+        r = len(out) if out is not None else 0
+        if r != slot:
+            return pos + max(0, min(r, slot) - start)
+        pos += slot - start
+        f += 1; start = 0
+    return size
+
+
 def random_lz_input_far(rng, n):
     """second seeded generator of the differential tests: far offsets (up to the 256 KiB window), periodic data, long zero runs (very
     long matches: zstd's "limited update after a very long match" at block starts), text-like alphabets"""

@@ -296,8 +296,8 @@ def test_inflated_frame_size_query_over_many_short_frames(zra):
 def test_randomised_random_access_on_damaged_frames(zra, seed):
     """DecompressRA on archives whose FRAMES are damaged (bit flips, overwrites, truncation; the header must still describe a table the
     reference can follow, tests/corpus.py seek_table_consistent): status of every query against libzstd behind the container code,
-    bytes wherever restatement and libzstd agree on them (a damaged frame may regenerate fewer bytes than frameSize without an error;
-    the reference then copies what its buffer held behind them, which is not specified)."""
+    bytes up to the first one the reference's call does not define (a damaged frame may regenerate fewer bytes than its slot without an
+    error; the reference then copies what its buffers held behind them: tests/corpus.py ra_defined_prefix)."""
     backend = "zl" if O.have_libzstd() else "zo"
     for case, a in C.mutated_archives(20000 + seed, 50, O.zra_compress):
         if not C.seek_table_consistent(a):
@@ -310,10 +310,14 @@ def test_randomised_random_access_on_damaged_frames(zra, seed):
             off = int(rng.randint(0, U))
             size = max(1, min(int(rng.choice([1, 100, fs, 2 * fs + 3, max(1, U - off - 1), max(1, U - off)])), 1 << 24))
             wq, qbytes = O.zra_ra(a, off, size, backend)
-            other = O.zra_ra(a, off, size, "zo")[1] if backend == "zl" else qbytes
             try:
                 g = zra.DecompressRA(a, off, size)
-                assert wq == (0, 0) and (g == qbytes or other != qbytes), (seed, case, (off, size), wq)
+                assert wq == (0, 0), (seed, case, (off, size), wq)
+                if g != qbytes:
+                    # (round 6: the bytes the reference's call defines are compared in every case — it used to be "all of them, or none
+                    #  when the two CPU restatements disagree", which depends on what the host's heap held)
+                    n = C.ra_defined_prefix(a, off, size, lambda fr, cap: O.decompress(fr, cap, backend))
+                    assert n < size and g[:n] == qbytes[:n], (seed, case, (off, size), wq, n)
             except zra.ZraError as e:
                 assert (e.zra, e.zstd) == wq, (seed, case, (off, size), wq, (e.zra, e.zstd))
 
