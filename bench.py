@@ -562,7 +562,10 @@ def main():
                 comm_side.gather_archive_begin(step.shard, 0, step.root.data_ptr() if rank == 0 else 0, step.root.numel() if rank == 0 else 0)
             else:
                 comm.gather_archive(step.shard, 0, step.root.data_ptr() if rank == 0 else 0, step.root.numel() if rank == 0 else 0)
-        torch.cuda.synchronize()
+        if comm_side is None:
+            torch.cuda.synchronize()
+        # (with the gather on its own stream a DEVICE-wide wait here would wait for it too and put it back in front of the serving; the
+        #  compress call has returned, so its outputs are complete (include/zra_hip.h) — t1 only splits the step for the two reported legs)
         t1 = time.perf_counter()
         # RA over this rank's own shard (the archive stays sharded for serving; queries are routed to the owner)
         if world == 1:
